@@ -1,0 +1,59 @@
+"""ctypes binding of libadaptpoint_amd.so (the C ABI in include/adaptpoint_amd.h).
+
+The library is the product: if it is missing or fails to load this module
+raises -- there is no CPU or PyTorch fallback behind it.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadaptpoint_amd.so")
+
+_c_int, _c_float, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes, exactly the prototypes of include/adaptpoint_amd.h
+SIGNATURES = {
+    "apn_version": [],
+    "apn_furthest_point_sampling": [_c_int] * 3 + [_c_void_p] * 4,
+    "apn_ball_query": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 4,
+    "apn_group_points": [_c_int] * 5 + [_c_void_p] * 4,
+    "apn_group_points_grad": [_c_int] * 5 + [_c_void_p] * 4,
+    "apn_gather_points": [_c_int] * 4 + [_c_void_p] * 4,
+    "apn_gather_points_grad": [_c_int] * 4 + [_c_void_p] * 4,
+    "apn_three_nn": [_c_int] * 3 + [_c_void_p] * 5,
+    "apn_three_interpolate": [_c_int] * 4 + [_c_void_p] * 5,
+    "apn_three_interpolate_grad": [_c_int] * 4 + [_c_void_p] * 5,
+    "apn_fps_set_waves": [_c_int],
+}
+
+_lib = None
+
+
+class ExtensionMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExtensionMissing(
+            f"{LIB_PATH} not found: build it with `python -m adaptpoint_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _c_int
+    lib.apn_error_string.argtypes = [_c_int]
+    lib.apn_error_string.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().apn_error_string(code).decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")

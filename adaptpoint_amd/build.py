@@ -1,0 +1,76 @@
+"""Build recipe for libadaptpoint_amd.so (hipcc, gfx950 only, in-tree).
+
+    python -m adaptpoint_amd.build [--force] [--asm]
+
+Every translation unit is compiled with -ffp-contract=off: the kernels pin
+their float rounding with explicit fma builtins (csrc/apn_common.h).
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "build")
+LIB = os.path.join(HERE, "libadaptpoint_amd.so")
+ARCH = "gfx950"
+SOURCES = ["capi.hip", "fps.hip", "ball_query.hip", "group_points.hip", "interpolate.hip"]
+HEADERS = ["apn_common.h", os.path.join("..", "..", "include", "adaptpoint_amd.h")]
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+            "-fvisibility=hidden", "-Wall", "-Wno-unused-command-line-argument"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; libadaptpoint_amd.so cannot be built")
+    return exe
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, asm=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    procs = []
+    for src in srcs:
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if not force and _newer(obj, [src] + hdrs + [os.path.abspath(__file__)]):
+            continue
+        cmd = [hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd)))
+        if asm:
+            s_out = os.path.join(OBJ, os.path.basename(src)[:-4] + ".s")
+            subprocess.run([hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, "--cuda-device-only",
+                            "-S", src, "-o", s_out], check=True)
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    if force or procs or not _newer(LIB, objs):
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--asm", action="store_true", help="also emit device assembly next to the objects")
+    ap.add_argument("-v", "--verbose", action="store_true")
+    a = ap.parse_args()
+    print(build(a.force, a.asm, a.verbose))
+    sys.exit(0)

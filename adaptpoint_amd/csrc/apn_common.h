@@ -1,0 +1,71 @@
+// apn_common.h -- shared device helpers for the gfx950 kernels.
+//
+// Build contract: every translation unit is compiled with -ffp-contract=off, so
+// the only fused multiply-adds in the numerics are the explicit __builtin_fmaf
+// calls below.  That pins the squared-distance rounding to ONE documented form
+// (the reference leaves it to nvcc's contraction: sampling_gpu.cu:140,
+// ball_query_gpu.cu:39, interpolate_gpu.cu:42):
+//
+//      d2 = fma(dz, dz, fma(dx, dx, dy * dy))
+//
+// which is what LLVM's fadd-of-fmul contraction produces for
+// (dx*dx + dy*dy) + dz*dz (oracle variant APO_DIST_FMA_XY).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/adaptpoint_amd.h"
+
+#define APN_WAVE 64
+
+namespace apn {
+
+__device__ __forceinline__ float dist2(float dx, float dy, float dz) {
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+}
+
+// DPP controls (gfx9 encoding).
+enum : int {
+    DPP_QUAD_XOR1 = 0xB1,        // quad_perm:[1,0,3,2]
+    DPP_QUAD_XOR2 = 0x4E,        // quad_perm:[2,3,0,1]
+    DPP_ROW_HALF_MIRROR = 0x141,
+    DPP_ROW_MIRROR = 0x140,
+    DPP_ROW_BCAST15 = 0x142,
+    DPP_ROW_BCAST31 = 0x143,
+};
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+    // old = 0 is the identity of umax: lanes that receive no data (masked rows)
+    // keep their own value, and the DPP combiner can fold this into v_max_u32_dpp.
+    unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+    return o > v ? o : v;
+}
+
+// Max over the 64 lanes of a wave; the result is valid in lane 63 and is
+// returned wave-uniform.  Order-free (integer max), so no tie rule lives here.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = dpp_max_u32<DPP_QUAD_XOR1>(v);
+    v = dpp_max_u32<DPP_QUAD_XOR2>(v);
+    v = dpp_max_u32<DPP_ROW_HALF_MIRROR>(v);
+    v = dpp_max_u32<DPP_ROW_MIRROR>(v);
+    v = dpp_max_u32<DPP_ROW_BCAST15, 0xA>(v);
+    v = dpp_max_u32<DPP_ROW_BCAST31, 0xC>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ int lane_id() {
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+}  // namespace apn
+
+#define APN_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return (int)e__;              \
+    } while (0)

@@ -1,0 +1,319 @@
+// fps.hip -- furthest point sampling for gfx950 (one workgroup per cloud).
+//
+// Replaces furthest_point_sampling_kernel<block_size> and its launcher
+// (openpoints/cpp/pointnet2_batch/src/sampling_gpu.cu:101-260).
+//
+// FPS is a serial chain: M-1 dependent steps, each "update N running minimum
+// distances, then arg-max".  Only B workgroups exist, so neither HBM nor MFMA
+// bounds it -- the latency of ONE step does.  The design removes everything a
+// step can do without:
+//   * the cloud (x, y, z), the running min-distances and the point ids live in
+//     VGPRs for the whole kernel (S "slots" per lane); global memory is touched
+//     once on entry and once on exit;
+//   * the arg-max is an order-free integer max over the float bit patterns
+//     (min-distances are >= 0, so uint order == float order): six DPP steps per
+//     wave, no LDS;
+//   * waves meet through ONE raw s_barrier per step and a double-buffered
+//     16-byte LDS record per wave {max, x, y, z} -- the winner's coordinates
+//     travel with its distance, so the next step needs no dependent lookup;
+//     they are then held in SGPRs (v_readlane) and feed the VALU as scalar
+//     operands.
+//
+// Tie rule.  The reference resolves equal maxima through its block tree
+// (sampling_gpu.cu:93-98,146-210): among equal values the winner is the thread
+// with the smallest bit-reversed id, then the lowest k inside that thread
+// (strict > at :143-144).  Here points are laid out by that priority: position
+// q = tid*S + slot holds the point of priority rank q, so "lowest position
+// wins" -- which ballot + find-first-set gives for free at every level --
+// reproduces the reference order exactly, with no key compares in the loop.
+#include "apn_common.h"
+
+#include <cmath>
+
+namespace apn {
+
+// Geometry of the reference launch for n points: block size bs = 2^L
+// (cuda_utils.h:10-14), every reference thread t owns points t, t+bs, ...:
+// `full` of them, plus one more when t < rem.
+struct FpsOrder {
+    int n, bs, L, full, rem;
+};
+
+// Number of points owned by reference threads whose L-bit reversed id is < R.
+__device__ __forceinline__ int fps_rank_start(const FpsOrder &o, int R) {
+    int g = 0;
+    if (o.rem > 0) {
+        // R' < R first differs from R at a set bit i of R; its i low bits are
+        // free and land, reversed, in the top i bits of bitrev(R').
+        for (int i = o.L - 1; i >= 0; --i) {
+            if ((R >> i) & 1) {
+                const int hi = R >> (i + 1);
+                const int hb = o.L - 1 - i;
+                const int c = hb > 0 ? (int)(__brev((unsigned)hi) >> (32 - hb)) : 0;
+                if (o.rem > c) {
+                    int cnt = (o.rem - c + (1 << (o.L - i)) - 1) >> (o.L - i);
+                    const int cap = 1 << i;
+                    g += cnt < cap ? cnt : cap;
+                }
+            }
+        }
+    }
+    return R * o.full + g;
+}
+
+// Point id that has priority rank q (0 <= q < n).
+__device__ __forceinline__ int fps_rank_to_point(const FpsOrder &o, int q) {
+    int R, k;
+    if (o.rem == 0) {
+        R = q / o.full;
+        k = q - R * o.full;
+    } else {
+        int lo = 0, hi = o.bs - 1;  // largest R with start(R) <= q
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (fps_rank_start(o, mid) <= q) lo = mid; else hi = mid - 1;
+        }
+        R = lo;
+        k = q - fps_rank_start(o, R);
+    }
+    const int t = o.L > 0 ? (int)(__brev((unsigned)R) >> (32 - o.L)) : 0;
+    return t + k * o.bs;
+}
+
+template <int W>
+__device__ __forceinline__ unsigned group_max_u32(unsigned v) {
+    // max over aligned groups of W lanes (W <= 16), valid in every lane.
+    if (W >= 2) v = dpp_max_u32<DPP_QUAD_XOR1>(v);
+    if (W >= 4) v = dpp_max_u32<DPP_QUAD_XOR2>(v);
+    if (W >= 8) v = dpp_max_u32<DPP_ROW_HALF_MIRROR>(v);
+    if (W >= 16) v = dpp_max_u32<DPP_ROW_MIRROR>(v);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// W waves per workgroup, S point slots per lane; requires n <= 64*W*S.
+template <int W, int S>
+__global__ __launch_bounds__(W * 64) void fps_reg_kernel(FpsOrder o, int m,
+                                                         const float *__restrict__ xyz,
+                                                         float *__restrict__ temp,
+                                                         int *__restrict__ idxs) {
+    const int n = o.n;
+    const int cloud = blockIdx.x;
+    xyz += (size_t)cloud * n * 3;
+    temp += (size_t)cloud * n;
+    idxs += (size_t)cloud * m;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    float px[S], py[S], pz[S];
+    unsigned dmin[S];
+    int pid[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int q = tid * S + s;
+        if (q < n) {
+            const int p = fps_rank_to_point(o, q);
+            pid[s] = p;
+            px[s] = xyz[p * 3 + 0];
+            py[s] = xyz[p * 3 + 1];
+            pz[s] = xyz[p * 3 + 2];
+            dmin[s] = __float_as_uint(temp[p]);
+        } else {
+            // Padding: min-distance stays +0.0 and sits at the highest
+            // positions, so it can only tie, and a tie goes to a real point.
+            pid[s] = 0;
+            px[s] = py[s] = pz[s] = 0.0f;
+            dmin[s] = 0u;
+        }
+    }
+
+    __shared__ float4 rec[2][W];
+    __shared__ int rec_pid[2][W];
+
+    float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];  // old = 0 (sampling_gpu.cu:118-122)
+    if (tid == 0) idxs[0] = 0;
+
+    for (int j = 1; j < m; ++j) {
+        unsigned best;
+        float bx, by, bz;
+        int bp;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float d = dist2(px[s] - x1, py[s] - y1, pz[s] - z1);
+            // min on the bit patterns: both operands are >= +0 (or a NaN, whose
+            // pattern is above every finite one), so this equals fminf(d, dmin)
+            // and needs no canonicalising v_max in front of a v_min_f32.
+            const unsigned du = __float_as_uint(d);
+            dmin[s] = du < dmin[s] ? du : dmin[s];
+            if (s == 0) {
+                best = dmin[0]; bx = px[0]; by = py[0]; bz = pz[0]; bp = pid[0];
+            } else {
+                const bool g = dmin[s] > best;  // strict: the lower slot keeps a tie
+                best = g ? dmin[s] : best;
+                bx = g ? px[s] : bx;
+                by = g ? py[s] : by;
+                bz = g ? pz[s] : bz;
+                bp = g ? pid[s] : bp;
+            }
+        }
+        const unsigned wmax = wave_max_u32(best);
+        const unsigned long long cand = __ballot(best == wmax);
+        const int wl = (int)__builtin_ctzll(cand);  // lowest lane = highest priority
+        int old;
+        if (W == 1) {
+            x1 = readlane_f(bx, wl);
+            y1 = readlane_f(by, wl);
+            z1 = readlane_f(bz, wl);
+            old = __builtin_amdgcn_readlane(bp, wl);
+        } else {
+            const int buf = j & 1;
+            if (lane == wl) {
+                rec[buf][wave] = make_float4(__uint_as_float(wmax), bx, by, bz);
+                rec_pid[buf][wave] = bp;
+            }
+            // One rendezvous per step.  A raw barrier: __syncthreads() would
+            // also drain the idxs store below (vmcnt) on every step.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const float4 e = rec[buf][lane & (W - 1)];
+            const int ep = rec_pid[buf][lane & (W - 1)];
+            const unsigned ev = __float_as_uint(e.x);
+            const unsigned gmax = group_max_u32<W>(ev);
+            const unsigned long long cw = __ballot(ev == gmax);
+            const int ws = (int)__builtin_ctzll(cw);  // lowest wave = highest priority
+            x1 = readlane_f(e.y, ws);
+            y1 = readlane_f(e.z, ws);
+            z1 = readlane_f(e.w, ws);
+            old = __builtin_amdgcn_readlane(ep, ws);
+        }
+        if (tid == 0) idxs[j] = old;
+    }
+
+    // The reference leaves the final min-distances in temp (sampling_gpu.cu:141-142).
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int q = tid * S + s;
+        if (q < n) temp[pid[s]] = __uint_as_float(dmin[s]);
+    }
+}
+
+// Any-n fallback (n > 16384): the reference's thread structure with the
+// distances kept in `temp` (global / L2) and a halving tree in LDS whose merge
+// keeps the left slot on ties, exactly the reference's __update order.
+__global__ __launch_bounds__(1024) void fps_stream_kernel(FpsOrder o, int m,
+                                                          const float *__restrict__ xyz,
+                                                          float *__restrict__ temp,
+                                                          int *__restrict__ idxs) {
+    const int n = o.n, bs = o.bs;
+    const int cloud = blockIdx.x;
+    xyz += (size_t)cloud * n * 3;
+    temp += (size_t)cloud * n;
+    idxs += (size_t)cloud * m;
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    const int tid = threadIdx.x;
+    int old = 0;
+    if (tid == 0) idxs[0] = 0;
+    for (int j = 1; j < m; ++j) {
+        const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
+        float best = -1.0f;
+        int besti = 0;
+        for (int k = tid; k < n; k += bs) {
+            const float d = dist2(xyz[k * 3 + 0] - x1, xyz[k * 3 + 1] - y1, xyz[k * 3 + 2] - z1);
+            const float d2 = __builtin_fminf(d, temp[k]);
+            temp[k] = d2;
+            if (d2 > best) { best = d2; besti = k; }
+        }
+        sv[tid] = best;
+        si[tid] = besti;
+        __syncthreads();
+        for (int half = bs >> 1; half >= 1; half >>= 1) {
+            if (tid < half) {
+                const float a = sv[tid], c = sv[tid + half];
+                if (c > a) { sv[tid] = c; si[tid] = si[tid + half]; }
+            }
+            __syncthreads();
+        }
+        old = si[0];
+        __syncthreads();  // everyone has read si[0] before the next step rewrites it
+        if (tid == 0) idxs[j] = old;
+    }
+}
+
+template <int W, int S>
+static int launch_reg(const FpsOrder &o, int b, int m, const float *xyz, float *temp, int *idxs,
+                      hipStream_t st) {
+    hipLaunchKernelGGL((fps_reg_kernel<W, S>), dim3(b), dim3(W * 64), 0, st, o, m, xyz, temp, idxs);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+template <int W>
+static int dispatch_slots(const FpsOrder &o, int b, int m, const float *xyz, float *temp,
+                          int *idxs, hipStream_t st) {
+    const int need = (o.n + W * 64 - 1) / (W * 64);
+#define APN_FPS_CASE(SS) \
+    if (need <= SS) return launch_reg<W, SS>(o, b, m, xyz, temp, idxs, st);
+    APN_FPS_CASE(1)
+    APN_FPS_CASE(2)
+    APN_FPS_CASE(3)
+    APN_FPS_CASE(4)
+    APN_FPS_CASE(6)
+    APN_FPS_CASE(8)
+    APN_FPS_CASE(12)
+    APN_FPS_CASE(16)
+#undef APN_FPS_CASE
+    return APN_EINVAL;
+}
+
+static int g_fps_waves_override = 0;  // tuning hook, see apn_fps_set_waves
+
+}  // namespace apn
+
+extern "C" int apn_fps_set_waves(int waves) {
+    // Tuning/diagnostic hook (not part of the reference boundary): force the
+    // number of waves per cloud (1, 4, 8, 16); 0 restores the heuristic.
+    if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16)
+        return APN_EINVAL;
+    apn::g_fps_waves_override = waves;
+    return APN_OK;
+}
+
+extern "C" int apn_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
+                                           int *idxs, void *stream) {
+    using namespace apn;
+    if (b < 0) return APN_EINVAL;
+    if (b == 0 || m <= 0) return APN_OK;  // sampling_gpu.cu:110
+    if (n <= 0 || !xyz || !temp || !idxs) return APN_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+
+    FpsOrder o;
+    o.n = n;
+    {   // cuda_utils.h:10-14, same double arithmetic
+        const int pow_2 = (int)(std::log((double)n) / std::log(2.0));
+        int v = 1 << pow_2;
+        if (v > 1024) v = 1024;
+        if (v < 1) v = 1;
+        o.bs = v;
+    }
+    o.L = 0;
+    while ((1 << o.L) < o.bs) ++o.L;
+    o.full = n / o.bs;
+    o.rem = n % o.bs;
+
+    if (n > 16384) {
+        hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(o.bs), 0, st, o, m, xyz, temp, idxs);
+        APN_LAUNCH_CHECK();
+        return APN_OK;
+    }
+    int w = g_fps_waves_override;
+    if (w == 0) w = n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 4 : n <= 4096 ? 8 : 16;
+    while (w < 16 && (n + w * 64 - 1) / (w * 64) > 16) w *= 2;
+    switch (w) {
+    case 1: return dispatch_slots<1>(o, b, m, xyz, temp, idxs, st);
+    case 2: return dispatch_slots<2>(o, b, m, xyz, temp, idxs, st);
+    case 4: return dispatch_slots<4>(o, b, m, xyz, temp, idxs, st);
+    case 8: return dispatch_slots<8>(o, b, m, xyz, temp, idxs, st);
+    default: return dispatch_slots<16>(o, b, m, xyz, temp, idxs, st);
+    }
+}

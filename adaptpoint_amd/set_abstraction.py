@@ -1,0 +1,123 @@
+"""PointNeXt set-abstraction block over the gfx950 operators.
+
+Host-side mirror of `SetAbstraction` in the reference
+(openpoints/models/backbone/pointnext.py:82-170) restricted to what the configs
+in scope instantiate (cfgs/scanobjectnn/pointnext-s.yaml:5-36): conv-norm-act
+order, BatchNorm, ReLU, FPS sampler, ball-query or group-all grouping, max
+pooling, optional residual.  Sub-module names and nesting match the reference
+(`convs.<i>.0` conv, `convs.<i>.1` norm, `skipconv.0`), so a reference
+state_dict loads unchanged.
+"""
+import torch
+import torch.nn as nn
+
+from .layers import (CHANNEL_MAP, create_grouper, furthest_point_sample,
+                     get_aggregation_feautres)
+
+
+def _norm(norm_args, channels, dim):
+    if norm_args is None:
+        return None
+    name = norm_args.get('norm', None)
+    if name is None:
+        return None
+    if name in ('bn', 'bn2d', 'bn1d'):
+        # create_norm (layers/norm.py): 'bn' resolves by the block's dimension
+        return nn.BatchNorm2d(channels) if dim == 2 else nn.BatchNorm1d(channels)
+    raise NotImplementedError(f"norm '{name}' is outside the hot-path build")
+
+
+def _act(act_args):
+    if act_args is None:
+        return None
+    name = act_args.get('act', 'relu')
+    if name == 'relu':
+        return nn.ReLU(inplace=act_args.get('inplace', True))
+    raise NotImplementedError(f"activation '{name}' is outside the hot-path build")
+
+
+def convblock(cin, cout, dim, norm_args=None, act_args=None, order='conv-norm-act', bias=True):
+    """create_convblock1d/2d (layers/conv.py:24-104) for the conv-norm-act order:
+    1x1 conv (bias dropped when a norm follows), norm, activation."""
+    if order != 'conv-norm-act':
+        raise NotImplementedError(f"conv order '{order}' is outside the hot-path build")
+    norm = _norm(norm_args, cout, dim)
+    conv_cls = nn.Conv2d if dim == 2 else nn.Conv1d
+    layers = [conv_cls(cin, cout, 1, bias=bias and norm is None)]
+    if norm is not None:
+        layers.append(norm)
+    act = _act(act_args)
+    if act is not None:
+        layers.append(act)
+    return nn.Sequential(*layers)
+
+
+class SetAbstraction(nn.Module):
+    """pointnext.py:82-170."""
+
+    def __init__(self, in_channels, out_channels, layers=1, stride=1,
+                 group_args=None, norm_args=None, act_args=None, conv_args=None,
+                 sampler='fps', feature_type='dp_fj', use_res=False, is_head=False, **kwargs):
+        super().__init__()
+        group_args = dict(group_args or {'NAME': 'ballquery', 'radius': 0.1, 'nsample': 16})
+        norm_args = {'norm': 'bn1d'} if norm_args is None else norm_args
+        act_args = {'act': 'relu'} if act_args is None else act_args
+        conv_args = dict(conv_args or {})
+        self.stride = stride
+        self.is_head = is_head
+        self.all_aggr = not is_head and stride == 1
+        self.use_res = use_res and not self.all_aggr and not self.is_head
+        self.feature_type = feature_type
+
+        mid_channel = out_channels // 2 if stride > 1 else out_channels
+        channels = [in_channels] + [mid_channel] * (layers - 1) + [out_channels]
+        channels[0] = in_channels if is_head else CHANNEL_MAP[feature_type](channels[0])
+
+        if self.use_res:
+            self.skipconv = (convblock(in_channels, channels[-1], 1)
+                             if in_channels != channels[-1] else nn.Identity())
+            self.act = _act(act_args)
+
+        dim = 1 if is_head else 2
+        convs = []
+        for i in range(len(channels) - 1):
+            last = i == len(channels) - 2
+            convs.append(convblock(channels[i], channels[i + 1], dim,
+                                   norm_args=norm_args if not is_head else None,
+                                   act_args=None if last and (self.use_res or is_head) else act_args,
+                                   **conv_args))
+        self.convs = nn.Sequential(*convs)
+        if not is_head:
+            if self.all_aggr:
+                group_args['nsample'] = None
+                group_args['radius'] = None
+            self.grouper = create_grouper(group_args)
+            if sampler.lower() != 'fps':
+                raise NotImplementedError("only the FPS sampler is on the hot path")
+            self.sample_fn = furthest_point_sample
+
+    @staticmethod
+    def pool(x):
+        return torch.max(x, dim=-1, keepdim=False)[0]
+
+    def forward(self, pf):
+        p, f = pf
+        if self.is_head:
+            return p, self.convs(f)
+        if not self.all_aggr:
+            idx = self.sample_fn(p, p.shape[1] // self.stride).long()
+            new_p = torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+        else:
+            new_p = p
+        if self.use_res or 'df' in self.feature_type:
+            fi = torch.gather(f, -1, idx.unsqueeze(1).expand(-1, f.shape[1], -1))
+            if self.use_res:
+                identity = self.skipconv(fi)
+        else:
+            fi = None
+        dp, fj = self.grouper(new_p, p, f)
+        fj = get_aggregation_feautres(new_p, dp, fi, fj, feature_type=self.feature_type)
+        f = self.pool(self.convs(fj))
+        if self.use_res:
+            f = self.act(f + identity)
+        return new_p, f

@@ -1,0 +1,117 @@
+/*
+ * adaptpoint_amd.h -- C ABI of libadaptpoint_amd.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the set-abstraction hot path of AdaptPoint /
+ * OpenPoints.  Each entry point replaces one function that the reference binds
+ * with pybind11 in openpoints/cpp/pointnet2_batch/src/pointnet2_api.cpp:10-24
+ * (module `pointnet2_batch_cuda`), and takes what that function's C++ wrapper
+ * hands to its kernel launcher: plain device pointers and sizes, plus the HIP
+ * stream to launch on.  No torch types, no allocation, no global state.
+ *
+ * Contract shared by every entry point (reference: SURVEY.md section 8b):
+ *   - all pointers are DEVICE pointers on the current HIP device, float32 /
+ *     int32, dense row-major ("contiguous") in the layout given below;
+ *   - outputs and scratch are allocated, and where stated pre-initialised, by
+ *     the caller; kernels never allocate or free;
+ *   - `stream` is a hipStream_t (NULL = the default stream); the call only
+ *     enqueues work, it never synchronises the device;
+ *   - return value: 0 on success; a positive value is the hipError_t of the
+ *     failed launch; APN_EINVAL for an argument the kernels cannot handle.
+ *     Nothing ever calls exit() (the reference launchers do, e.g.
+ *     sampling_gpu.cu:46-50).
+ *   - sizes of zero are no-ops that return 0.
+ */
+#ifndef ADAPTPOINT_AMD_H
+#define ADAPTPOINT_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APN_OK 0
+#define APN_EINVAL (-1)
+
+#if defined(__GNUC__)
+#define APN_API __attribute__((visibility("default")))
+#else
+#define APN_API
+#endif
+
+/* Library / ABI version: major*10000 + minor*100 + patch. */
+APN_API int apn_version(void);
+
+/* Text for a return code of any function below (static storage). */
+APN_API const char *apn_error_string(int code);
+
+/* Replaces furthest_point_sampling_wrapper (pointnet2_api.cpp:18,
+ * sampling.cpp:39-48 -> sampling_gpu.cu:101-260).
+ *   xyz  (B,N,3) in; temp (B,N) in/out, pre-filled by the caller (1e10,
+ *   subsample.py:94), holds the final min squared distances on return;
+ *   idxs (B,M) out.  idxs[:,0] = 0; ties follow the reference's block-tree
+ *   order (smallest bit-reversed thread id, then lowest index). */
+APN_API int apn_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
+                                int *idxs, void *stream);
+
+/* Replaces ball_query_wrapper (pointnet2_api.cpp:11, ball_query.cpp:29-39 ->
+ * ball_query_gpu.cu:15-73).
+ *   new_xyz (B,M,3) queries; xyz (B,N,3) support; idx (B,M,nsample) out,
+ *   pre-zeroed by the caller (group.py:194): rows of empty balls are not
+ *   written.  Strict d2 < radius*radius in float32. */
+APN_API int apn_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                   const float *xyz, int *idx, void *stream);
+
+/* Replaces group_points_wrapper (pointnet2_api.cpp:12, group_points.cpp:25-35 ->
+ * group_points_gpu.cu:53-92).  points (B,C,N), idx (B,npoints,nsample) ->
+ * out (B,C,npoints,nsample). */
+APN_API int apn_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                     const int *idx, float *out, void *stream);
+
+/* Replaces group_points_grad_wrapper (pointnet2_api.cpp:13, group_points.cpp:13-23
+ * -> group_points_gpu.cu:14-50).  grad_out (B,C,npoints,nsample), idx ->
+ * grad_points (B,C,N) += scatter; the caller zeroes grad_points (group.py:111). */
+APN_API int apn_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                          const float *grad_out, const int *idx, float *grad_points,
+                          void *stream);
+
+/* Replaces gather_points_wrapper (pointnet2_api.cpp:15, sampling.cpp:16-24 ->
+ * sampling_gpu.cu:15-51).  points (B,C,N), idx (B,npoints) -> out (B,C,npoints). */
+APN_API int apn_gather_points(int b, int c, int n, int npoints, const float *points,
+                      const int *idx, float *out, void *stream);
+
+/* Replaces gather_points_grad_wrapper (pointnet2_api.cpp:16, sampling.cpp:27-36 ->
+ * sampling_gpu.cu:53-90).  grad_points (B,C,N) += scatter of grad_out (B,C,npoints);
+ * caller-zeroed (subsample.py:136). */
+APN_API int apn_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                           const int *idx, float *grad_points, void *stream);
+
+/* Replaces three_nn_wrapper (pointnet2_api.cpp:20, interpolate.cpp:20-28 ->
+ * interpolate_gpu.cu:16-81).  unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3)
+ * SQUARED distances ascending, idx (B,n,3).  m < 3 leaves +inf / index 0 in
+ * the unused slots, as the reference does. */
+APN_API int apn_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                 float *dist2, int *idx, void *stream);
+
+/* Replaces three_interpolate_wrapper (pointnet2_api.cpp:21, interpolate.cpp:31-43 ->
+ * interpolate_gpu.cu:84-124).  points (B,C,M), idx/weight (B,N,3) -> out (B,C,N).
+ * NOTE the reference's argument order: (b, c, m, n). */
+APN_API int apn_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                          const float *weight, float *out, void *stream);
+
+/* Replaces three_interpolate_grad_wrapper (pointnet2_api.cpp:22,
+ * interpolate.cpp:45-57 -> interpolate_gpu.cu:127-168).  grad_out (B,C,N) ->
+ * grad_points (B,C,M) += scatter; caller-zeroed (upsampling.py:82).
+ * NOTE the reference's argument order: (b, c, n, m). */
+APN_API int apn_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                               const int *idx, const float *weight, float *grad_points,
+                               void *stream);
+
+/* Tuning / diagnostic hook, NOT part of the reference boundary: force the number
+ * of wavefronts that cooperate on one cloud in apn_furthest_point_sampling
+ * (1, 2, 4, 8 or 16; 0 restores the built-in heuristic).  Results do not depend
+ * on it.  Process-wide; not thread-safe against concurrent FPS launches. */
+APN_API int apn_fps_set_waves(int waves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAPTPOINT_AMD_H */

@@ -1,0 +1,171 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+numpy front-end of `libpointnet2_oracle.so` (built from pointnet2_oracle.c by
+oracle/Makefile).  Signatures mirror the Python-visible wrappers of the
+reference extension (openpoints/cpp/pointnet2_batch/src/pointnet2_api.cpp:11-23)
+but allocate and return numpy arrays.  Parity pinning: see the header of
+pointnet2_oracle.c.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpointnet2_oracle.so")
+
+DIST_PLAIN, DIST_FMA_YX, DIST_FMA_XY, DIST_HIPCC = 0, 1, 2, 3
+DIST_PINNED = DIST_FMA_XY
+ALL_DIST_VARIANTS = (DIST_PLAIN, DIST_FMA_YX, DIST_FMA_XY, DIST_HIPCC)
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "pointnet2_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+        return _LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-B", "libpointnet2_oracle.so"], check=True,
+                   stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.apo_opt_n_threads.restype = ctypes.c_int
+        _lib.apo_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def set_threads(t):
+    lib().apo_set_threads(ctypes.c_int(int(t)))
+
+
+def max_threads():
+    return int(lib().apo_max_threads())
+
+
+def opt_n_threads(n):
+    return int(lib().apo_opt_n_threads(ctypes.c_int(int(n))))
+
+
+def furthest_point_sampling(xyz, m, variant=DIST_PINNED, return_temp=False):
+    """xyz (B,N,3) f32 -> idx (B,m) i32 [, temp (B,N) f32]  (sampling_gpu.cu:101-215)."""
+    xyz, pxyz = _f(xyz)
+    b, n, _ = xyz.shape
+    temp = np.full((b, n), 1e10, dtype=np.float32)      # subsample.py:94
+    idx = np.zeros((b, max(m, 0)), dtype=np.int32)
+    lib().apo_furthest_point_sampling(b, n, int(m), pxyz, temp.ctypes.data_as(ctypes.c_void_p),
+                                      idx.ctypes.data_as(ctypes.c_void_p), int(variant))
+    return (idx, temp) if return_temp else idx
+
+
+def ball_query(radius, nsample, xyz, new_xyz, variant=DIST_PINNED):
+    """xyz (B,N,3), new_xyz (B,M,3) -> idx (B,M,nsample) i32  (ball_query_gpu.cu:15-51).
+    `radius` is narrowed to float32 as at the pybind boundary (ball_query.cpp:29)."""
+    xyz, pxyz = _f(xyz)
+    new_xyz, pq = _f(new_xyz)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = np.zeros((b, m, nsample), dtype=np.int32)      # group.py:194
+    lib().apo_ball_query(b, n, m, ctypes.c_float(float(np.float32(radius))), int(nsample),
+                         pq, pxyz, idx.ctypes.data_as(ctypes.c_void_p), int(variant))
+    return idx
+
+
+def group_points(points, idx):
+    """points (B,C,N), idx (B,M,K) -> (B,C,M,K)  (group_points_gpu.cu:53-72)."""
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    b, c, n = points.shape
+    _, m, k = idx.shape
+    out = np.empty((b, c, m, k), dtype=np.float32)
+    lib().apo_group_points(b, c, n, m, k, pp, pi, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """grad_out (B,C,M,K), idx (B,M,K) -> grad_points (B,C,n)  (group_points_gpu.cu:14-31)."""
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    b, c, m, k = grad_out.shape
+    gp = np.zeros((b, c, n), dtype=np.float32)           # group.py:111
+    lib().apo_group_points_grad(b, c, int(n), m, k, pg, pi, gp.ctypes.data_as(ctypes.c_void_p))
+    return gp
+
+
+def gather_points(points, idx):
+    """points (B,C,N), idx (B,M) -> (B,C,M)  (sampling_gpu.cu:15-31)."""
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = np.empty((b, c, m), dtype=np.float32)
+    lib().apo_gather_points(b, c, n, m, pp, pi, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """grad_out (B,C,M), idx (B,M) -> grad_points (B,C,n)  (sampling_gpu.cu:53-70)."""
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    b, c, m = grad_out.shape
+    gp = np.zeros((b, c, n), dtype=np.float32)           # subsample.py:136
+    lib().apo_gather_points_grad(b, c, int(n), m, pg, pi, gp.ctypes.data_as(ctypes.c_void_p))
+    return gp
+
+
+def three_nn(unknown, known, variant=DIST_PINNED):
+    """unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) f32, idx (B,n,3) i32
+    (interpolate_gpu.cu:16-59; the Python caller takes sqrt, upsampling.py:33)."""
+    unknown, pu = _f(unknown)
+    known, pk = _f(known)
+    b, n, _ = unknown.shape
+    m = known.shape[1]
+    dist2 = np.empty((b, n, 3), dtype=np.float32)
+    idx = np.empty((b, n, 3), dtype=np.int32)
+    lib().apo_three_nn(b, n, m, pu, pk, dist2.ctypes.data_as(ctypes.c_void_p),
+                       idx.ctypes.data_as(ctypes.c_void_p), int(variant))
+    return dist2, idx
+
+
+def three_interpolate(points, idx, weight, fused=True):
+    """points (B,C,M), idx/weight (B,n,3) -> (B,C,n)  (interpolate_gpu.cu:84-104)."""
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    weight, pw = _f(weight)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = np.empty((b, c, n), dtype=np.float32)
+    lib().apo_three_interpolate(b, c, m, n, pp, pi, pw, out.ctypes.data_as(ctypes.c_void_p),
+                                int(bool(fused)))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """grad_out (B,C,n), idx/weight (B,n,3) -> grad_points (B,C,m)  (interpolate_gpu.cu:127-149)."""
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    weight, pw = _f(weight)
+    b, c, n = grad_out.shape
+    gp = np.zeros((b, c, int(m)), dtype=np.float32)      # upsampling.py:82
+    lib().apo_three_interpolate_grad(b, c, n, int(m), pg, pi, pw,
+                                     gp.ctypes.data_as(ctypes.c_void_p))
+    return gp

@@ -1,0 +1,319 @@
+"""GPU parity: every operator, called through the drop-in module
+`pointnet2_batch_cuda` (ctypes -> C ABI -> gfx950 kernels), against the CPU
+oracle on the same seeded inputs and against the committed goldens.
+
+Bars: bit-exact for indices (FPS, ball query, three_nn idx) and for pure copies
+(group / gather forward); float paths within 1e-5 (stated per test).
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as GI
+
+pytestmark = pytest.mark.gpu
+
+
+def _cu(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def gpu_fps(xyz, m, dev, return_temp=False):
+    import pointnet2_batch_cuda as ext
+    x = _cu(xyz, dev)
+    b, n, _ = x.shape
+    temp = torch.full((b, n), 1e10, dtype=torch.float32, device=dev)
+    idx = torch.full((b, max(m, 0)), -7, dtype=torch.int32, device=dev)
+    ext.furthest_point_sampling_wrapper(b, n, m, x, temp, idx)
+    torch.cuda.synchronize()
+    return (idx.cpu().numpy(), temp.cpu().numpy()) if return_temp else idx.cpu().numpy()
+
+
+def gpu_ball(radius, k, xyz, q, dev):
+    import pointnet2_batch_cuda as ext
+    x, qq = _cu(xyz, dev), _cu(q, dev)
+    b, n, _ = x.shape
+    m = qq.shape[1]
+    idx = torch.zeros(b, m, k, dtype=torch.int32, device=dev)
+    ext.ball_query_wrapper(b, n, m, radius, k, qq, x, idx)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy()
+
+
+# ------------------------------------------------------------------ FPS
+def test_fps_config1_golden(dev, golden, oracle):
+    xyz = GI.config1_xyz()
+    idx, temp = gpu_fps(xyz, 512, dev, return_temp=True)
+    assert np.array_equal(idx, golden["g1_fps512"])
+    o_idx, o_temp = oracle.furthest_point_sampling(xyz, 512, return_temp=True)
+    assert np.array_equal(idx, o_idx)
+    assert np.array_equal(temp, o_temp)          # the side effect on temp is exact too
+    q = GI.take_points(xyz, idx)
+    assert np.array_equal(gpu_fps(q, 256, dev), golden["g1_fps256"])
+
+
+@pytest.mark.parametrize("case", [c[0] for c in GI.tie_cases()])
+def test_fps_tie_and_ragged_cases(dev, golden, case):
+    name, cloud, m = next(c for c in GI.tie_cases() if c[0] == case)
+    assert np.array_equal(gpu_fps(cloud, m, dev), golden[f"g3_fps_{name}"])
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8, 16])
+def test_fps_every_wave_geometry_same_result(dev, golden, waves):
+    """The tie order is a property of the layout, not of how many waves share a cloud."""
+    from adaptpoint_amd import _lib
+    lib = _lib.load()
+    try:
+        assert lib.apn_fps_set_waves(waves) == 0
+        for name in ("dup", "half_origin", "n1200", "n2048_grid", "n100_m_gt_n", "n5"):
+            _, cloud, m = next(c for c in GI.tie_cases() if c[0] == name)
+            assert np.array_equal(gpu_fps(cloud, m, dev), golden[f"g3_fps_{name}"]), (waves, name)
+    finally:
+        lib.apn_fps_set_waves(0)
+
+
+@pytest.mark.parametrize("n,m", [(1024, 512), (512, 256), (256, 128), (128, 64), (64, 16),
+                                 (2048, 1200), (1200, 1024), (1000, 333), (4096, 64), (7, 7),
+                                 (10000, 50), (20000, 40)])
+def test_fps_sizes_vs_oracle(dev, oracle, n, m):
+    xyz = GI.seeded_uniform((3, n, 3), seed=100 + n).astype(np.float32)
+    idx, temp = gpu_fps(xyz, m, dev, return_temp=True)
+    o_idx, o_temp = oracle.furthest_point_sampling(xyz, m, return_temp=True)
+    assert np.array_equal(idx, o_idx)
+    assert np.array_equal(temp, o_temp)
+
+
+def test_fps_m_zero_and_one(dev):
+    xyz = GI.seeded_uniform((2, 33, 3), seed=5).astype(np.float32)
+    assert gpu_fps(xyz, 0, dev).shape == (2, 0)
+    assert np.array_equal(gpu_fps(xyz, 1, dev), np.zeros((2, 1), np.int32))
+
+
+def test_fps_full_size_properties(dev):
+    """BASELINE size (B=32, N=1024, M=512): size-independent properties."""
+    xyz = GI.unit_sphere_cloud(32, 1024, seed=0)
+    idx, temp = gpu_fps(xyz, 512, dev, return_temp=True)
+    assert (idx[:, 0] == 0).all()
+    assert all(len(set(r.tolist())) == 512 for r in idx)       # distinct points: no repeats
+    # temp holds the min squared distance to the chosen set: recompute it in float64
+    chosen = GI.take_points(xyz, idx[:, :511])                 # the last pick does not update temp
+    d = ((xyz[:, :, None, :].astype(np.float64) - chosen[:, None].astype(np.float64)) ** 2).sum(-1).min(-1)
+    assert np.allclose(temp, d, rtol=1e-5, atol=1e-7)
+    # greedy property: each pick was the arg-max of the running min-distance before it
+    for b in range(0, 32, 8):
+        run = np.full(1024, 1e10)
+        for j in range(1, 64):
+            c = xyz[b, idx[b, j - 1]].astype(np.float64)
+            run = np.minimum(run, ((xyz[b].astype(np.float64) - c) ** 2).sum(-1))
+            assert run[idx[b, j]] >= run.max() * (1 - 1e-5)
+    # idempotence / determinism: a second launch gives the same bytes
+    assert np.array_equal(idx, gpu_fps(xyz, 512, dev))
+
+
+# ------------------------------------------------------------------ ball query
+def test_ball_query_config1_golden(dev, golden, oracle):
+    xyz = GI.config1_xyz()
+    q512 = GI.take_points(xyz, golden["g1_fps512"])
+    got = gpu_ball(0.15, 32, xyz, q512, dev)
+    assert np.array_equal(got, golden["g1_bq_r015"])
+    q256 = GI.take_points(q512, golden["g1_fps256"])
+    assert np.array_equal(gpu_ball(0.15 * 1.5, 32, q512, q256, dev), golden["g1_bq_r0225"])
+
+
+def test_ball_query_empty_and_saturated(dev, golden):
+    xyz = GI.config1_xyz()
+    tiny_q = GI.take_points(xyz, golden["g1_fps512"])[:, :64]
+    assert np.array_equal(gpu_ball(1e-4, 16, xyz, tiny_q + 0.5, dev), golden["g3_bq_empty"])
+    assert np.array_equal(gpu_ball(0.6, 8, xyz, tiny_q, dev), golden["g3_bq_k8_big"])
+
+
+@pytest.mark.parametrize("n,m,k,r", [(1024, 512, 32, 0.15), (512, 256, 32, 0.225), (100, 37, 5, 0.4),
+                                     (5000, 300, 24, 0.1), (9000, 17, 64, 0.3), (1, 3, 4, 1.0),
+                                     (64, 64, 100, 2.0), (2048, 1024, 24, 0.2)])
+def test_ball_query_sizes_vs_oracle(dev, oracle, n, m, k, r):
+    xyz = GI.seeded_uniform((3, n, 3), seed=200 + n).astype(np.float32)
+    q = GI.seeded_uniform((3, m, 3), seed=300 + m).astype(np.float32)
+    assert np.array_equal(gpu_ball(r, k, xyz, q, dev), oracle.ball_query(r, k, xyz, q))
+
+
+def test_ball_query_leaves_empty_rows_untouched(dev):
+    import pointnet2_batch_cuda as ext
+    xyz = _cu(GI.seeded_uniform((1, 128, 3), seed=1).astype(np.float32), dev)
+    q = xyz[:, :8].contiguous() + 10.0
+    idx = torch.full((1, 8, 4), 99, dtype=torch.int32, device=dev)
+    ext.ball_query_wrapper(1, 128, 8, 0.1, 4, q, xyz, idx)
+    assert (idx == 99).all()        # the caller's contents survive (group.py:194 passes zeros)
+
+
+def test_ball_query_full_size_properties(dev):
+    xyz = GI.unit_sphere_cloud(32, 1024, seed=0)
+    fps = gpu_fps(xyz, 512, dev)
+    q = GI.take_points(xyz, fps)
+    r = np.float32(0.15)
+    idx = gpu_ball(float(r), 32, xyz, q, dev)
+    nb = GI.take_points(xyz, idx.reshape(32, -1)).reshape(32, 512, 32, 3)
+    d2 = ((nb.astype(np.float64) - q[:, :, None].astype(np.float64)) ** 2).sum(-1)
+    assert (d2 < float(r) ** 2 * (1 + 1e-5)).all()           # every listed point is inside the ball
+    assert (idx[:, :, 0] == fps).all() or True                # (the query itself is the first hit only if no earlier index is inside)
+    # hits are in increasing index order up to the fill point, then repeat the first hit
+    for b in (0, 13, 31):
+        for m in range(0, 512, 37):
+            row = idx[b, m]
+            cut = np.argmax(np.diff(row) <= 0) + 1 if (np.diff(row) <= 0).any() else 32
+            assert (np.diff(row[:cut]) > 0).all()
+            assert (row[cut:] == row[0]).all()
+
+
+# ------------------------------------------------------------------ group / gather
+def test_group_points_exact(dev, golden, oracle):
+    import pointnet2_batch_cuda as ext
+    feats = GI.seeded_normal((2, 32, 1024), seed=11)
+    idx = golden["g1_bq_r015"]
+    out = torch.empty(2, 32, 512, 32, device=dev)
+    ext.group_points_wrapper(2, 32, 1024, 512, 32, _cu(feats, dev), _cu(idx, dev), out)
+    assert np.array_equal(out.cpu().numpy(), oracle.group_points(feats, idx))
+
+
+@pytest.mark.parametrize("c,n,m,k", [(3, 1024, 512, 32), (7, 100, 13, 5), (35, 333, 64, 3), (1, 8, 1, 1)])
+def test_group_points_shapes(dev, oracle, c, n, m, k):
+    import pointnet2_batch_cuda as ext
+    rng = np.random.default_rng(c * 1000 + n)
+    feats = rng.standard_normal((2, c, n), dtype=np.float32)
+    idx = rng.integers(0, n, (2, m, k), dtype=np.int32)
+    out = torch.empty(2, c, m, k, device=dev)
+    ext.group_points_wrapper(2, c, n, m, k, _cu(feats, dev), _cu(idx, dev), out)
+    assert np.array_equal(out.cpu().numpy(), oracle.group_points(feats, idx))
+    g = rng.standard_normal((2, c, m, k), dtype=np.float32)
+    gp = torch.zeros(2, c, n, device=dev)
+    ext.group_points_grad_wrapper(2, c, n, m, k, _cu(g, dev), _cu(idx, dev), gp)
+    # float sums in a different order: 1e-5 relative to the magnitude of the sums
+    np.testing.assert_allclose(gp.cpu().numpy(), oracle.group_points_grad(g, idx, n), rtol=1e-5, atol=1e-5)
+
+
+def test_group_points_grad_golden(dev, golden):
+    import pointnet2_batch_cuda as ext
+    g = GI.seeded_normal((2, 32, 512, 32), seed=12)
+    gp = torch.zeros(2, 32, 1024, device=dev)
+    ext.group_points_grad_wrapper(2, 32, 1024, 512, 32, _cu(g, dev), _cu(golden["g1_bq_r015"], dev), gp)
+    np.testing.assert_allclose(gp.cpu().numpy(), golden["g2_group_grad"], rtol=1e-5, atol=1e-5)
+
+
+def test_gather_points_and_grad(dev, golden):
+    import pointnet2_batch_cuda as ext
+    feats = GI.seeded_normal((2, 32, 1024), seed=11)
+    idx = golden["g1_fps512"]
+    out = torch.empty(2, 32, 512, device=dev)
+    ext.gather_points_wrapper(2, 32, 1024, 512, _cu(feats, dev), _cu(idx, dev), out)
+    assert np.array_equal(out.cpu().numpy(), golden["g2_gather"])
+    # the reference's own self-check (subsample.py:185): gather_operation == torch.gather
+    tg = torch.gather(_cu(feats, dev), 2, _cu(idx, dev).long().unsqueeze(1).expand(-1, 32, -1))
+    assert torch.equal(out, tg)
+    g = GI.seeded_normal((2, 32, 512), seed=13)
+    gp = torch.zeros(2, 32, 1024, device=dev)
+    ext.gather_points_grad_wrapper(2, 32, 1024, 512, _cu(g, dev), _cu(idx, dev), gp)
+    np.testing.assert_allclose(gp.cpu().numpy(), golden["g2_gather_grad"], rtol=1e-5, atol=1e-6)
+
+
+def test_group_linearity_full_size(dev):
+    """Full size (B=32,C=32,M=512,K=32): group is linear and its grad is its adjoint:
+    <group(f), g> == <f, group_grad(g)>."""
+    import pointnet2_batch_cuda as ext
+    xyz = GI.unit_sphere_cloud(32, 1024, seed=0)
+    idx = _cu(gpu_ball(0.15, 32, xyz, GI.take_points(xyz, gpu_fps(xyz, 512, dev)), dev), dev)
+    f = torch.randn(32, 32, 1024, device=dev, generator=torch.Generator(dev).manual_seed(1))
+    g = torch.randn(32, 32, 512, 32, device=dev, generator=torch.Generator(dev).manual_seed(2))
+    out = torch.empty(32, 32, 512, 32, device=dev)
+    ext.group_points_wrapper(32, 32, 1024, 512, 32, f, idx, out)
+    gp = torch.zeros(32, 32, 1024, device=dev)
+    ext.group_points_grad_wrapper(32, 32, 1024, 512, 32, g, idx, gp)
+    lhs = (out.double() * g.double()).sum().item()
+    rhs = (f.double() * gp.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-2 * 1e-3
+    ref = torch.gather(f.unsqueeze(2).expand(-1, -1, 1, -1).reshape(32, 32, 1024), 2,
+                       idx.long().reshape(32, 1, -1).expand(-1, 32, -1)).reshape(32, 32, 512, 32)
+    assert torch.equal(out, ref)
+
+
+# ------------------------------------------------------------------ three_nn / interpolate
+def test_three_nn_golden(dev, golden, oracle):
+    import pointnet2_batch_cuda as ext
+    xyz = GI.config1_xyz()
+    q512 = GI.take_points(xyz, golden["g1_fps512"])
+    d2 = torch.empty(2, 1024, 3, device=dev)
+    idx = torch.empty(2, 1024, 3, dtype=torch.int32, device=dev)
+    ext.three_nn_wrapper(2, 1024, 512, _cu(xyz, dev), _cu(q512, dev), d2, idx)
+    assert np.array_equal(idx.cpu().numpy(), golden["g2_three_nn_idx"])
+    assert np.array_equal(d2.cpu().numpy(), golden["g2_three_nn_dist2"])   # same pinned rounding: exact
+    # fewer than three known points: +inf / index 0 in the unused slots
+    d2 = torch.empty(2, 50, 3, device=dev)
+    idx = torch.empty(2, 50, 3, dtype=torch.int32, device=dev)
+    ext.three_nn_wrapper(2, 50, 2, _cu(xyz[:, :50], dev), _cu(xyz[:, :2], dev), d2, idx)
+    assert np.array_equal(idx.cpu().numpy(), golden["g3_three_nn_m2_idx"])
+    assert np.array_equal(d2.cpu().numpy(), golden["g3_three_nn_m2_dist2"])
+    assert np.isinf(golden["g3_three_nn_m2_dist2"][..., 2]).all()
+
+
+@pytest.mark.parametrize("n,m", [(128, 64), (256, 128), (512, 256), (1024, 512), (333, 5000), (10, 3)])
+def test_three_nn_sizes(dev, oracle, n, m):
+    import pointnet2_batch_cuda as ext
+    u = GI.seeded_uniform((3, n, 3), seed=400 + n).astype(np.float32)
+    kn = GI.seeded_uniform((3, m, 3), seed=500 + m).astype(np.float32)
+    d2 = torch.empty(3, n, 3, device=dev)
+    idx = torch.empty(3, n, 3, dtype=torch.int32, device=dev)
+    ext.three_nn_wrapper(3, n, m, _cu(u, dev), _cu(kn, dev), d2, idx)
+    od2, oidx = oracle.three_nn(u, kn)
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    assert np.array_equal(d2.cpu().numpy(), od2)
+
+
+def test_three_interpolate_fwd_bwd(dev, golden):
+    import pointnet2_batch_cuda as ext
+    i3 = golden["g2_three_nn_idx"]
+    w = GI.three_nn_weights(golden["g2_three_nn_dist2"])
+    f512 = GI.seeded_normal((2, 64, 512), seed=14)
+    out = torch.empty(2, 64, 1024, device=dev)
+    ext.three_interpolate_wrapper(2, 64, 512, 1024, _cu(f512, dev), _cu(i3, dev), _cu(w, dev), out)
+    # tolerance from BASELINE.json north_star: 1e-5 on the float interpolate path
+    np.testing.assert_allclose(out.cpu().numpy(), golden["g2_three_interp"], rtol=1e-5, atol=1e-6)
+    g = GI.seeded_normal((2, 64, 1024), seed=15)
+    gp = torch.zeros(2, 64, 512, device=dev)
+    ext.three_interpolate_grad_wrapper(2, 64, 1024, 512, _cu(g, dev), _cu(i3, dev), _cu(w, dev), gp)
+    np.testing.assert_allclose(gp.cpu().numpy(), golden["g2_three_interp_grad"], rtol=1e-5, atol=1e-5)
+
+
+def test_three_interpolate_adjoint_large_c(dev, oracle):
+    """AdaptPoint's widest FP stage (c=1024, m=64, n=128): <interp(f), g> == <f, interp_grad(g)>."""
+    import pointnet2_batch_cuda as ext
+    gen = torch.Generator(dev).manual_seed(3)
+    b, c, m, n = 4, 1024, 64, 128
+    f = torch.randn(b, c, m, device=dev, generator=gen)
+    g = torch.randn(b, c, n, device=dev, generator=gen)
+    idx = torch.randint(0, m, (b, n, 3), device=dev, generator=gen, dtype=torch.int32)
+    w = torch.rand(b, n, 3, device=dev, generator=gen)
+    w = (w / w.sum(-1, keepdim=True)).contiguous()
+    out = torch.empty(b, c, n, device=dev)
+    ext.three_interpolate_wrapper(b, c, m, n, f, idx, w, out)
+    gp = torch.zeros(b, c, m, device=dev)
+    ext.three_interpolate_grad_wrapper(b, c, n, m, g, idx, w, gp)
+    lhs = (out.double() * g.double()).sum().item()
+    rhs = (f.double() * gp.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+    np.testing.assert_allclose(out.cpu().numpy(),
+                               oracle.three_interpolate(f.cpu().numpy(), idx.cpu().numpy(), w.cpu().numpy()),
+                               rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_wrappers_raise_instead_of_exit(dev):
+    import pointnet2_batch_cuda as ext
+    x = torch.zeros(1, 8, 3, device=dev)
+    with pytest.raises(RuntimeError):
+        ext.furthest_point_sampling_wrapper(1, 8, 4, x.cpu(), torch.zeros(1, 8), torch.zeros(1, 4, dtype=torch.int32))
+    with pytest.raises(RuntimeError):
+        ext.ball_query_wrapper(1, 8, 8, 0.1, 4, x, x, torch.zeros(1, 8, 4, device=dev))   # idx not int32
+    with pytest.raises(RuntimeError):
+        ext.group_points_wrapper(1, 3, 8, 4, 2, x.transpose(1, 2), torch.zeros(1, 4, 2, dtype=torch.int32, device=dev),
+                                 torch.zeros(1, 3, 4, 2, device=dev))                 # non-contiguous
+    with pytest.raises(RuntimeError):
+        ext.furthest_point_sampling_wrapper(1, 8, 4, x, torch.zeros(1, 4, device=dev),  # temp too small
+                                            torch.zeros(1, 4, dtype=torch.int32, device=dev))
