@@ -1,0 +1,77 @@
+"""Data-parallel plumbing shared by bench.py and the tests: one process per GPU,
+clouds sharded by rank (no data-path collective: every operator of the hot path is
+independent per cloud), gradient all-reduce through
+torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return (int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend, device=None):
+    world, rank, _ = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if device is not None and device.type == "cuda":
+            kw["device_id"] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return world, rank
+
+
+def fence(device=None):
+    """barrier + device synchronize: brackets the timed region on both sides."""
+    if dist.is_initialized():
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(seconds, device=None):
+    if not dist.is_initialized():
+        return seconds
+    dev = device if device is not None and device.type == "cuda" else torch.device("cpu")
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_steps(step, steps, warmup, device=None):
+    """W untimed warm-up steps, then exactly `steps` timed ones between two fences;
+    returns the MAX elapsed seconds over ranks."""
+    for _ in range(warmup):
+        step()
+    fence(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence(device)
+    return max_over_ranks(time.perf_counter() - t0, device)
+
+
+def shard_seed(base_seed, rank):
+    """Each rank draws its own clouds: global batch = world * per-rank batch."""
+    return base_seed + 1000 * rank
+
+
+def host_threads(cap=None):
+    """Threads this process may actually use (affinity / cgroup aware)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    if cap:
+        n = min(n, cap)
+    return max(1, n)

@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- set-abstraction forward+backward throughput on MI355X.
+
+Metric (BASELINE.json): set-abstraction fwd+bwd point-clouds/sec at B=32, N=1024
+(npoint=512, nsample=32), at 1/2/4/8 GPUs.  Workload = BASELINE.json configs[1]:
+PointNeXt-S stage-1 SetAbstraction (cfgs/scanobjectnn/pointnext-s.yaml:5-36;
+openpoints/models/backbone/pointnext.py:82-170): FPS 1024->512, ball query r=0.15
+K=32, group xyz + 32 features, dp/radius, Conv2d 35->32 BN ReLU, Conv2d 32->64 BN,
+max over K, skip Conv1d 32->64, ReLU; loss = out.sum(); grads w.r.t. features and
+weights.  A "step" is one such pass over one batch of 32 synthetic clouds per GPU
+(distribution D1 of SURVEY.md section 8d: uniform cube -> centred -> unit sphere).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: one process per GPU, batch sharded by cloud (weak scaling, 32 per
+GPU), SyncBatchNorm + gradient all-reduce over RCCL as the reference does at
+world_size > 1 (examples/classification/main.py:27, train_autoaug.py:275-282).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+B_PER_GPU, N_PTS, NPOINT, NSAMPLE, C_IN, C_OUT, RADIUS = 32, 1024, 512, 32, 32, 64, 0.15
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_block():
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    return SetAbstraction(C_IN, C_OUT, layers=2, stride=2,
+                          group_args={'NAME': 'ballquery', 'radius': RADIUS, 'nsample': NSAMPLE,
+                                      'normalize_dp': True},
+                          norm_args={'norm': 'bn'}, act_args={'act': 'relu'},
+                          conv_args={'order': 'conv-norm-act'}, sampler='fps',
+                          feature_type='dp_fj', use_res=True)
+
+
+def make_inputs(batch, seed):
+    import golden_inputs as GI
+    p = torch.from_numpy(GI.unit_sphere_cloud(batch, N_PTS, seed=seed))
+    f = torch.from_numpy(GI.seeded_normal((batch, C_IN, N_PTS), seed=seed + 7))
+    return p, f
+
+
+# Algorithmic bytes one launch of each kernel must move (per cloud
+# x the clouds of one launch); see DESIGN.md "Kernels and rooflines".
+def algorithmic_bytes(batch):
+    mk = NPOINT * NSAMPLE
+    return {
+        "fps": batch * (N_PTS * 12 + NPOINT * 4),                          # xyz in, idx out
+        "ball_query": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4),         # xyz, queries, idx out
+        "group_xyz": batch * (3 * N_PTS * 4 + mk * 4 + 3 * mk * 4),        # rows, idx, out
+        "group_feat": batch * (C_IN * N_PTS * 4 + mk * 4 + C_IN * mk * 4),
+        "group_feat_grad": batch * (C_IN * mk * 4 + mk * 4 + 2 * C_IN * N_PTS * 4),
+    }
+
+
+class KernelTimer:
+    """HIP-event timing of the extension's launches, on the stream they run on
+    (ops.py launches on torch's current stream, which is what these events see)."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def wrap(self, name, fn):
+        def timed(*a, **k):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **k)
+            e.record()
+            self.pairs.setdefault(name, []).append((s, e))
+            return r
+        return timed
+
+    def mean_us(self):
+        torch.cuda.synchronize()
+        return {k: 1e3 * sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in self.pairs.items()}
+
+
+def instrument(timer, only=None):
+    """Route adaptpoint_amd.layers' calls into the extension through event pairs."""
+    from adaptpoint_amd import ops
+    saved = {}
+
+    def key_group(b, c, *a):
+        return "group_xyz" if c == 3 else "group_feat"
+
+    def patch(attr, name_fn):
+        orig = getattr(ops, attr)
+        saved[attr] = orig
+
+        def call(*a, **k):
+            name = name_fn(*a) if callable(name_fn) else name_fn
+            if only is not None and name not in only:
+                return orig(*a, **k)
+            return timer.wrap(name, orig)(*a, **k)
+        setattr(ops, attr, call)
+
+    patch("furthest_point_sampling_wrapper", "fps")
+    patch("ball_query_wrapper", "ball_query")
+    patch("group_points_wrapper", key_group)
+    patch("group_points_grad_wrapper", lambda b, c, *a: "group_xyz_grad" if c == 3 else "group_feat_grad")
+
+    def restore():
+        for k, v in saved.items():
+            setattr(ops, k, v)
+    return restore
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle port of the same block on the host cores: bounded sample."""
+    from oracle import cpu_block as CB
+    from oracle import oracle as O
+    from adaptpoint_amd import dp
+    threads = dp.host_threads(cap=64)            # affinity / cgroup aware, not os.cpu_count()
+    torch.set_num_threads(threads)
+    O.set_threads(threads)
+    torch.manual_seed(0)
+    blk = CB.build_cpu_block(make_block)
+    blk.train()
+    p, f = make_inputs(B_PER_GPU, seed=0)
+    CB.run_step(blk, p, f)                       # warm-up (page-in, thread pools)
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        CB.run_step(blk, p, f)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el >= seconds_budget or iters >= 10:
+            break
+    return {"value": B_PER_GPU * iters / el, "unit": "point-clouds/s", "cores": threads,
+            "kind": "port",
+            "sample": f"{iters} fwd+bwd steps of the same block (B={B_PER_GPU}, N={N_PTS}, "
+                      f"npoint={NPOINT}, nsample={NSAMPLE}) after 1 warm-up: C oracle "
+                      f"(OpenMP, {threads} threads) for FPS/ball/group, torch-CPU "
+                      f"({torch.get_num_threads()} threads) for conv/BN/max; {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="auto",
+                    help="SyncBatchNorm at world_size>1 (auto = on, as the reference)")
+    ap.add_argument("--backend", default="nccl")
+    args = ap.parse_args()
+
+    from adaptpoint_amd import dp
+    world, rank, local_rank = dp.env_world()
+    distributed = world > 1
+    if distributed and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not distributed and args.gpus != 1:
+        raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
+
+    from adaptpoint_amd import _lib
+    _lib.load()                                   # the HIP extension or nothing
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dp.init(args.backend, dev)
+
+    torch.manual_seed(0)                          # identical initial weights on every rank
+    blk = make_block().to(dev)
+    blk.train()
+    sync_bn = distributed and args.sync_bn != "off"
+    if sync_bn:
+        blk = torch.nn.SyncBatchNorm.convert_sync_batchnorm(blk)
+    model = blk
+    if distributed:
+        model = torch.nn.parallel.DistributedDataParallel(blk, device_ids=[local_rank],
+                                                          output_device=local_rank)
+    p, f = make_inputs(B_PER_GPU, seed=dp.shard_seed(0, rank))   # each rank its own shard of clouds
+    p = p.to(dev)
+    f = f.to(dev).requires_grad_(True)
+    params = [q for q in blk.parameters()]
+
+    def step():
+        f.grad = None
+        for q in params:
+            q.grad = None
+        new_p, out = model([p, f])
+        out.sum().backward()
+        return out
+
+    timer = KernelTimer()
+    restore = instrument(timer, only={"fps"})     # events around the dominant kernel only
+    # W warm-up steps, barrier + synchronize, K timed steps, barrier + synchronize, MAX over ranks
+    elapsed = dp.timed_steps(step, args.steps, args.warmup, dev)
+    restore()
+    fps_us = timer.mean_us()["fps"]               # includes the warm-up launches (same kernel)
+
+    # per-kernel view (un-timed extra pass): events around every extension launch
+    timer_all = KernelTimer()
+    restore = instrument(timer_all)
+    for _ in range(min(args.steps, 20)):
+        step()
+    per_kernel_us = timer_all.mean_us()
+    restore()
+
+    total_clouds = B_PER_GPU * world * args.steps
+    value = total_clouds / elapsed
+    ab = algorithmic_bytes(B_PER_GPU)
+    kernels = {}
+    for k, us in sorted(per_kernel_us.items()):
+        ent = {"avg_us": round(us, 2)}
+        if k in ab:
+            ent["algorithmic_bytes"] = ab[k]
+            ent["achieved_GBps"] = round(ab[k] / us * 1e-3, 2)
+            ent["frac_hbm"] = round(ab[k] / us * 1e-3 / HBM_PEAK_GBS, 5)
+        kernels[k] = ent
+    dominant = max(per_kernel_us, key=per_kernel_us.get)
+    dom_us = fps_us if dominant == "fps" else per_kernel_us[dominant]
+    achieved = ab.get(dominant, 0) / dom_us * 1e-3
+    roofline = {
+        "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+        "avg_launch_us": round(dom_us, 2),
+        "note": ("FPS is a serial chain of npoint-1 dependent arg-max steps on B workgroups; its "
+                 "bound is per-step latency, not HBM or MFMA (DESIGN.md). step_ns = avg launch "
+                 "/ (npoint-1)."),
+        "fps_step_ns": round(fps_us * 1e3 / (NPOINT - 1), 1),
+        "kernels": kernels,
+    }
+
+    result = {
+        "metric": "set-abstraction fwd+bwd point-clouds/sec (B=32,N=1024)",
+        "value": round(value, 2), "unit": "point-clouds/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PointNeXt-S stage-1 SetAbstraction fwd+bwd, B=32/GPU N=1024 "
+                               "npoint=512 nsample=32 r=0.15 C 32->64 (BASELINE configs[1]); "
+                               "clouds: uniform cube centred+scaled to the unit sphere (D1)",
+                   "global_batch": B_PER_GPU * world,
+                   "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else "")},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

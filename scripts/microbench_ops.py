@@ -1,0 +1,87 @@
+"""Per-operator timing on the GPU box (HIP events on torch's stream).
+
+    python scripts/microbench_ops.py fps        # FPS by wave geometry and size
+    python scripts/microbench_ops.py ops        # every extension op at the bench shape
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import golden_inputs as GI
+from adaptpoint_amd import _lib, ops
+
+
+def time_us(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record(); fn(); e.record()
+    torch.cuda.synchronize()
+    t = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
+    return t[len(t) // 2], t[0]
+
+
+def bench_fps():
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    for (b, n, m) in [(32, 1024, 512), (32, 512, 256), (32, 256, 128), (32, 128, 64), (32, 2048, 1200), (32, 2048, 512), (32, 4096, 1024), (32, 8192, 512), (1, 1024, 512), (256, 1024, 512)]:
+        xyz = torch.from_numpy(GI.unit_sphere_cloud(b, n, seed=0)).to(dev)
+        temp = torch.empty(b, n, device=dev)
+        idx = torch.empty(b, m, dtype=torch.int32, device=dev)
+        line = f"B={b:4d} N={n:5d} M={m:5d}: "
+        for w in (0, 1, 2, 4, 8, 16):
+            if w and (n + w * 64 - 1) // (w * 64) > 16:
+                line += f" w{w}=   n/a   "
+                continue
+            lib.apn_fps_set_waves(w)
+
+            def run():
+                temp.fill_(1e10)
+                ops.furthest_point_sampling_wrapper(b, n, m, xyz, temp, idx)
+            med, mn = time_us(run)
+            fill, _ = time_us(lambda: temp.fill_(1e10))
+            line += f" w{w}={med - fill:7.1f}us ({(med - fill) * 1e3 / max(m - 1, 1):5.0f}ns/step)"
+        lib.apn_fps_set_waves(0)
+        print(line, flush=True)
+
+
+def bench_ops():
+    dev = torch.device("cuda:0")
+    B, N, M, K, C = 32, 1024, 512, 32, 32
+    xyz = torch.from_numpy(GI.unit_sphere_cloud(B, N, seed=0)).to(dev)
+    temp = torch.full((B, N), 1e10, device=dev)
+    fidx = torch.empty(B, M, dtype=torch.int32, device=dev)
+    ops.furthest_point_sampling_wrapper(B, N, M, xyz, temp, fidx)
+    q = torch.gather(xyz, 1, fidx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx = torch.zeros(B, M, K, dtype=torch.int32, device=dev)
+    print("ball_query     %8.1f us" % time_us(lambda: ops.ball_query_wrapper(B, N, M, 0.15, K, q, xyz, idx))[0])
+    f = torch.randn(B, C, N, device=dev)
+    out = torch.empty(B, C, M, K, device=dev)
+    print("group C=32     %8.1f us" % time_us(lambda: ops.group_points_wrapper(B, C, N, M, K, f, idx, out))[0])
+    g = torch.randn(B, C, M, K, device=dev)
+    gp = torch.zeros(B, C, N, device=dev)
+    print("group_grad C=32%8.1f us" % time_us(lambda: ops.group_points_grad_wrapper(B, C, N, M, K, g, idx, gp))[0])
+    xt = xyz.transpose(1, 2).contiguous()
+    o3 = torch.empty(B, 3, M, K, device=dev)
+    print("group C=3      %8.1f us" % time_us(lambda: ops.group_points_wrapper(B, 3, N, M, K, xt, idx, o3))[0])
+    d2 = torch.empty(B, N, 3, device=dev)
+    i3 = torch.empty(B, N, 3, dtype=torch.int32, device=dev)
+    print("three_nn       %8.1f us" % time_us(lambda: ops.three_nn_wrapper(B, N, M, xyz, q, d2, i3))[0])
+    w = torch.rand(B, N, 3, device=dev)
+    fm = torch.randn(B, 64, M, device=dev)
+    o = torch.empty(B, 64, N, device=dev)
+    print("three_interp   %8.1f us" % time_us(lambda: ops.three_interpolate_wrapper(B, 64, M, N, fm, i3, w, o))[0])
+    go = torch.randn(B, 64, N, device=dev)
+    gm = torch.zeros(B, 64, M, device=dev)
+    print("three_interp_g %8.1f us" % time_us(lambda: ops.three_interpolate_grad_wrapper(B, 64, N, M, go, i3, w, gm))[0])
+
+
+if __name__ == "__main__":
+    {"fps": bench_fps, "ops": bench_ops}[sys.argv[1] if len(sys.argv) > 1 else "fps"]()

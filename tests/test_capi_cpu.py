@@ -1,0 +1,82 @@
+"""CPU suite: the C-ABI library loads and exports exactly what include/adaptpoint_amd.h
+declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "adaptpoint_amd.h")
+
+
+def header_prototypes():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"APN_API\s+(?:const\s+char\s*\*|int)\s*(apn_\w+)\s*\(([^)]*)\)\s*;", src):
+        args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
+        protos[m.group(1)] = args
+    return protos
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from adaptpoint_amd import build as apn_build
+    path = apn_build.build()           # hipcc cross-compiles gfx950 without a GPU
+    return ctypes.CDLL(path)
+
+
+def test_header_declares_the_nine_reference_entry_points():
+    protos = header_prototypes()
+    for name in ["apn_ball_query", "apn_group_points", "apn_group_points_grad", "apn_gather_points",
+                 "apn_gather_points_grad", "apn_furthest_point_sampling", "apn_three_nn",
+                 "apn_three_interpolate", "apn_three_interpolate_grad"]:
+        assert name in protos
+        assert protos[name][-1].replace(" ", "") == "void*stream"
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in header_prototypes():
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+
+
+def test_ctypes_signatures_match_header_arity():
+    from adaptpoint_amd import _lib
+    protos = header_prototypes()
+    for name, argtypes in _lib.SIGNATURES.items():
+        assert name in protos, name
+        assert len(argtypes) == len(protos[name]), name
+        for at, decl in zip(argtypes, protos[name]):
+            if "*" in decl:
+                assert at is ctypes.c_void_p, (name, decl)
+            elif decl.startswith("float"):
+                assert at is ctypes.c_float, (name, decl)
+            else:
+                assert at is ctypes.c_int, (name, decl)
+
+
+def test_version_and_error_strings(lib):
+    lib.apn_version.restype = ctypes.c_int
+    assert lib.apn_version() >= 100
+    lib.apn_error_string.restype = ctypes.c_char_p
+    assert lib.apn_error_string(0) == b"success"
+    assert b"invalid" in lib.apn_error_string(-1)
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    """Bad sizes are rejected before any HIP call; zero sizes are no-ops."""
+    f = lib.apn_furthest_point_sampling
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
+    assert f(-1, 8, 4, None, None, None, None) == -1
+    assert f(0, 8, 4, None, None, None, None) == 0
+    assert f(2, 8, 0, None, None, None, None) == 0          # m <= 0: the reference kernel returns at once
+    assert f(2, 0, 4, None, None, None, None) == -1
+    assert f(2, 8, 4, None, None, None, None) == -1          # null pointers
+    g = lib.apn_group_points
+    g.restype = ctypes.c_int
+    g.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 4
+    assert g(1, 4, 8, 0, 3, None, None, None, None) == 0
+    assert g(1, 4, 8, 1 << 20, 1 << 20, None, None, None, None) == -1   # npoints*nsample overflows int
+    assert lib.apn_fps_set_waves(3) == -1 and lib.apn_fps_set_waves(0) == 0

@@ -1,0 +1,105 @@
+"""CPU suite: host-side logic of the drop-in boundary and of the layer mirror."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as GI
+
+
+def test_drop_in_module_exports_reference_symbols():
+    import pointnet2_batch_cuda as ext
+    # openpoints/cpp/pointnet2_batch/src/pointnet2_api.cpp:11-23
+    for name in ["ball_query_wrapper", "group_points_wrapper", "group_points_grad_wrapper",
+                 "gather_points_wrapper", "gather_points_grad_wrapper",
+                 "furthest_point_sampling_wrapper", "three_nn_wrapper",
+                 "three_interpolate_wrapper", "three_interpolate_grad_wrapper"]:
+        assert callable(getattr(ext, name))
+
+
+def test_chamfer_stub_is_inert():
+    import chamfer
+    with pytest.raises(NotImplementedError):
+        chamfer.forward()
+    with pytest.raises(NotImplementedError):
+        chamfer.backward()
+
+
+def test_wrappers_have_no_cpu_path():
+    """The product path fails loudly off-GPU: no oracle / PyTorch fallback behind it."""
+    import pointnet2_batch_cuda as ext
+    x = torch.zeros(1, 8, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ext.furthest_point_sampling_wrapper(1, 8, 4, x, torch.zeros(1, 8), torch.zeros(1, 4, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ext.ball_query_wrapper(1, 8, 8, 0.1, 4, x, x, torch.zeros(1, 8, 4, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ext.three_nn_wrapper(1, 8, 8, x, x, torch.zeros(1, 8, 3), torch.zeros(1, 8, 3, dtype=torch.int32))
+
+
+def test_product_package_never_imports_oracle():
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "pointnet2_batch_cuda.py"), os.path.join(root, "chamfer.py")]
+    for d, _, fs in os.walk(os.path.join(root, "adaptpoint_amd")):
+        files += [os.path.join(d, f) for f in fs if f.endswith((".py", ".hip", ".h"))]
+    for f in files:
+        assert not re.search(r"^\s*(from|import)\s+oracle|libpointnet2_oracle", open(f).read(), re.M), f
+
+
+def test_missing_extension_raises(monkeypatch, tmp_path):
+    from adaptpoint_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.ExtensionMissing):
+        _lib.load()
+
+
+def test_set_abstraction_mirror_matches_reference_module(golden):
+    """The host-side SetAbstraction, run on CPU over the oracle ops, reproduces the
+    REFERENCE module's output and gradients captured by tests/golden/make_golden.py
+    (openpoints/models/backbone/pointnext.py:82-170 imported from /root/reference)."""
+    from oracle import cpu_block as CB
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+
+    def mk():
+        return SetAbstraction(32, 64, layers=2, stride=2,
+                              group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                              norm_args={'norm': 'bn'}, act_args={'act': 'relu'},
+                              conv_args={'order': 'conv-norm-act'}, use_res=True)
+    blk = CB.build_cpu_block(mk)
+    sd = {k.split("/", 1)[1]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith("g4_sa_state/")}
+    assert set(sd) == set(blk.state_dict())          # same parameter names/nesting as the reference
+    blk.load_state_dict(sd)
+    blk.train()
+    p = torch.from_numpy(GI.unit_sphere_cloud(2, 1024, seed=3))
+    f = torch.from_numpy(GI.seeded_normal((2, 32, 1024), seed=4)).requires_grad_(True)
+    with CB.CpuOps():
+        new_p, out = blk([p, f])
+        w = torch.from_numpy(GI.seeded_normal(tuple(out.shape), seed=5))
+        (out * w).sum().backward()
+    np.testing.assert_allclose(new_p.numpy(), golden["g4_sa_new_p"], rtol=0, atol=0)
+    np.testing.assert_allclose(out.detach().numpy(), golden["g4_sa_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f.grad.numpy(), golden["g4_sa_grad_f"], rtol=1e-5, atol=1e-6)
+    for k, prm in blk.named_parameters():
+        np.testing.assert_allclose(prm.grad.numpy(), golden["g4_sa_grad/" + k], rtol=1e-4, atol=1e-5)
+
+
+def test_query_and_group_mirror(golden):
+    from oracle import cpu_block as CB
+    from adaptpoint_amd.layers import QueryAndGroup
+    xyz = GI.config1_xyz()
+    q = GI.take_points(xyz, golden["g1_fps512"])
+    feats = GI.seeded_normal((2, 32, 1024), seed=11)
+    with CB.CpuOps():
+        dp, fj = QueryAndGroup(0.15, 32, normalize_dp=True)(torch.from_numpy(q), torch.from_numpy(xyz), torch.from_numpy(feats))
+    np.testing.assert_allclose(dp.numpy(), golden["g4_qg_dp"], rtol=1e-6, atol=1e-7)
+    chk = np.array([fj.double().sum().item(), fj.double().abs().sum().item()])
+    np.testing.assert_allclose(chk, golden["g4_qg_fj_checksum"], rtol=1e-12)
+
+
+def test_grouper_factory_and_channel_map():
+    from adaptpoint_amd.layers import CHANNEL_MAP, GroupAll, QueryAndGroup, create_grouper
+    assert isinstance(create_grouper({'NAME': 'ballquery', 'radius': 0.1, 'nsample': 8}), QueryAndGroup)
+    assert isinstance(create_grouper({'NAME': 'ballquery', 'radius': None, 'nsample': None}), GroupAll)
+    assert CHANNEL_MAP['dp_fj'](32) == 35
