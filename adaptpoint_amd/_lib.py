@@ -24,6 +24,10 @@ SIGNATURES = {
     "apn_three_interpolate": [_c_int] * 4 + [_c_void_p] * 5,
     "apn_three_interpolate_grad": [_c_int] * 4 + [_c_void_p] * 5,
     "apn_fps_set_waves": [_c_int],
+    "apn_sa_grid_blocks": [_c_int] * 2,
+    "apn_sa_prep_features": [_c_int] * 3 + [_c_void_p] * 3,
+    "apn_sa_fwd_stats1": [_c_int] * 7 + [_c_float] + [_c_void_p] * 7,
+    "apn_sa_fwd_main": [_c_int] * 7 + [_c_float] + [_c_void_p] * 13,
 }
 
 _lib = None

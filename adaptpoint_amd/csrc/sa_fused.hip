@@ -1,0 +1,306 @@
+// sa_fused.hip -- the grouped shared-MLP of a PointNeXt set-abstraction block as
+// one MFMA pipeline per pass, for gfx950.
+//
+// What it replaces.  After FPS and ball query the reference block
+// (openpoints/models/backbone/pointnext.py:157-168 with QueryAndGroup,
+// openpoints/models/layers/group.py:235-255,323-335) materialises
+//     fj = cat[(xyz[idx]-new_xyz)/r , f[idx]]         (B, 3+C, M, K)   73 MB @ B=32
+//     y1 = Conv2d(3+C -> C1)(fj); a1 = ReLU(BN(y1))   (B, C1,  M, K)   67 MB x3
+//     y2 = Conv2d(C1 -> C2)(a1);  z  = BN(y2)         (B, C2,  M, K)  134 MB x2
+//     o  = max_K z                                    (B, C2,  M)
+// in HBM (~0.5 GB moved forward, ~1 GB forward+backward).  Here no (.,M,K) tensor
+// ever exists: every pass re-gathers the neighbourhood rows of a point-major bf16
+// copy of f (4 MB, L2 resident), and runs the whole chain in registers.  A tile is
+// one query = K = 32 positions; one wave owns a tile at a time.
+//
+// MFMA mapping (v_mfma_f32_32x32x16_bf16, f32 accumulate).  Operand lane maps
+// (cdna_hip_programming.md section 3): lane l = (r = l&31, h = l>>5) holds
+// A[row r][k = 8h+j] / B[k = 8h+j][col r], j = 0..7; C/D: col = lane&31,
+// row(reg,h) = (reg&3) + 8*(reg>>2) + 4*h.  Chosen so that NO data ever moves
+// between lanes inside the chain:
+//   * the gather is per position, so lane (pos, h) naturally holds 8 consecutive
+//     input channels of its position: X is an A operand (rows = positions) or, with
+//     the two builtin arguments swapped, a B operand (cols = positions);
+//   * conv1 is issued "transposed"  Y1^T = W1 * X^T : accumulator lane = position,
+//     register = mid channel row(reg,h).  After BN+ReLU, registers 8s..8s+7 packed
+//     to bf16 ARE the A fragment of k-step s of conv2 (the "accumulator as next
+//     operand" rule), with k order row(8s+j,h); W2's fragments are built in that
+//     same order once per wave;
+//   * conv2 is issued "straight"  Y2 = A1 * W2^T : accumulator lane = output
+//     channel, register = position -- so BatchNorm statistics (sum over positions)
+//     and the max over the K neighbours are sums/maxima over a lane's OWN registers
+//     plus one exchange between the two lane halves.
+//
+// BatchNorm in training mode needs batch statistics between a conv and its
+// activation, so the forward is two passes over the tiles:
+//   pass 1  gather, conv1                      -> per-channel sum / sum-of-squares of y1
+//   pass 2  gather, conv1, BN1+ReLU, conv2     -> sum / sumsq of y2, and per (query, channel)
+//                                                 the extreme of y2 over K and where it is
+// BN2 is affine per channel, so max_K BN2(y2) = scale*ext_K(y2)+shift with ext = max
+// when gamma2 >= 0 and min otherwise: no third pass.  Statistics leave the kernels
+// as per-workgroup partial rows, summed in float64 by the caller (deterministic, and
+// the natural place for the SyncBatchNorm all-reduce at world_size > 1).
+//
+// Roofline: compulsory HBM traffic of pass 2 at B=32 is xyz 0.4 + idx 2.1 + ft 2.1
+// + out 2 x 4.2 MB ~ 13 MB (1.6 us at 8 TB/s); bf16 MFMA work 7 x 32 cycles per tile.
+// Both are far below the per-tile VALU/gather latency, which is what bounds it.
+#include "apn_common.h"
+
+namespace apn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int SA_C = 32;     // feature channels in
+constexpr int SA_C1 = 32;    // mid channels
+constexpr int SA_C2 = 64;    // out channels
+constexpr int SA_K = 32;     // neighbours per query = positions per tile
+constexpr int SA_WAVES = 4;  // waves per workgroup
+
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16 &v, int base) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[base + j];
+    return o;
+}
+
+// (B,C,N) f32 channel-major  ->  (B,N,C) bf16 point-major, C = 32: one 64-byte row per point.
+__global__ __launch_bounds__(256) void sa_prep_features_kernel(int n, const float *__restrict__ f,
+                                                               __bf16 *__restrict__ ft) {
+    __shared__ float tile[SA_C][65];
+    const int cloud = blockIdx.y;
+    const int n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    for (int c = ty; c < SA_C; c += 4) {
+        const int p = n0 + tx;
+        tile[c][tx] = p < n ? f[((size_t)cloud * SA_C + c) * n + p] : 0.0f;
+    }
+    __syncthreads();
+    // 64 points x 32 channels: thread -> (point = tid>>2, 8 channels = (tid&3)*8)
+    const int pt = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 8;
+    if (n0 + pt < n) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)tile[c0 + j][pt];
+        *reinterpret_cast<bf16x8 *>(ft + ((size_t)cloud * n + n0 + pt) * SA_C + c0) = o;
+    }
+}
+
+struct SaArgs {
+    int b, n, m;                 // clouds, support points, queries
+    const float *xyz;            // (B,N,3)
+    const float *new_xyz;        // (B,M,3)
+    const __bf16 *ft;            // (B,N,32) bf16
+    const int *idx;              // (B,M,32)
+    const float *w1;             // (32, 35): columns [dp(3), f(32)] as the reference's cat([dp, fj])
+    float radius;
+};
+
+// Per-wave constant operand fragments of conv1: lane (r = mid channel, h), step s,
+// element j  <->  input channel k = 16 s + 8 h + j: features 0..31, then dp x,y,z.
+__device__ __forceinline__ void load_w1_frags(const float *__restrict__ w1, int r, int h,
+                                              bf16x8 (&wf)[3]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[s][j] = (__bf16)w1[r * 35 + 3 + 16 * s + 8 * h + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wf[2][j] = (__bf16)((h == 0 && j < 3) ? w1[r * 35 + j] : 0.0f);
+}
+
+// Gather one tile: lane (pos, h) fetches 2 x 16 bytes of its neighbour's bf16 row,
+// and (h = 0) the normalised relative position.
+__device__ __forceinline__ void gather_tile(const SaArgs &a, int tile, int pos, int h,
+                                            bf16x8 (&x)[3]) {
+    const int cloud = tile / a.m;
+    const int nb = a.idx[(size_t)tile * SA_K + pos];
+    const uint4 *row = reinterpret_cast<const uint4 *>(a.ft + ((size_t)cloud * a.n + nb) * SA_C);
+    const uint4 c0 = row[h], c1 = row[2 + h];
+    x[0] = __builtin_bit_cast(bf16x8, c0);
+    x[1] = __builtin_bit_cast(bf16x8, c1);
+    const float *q = a.new_xyz + (size_t)tile * 3;           // wave-uniform
+    const float *p = a.xyz + ((size_t)cloud * a.n + nb) * 3;
+    bf16x8 d;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = (__bf16)0.0f;
+    if (h == 0) {
+        // group.py:250-253: (grouped_xyz - query) then /= radius
+        d[0] = (__bf16)((p[0] - q[0]) / a.radius);
+        d[1] = (__bf16)((p[1] - q[1]) / a.radius);
+        d[2] = (__bf16)((p[2] - q[2]) / a.radius);
+    }
+    x[2] = d;
+}
+
+// Workgroup-level fold of per-lane statistics into one partial row per workgroup.
+// vals[i] belongs to channel (i * 32 + r) of this lane's half; halves and waves add.
+template <int NV>
+__device__ __forceinline__ void write_partials(float (&vals)[NV], float *__restrict__ out_row,
+                                               int lane, int wave) {
+    __shared__ float red[SA_WAVES][NV][32];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float other = __shfl_xor(vals[i], 32);
+        if (lane < 32) red[wave][i][lane] = vals[i] + other;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NV * 32; e += SA_WAVES * 64) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < SA_WAVES; ++w) s += red[w][e >> 5][e & 31];
+        out_row[e] = s;
+    }
+}
+
+// Pass 1: statistics of y1 = conv1(x).  partials: [gridDim.x][64] = {sum[32], sumsq[32]}.
+__global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
+                                                                      float *__restrict__ partials) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    bf16x8 w1f[3];
+    load_w1_frags(a.w1, r, h, w1f);
+    float st[2] = {0.0f, 0.0f};
+    const int tiles = a.b * a.m;
+    for (int tile = blockIdx.x * SA_WAVES + wave; tile < tiles; tile += gridDim.x * SA_WAVES) {
+        bf16x8 x[3];
+        gather_tile(a, tile, r, h, x);
+        f32x16 y = {0};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) y = mfma(x[s], w1f[s], y);  // Y1: lane = mid channel
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[0] += y[i]; st[1] += y[i] * y[i]; }
+    }
+    write_partials<2>(st, partials + (size_t)blockIdx.x * 64, lane, wave);
+}
+
+// Pass 2.  scale1/shift1: BN1 folded to y*scale+shift; sgn2[c] = +1/-1 (sign of gamma2).
+// Outputs ysel/ksel (B,M,64): the extreme of y2 over K and its position; partials:
+// [gridDim.x][128] = {sum[64], sumsq[64]} of y2.
+__global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
+    SaArgs a, const float *__restrict__ w2, const float *__restrict__ scale1,
+    const float *__restrict__ shift1, const float *__restrict__ sgn2, float *__restrict__ ysel,
+    unsigned char *__restrict__ ksel, float *__restrict__ partials) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    bf16x8 w1f[3];
+    load_w1_frags(a.w1, r, h, w1f);
+    // conv2 B fragments: lane (out channel 32 t + r, h), step s, element j <-> mid channel row(8s+j, h)
+    bf16x8 w2f[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                w2f[t][s][j] = (__bf16)w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
+    float sc1[16], sh1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        sc1[i] = scale1[acc_row(i, h)];
+        sh1[i] = shift1[acc_row(i, h)];
+    }
+    const float sg[2] = {sgn2[r], sgn2[32 + r]};
+    float st[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum t0, sum t1, sumsq t0, sumsq t1
+
+    const int tiles = a.b * a.m;
+    for (int tile = blockIdx.x * SA_WAVES + wave; tile < tiles; tile += gridDim.x * SA_WAVES) {
+        bf16x8 x[3];
+        gather_tile(a, tile, r, h, x);
+        f32x16 y1 = {0};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) y1 = mfma(w1f[s], x[s], y1);  // Y1^T: lane = position
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y1[i] = __builtin_fmaxf(__builtin_fmaf(y1[i], sc1[i], sh1[i]), 0.0f);
+        const bf16x8 a0 = pack8(y1, 0), a1 = pack8(y1, 8);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 y2 = {0};
+            y2 = mfma(a0, w2f[t][0], y2);  // Y2: lane = out channel 32 t + r, register = position
+            y2 = mfma(a1, w2f[t][1], y2);
+            float best = sg[t] * y2[0];
+            int bpos = 0;
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s1 += y2[i];
+                s2 += y2[i] * y2[i];
+                const float v = sg[t] * y2[i];
+                if (i > 0 && v > best) { best = v; bpos = i; }
+            }
+            st[t] += s1;
+            st[2 + t] += s2;
+            int kpos = acc_row(bpos, h);
+            const float obest = __shfl_xor(best, 32);
+            const int okpos = __shfl_xor(kpos, 32);
+            if (obest > best || (obest == best && okpos < kpos)) { best = obest; kpos = okpos; }
+            if (h == 0) {
+                ysel[(size_t)tile * SA_C2 + 32 * t + r] = sg[t] * best;
+                ksel[(size_t)tile * SA_C2 + 32 * t + r] = (unsigned char)kpos;
+            }
+        }
+    }
+    write_partials<4>(st, partials + (size_t)blockIdx.x * 128, lane, wave);
+}
+
+static int sa_grid(int tiles) {
+    // two workgroups of 4 waves per CU when there is enough work: 2 waves per SIMD
+    int g = (tiles + SA_WAVES - 1) / SA_WAVES;
+    return g < 512 ? (g < 1 ? 1 : g) : 512;
+}
+
+}  // namespace apn
+
+extern "C" int apn_sa_grid_blocks(int b, int m) { return apn::sa_grid(b * m); }
+
+extern "C" int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, void *stream) {
+    using namespace apn;
+    if (b < 0 || n < 0 || c != SA_C) return APN_EINVAL;
+    if (b == 0 || n == 0) return APN_OK;
+    if (!f || !ft || b > 65535) return APN_EINVAL;
+    hipLaunchKernelGGL(sa_prep_features_kernel, dim3((n + 63) / 64, b), dim3(256), 0,
+                       (hipStream_t)stream, n, f, (__bf16 *)ft);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+static int sa_check(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample) {
+    using namespace apn;
+    if (b <= 0 || n <= 0 || m <= 0) return APN_EINVAL;
+    if (c_in != SA_C || c_mid != SA_C1 || c_out != SA_C2 || nsample != SA_K) return APN_EINVAL;
+    if ((long long)b * m > 0x7fffffffLL / 64) return APN_EINVAL;
+    return APN_OK;
+}
+
+extern "C" int apn_sa_fwd_stats1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
+                                 float radius, const float *xyz, const float *new_xyz,
+                                 const void *ft, const int *idx, const float *w1, float *partials,
+                                 void *stream) {
+    using namespace apn;
+    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample)) return e;
+    SaArgs a{b, n, m, xyz, new_xyz, (const __bf16 *)ft, idx, w1, radius};
+    hipLaunchKernelGGL(sa_fwd_stats1_kernel, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                       (hipStream_t)stream, a, partials);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
+                               float radius, const float *xyz, const float *new_xyz, const void *ft,
+                               const int *idx, const float *w1, const float *w2,
+                               const float *scale1, const float *shift1, const float *sgn2,
+                               float *ysel, void *ksel, float *partials, void *stream) {
+    using namespace apn;
+    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample)) return e;
+    SaArgs a{b, n, m, xyz, new_xyz, (const __bf16 *)ft, idx, w1, radius};
+    hipLaunchKernelGGL(sa_fwd_main_kernel, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                       (hipStream_t)stream, a, w2, scale1, shift1, sgn2, ysel,
+                       (unsigned char *)ksel, partials);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}

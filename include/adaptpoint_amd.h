@@ -105,6 +105,41 @@ APN_API int apn_three_interpolate_grad(int b, int c, int n, int m, const float *
                                const int *idx, const float *weight, float *grad_points,
                                void *stream);
 
+/* ------------------------------------------------------------------------
+ * Fused set-abstraction MLP (no single reference entry point: the reference runs
+ * this chain as PyTorch ops over materialised (B,C,M,K) tensors --
+ * openpoints/models/layers/group.py:235-255,323-335 and
+ * openpoints/models/backbone/pointnext.py:157-168).  Shapes supported by this
+ * build: c_in = 32 features (+3 relative xyz), c_mid = 32, c_out = 64,
+ * nsample = 32; anything else returns APN_EINVAL and callers use the unfused ops.
+ *   xyz (B,N,3) f32, new_xyz (B,M,3) f32, ft (B,N,32) bf16 point-major copy of the
+ *   features, idx (B,M,32) i32, w1 (32,35) f32 with columns [dp(3), f(32)],
+ *   w2 (64,32) f32.  "partials" are per-workgroup rows of per-channel sums, summed
+ *   by the caller (rows = apn_sa_grid_blocks(b, m)).
+ * ------------------------------------------------------------------------ */
+
+/* Workgroups (= partial rows) the fused passes launch for B clouds x M queries. */
+APN_API int apn_sa_grid_blocks(int b, int m);
+
+/* f (B,C,N) f32 -> ft (B,N,C) bf16 (C must be 32). */
+APN_API int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, void *stream);
+
+/* Forward pass 1: partials[rows][64] = {sum, sumsq}[32] of y1 = conv1(cat(dp, f[idx])). */
+APN_API int apn_sa_fwd_stats1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
+                              float radius, const float *xyz, const float *new_xyz,
+                              const void *ft, const int *idx, const float *w1, float *partials,
+                              void *stream);
+
+/* Forward pass 2: a1 = relu(y1*scale1+shift1); y2 = conv2(a1);
+ * ysel/ksel (B,M,64): per (query, channel) the extreme of y2 over the K neighbours
+ * (max where sgn2 = +1, min where sgn2 = -1) and the neighbour slot holding it;
+ * partials[rows][128] = {sum[64], sumsq[64]} of y2. */
+APN_API int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
+                            float radius, const float *xyz, const float *new_xyz, const void *ft,
+                            const int *idx, const float *w1, const float *w2,
+                            const float *scale1, const float *shift1, const float *sgn2,
+                            float *ysel, void *ksel, float *partials, void *stream);
+
 /* Tuning / diagnostic hook, NOT part of the reference boundary: force the number
  * of wavefronts that cooperate on one cloud in apn_furthest_point_sampling
  * (1, 2, 4, 8 or 16; 0 restores the built-in heuristic).  Results do not depend
