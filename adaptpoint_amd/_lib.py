@@ -28,6 +28,8 @@ SIGNATURES = {
     "apn_sa_prep_features": [_c_int] * 3 + [_c_void_p] * 3,
     "apn_sa_fwd_stats1": [_c_int] * 7 + [_c_float] + [_c_void_p] * 7,
     "apn_sa_fwd_main": [_c_int] * 7 + [_c_float] + [_c_void_p] * 13,
+    "apn_sa_bwd_pass1": [_c_int] * 7 + [_c_float] + [_c_void_p] * 15,
+    "apn_sa_bwd_pass2": [_c_int] * 7 + [_c_float] + [_c_void_p] * 15,
 }
 
 _lib = None

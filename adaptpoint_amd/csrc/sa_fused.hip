@@ -248,6 +248,222 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
     write_partials<4>(st, partials + (size_t)blockIdx.x * 128, lane, wave);
 }
 
+// ---------------------------------------------------------------------------
+// Backward.  Given g_out = dL/d(max_K BN2(y2)) the caller forms, from (B,M,64)
+// tensors only, BN2's two reduction terms S1 = sum g, S2 = sum g*yhat_sel and the
+// per-channel constants of
+//     dL/dy2 = goa[q,c] * [pos == ksel[q,c]]  +  y2 * D2[c] + E2[c]
+// (goa = g * gamma2*invstd2; the dense part is BN's mean/variance feedback).  Two
+// passes re-run the chain per tile:
+//   pass 1  -> dL/dW2 (64x32, an MFMA over positions), and BN1's reduction terms
+//              T1 = sum g_u, T2 = sum g_u * yhat1 with g_u = (dL/da1) * [a1 > 0]
+//   pass 2  -> dL/dy1 = g_u*ca + yhat1*cb + cc per position, summed per source point
+//              into G (B,N,32) (float atomics, de-duplicated) and per query into
+//              H (B,M,32).  Everything downstream of dL/dy1 is linear in it, so
+//              dL/df = G * W1f, dL/dW1f = G^T * f, and the relative-position
+//              columns follow from G, H and the coordinates (fused.py): three tiny
+//              GEMMs instead of a (B,35,M,K) gradient tensor.
+// dL/da1 = dL/dy2 * W2 never needs y2 transposed: the dense part folds to
+// a1 * (W2^T diag(D2) W2) + E2*W2 (a 32x32 matrix Qm and a vector, built by the
+// caller), and the sparse part is a one-hot-weighted (pos x channel) operand built
+// from ksel/goa by compares -- both land as MFMAs in the [lane = mid channel,
+// register = position] layout that the ReLU mask and BN1 terms already use.
+struct SaBwdArgs {
+    const float *w2;        // (64,32)
+    const float *scale1, *shift1, *mean1, *inv1;   // BN1 fold and statistics [32]
+    const float *qm;        // (32,32)  W2^T diag(D2) W2, qm[k][mid]
+    const float *evec;      // [32]     sum_c E2[c] W2[c][mid]
+    const float *d2, *e2;   // [64]
+    const float *goa;       // (B,M,64)
+    const unsigned char *ksel;  // (B,M,64)
+    const float *ca, *cb, *cc;  // [32] pass 2: dL/dy1 = g_u*ca + yhat1*cb + cc
+};
+
+template <int PASS>
+__global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
+                                                               float *__restrict__ partials,
+                                                               float *__restrict__ gw2_partials,
+                                                               float *__restrict__ G,
+                                                               float *__restrict__ H) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    bf16x8 w1f[3];
+    load_w1_frags(a.w1, r, h, w1f);
+    float sc1v[16], sh1v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        sc1v[i] = g.scale1[acc_row(i, h)];
+        sh1v[i] = g.shift1[acc_row(i, h)];
+    }
+    const float sc1 = g.scale1[r], sh1 = g.shift1[r], mu1 = g.mean1[r], iv1 = g.inv1[r];
+    // term 1 of dL/da1: B fragments of Qm, k slot (h,j) of step s <-> mid' = row(8s+j,h)
+    bf16x8 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)g.qm[acc_row(8 * s + j, h) * SA_C1 + r];
+    // term 3: B fragments of W2 with k = output channel in natural order 16 s + 8 h + j
+    bf16x8 w2tf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w2tf[s][j] = (__bf16)g.w2[(16 * s + 8 * h + j) * SA_C1 + r];
+    const float ev = g.evec[r];
+
+    bf16x8 w2f[2][2];
+    float d2v[2], e2v[2];
+    f32x16 gw2[2];
+    if (PASS == 1) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    w2f[t][s][j] = (__bf16)g.w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
+            d2v[t] = g.d2[32 * t + r];
+            e2v[t] = g.e2[32 * t + r];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gw2[t][i] = 0.0f;
+        }
+    }
+    float ca = 0.f, cb = 0.f, cc = 0.f;
+    if (PASS == 2) { ca = g.ca[r]; cb = g.cb[r]; cc = g.cc[r]; }
+    float st[2] = {0.0f, 0.0f};
+
+    const int tiles = a.b * a.m;
+    for (int tile = blockIdx.x * SA_WAVES + wave; tile < tiles; tile += gridDim.x * SA_WAVES) {
+        bf16x8 x[3];
+        gather_tile(a, tile, r, h, x);
+        // conv1 in both layouts (3 + 3 MFMAs on the same fragments)
+        f32x16 yT = {0}, y1 = {0};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            yT = mfma(w1f[s], x[s], yT);   // lane = position, register = mid channel
+            y1 = mfma(x[s], w1f[s], y1);   // lane = mid channel, register = position
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            yT[i] = __builtin_fmaxf(__builtin_fmaf(yT[i], sc1v[i], sh1v[i]), 0.0f);
+        const bf16x8 a0 = pack8(yT, 0), a1 = pack8(yT, 8);
+
+        // one-hot-weighted operand of the sparse part: lane (pos r, h), step s, element j
+        // <-> channel c = 16 s + 8 h + j
+        bf16x8 sp[4];
+        {
+            const float *go = g.goa + (size_t)tile * SA_C2 + 8 * h;
+            const unsigned char *ks = g.ksel + (size_t)tile * SA_C2 + 8 * h;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(go + 16 * s);
+                const float4 v1 = *reinterpret_cast<const float4 *>(go + 16 * s + 4);
+                const uint2 kb = *reinterpret_cast<const uint2 *>(ks + 16 * s);
+                const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned kk = ((j < 4 ? kb.x : kb.y) >> (8 * (j & 3))) & 0xffu;
+                    sp[s][j] = (__bf16)(kk == (unsigned)r ? vv[j] : 0.0f);
+                }
+            }
+        }
+        // dL/da1 [lane = mid, register = position]
+        f32x16 ga;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ga[i] = ev;
+        ga = mfma(a0, qf[0], ga);
+        ga = mfma(a1, qf[1], ga);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ga = mfma(sp[s], w2tf[s], ga);
+
+        float yhat[16];
+        f32x16 an;   // a1 in the [lane = mid] layout (pass 1: B operand of dL/dW2)
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float u = __builtin_fmaf(y1[i], sc1, sh1);
+            yhat[i] = (y1[i] - mu1) * iv1;
+            an[i] = __builtin_fmaxf(u, 0.0f);
+            ga[i] = u > 0.0f ? ga[i] : 0.0f;   // g_u
+            s1 += ga[i];
+            s2 += ga[i] * yhat[i];
+        }
+
+        if (PASS == 1) {
+            st[0] += s1;
+            st[1] += s2;
+            const bf16x8 b0 = pack8(an, 0), b1 = pack8(an, 8);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16 y2 = {0};
+                y2 = mfma(a0, w2f[t][0], y2);
+                y2 = mfma(a1, w2f[t][1], y2);
+                const int c = 32 * t + r;
+                const float gsel = g.goa[(size_t)tile * SA_C2 + c];
+                const int ksl = g.ksel[(size_t)tile * SA_C2 + c];
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    y2[i] = __builtin_fmaf(y2[i], d2v[t], e2v[t]) + (acc_row(i, h) == ksl ? gsel : 0.0f);
+                // dL/dW2[out][mid] += sum_pos dL/dy2[pos][out] * a1[pos][mid]
+                gw2[t] = mfma(pack8(y2, 0), b0, gw2[t]);
+                gw2[t] = mfma(pack8(y2, 8), b1, gw2[t]);
+            }
+        } else {
+            // dL/dy1 and its two scatters
+            float gy[16];
+            float hs = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                gy[i] = __builtin_fmaf(ga[i], ca, __builtin_fmaf(yhat[i], cb, cc));
+                hs += gy[i];
+            }
+            hs += __shfl_xor(hs, 32);
+            if (h == 0) H[(size_t)tile * SA_C1 + r] = hs;
+            // Rows produced by ball query end in a run of slots that repeat slot 0
+            // (ball_query_gpu.cu:41-45): fold that run into slot 0 before the atomics.
+            const int nb = a.idx[(size_t)tile * SA_K + r];
+            const int nb0 = __builtin_amdgcn_readfirstlane(nb);
+            const unsigned eq = (unsigned)__ballot(nb == nb0);          // lanes 0..31 = positions
+            const int tail = (~eq == 0u) ? 32 : __builtin_clz(~eq);      // leading ones of eq
+            int cnt = SA_K - tail;
+            if (cnt < 1) cnt = 1;
+            float extra = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) extra += acc_row(i, h) >= cnt ? gy[i] : 0.0f;
+            extra += __shfl_xor(extra, 32);
+            if (h == 0) gy[0] += extra;
+            const int cloud = tile / a.m;
+            float *Gc = G + (size_t)cloud * a.n * SA_C1 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (acc_row(i, 0) < cnt) {   // wave-uniform: is any lane's position live?
+                    const int n0 = __builtin_amdgcn_readlane(nb, acc_row(i, 0));
+                    const int n1 = __builtin_amdgcn_readlane(nb, acc_row(i, 1));
+                    const int nn = h ? n1 : n0;
+                    if (acc_row(i, h) < cnt) atomicAdd(Gc + (size_t)nn * SA_C1, gy[i]);
+                }
+            }
+        }
+    }
+    if (PASS == 1) {
+        write_partials<2>(st, partials + (size_t)blockIdx.x * 64, lane, wave);
+        // dL/dW2 partial of this workgroup: D[row = out row(i,h) + 32 t][col = mid r]
+        __shared__ float wred[SA_WAVES][SA_C2 * SA_C1];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                wred[wave][(32 * t + acc_row(i, h)) * SA_C1 + r] = gw2[t][i];
+        __syncthreads();
+        float *dst = gw2_partials + (size_t)blockIdx.x * SA_C2 * SA_C1;
+        for (int e = threadIdx.x; e < SA_C2 * SA_C1; e += SA_WAVES * 64) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < SA_WAVES; ++w) s += wred[w][e];
+            dst[e] = s;
+        }
+    }
+}
+
 static int sa_grid(int tiles) {
     // two workgroups of 4 waves per CU when there is enough work: 2 waves per SIMD
     int g = (tiles + SA_WAVES - 1) / SA_WAVES;
@@ -301,6 +517,52 @@ extern "C" int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_o
     hipLaunchKernelGGL(sa_fwd_main_kernel, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
                        (hipStream_t)stream, a, w2, scale1, shift1, sgn2, ysel,
                        (unsigned char *)ksel, partials);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+static apn::SaBwdArgs sa_bwd_args(const float *w2, const float *bn1 /* [4][32]: scale, shift, mean, inv */,
+                                  const float *qm, const float *evec, const float *d2e2 /* [2][64] */,
+                                  const float *goa, const void *ksel, const float *cabc /* [3][32] or null */) {
+    apn::SaBwdArgs g;
+    g.w2 = w2;
+    g.scale1 = bn1; g.shift1 = bn1 + 32; g.mean1 = bn1 + 64; g.inv1 = bn1 + 96;
+    g.qm = qm; g.evec = evec;
+    g.d2 = d2e2; g.e2 = d2e2 ? d2e2 + 64 : nullptr;
+    g.goa = goa; g.ksel = (const unsigned char *)ksel;
+    g.ca = cabc; g.cb = cabc ? cabc + 32 : nullptr; g.cc = cabc ? cabc + 64 : nullptr;
+    return g;
+}
+
+extern "C" int apn_sa_bwd_pass1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
+                                float radius, const float *xyz, const float *new_xyz, const void *ft,
+                                const int *idx, const float *w1, const float *w2, const float *bn1,
+                                const float *qm, const float *evec, const float *d2e2,
+                                const float *goa, const void *ksel, float *partials,
+                                float *gw2_partials, void *stream) {
+    using namespace apn;
+    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample)) return e;
+    SaArgs a{b, n, m, xyz, new_xyz, (const __bf16 *)ft, idx, w1, radius};
+    SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, d2e2, goa, ksel, nullptr);
+    hipLaunchKernelGGL(sa_bwd_kernel<1>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                       (hipStream_t)stream, a, g, partials, gw2_partials, (float *)nullptr,
+                       (float *)nullptr);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_bwd_pass2(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
+                                float radius, const float *xyz, const float *new_xyz, const void *ft,
+                                const int *idx, const float *w1, const float *w2, const float *bn1,
+                                const float *qm, const float *evec, const float *goa,
+                                const void *ksel, const float *cabc, float *G, float *H,
+                                void *stream) {
+    using namespace apn;
+    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample)) return e;
+    SaArgs a{b, n, m, xyz, new_xyz, (const __bf16 *)ft, idx, w1, radius};
+    SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, nullptr, goa, ksel, cabc);
+    hipLaunchKernelGGL(sa_bwd_kernel<2>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                       (hipStream_t)stream, a, g, (float *)nullptr, (float *)nullptr, G, H);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

@@ -107,3 +107,86 @@ class FusedForward:
         self.out = (ysel * scale2.float() + shift2.float()).transpose(1, 2).contiguous()  # (B,64,M)
         self.saved = dict(ft=ft, w1=w1, w2=w2, scale1=sc1f, shift1=sh1f, mean1=mean1, inv1=inv1,
                           mean2=mean2, inv2=inv2, scale2=scale2, ysel=ysel, ksel=ksel, count=count)
+
+
+class GroupedMlpMax(torch.autograd.Function):
+    """autograd wrapper: out (B,64,M) = max_K bn2(conv2(relu(bn1(conv1(cat[dp, f[idx]])))))."""
+
+    @staticmethod
+    def forward(ctx, p, new_p, f, idx, radius, w1, g1, b1, w2, g2, b2, conv1, bn1, conv2, bn2,
+                sync_bn):
+        fw = FusedForward(p.contiguous(), new_p.contiguous(), f.contiguous(), idx.contiguous(),
+                          radius, conv1, bn1, conv2, bn2, sync_bn)
+        ctx.fw = fw
+        ctx.tensors = (p, new_p, idx)
+        ctx.bn = (bn1, bn2)
+        ctx.sync_bn = sync_bn
+        ctx.need_xyz_grad = p.requires_grad or new_p.requires_grad
+        return fw.out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        fw, sv = ctx.fw, ctx.fw.saved
+        p, new_p, idx = ctx.tensors
+        bn1, bn2 = ctx.bn
+        B, N, M, C, C1, C2, K = fw.dims
+        dev = g_out.device
+        P = sv["count"]
+        go = g_out.transpose(1, 2).contiguous().float()                     # (B,M,64)
+        mean2, inv2, scale2 = sv["mean2"], sv["inv2"], sv["scale2"]
+        yhat_sel = (sv["ysel"].double() - mean2) * inv2
+        S = torch.stack([go.double().sum((0, 1)), (go.double() * yhat_sel).sum((0, 1))])
+        _allreduce_(S, ctx.sync_bn)
+        S1, S2 = S[0], S[1]
+        w1, w2 = sv["w1"], sv["w2"]
+        w2d = w2.double()
+        D2 = -scale2 * inv2 * S2 / P
+        E2 = -scale2 * S1 / P + scale2 * mean2 * inv2 * S2 / P
+        goa = (go * scale2.float()).contiguous()
+        qm = (w2d.t() @ (D2.unsqueeze(1) * w2d)).float().contiguous()      # (32,32)
+        evec = (E2 @ w2d).float().contiguous()
+        d2e2 = torch.stack([D2, E2]).float().contiguous()
+        bn1pack = torch.stack([sv["scale1"].double(), sv["shift1"].double(), sv["mean1"],
+                               sv["inv1"]]).float().contiguous()
+        lib = _lib.load()
+        rows = lib.apn_sa_grid_blocks(B, M)
+        hdr = (B, N, M, C, C1, C2, K, fw.radius, p.data_ptr(), new_p.data_ptr(),
+               sv["ft"].data_ptr(), idx.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+               bn1pack.data_ptr(), qm.data_ptr(), evec.data_ptr())
+        part = torch.empty(rows, 64, dtype=torch.float32, device=dev)
+        gw2p = torch.empty(rows, C2 * C1, dtype=torch.float32, device=dev)
+        _call("apn_sa_bwd_pass1", dev, *hdr, d2e2.data_ptr(), goa.data_ptr(),
+              sv["ksel"].data_ptr(), part.data_ptr(), gw2p.data_ptr())
+        T = _allreduce_(part.double().sum(0), ctx.sync_bn)
+        T1, T2 = T[:32], T[32:]
+        sc1 = sv["scale1"].double()
+        cabc = torch.stack([sc1, -sc1 * T2 / P, -sc1 * T1 / P]).float().contiguous()
+        G = torch.zeros(B, N, C1, dtype=torch.float32, device=dev)
+        H = torch.empty(B, M, C1, dtype=torch.float32, device=dev)
+        _call("apn_sa_bwd_pass2", dev, *hdr, goa.data_ptr(), sv["ksel"].data_ptr(),
+              cabc.data_ptr(), G.data_ptr(), H.data_ptr())
+        # everything downstream of dL/dy1 is linear: three small GEMMs
+        w1f, w1p = w1[:, 3:], w1[:, :3]
+        g_f = torch.matmul(G, w1f).transpose(1, 2).contiguous()             # (B,32,N)
+        g_w1f = torch.einsum('bnm,bni->mi', G, sv["ft"].float())
+        Gd, Hd = G.double(), H.double()
+        g_w1p = (torch.einsum('bnm,bnd->md', Gd, p.double())
+                 - torch.einsum('bqm,bqd->md', Hd, new_p.double())) / fw.radius
+        g_w1 = torch.cat([g_w1p.float(), g_w1f], 1).reshape(C1, C + 3, 1, 1)
+        g_w2 = gw2p.sum(0).reshape(C2, C1, 1, 1)
+        g_p = g_newp = None
+        if ctx.need_xyz_grad:
+            g_p = torch.matmul(G, w1p) / fw.radius
+            g_newp = -torch.matmul(H, w1p) / fw.radius
+        g_g1 = T2.float() if bn1.weight is not None else None
+        g_b1 = T1.float() if bn1.bias is not None else None
+        g_g2 = S2.float() if bn2.weight is not None else None
+        g_b2 = S1.float() if bn2.bias is not None else None
+        ctx.fw = None
+        return (g_p, g_newp, g_f, None, None, g_w1, g_g1, g_b1, g_w2, g_g2, g_b2,
+                None, None, None, None, None)
+
+
+def grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2, sync_bn=False):
+    return GroupedMlpMax.apply(p, new_p, f, idx, radius, conv1.weight, bn1.weight, bn1.bias,
+                               conv2.weight, bn2.weight, bn2.bias, conv1, bn1, conv2, bn2, sync_bn)

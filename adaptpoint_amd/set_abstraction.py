@@ -57,7 +57,8 @@ class SetAbstraction(nn.Module):
 
     def __init__(self, in_channels, out_channels, layers=1, stride=1,
                  group_args=None, norm_args=None, act_args=None, conv_args=None,
-                 sampler='fps', feature_type='dp_fj', use_res=False, is_head=False, **kwargs):
+                 sampler='fps', feature_type='dp_fj', use_res=False, is_head=False, fused=False,
+                 sync_bn=False, **kwargs):
         super().__init__()
         group_args = dict(group_args or {'NAME': 'ballquery', 'radius': 0.1, 'nsample': 16})
         norm_args = {'norm': 'bn1d'} if norm_args is None else norm_args
@@ -68,6 +69,10 @@ class SetAbstraction(nn.Module):
         self.all_aggr = not is_head and stride == 1
         self.use_res = use_res and not self.all_aggr and not self.is_head
         self.feature_type = feature_type
+        # fused=True routes group -> conv/BN/ReLU -> conv/BN -> max through csrc/sa_fused.hip
+        # when the shapes allow; sync_bn=True all-reduces its BatchNorm statistics.
+        self.fused = fused
+        self.sync_bn = sync_bn
 
         mid_channel = out_channels // 2 if stride > 1 else out_channels
         channels = [in_channels] + [mid_channel] * (layers - 1) + [out_channels]
@@ -96,6 +101,27 @@ class SetAbstraction(nn.Module):
                 raise NotImplementedError("only the FPS sampler is on the hot path")
             self.sample_fn = furthest_point_sample
 
+    def _fused_forward(self, new_p, p, f):
+        """max_K convs(cat[dp, f[idx]]) through the fused kernels, or None if unsupported."""
+        from . import fused
+        from .layers import QueryAndGroup, ball_query
+        g = self.grouper
+        if not (isinstance(g, QueryAndGroup) and g.relative_xyz and g.normalize_dp
+                and self.feature_type == 'dp_fj' and len(self.convs) == 2):
+            return None
+        blk1, blk2 = self.convs[0], self.convs[1]
+        if not (len(blk1) == 3 and isinstance(blk1[1], nn.BatchNorm2d) and isinstance(blk1[2], nn.ReLU)
+                and len(blk2) in (2, 3) and isinstance(blk2[1], nn.BatchNorm2d)):
+            return None
+        idx = ball_query(g.radius, g.nsample, p, new_p)
+        if not fused.supported(p, f, idx, blk1[0], blk2[0]):
+            return None
+        out = fused.grouped_mlp_max(p, new_p, f, idx, g.radius, blk1[0], blk1[1], blk2[0], blk2[1],
+                                    sync_bn=self.sync_bn)
+        if len(blk2) == 3:      # activation after the last BN commutes with the max
+            out = blk2[2](out)
+        return out
+
     @staticmethod
     def pool(x):
         return torch.max(x, dim=-1, keepdim=False)[0]
@@ -115,9 +141,13 @@ class SetAbstraction(nn.Module):
                 identity = self.skipconv(fi)
         else:
             fi = None
-        dp, fj = self.grouper(new_p, p, f)
-        fj = get_aggregation_feautres(new_p, dp, fi, fj, feature_type=self.feature_type)
-        f = self.pool(self.convs(fj))
+        fused_out = self._fused_forward(new_p, p, f) if self.fused else None
+        if fused_out is not None:
+            f = fused_out
+        else:
+            dp, fj = self.grouper(new_p, p, f)
+            fj = get_aggregation_feautres(new_p, dp, fi, fj, feature_type=self.feature_type)
+            f = self.pool(self.convs(fj))
         if self.use_res:
             f = self.act(f + identity)
         return new_p, f

@@ -140,6 +140,27 @@ APN_API int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out,
                             const float *scale1, const float *shift1, const float *sgn2,
                             float *ysel, void *ksel, float *partials, void *stream);
 
+/* Backward of the fused chain, two passes (see csrc/sa_fused.hip for the algebra).
+ *   bn1   [4][32]  = {scale1, shift1, mean1, invstd1}
+ *   qm    (32,32)  = W2^T diag(D2) W2 ; evec [32] = E2 W2 ; d2e2 [2][64] = {D2, E2}
+ *   goa   (B,M,64) = dL/dout * gamma2*invstd2 ; ksel (B,M,64) from the forward
+ * pass 1 -> partials[rows][64] = {sum g_u, sum g_u*yhat1}[32], gw2_partials[rows][64*32].
+ * pass 2 (cabc [3][32] = {ca, cb, cc}: dL/dy1 = g_u*ca + yhat1*cb + cc)
+ *        -> G (B,N,32) += per-source-point sums of dL/dy1 (caller-zeroed, float atomics),
+ *           H (B,M,32)  = per-query sums of dL/dy1. */
+APN_API int apn_sa_bwd_pass1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
+                             float radius, const float *xyz, const float *new_xyz, const void *ft,
+                             const int *idx, const float *w1, const float *w2, const float *bn1,
+                             const float *qm, const float *evec, const float *d2e2,
+                             const float *goa, const void *ksel, float *partials,
+                             float *gw2_partials, void *stream);
+APN_API int apn_sa_bwd_pass2(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
+                             float radius, const float *xyz, const float *new_xyz, const void *ft,
+                             const int *idx, const float *w1, const float *w2, const float *bn1,
+                             const float *qm, const float *evec, const float *goa,
+                             const void *ksel, const float *cabc, float *G, float *H,
+                             void *stream);
+
 /* Tuning / diagnostic hook, NOT part of the reference boundary: force the number
  * of wavefronts that cooperate on one cloud in apn_furthest_point_sampling
  * (1, 2, 4, 8 or 16; 0 restores the built-in heuristic).  Results do not depend

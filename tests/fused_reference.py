@@ -15,8 +15,7 @@ def group(t, idx):
     return torch.gather(t, 2, idx.long().reshape(B, 1, M * K).expand(-1, C, -1)).reshape(B, C, M, K)
 
 
-@torch.no_grad()
-def chain(p, new_p, f, idx, radius, w1, g1, b1, w2, g2, b2, eps=1e-5, emulate_bf16=False):
+def chain_grad(p, new_p, f, idx, radius, w1, g1, b1, w2, g2, b2, eps=1e-5, emulate_bf16=False):
     """Returns out (B,C2,M) and intermediates, in float64 (training-mode BatchNorm)."""
     rnd = _bf if emulate_bf16 else (lambda x: x.double())
     dp = (group(p.transpose(1, 2).contiguous(), idx) - new_p.transpose(1, 2).unsqueeze(-1)) / radius
@@ -32,3 +31,8 @@ def chain(p, new_p, f, idx, radius, w1, g1, b1, w2, g2, b2, eps=1e-5, emulate_bf
     v2 = y2.var((0, 2, 3), unbiased=False, keepdim=True)
     z = (y2 - m2) / torch.sqrt(v2 + eps) * g2.double().view(1, -1, 1, 1) + b2.double().view(1, -1, 1, 1)
     return z.max(-1)[0], dict(y1=y1, a1=a1, y2=y2, m1=m1, v1=v1, m2=m2, v2=v2)
+
+
+@torch.no_grad()
+def chain(*a, **k):
+    return chain_grad(*a, **k)

@@ -71,3 +71,74 @@ def test_fused_forward_updates_running_stats(dev):
                                (0.9 + 0.1 * mid["v1"].flatten() * n / (n - 1)).cpu().numpy(), rtol=2e-3)
     np.testing.assert_allclose(bn2.running_mean.cpu().numpy(), 0.1 * mid["m2"].flatten().cpu().numpy(), rtol=5e-3, atol=5e-4)
     assert int(bn1.num_batches_tracked) == 1 and int(bn2.num_batches_tracked) == 1
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12))
+
+
+def _rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("neg_gamma", [False, True])
+def test_fused_backward_matches_autograd(dev, neg_gamma):
+    """Gradients of the fused op vs torch autograd through the plain chain.
+    Tolerance: max |err| / max |ref| <= 2e-2 against the bf16-rounding reference (the fused
+    backward additionally rounds dL/dy2 and the one-hot operand to bf16 for its MFMAs).
+    Against the fp32 chain the comparison is in relative L2 norm, <= 0.25: rounding the inputs
+    to bf16 flips the arg-max of the K-pool wherever two neighbours are within 2^-8, which moves
+    whole gradient entries from one point to another (an element-wise max norm is meaningless
+    there); the aggregated parameter gradients stay within 0.15."""
+    from adaptpoint_amd.fused import grouped_mlp_max
+    from fused_reference import chain_grad
+    p, new_p, f, idx, conv1, bn1, conv2, bn2 = _setup(dev, neg_gamma=neg_gamma, seed=5)
+    wts = torch.randn(4, 64, 512, device=dev, generator=torch.Generator(dev).manual_seed(9))
+    p.requires_grad_(True); new_p.requires_grad_(True); f.requires_grad_(True)
+    out = grouped_mlp_max(p, new_p, f, idx, 0.15, conv1, bn1, conv2, bn2)
+    (out * wts).sum().backward()
+    torch.cuda.synchronize()
+    got = dict(f=f.grad.clone(), p=p.grad.clone(), newp=new_p.grad.clone(),
+               w1=conv1.weight.grad.view(32, 35).clone(), w2=conv2.weight.grad.view(64, 32).clone(),
+               g1=bn1.weight.grad.clone(), b1=bn1.bias.grad.clone(),
+               g2=bn2.weight.grad.clone(), b2=bn2.bias.grad.clone())
+    for emu, tol in ((True, 2e-2), (False, None)):
+        leaves = [t.detach().clone().requires_grad_(True) for t in
+                  (p, new_p, f, conv1.weight.view(32, 35), bn1.weight, bn1.bias,
+                   conv2.weight.view(64, 32), bn2.weight, bn2.bias)]
+        rp, rq, rf, rw1, rg1, rb1, rw2, rg2, rb2 = leaves
+        ref, _ = chain_grad(rp, rq, rf, idx, 0.15, rw1, rg1, rb1, rw2, rg2, rb2, emulate_bf16=emu)
+        (ref * wts.double()).sum().backward()
+        want = dict(f=rf.grad, p=rp.grad, newp=rq.grad, w1=rw1.grad, w2=rw2.grad,
+                    g1=rg1.grad, b1=rb1.grad, g2=rg2.grad, b2=rb2.grad)
+        errs = {k: (_rel if emu else _rel_l2)(got[k], want[k]) for k in got}
+        print(("bf16-emu max-norm" if emu else "fp32 rel-L2      "), {k: "%.2e" % v for k, v in errs.items()})
+        for k, v in errs.items():
+            assert v <= (tol if emu else (0.25 if k in ("f", "p", "newp") else 0.15)), (k, v, emu)
+
+
+def test_set_abstraction_fused_equals_unfused(dev):
+    """The block with fused=True against the same block over the nine unfused operators
+    (the drop-in path): same weights, same input."""
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    kw = dict(layers=2, stride=2, group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32,
+                                              'normalize_dp': True},
+              norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+              use_res=True)
+    torch.manual_seed(1)
+    a = SetAbstraction(32, 64, **kw).to(dev)
+    b = SetAbstraction(32, 64, fused=True, **kw).to(dev)
+    b.load_state_dict(a.state_dict())
+    p = torch.from_numpy(GI.unit_sphere_cloud(8, 1024, seed=2)).to(dev)
+    f1 = torch.from_numpy(GI.seeded_normal((8, 32, 1024), seed=3)).to(dev).requires_grad_(True)
+    f2 = f1.detach().clone().requires_grad_(True)
+    pa, oa = a([p, f1])
+    pb, ob = b([p, f2])
+    assert torch.equal(pa, pb)
+    oa.sum().backward(); ob.sum().backward()
+    assert (oa - ob).abs().max() <= 1.5e-1 and (oa - ob).abs().mean() <= 1e-2
+    assert _rel_l2(f2.grad, f1.grad) <= 0.25
+    for (k, qa), (_, qb) in zip(a.named_parameters(), b.named_parameters()):
+        assert _rel_l2(qb.grad, qa.grad) <= 0.15, k
+    for (k, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.allclose(ba.float(), bb.float(), rtol=2e-2, atol=2e-3), k
