@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadaptpoint_amd.so")
 
 _c_int, _c_float, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+_c_double = ctypes.c_double
 
 # name -> argtypes, exactly the prototypes of include/adaptpoint_amd.h
 SIGNATURES = {
@@ -30,6 +31,20 @@ SIGNATURES = {
     "apn_sa_fwd_main": [_c_int] * 7 + [_c_float] + [_c_void_p] * 13,
     "apn_sa_bwd_pass1": [_c_int] * 7 + [_c_float] + [_c_void_p] * 15,
     "apn_sa_bwd_pass2": [_c_int] * 7 + [_c_float] + [_c_void_p] * 15,
+    "apn_sa_reduce_rows": [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
+    "apn_sa_bn_fold": [_c_void_p, _c_int, _c_double, _c_void_p, _c_void_p, _c_float, _c_float,
+                       _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p],
+    "apn_sa_sign": [_c_void_p, _c_int, _c_void_p, _c_void_p],
+    "apn_sa_fwd_out": [_c_int, _c_int] + [_c_void_p] * 4,
+    "apn_sa_bwd_prep_rows": [_c_int, _c_int],
+    "apn_sa_bwd_prep": [_c_int, _c_int] + [_c_void_p] * 6,
+    "apn_sa_bwd_consts2": [_c_void_p] * 3 + [_c_double, _c_int] + [_c_void_p] * 6,
+    "apn_sa_bwd_consts1": [_c_void_p] * 2 + [_c_double, _c_int] + [_c_void_p] * 4,
+    "apn_sa_bwd_input_grad": [_c_int] * 3 + [_c_void_p] * 3 + [_c_float] + [_c_void_p] * 4,
+    "apn_sa_bwd_weight_rows": [_c_int, _c_int],
+    "apn_sa_bwd_weight_grad": [_c_int] * 3 + [_c_void_p] * 7,
+    "apn_sa_bwd_w1_final": [_c_void_p, _c_float, _c_void_p, _c_void_p],
+    "apn_sa_cast_d2f": [_c_void_p, _c_int, _c_void_p, _c_void_p],
 }
 
 _lib = None

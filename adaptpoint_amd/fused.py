@@ -1,4 +1,4 @@
-"""Fused grouped shared-MLP of a set-abstraction block (csrc/sa_fused.hip).
+"""Fused grouped shared-MLP of a set-abstraction block (csrc/sa_fused.hip, sa_glue.hip).
 
 `grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2)` computes, for the
 shapes the fused kernels support,
@@ -7,9 +7,13 @@ shapes the fused kernels support,
     y1  = conv1(cat[dp, fj]) ; a1 = relu(bn1(y1))                 pointnext.py:119-128,166
     y2  = conv2(a1) ; out = max_K bn2(y2)                         pointnext.py:166
 
-without materialising any (B, C, M, K) tensor.  BatchNorm runs in training mode
-(batch statistics, running buffers updated) exactly when the modules are in
-training mode; the MFMA contraction is bf16 x bf16 -> f32.
+without materialising any (B, C, M, K) tensor, forward and backward.  BatchNorm follows
+the modules' training flag (batch statistics + running-buffer update, or the running
+buffers); the MFMA contractions are bf16 x bf16 -> f32, every statistic is f32 partials
+summed in f64.  The whole op is a fixed sequence of kernel launches on the current
+stream -- no host reads -- so it can be captured in a HIP graph.  With sync_bn=True the
+per-channel sums are all-reduced across ranks (SyncBatchNorm semantics) at the three
+points where statistics leave the kernels.
 """
 import torch
 import torch.distributed as dist
@@ -19,7 +23,7 @@ from . import _lib
 
 def supported(p, f, idx, conv1, conv2):
     return (f.is_cuda and f.dtype == torch.float32 and f.shape[1] == 32 and idx.shape[2] == 32
-            and conv1.weight.shape[:2] == (32, 35) and conv2.weight.shape[:2] == (64, 32)
+            and tuple(conv1.weight.shape[:2]) == (32, 35) and tuple(conv2.weight.shape[:2]) == (64, 32)
             and conv1.bias is None and conv2.bias is None)
 
 
@@ -30,36 +34,40 @@ def _call(name, dev, *args):
     _lib.check(code, name)
 
 
-def _allreduce_(t, sync):
-    if sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t)
-    return t
+def _ptr(t):
+    return None if t is None else t.data_ptr()
 
 
-def _bn_fold(sum_, sumsq, count, bn, training):
-    """Per-channel (scale, shift, mean, invstd) of a BatchNorm given batch sums."""
-    if training or not bn.track_running_stats:
-        mean = sum_ / count
-        var = (sumsq / count - mean * mean).clamp_min_(0.0)
-        if training and bn.track_running_stats:
-            with torch.no_grad():
-                mom = bn.momentum if bn.momentum is not None else 0.1
-                unbiased = var * (count / max(count - 1.0, 1.0))
-                bn.running_mean.mul_(1 - mom).add_(mean.float(), alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(unbiased.float(), alpha=mom)
-                bn.num_batches_tracked += 1
-    else:
-        mean, var = bn.running_mean.double(), bn.running_var.double()
-    invstd = torch.rsqrt(var + bn.eps)
-    gamma = bn.weight.double() if bn.weight is not None else torch.ones_like(mean)
-    beta = bn.bias.double() if bn.bias is not None else torch.zeros_like(mean)
-    scale = gamma * invstd
-    shift = beta - mean * scale
-    return scale, shift, mean, invstd
+def _world(sync):
+    if sync and dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
+def _reduce(part, ncol, dev, sync):
+    """float partial rows -> float64 column sums (all-reduced over ranks when sync)."""
+    out = torch.empty(ncol, dtype=torch.float64, device=dev)
+    _call("apn_sa_reduce_rows", dev, part.data_ptr(), part.shape[0], ncol, out.data_ptr())
+    if _world(sync) > 1:
+        dist.all_reduce(out)
+    return out
+
+
+def _fold(sums, c, count, bn, dev):
+    pack = torch.empty(4, c, dtype=torch.float32, device=dev)
+    training = bn.training or not bn.track_running_stats
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    track = bn.track_running_stats
+    _call("apn_sa_bn_fold", dev, _ptr(sums), c, float(count), _ptr(bn.weight), _ptr(bn.bias),
+          float(bn.eps), float(mom), _ptr(bn.running_mean) if track else None,
+          _ptr(bn.running_var) if track else None,
+          _ptr(bn.num_batches_tracked) if (track and bn.training) else None,
+          1 if training else 0, pack.data_ptr())
+    return pack, training
 
 
 class FusedForward:
-    """Forward of the fused chain; returns what the backward needs as well."""
+    """Forward of the fused chain; keeps what the backward needs."""
 
     def __init__(self, p, new_p, f, idx, radius, conv1, bn1, conv2, bn2, sync_bn=False):
         dev = f.device
@@ -68,45 +76,42 @@ class FusedForward:
         K = idx.shape[2]
         self.dims = (B, N, M, C, 32, 64, K)
         self.radius = float(radius)
+        self.sync = sync_bn
         lib = _lib.load()
         rows = lib.apn_sa_grid_blocks(B, M)
-        w1 = conv1.weight.detach().reshape(32, 35).contiguous()
-        w2 = conv2.weight.detach().reshape(64, 32).contiguous()
+        w1 = conv1.weight.detach().reshape(32, 35)
+        w2 = conv2.weight.detach().reshape(64, 32)
+        w1 = w1 if w1.is_contiguous() else w1.contiguous()
+        w2 = w2 if w2.is_contiguous() else w2.contiguous()
         ft = torch.empty(B, N, C, dtype=torch.bfloat16, device=dev)
         _call("apn_sa_prep_features", dev, B, C, N, f.data_ptr(), ft.data_ptr())
         hdr = (B, N, M, C, 32, 64, K, self.radius, p.data_ptr(), new_p.data_ptr(), ft.data_ptr(),
                idx.data_ptr(), w1.data_ptr())
-        training1 = bn1.training
-        count = float(B * M * K)
-        if training1:
+        count = float(B * M * K) * _world(sync_bn)
+        sums1 = None
+        if bn1.training or not bn1.track_running_stats:
             part1 = torch.empty(rows, 64, dtype=torch.float32, device=dev)
             _call("apn_sa_fwd_stats1", dev, *hdr, part1.data_ptr())
-            s = _allreduce_(part1.double().sum(0), sync_bn)
-            if sync_bn and dist.is_initialized():
-                count *= dist.get_world_size()
-            sum1, sq1 = s[:32], s[32:]
-        else:
-            sum1 = sq1 = None
-        scale1, shift1, mean1, inv1 = _bn_fold(sum1, sq1, count, bn1, training1)
-        gamma2 = bn2.weight.detach() if bn2.weight is not None else torch.ones(64, device=dev)
-        sgn2 = torch.where(gamma2 >= 0, 1.0, -1.0).float().contiguous()
+            sums1 = _reduce(part1, 64, dev, sync_bn)
+        pack1, self.train1 = _fold(sums1, 32, count, bn1, dev)
+        sgn2 = torch.empty(64, dtype=torch.float32, device=dev)
+        _call("apn_sa_sign", dev, _ptr(bn2.weight), 64, sgn2.data_ptr())
         ysel = torch.empty(B, M, 64, dtype=torch.float32, device=dev)
         ksel = torch.empty(B, M, 64, dtype=torch.uint8, device=dev)
         part2 = torch.empty(rows, 128, dtype=torch.float32, device=dev)
-        sc1f, sh1f = scale1.float().contiguous(), shift1.float().contiguous()
-        _call("apn_sa_fwd_main", dev, *hdr, w2.data_ptr(), sc1f.data_ptr(), sh1f.data_ptr(),
-              sgn2.data_ptr(), ysel.data_ptr(), ksel.data_ptr(), part2.data_ptr())
-        training2 = bn2.training
-        if training2:
-            s = _allreduce_(part2.double().sum(0), sync_bn)
-            sum2, sq2 = s[:64], s[64:]
-        else:
-            sum2 = sq2 = None
-        scale2, shift2, mean2, inv2 = _bn_fold(sum2, sq2, count, bn2, training2)
+        _call("apn_sa_fwd_main", dev, *hdr, w2.data_ptr(), pack1.data_ptr(),
+              pack1.data_ptr() + 4 * 32, sgn2.data_ptr(), ysel.data_ptr(), ksel.data_ptr(),
+              part2.data_ptr())
+        sums2 = None
+        if bn2.training or not bn2.track_running_stats:
+            sums2 = _reduce(part2, 128, dev, sync_bn)
+        pack2, self.train2 = _fold(sums2, 64, count, bn2, dev)
         # max_K bn2(y2) = scale2 * ext_K(y2) + shift2  (ext = max where gamma2 >= 0, else min)
-        self.out = (ysel * scale2.float() + shift2.float()).transpose(1, 2).contiguous()  # (B,64,M)
-        self.saved = dict(ft=ft, w1=w1, w2=w2, scale1=sc1f, shift1=sh1f, mean1=mean1, inv1=inv1,
-                          mean2=mean2, inv2=inv2, scale2=scale2, ysel=ysel, ksel=ksel, count=count)
+        out = torch.empty(B, 64, M, dtype=torch.float32, device=dev)
+        _call("apn_sa_fwd_out", dev, B, M, ysel.data_ptr(), pack2.data_ptr(), out.data_ptr())
+        self.out = out
+        self.saved = dict(ft=ft, w1=w1, w2=w2, pack1=pack1, pack2=pack2, ysel=ysel, ksel=ksel,
+                          count=count)
 
 
 class GroupedMlpMax(torch.autograd.Function):
@@ -118,73 +123,81 @@ class GroupedMlpMax(torch.autograd.Function):
         fw = FusedForward(p.contiguous(), new_p.contiguous(), f.contiguous(), idx.contiguous(),
                           radius, conv1, bn1, conv2, bn2, sync_bn)
         ctx.fw = fw
-        ctx.tensors = (p, new_p, idx)
-        ctx.bn = (bn1, bn2)
-        ctx.sync_bn = sync_bn
-        ctx.need_xyz_grad = p.requires_grad or new_p.requires_grad
+        ctx.tensors = (p.contiguous(), new_p.contiguous(), idx.contiguous())
+        ctx.has_affine = (g1 is not None, b1 is not None, g2 is not None, b2 is not None)
+        ctx.need_xyz_grad = (p.requires_grad, new_p.requires_grad)
         return fw.out
 
     @staticmethod
     def backward(ctx, g_out):
         fw, sv = ctx.fw, ctx.fw.saved
         p, new_p, idx = ctx.tensors
-        bn1, bn2 = ctx.bn
         B, N, M, C, C1, C2, K = fw.dims
         dev = g_out.device
-        P = sv["count"]
-        go = g_out.transpose(1, 2).contiguous().float()                     # (B,M,64)
-        mean2, inv2, scale2 = sv["mean2"], sv["inv2"], sv["scale2"]
-        yhat_sel = (sv["ysel"].double() - mean2) * inv2
-        S = torch.stack([go.double().sum((0, 1)), (go.double() * yhat_sel).sum((0, 1))])
-        _allreduce_(S, ctx.sync_bn)
-        S1, S2 = S[0], S[1]
-        w1, w2 = sv["w1"], sv["w2"]
-        w2d = w2.double()
-        D2 = -scale2 * inv2 * S2 / P
-        E2 = -scale2 * S1 / P + scale2 * mean2 * inv2 * S2 / P
-        goa = (go * scale2.float()).contiguous()
-        qm = (w2d.t() @ (D2.unsqueeze(1) * w2d)).float().contiguous()      # (32,32)
-        evec = (E2 @ w2d).float().contiguous()
-        d2e2 = torch.stack([D2, E2]).float().contiguous()
-        bn1pack = torch.stack([sv["scale1"].double(), sv["shift1"].double(), sv["mean1"],
-                               sv["inv1"]]).float().contiguous()
+        P, sync = sv["count"], fw.sync
         lib = _lib.load()
+        f32 = dict(dtype=torch.float32, device=dev)
+        g_out = g_out.contiguous()
+        w1, w2, pack1, pack2 = sv["w1"], sv["w2"], sv["pack1"], sv["pack2"]
+
+        # BN2 reduction terms from (B,M,64) tensors only
+        goa = torch.empty(B, M, C2, **f32)
+        prow = lib.apn_sa_bwd_prep_rows(B, M)
+        partS = torch.empty(prow, 128, **f32)
+        _call("apn_sa_bwd_prep", dev, B, M, g_out.data_ptr(), sv["ysel"].data_ptr(),
+              pack2.data_ptr(), goa.data_ptr(), partS.data_ptr())
+        S = _reduce(partS, 128, dev, sync)
+        d2e2 = torch.empty(2, C2, **f32)
+        qm = torch.empty(C1, C1, **f32)
+        evec = torch.empty(C1, **f32)
+        g_g2 = torch.empty(C2, **f32)
+        g_b2 = torch.empty(C2, **f32)
+        _call("apn_sa_bwd_consts2", dev, S.data_ptr(), pack2.data_ptr(), w2.data_ptr(), float(P),
+              1 if fw.train2 else 0, d2e2.data_ptr(), qm.data_ptr(), evec.data_ptr(),
+              g_g2.data_ptr(), g_b2.data_ptr())
+
         rows = lib.apn_sa_grid_blocks(B, M)
         hdr = (B, N, M, C, C1, C2, K, fw.radius, p.data_ptr(), new_p.data_ptr(),
                sv["ft"].data_ptr(), idx.data_ptr(), w1.data_ptr(), w2.data_ptr(),
-               bn1pack.data_ptr(), qm.data_ptr(), evec.data_ptr())
-        part = torch.empty(rows, 64, dtype=torch.float32, device=dev)
-        gw2p = torch.empty(rows, C2 * C1, dtype=torch.float32, device=dev)
+               pack1.data_ptr(), qm.data_ptr(), evec.data_ptr())
+        part = torch.empty(rows, 64, **f32)
+        gw2p = torch.empty(rows, C2 * C1, **f32)
         _call("apn_sa_bwd_pass1", dev, *hdr, d2e2.data_ptr(), goa.data_ptr(),
               sv["ksel"].data_ptr(), part.data_ptr(), gw2p.data_ptr())
-        T = _allreduce_(part.double().sum(0), ctx.sync_bn)
-        T1, T2 = T[:32], T[32:]
-        sc1 = sv["scale1"].double()
-        cabc = torch.stack([sc1, -sc1 * T2 / P, -sc1 * T1 / P]).float().contiguous()
-        G = torch.zeros(B, N, C1, dtype=torch.float32, device=dev)
-        H = torch.empty(B, M, C1, dtype=torch.float32, device=dev)
+        T = _reduce(part, 64, dev, sync)
+        gw2d = _reduce(gw2p, C2 * C1, dev, False)      # weight grads are reduced by DDP, not here
+        g_w2 = torch.empty(C2, C1, 1, 1, **f32)
+        _call("apn_sa_cast_d2f", dev, gw2d.data_ptr(), C2 * C1, g_w2.data_ptr())
+        cabc = torch.empty(3, C1, **f32)
+        g_g1 = torch.empty(C1, **f32)
+        g_b1 = torch.empty(C1, **f32)
+        _call("apn_sa_bwd_consts1", dev, T.data_ptr(), pack1.data_ptr(), float(P),
+              1 if fw.train1 else 0, cabc.data_ptr(), g_g1.data_ptr(), g_b1.data_ptr())
+
+        G = torch.zeros(B, N, C1, **f32)
+        H = torch.empty(B, M, C1, **f32)
         _call("apn_sa_bwd_pass2", dev, *hdr, goa.data_ptr(), sv["ksel"].data_ptr(),
               cabc.data_ptr(), G.data_ptr(), H.data_ptr())
-        # everything downstream of dL/dy1 is linear: three small GEMMs
-        w1f, w1p = w1[:, 3:], w1[:, :3]
-        g_f = torch.matmul(G, w1f).transpose(1, 2).contiguous()             # (B,32,N)
-        g_w1f = torch.einsum('bnm,bni->mi', G, sv["ft"].float())
-        Gd, Hd = G.double(), H.double()
-        g_w1p = (torch.einsum('bnm,bnd->md', Gd, p.double())
-                 - torch.einsum('bqm,bqd->md', Hd, new_p.double())) / fw.radius
-        g_w1 = torch.cat([g_w1p.float(), g_w1f], 1).reshape(C1, C + 3, 1, 1)
-        g_w2 = gw2p.sum(0).reshape(C2, C1, 1, 1)
-        g_p = g_newp = None
-        if ctx.need_xyz_grad:
-            g_p = torch.matmul(G, w1p) / fw.radius
-            g_newp = -torch.matmul(H, w1p) / fw.radius
-        g_g1 = T2.float() if bn1.weight is not None else None
-        g_b1 = T1.float() if bn1.bias is not None else None
-        g_g2 = S2.float() if bn2.weight is not None else None
-        g_b2 = S1.float() if bn2.bias is not None else None
+
+        # everything downstream of dL/dy1 is linear in G (per source point) and H (per query)
+        g_f = torch.empty(B, C, N, **f32)
+        need_p, need_q = ctx.need_xyz_grad
+        g_p = torch.zeros(B, N, 3, **f32) if need_p else None
+        g_newp = torch.empty(B, M, 3, **f32) if need_q else None
+        _call("apn_sa_bwd_input_grad", dev, B, N, M, G.data_ptr(), H.data_ptr(), w1.data_ptr(),
+              fw.radius, g_f.data_ptr(), _ptr(g_p), _ptr(g_newp))
+        wrows = lib.apn_sa_bwd_weight_rows(B, N)
+        partW = torch.empty(wrows, 32 * 38, **f32)
+        _call("apn_sa_bwd_weight_grad", dev, B, N, M, G.data_ptr(), H.data_ptr(),
+              sv["ft"].data_ptr(), p.data_ptr(), new_p.data_ptr(), partW.data_ptr())
+        sW = _reduce(partW, 32 * 38, dev, False)
+        g_w1 = torch.empty(C1, C + 3, 1, 1, **f32)
+        _call("apn_sa_bwd_w1_final", dev, sW.data_ptr(), fw.radius, g_w1.data_ptr())
+
+        a1, a2, a3, a4 = ctx.has_affine
         ctx.fw = None
-        return (g_p, g_newp, g_f, None, None, g_w1, g_g1, g_b1, g_w2, g_g2, g_b2,
-                None, None, None, None, None)
+        return (g_p, g_newp, g_f, None, None, g_w1, g_g1 if a1 else None, g_b1 if a2 else None,
+                g_w2, g_g2 if a3 else None, g_b2 if a4 else None, None, None, None, None, None)
 
 
 def grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2, sync_bn=False):

@@ -38,9 +38,9 @@ B_PER_GPU, N_PTS, NPOINT, NSAMPLE, C_IN, C_OUT, RADIUS = 32, 1024, 512, 32, 32, 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def make_block():
+def make_block(fused=False, sync_bn=False):
     from adaptpoint_amd.set_abstraction import SetAbstraction
-    return SetAbstraction(C_IN, C_OUT, layers=2, stride=2,
+    return SetAbstraction(C_IN, C_OUT, layers=2, stride=2, fused=fused, sync_bn=sync_bn,
                           group_args={'NAME': 'ballquery', 'radius': RADIUS, 'nsample': NSAMPLE,
                                       'normalize_dp': True},
                           norm_args={'norm': 'bn'}, act_args={'act': 'relu'},
@@ -115,9 +115,20 @@ def instrument(timer, only=None):
     patch("group_points_wrapper", key_group)
     patch("group_points_grad_wrapper", lambda b, c, *a: "group_xyz_grad" if c == 3 else "group_feat_grad")
 
+    from adaptpoint_amd import fused
+    orig_call = fused._call
+
+    def fused_call(name, dev, *a):
+        short = name.replace("apn_", "")
+        if only is not None and short not in only:
+            return orig_call(name, dev, *a)
+        return timer.wrap(short, orig_call)(name, dev, *a)
+    fused._call = fused_call
+
     def restore():
         for k, v in saved.items():
             setattr(ops, k, v)
+        fused._call = orig_call
     return restore
 
 
@@ -159,6 +170,11 @@ def main():
     ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="auto",
                     help="SyncBatchNorm at world_size>1 (auto = on, as the reference)")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step from a captured HIP graph (auto: on at 1 GPU)")
+    ap.add_argument("--mlp", choices=["fused-bf16", "torch-f32"], default="fused-bf16",
+                    help="grouped shared-MLP: fused bf16-MFMA kernels (csrc/sa_fused.hip) or the "
+                         "unfused drop-in path (nine extension ops + PyTorch conv/BN in fp32)")
     args = ap.parse_args()
 
     from adaptpoint_amd import dp
@@ -178,10 +194,11 @@ def main():
     dp.init(args.backend, dev)
 
     torch.manual_seed(0)                          # identical initial weights on every rank
-    blk = make_block().to(dev)
-    blk.train()
     sync_bn = distributed and args.sync_bn != "off"
-    if sync_bn:
+    fused_mlp = args.mlp == "fused-bf16"
+    blk = make_block(fused=fused_mlp, sync_bn=sync_bn).to(dev)
+    blk.train()
+    if sync_bn and not fused_mlp:
         blk = torch.nn.SyncBatchNorm.convert_sync_batchnorm(blk)
     model = blk
     if distributed:
@@ -200,18 +217,48 @@ def main():
         out.sum().backward()
         return out
 
+    use_graph = (args.graph == "on") or (args.graph == "auto" and not distributed)
+    eager_step = step
+    if use_graph:
+        # Whole-step capture: every launch of the step (extension kernels through ctypes on the
+        # capture stream, PyTorch ops, autograd) becomes one hipGraph; replay has no host work.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        f.grad = None
+        for q in params:
+            q.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            new_p_, out_ = model([p, f])
+            out_.sum().backward()
+        step = graph.replay
+
     timer = KernelTimer()
-    restore = instrument(timer, only={"fps"})     # events around the dominant kernel only
+    restore = instrument(timer, only={"fps"} if not use_graph else set())
     # W warm-up steps, barrier + synchronize, K timed steps, barrier + synchronize, MAX over ranks
     elapsed = dp.timed_steps(step, args.steps, args.warmup, dev)
     restore()
-    fps_us = timer.mean_us()["fps"]               # includes the warm-up launches (same kernel)
+    if use_graph:
+        # launches inside a graph cannot carry per-kernel events: time the same launch, same
+        # inputs, eagerly on the same stream right after the timed region
+        t2 = KernelTimer()
+        r2 = instrument(t2, only={"fps"})
+        for _ in range(20):
+            eager_step()
+        r2()
+        fps_us = t2.mean_us()["fps"]
+    else:
+        fps_us = timer.mean_us()["fps"]           # includes the warm-up launches (same kernel)
 
     # per-kernel view (un-timed extra pass): events around every extension launch
     timer_all = KernelTimer()
     restore = instrument(timer_all)
     for _ in range(min(args.steps, 20)):
-        step()
+        eager_step()
     per_kernel_us = timer_all.mean_us()
     restore()
 
@@ -245,10 +292,14 @@ def main():
         "value": round(value, 2), "unit": "point-clouds/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if fused_mlp else "f32", "data": "synthetic",
         "config": {"workload": "PointNeXt-S stage-1 SetAbstraction fwd+bwd, B=32/GPU N=1024 "
                                "npoint=512 nsample=32 r=0.15 C 32->64 (BASELINE configs[1]); "
                                "clouds: uniform cube centred+scaled to the unit sphere (D1)",
+                   "mlp": ("fused bf16 MFMA (f32 accumulate, f32 BatchNorm statistics)" if fused_mlp
+                           else "unfused: extension ops + PyTorch fp32 conv/BN"),
+                   "launch": "hipGraph replay" if use_graph else "eager",
                    "global_batch": B_PER_GPU * world,
                    "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else "")},
         "roofline": roofline,

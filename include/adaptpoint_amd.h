@@ -161,6 +161,38 @@ APN_API int apn_sa_bwd_pass2(int b, int n, int m, int c_in, int c_mid, int c_out
                              const void *ksel, const float *cabc, float *G, float *H,
                              void *stream);
 
+/* Small kernels between the fused passes (csrc/sa_glue.hip); all graph-capturable.
+ * "pack" = {scale, shift, mean, invstd}[C] of a BatchNorm folded to y*scale+shift. */
+APN_API int apn_sa_reduce_rows(const float *part, int rows, int ncol, double *out, void *stream);
+APN_API int apn_sa_bn_fold(const double *sums, int c, double count, const float *gamma,
+                           const float *beta, float eps, float momentum, float *running_mean,
+                           float *running_var, void *num_batches_tracked, int training,
+                           float *pack, void *stream);
+APN_API int apn_sa_sign(const float *gamma, int c, float *sgn, void *stream);
+/* out (B,64,M) = ysel (B,M,64) * scale2 + shift2 */
+APN_API int apn_sa_fwd_out(int b, int m, const float *ysel, const float *pack2, float *out,
+                           void *stream);
+/* goa (B,M,64) = g_out (B,64,M) * scale2; part[apn_sa_bwd_prep_rows][128] = partial {S1, S2} */
+APN_API int apn_sa_bwd_prep_rows(int b, int m);
+APN_API int apn_sa_bwd_prep(int b, int m, const float *g_out, const float *ysel,
+                            const float *pack2, float *goa, float *part, void *stream);
+APN_API int apn_sa_bwd_consts2(const double *S, const float *pack2, const float *w2, double count,
+                               int training, float *d2e2, float *qm, float *evec,
+                               float *g_gamma2, float *g_beta2, void *stream);
+APN_API int apn_sa_bwd_consts1(const double *T, const float *pack1, double count, int training,
+                               float *cabc, float *g_gamma1, float *g_beta1, void *stream);
+/* g_f (B,32,N) = G W1[:,3:]; optional g_p (B,N,3) += G W1[:,:3]/r, g_newp (B,M,3) = -H W1[:,:3]/r */
+APN_API int apn_sa_bwd_input_grad(int b, int n, int m, const float *G, const float *H,
+                                  const float *w1, float radius, float *g_f, float *g_p,
+                                  float *g_newp, void *stream);
+/* part[apn_sa_bwd_weight_rows][32*38]: per-block sums for dL/dW1 (see sa_glue.hip) */
+APN_API int apn_sa_bwd_weight_rows(int b, int n);
+APN_API int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const float *H,
+                                   const void *ft, const float *xyz, const float *new_xyz,
+                                   float *part, void *stream);
+APN_API int apn_sa_bwd_w1_final(const double *sums, float radius, float *g_w1, void *stream);
+APN_API int apn_sa_cast_d2f(const double *src, int nelem, float *dst, void *stream);
+
 /* Tuning / diagnostic hook, NOT part of the reference boundary: force the number
  * of wavefronts that cooperate on one cloud in apn_furthest_point_sampling
  * (1, 2, 4, 8 or 16; 0 restores the built-in heuristic).  Results do not depend

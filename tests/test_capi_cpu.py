@@ -52,6 +52,8 @@ def test_ctypes_signatures_match_header_arity():
                 assert at is ctypes.c_void_p, (name, decl)
             elif decl.startswith("float"):
                 assert at is ctypes.c_float, (name, decl)
+            elif decl.startswith("double"):
+                assert at is ctypes.c_double, (name, decl)
             else:
                 assert at is ctypes.c_int, (name, decl)
 
