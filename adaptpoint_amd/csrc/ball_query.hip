@@ -28,7 +28,7 @@ constexpr int BQ_CHUNK = 4096;             // support points staged per LDS pass
 // Grid: (ceil(M / queries_per_block), B).  Each wave owns queries
 // q0 + wave, q0 + wave + BQ_WAVES, ... of its block's tile.
 __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
-    int n, int m, float radius2, int nsample, int q_per_block,
+    int n, int m, float radius2, int nsample, int q_per_block, int zero_empty,
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, int *__restrict__ idx) {
     // Dynamic LDS: three coordinate planes of `chunk` floats, then per query of
     // the tile its hit count so far and its first hit.
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
     for (int q = q_begin + wave; q < q_end; q += BQ_WAVES) {
         const int ql = q - q_begin;
         const int cnt = __builtin_amdgcn_readfirstlane(cnt_of[ql]);
-        if (cnt == 0 || cnt >= nsample) continue;
-        const int first = __builtin_amdgcn_readfirstlane(first_of[ql]);
+        if ((cnt == 0 && !zero_empty) || cnt >= nsample) continue;
+        const int first = __builtin_amdgcn_readfirstlane(first_of[ql]);   // 0 for an empty ball
         int *row = idx + (size_t)q * nsample;
         for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;
     }
@@ -106,11 +106,12 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
 
 }  // namespace apn
 
-extern "C" int apn_ball_query(int b, int n, int m, float radius, int nsample,
-                              const float *new_xyz, const float *xyz, int *idx, void *stream) {
+static int ball_query_impl(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                           const float *xyz, int *idx, int zero_empty, void *stream) {
     using namespace apn;
     if (b < 0 || n < 0 || m < 0 || nsample < 0) return APN_EINVAL;
-    if (b == 0 || m == 0 || nsample == 0 || n == 0) return APN_OK;
+    if (b == 0 || m == 0 || nsample == 0) return APN_OK;
+    if (n == 0 && !zero_empty) return APN_OK;
     if (!new_xyz || !xyz || !idx) return APN_EINVAL;
     const float radius2 = radius * radius;  // ball_query_gpu.cu:29 (float32 product)
     // Tile so that B * blocks_x comfortably exceeds the 256 CUs while each
@@ -122,7 +123,19 @@ extern "C" int apn_ball_query(int b, int n, int m, float radius, int nsample,
     const int chunk = n < BQ_CHUNK ? n : BQ_CHUNK;
     const size_t dyn = sizeof(float) * 3 * chunk + sizeof(int) * 2 * q_per_block;
     hipLaunchKernelGGL(ball_query_kernel, grid, dim3(BQ_WAVES * 64), dyn, (hipStream_t)stream, n,
-                       m, radius2, nsample, q_per_block, new_xyz, xyz, idx);
+                       m, radius2, nsample, q_per_block, zero_empty, new_xyz, xyz, idx);
     APN_LAUNCH_CHECK();
     return APN_OK;
+}
+
+extern "C" int apn_ball_query(int b, int n, int m, float radius, int nsample,
+                              const float *new_xyz, const float *xyz, int *idx, void *stream) {
+    return ball_query_impl(b, n, m, radius, nsample, new_xyz, xyz, idx, 0, stream);
+}
+
+// Same search, but rows of empty balls are WRITTEN as zeros, so the caller need not
+// pre-zero idx (the state group.py:194 + the reference kernel leave behind).
+extern "C" int apn_ball_query_zero(int b, int n, int m, float radius, int nsample,
+                                   const float *new_xyz, const float *xyz, int *idx, void *stream) {
+    return ball_query_impl(b, n, m, radius, nsample, new_xyz, xyz, idx, 1, stream);
 }

@@ -95,12 +95,14 @@ template <int W, int S>
 __global__ __launch_bounds__(W * 64) void fps_reg_kernel(FpsOrder o, int m,
                                                          const float *__restrict__ xyz,
                                                          float *__restrict__ temp,
-                                                         int *__restrict__ idxs) {
+                                                         int *__restrict__ idxs,
+                                                         float *__restrict__ new_xyz) {
     const int n = o.n;
     const int cloud = blockIdx.x;
     xyz += (size_t)cloud * n * 3;
     temp += (size_t)cloud * n;
     idxs += (size_t)cloud * m;
+    if (new_xyz) new_xyz += (size_t)cloud * m * 3;   // optional: coordinates of the picks
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -132,7 +134,10 @@ __global__ __launch_bounds__(W * 64) void fps_reg_kernel(FpsOrder o, int m,
     __shared__ int rec_pid[2][W];
 
     float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];  // old = 0 (sampling_gpu.cu:118-122)
-    if (tid == 0) idxs[0] = 0;
+    if (tid == 0) {
+        idxs[0] = 0;
+        if (new_xyz) { new_xyz[0] = x1; new_xyz[1] = y1; new_xyz[2] = z1; }
+    }
 
     for (int j = 1; j < m; ++j) {
         unsigned best;
@@ -187,6 +192,13 @@ __global__ __launch_bounds__(W * 64) void fps_reg_kernel(FpsOrder o, int m,
             old = __builtin_amdgcn_readlane(ep, ws);
         }
         if (tid == 0) idxs[j] = old;
+        // the winner's coordinates are already wave-uniform: the gather of the sampled points
+        // (pointnext.py:147) is one 12-byte store, issued by the LAST wave so that wave 0,
+        // which already stores the index, is not the straggler at the next barrier
+        if (new_xyz && tid >= (W - 1) * 64 && tid < (W - 1) * 64 + 3) {
+            const int d = tid - (W - 1) * 64;
+            new_xyz[j * 3 + d] = d == 0 ? x1 : d == 1 ? y1 : z1;
+        }
     }
 
     // The reference leaves the final min-distances in temp (sampling_gpu.cu:141-142).
@@ -242,18 +254,19 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(FpsOrder o, int m,
 
 template <int W, int S>
 static int launch_reg(const FpsOrder &o, int b, int m, const float *xyz, float *temp, int *idxs,
-                      hipStream_t st) {
-    hipLaunchKernelGGL((fps_reg_kernel<W, S>), dim3(b), dim3(W * 64), 0, st, o, m, xyz, temp, idxs);
+                      float *new_xyz, hipStream_t st) {
+    hipLaunchKernelGGL((fps_reg_kernel<W, S>), dim3(b), dim3(W * 64), 0, st, o, m, xyz, temp, idxs,
+                       new_xyz);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
 template <int W>
 static int dispatch_slots(const FpsOrder &o, int b, int m, const float *xyz, float *temp,
-                          int *idxs, hipStream_t st) {
+                          int *idxs, float *new_xyz, hipStream_t st) {
     const int need = (o.n + W * 64 - 1) / (W * 64);
 #define APN_FPS_CASE(SS) \
-    if (need <= SS) return launch_reg<W, SS>(o, b, m, xyz, temp, idxs, st);
+    if (need <= SS) return launch_reg<W, SS>(o, b, m, xyz, temp, idxs, new_xyz, st);
     APN_FPS_CASE(1)
     APN_FPS_CASE(2)
     APN_FPS_CASE(3)
@@ -279,8 +292,8 @@ extern "C" int apn_fps_set_waves(int waves) {
     return APN_OK;
 }
 
-extern "C" int apn_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
-                                           int *idxs, void *stream) {
+static int fps_impl(int b, int n, int m, const float *xyz, float *temp, int *idxs, float *new_xyz,
+                    void *stream) {
     using namespace apn;
     if (b < 0) return APN_EINVAL;
     if (b == 0 || m <= 0) return APN_OK;  // sampling_gpu.cu:110
@@ -310,10 +323,23 @@ extern "C" int apn_furthest_point_sampling(int b, int n, int m, const float *xyz
     if (w == 0) w = n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 4 : n <= 4096 ? 8 : 16;
     while (w < 16 && (n + w * 64 - 1) / (w * 64) > 16) w *= 2;
     switch (w) {
-    case 1: return dispatch_slots<1>(o, b, m, xyz, temp, idxs, st);
-    case 2: return dispatch_slots<2>(o, b, m, xyz, temp, idxs, st);
-    case 4: return dispatch_slots<4>(o, b, m, xyz, temp, idxs, st);
-    case 8: return dispatch_slots<8>(o, b, m, xyz, temp, idxs, st);
-    default: return dispatch_slots<16>(o, b, m, xyz, temp, idxs, st);
+    case 1: return dispatch_slots<1>(o, b, m, xyz, temp, idxs, new_xyz, st);
+    case 2: return dispatch_slots<2>(o, b, m, xyz, temp, idxs, new_xyz, st);
+    case 4: return dispatch_slots<4>(o, b, m, xyz, temp, idxs, new_xyz, st);
+    case 8: return dispatch_slots<8>(o, b, m, xyz, temp, idxs, new_xyz, st);
+    default: return dispatch_slots<16>(o, b, m, xyz, temp, idxs, new_xyz, st);
     }
+}
+
+extern "C" int apn_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
+                                           int *idxs, void *stream) {
+    return fps_impl(b, n, m, xyz, temp, idxs, nullptr, stream);
+}
+
+// FPS that also writes the sampled coordinates new_xyz (B,M,3) = xyz[idx]
+// (pointnext.py:146-147 in one launch).  n <= 16384 only (the register-resident kernel).
+extern "C" int apn_furthest_point_sampling_xyz(int b, int n, int m, const float *xyz, float *temp,
+                                               int *idxs, float *new_xyz, void *stream) {
+    if (n > 16384 || !new_xyz) return APN_EINVAL;
+    return fps_impl(b, n, m, xyz, temp, idxs, new_xyz, stream);
 }

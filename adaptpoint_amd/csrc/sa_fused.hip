@@ -38,8 +38,9 @@
 //                                                 the extreme of y2 over K and where it is
 // BN2 is affine per channel, so max_K BN2(y2) = scale*ext_K(y2)+shift with ext = max
 // when gamma2 >= 0 and min otherwise: no third pass.  Statistics leave the kernels
-// as per-workgroup partial rows, summed in float64 by the caller (deterministic, and
-// the natural place for the SyncBatchNorm all-reduce at world_size > 1).
+// as one partial row per workgroup; the small consumer kernels of sa_glue.hip sum the
+// rows in float64 (deterministic).  At world_size > 1 the summed rows are what the
+// SyncBatchNorm all-reduce runs on.
 //
 // Roofline: compulsory HBM traffic of pass 2 at B=32 is xyz 0.4 + idx 2.1 + ft 2.1
 // + out 2 x 4.2 MB ~ 13 MB (1.6 us at 8 TB/s); bf16 MFMA work 7 x 32 cycles per tile.
@@ -138,10 +139,12 @@ __device__ __forceinline__ void gather_tile(const SaArgs &a, int tile, int pos, 
     x[2] = d;
 }
 
-// Workgroup-level fold of per-lane statistics into one partial row per workgroup.
-// vals[i] belongs to channel (i * 32 + r) of this lane's half; halves and waves add.
+// Workgroup-level fold of per-lane statistics into ONE partial row per workgroup:
+// part[blockIdx.x][NV*32].  vals[i] belongs to channel (i*32 + r) of this lane's half;
+// halves and waves add.  The consumer kernel (sa_glue.hip) sums the rows in float64 --
+// deterministic, and cheaper than 512 workgroups contending on 64 atomic addresses.
 template <int NV>
-__device__ __forceinline__ void write_partials(float (&vals)[NV], float *__restrict__ out_row,
+__device__ __forceinline__ void write_partials(float (&vals)[NV], float *__restrict__ part,
                                                int lane, int wave) {
     __shared__ float red[SA_WAVES][NV][32];
 #pragma unroll
@@ -150,17 +153,18 @@ __device__ __forceinline__ void write_partials(float (&vals)[NV], float *__restr
         if (lane < 32) red[wave][i][lane] = vals[i] + other;
     }
     __syncthreads();
+    float *row = part + (size_t)blockIdx.x * NV * 32;
     for (int e = threadIdx.x; e < NV * 32; e += SA_WAVES * 64) {
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < SA_WAVES; ++w) s += red[w][e >> 5][e & 31];
-        out_row[e] = s;
+        row[e] = s;
     }
 }
 
-// Pass 1: statistics of y1 = conv1(x).  partials: [gridDim.x][64] = {sum[32], sumsq[32]}.
+// Pass 1: statistics of y1 = conv1(x).  part[gridDim.x][64] = {sum[32], sumsq[32]}.
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
-                                                                      float *__restrict__ partials) {
+                                                                      float *__restrict__ part) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     bf16x8 w1f[3];
@@ -176,16 +180,16 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
 #pragma unroll
         for (int i = 0; i < 16; ++i) { st[0] += y[i]; st[1] += y[i] * y[i]; }
     }
-    write_partials<2>(st, partials + (size_t)blockIdx.x * 64, lane, wave);
+    write_partials<2>(st, part, lane, wave);
 }
 
 // Pass 2.  scale1/shift1: BN1 folded to y*scale+shift; sgn2[c] = +1/-1 (sign of gamma2).
-// Outputs ysel/ksel (B,M,64): the extreme of y2 over K and its position; partials:
-// [gridDim.x][128] = {sum[64], sumsq[64]} of y2.
+// Outputs ysel/ksel (B,M,64): the extreme of y2 over K and its position;
+// part[gridDim.x][128] = {sum[64], sumsq[64]} of y2.
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
     SaArgs a, const float *__restrict__ w2, const float *__restrict__ scale1,
     const float *__restrict__ shift1, const float *__restrict__ sgn2, float *__restrict__ ysel,
-    unsigned char *__restrict__ ksel, float *__restrict__ partials) {
+    unsigned char *__restrict__ ksel, float *__restrict__ part) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     bf16x8 w1f[3];
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
             }
         }
     }
-    write_partials<4>(st, partials + (size_t)blockIdx.x * 128, lane, wave);
+    write_partials<4>(st, part, lane, wave);
 }
 
 // ---------------------------------------------------------------------------
@@ -281,8 +285,8 @@ struct SaBwdArgs {
 
 template <int PASS>
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
-                                                               float *__restrict__ partials,
-                                                               float *__restrict__ gw2_partials,
+                                                               float *__restrict__ part,
+                                                               float *__restrict__ gw2_acc,
                                                                float *__restrict__ G,
                                                                float *__restrict__ H) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -445,8 +449,9 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdAr
         }
     }
     if (PASS == 1) {
-        write_partials<2>(st, partials + (size_t)blockIdx.x * 64, lane, wave);
-        // dL/dW2 partial of this workgroup: D[row = out row(i,h) + 32 t][col = mid r]
+        write_partials<2>(st, part, lane, wave);
+        // dL/dW2 of this workgroup, D[row = out row(i,h) + 32 t][col = mid r]: fold the four
+        // waves in LDS, then one float atomic per element into the zeroed (64,32) gradient.
         __shared__ float wred[SA_WAVES][SA_C2 * SA_C1];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -454,12 +459,11 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdAr
             for (int i = 0; i < 16; ++i)
                 wred[wave][(32 * t + acc_row(i, h)) * SA_C1 + r] = gw2[t][i];
         __syncthreads();
-        float *dst = gw2_partials + (size_t)blockIdx.x * SA_C2 * SA_C1;
         for (int e = threadIdx.x; e < SA_C2 * SA_C1; e += SA_WAVES * 64) {
-            float s = 0.0f;
+            float sum = 0.0f;
 #pragma unroll
-            for (int w = 0; w < SA_WAVES; ++w) s += wred[w][e];
-            dst[e] = s;
+            for (int w = 0; w < SA_WAVES; ++w) sum += wred[w][e];
+            atomicAdd(gw2_acc + e, sum);
         }
     }
 }
@@ -495,13 +499,13 @@ static int sa_check(int b, int n, int m, int c_in, int c_mid, int c_out, int nsa
 
 extern "C" int apn_sa_fwd_stats1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                                  float radius, const float *xyz, const float *new_xyz,
-                                 const void *ft, const int *idx, const float *w1, float *partials,
+                                 const void *ft, const int *idx, const float *w1, float *part,
                                  void *stream) {
     using namespace apn;
     if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample)) return e;
     SaArgs a{b, n, m, xyz, new_xyz, (const __bf16 *)ft, idx, w1, radius};
     hipLaunchKernelGGL(sa_fwd_stats1_kernel, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                       (hipStream_t)stream, a, partials);
+                       (hipStream_t)stream, a, part);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -510,13 +514,13 @@ extern "C" int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_o
                                float radius, const float *xyz, const float *new_xyz, const void *ft,
                                const int *idx, const float *w1, const float *w2,
                                const float *scale1, const float *shift1, const float *sgn2,
-                               float *ysel, void *ksel, float *partials, void *stream) {
+                               float *ysel, void *ksel, float *part, void *stream) {
     using namespace apn;
     if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample)) return e;
     SaArgs a{b, n, m, xyz, new_xyz, (const __bf16 *)ft, idx, w1, radius};
     hipLaunchKernelGGL(sa_fwd_main_kernel, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
                        (hipStream_t)stream, a, w2, scale1, shift1, sgn2, ysel,
-                       (unsigned char *)ksel, partials);
+                       (unsigned char *)ksel, part);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -538,14 +542,14 @@ extern "C" int apn_sa_bwd_pass1(int b, int n, int m, int c_in, int c_mid, int c_
                                 float radius, const float *xyz, const float *new_xyz, const void *ft,
                                 const int *idx, const float *w1, const float *w2, const float *bn1,
                                 const float *qm, const float *evec, const float *d2e2,
-                                const float *goa, const void *ksel, float *partials,
-                                float *gw2_partials, void *stream) {
+                                const float *goa, const void *ksel, float *part,
+                                float *gw2_acc, void *stream) {
     using namespace apn;
     if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample)) return e;
     SaArgs a{b, n, m, xyz, new_xyz, (const __bf16 *)ft, idx, w1, radius};
     SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, d2e2, goa, ksel, nullptr);
     hipLaunchKernelGGL(sa_bwd_kernel<1>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                       (hipStream_t)stream, a, g, partials, gw2_partials, (float *)nullptr,
+                       (hipStream_t)stream, a, g, part, gw2_acc, (float *)nullptr,
                        (float *)nullptr);
     APN_LAUNCH_CHECK();
     return APN_OK;

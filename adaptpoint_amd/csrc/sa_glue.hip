@@ -1,46 +1,76 @@
 // sa_glue.hip -- the small kernels between the fused set-abstraction passes
-// (csrc/sa_fused.hip): partial-row reductions in float64, BatchNorm folding and
-// running-statistics update, the (B,M,64) <-> (B,64,M) layout changes, the
-// per-channel constants of the backward, and the three "everything downstream of
-// dL/dy1 is linear" products.  They replace ~150 tiny PyTorch launches per step
-// (and two pathological long-K rocBLAS GEMMs) with a fixed sequence of ~10, all
-// graph-capturable: no host reads, no allocation.
+// (csrc/sa_fused.hip): BatchNorm folding and running-statistics update, the
+// (B,M,64) <-> (B,64,M) layout changes with the block's skip branch (Conv1d on the
+// sampled points, add, ReLU) and its backward folded in, the per-channel constants of
+// the backward, and the "everything downstream of dL/dy1 is linear" products.  They
+// replace ~150 tiny PyTorch launches per step (and two pathological long-K rocBLAS
+// GEMMs) with a fixed sequence of 8, all graph-capturable: no host reads, no
+// allocation.  Cross-workgroup sums are float64 atomics into caller-zeroed accumulators.
 #include "apn_common.h"
 
 namespace apn {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-// out[c] += sum over this workgroup's slice of rows of part[row][c], in float64.
-// 256 threads = 64 columns x 4 row groups; grid = (ceil(ncol/64), row slices); the
-// slices meet through float64 atomics on the zeroed output (a handful per column).
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float *__restrict__ part, int rows,
-                                                          int ncol, double *__restrict__ out) {
-    __shared__ double red[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
-    const int per = (rows + gridDim.y - 1) / gridDim.y;
-    const int r0 = blockIdx.y * per, r1 = min(r0 + per, rows);
+// sums[c] = sum_rows part[row][c] in float64, for a workgroup of 1024 threads and
+// ncol <= 128 (ncol a power of two): threads = ncol columns x (1024/ncol) row groups.
+// With part == null the caller's `sums` (already reduced, e.g. all-reduced over ranks)
+// are copied instead.  Result valid in `out` after the trailing barrier.
+__device__ __forceinline__ void block_sum_rows(const float *__restrict__ part, int rows, int ncol,
+                                               const double *__restrict__ sums, double *out) {
+    __shared__ double red[1024];
+    const int t = threadIdx.x;
+    if (!part) {
+        if (t < ncol) out[t] = sums[t];
+        __syncthreads();
+        return;
+    }
+    const int c = t % ncol, g = t / ncol, groups = 1024 / ncol;
     double s = 0.0;
-    if (c < ncol)
-        for (int r = r0 + ry; r < r1; r += 4) s += (double)part[(size_t)r * ncol + c];
-    red[ry][cx] = s;
+    int r = g;
+    for (; r + 7 * groups < rows; r += 8 * groups) {   // 8 independent loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(r + u * groups) * ncol + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; r < rows; r += groups) s += (double)part[(size_t)r * ncol + c];
+    red[t] = s;
     __syncthreads();
-    if (ry == 0 && c < ncol)
-        atomicAdd(out + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+    if (t < ncol) {
+        double acc = 0.0;
+        for (int k = 0; k < groups; ++k) acc += red[k * ncol + t];
+        out[t] = acc;
+    }
+    __syncthreads();
 }
 
-// BatchNorm fold.  sums = {sum[C], sumsq[C]} over `count` positions (already summed
-// over ranks when SyncBatchNorm is on).  pack = {scale, shift, mean, invstd}[C].
+// Row sums only (the SyncBatchNorm path: reduce -> all_reduce -> consumer with part == null).
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float *__restrict__ part, int rows,
+                                                           int ncol, double *__restrict__ out) {
+    __shared__ double s[128];
+    block_sum_rows(part, rows, ncol, nullptr, s);
+    if (threadIdx.x < ncol) out[threadIdx.x] = s[threadIdx.x];
+}
+
+// BatchNorm fold.  {sum[C], sumsq[C]} over `count` positions come as partial rows
+// (part, rows) or as reduced sums.  pack = {scale, shift, mean, invstd}[C].
 // training: batch statistics (biased variance), running buffers updated with the
 // unbiased variance (torch.nn.BatchNorm semantics); otherwise the running buffers.
-__global__ void bn_fold_kernel(const double *__restrict__ sums, int c, double count,
-                               const float *__restrict__ gamma, const float *__restrict__ beta,
-                               float eps, float momentum, float *__restrict__ running_mean,
-                               float *__restrict__ running_var, long long *__restrict__ nbt,
-                               int training, float *__restrict__ pack) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Rider: sgn_out[i] = sign (+1/-1) of ANOTHER BatchNorm's gamma -- which extreme of y2
+// the K-pool keeps.
+__global__ __launch_bounds__(1024) void bn_fold_kernel(
+    const float *__restrict__ part, int rows, const double *__restrict__ sums_in, int c, double count,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
+    float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt,
+    int training, float *__restrict__ pack, const float *__restrict__ sgn_gamma, int sgn_c,
+    float *__restrict__ sgn_out) {
+    __shared__ double sums[128];
+    if (training) block_sum_rows(part, rows, 2 * c, sums_in, sums);
+    const int i = threadIdx.x;
     if (i == 0 && training && nbt) *nbt += 1;
+    if (sgn_out && i < sgn_c) sgn_out[i] = (!sgn_gamma || sgn_gamma[i] >= 0.0f) ? 1.0f : -1.0f;
     if (i >= c) return;
     double mean, var;
     if (training) {
@@ -64,41 +94,90 @@ __global__ void bn_fold_kernel(const double *__restrict__ sums, int c, double co
     pack[3 * c + i] = (float)inv;
 }
 
-// sign of gamma2 per channel (+1 / -1): which extreme of y2 the K-pool keeps.
-__global__ void sign_kernel(const float *__restrict__ gamma, int c, float *__restrict__ sgn) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < c) sgn[i] = (!gamma || gamma[i] >= 0.0f) ? 1.0f : -1.0f;
-}
-
-// out[b][c][m] = ysel[b][m][c] * scale2[c] + shift2[c]      (C = 64)
-__global__ __launch_bounds__(256) void fwd_out_kernel(int m, const float *__restrict__ ysel,
+// out[b][c][m] = act( ysel[b][m][c] * scale2[c] + shift2[c] + identity[b][c][m] )   (C = 64)
+// identity = Ws * f[b][:, fidx[b][m]] + bs  (the block's skip Conv1d on the sampled points,
+// pointnext.py:157-161) when ws != null; act = ReLU when relu != 0 (pointnext.py:167-168).
+__global__ __launch_bounds__(256) void fwd_out_kernel(int n, int m, const float *__restrict__ ysel,
                                                       const float *__restrict__ pack2,
+                                                      const float *__restrict__ f,
+                                                      const int *__restrict__ fidx,
+                                                      const float *__restrict__ ws,
+                                                      const float *__restrict__ bs, int relu,
                                                       float *__restrict__ out) {
     __shared__ float tile[64][65];
+    __shared__ float sfi[64][33];
+    __shared__ float sws[64][33];
     const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (ws) {
+        for (int e = threadIdx.x; e < 64 * 32; e += 256) sws[e >> 5][e & 31] = ws[e];
+        // fi[q][i] = f[b][i][fidx[b][q]]: lanes over queries, loop over channels
+        const int q = m0 + tx;
+        const int src = q < m ? fidx[(size_t)cloud * m + q] : 0;
+        for (int i = ty; i < 32; i += 4)
+            sfi[tx][i] = q < m ? f[((size_t)cloud * 32 + i) * n + src] : 0.0f;
+    }
     for (int j = ty; j < 64; j += 4) {   // j = query within tile, tx = channel
         const int q = m0 + j;
         tile[j][tx] = q < m ? ysel[((size_t)cloud * m + q) * 64 + tx] * pack2[tx] + pack2[64 + tx] : 0.f;
     }
     __syncthreads();
-    for (int c = ty; c < 64; c += 4)     // c = channel, tx = query
-        if (m0 + tx < m) out[((size_t)cloud * 64 + c) * m + m0 + tx] = tile[tx][c];
+    for (int c = ty; c < 64; c += 4) {   // c = channel, tx = query
+        float v = tile[tx][c];
+        if (ws) {
+            float idn = bs ? bs[c] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) idn += sws[c][i] * sfi[tx][i];
+            v += idn;
+        }
+        if (relu) v = fmaxf(v, 0.0f);
+        if (m0 + tx < m) out[((size_t)cloud * 64 + c) * m + m0 + tx] = v;
+    }
 }
 
-// goa[b][m][c] = g_out[b][c][m] * scale2[c]; partial sums of S1 = sum g, S2 = sum g*yhat_sel,
-// yhat_sel = (ysel - mean2) * invstd2.   part: [gridDim.x*gridDim.y][128].
-__global__ __launch_bounds__(256) void bwd_prep_kernel(int m, const float *__restrict__ g_out,
+// Backward entry.  g = g_out * [out > 0] (when relu) is dL/d(pre-activation).
+//   goa[b][m][c] = g * scale2[c]                      -> the fused passes
+//   partS[blk][128] = {S1 = sum g, S2 = sum g * yhat_sel} of the block's 64 queries
+//                     (S1 is also dL/dbs), blk = blockIdx.y * gridDim.x + blockIdx.x
+// and, with the skip branch (ws != null):
+//   partWs[blk][64*32] = sum_q g[q][c] * fi[q][i]        (dL/dWs of the block's queries)
+//   gip[b][n][i]   += sum_c ws[c][i] * g[q][c]  at n = fidx[b][q]   (dL/df through the skip,
+//                     point-major rows: 128-byte atomic segments)
+__global__ __launch_bounds__(256) void bwd_prep_kernel(int n, int m, const float *__restrict__ g_out,
+                                                       const float *__restrict__ out, int relu,
                                                        const float *__restrict__ ysel,
                                                        const float *__restrict__ pack2,
+                                                       const float *__restrict__ f,
+                                                       const int *__restrict__ fidx,
+                                                       const float *__restrict__ ws,
                                                        float *__restrict__ goa,
-                                                       float *__restrict__ part) {
-    __shared__ float tile[64][65];
+                                                       float *__restrict__ partS,
+                                                       float *__restrict__ partWs,
+                                                       float *__restrict__ gip) {
+    __shared__ float tile[64][65];       // g[q][c]
     __shared__ float red[4][2][64];
+    __shared__ float sfi[64][33];
+    __shared__ float sws[64][33];
+    __shared__ int ssrc[64];
     const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int c = ty; c < 64; c += 4)     // read (c, query tx): coalesced over queries
-        tile[tx][c] = m0 + tx < m ? g_out[((size_t)cloud * 64 + c) * m + m0 + tx] : 0.0f;
+    for (int c = ty; c < 64; c += 4) {   // read (c, query tx): coalesced over queries
+        float g = 0.0f;
+        if (m0 + tx < m) {
+            const size_t o = ((size_t)cloud * 64 + c) * m + m0 + tx;
+            g = g_out[o];
+            if (relu && !(out[o] > 0.0f)) g = 0.0f;
+        }
+        tile[tx][c] = g;
+    }
+    if (ws) {
+        for (int e = threadIdx.x; e < 64 * 32; e += 256) sws[e >> 5][e & 31] = ws[e];
+        const int q = m0 + tx;
+        const int src = q < m ? fidx[(size_t)cloud * m + q] : 0;
+        if (ty == 0) ssrc[tx] = src;
+        for (int i = ty; i < 32; i += 4)
+            sfi[tx][i] = q < m ? f[((size_t)cloud * 32 + i) * n + src] : 0.0f;
+    }
     __syncthreads();
     const float sc = pack2[tx], mu = pack2[128 + tx], iv = pack2[192 + tx];
     float s1 = 0.0f, s2 = 0.0f;
@@ -115,16 +194,37 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(int m, const float *__res
     red[ty][0][tx] = s1;
     red[ty][1][tx] = s2;
     __syncthreads();
-    if (ty < 2) {
-        float *row = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 128;
-        row[ty * 64 + tx] = red[0][ty][tx] + red[1][ty][tx] + red[2][ty][tx] + red[3][ty][tx];
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (ty < 2)
+        partS[blk * 128 + ty * 64 + tx] = red[0][ty][tx] + red[1][ty][tx] + red[2][ty][tx] + red[3][ty][tx];
+    if (ws) {
+        // dL/dWs[c][i]: thread (c = tx, 8 inputs i = 8*ty..)
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 64; ++q) {
+            const float g = tile[q][tx];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += g * sfi[q][8 * ty + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) partWs[blk * 2048 + tx * 32 + 8 * ty + j] = a[j];
+        // dL/dfi[q][i] -> point-major gip rows: thread (i = tid & 31, 8 queries)
+        const int i = threadIdx.x & 31, qg = threadIdx.x >> 5;
+        for (int q = qg; q < 64; q += 8) {
+            if (m0 + q < m) {
+                float v = 0.0f;
+#pragma unroll 8
+                for (int c = 0; c < 64; ++c) v += sws[c][i] * tile[q][c];
+                atomicAdd(gip + ((size_t)cloud * n + ssrc[q]) * 32 + i, v);
+            }
+        }
     }
 }
 
 // Per-channel constants of dL/dy2 = goa*[pos==ksel] + y2*D2 + E2 and their images
 // through W2:  qm = W2^T diag(D2) W2 (32x32), evec = E2 W2.  Also dL/dgamma2, dL/dbeta2.
 // One workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void bwd_consts2_kernel(const double *__restrict__ S,
+__global__ __launch_bounds__(1024) void bwd_consts2_kernel(const float *__restrict__ partS, int rows,
+                                                           const double *__restrict__ S_in,
                                                            const float *__restrict__ pack2,
                                                            const float *__restrict__ w2, double count,
                                                            int training, float *__restrict__ d2e2,
@@ -132,7 +232,8 @@ __global__ __launch_bounds__(1024) void bwd_consts2_kernel(const double *__restr
                                                            float *__restrict__ evec,
                                                            float *__restrict__ g_gamma2,
                                                            float *__restrict__ g_beta2) {
-    __shared__ double D[64], E[64];
+    __shared__ double D[64], E[64], S[128];
+    block_sum_rows(partS, rows, 128, S_in, S);
     const int t = threadIdx.x;
     if (t < 64) {
         const double sc = pack2[t], mu = pack2[128 + t], iv = pack2[192 + t];
@@ -161,9 +262,12 @@ __global__ __launch_bounds__(1024) void bwd_consts2_kernel(const double *__restr
 }
 
 // dL/dy1 = g_u*ca + yhat1*cb + cc ; dL/dgamma1 = T2, dL/dbeta1 = T1.
-__global__ void bwd_consts1_kernel(const double *__restrict__ T, const float *__restrict__ pack1,
-                                   double count, int training, float *__restrict__ cabc,
-                                   float *__restrict__ g_gamma1, float *__restrict__ g_beta1) {
+__global__ __launch_bounds__(1024) void bwd_consts1_kernel(
+    const float *__restrict__ partT, int rows, const double *__restrict__ T_in,
+    const float *__restrict__ pack1, double count, int training, float *__restrict__ cabc,
+    float *__restrict__ g_gamma1, float *__restrict__ g_beta1) {
+    __shared__ double T[64];
+    block_sum_rows(partT, rows, 64, T_in, T);
     const int i = threadIdx.x;
     if (i >= 32) return;
     const double sc = pack1[i];
@@ -174,24 +278,27 @@ __global__ void bwd_consts1_kernel(const double *__restrict__ T, const float *__
     if (g_beta1) g_beta1[i] = (float)T[i];
 }
 
-// dL/df[b][i][n] = sum_mid G[b][n][mid] * W1[mid][3+i];  optionally
+// dL/df[b][i][n] = sum_mid G[b][n][mid] * W1[mid][3+i]  (+ gip[b][n][i], the skip branch);  optionally
 // dL/dp[b][n][d] = sum_mid G[b][n][mid] * W1[mid][d] / r  (accumulated: +=).
 __global__ __launch_bounds__(256) void bwd_input_grad_kernel(int n, const float *__restrict__ G,
                                                              const float *__restrict__ w1,
+                                                             const float *__restrict__ gip,
                                                              float inv_r, float *__restrict__ g_f,
                                                              float *__restrict__ g_p) {
     __shared__ float sw[32][36];     // W1[mid][35]
     __shared__ float sg[64][33];     // G tile [point][mid]
+    __shared__ float si[64][33];     // gip tile [point][i]
     const int cloud = blockIdx.y, n0 = blockIdx.x * 64;
     for (int e = threadIdx.x; e < 32 * 35; e += 256) sw[e / 35][e % 35] = w1[e];
     for (int e = threadIdx.x; e < 64 * 32; e += 256) {
         const int pt = e >> 5, mid = e & 31;
         sg[pt][mid] = n0 + pt < n ? G[((size_t)cloud * n + n0 + pt) * 32 + mid] : 0.0f;
+        si[pt][mid] = (gip && n0 + pt < n) ? gip[((size_t)cloud * n + n0 + pt) * 32 + mid] : 0.0f;
     }
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // tx = point, ty = channel group
     for (int i = ty; i < 32; i += 4) {
-        float s = 0.0f;
+        float s = si[tx][i];
 #pragma unroll
         for (int mid = 0; mid < 32; ++mid) s += sg[tx][mid] * sw[mid][3 + i];
         if (n0 + tx < n) g_f[((size_t)cloud * 32 + i) * n + n0 + tx] = s;
@@ -220,12 +327,14 @@ __global__ __launch_bounds__(256) void bwd_query_grad_kernel(int total_q, const 
     for (int d = 0; d < 3; ++d) g_q[(size_t)q * 3 + d] = -s[d] * inv_r;
 }
 
-// Partial products over points for dL/dW1:  part[block][mid][38] with columns
-//   0..2   sum_n G[n][mid] * xyz[n][d]          (block's points)
-//   3..5   sum_q H[q][mid] * new_xyz[q][d]      (block's queries)
+// Products over points for dL/dW1: partW[block][mid][38], columns
+//   0..2   sum_n G[n][mid] * xyz[n][d]
+//   3..5   sum_q H[q][mid] * new_xyz[q][d]
 //   6..37  sum_n G[n][mid] * ft[n][i]
-// The caller sums blocks in float64 and forms (col0-2 - col3-5)/r.  A workgroup stages
-// WG_PTS points (and its share of queries) in LDS; thread (mid, group) owns 5 columns.
+// over the block's tile of WG_PTS points and its share of queries.  bwd_finalize sums the
+// blocks in float64 and forms (col0-2 - col3-5)/r.  256 threads = 32 mid x 8 column
+// groups; column group g owns columns {g, g+8, g+16, g+24, g+32}: every wave (two groups)
+// then runs the same instruction stream, and the staged tile is read as sB[pt][col].
 constexpr int WG_PTS = 64;
 __global__ __launch_bounds__(256) void bwd_weight_grad_kernel(int total_n, int total_q,
                                                               const float *__restrict__ G,
@@ -234,59 +343,97 @@ __global__ __launch_bounds__(256) void bwd_weight_grad_kernel(int total_n, int t
                                                               const float *__restrict__ xyz,
                                                               const float *__restrict__ new_xyz,
                                                               int q_per_block,
-                                                              float *__restrict__ part) {
-    __shared__ float sG[WG_PTS][33], sX[WG_PTS][36], sH[WG_PTS][33], sQ[WG_PTS][4];
+                                                              float *__restrict__ partW) {
+    __shared__ float sG[WG_PTS][33];    // G [point][mid]
+    __shared__ float sH[WG_PTS][33];    // H [query][mid]
+    __shared__ float sB[WG_PTS][41];    // columns 0..2 xyz, 3..5 new_xyz (query rows), 6..37 ft
     const int tid = threadIdx.x;
     const int n0 = blockIdx.x * WG_PTS, q0 = blockIdx.x * q_per_block;
     for (int e = tid; e < WG_PTS * 32; e += 256) {
         const int pt = e >> 5, c = e & 31;
         const bool ok = n0 + pt < total_n;
         sG[pt][c] = ok ? G[(size_t)(n0 + pt) * 32 + c] : 0.0f;
-        sX[pt][3 + c] = ok ? (float)ft[(size_t)(n0 + pt) * 32 + c] : 0.0f;
+        sB[pt][6 + c] = ok ? (float)ft[(size_t)(n0 + pt) * 32 + c] : 0.0f;
         const bool okq = pt < q_per_block && q0 + pt < total_q;
         sH[pt][c] = okq ? H[(size_t)(q0 + pt) * 32 + c] : 0.0f;
     }
     for (int e = tid; e < WG_PTS * 3; e += 256) {
         const int pt = e / 3, d = e % 3;
-        sX[pt][d] = n0 + pt < total_n ? xyz[(size_t)(n0 + pt) * 3 + d] : 0.0f;
-        sQ[pt][d] = (pt < q_per_block && q0 + pt < total_q) ? new_xyz[(size_t)(q0 + pt) * 3 + d] : 0.0f;
+        sB[pt][d] = n0 + pt < total_n ? xyz[(size_t)(n0 + pt) * 3 + d] : 0.0f;
+        sB[pt][3 + d] = (pt < q_per_block && q0 + pt < total_q) ? new_xyz[(size_t)(q0 + pt) * 3 + d] : 0.0f;
     }
+    for (int e = tid; e < WG_PTS * 2; e += 256) sB[e >> 1][38 + (e & 1)] = 0.0f;   // pad columns 38, 39
     __syncthreads();
-    const int mid = tid & 31, grp = tid >> 5;   // 8 groups x 5 columns = 40 >= 38
+    const int mid = tid & 31, grp = tid >> 5;
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    // column grp + 8 j; only j = 0 can be a query column (3..5), and only for grp in {3,4,5}
+    const bool qcol = grp >= 3 && grp <= 5;
+#pragma unroll 4
     for (int pt = 0; pt < WG_PTS; ++pt) {
-        const float g = sG[pt][mid], hq = sH[pt][mid];
+        const float g = sG[pt][mid];
+        const float a0 = qcol ? sH[pt][mid] : g;
+        acc[0] += a0 * sB[pt][grp];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int col = grp * 5 + j;            // compile-time pattern per group after unroll
-            float x;
-            if (col < 3) x = g * sX[pt][col];
-            else if (col < 6) x = hq * sQ[pt][col - 3];
-            else if (col < 38) x = g * sX[pt][col - 3];
-            else x = 0.0f;
-            acc[j] += x;
-        }
+        for (int j = 1; j < 5; ++j) acc[j] += g * sB[pt][grp + 8 * j];
     }
-    float *row = part + (size_t)blockIdx.x * 32 * 38;
+    float *row = partW + (size_t)blockIdx.x * 32 * 38;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        const int col = grp * 5 + j;
+        const int col = grp + 8 * j;
         if (col < 38) row[mid * 38 + col] = acc[j];
     }
 }
 
-// g_w1[mid][0..2] = (s[mid][0..2] - s[mid][3..5]) / r ; g_w1[mid][3+i] = s[mid][6+i]
-__global__ void bwd_w1_final_kernel(const double *__restrict__ s, double inv_r, float *__restrict__ g_w1) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 32 * 35) return;
-    const int mid = e / 35, col = e % 35;
-    g_w1[e] = col < 3 ? (float)((s[mid * 38 + col] - s[mid * 38 + 3 + col]) * inv_r)
-                      : (float)s[mid * 38 + 3 + col];
+// Parameter gradients out of the partial rows (column sums in float64):
+//   g_w1[mid][0..2] = (W[mid][0..2] - W[mid][3..5]) / r ; g_w1[mid][3+i] = W[mid][6+i],
+//        W = sum_rows partW[row][32*38]
+//   g_ws[c][i] = sum_rows partWs[row][64*32] ;  g_bs[c] = sum_rows partS[row][c]
+// A workgroup owns 64 output elements x 4 row groups; loads are issued 8 deep.
+__device__ __forceinline__ double col_sum(const float *__restrict__ base, int rows, int stride,
+                                          int col, int g) {
+    double s = 0.0;
+    int r = g;
+    for (; r + 28 < rows; r += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r + 4 * u) * stride + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; r < rows; r += 4) s += (double)base[(size_t)r * stride + col];
+    return s;
 }
 
-__global__ void cast_d2f_kernel(const double *__restrict__ s, int nelem, float *__restrict__ o) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < nelem) o[e] = (float)s[e];
+__global__ __launch_bounds__(256) void bwd_finalize_kernel(
+    const float *__restrict__ partW, int rowsW, double inv_r, float *__restrict__ g_w1,
+    const float *__restrict__ partWs, int rowsS, float *__restrict__ g_ws,
+    const float *__restrict__ partS, float *__restrict__ g_bs) {
+    __shared__ double red[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + o;
+    double v = 0.0;
+    int kind = 0;   // 1: g_w1, 2: g_ws, 3: g_bs
+    if (e < 32 * 35) {
+        kind = 1;
+        const int mid = e / 35, col = e % 35;
+        if (col < 3)
+            v = (col_sum(partW, rowsW, 1216, mid * 38 + col, g) -
+                 col_sum(partW, rowsW, 1216, mid * 38 + 3 + col, g)) * inv_r;
+        else
+            v = col_sum(partW, rowsW, 1216, mid * 38 + 3 + col, g);
+    } else if (e < 32 * 35 + 2048) {
+        if (g_ws) { kind = 2; v = col_sum(partWs, rowsS, 2048, e - 32 * 35, g); }
+    } else if (e < 32 * 35 + 2048 + 64) {
+        if (g_bs) { kind = 3; v = col_sum(partS, rowsS, 128, e - 32 * 35 - 2048, g); }
+    }
+    red[g][o] = v;
+    __syncthreads();
+    if (g == 0 && kind) {
+        const float r = (float)(red[0][o] + red[1][o] + red[2][o] + red[3][o]);
+        if (kind == 1) g_w1[e] = r;
+        else if (kind == 2) g_ws[e - 32 * 35] = r;
+        else g_bs[e - 32 * 35 - 2048] = r;
+    }
 }
 
 }  // namespace apn
@@ -294,83 +441,80 @@ __global__ void cast_d2f_kernel(const double *__restrict__ s, int nelem, float *
 #define APN_ST ((hipStream_t)stream)
 
 extern "C" int apn_sa_reduce_rows(const float *part, int rows, int ncol, double *out, void *stream) {
-    if (rows < 0 || ncol <= 0 || !part || !out) return APN_EINVAL;
-    hipError_t me = hipMemsetAsync(out, 0, sizeof(double) * (size_t)ncol, APN_ST);
-    if (me != hipSuccess) return (int)me;
-    int slices = (rows + 31) / 32;           // ~32 rows per workgroup slice
-    if (slices < 1) slices = 1;
-    if (slices > 64) slices = 64;
-    hipLaunchKernelGGL(apn::reduce_rows_kernel, dim3((ncol + 63) / 64, slices), dim3(256), 0, APN_ST,
-                       part, rows, ncol, out);
+    if (rows < 0 || ncol <= 0 || ncol > 128 || (1024 % ncol) || !part || !out) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::reduce_rows_kernel, dim3(1), dim3(1024), 0, APN_ST, part, rows, ncol, out);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
-extern "C" int apn_sa_bn_fold(const double *sums, int c, double count, const float *gamma,
-                              const float *beta, float eps, float momentum, float *running_mean,
-                              float *running_var, void *num_batches_tracked, int training,
-                              float *pack, void *stream) {
-    if (c <= 0 || !pack || (training && !sums) || (!training && (!running_mean || !running_var)))
-        return APN_EINVAL;
-    hipLaunchKernelGGL(apn::bn_fold_kernel, dim3((c + 63) / 64), dim3(64), 0, APN_ST, sums, c, count,
+extern "C" int apn_sa_bn_fold(const float *part, int rows, const double *sums, int c, double count,
+                              const float *gamma, const float *beta, float eps, float momentum,
+                              float *running_mean, float *running_var, void *num_batches_tracked,
+                              int training, float *pack, const float *sgn_gamma, int sgn_c,
+                              float *sgn_out, void *stream) {
+    if ((c != 32 && c != 64) || !pack || sgn_c > 1024) return APN_EINVAL;
+    if (training && !part && !sums) return APN_EINVAL;
+    if (!training && (!running_mean || !running_var)) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::bn_fold_kernel, dim3(1), dim3(1024), 0, APN_ST, part, rows, sums, c, count,
                        gamma, beta, eps, momentum, running_mean, running_var,
-                       (long long *)num_batches_tracked, training, pack);
+                       (long long *)num_batches_tracked, training, pack, sgn_gamma, sgn_c, sgn_out);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
-extern "C" int apn_sa_sign(const float *gamma, int c, float *sgn, void *stream) {
-    if (c <= 0 || !sgn) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::sign_kernel, dim3((c + 63) / 64), dim3(64), 0, APN_ST, gamma, c, sgn);
-    APN_LAUNCH_CHECK();
-    return APN_OK;
-}
-
-extern "C" int apn_sa_fwd_out(int b, int m, const float *ysel, const float *pack2, float *out,
-                              void *stream) {
+extern "C" int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const float *pack2,
+                              const float *f, const int *fidx, const float *ws, const float *bs,
+                              int relu, float *out, void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || !ysel || !pack2 || !out) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::fwd_out_kernel, dim3((m + 63) / 64, b), dim3(256), 0, APN_ST, m, ysel,
-                       pack2, out);
+    if (ws && (!f || !fidx || n <= 0)) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::fwd_out_kernel, dim3((m + 63) / 64, b), dim3(256), 0, APN_ST, n, m, ysel,
+                       pack2, f, fidx, ws, bs, relu, out);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
 extern "C" int apn_sa_bwd_prep_rows(int b, int m) { return b * ((m + 63) / 64); }
 
-extern "C" int apn_sa_bwd_prep(int b, int m, const float *g_out, const float *ysel,
-                               const float *pack2, float *goa, float *part, void *stream) {
-    if (b <= 0 || m <= 0 || b > 65535 || !g_out || !ysel || !pack2 || !goa || !part) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::bwd_prep_kernel, dim3((m + 63) / 64, b), dim3(256), 0, APN_ST, m, g_out,
-                       ysel, pack2, goa, part);
+extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, const float *out, int relu,
+                               const float *ysel, const float *pack2, const float *f,
+                               const int *fidx, const float *ws, float *goa, float *partS,
+                               float *partWs, float *gip, void *stream) {
+    if (b <= 0 || m <= 0 || b > 65535 || !g_out || !ysel || !pack2 || !goa || !partS) return APN_EINVAL;
+    if (relu && !out) return APN_EINVAL;
+    if (ws && (!f || !fidx || !partWs || !gip || n <= 0)) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::bwd_prep_kernel, dim3((m + 63) / 64, b), dim3(256), 0, APN_ST, n, m, g_out,
+                       out, relu, ysel, pack2, f, fidx, ws, goa, partS, partWs, gip);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
-extern "C" int apn_sa_bwd_consts2(const double *S, const float *pack2, const float *w2, double count,
-                                  int training, float *d2e2, float *qm, float *evec,
-                                  float *g_gamma2, float *g_beta2, void *stream) {
-    if (!S || !pack2 || !w2 || !d2e2 || !qm || !evec) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::bwd_consts2_kernel, dim3(1), dim3(1024), 0, APN_ST, S, pack2, w2, count,
-                       training, d2e2, qm, evec, g_gamma2, g_beta2);
+extern "C" int apn_sa_bwd_consts2(const float *partS, int rows, const double *S, const float *pack2,
+                                  const float *w2, double count, int training, float *d2e2,
+                                  float *qm, float *evec, float *g_gamma2, float *g_beta2,
+                                  void *stream) {
+    if ((!partS && !S) || !pack2 || !w2 || !d2e2 || !qm || !evec) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::bwd_consts2_kernel, dim3(1), dim3(1024), 0, APN_ST, partS, rows, S, pack2,
+                       w2, count, training, d2e2, qm, evec, g_gamma2, g_beta2);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
-extern "C" int apn_sa_bwd_consts1(const double *T, const float *pack1, double count, int training,
-                                  float *cabc, float *g_gamma1, float *g_beta1, void *stream) {
-    if (!T || !pack1 || !cabc) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::bwd_consts1_kernel, dim3(1), dim3(64), 0, APN_ST, T, pack1, count,
-                       training, cabc, g_gamma1, g_beta1);
+extern "C" int apn_sa_bwd_consts1(const float *partT, int rows, const double *T, const float *pack1,
+                                  double count, int training, float *cabc, float *g_gamma1,
+                                  float *g_beta1, void *stream) {
+    if ((!partT && !T) || !pack1 || !cabc) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::bwd_consts1_kernel, dim3(1), dim3(1024), 0, APN_ST, partT, rows, T, pack1,
+                       count, training, cabc, g_gamma1, g_beta1);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
 extern "C" int apn_sa_bwd_input_grad(int b, int n, int m, const float *G, const float *H,
-                                     const float *w1, float radius, float *g_f, float *g_p,
-                                     float *g_newp, void *stream) {
+                                     const float *w1, const float *gip, float radius, float *g_f,
+                                     float *g_p, float *g_newp, void *stream) {
     if (b <= 0 || n <= 0 || b > 65535 || !G || !w1 || !g_f) return APN_EINVAL;
     hipLaunchKernelGGL(apn::bwd_input_grad_kernel, dim3((n + 63) / 64, b), dim3(256), 0, APN_ST, n, G,
-                       w1, 1.0f / radius, g_f, g_p);
+                       w1, gip, 1.0f / radius, g_f, g_p);
     APN_LAUNCH_CHECK();
     if (g_newp) {
         if (!H || m <= 0) return APN_EINVAL;
@@ -385,29 +529,24 @@ extern "C" int apn_sa_bwd_weight_rows(int b, int n) { return (b * n + apn::WG_PT
 
 extern "C" int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const float *H,
                                       const void *ft, const float *xyz, const float *new_xyz,
-                                      float *part, void *stream) {
-    if (b <= 0 || n <= 0 || m <= 0 || !G || !H || !ft || !xyz || !new_xyz || !part) return APN_EINVAL;
+                                      float *partW, void *stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || !G || !H || !ft || !xyz || !new_xyz || !partW) return APN_EINVAL;
     const int blocks = apn_sa_bwd_weight_rows(b, n);
     const int qpb = (b * m + blocks - 1) / blocks;   // queries are spread evenly over the blocks
     if (qpb > apn::WG_PTS) return APN_EINVAL;        // needs m <= n (always true after sampling)
     hipLaunchKernelGGL(apn::bwd_weight_grad_kernel, dim3(blocks), dim3(256), 0, APN_ST, b * n, b * m, G,
-                       H, (const __bf16 *)ft, xyz, new_xyz, qpb, part);
+                       H, (const __bf16 *)ft, xyz, new_xyz, qpb, partW);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
-extern "C" int apn_sa_bwd_w1_final(const double *sums, float radius, float *g_w1, void *stream) {
-    if (!sums || !g_w1) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::bwd_w1_final_kernel, dim3((32 * 35 + 255) / 256), dim3(256), 0, APN_ST,
-                       sums, 1.0 / (double)radius, g_w1);
-    APN_LAUNCH_CHECK();
-    return APN_OK;
-}
-
-extern "C" int apn_sa_cast_d2f(const double *src, int nelem, float *dst, void *stream) {
-    if (nelem <= 0 || !src || !dst) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::cast_d2f_kernel, dim3((nelem + 255) / 256), dim3(256), 0, APN_ST, src,
-                       nelem, dst);
+extern "C" int apn_sa_bwd_finalize(const float *partW, int rows_w, float radius, float *g_w1,
+                                   const float *partWs, int rows_s, float *g_ws,
+                                   const float *partS, float *g_bs, void *stream) {
+    if (!partW || !g_w1 || (g_ws && !partWs) || (g_bs && !partS)) return APN_EINVAL;
+    const int total = 32 * 35 + 2048 + 64;
+    hipLaunchKernelGGL(apn::bwd_finalize_kernel, dim3((total + 63) / 64), dim3(256), 0, APN_ST, partW,
+                       rows_w, 1.0 / (double)radius, g_w1, partWs, rows_s, g_ws, partS, g_bs);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

@@ -65,6 +65,12 @@ def algorithmic_bytes(batch):
         "group_xyz": batch * (3 * N_PTS * 4 + mk * 4 + 3 * mk * 4),        # rows, idx, out
         "group_feat": batch * (C_IN * N_PTS * 4 + mk * 4 + C_IN * mk * 4),
         "group_feat_grad": batch * (C_IN * mk * 4 + mk * 4 + 2 * C_IN * N_PTS * 4),
+        # fused passes: xyz + queries + idx + bf16 feature table in; pooled outputs / G, H out
+        "sa_fwd_stats1": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64),
+        "sa_fwd_main": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64 + NPOINT * 64 * 5),
+        "sa_bwd_pass1": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64 + NPOINT * 64 * 5),
+        "sa_bwd_pass2": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64 + NPOINT * 64 * 5
+                                 + N_PTS * 128 + NPOINT * 128),
     }
 
 
@@ -118,8 +124,11 @@ def instrument(timer, only=None):
     from adaptpoint_amd import fused
     orig_call = fused._call
 
+    alias = {"furthest_point_sampling_xyz": "fps", "ball_query_zero": "ball_query"}
+
     def fused_call(name, dev, *a):
         short = name.replace("apn_", "")
+        short = alias.get(short, short)
         if only is not None and short not in only:
             return orig_call(name, dev, *a)
         return timer.wrap(short, orig_call)(name, dev, *a)

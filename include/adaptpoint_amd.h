@@ -106,17 +106,30 @@ APN_API int apn_three_interpolate_grad(int b, int c, int n, int m, const float *
                                void *stream);
 
 /* ------------------------------------------------------------------------
- * Fused set-abstraction MLP (no single reference entry point: the reference runs
+ * Fused set-abstraction block (no single reference entry point: the reference runs
  * this chain as PyTorch ops over materialised (B,C,M,K) tensors --
  * openpoints/models/layers/group.py:235-255,323-335 and
- * openpoints/models/backbone/pointnext.py:157-168).  Shapes supported by this
+ * openpoints/models/backbone/pointnext.py:146-168).  Shapes supported by this
  * build: c_in = 32 features (+3 relative xyz), c_mid = 32, c_out = 64,
  * nsample = 32; anything else returns APN_EINVAL and callers use the unfused ops.
  *   xyz (B,N,3) f32, new_xyz (B,M,3) f32, ft (B,N,32) bf16 point-major copy of the
  *   features, idx (B,M,32) i32, w1 (32,35) f32 with columns [dp(3), f(32)],
- *   w2 (64,32) f32.  "partials" are per-workgroup rows of per-channel sums, summed
- *   by the caller (rows = apn_sa_grid_blocks(b, m)).
+ *   w2 (64,32) f32.  Per-channel statistics leave the pass kernels as one partial
+ *   row per workgroup ("part", rows = apn_sa_grid_blocks(b, m)); the small consumer
+ *   kernels sum the rows in float64, or take already reduced (e.g. all-reduced)
+ *   float64 sums instead when part == NULL.  dL/dW2, G and gip are float atomic adds
+ *   into caller-zeroed buffers.
+ *   "pack" = {scale, shift, mean, invstd}[C] of a BatchNorm folded to y*scale+shift.
+ * Everything below only enqueues kernels (graph-capturable).
  * ------------------------------------------------------------------------ */
+
+/* FPS that also writes new_xyz (B,M,3) = xyz[idx] (pointnext.py:146-147); n <= 16384. */
+APN_API int apn_furthest_point_sampling_xyz(int b, int n, int m, const float *xyz, float *temp,
+                                            int *idxs, float *new_xyz, void *stream);
+
+/* apn_ball_query that writes zeros into the rows of empty balls (no pre-zeroed idx needed). */
+APN_API int apn_ball_query_zero(int b, int n, int m, float radius, int nsample,
+                                const float *new_xyz, const float *xyz, int *idx, void *stream);
 
 /* Workgroups (= partial rows) the fused passes launch for B clouds x M queries. */
 APN_API int apn_sa_grid_blocks(int b, int m);
@@ -124,36 +137,75 @@ APN_API int apn_sa_grid_blocks(int b, int m);
 /* f (B,C,N) f32 -> ft (B,N,C) bf16 (C must be 32). */
 APN_API int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, void *stream);
 
-/* Forward pass 1: partials[rows][64] = {sum, sumsq}[32] of y1 = conv1(cat(dp, f[idx])). */
+/* Forward pass 1: part[rows][64] = {sum, sumsq}[32] of y1 = conv1(cat(dp, f[idx])). */
 APN_API int apn_sa_fwd_stats1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                               float radius, const float *xyz, const float *new_xyz,
-                              const void *ft, const int *idx, const float *w1, float *partials,
+                              const void *ft, const int *idx, const float *w1, float *part,
                               void *stream);
+
+/* out[ncol] = float64 column sums of part[rows][ncol] (ncol <= 128, a power of two): the
+ * SyncBatchNorm path reduces, all-reduces, then calls the consumer with part == NULL. */
+APN_API int apn_sa_reduce_rows(const float *part, int rows, int ncol, double *out, void *stream);
+
+/* BatchNorm fold: {sum, sumsq}[C] over `count` positions (part[rows][2C], or sums[2C] when
+ * part == NULL) -> pack[4][C]; updates the running buffers / num_batches_tracked when
+ * training (torch.nn.BatchNorm semantics); uses the running buffers when not training.
+ * Rider: sgn_out[i] = sign(sgn_gamma[i]), i < sgn_c.  C = 32 or 64. */
+APN_API int apn_sa_bn_fold(const float *part, int rows, const double *sums, int c, double count,
+                           const float *gamma, const float *beta, float eps, float momentum,
+                           float *running_mean, float *running_var, void *num_batches_tracked,
+                           int training, float *pack, const float *sgn_gamma, int sgn_c,
+                           float *sgn_out, void *stream);
 
 /* Forward pass 2: a1 = relu(y1*scale1+shift1); y2 = conv2(a1);
  * ysel/ksel (B,M,64): per (query, channel) the extreme of y2 over the K neighbours
  * (max where sgn2 = +1, min where sgn2 = -1) and the neighbour slot holding it;
- * partials[rows][128] = {sum[64], sumsq[64]} of y2. */
+ * part[rows][128] = {sum[64], sumsq[64]} of y2. */
 APN_API int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                             float radius, const float *xyz, const float *new_xyz, const void *ft,
                             const int *idx, const float *w1, const float *w2,
                             const float *scale1, const float *shift1, const float *sgn2,
-                            float *ysel, void *ksel, float *partials, void *stream);
+                            float *ysel, void *ksel, float *part, void *stream);
 
-/* Backward of the fused chain, two passes (see csrc/sa_fused.hip for the algebra).
- *   bn1   [4][32]  = {scale1, shift1, mean1, invstd1}
- *   qm    (32,32)  = W2^T diag(D2) W2 ; evec [32] = E2 W2 ; d2e2 [2][64] = {D2, E2}
- *   goa   (B,M,64) = dL/dout * gamma2*invstd2 ; ksel (B,M,64) from the forward
- * pass 1 -> partials[rows][64] = {sum g_u, sum g_u*yhat1}[32], gw2_partials[rows][64*32].
- * pass 2 (cabc [3][32] = {ca, cb, cc}: dL/dy1 = g_u*ca + yhat1*cb + cc)
- *        -> G (B,N,32) += per-source-point sums of dL/dy1 (caller-zeroed, float atomics),
- *           H (B,M,32)  = per-query sums of dL/dy1. */
+/* out (B,64,M) = act(ysel*scale2 + shift2 + Ws f[:, fidx] + bs); ws/bs/f/fidx may be null
+ * (no skip branch), relu = 0/1.  f (B,32,N), fidx (B,M), ws (64,32), bs (64). */
+APN_API int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const float *pack2,
+                           const float *f, const int *fidx, const float *ws, const float *bs,
+                           int relu, float *out, void *stream);
+
+/* Backward entry: g = g_out * [out > 0] (relu) ; goa (B,M,64) = g * scale2;
+ * partS[rows][128] = {sum g, sum g*yhat_sel} per block of 64 queries
+ * (rows = apn_sa_bwd_prep_rows(b, m)); with the skip branch partWs[rows][64*32] = dL/dWs
+ * per block and gip (B,N,32) += Ws^T g at the sampled points (caller-zeroed). */
+APN_API int apn_sa_bwd_prep_rows(int b, int m);
+APN_API int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, const float *out, int relu,
+                            const float *ysel, const float *pack2, const float *f,
+                            const int *fidx, const float *ws, float *goa, float *partS,
+                            float *partWs, float *gip, void *stream);
+
+/* Constants of dL/dy2 = goa*[pos==ksel] + y2*D2 + E2: d2e2 [2][64], qm (32,32) =
+ * W2^T diag(D2) W2, evec [32] = E2 W2; g_gamma2 = S2, g_beta2 = S1. */
+APN_API int apn_sa_bwd_consts2(const float *partS, int rows, const double *S, const float *pack2,
+                               const float *w2, double count, int training, float *d2e2,
+                               float *qm, float *evec, float *g_gamma2, float *g_beta2,
+                               void *stream);
+
+/* Backward pass 1 -> part[rows][64] = {sum g_u, sum g_u*yhat1}[32]; gw2_acc[64*32] += dL/dW2.
+ *   bn1 = pack1 [4][32]. */
 APN_API int apn_sa_bwd_pass1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                              float radius, const float *xyz, const float *new_xyz, const void *ft,
                              const int *idx, const float *w1, const float *w2, const float *bn1,
                              const float *qm, const float *evec, const float *d2e2,
-                             const float *goa, const void *ksel, float *partials,
-                             float *gw2_partials, void *stream);
+                             const float *goa, const void *ksel, float *part, float *gw2_acc,
+                             void *stream);
+
+/* cabc [3][32]: dL/dy1 = g_u*ca + yhat1*cb + cc ; g_gamma1 = T2, g_beta1 = T1. */
+APN_API int apn_sa_bwd_consts1(const float *partT, int rows, const double *T, const float *pack1,
+                               double count, int training, float *cabc, float *g_gamma1,
+                               float *g_beta1, void *stream);
+
+/* Backward pass 2 -> G (B,N,32) += per-source-point sums of dL/dy1 (caller-zeroed, float
+ * atomics), H (B,M,32) = per-query sums of dL/dy1. */
 APN_API int apn_sa_bwd_pass2(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                              float radius, const float *xyz, const float *new_xyz, const void *ft,
                              const int *idx, const float *w1, const float *w2, const float *bn1,
@@ -161,37 +213,23 @@ APN_API int apn_sa_bwd_pass2(int b, int n, int m, int c_in, int c_mid, int c_out
                              const void *ksel, const float *cabc, float *G, float *H,
                              void *stream);
 
-/* Small kernels between the fused passes (csrc/sa_glue.hip); all graph-capturable.
- * "pack" = {scale, shift, mean, invstd}[C] of a BatchNorm folded to y*scale+shift. */
-APN_API int apn_sa_reduce_rows(const float *part, int rows, int ncol, double *out, void *stream);
-APN_API int apn_sa_bn_fold(const double *sums, int c, double count, const float *gamma,
-                           const float *beta, float eps, float momentum, float *running_mean,
-                           float *running_var, void *num_batches_tracked, int training,
-                           float *pack, void *stream);
-APN_API int apn_sa_sign(const float *gamma, int c, float *sgn, void *stream);
-/* out (B,64,M) = ysel (B,M,64) * scale2 + shift2 */
-APN_API int apn_sa_fwd_out(int b, int m, const float *ysel, const float *pack2, float *out,
-                           void *stream);
-/* goa (B,M,64) = g_out (B,64,M) * scale2; part[apn_sa_bwd_prep_rows][128] = partial {S1, S2} */
-APN_API int apn_sa_bwd_prep_rows(int b, int m);
-APN_API int apn_sa_bwd_prep(int b, int m, const float *g_out, const float *ysel,
-                            const float *pack2, float *goa, float *part, void *stream);
-APN_API int apn_sa_bwd_consts2(const double *S, const float *pack2, const float *w2, double count,
-                               int training, float *d2e2, float *qm, float *evec,
-                               float *g_gamma2, float *g_beta2, void *stream);
-APN_API int apn_sa_bwd_consts1(const double *T, const float *pack1, double count, int training,
-                               float *cabc, float *g_gamma1, float *g_beta1, void *stream);
-/* g_f (B,32,N) = G W1[:,3:]; optional g_p (B,N,3) += G W1[:,:3]/r, g_newp (B,M,3) = -H W1[:,:3]/r */
+/* g_f (B,32,N) = G W1[:,3:] (+ gip); optional g_p (B,N,3) += G W1[:,:3]/r and
+ * g_newp (B,M,3) = -H W1[:,:3]/r. */
 APN_API int apn_sa_bwd_input_grad(int b, int n, int m, const float *G, const float *H,
-                                  const float *w1, float radius, float *g_f, float *g_p,
-                                  float *g_newp, void *stream);
-/* part[apn_sa_bwd_weight_rows][32*38]: per-block sums for dL/dW1 (see sa_glue.hip) */
+                                  const float *w1, const float *gip, float radius, float *g_f,
+                                  float *g_p, float *g_newp, void *stream);
+
+/* partW[apn_sa_bwd_weight_rows(b, n)][32*38]: per-block products for dL/dW1 (sa_glue.hip). */
 APN_API int apn_sa_bwd_weight_rows(int b, int n);
 APN_API int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const float *H,
                                    const void *ft, const float *xyz, const float *new_xyz,
-                                   float *part, void *stream);
-APN_API int apn_sa_bwd_w1_final(const double *sums, float radius, float *g_w1, void *stream);
-APN_API int apn_sa_cast_d2f(const double *src, int nelem, float *dst, void *stream);
+                                   float *partW, void *stream);
+
+/* Column sums in float64 -> g_w1 (32,35) from partW; optional g_ws (64,32) from partWs and
+ * g_bs [64] from partS (rows_s rows each). */
+APN_API int apn_sa_bwd_finalize(const float *partW, int rows_w, float radius, float *g_w1,
+                                const float *partWs, int rows_s, float *g_ws,
+                                const float *partS, float *g_bs, void *stream);
 
 /* Tuning / diagnostic hook, NOT part of the reference boundary: force the number
  * of wavefronts that cooperate on one cloud in apn_furthest_point_sampling

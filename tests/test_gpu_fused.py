@@ -42,17 +42,18 @@ def _setup(dev, B=4, seed=0, neg_gamma=False):
 
 @pytest.mark.parametrize("neg_gamma", [False, True])
 def test_fused_forward_matches_pytorch(dev, neg_gamma):
-    from adaptpoint_amd.fused import FusedForward, supported
+    from adaptpoint_amd.fused import grouped_mlp_max, supported
     p, new_p, f, idx, conv1, bn1, conv2, bn2 = _setup(dev, neg_gamma=neg_gamma)
     assert supported(p, f, idx, conv1, conv2)
-    fw = FusedForward(p, new_p, f, idx, 0.15, conv1, bn1, conv2, bn2)
+    with torch.no_grad():
+        out = grouped_mlp_max(p, new_p, f, idx, 0.15, conv1, bn1, conv2, bn2)
     torch.cuda.synchronize()
     args = (p, new_p, f, idx, 0.15, conv1.weight.view(32, 35), bn1.weight, bn1.bias,
             conv2.weight.view(64, 32), bn2.weight, bn2.bias)
     ref_bf, _ = chain(*args, emulate_bf16=True)
     ref_32, _ = chain(*args, emulate_bf16=False)
-    e_bf = (fw.out.double() - ref_bf).abs()
-    e_32 = (fw.out.double() - ref_32).abs()
+    e_bf = (out.double() - ref_bf).abs()
+    e_32 = (out.double() - ref_32).abs()
     print("fused fwd err vs bf16-emulation max %.3e mean %.3e | vs fp32 max %.3e mean %.3e"
           % (e_bf.max(), e_bf.mean(), e_32.max(), e_32.mean()))
     assert e_bf.max() <= 2e-2 and e_bf.mean() <= 5e-4
@@ -60,9 +61,10 @@ def test_fused_forward_matches_pytorch(dev, neg_gamma):
 
 
 def test_fused_forward_updates_running_stats(dev):
-    from adaptpoint_amd.fused import FusedForward
+    from adaptpoint_amd.fused import grouped_mlp_max
     p, new_p, f, idx, conv1, bn1, conv2, bn2 = _setup(dev, B=2, seed=3)
-    FusedForward(p, new_p, f, idx, 0.15, conv1, bn1, conv2, bn2)
+    with torch.no_grad():
+        grouped_mlp_max(p, new_p, f, idx, 0.15, conv1, bn1, conv2, bn2)
     _, mid = chain(p, new_p, f, idx, 0.15, conv1.weight.view(32, 35), bn1.weight, bn1.bias,
                    conv2.weight.view(64, 32), bn2.weight, bn2.bias, emulate_bf16=True)
     n = 2 * 512 * 32
@@ -142,3 +144,56 @@ def test_set_abstraction_fused_equals_unfused(dev):
         assert _rel_l2(qb.grad, qa.grad) <= 0.15, k
     for (k, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         assert torch.allclose(ba.float(), bb.float(), rtol=2e-2, atol=2e-3), k
+
+
+def test_fused_block_new_p_and_idx_are_exact(dev, oracle):
+    """The sampling / query stage inside the fused block is the index-exact one."""
+    from adaptpoint_amd.fused import _call
+    xyz = GI.unit_sphere_cloud(4, 1024, seed=11)
+    p = torch.from_numpy(xyz).to(dev)
+    fidx = torch.empty(4, 512, dtype=torch.int32, device=dev)
+    new_p = torch.empty(4, 512, 3, device=dev)
+    temp = torch.full((4, 1024), 1e10, device=dev)
+    _call("apn_furthest_point_sampling_xyz", dev, 4, 1024, 512, p.data_ptr(), temp.data_ptr(),
+          fidx.data_ptr(), new_p.data_ptr())
+    o_idx = oracle.furthest_point_sampling(xyz, 512)
+    assert np.array_equal(fidx.cpu().numpy(), o_idx)
+    assert np.array_equal(new_p.cpu().numpy(), GI.take_points(xyz, o_idx))
+    idx = torch.full((4, 512, 32), -5, dtype=torch.int32, device=dev)     # NOT pre-zeroed
+    far = new_p.clone()
+    far[:, :7] += 9.0                                                       # some empty balls
+    _call("apn_ball_query_zero", dev, 4, 1024, 512, 0.15, 32, far.data_ptr(), p.data_ptr(), idx.data_ptr())
+    assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(0.15, 32, xyz, far.cpu().numpy()))
+
+
+def test_fused_block_eval_mode_and_xyz_grad(dev):
+    """eval-mode BatchNorm (running statistics) forward+backward, with gradient flowing to the
+    coordinates -- the AdaptPoint feedback path (function_adaptpoint/ganloss_cls.py:31-65)."""
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    kw = dict(layers=2, stride=2, group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32,
+                                              'normalize_dp': True},
+              norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+              use_res=True)
+    torch.manual_seed(4)
+    a = SetAbstraction(32, 64, **kw).to(dev)
+    b = SetAbstraction(32, 64, fused=True, **kw).to(dev)
+    with torch.no_grad():
+        for bn in (a.convs[0][1], a.convs[1][1]):
+            bn.running_mean.uniform_(-0.2, 0.2)
+            bn.running_var.uniform_(0.5, 1.5)
+    b.load_state_dict(a.state_dict())
+    a.eval(); b.eval()
+    p1 = torch.from_numpy(GI.unit_sphere_cloud(4, 1024, seed=6)).to(dev).requires_grad_(True)
+    p2 = p1.detach().clone().requires_grad_(True)
+    f1 = torch.from_numpy(GI.seeded_normal((4, 32, 1024), seed=7)).to(dev).requires_grad_(True)
+    f2 = f1.detach().clone().requires_grad_(True)
+    wts = torch.randn(4, 64, 512, device=dev, generator=torch.Generator(dev).manual_seed(1))
+    pa, oa = a([p1, f1]); ((oa * wts).sum() + pa.sum()).backward()
+    pb, ob = b([p2, f2]); ((ob * wts).sum() + pb.sum()).backward()
+    assert torch.equal(pa, pb)
+    assert (oa - ob).abs().max() <= 1.5e-1 and (oa - ob).abs().mean() <= 1e-2
+    assert _rel_l2(f2.grad, f1.grad) <= 0.25
+    assert _rel_l2(p2.grad, p1.grad) <= 0.25
+    sd_a, sd_b = a.state_dict(), b.state_dict()
+    for k in sd_a:                     # eval mode: no buffer moved
+        assert torch.equal(sd_a[k], sd_b[k]), k
