@@ -25,6 +25,8 @@ SIGNATURES = {
     "apn_three_interpolate": [_c_int] * 4 + [_c_void_p] * 5,
     "apn_three_interpolate_grad": [_c_int] * 4 + [_c_void_p] * 5,
     "apn_fps_set_waves": [_c_int],
+    "apn_fps_set_algo": [_c_int],
+    "apn_fps_debug_stamps": [_c_int] * 3 + [_c_void_p] * 5,
     "apn_furthest_point_sampling_xyz": [_c_int] * 3 + [_c_void_p] * 5,
     "apn_ball_query_zero": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 4,
     "apn_sa_grid_blocks": [_c_int] * 2,

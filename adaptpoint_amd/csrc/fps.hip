@@ -209,6 +209,217 @@ __global__ __launch_bounds__(W * 64) void fps_reg_kernel(FpsOrder o, int m,
     }
 }
 
+// Second-generation step for n <= 4096: the cross-wave arg-max is ONE LDS 64-bit atomic
+// max instead of per-wave records + a second reduction.
+//   key = (min-distance bits << 32) | (0xFFFFFFFF - priority rank)
+// so the maximum key is the largest distance and, among equals, the smallest rank: the
+// reference's tie rule falls out of the integer compare, across lanes AND waves, with no
+// election (every lane that holds its wave's maximum issues the atomic; normally one).
+// After the barrier every lane reads the winning key (broadcast ds_read_b64) and then the
+// winner's {x,y,z,id} from a rank-indexed LDS table (broadcast ds_read_b128): the next
+// step's coordinates arrive in VGPRs, with no ballot / find-first / readlane on the
+// critical path.  Three key slots rotate; slot (j+1)%3 is zeroed during step j, after
+// barrier j-1 proved that every wave finished reading it and before barrier j lets
+// anyone use it again.
+template <int W, int S>
+__global__ __launch_bounds__(W * 64) void fps_atomic_kernel(FpsOrder o, int m,
+                                                            const float *__restrict__ xyz,
+                                                            float *__restrict__ temp,
+                                                            int *__restrict__ idxs,
+                                                            float *__restrict__ new_xyz) {
+    extern __shared__ float4 tab[];            // [n] {x, y, z, id} by priority rank
+    __shared__ unsigned long long slot[3];
+    const int n = o.n;
+    const int cloud = blockIdx.x;
+    xyz += (size_t)cloud * n * 3;
+    temp += (size_t)cloud * n;
+    idxs += (size_t)cloud * m;
+    if (new_xyz) new_xyz += (size_t)cloud * m * 3;
+    const int tid = threadIdx.x;
+
+    float px[S], py[S], pz[S];
+    unsigned dmin[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int q = tid * S + s;
+        if (q < n) {
+            const int p = fps_rank_to_point(o, q);
+            px[s] = xyz[p * 3 + 0];
+            py[s] = xyz[p * 3 + 1];
+            pz[s] = xyz[p * 3 + 2];
+            dmin[s] = __float_as_uint(temp[p]);
+            tab[q] = make_float4(px[s], py[s], pz[s], __int_as_float(p));
+        } else {
+            px[s] = py[s] = pz[s] = 0.0f;      // padding: distance stays +0.0 at the highest ranks
+            dmin[s] = 0u;
+        }
+    }
+    if (tid < 3) slot[tid] = 0ull;
+    float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+    if (tid == 0) {
+        idxs[0] = 0;
+        if (new_xyz) { new_xyz[0] = x1; new_xyz[1] = y1; new_xyz[2] = z1; }
+    }
+    __syncthreads();
+
+    // LDS byte offsets of the three key slots (ds_max_u64 / ds_write_b64 take raw offsets)
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    const unsigned slot0 = (unsigned)(size_t)(lds_u64 *)&slot[0];
+    int cur = 1, nxt = 2;                      // j % 3 and (j + 1) % 3
+    for (int j = 1; j < m; ++j) {
+        unsigned best = 0u;
+        int bslot = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float d = dist2(px[s] - x1, py[s] - y1, pz[s] - z1);
+            const unsigned du = __float_as_uint(d);
+            dmin[s] = du < dmin[s] ? du : dmin[s];
+            if (s == 0) {
+                best = dmin[0];
+            } else {
+                const bool g = dmin[s] > best;   // strict: the lower slot keeps a tie
+                best = g ? dmin[s] : best;
+                bslot = g ? s : bslot;
+            }
+        }
+        const unsigned wmax = wave_max_u32(best);
+        if (best == wmax) {
+            // hand-issued so that the compiler's atomic optimizer does not wrap the (almost
+            // always single-lane) atomic in a scalar reduction loop
+            const unsigned long long key =
+                ((unsigned long long)best << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(tid * S + bslot));
+            asm volatile("ds_max_u64 %0, %1" :: "v"(slot0 + 8u * (unsigned)cur), "v"(key) : "memory");
+        }
+        if (tid == 0) slot[nxt] = 0ull;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned long long k = slot[cur];
+        const unsigned rank = 0xFFFFFFFFu - (unsigned)k;
+        const float4 w = tab[rank];
+        x1 = w.x; y1 = w.y; z1 = w.z;
+        if (tid == 0) idxs[j] = __float_as_int(w.w);
+        if (new_xyz && tid >= (W - 1) * 64 && tid < (W - 1) * 64 + 3) {
+            const int d = tid - (W - 1) * 64;
+            new_xyz[j * 3 + d] = d == 0 ? x1 : d == 1 ? y1 : z1;
+        }
+        cur = nxt;
+        nxt = nxt == 2 ? 0 : nxt + 1;
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int q = tid * S + s;
+        if (q < n) temp[__float_as_int(tab[q].w)] = __uint_as_float(dmin[s]);
+    }
+}
+
+// Diagnostic twin of fps_reg_kernel<8,2> (n = 1024): identical step, with s_memtime
+// stamps around its segments accumulated by wave 0 into dbg[0..5] (cycles summed over the
+// m-1 steps).  Never used by the product path; its run time is not representative
+// (the stamps serialise), only the SHARES are (cdna_hip_programming.md section 7).
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+
+__global__ __launch_bounds__(512) void fps_stamp_kernel(FpsOrder o, int m, const float *__restrict__ xyz,
+                                                        float *__restrict__ temp,
+                                                        int *__restrict__ idxs,
+                                                        unsigned long long *__restrict__ dbg) {
+    constexpr int W = 8, S = 2;
+    const int n = o.n;
+    const int cloud = blockIdx.x;
+    xyz += (size_t)cloud * n * 3;
+    temp += (size_t)cloud * n;
+    idxs += (size_t)cloud * m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float px[S], py[S], pz[S];
+    unsigned dmin[S];
+    int pid[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int q = tid * S + s;
+        const int p = q < n ? fps_rank_to_point(o, q) : 0;
+        pid[s] = p;
+        px[s] = q < n ? xyz[p * 3 + 0] : 0.f;
+        py[s] = q < n ? xyz[p * 3 + 1] : 0.f;
+        pz[s] = q < n ? xyz[p * 3 + 2] : 0.f;
+        dmin[s] = q < n ? __float_as_uint(temp[p]) : 0u;
+    }
+    __shared__ float4 rec[2][W];
+    __shared__ int rec_pid[2][W];
+    float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+    if (tid == 0) idxs[0] = 0;
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 1; j < m; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t0 = stamp();
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned best; float bx, by, bz; int bp;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float d = dist2(px[s] - x1, py[s] - y1, pz[s] - z1);
+            const unsigned du = __float_as_uint(d);
+            dmin[s] = du < dmin[s] ? du : dmin[s];
+            if (s == 0) { best = dmin[0]; bx = px[0]; by = py[0]; bz = pz[0]; bp = pid[0]; }
+            else {
+                const bool g = dmin[s] > best;
+                best = g ? dmin[s] : best; bx = g ? px[s] : bx; by = g ? py[s] : by;
+                bz = g ? pz[s] : bz; bp = g ? pid[s] : bp;
+            }
+        }
+        asm volatile("" :: "v"(best));
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t1 = stamp();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned wmax = wave_max_u32(best);
+        asm volatile("" :: "s"(wmax));
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t2 = stamp();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long cand = __ballot(best == wmax);
+        const int wl = (int)__builtin_ctzll(cand);
+        const int buf = j & 1;
+        if (lane == wl) {
+            rec[buf][wave] = make_float4(__uint_as_float(wmax), bx, by, bz);
+            rec_pid[buf][wave] = bp;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t3 = stamp();   // includes the lgkmcnt(0) wait for the ds_write
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t4 = stamp();
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 e = rec[buf][lane & (W - 1)];
+        const int ep = rec_pid[buf][lane & (W - 1)];
+        asm volatile("" :: "v"(e.x), "v"(ep));
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t5 = stamp();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned ev = __float_as_uint(e.x);
+        const unsigned gmax = group_max_u32<W>(ev);
+        const unsigned long long cw = __ballot(ev == gmax);
+        const int ws = (int)__builtin_ctzll(cw);
+        x1 = readlane_f(e.y, ws); y1 = readlane_f(e.z, ws); z1 = readlane_f(e.w, ws);
+        const int old = __builtin_amdgcn_readlane(ep, ws);
+        if (tid == 0) idxs[j] = old;
+        asm volatile("" :: "s"(x1), "s"(y1), "s"(z1));
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t6 = stamp();
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2;
+        acc[3] += t4 - t3; acc[4] += t5 - t4; acc[5] += t6 - t5;
+    }
+    if (tid == 0 && cloud == 0)
+        for (int i = 0; i < 6; ++i) dbg[i] = acc[i];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int q = tid * S + s;
+        if (q < n) temp[pid[s]] = __uint_as_float(dmin[s]);
+    }
+}
+
 // Any-n fallback (n > 16384): the reference's thread structure with the
 // distances kept in `temp` (global / L2) and a halving tree in LDS whose merge
 // keeps the left slot on ties, exactly the reference's __update order.
@@ -252,9 +463,17 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(FpsOrder o, int m,
     }
 }
 
+static int g_fps_algo = 0;   // 0: LDS-atomic step when it applies; 1: per-wave records (first generation)
+
 template <int W, int S>
 static int launch_reg(const FpsOrder &o, int b, int m, const float *xyz, float *temp, int *idxs,
                       float *new_xyz, hipStream_t st) {
+    if (W > 1 && o.n <= 4096 && g_fps_algo == 0) {
+        hipLaunchKernelGGL((fps_atomic_kernel<W, S>), dim3(b), dim3(W * 64), sizeof(float4) * o.n, st,
+                           o, m, xyz, temp, idxs, new_xyz);
+        APN_LAUNCH_CHECK();
+        return APN_OK;
+    }
     hipLaunchKernelGGL((fps_reg_kernel<W, S>), dim3(b), dim3(W * 64), 0, st, o, m, xyz, temp, idxs,
                        new_xyz);
     APN_LAUNCH_CHECK();
@@ -282,6 +501,14 @@ static int dispatch_slots(const FpsOrder &o, int b, int m, const float *xyz, flo
 static int g_fps_waves_override = 0;  // tuning hook, see apn_fps_set_waves
 
 }  // namespace apn
+
+extern "C" int apn_fps_set_algo(int algo) {
+    // Tuning/diagnostic hook: 0 = default (LDS-atomic step for n <= 4096), 1 = force the
+    // first-generation per-wave-record step.  Results do not depend on it.
+    if (algo != 0 && algo != 1) return APN_EINVAL;
+    apn::g_fps_algo = algo;
+    return APN_OK;
+}
 
 extern "C" int apn_fps_set_waves(int waves) {
     // Tuning/diagnostic hook (not part of the reference boundary): force the
@@ -342,4 +569,16 @@ extern "C" int apn_furthest_point_sampling_xyz(int b, int n, int m, const float 
                                                int *idxs, float *new_xyz, void *stream) {
     if (n > 16384 || !new_xyz) return APN_EINVAL;
     return fps_impl(b, n, m, xyz, temp, idxs, new_xyz, stream);
+}
+
+// Diagnostic only (see fps_stamp_kernel): n must be 1024; dbg receives 6 cycle sums.
+extern "C" int apn_fps_debug_stamps(int b, int n, int m, const float *xyz, float *temp, int *idxs,
+                                    unsigned long long *dbg, void *stream) {
+    using namespace apn;
+    if (n != 1024 || b <= 0 || m <= 1 || !dbg) return APN_EINVAL;
+    FpsOrder o{1024, 1024, 10, 1, 0};
+    hipLaunchKernelGGL(fps_stamp_kernel, dim3(b), dim3(512), 0, (hipStream_t)stream, o, m, xyz, temp,
+                       idxs, dbg);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
 }

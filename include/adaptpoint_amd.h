@@ -237,6 +237,16 @@ APN_API int apn_sa_bwd_finalize(const float *partW, int rows_w, float radius, fl
  * on it.  Process-wide; not thread-safe against concurrent FPS launches. */
 APN_API int apn_fps_set_waves(int waves);
 
+/* Tuning / diagnostic hook: FPS step algorithm, 0 = default (one LDS 64-bit atomic max per
+ * step, n <= 4096), 1 = per-wave records + second reduction.  Results do not depend on it. */
+APN_API int apn_fps_set_algo(int algo);
+
+/* Diagnostic only: the FPS step of the n = 1024 geometry with s_memtime stamps; dbg[0..5]
+ * = cycles summed over the m-1 steps for {update, wave max, pick+LDS write, barrier,
+ * LDS read, group max + broadcast}.  Not part of the product path. */
+APN_API int apn_fps_debug_stamps(int b, int n, int m, const float *xyz, float *temp, int *idxs,
+                                 unsigned long long *dbg, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,9 +36,12 @@ def bench_fps():
         temp = torch.empty(b, n, device=dev)
         idx = torch.empty(b, m, dtype=torch.int32, device=dev)
         line = f"B={b:4d} N={n:5d} M={m:5d}: "
-        for w in (0, 1, 2, 4, 8, 16):
+        for algo in (0, 1):
+          lib.apn_fps_set_algo(algo)
+          line += f" [algo{algo}]"
+          for w in (0, 2, 4, 8, 16):
             if w and (n + w * 64 - 1) // (w * 64) > 16:
-                line += f" w{w}=   n/a   "
+                line += f" w{w}=  n/a "
                 continue
             lib.apn_fps_set_waves(w)
 
@@ -47,8 +50,9 @@ def bench_fps():
                 ops.furthest_point_sampling_wrapper(b, n, m, xyz, temp, idx)
             med, mn = time_us(run)
             fill, _ = time_us(lambda: temp.fill_(1e10))
-            line += f" w{w}={med - fill:7.1f}us ({(med - fill) * 1e3 / max(m - 1, 1):5.0f}ns/step)"
+            line += f" w{w}={med - fill:6.1f}us({(med - fill) * 1e3 / max(m - 1, 1):4.0f})"
         lib.apn_fps_set_waves(0)
+        lib.apn_fps_set_algo(0)
         print(line, flush=True)
 
 
@@ -83,5 +87,37 @@ def bench_ops():
     print("three_interp_g %8.1f us" % time_us(lambda: ops.three_interpolate_grad_wrapper(B, 64, N, M, go, i3, w, gm))[0])
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and (len(sys.argv) < 2 or sys.argv[1] in ("fps", "ops")):
     {"fps": bench_fps, "ops": bench_ops}[sys.argv[1] if len(sys.argv) > 1 else "fps"]()
+
+
+def fps_stamps():
+    """Where one FPS step spends its cycles (diagnostic kernel with s_memtime stamps)."""
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    b, n, m = 32, 1024, 512
+    xyz = torch.from_numpy(GI.unit_sphere_cloud(b, n, seed=0)).to(dev)
+    temp = torch.full((b, n), 1e10, device=dev)
+    idx = torch.empty(b, m, dtype=torch.int32, device=dev)
+    dbg = torch.zeros(8, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        temp.fill_(1e10)
+        rc = lib.apn_fps_debug_stamps(b, n, m, xyz.data_ptr(), temp.data_ptr(), idx.data_ptr(), dbg.data_ptr(), st)
+        assert rc == 0
+    torch.cuda.synchronize()
+    ref = torch.empty(b, m, dtype=torch.int32, device=dev)
+    temp.fill_(1e10)
+    ops.furthest_point_sampling_wrapper(b, n, m, xyz, temp, ref)
+    assert torch.equal(ref, idx), "stamped kernel diverged from the product kernel"
+    names = ["update", "wave max (6 DPP + readlane)", "ballot/ff1 + LDS write (+lgkm wait)", "s_barrier",
+             "LDS read", "group max + ballot + 4 readlanes"]
+    c = dbg.cpu().numpy()[:6] / (m - 1)
+    print("memtime ticks per step (100 MHz? or shader clock -- see ratio), incl. ~40 per stamp:")
+    for nme, v in zip(names, c):
+        print(f"  {nme:40s} {v:8.1f}")
+    print(f"  total {c.sum():.1f}")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "stamps":
+    fps_stamps()

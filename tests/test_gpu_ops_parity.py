@@ -58,18 +58,22 @@ def test_fps_tie_and_ragged_cases(dev, golden, case):
     assert np.array_equal(gpu_fps(cloud, m, dev), golden[f"g3_fps_{name}"])
 
 
+@pytest.mark.parametrize("algo", [0, 1])
 @pytest.mark.parametrize("waves", [1, 2, 4, 8, 16])
-def test_fps_every_wave_geometry_same_result(dev, golden, waves):
-    """The tie order is a property of the layout, not of how many waves share a cloud."""
+def test_fps_every_wave_geometry_same_result(dev, golden, waves, algo):
+    """The tie order is a property of the layout, not of how many waves share a cloud nor of
+    how they meet (one LDS 64-bit atomic max, or per-wave records)."""
     from adaptpoint_amd import _lib
     lib = _lib.load()
     try:
         assert lib.apn_fps_set_waves(waves) == 0
+        assert lib.apn_fps_set_algo(algo) == 0
         for name in ("dup", "half_origin", "n1200", "n2048_grid", "n100_m_gt_n", "n5"):
             _, cloud, m = next(c for c in GI.tie_cases() if c[0] == name)
             assert np.array_equal(gpu_fps(cloud, m, dev), golden[f"g3_fps_{name}"]), (waves, name)
     finally:
         lib.apn_fps_set_waves(0)
+        lib.apn_fps_set_algo(0)
 
 
 @pytest.mark.parametrize("n,m", [(1024, 512), (512, 256), (256, 128), (128, 64), (64, 16),
