@@ -49,6 +49,14 @@ SIGNATURES = {
     "apn_sa_bwd_weight_grad": [_c_int] * 3 + [_c_void_p] * 7,
     "apn_sa_bwd_finalize": [_c_void_p, _c_int, _c_float, _c_void_p, _c_void_p, _c_int, _c_void_p,
                             _c_void_p, _c_void_p, _c_void_p],
+    "apn_sa_forward_seq": ([_c_int] * 4 + [_c_float] + [_c_void_p] * 9
+                           + [_c_void_p] * 5 + [_c_float, _c_float, _c_int]
+                           + [_c_void_p] * 5 + [_c_float, _c_float, _c_int]
+                           + [_c_double, _c_int] + [_c_void_p] * 12),
+    "apn_sa_backward_seq": ([_c_int] * 4 + [_c_float] + [_c_void_p] * 14 + [_c_int] * 3
+                            + [_c_double] + [_c_void_p] * 2 + [ctypes.c_size_t]
+                            + [_c_void_p] * 26),
+    "apn_sa_sample_seq": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 6,
 }
 
 _lib = None

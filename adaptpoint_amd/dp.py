@@ -15,9 +15,9 @@ def env_world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init(backend, device=None):
+def init(backend, device=None, force=False):
     world, rank, _ = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}

@@ -32,6 +32,11 @@ from . import _lib
 
 C_IN, C_MID, C_OUT, K_NS = 32, 32, 64, 32
 
+# Diagnostics: True issues every kernel as its own foreign call (the Python mirror of
+# csrc/sa_seq.hip below) so that per-kernel HIP events can be placed around them
+# (bench.py's per-kernel table).  The product default is one C call per direction.
+PER_KERNEL_LAUNCH = False
+
 
 def supported(p, f, idx_or_k, conv1, conv2):
     k = idx_or_k.shape[2] if torch.is_tensor(idx_or_k) else int(idx_or_k)
@@ -42,15 +47,52 @@ def supported(p, f, idx_or_k, conv1, conv2):
             and conv1.bias is None and conv2.bias is None)
 
 
-def _call(name, dev, *args):
-    lib = _lib.load()
-    with torch.cuda.device(dev):
-        code = getattr(lib, name)(*args, torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(code, name)
+_FN = {}
+
+
+def _call(name, dev, *args, stream=None):
+    """One launch: the C entry point `name` on PyTorch's current stream of `dev` (or on the
+    given raw stream handle).  Assumes `dev` is the current device (callers of this module
+    run under the tensors' device, as torch.nn modules do); other devices take the guard."""
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib.load(), name)
+    if stream is None:
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            with torch.cuda.device(dev):
+                code = fn(*args, torch.cuda.current_stream(dev).cuda_stream)
+            if code:
+                _lib.check(code, name)
+            return
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    code = fn(*args, stream)
+    if code:
+        _lib.check(code, name)
+
+
+class _Launcher:
+    """A run of launches on one stream: resolves the stream handle once (host time matters:
+    an eager step is ~25 launches and must not become host-bound).  It calls through the
+    module-level name `_call`, so instrumentation that wraps `fused._call` sees every launch."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            self.stream = None               # let _call take the device guard
+        else:
+            self.stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def __call__(self, name, *args):
+        _call(name, self.dev, *args, stream=self.stream)
 
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
+
+
+# Testing hook: run the phased SyncBatchNorm path (reduce rows -> all_reduce -> consumer with
+# sums) even when there is a single rank, so that it can be validated on one GPU.
+FORCE_PHASED = False
 
 
 def _world(sync):
@@ -59,32 +101,39 @@ def _world(sync):
     return 1
 
 
-def _rows_or_sums(part, ncol, dev, sync):
-    """(part_ptr, rows, sums_ptr, keepalive): the consumer kernels sum the partial rows
-    themselves; with SyncBatchNorm on they get float64 sums all-reduced over ranks."""
-    if part is None:
-        return None, 0, None, None
-    if _world(sync) > 1:
-        sums = torch.empty(ncol, dtype=torch.float64, device=dev)
-        _call("apn_sa_reduce_rows", dev, part.data_ptr(), part.shape[0], ncol, sums.data_ptr())
+def _phased(sync):
+    return _world(sync) > 1 or (FORCE_PHASED and sync)
+
+
+def _carve(dev, sizes, zero=False):
+    """One allocation, many float32 views: sizes = [(name, n_floats)] -> dict of 1-D views.
+    Offsets are rounded to 64 floats (256 B) so every view is safely aligned."""
+    offs, total = [], 0
+    for _, nfl in sizes:
+        offs.append(total)
+        total += (int(nfl) + 63) // 64 * 64
+    buf = (torch.zeros if zero else torch.empty)(max(total, 64), dtype=torch.float32, device=dev)
+    return {name: buf[o:o + int(nfl)] for (name, nfl), o in zip(sizes, offs)}, buf
+
+
+def _all_reduce_rows(call, part, rows, ncol, dev):
+    """SyncBatchNorm exchange: float64 column sums of the partial rows, all-reduced."""
+    sums = torch.empty(ncol, dtype=torch.float64, device=dev)
+    call("apn_sa_reduce_rows", part.data_ptr(), rows, ncol, sums.data_ptr())
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(sums)
-        return None, 0, sums.data_ptr(), sums
-    return part.data_ptr(), part.shape[0], None, part
+    return sums
 
 
-def _fold(part, c, count, bn, dev, sync, sgn_gamma=None, sgn_out=None):
-    pack = torch.empty(4, c, dtype=torch.float32, device=dev)
+def _bn_args(bn):
+    """(gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, training)."""
     training = bn.training or not bn.track_running_stats
-    mom = bn.momentum if bn.momentum is not None else 0.1
     track = bn.track_running_stats
-    pp, rows, sp, _keep = _rows_or_sums(part if training else None, 2 * c, dev, sync)
-    _call("apn_sa_bn_fold", dev, pp, rows, sp, c, float(count),
-          _ptr(bn.weight), _ptr(bn.bias), float(bn.eps), float(mom),
-          _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
-          _ptr(bn.num_batches_tracked) if (track and bn.training) else None,
-          1 if training else 0, pack.data_ptr(), _ptr(sgn_gamma),
-          0 if sgn_out is None else sgn_out.numel(), _ptr(sgn_out))
-    return pack, training
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    return (_ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean) if track else None,
+            _ptr(bn.running_var) if track else None,
+            _ptr(bn.num_batches_tracked) if (track and bn.training) else None,
+            float(bn.eps), float(mom), 1 if training else 0)
 
 
 def _mat(w, rows, cols):
@@ -98,6 +147,8 @@ class _Forward:
     def __init__(self, p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
                  sync_bn):
         dev = f.device
+        call = _Launcher(dev)
+        lib = _lib.load()
         B, C, N = f.shape
         M = new_p.shape[1]
         self.dims = (B, N, M)
@@ -110,34 +161,40 @@ class _Forward:
         if skip_conv is not None:
             ws = _mat(skip_conv.weight, C_OUT, C_IN)
             bs = skip_conv.bias.detach() if skip_conv.bias is not None else None
-        ft = torch.empty(B, N, C, dtype=torch.bfloat16, device=dev)
-        _call("apn_sa_prep_features", dev, B, C, N, f.data_ptr(), ft.data_ptr())
-        hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, self.radius, p.data_ptr(), new_p.data_ptr(),
-               ft.data_ptr(), idx.data_ptr(), w1.data_ptr())
-        count = float(B * M * K_NS) * _world(sync_bn)
-        rows = _lib.load().apn_sa_grid_blocks(B, M)
-        part1 = None
-        if bn1.training or not bn1.track_running_stats:
-            part1 = torch.empty(rows, 64, dtype=torch.float32, device=dev)
-            _call("apn_sa_fwd_stats1", dev, *hdr, part1.data_ptr())
-        sgn2 = torch.empty(C_OUT, dtype=torch.float32, device=dev)
-        pack1, self.train1 = _fold(part1, C_MID, count, bn1, dev, sync_bn, bn2.weight, sgn2)
-        ysel = torch.empty(B, M, C_OUT, dtype=torch.float32, device=dev)
-        ksel = torch.empty(B, M, C_OUT, dtype=torch.uint8, device=dev)
-        part2 = torch.empty(rows, 128, dtype=torch.float32, device=dev)
-        _call("apn_sa_fwd_main", dev, *hdr, w2.data_ptr(), pack1.data_ptr(),
-              pack1.data_ptr() + 4 * C_MID, sgn2.data_ptr(), ysel.data_ptr(), ksel.data_ptr(),
-              part2.data_ptr())
-        pack2, self.train2 = _fold(part2, C_OUT, count, bn2, dev, sync_bn)
-        # max_K bn2(y2) = scale2 * ext_K(y2) + shift2  (ext = max where gamma2 >= 0, else min)
+        world = _world(sync_bn)
+        count = float(B * M * K_NS) * world
+        rows = lib.apn_sa_grid_blocks(B, M)
+        v, _buf = _carve(dev, [("ft", B * N * C // 2), ("pack1", 4 * C_MID), ("pack2", 4 * C_OUT),
+                               ("sgn2", C_OUT), ("ysel", B * M * C_OUT), ("ksel", B * M * C_OUT // 4),
+                               ("part1", rows * 64), ("part2", rows * 128)])
         out = torch.empty(B, C_OUT, M, dtype=torch.float32, device=dev)
-        _call("apn_sa_fwd_out", dev, B, N, M, ysel.data_ptr(), pack2.data_ptr(),
-              f.data_ptr() if ws is not None else None, _ptr(fidx) if ws is not None else None,
-              _ptr(ws), _ptr(bs), self.relu, out.data_ptr())
+        bn1a, bn2a = _bn_args(bn1), _bn_args(bn2)
+        self.train1, self.train2 = bool(bn1a[7]), bool(bn2a[7])
+
+        def run(phases, sums1=None, sums2=None):
+            if PER_KERNEL_LAUNCH:
+                return _forward_per_kernel(call, phases, B, N, M, self.radius, p, new_p, f, idx, fidx,
+                                           w1, w2, ws, bs, bn1a, bn2a, count, self.relu, v, sums1,
+                                           sums2, out, rows)
+            call("apn_sa_forward_seq", phases, B, N, M, self.radius, p.data_ptr(), new_p.data_ptr(),
+                 f.data_ptr(), idx.data_ptr(), _ptr(fidx), w1.data_ptr(), w2.data_ptr(), _ptr(ws),
+                 _ptr(bs), *bn1a, *bn2a, count, self.relu, v["ft"].data_ptr(),
+                 v["part1"].data_ptr(), v["part2"].data_ptr(), _ptr(sums1), _ptr(sums2),
+                 v["pack1"].data_ptr(), v["pack2"].data_ptr(), v["sgn2"].data_ptr(),
+                 v["ysel"].data_ptr(), v["ksel"].data_ptr(), out.data_ptr())
+
+        if not _phased(sync_bn):
+            run(7)
+        else:                                   # SyncBatchNorm: all-reduce between the phases
+            run(1)
+            s1 = _all_reduce_rows(call, v["part1"], rows, 64, dev) if self.train1 else None
+            run(2, sums1=s1)
+            s2 = _all_reduce_rows(call, v["part2"], rows, 128, dev) if self.train2 else None
+            run(4, sums2=s2)
         self.out = out
-        self.saved = dict(p=p, f=f, new_p=new_p, idx=idx, fidx=fidx, ft=ft, w1=w1, w2=w2, ws=ws,
-                          has_bs=bs is not None, pack1=pack1, pack2=pack2, ysel=ysel, ksel=ksel,
-                          count=count)
+        self.saved = dict(p=p, f=f, new_p=new_p, idx=idx, fidx=fidx, ft=v["ft"], w1=w1, w2=w2, ws=ws,
+                          has_bs=bs is not None, pack1=v["pack1"], pack2=v["pack2"], ysel=v["ysel"],
+                          ksel=v["ksel"], count=count)
 
 
 def _backward(fw, g_out, need_p, need_newp):
@@ -148,72 +205,126 @@ def _backward(fw, g_out, need_p, need_newp):
     P, sync = sv["count"], fw.sync
     f32 = dict(dtype=torch.float32, device=dev)
     g_out = g_out.contiguous()
-    w1, w2, ws, pack1, pack2 = sv["w1"], sv["w2"], sv["ws"], sv["pack1"], sv["pack2"]
-    p, new_p, idx, ft = sv["p"], sv["new_p"], sv["idx"], sv["ft"]
+    w1, w2, ws = sv["w1"], sv["w2"], sv["ws"]
     has_skip = ws is not None
-
     lib = _lib.load()
-    # one zero-fill for every atomically accumulated buffer of the backward
-    nf = C_OUT * C_MID + B * N * C_MID * (2 if has_skip else 1)
-    accf = torch.zeros(nf, **f32)
-    g_w2 = accf[:C_OUT * C_MID]
-    o = C_OUT * C_MID
-    G = accf[o:o + B * N * C_MID]
-    o += B * N * C_MID
-    gip = accf[o:o + B * N * C_MID] if has_skip else None
-
-    goa = torch.empty(B, M, C_OUT, **f32)
-    prow = lib.apn_sa_bwd_prep_rows(B, M)
-    partS = torch.empty(prow, 128, **f32)
-    partWs = torch.empty(prow, C_OUT * C_IN, **f32) if has_skip else None
-    _call("apn_sa_bwd_prep", dev, B, N, M, g_out.data_ptr(), fw.out.data_ptr(), fw.relu,
-          sv["ysel"].data_ptr(), pack2.data_ptr(), sv["f"].data_ptr() if has_skip else None,
-          _ptr(sv["fidx"]) if has_skip else None, _ptr(ws), goa.data_ptr(), partS.data_ptr(),
-          _ptr(partWs), _ptr(gip))
-    d2e2 = torch.empty(2, C_OUT, **f32)
-    qm = torch.empty(C_MID, C_MID, **f32)
-    evec = torch.empty(C_MID, **f32)
-    g_g2 = torch.empty(C_OUT, **f32)
-    g_b2 = torch.empty(C_OUT, **f32)
-    pp, nr, sp, _k1 = _rows_or_sums(partS, 128, dev, sync)
-    _call("apn_sa_bwd_consts2", dev, pp, nr, sp, pack2.data_ptr(), w2.data_ptr(), float(P),
-          1 if fw.train2 else 0, d2e2.data_ptr(), qm.data_ptr(), evec.data_ptr(),
-          g_g2.data_ptr(), g_b2.data_ptr())
-    hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, fw.radius, p.data_ptr(), new_p.data_ptr(),
-           ft.data_ptr(), idx.data_ptr(), w1.data_ptr(), w2.data_ptr(), pack1.data_ptr(),
-           qm.data_ptr(), evec.data_ptr())
+    call = _Launcher(dev)
     rows = lib.apn_sa_grid_blocks(B, M)
-    partT = torch.empty(rows, 64, **f32)
-    _call("apn_sa_bwd_pass1", dev, *hdr, d2e2.data_ptr(), goa.data_ptr(), sv["ksel"].data_ptr(),
-          partT.data_ptr(), g_w2.data_ptr())
-    cabc = torch.empty(3, C_MID, **f32)
-    g_g1 = torch.empty(C_MID, **f32)
-    g_b1 = torch.empty(C_MID, **f32)
-    pp, nr, sp, _k2 = _rows_or_sums(partT, 64, dev, sync)
-    _call("apn_sa_bwd_consts1", dev, pp, nr, sp, pack1.data_ptr(), float(P),
-          1 if fw.train1 else 0, cabc.data_ptr(), g_g1.data_ptr(), g_b1.data_ptr())
-    H = torch.empty(B, M, C_MID, **f32)
-    _call("apn_sa_bwd_pass2", dev, *hdr, goa.data_ptr(), sv["ksel"].data_ptr(), cabc.data_ptr(),
-          G.data_ptr(), H.data_ptr())
-    # everything downstream of dL/dy1 is linear in G (per source point) and H (per query)
+    prow = lib.apn_sa_bwd_prep_rows(B, M)
+    wrows = lib.apn_sa_bwd_weight_rows(B, N)
+
+    # scratch: the zero-filled (atomically accumulated) region first, contiguous
+    zsizes = [("G", B * N * C_MID)] + ([("gip", B * N * C_MID)] if has_skip else [])
+    sizes = zsizes + [("goa", B * M * C_OUT), ("partS", prow * 128),
+                      ("partWs", prow * C_OUT * C_IN if has_skip else 0), ("partT", rows * 64),
+                      ("partW", wrows * 32 * 38), ("d2e2", 2 * C_OUT), ("qm", C_MID * C_MID),
+                      ("evec", C_MID), ("cabc", 3 * C_MID), ("H", B * M * C_MID)]
+    v, buf = _carve(dev, sizes)
+    zero_floats = sum((nfl + 63) // 64 * 64 for _, nfl in zsizes)
+    # small gradients in one buffer (kept alive by the parameters' .grad), g_w2 zero-filled
+    gsz = [("w2", C_OUT * C_MID), ("w1", C_MID * (C_IN + 3)), ("g1", C_MID), ("b1", C_MID),
+           ("g2", C_OUT), ("b2", C_OUT), ("ws", C_OUT * C_IN if has_skip else 0),
+           ("bs", C_OUT if (has_skip and sv["has_bs"]) else 0)]
+    g, _gbuf = _carve(dev, gsz, zero=True)
     g_f = torch.empty(B, C_IN, N, **f32)
     g_p = torch.zeros(B, N, 3, **f32) if need_p else None
     g_newp = torch.empty(B, M, 3, **f32) if need_newp else None
-    _call("apn_sa_bwd_input_grad", dev, B, N, M, G.data_ptr(), H.data_ptr(), w1.data_ptr(),
-          _ptr(gip), fw.radius, g_f.data_ptr(), _ptr(g_p), _ptr(g_newp))
-    wrows = lib.apn_sa_bwd_weight_rows(B, N)
-    partW = torch.empty(wrows, 32 * 38, **f32)
-    _call("apn_sa_bwd_weight_grad", dev, B, N, M, G.data_ptr(), H.data_ptr(), ft.data_ptr(),
-          p.data_ptr(), new_p.data_ptr(), partW.data_ptr())
-    g_w1 = torch.empty(C_MID, C_IN + 3, 1, 1, **f32)
-    g_ws = torch.empty(C_OUT, C_IN, 1, **f32) if has_skip else None
-    g_bs = torch.empty(C_OUT, **f32) if (has_skip and sv["has_bs"]) else None
+
+    def run(phases, sumsS=None, sumsT=None):
+        if PER_KERNEL_LAUNCH:
+            return _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, sumsS,
+                                        sumsT, g_f, g_p, g_newp, rows, prow, wrows, has_skip)
+        call("apn_sa_backward_seq", phases, B, N, M, fw.radius, sv["p"].data_ptr(),
+             sv["new_p"].data_ptr(), sv["f"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["fidx"]),
+             w1.data_ptr(), w2.data_ptr(), _ptr(ws), sv["ft"].data_ptr(), sv["pack1"].data_ptr(),
+             sv["pack2"].data_ptr(), sv["ysel"].data_ptr(), sv["ksel"].data_ptr(),
+             fw.out.data_ptr(), fw.relu, 1 if fw.train1 else 0, 1 if fw.train2 else 0, float(P),
+             g_out.data_ptr(), buf.data_ptr(), zero_floats * 4, g["w2"].data_ptr(),
+             v["G"].data_ptr(), v["gip"].data_ptr() if has_skip else None, v["goa"].data_ptr(),
+             v["partS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None,
+             v["partT"].data_ptr(), v["partW"].data_ptr(), _ptr(sumsS), _ptr(sumsT),
+             v["d2e2"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr(), v["cabc"].data_ptr(),
+             v["H"].data_ptr(), g_f.data_ptr(), _ptr(g_p), _ptr(g_newp), g["w1"].data_ptr(),
+             g["g1"].data_ptr(), g["b1"].data_ptr(), g["g2"].data_ptr(), g["b2"].data_ptr(),
+             g["ws"].data_ptr() if has_skip else None,
+             g["bs"].data_ptr() if (has_skip and sv["has_bs"]) else None)
+
+    if not _phased(sync):
+        run(7)
+    else:
+        run(1)
+        sS = _all_reduce_rows(call, v["partS"], prow, 128, dev)
+        run(2, sumsS=sS)
+        sT = _all_reduce_rows(call, v["partT"], rows, 64, dev)
+        run(4, sumsT=sT)
     # weight gradients are per-rank sums here; DistributedDataParallel averages them
-    _call("apn_sa_bwd_finalize", dev, partW.data_ptr(), wrows, fw.radius, g_w1.data_ptr(),
-          _ptr(partWs), prow, _ptr(g_ws), partS.data_ptr(), _ptr(g_bs))
-    return dict(f=g_f, p=g_p, new_p=g_newp, w1=g_w1, w2=g_w2.view(C_OUT, C_MID, 1, 1),
-                g1=g_g1, b1=g_b1, g2=g_g2, b2=g_b2,
-                ws=g_ws, bs=g_bs)
+    return dict(f=g_f, p=g_p, new_p=g_newp, w1=g["w1"].view(C_MID, C_IN + 3, 1, 1),
+                w2=g["w2"].view(C_OUT, C_MID, 1, 1), g1=g["g1"], b1=g["b1"], g2=g["g2"], b2=g["b2"],
+                ws=g["ws"].view(C_OUT, C_IN, 1) if has_skip else None,
+                bs=g["bs"] if (has_skip and sv["has_bs"]) else None)
+
+
+def _forward_per_kernel(call, phases, B, N, M, radius, p, new_p, f, idx, fidx, w1, w2, ws, bs, bn1a,
+                        bn2a, count, relu, v, sums1, sums2, out, rows):
+    """Python mirror of apn_sa_forward_seq (csrc/sa_seq.hip), one foreign call per kernel."""
+    hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, radius, p.data_ptr(), new_p.data_ptr(),
+           v["ft"].data_ptr(), idx.data_ptr(), w1.data_ptr())
+    if phases & 1:
+        call("apn_sa_prep_features", B, C_IN, N, f.data_ptr(), v["ft"].data_ptr())
+        if bn1a[7]:
+            call("apn_sa_fwd_stats1", *hdr, v["part1"].data_ptr())
+    if phases & 2:
+        call("apn_sa_bn_fold", None if sums1 is not None else v["part1"].data_ptr(), rows, _ptr(sums1),
+             C_MID, count, bn1a[0], bn1a[1], bn1a[5], bn1a[6], bn1a[2], bn1a[3], bn1a[4], bn1a[7],
+             v["pack1"].data_ptr(), bn2a[0], C_OUT, v["sgn2"].data_ptr())
+        call("apn_sa_fwd_main", *hdr, w2.data_ptr(), v["pack1"].data_ptr(),
+             v["pack1"].data_ptr() + 4 * C_MID, v["sgn2"].data_ptr(), v["ysel"].data_ptr(),
+             v["ksel"].data_ptr(), v["part2"].data_ptr())
+    if phases & 4:
+        call("apn_sa_bn_fold", None if sums2 is not None else v["part2"].data_ptr(), rows, _ptr(sums2),
+             C_OUT, count, bn2a[0], bn2a[1], bn2a[5], bn2a[6], bn2a[2], bn2a[3], bn2a[4], bn2a[7],
+             v["pack2"].data_ptr(), None, 0, None)
+        call("apn_sa_fwd_out", B, N, M, v["ysel"].data_ptr(), v["pack2"].data_ptr(),
+             f.data_ptr() if ws is not None else None, _ptr(fidx) if ws is not None else None,
+             _ptr(ws), _ptr(bs), relu, out.data_ptr())
+
+
+def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, sumsS, sumsT, g_f, g_p,
+                         g_newp, rows, prow, wrows, has_skip):
+    """Python mirror of apn_sa_backward_seq (csrc/sa_seq.hip), one foreign call per kernel."""
+    B, N, M = fw.dims
+    w1, w2, ws, P = sv["w1"], sv["w2"], sv["ws"], float(sv["count"])
+    gip = v["gip"].data_ptr() if has_skip else None
+    hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, fw.radius, sv["p"].data_ptr(), sv["new_p"].data_ptr(),
+           sv["ft"].data_ptr(), sv["idx"].data_ptr(), w1.data_ptr(), w2.data_ptr(),
+           sv["pack1"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr())
+    if phases & 1:
+        buf[:zero_floats].zero_()
+        call("apn_sa_bwd_prep", B, N, M, g_out.data_ptr(), fw.out.data_ptr(), fw.relu,
+             sv["ysel"].data_ptr(), sv["pack2"].data_ptr(), sv["f"].data_ptr() if has_skip else None,
+             _ptr(sv["fidx"]) if has_skip else None, _ptr(ws), v["goa"].data_ptr(),
+             v["partS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None, gip)
+    if phases & 2:
+        call("apn_sa_bwd_consts2", None if sumsS is not None else v["partS"].data_ptr(), prow,
+             _ptr(sumsS), sv["pack2"].data_ptr(), w2.data_ptr(), P, 1 if fw.train2 else 0,
+             v["d2e2"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr(), g["g2"].data_ptr(),
+             g["b2"].data_ptr())
+        call("apn_sa_bwd_pass1", *hdr, v["d2e2"].data_ptr(), v["goa"].data_ptr(),
+             sv["ksel"].data_ptr(), v["partT"].data_ptr(), g["w2"].data_ptr())
+    if phases & 4:
+        call("apn_sa_bwd_consts1", None if sumsT is not None else v["partT"].data_ptr(), rows,
+             _ptr(sumsT), sv["pack1"].data_ptr(), P, 1 if fw.train1 else 0, v["cabc"].data_ptr(),
+             g["g1"].data_ptr(), g["b1"].data_ptr())
+        call("apn_sa_bwd_pass2", *hdr, v["goa"].data_ptr(), sv["ksel"].data_ptr(),
+             v["cabc"].data_ptr(), v["G"].data_ptr(), v["H"].data_ptr())
+        call("apn_sa_bwd_input_grad", B, N, M, v["G"].data_ptr(), v["H"].data_ptr(), w1.data_ptr(), gip,
+             fw.radius, g_f.data_ptr(), _ptr(g_p), _ptr(g_newp))
+        call("apn_sa_bwd_weight_grad", B, N, M, v["G"].data_ptr(), v["H"].data_ptr(),
+             sv["ft"].data_ptr(), sv["p"].data_ptr(), sv["new_p"].data_ptr(), v["partW"].data_ptr())
+        call("apn_sa_bwd_finalize", v["partW"].data_ptr(), wrows, fw.radius, g["w1"].data_ptr(),
+             v["partWs"].data_ptr() if has_skip else None, prow,
+             g["ws"].data_ptr() if has_skip else None, v["partS"].data_ptr(),
+             g["bs"].data_ptr() if (has_skip and sv["has_bs"]) else None)
 
 
 class _GroupedMlpMax(torch.autograd.Function):
@@ -244,23 +355,58 @@ def grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2, sync_bn=Fa
                                 (radius, conv1, bn1, conv2, bn2, sync_bn))
 
 
+class Sampling:
+    """The index stage of a block: fidx (B,M) i32 = FPS picks, new_p (B,M,3) = p[fidx],
+    idx (B,M,K) i32 = ball-query neighbours.  It depends on the coordinates only -- never on
+    features or weights -- so it can be computed ahead of the feature path (another stream,
+    the next batch) and handed to `fused_set_abstraction(..., sampling=...)`.
+    The three tensors are views of ONE buffer, so a double-buffered pipeline rotates them
+    with a single copy."""
+
+    def __init__(self, B, M, K, device):
+        self.shape = (B, M, K)
+        self.buf = torch.empty(B * M * (1 + 3 + K), dtype=torch.int32, device=device)
+        o = 0
+        self.fidx = self.buf[o:o + B * M].view(B, M)
+        o += B * M
+        self.new_p = self.buf[o:o + B * M * 3].view(torch.float32).view(B, M, 3)
+        o += B * M * 3
+        self.idx = self.buf[o:o + B * M * K].view(B, M, K)
+
+
+@torch.no_grad()
+def sample_and_query(p, npoint, radius, nsample=K_NS, out=None):
+    """FPS (+ gather of the sampled coordinates, one launch; pointnext.py:146-147) and ball
+    query (group.py:245) on the current stream."""
+    p = p.contiguous()
+    dev = p.device
+    B, N, _ = p.shape
+    smp = out if out is not None else Sampling(B, npoint, nsample, dev)
+    assert smp.shape == (B, npoint, nsample)
+    call = _Launcher(dev)
+    if PER_KERNEL_LAUNCH:
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=dev)
+        call("apn_furthest_point_sampling_xyz", B, N, npoint, p.data_ptr(), temp.data_ptr(),
+             smp.fidx.data_ptr(), smp.new_p.data_ptr())
+        call("apn_ball_query_zero", B, N, npoint, float(radius), nsample, smp.new_p.data_ptr(),
+             p.data_ptr(), smp.idx.data_ptr())
+        return smp
+    temp = torch.empty(B, N, dtype=torch.float32, device=dev)       # filled with 1e10 by the call
+    call("apn_sa_sample_seq", B, N, npoint, float(radius), nsample, p.data_ptr(), temp.data_ptr(),
+         smp.fidx.data_ptr(), smp.new_p.data_ptr(), smp.idx.data_ptr())
+    return smp
+
+
 class _SetAbstraction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, f, w1, g1, b1, w2, g2, b2, ws, bs, mods):
-        npoint, radius, conv1, bn1, conv2, bn2, skip_conv, relu, sync_bn = mods
+        npoint, radius, conv1, bn1, conv2, bn2, skip_conv, relu, sync_bn, sampling = mods
         p = p.contiguous()
         f = f.contiguous()
-        dev = f.device
-        B, N, _ = p.shape
-        # FPS + gather of the sampled points in one launch (pointnext.py:146-147)
-        fidx = torch.empty(B, npoint, dtype=torch.int32, device=dev)
-        new_p = torch.empty(B, npoint, 3, dtype=torch.float32, device=dev)
-        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=dev)
-        _call("apn_furthest_point_sampling_xyz", dev, B, N, npoint, p.data_ptr(), temp.data_ptr(),
-              fidx.data_ptr(), new_p.data_ptr())
-        idx = torch.empty(B, npoint, K_NS, dtype=torch.int32, device=dev)
-        _call("apn_ball_query_zero", dev, B, N, npoint, float(radius), K_NS, new_p.data_ptr(),
-              p.data_ptr(), idx.data_ptr())
+        smp = sampling if sampling is not None else sample_and_query(p, npoint, radius)
+        fidx, new_p, idx = smp.fidx, smp.new_p, smp.idx
+        if p.requires_grad:
+            new_p = new_p.clone()          # returned as a differentiable output
         fw = _Forward(p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
                       sync_bn)
         ctx.fw = fw
@@ -286,11 +432,13 @@ class _SetAbstraction(torch.autograd.Function):
 
 
 def fused_set_abstraction(p, f, npoint, radius, conv1, bn1, conv2, bn2, skip_conv=None, relu=True,
-                          sync_bn=False):
-    """(new_p (B,npoint,3), out (B,64,npoint)) of a PointNeXt set-abstraction block."""
+                          sync_bn=False, sampling=None):
+    """(new_p (B,npoint,3), out (B,64,npoint)) of a PointNeXt set-abstraction block.
+    `sampling`: a precomputed `Sampling` of p (same npoint / radius), else computed here."""
     assert skip_conv is None or isinstance(skip_conv, nn.Conv1d)
     ws = skip_conv.weight if skip_conv is not None else None
     bs = skip_conv.bias if skip_conv is not None else None
     return _SetAbstraction.apply(p, f, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight,
                                  bn2.bias, ws, bs,
-                                 (npoint, radius, conv1, bn1, conv2, bn2, skip_conv, relu, sync_bn))
+                                 (npoint, radius, conv1, bn1, conv2, bn2, skip_conv, relu, sync_bn,
+                                  sampling))

@@ -115,7 +115,13 @@ class SetAbstraction(nn.Module):
             return None
         return blk1[0], blk1[1], blk2[0], blk2[1], len(blk2) == 3
 
-    def _fused_block(self, p, f):
+    def sample(self, p, out=None):
+        """The block's index stage alone (FPS + ball query) -> adaptpoint_amd.fused.Sampling."""
+        from . import fused
+        return fused.sample_and_query(p, p.shape[1] // self.stride, self.grouper.radius,
+                                      self.grouper.nsample, out=out)
+
+    def _fused_block(self, p, f, sampling=None):
         """The whole block (FPS, ball query, grouped MLP, pool, skip, ReLU) through
         adaptpoint_amd.fused, or None when the configuration / shapes are not covered."""
         from . import fused
@@ -135,7 +141,8 @@ class SetAbstraction(nn.Module):
         else:
             relu = relu_after
         return fused.fused_set_abstraction(p, f, p.shape[1] // self.stride, g.radius, conv1, bn1,
-                                           conv2, bn2, skip, relu, sync_bn=self.sync_bn)
+                                           conv2, bn2, skip, relu, sync_bn=self.sync_bn,
+                                           sampling=sampling)
 
     def _fused_forward(self, new_p, p, f):
         """max_K convs(cat[dp, f[idx]]) through the fused kernels, or None if unsupported."""
@@ -159,14 +166,16 @@ class SetAbstraction(nn.Module):
     def pool(x):
         return torch.max(x, dim=-1, keepdim=False)[0]
 
-    def forward(self, pf):
+    def forward(self, pf, sampling=None):
         p, f = pf
         if self.is_head:
             return p, self.convs(f)
         if self.fused:
-            res = self._fused_block(p, f)
+            res = self._fused_block(p, f, sampling)
             if res is not None:
                 return res
+        if sampling is not None:
+            raise NotImplementedError("a precomputed sampling needs the fused block path")
         if not self.all_aggr:
             idx = self.sample_fn(p, p.shape[1] // self.stride).long()
             new_p = torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))

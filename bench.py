@@ -123,21 +123,23 @@ def instrument(timer, only=None):
 
     from adaptpoint_amd import fused
     orig_call = fused._call
+    fused.PER_KERNEL_LAUNCH = True        # one foreign call per kernel, so each can carry events
 
     alias = {"furthest_point_sampling_xyz": "fps", "ball_query_zero": "ball_query"}
 
-    def fused_call(name, dev, *a):
+    def fused_call(name, dev, *a, **kw):
         short = name.replace("apn_", "")
         short = alias.get(short, short)
         if only is not None and short not in only:
-            return orig_call(name, dev, *a)
-        return timer.wrap(short, orig_call)(name, dev, *a)
+            return orig_call(name, dev, *a, **kw)
+        return timer.wrap(short, orig_call)(name, dev, *a, **kw)
     fused._call = fused_call
 
     def restore():
         for k, v in saved.items():
             setattr(ops, k, v)
         fused._call = orig_call
+        fused.PER_KERNEL_LAUNCH = False
     return restore
 
 
@@ -179,6 +181,10 @@ def main():
     ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="auto",
                     help="SyncBatchNorm at world_size>1 (auto = on, as the reference)")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--pipeline", choices=["on", "off"], default="on",
+                    help="software-pipeline the index stage: FPS + ball query of batch k+1 run on "
+                         "a second HIP stream beside the MLP forward+backward of batch k (the "
+                         "index stage depends on coordinates only); fused path only")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from a captured HIP graph (auto: on at 1 GPU)")
     ap.add_argument("--mlp", choices=["fused-bf16", "torch-f32"], default="fused-bf16",
@@ -188,7 +194,10 @@ def main():
 
     from adaptpoint_amd import dp
     world, rank, local_rank = dp.env_world()
-    distributed = world > 1
+    # APN_BENCH_FORCE_DISTRIBUTED=1: take the N>1 code path (process group, DDP, SyncBatchNorm
+    # phases, eager launch) even at world_size 1 -- lets a one-GPU box exercise it.
+    force_dist = os.environ.get("APN_BENCH_FORCE_DISTRIBUTED") == "1"
+    distributed = world > 1 or force_dist
     if distributed and args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not distributed and args.gpus != 1:
@@ -200,7 +209,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dp.init(args.backend, dev)
+    dp.init(args.backend, dev, force=force_dist)
+    if force_dist:
+        from adaptpoint_amd import fused as _fused
+        _fused.FORCE_PHASED = True
 
     torch.manual_seed(0)                          # identical initial weights on every rank
     sync_bn = distributed and args.sync_bn != "off"
@@ -218,13 +230,33 @@ def main():
     f = f.to(dev).requires_grad_(True)
     params = [q for q in blk.parameters()]
 
+    # the two-stream pipeline pays only when the step is GPU-bound, i.e. under graph replay
+    pipelined = fused_mlp and args.pipeline == "on" and not distributed
+    if pipelined:
+        from adaptpoint_amd.fused import Sampling
+        side_stream = torch.cuda.Stream()
+        cur_smp = blk.sample(p)                       # prologue: index stage of batch 0
+        nxt_smp = Sampling(*cur_smp.shape, dev)
+
+    def fwd_bwd():
+        if not pipelined:
+            new_p, out = model([p, f])
+            out.sum().backward()
+            return
+        main = torch.cuda.current_stream()
+        side_stream.wait_stream(main)                 # fork
+        with torch.cuda.stream(side_stream):
+            blk.sample(p, out=nxt_smp)                # index stage of batch k+1 (32 CUs busy)
+        new_p, out = model([p, f], sampling=cur_smp)  # MLP forward+backward of batch k
+        out.sum().backward()
+        main.wait_stream(side_stream)                 # join
+        cur_smp.buf.copy_(nxt_smp.buf)                # rotate the double buffer (2.3 MB)
+
     def step():
         f.grad = None
         for q in params:
             q.grad = None
-        new_p, out = model([p, f])
-        out.sum().backward()
-        return out
+        fwd_bwd()
 
     use_graph = (args.graph == "on") or (args.graph == "auto" and not distributed)
     eager_step = step
@@ -242,26 +274,20 @@ def main():
             q.grad = None
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            new_p_, out_ = model([p, f])
-            out_.sum().backward()
+            fwd_bwd()
         step = graph.replay
 
-    timer = KernelTimer()
-    restore = instrument(timer, only={"fps"} if not use_graph else set())
     # W warm-up steps, barrier + synchronize, K timed steps, barrier + synchronize, MAX over ranks
     elapsed = dp.timed_steps(step, args.steps, args.warmup, dev)
-    restore()
-    if use_graph:
-        # launches inside a graph cannot carry per-kernel events: time the same launch, same
-        # inputs, eagerly on the same stream right after the timed region
-        t2 = KernelTimer()
-        r2 = instrument(t2, only={"fps"})
-        for _ in range(20):
-            eager_step()
-        r2()
-        fps_us = t2.mean_us()["fps"]
-    else:
-        fps_us = timer.mean_us()["fps"]           # includes the warm-up launches (same kernel)
+    # The timed step issues whole launch sequences (one C call per direction, or one hipGraph),
+    # which cannot carry per-kernel events.  The dominant kernel is therefore timed right after
+    # the timed region: the same launch, same inputs, same stream, HIP events around it.
+    t2 = KernelTimer()
+    r2 = instrument(t2, only={"fps"})
+    for _ in range(20):
+        eager_step()
+    r2()
+    fps_us = t2.mean_us()["fps"]
 
     # per-kernel view (un-timed extra pass): events around every extension launch
     timer_all = KernelTimer()
@@ -309,6 +335,8 @@ def main():
                    "mlp": ("fused bf16 MFMA (f32 accumulate, f32 BatchNorm statistics)" if fused_mlp
                            else "unfused: extension ops + PyTorch fp32 conv/BN"),
                    "launch": "hipGraph replay" if use_graph else "eager",
+                   "pipeline": ("index stage (FPS + ball query) of batch k+1 on a second stream "
+                                "beside the MLP fwd+bwd of batch k" if pipelined else "none"),
                    "global_batch": B_PER_GPU * world,
                    "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else "")},
         "roofline": roofline,

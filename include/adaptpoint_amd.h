@@ -24,6 +24,8 @@
 #ifndef ADAPTPOINT_AMD_H
 #define ADAPTPOINT_AMD_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -230,6 +232,37 @@ APN_API int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const fl
 APN_API int apn_sa_bwd_finalize(const float *partW, int rows_w, float radius, float *g_w1,
                                 const float *partWs, int rows_s, float *g_ws,
                                 const float *partS, float *g_bs, void *stream);
+
+/* Whole-direction launch sequences (csrc/sa_seq.hip): the same kernels as above, enqueued
+ * back-to-back by ONE call so that an eager step stays GPU-bound.  `phases` (bit mask
+ * 1|2|4) selects the part to enqueue, so a caller can all-reduce the BatchNorm sums between
+ * phases (SyncBatchNorm): forward 1 = prep+stats1, 2 = fold1+main, 4 = fold2+out; backward
+ * 1 = zero+prep, 2 = consts2+pass1, 4 = consts1+pass2+input/weight grads+finalize.
+ * sums* (float64, reduced over ranks) replace the partial rows when non-NULL. */
+APN_API int apn_sa_forward_seq(
+    int phases, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
+    const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
+    const float *ws, const float *bs,
+    const float *g1, const float *b1, float *rm1, float *rv1, void *nbt1, float eps1, float mom1,
+    int train1,
+    const float *g2, const float *b2, float *rm2, float *rv2, void *nbt2, float eps2, float mom2,
+    int train2,
+    double count, int relu, void *ft, float *part1, float *part2, const double *sums1,
+    const double *sums2, float *pack1, float *pack2, float *sgn2, float *ysel, void *ksel,
+    float *out, void *stream);
+APN_API int apn_sa_backward_seq(
+    int phases, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
+    const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
+    const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
+    const void *ksel, const float *out, int relu, int train1, int train2, double count,
+    const float *g_out, float *zero_base, size_t zero_bytes, float *g_w2, float *G, float *gip,
+    float *goa, float *partS, float *partWs, float *partT, float *partW, const double *sumsS,
+    const double *sumsT, float *d2e2, float *qm, float *evec, float *cabc, float *H,
+    float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_g1, float *g_b1, float *g_g2,
+    float *g_b2, float *g_ws, float *g_bs, void *stream);
+/* Index stage: temp := 1e10, FPS (+ sampled coordinates), ball query (zero-filling). */
+APN_API int apn_sa_sample_seq(int b, int n, int m, float radius, int nsample, const float *xyz,
+                              float *temp, int *fidx, float *new_xyz, int *idx, void *stream);
 
 /* Tuning / diagnostic hook, NOT part of the reference boundary: force the number
  * of wavefronts that cooperate on one cloud in apn_furthest_point_sampling

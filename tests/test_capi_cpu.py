@@ -54,6 +54,8 @@ def test_ctypes_signatures_match_header_arity():
                 assert at is ctypes.c_float, (name, decl)
             elif decl.startswith("double"):
                 assert at is ctypes.c_double, (name, decl)
+            elif decl.startswith("size_t"):
+                assert at is ctypes.c_size_t, (name, decl)
             else:
                 assert at is ctypes.c_int, (name, decl)
 

@@ -1,0 +1,27 @@
+"""GPU test of the N>1 code path of bench.py on ONE GPU: a world_size-1 NCCL (= RCCL) process
+group, DistributedDataParallel around the fused block, SyncBatchNorm semantics switched on.
+(Real multi-rank RCCL cannot be exercised on a one-GPU box; the sharding / averaging logic is
+covered at world_size 2 over gloo in test_dp_gloo_cpu.py.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_distributed_path_world1(dev):
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29731", APN_BENCH_FORCE_DISTRIBUTED="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10",
+                          "--warmup", "3", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert "syncbn" in d["config"]["parallelism"]
+    assert d["config"]["launch"] == "eager"

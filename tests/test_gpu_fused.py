@@ -197,3 +197,57 @@ def test_fused_block_eval_mode_and_xyz_grad(dev):
     sd_a, sd_b = a.state_dict(), b.state_dict()
     for k in sd_a:                     # eval mode: no buffer moved
         assert torch.equal(sd_a[k], sd_b[k]), k
+
+
+def test_phased_syncbn_path_equals_single_call(dev):
+    """The SyncBatchNorm code path (three phases per direction, float64 row sums handed to the
+    consumers instead of partial rows) gives the same numbers as the single-call path."""
+    from adaptpoint_amd import fused
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    kw = dict(layers=2, stride=2, group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32,
+                                              'normalize_dp': True},
+              norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+              use_res=True, fused=True)
+    torch.manual_seed(2)
+    a = SetAbstraction(32, 64, **kw).to(dev)
+    b = SetAbstraction(32, 64, sync_bn=True, **kw).to(dev)
+    b.load_state_dict(a.state_dict())
+    p = torch.from_numpy(GI.unit_sphere_cloud(4, 1024, seed=8)).to(dev)
+    f1 = torch.from_numpy(GI.seeded_normal((4, 32, 1024), seed=9)).to(dev).requires_grad_(True)
+    f2 = f1.detach().clone().requires_grad_(True)
+    _, oa = a([p, f1]); oa.sum().backward()
+    try:
+        fused.FORCE_PHASED = True
+        _, ob = b([p, f2]); ob.sum().backward()
+    finally:
+        fused.FORCE_PHASED = False
+    assert torch.allclose(oa, ob, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(f1.grad, f2.grad, rtol=1e-4, atol=1e-6)
+    for (k, qa), (_, qb) in zip(a.named_parameters(), b.named_parameters()):
+        assert _rel(qb.grad, qa.grad) <= 1e-4, k     # max-norm relative; g_w2 sums by float atomics
+    for (k, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.allclose(ba.float(), bb.float(), rtol=1e-6, atol=1e-7), k
+
+
+def test_per_kernel_diagnostic_path_equals_sequences(dev):
+    from adaptpoint_amd import fused
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    kw = dict(layers=2, stride=2, group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32,
+                                              'normalize_dp': True},
+              norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+              use_res=True, fused=True)
+    torch.manual_seed(3)
+    a = SetAbstraction(32, 64, **kw).to(dev)
+    b = SetAbstraction(32, 64, **kw).to(dev)
+    b.load_state_dict(a.state_dict())
+    p = torch.from_numpy(GI.unit_sphere_cloud(2, 1024, seed=8)).to(dev)
+    f1 = torch.from_numpy(GI.seeded_normal((2, 32, 1024), seed=9)).to(dev).requires_grad_(True)
+    f2 = f1.detach().clone().requires_grad_(True)
+    _, oa = a([p, f1]); oa.sum().backward()
+    try:
+        fused.PER_KERNEL_LAUNCH = True
+        _, ob = b([p, f2]); ob.sum().backward()
+    finally:
+        fused.PER_KERNEL_LAUNCH = False
+    assert torch.equal(oa, ob)
+    assert torch.allclose(f1.grad, f2.grad, rtol=1e-4, atol=1e-6)
