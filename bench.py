@@ -60,7 +60,8 @@ def make_inputs(batch, seed):
 def algorithmic_bytes(batch):
     mk = NPOINT * NSAMPLE
     return {
-        "fps": batch * (N_PTS * 12 + NPOINT * 4),                          # xyz in, idx out
+        # xyz in, temp in+out (the reference's scratch, part of its contract), idx + sampled xyz out
+        "fps": batch * (N_PTS * 12 + 2 * N_PTS * 4 + NPOINT * 4 + NPOINT * 12),
         "ball_query": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4),         # xyz, queries, idx out
         "group_xyz": batch * (3 * N_PTS * 4 + mk * 4 + 3 * mk * 4),        # rows, idx, out
         "group_feat": batch * (C_IN * N_PTS * 4 + mk * 4 + C_IN * mk * 4),
@@ -143,7 +144,7 @@ def instrument(timer, only=None):
     return restore
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=15.0):
     """The oracle port of the same block on the host cores: bounded sample."""
     from oracle import cpu_block as CB
     from oracle import oracle as O
@@ -162,7 +163,7 @@ def cpu_baseline(seconds_budget=20.0):
         CB.run_step(blk, p, f)
         iters += 1
         el = time.perf_counter() - t0
-        if el >= seconds_budget or iters >= 10:
+        if el >= seconds_budget or iters >= 60:
             break
     return {"value": B_PER_GPU * iters / el, "unit": "point-clouds/s", "cores": threads,
             "kind": "port",
@@ -308,12 +309,20 @@ def main():
             ent["achieved_GBps"] = round(ab[k] / us * 1e-3, 2)
             ent["frac_hbm"] = round(ab[k] / us * 1e-3 / HBM_PEAK_GBS, 5)
         kernels[k] = ent
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):       # PMC-measured HBM bytes per launch (rocprofv3 --pmc, committed)
+        traffic = json.load(open(tpath)).get("bytes_per_launch", {})
+    for k, ent in kernels.items():
+        if k in traffic:
+            ent["traffic_bytes_pmc"] = traffic[k]
     dominant = max(per_kernel_us, key=per_kernel_us.get)
     dom_us = fps_us if dominant == "fps" else per_kernel_us[dominant]
     achieved = ab.get(dominant, 0) / dom_us * 1e-3
     roofline = {
         "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+        "traffic": traffic.get(dominant),
         "avg_launch_us": round(dom_us, 2),
         "note": ("FPS is a serial chain of npoint-1 dependent arg-max steps on B workgroups; its "
                  "bound is per-step latency, not HBM or MFMA (DESIGN.md). step_ns = avg launch "
