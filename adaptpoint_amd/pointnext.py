@@ -1,0 +1,135 @@
+"""PointNeXt-S classifier over the gfx950 set-abstraction blocks.
+
+Host-side mirror of the model `cfgs/scanobjectnn/pointnext-s.yaml:5-36` builds in the reference:
+`BaseCls` (openpoints/models/classification/cls_base.py:13-39) = `PointNextEncoder`
+(openpoints/models/backbone/pointnext.py:312-441; blocks [1]*6, so every stage is one
+SetAbstraction and no InvResMLP exists) + `ClsHead` (cls_base.py:78-136).  Module nesting and
+names match the reference (`encoder.encoder.<stage>.0....`, `prediction.head.<i>....`), so a
+reference state_dict loads unchanged.  Stage 1 (1024 -> 512 points, 32 -> 64 channels) has the
+shape the fused kernels cover; the other stages run the unfused extension operators + PyTorch.
+"""
+import torch
+import torch.nn as nn
+
+from .set_abstraction import SetAbstraction
+
+
+class PointNextEncoderS(nn.Module):
+    """pointnext.py:338-441 for sa_layers=2, sa_use_res=True, one block per stage."""
+
+    def __init__(self, in_channels=4, width=32, strides=(1, 2, 2, 2, 2, 1), radius=0.15,
+                 radius_scaling=1.5, nsample=32, fused=False, sync_bn=False):
+        super().__init__()
+        self.strides = list(strides)
+        # _to_full_list (pointnext.py:389-407): the radius grows after every down-sampling stage
+        radii, r = [], radius
+        for s in self.strides:
+            radii.append(r)
+            if s != 1:
+                r *= radius_scaling
+        channels = []
+        for s in self.strides:
+            if s != 1:
+                width *= 2
+            channels.append(width)
+        stages, cin = [], in_channels
+        for i, (s, c) in enumerate(zip(self.strides, channels)):
+            is_head = i == 0 and s == 1
+            sa = SetAbstraction(cin, c, layers=1 if is_head else 2, stride=s,
+                                group_args={'NAME': 'ballquery', 'radius': radii[i], 'nsample': nsample,
+                                            'normalize_dp': True},
+                                norm_args={'norm': 'bn'}, act_args={'act': 'relu'},
+                                conv_args={'order': 'conv-norm-act'}, sampler='fps',
+                                feature_type='dp_fj', use_res=True, is_head=is_head,
+                                fused=fused, sync_bn=sync_bn)
+            stages.append(nn.Sequential(sa))
+            cin = c
+        self.encoder = nn.Sequential(*stages)
+        self.out_channels = channels[-1]
+        self.radii = radii
+
+    def forward_cls_feat(self, p0, f0=None):
+        if hasattr(p0, 'keys'):
+            p0, f0 = p0['pos'], p0.get('x', None)
+        if f0 is None:
+            f0 = p0.clone().transpose(1, 2).contiguous()
+        for stage in self.encoder:
+            p0, f0 = stage[0]([p0, f0])
+        return f0.squeeze(-1)
+
+
+class ClsHead(nn.Module):
+    """cls_base.py:78-136 with mlps [512, 256], BatchNorm1d, ReLU, dropout 0.5."""
+
+    def __init__(self, num_classes=15, in_channels=512, mlps=(512, 256), dropout=0.5):
+        super().__init__()
+        dims = [in_channels] + list(mlps) + [num_classes]
+        heads = []
+        for i in range(len(dims) - 2):
+            heads.append(nn.Sequential(nn.Linear(dims[i], dims[i + 1], bias=False),
+                                       nn.BatchNorm1d(dims[i + 1]), nn.ReLU(inplace=True)))
+            if dropout:
+                heads.append(nn.Dropout(dropout))
+        heads.append(nn.Sequential(nn.Linear(dims[-2], dims[-1])))
+        self.head = nn.Sequential(*heads)
+
+    def forward(self, x):
+        return self.head(x)
+
+
+class SmoothCrossEntropy(nn.Module):
+    """openpoints/loss/build.py:12-66 (label_smoothing > 0 branch, no ignore_index/weight)."""
+
+    def __init__(self, label_smoothing=0.3):
+        super().__init__()
+        self.label_smoothing = label_smoothing
+
+    def forward(self, pred, gt):
+        n_class = pred.size(1)
+        one_hot = torch.zeros_like(pred).scatter(1, gt.view(-1, 1), 1)
+        one_hot = one_hot * (1 - self.label_smoothing) + (1 - one_hot) * self.label_smoothing / (n_class - 1)
+        return -(one_hot * torch.log_softmax(pred, dim=1)).sum(dim=1).mean()
+
+
+class PointNextSClassifier(nn.Module):
+    """BaseCls for cfgs/scanobjectnn/pointnext-s.yaml (+ criterion of cfgs/scanobjectnn/default.yaml:36-38)."""
+
+    def __init__(self, num_classes=15, fused=False, sync_bn=False):
+        super().__init__()
+        self.encoder = PointNextEncoderS(fused=fused, sync_bn=sync_bn)
+        self.prediction = ClsHead(num_classes, self.encoder.out_channels)
+        self.criterion = SmoothCrossEntropy(0.3)
+
+    def forward(self, data):
+        return self.prediction(self.encoder.forward_cls_feat(data))
+
+    def get_logits_loss(self, data, gt):
+        logits = self.forward(data)
+        return logits, self.criterion(logits, gt.long())
+
+
+def fill_parameters_by_name(model, scale=0.08):
+    """Deterministic, construction-order independent weights: every tensor of the state_dict is
+    drawn from a generator seeded by its NAME.  Used so that the reference model (imported in the
+    build container to make goldens) and this mirror hold identical weights without shipping a
+    5 MB state_dict."""
+    import zlib
+    sd = model.state_dict()
+    with torch.no_grad():
+        for name, t in sd.items():
+            g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+            if name.endswith('num_batches_tracked'):
+                continue
+            if name.endswith('running_var'):
+                v = 0.5 + torch.rand(t.shape, generator=g)
+            elif name.endswith('running_mean'):
+                v = 0.1 * torch.randn(t.shape, generator=g)
+            elif t.dim() == 1 and name.endswith('weight'):          # norm gamma
+                v = 0.75 + 0.5 * torch.rand(t.shape, generator=g)
+            elif t.dim() == 1:                                        # biases
+                v = 0.05 * torch.randn(t.shape, generator=g)
+            else:
+                fan_in = t[0].numel()
+                v = torch.randn(t.shape, generator=g) * (1.0 / fan_in) ** 0.5
+            t.copy_(v.to(t.dtype))
+    return model

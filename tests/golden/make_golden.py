@@ -257,6 +257,45 @@ def main():
     out["g4_qg_dp"] = dp.numpy()
     out["g4_qg_fj_checksum"] = np.array([fj.double().sum().item(), fj.double().abs().sum().item()])
 
+    # ---- G5: the full PointNeXt-S classifier (BASELINE configs[2]) ---------------------
+    import openpoints.models.classification.cls_base as ref_cls
+    import openpoints.models.backbone.pointnext as ref_pn
+    from adaptpoint_amd.pointnext import fill_parameters_by_name
+    enc = ref_pn.PointNextEncoder(in_channels=4, width=32, blocks=[1, 1, 1, 1, 1, 1],
+                                  strides=[1, 2, 2, 2, 2, 1], sa_layers=2, sa_use_res=True,
+                                  radius=0.15, radius_scaling=1.5, nsample=32, expansion=4,
+                                  aggr_args={'feature_type': 'dp_fj', 'reduction': 'max'},
+                                  group_args=EasyDict(NAME='ballquery', normalize_dp=True),
+                                  conv_args={'order': 'conv-norm-act'}, act_args={'act': 'relu'},
+                                  norm_args={'norm': 'bn'})
+    head = ref_cls.ClsHead(num_classes=15, in_channels=enc.out_channels, mlps=[512, 256],
+                           norm_args={'norm': 'bn1d'})
+    class _Cls(torch.nn.Module):          # BaseCls without the registry/config machinery
+        def __init__(self):
+            super().__init__()
+            self.encoder, self.prediction = enc, head
+        def forward(self, data):
+            return self.prediction(self.encoder.forward_cls_feat(data))
+    ref_model = fill_parameters_by_name(_Cls())
+    assert sum(q.numel() for q in ref_model.parameters()) == 1367119     # pointnext-s.yaml:1-3
+    out["g5_state_keys"] = np.array(sorted(ref_model.state_dict().keys()))
+    pos = _t(GI.unit_sphere_cloud(2, 1024, seed=31))
+    x = torch.cat([pos, pos[:, :, 1:2] - pos[:, :, 1:2].min(1, keepdim=True)[0]], -1).transpose(1, 2).contiguous()
+    ref_model.eval()
+    with torch.no_grad():
+        out["g5_logits_eval"] = ref_model({'pos': pos, 'x': x}).numpy()
+    ref_model.train()
+    for mod in ref_model.modules():       # dropout off: the only RNG in the forward
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    pos_t = pos.clone()
+    xt = x.clone().requires_grad_(True)
+    logits = ref_model({'pos': pos_t, 'x': xt})
+    logits.square().sum().backward()
+    out["g5_logits_train"] = logits.detach().numpy()
+    out["g5_grad_x_checksum"] = np.array([xt.grad.double().sum().item(), xt.grad.double().abs().sum().item()])
+    out["g5_grad_stem_w"] = ref_model.encoder.encoder[0][0].convs[0][0].weight.grad.numpy()
+
     path = os.path.join(HERE, "pointnet2_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
