@@ -64,16 +64,49 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ bf16x8 pack8(const f32x16 &v, int base) {
-    bf16x8 o;
+// Operand precision.  NS = 1: operands rounded to bf16 (8 significant bits).  NS = 2: every
+// f32 operand is split into hi + lo bf16 parts (16 significant bits) and a product is three
+// MFMAs, hi*hi + hi*lo + lo*hi ("bf16x3"; the dropped lo*lo term is 2^-18 relative): the
+// contraction then agrees with an fp32 one to ~1e-5 at 3x the (small) MFMA cost.
+template <int NS>
+struct Frag {
+    bf16x8 p[NS];
+};
+
+template <int NS>
+__device__ __forceinline__ Frag<NS> make_frag(const float (&v)[8]) {
+    Frag<NS> o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[base + j];
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 hi = (__bf16)v[j];
+        o.p[0][j] = hi;
+        if (NS == 2) o.p[NS - 1][j] = (__bf16)(v[j] - (float)hi);
+    }
     return o;
 }
 
+template <int NS>
+__device__ __forceinline__ Frag<NS> pack8(const f32x16 &v, int base) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = v[base + j];
+    return make_frag<NS>(t);
+}
+
+template <int NS>
+__device__ __forceinline__ f32x16 mfma(const Frag<NS> &a, const Frag<NS> &b, f32x16 c) {
+    if (NS == 2) {                       // small terms first, the hi*hi term last
+        c = mfma(a.p[NS - 1], b.p[0], c);
+        c = mfma(a.p[0], b.p[NS - 1], c);
+    }
+    return mfma(a.p[0], b.p[0], c);
+}
+
 // (B,C,N) f32 channel-major  ->  (B,N,C) bf16 point-major, C = 32: one 64-byte row per point.
+// ft_lo (optional): the bf16 remainder f - float(ft), for the split-operand mode.
 __global__ __launch_bounds__(256) void sa_prep_features_kernel(int n, const float *__restrict__ f,
-                                                               __bf16 *__restrict__ ft) {
+                                                               __bf16 *__restrict__ ft,
+                                                               __bf16 *__restrict__ ft_lo) {
     __shared__ float tile[SA_C][65];
     const int cloud = blockIdx.y;
     const int n0 = blockIdx.x * 64;
@@ -86,10 +119,14 @@ __global__ __launch_bounds__(256) void sa_prep_features_kernel(int n, const floa
     // 64 points x 32 channels: thread -> (point = tid>>2, 8 channels = (tid&3)*8)
     const int pt = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 8;
     if (n0 + pt < n) {
-        bf16x8 o;
+        bf16x8 o, ol;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)tile[c0 + j][pt];
+        for (int j = 0; j < 8; ++j) {
+            o[j] = (__bf16)tile[c0 + j][pt];
+            ol[j] = (__bf16)(tile[c0 + j][pt] - (float)o[j]);
+        }
         *reinterpret_cast<bf16x8 *>(ft + ((size_t)cloud * n + n0 + pt) * SA_C + c0) = o;
+        if (ft_lo) *reinterpret_cast<bf16x8 *>(ft_lo + ((size_t)cloud * n + n0 + pt) * SA_C + c0) = ol;
     }
 }
 
@@ -98,6 +135,7 @@ struct SaArgs {
     const float *xyz;            // (B,N,3)
     const float *new_xyz;        // (B,M,3)
     const __bf16 *ft;            // (B,N,32) bf16
+    const __bf16 *ft_lo;         // (B,N,32) bf16 remainders (split-operand mode), else null
     const int *idx;              // (B,M,32)
     const float *w1;             // (32, 35): columns [dp(3), f(32)] as the reference's cat([dp, fj])
     float radius;
@@ -105,38 +143,46 @@ struct SaArgs {
 
 // Per-wave constant operand fragments of conv1: lane (r = mid channel, h), step s,
 // element j  <->  input channel k = 16 s + 8 h + j: features 0..31, then dp x,y,z.
+template <int NS>
 __device__ __forceinline__ void load_w1_frags(const float *__restrict__ w1, int r, int h,
-                                              bf16x8 (&wf)[3]) {
+                                              Frag<NS> (&wf)[3]) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 3; ++s) {
+        float t[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wf[s][j] = (__bf16)w1[r * 35 + 3 + 16 * s + 8 * h + j];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wf[2][j] = (__bf16)((h == 0 && j < 3) ? w1[r * 35 + j] : 0.0f);
+        for (int j = 0; j < 8; ++j)
+            t[j] = s < 2 ? w1[r * 35 + 3 + 16 * s + 8 * h + j]
+                         : ((h == 0 && j < 3) ? w1[r * 35 + j] : 0.0f);
+        wf[s] = make_frag<NS>(t);
+    }
 }
 
-// Gather one tile: lane (pos, h) fetches 2 x 16 bytes of its neighbour's bf16 row,
-// and (h = 0) the normalised relative position.
+// Gather one tile: lane (pos, h) fetches 2 x 16 bytes of its neighbour's bf16 row (and of
+// the remainder row in split mode), and (h = 0) the normalised relative position.
+template <int NS>
 __device__ __forceinline__ void gather_tile(const SaArgs &a, int tile, int pos, int h,
-                                            bf16x8 (&x)[3]) {
+                                            Frag<NS> (&x)[3]) {
     const int cloud = tile / a.m;
     const int nb = a.idx[(size_t)tile * SA_K + pos];
-    const uint4 *row = reinterpret_cast<const uint4 *>(a.ft + ((size_t)cloud * a.n + nb) * SA_C);
-    const uint4 c0 = row[h], c1 = row[2 + h];
-    x[0] = __builtin_bit_cast(bf16x8, c0);
-    x[1] = __builtin_bit_cast(bf16x8, c1);
+    const size_t rowoff = ((size_t)cloud * a.n + nb) * SA_C;
+    const uint4 *row = reinterpret_cast<const uint4 *>(a.ft + rowoff);
+    x[0].p[0] = __builtin_bit_cast(bf16x8, row[h]);
+    x[1].p[0] = __builtin_bit_cast(bf16x8, row[2 + h]);
+    if (NS == 2) {
+        const uint4 *rl = reinterpret_cast<const uint4 *>(a.ft_lo + rowoff);
+        x[0].p[NS - 1] = __builtin_bit_cast(bf16x8, rl[h]);
+        x[1].p[NS - 1] = __builtin_bit_cast(bf16x8, rl[2 + h]);
+    }
     const float *q = a.new_xyz + (size_t)tile * 3;           // wave-uniform
     const float *p = a.xyz + ((size_t)cloud * a.n + nb) * 3;
-    bf16x8 d;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) d[j] = (__bf16)0.0f;
+    float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (h == 0) {
         // group.py:250-253: (grouped_xyz - query) then /= radius
-        d[0] = (__bf16)((p[0] - q[0]) / a.radius);
-        d[1] = (__bf16)((p[1] - q[1]) / a.radius);
-        d[2] = (__bf16)((p[2] - q[2]) / a.radius);
+        d[0] = (p[0] - q[0]) / a.radius;
+        d[1] = (p[1] - q[1]) / a.radius;
+        d[2] = (p[2] - q[2]) / a.radius;
     }
-    x[2] = d;
+    x[2] = make_frag<NS>(d);
 }
 
 // Workgroup-level fold of per-lane statistics into ONE partial row per workgroup:
@@ -163,20 +209,21 @@ __device__ __forceinline__ void write_partials(float (&vals)[NV], float *__restr
 }
 
 // Pass 1: statistics of y1 = conv1(x).  part[gridDim.x][64] = {sum[32], sumsq[32]}.
+template <int NS>
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
                                                                       float *__restrict__ part) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    bf16x8 w1f[3];
-    load_w1_frags(a.w1, r, h, w1f);
+    Frag<NS> w1f[3];
+    load_w1_frags<NS>(a.w1, r, h, w1f);
     float st[2] = {0.0f, 0.0f};
     const int tiles = a.b * a.m;
     for (int tile = blockIdx.x * SA_WAVES + wave; tile < tiles; tile += gridDim.x * SA_WAVES) {
-        bf16x8 x[3];
-        gather_tile(a, tile, r, h, x);
+        Frag<NS> x[3];
+        gather_tile<NS>(a, tile, r, h, x);
         f32x16 y = {0};
 #pragma unroll
-        for (int s = 0; s < 3; ++s) y = mfma(x[s], w1f[s], y);  // Y1: lane = mid channel
+        for (int s = 0; s < 3; ++s) y = mfma<NS>(x[s], w1f[s], y);  // Y1: lane = mid channel
 #pragma unroll
         for (int i = 0; i < 16; ++i) { st[0] += y[i]; st[1] += y[i] * y[i]; }
     }
@@ -186,23 +233,26 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
 // Pass 2.  scale1/shift1: BN1 folded to y*scale+shift; sgn2[c] = +1/-1 (sign of gamma2).
 // Outputs ysel/ksel (B,M,64): the extreme of y2 over K and its position;
 // part[gridDim.x][128] = {sum[64], sumsq[64]} of y2.
+template <int NS>
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
     SaArgs a, const float *__restrict__ w2, const float *__restrict__ scale1,
     const float *__restrict__ shift1, const float *__restrict__ sgn2, float *__restrict__ ysel,
     unsigned char *__restrict__ ksel, float *__restrict__ part) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    bf16x8 w1f[3];
-    load_w1_frags(a.w1, r, h, w1f);
+    Frag<NS> w1f[3];
+    load_w1_frags<NS>(a.w1, r, h, w1f);
     // conv2 B fragments: lane (out channel 32 t + r, h), step s, element j <-> mid channel row(8s+j, h)
-    bf16x8 w2f[2][2];
+    Frag<NS> w2f[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+            float tmp[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                w2f[t][s][j] = (__bf16)w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
+            for (int j = 0; j < 8; ++j) tmp[j] = w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
+            w2f[t][s] = make_frag<NS>(tmp);
+        }
     float sc1[16], sh1[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -214,19 +264,19 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
 
     const int tiles = a.b * a.m;
     for (int tile = blockIdx.x * SA_WAVES + wave; tile < tiles; tile += gridDim.x * SA_WAVES) {
-        bf16x8 x[3];
-        gather_tile(a, tile, r, h, x);
+        Frag<NS> x[3];
+        gather_tile<NS>(a, tile, r, h, x);
         f32x16 y1 = {0};
 #pragma unroll
-        for (int s = 0; s < 3; ++s) y1 = mfma(w1f[s], x[s], y1);  // Y1^T: lane = position
+        for (int s = 0; s < 3; ++s) y1 = mfma<NS>(w1f[s], x[s], y1);  // Y1^T: lane = position
 #pragma unroll
         for (int i = 0; i < 16; ++i) y1[i] = __builtin_fmaxf(__builtin_fmaf(y1[i], sc1[i], sh1[i]), 0.0f);
-        const bf16x8 a0 = pack8(y1, 0), a1 = pack8(y1, 8);
+        const Frag<NS> a0 = pack8<NS>(y1, 0), a1 = pack8<NS>(y1, 8);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 y2 = {0};
-            y2 = mfma(a0, w2f[t][0], y2);  // Y2: lane = out channel 32 t + r, register = position
-            y2 = mfma(a1, w2f[t][1], y2);
+            y2 = mfma<NS>(a0, w2f[t][0], y2);  // Y2: lane = out channel 32 t + r, register = position
+            y2 = mfma<NS>(a1, w2f[t][1], y2);
             float best = sg[t] * y2[0];
             int bpos = 0;
             float s1 = 0.0f, s2 = 0.0f;
@@ -283,7 +333,7 @@ struct SaBwdArgs {
     const float *ca, *cb, *cc;  // [32] pass 2: dL/dy1 = g_u*ca + yhat1*cb + cc
 };
 
-template <int PASS>
+template <int PASS, int NS>
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
                                                                float *__restrict__ part,
                                                                float *__restrict__ gw2_acc,
@@ -291,8 +341,8 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdAr
                                                                float *__restrict__ H) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    bf16x8 w1f[3];
-    load_w1_frags(a.w1, r, h, w1f);
+    Frag<NS> w1f[3];
+    load_w1_frags<NS>(a.w1, r, h, w1f);
     float sc1v[16], sh1v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -301,30 +351,38 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdAr
     }
     const float sc1 = g.scale1[r], sh1 = g.shift1[r], mu1 = g.mean1[r], iv1 = g.inv1[r];
     // term 1 of dL/da1: B fragments of Qm, k slot (h,j) of step s <-> mid' = row(8s+j,h)
-    bf16x8 qf[2];
+    Frag<NS> qf[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
+        float tmp[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)g.qm[acc_row(8 * s + j, h) * SA_C1 + r];
+        for (int j = 0; j < 8; ++j) tmp[j] = g.qm[acc_row(8 * s + j, h) * SA_C1 + r];
+        qf[s] = make_frag<NS>(tmp);
+    }
     // term 3: B fragments of W2 with k = output channel in natural order 16 s + 8 h + j
-    bf16x8 w2tf[4];
+    Frag<NS> w2tf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s) {
+        float tmp[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w2tf[s][j] = (__bf16)g.w2[(16 * s + 8 * h + j) * SA_C1 + r];
+        for (int j = 0; j < 8; ++j) tmp[j] = g.w2[(16 * s + 8 * h + j) * SA_C1 + r];
+        w2tf[s] = make_frag<NS>(tmp);
+    }
     const float ev = g.evec[r];
 
-    bf16x8 w2f[2][2];
+    Frag<NS> w2f[2][2];
     float d2v[2], e2v[2];
     f32x16 gw2[2];
     if (PASS == 1) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s) {
+                float tmp[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    w2f[t][s][j] = (__bf16)g.w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
+                for (int j = 0; j < 8; ++j) tmp[j] = g.w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
+                w2f[t][s] = make_frag<NS>(tmp);
+            }
             d2v[t] = g.d2[32 * t + r];
             e2v[t] = g.e2[32 * t + r];
 #pragma unroll
@@ -337,23 +395,23 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdAr
 
     const int tiles = a.b * a.m;
     for (int tile = blockIdx.x * SA_WAVES + wave; tile < tiles; tile += gridDim.x * SA_WAVES) {
-        bf16x8 x[3];
-        gather_tile(a, tile, r, h, x);
-        // conv1 in both layouts (3 + 3 MFMAs on the same fragments)
+        Frag<NS> x[3];
+        gather_tile<NS>(a, tile, r, h, x);
+        // conv1 in both layouts (3 + 3 k-steps on the same fragments)
         f32x16 yT = {0}, y1 = {0};
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            yT = mfma(w1f[s], x[s], yT);   // lane = position, register = mid channel
-            y1 = mfma(x[s], w1f[s], y1);   // lane = mid channel, register = position
+            yT = mfma<NS>(w1f[s], x[s], yT);   // lane = position, register = mid channel
+            y1 = mfma<NS>(x[s], w1f[s], y1);   // lane = mid channel, register = position
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             yT[i] = __builtin_fmaxf(__builtin_fmaf(yT[i], sc1v[i], sh1v[i]), 0.0f);
-        const bf16x8 a0 = pack8(yT, 0), a1 = pack8(yT, 8);
+        const Frag<NS> a0 = pack8<NS>(yT, 0), a1 = pack8<NS>(yT, 8);
 
         // one-hot-weighted operand of the sparse part: lane (pos r, h), step s, element j
         // <-> channel c = 16 s + 8 h + j
-        bf16x8 sp[4];
+        Frag<NS> sp[4];
         {
             const float *go = g.goa + (size_t)tile * SA_C2 + 8 * h;
             const unsigned char *ks = g.ksel + (size_t)tile * SA_C2 + 8 * h;
@@ -362,22 +420,23 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdAr
                 const float4 v0 = *reinterpret_cast<const float4 *>(go + 16 * s);
                 const float4 v1 = *reinterpret_cast<const float4 *>(go + 16 * s + 4);
                 const uint2 kb = *reinterpret_cast<const uint2 *>(ks + 16 * s);
-                const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const unsigned kk = ((j < 4 ? kb.x : kb.y) >> (8 * (j & 3))) & 0xffu;
-                    sp[s][j] = (__bf16)(kk == (unsigned)r ? vv[j] : 0.0f);
+                    vv[j] = kk == (unsigned)r ? vv[j] : 0.0f;
                 }
+                sp[s] = make_frag<NS>(vv);
             }
         }
         // dL/da1 [lane = mid, register = position]
         f32x16 ga;
 #pragma unroll
         for (int i = 0; i < 16; ++i) ga[i] = ev;
-        ga = mfma(a0, qf[0], ga);
-        ga = mfma(a1, qf[1], ga);
+        ga = mfma<NS>(a0, qf[0], ga);
+        ga = mfma<NS>(a1, qf[1], ga);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ga = mfma(sp[s], w2tf[s], ga);
+        for (int s = 0; s < 4; ++s) ga = mfma<NS>(sp[s], w2tf[s], ga);
 
         float yhat[16];
         f32x16 an;   // a1 in the [lane = mid] layout (pass 1: B operand of dL/dW2)
@@ -395,12 +454,12 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdAr
         if (PASS == 1) {
             st[0] += s1;
             st[1] += s2;
-            const bf16x8 b0 = pack8(an, 0), b1 = pack8(an, 8);
+            const Frag<NS> b0 = pack8<NS>(an, 0), b1 = pack8<NS>(an, 8);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x16 y2 = {0};
-                y2 = mfma(a0, w2f[t][0], y2);
-                y2 = mfma(a1, w2f[t][1], y2);
+                y2 = mfma<NS>(a0, w2f[t][0], y2);
+                y2 = mfma<NS>(a1, w2f[t][1], y2);
                 const int c = 32 * t + r;
                 const float gsel = g.goa[(size_t)tile * SA_C2 + c];
                 const int ksl = g.ksel[(size_t)tile * SA_C2 + c];
@@ -408,8 +467,8 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdAr
                 for (int i = 0; i < 16; ++i)
                     y2[i] = __builtin_fmaf(y2[i], d2v[t], e2v[t]) + (acc_row(i, h) == ksl ? gsel : 0.0f);
                 // dL/dW2[out][mid] += sum_pos dL/dy2[pos][out] * a1[pos][mid]
-                gw2[t] = mfma(pack8(y2, 0), b0, gw2[t]);
-                gw2[t] = mfma(pack8(y2, 8), b1, gw2[t]);
+                gw2[t] = mfma<NS>(pack8<NS>(y2, 0), b0, gw2[t]);
+                gw2[t] = mfma<NS>(pack8<NS>(y2, 8), b1, gw2[t]);
             }
         } else {
             // dL/dy1 and its two scatters
@@ -478,19 +537,31 @@ static int sa_grid(int tiles) {
 
 extern "C" int apn_sa_grid_blocks(int b, int m) { return apn::sa_grid(b * m); }
 
-extern "C" int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, void *stream) {
+// ft holds `precision` tables of (B,N,32) bf16 back to back: [hi] or [hi][lo].
+extern "C" int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, int precision,
+                                    void *stream) {
     using namespace apn;
-    if (b < 0 || n < 0 || c != SA_C) return APN_EINVAL;
+    if (b < 0 || n < 0 || c != SA_C || (precision != 1 && precision != 2)) return APN_EINVAL;
     if (b == 0 || n == 0) return APN_OK;
     if (!f || !ft || b > 65535) return APN_EINVAL;
+    __bf16 *hi = (__bf16 *)ft;
+    __bf16 *lo = precision == 2 ? hi + (size_t)b * n * SA_C : nullptr;
     hipLaunchKernelGGL(sa_prep_features_kernel, dim3((n + 63) / 64, b), dim3(256), 0,
-                       (hipStream_t)stream, n, f, (__bf16 *)ft);
+                       (hipStream_t)stream, n, f, hi, lo);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
-static int sa_check(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample) {
+static apn::SaArgs sa_args(int b, int n, int m, const float *xyz, const float *new_xyz, const void *ft,
+                           int precision, const int *idx, const float *w1, float radius) {
+    const __bf16 *hi = (const __bf16 *)ft;
+    return apn::SaArgs{b, n, m, xyz, new_xyz, hi,
+                       precision == 2 ? hi + (size_t)b * n * apn::SA_C : nullptr, idx, w1, radius};
+}
+
+static int sa_check(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample, int precision) {
     using namespace apn;
+    if (precision != 1 && precision != 2) return APN_EINVAL;
     if (b <= 0 || n <= 0 || m <= 0) return APN_EINVAL;
     if (c_in != SA_C || c_mid != SA_C1 || c_out != SA_C2 || nsample != SA_K) return APN_EINVAL;
     if ((long long)b * m > 0x7fffffffLL / 64) return APN_EINVAL;
@@ -498,29 +569,38 @@ static int sa_check(int b, int n, int m, int c_in, int c_mid, int c_out, int nsa
 }
 
 extern "C" int apn_sa_fwd_stats1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                                 float radius, const float *xyz, const float *new_xyz,
+                                 int precision, float radius, const float *xyz, const float *new_xyz,
                                  const void *ft, const int *idx, const float *w1, float *part,
                                  void *stream) {
     using namespace apn;
-    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample)) return e;
-    SaArgs a{b, n, m, xyz, new_xyz, (const __bf16 *)ft, idx, w1, radius};
-    hipLaunchKernelGGL(sa_fwd_stats1_kernel, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                       (hipStream_t)stream, a, part);
+    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
+    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius);
+    if (precision == 2)
+        hipLaunchKernelGGL(sa_fwd_stats1_kernel<2>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                           (hipStream_t)stream, a, part);
+    else
+        hipLaunchKernelGGL(sa_fwd_stats1_kernel<1>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                           (hipStream_t)stream, a, part);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
 extern "C" int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                               float radius, const float *xyz, const float *new_xyz, const void *ft,
+                               int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
                                const int *idx, const float *w1, const float *w2,
                                const float *scale1, const float *shift1, const float *sgn2,
                                float *ysel, void *ksel, float *part, void *stream) {
     using namespace apn;
-    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample)) return e;
-    SaArgs a{b, n, m, xyz, new_xyz, (const __bf16 *)ft, idx, w1, radius};
-    hipLaunchKernelGGL(sa_fwd_main_kernel, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                       (hipStream_t)stream, a, w2, scale1, shift1, sgn2, ysel,
-                       (unsigned char *)ksel, part);
+    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
+    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius);
+    if (precision == 2)
+        hipLaunchKernelGGL(sa_fwd_main_kernel<2>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                           (hipStream_t)stream, a, w2, scale1, shift1, sgn2, ysel,
+                           (unsigned char *)ksel, part);
+    else
+        hipLaunchKernelGGL(sa_fwd_main_kernel<1>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                           (hipStream_t)stream, a, w2, scale1, shift1, sgn2, ysel,
+                           (unsigned char *)ksel, part);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -539,34 +619,43 @@ static apn::SaBwdArgs sa_bwd_args(const float *w2, const float *bn1 /* [4][32]: 
 }
 
 extern "C" int apn_sa_bwd_pass1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                                float radius, const float *xyz, const float *new_xyz, const void *ft,
+                                int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
                                 const int *idx, const float *w1, const float *w2, const float *bn1,
                                 const float *qm, const float *evec, const float *d2e2,
                                 const float *goa, const void *ksel, float *part,
                                 float *gw2_acc, void *stream) {
     using namespace apn;
-    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample)) return e;
-    SaArgs a{b, n, m, xyz, new_xyz, (const __bf16 *)ft, idx, w1, radius};
+    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
+    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius);
     SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, d2e2, goa, ksel, nullptr);
-    hipLaunchKernelGGL(sa_bwd_kernel<1>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                       (hipStream_t)stream, a, g, part, gw2_acc, (float *)nullptr,
-                       (float *)nullptr);
+    if (precision == 2)
+        hipLaunchKernelGGL((sa_bwd_kernel<1, 2>), dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                           (hipStream_t)stream, a, g, part, gw2_acc, (float *)nullptr,
+                           (float *)nullptr);
+    else
+        hipLaunchKernelGGL((sa_bwd_kernel<1, 1>), dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                           (hipStream_t)stream, a, g, part, gw2_acc, (float *)nullptr,
+                           (float *)nullptr);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
 extern "C" int apn_sa_bwd_pass2(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                                float radius, const float *xyz, const float *new_xyz, const void *ft,
+                                int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
                                 const int *idx, const float *w1, const float *w2, const float *bn1,
                                 const float *qm, const float *evec, const float *goa,
                                 const void *ksel, const float *cabc, float *G, float *H,
                                 void *stream) {
     using namespace apn;
-    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample)) return e;
-    SaArgs a{b, n, m, xyz, new_xyz, (const __bf16 *)ft, idx, w1, radius};
+    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
+    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius);
     SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, nullptr, goa, ksel, cabc);
-    hipLaunchKernelGGL(sa_bwd_kernel<2>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                       (hipStream_t)stream, a, g, (float *)nullptr, (float *)nullptr, G, H);
+    if (precision == 2)
+        hipLaunchKernelGGL((sa_bwd_kernel<2, 2>), dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                           (hipStream_t)stream, a, g, (float *)nullptr, (float *)nullptr, G, H);
+    else
+        hipLaunchKernelGGL((sa_bwd_kernel<2, 1>), dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+                           (hipStream_t)stream, a, g, (float *)nullptr, (float *)nullptr, G, H);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256) void bwd_weight_grad_kernel(int total_n, int t
                                                               const float *__restrict__ G,
                                                               const float *__restrict__ H,
                                                               const __bf16 *__restrict__ ft,
+                                                              const __bf16 *__restrict__ ft_lo,
                                                               const float *__restrict__ xyz,
                                                               const float *__restrict__ new_xyz,
                                                               int q_per_block,
@@ -353,7 +354,9 @@ __global__ __launch_bounds__(256) void bwd_weight_grad_kernel(int total_n, int t
         const int pt = e >> 5, c = e & 31;
         const bool ok = n0 + pt < total_n;
         sG[pt][c] = ok ? G[(size_t)(n0 + pt) * 32 + c] : 0.0f;
-        sB[pt][6 + c] = ok ? (float)ft[(size_t)(n0 + pt) * 32 + c] : 0.0f;
+        float fv = ok ? (float)ft[(size_t)(n0 + pt) * 32 + c] : 0.0f;
+        if (ft_lo && ok) fv += (float)ft_lo[(size_t)(n0 + pt) * 32 + c];     // split mode: hi + lo
+        sB[pt][6 + c] = fv;
         const bool okq = pt < q_per_block && q0 + pt < total_q;
         sH[pt][c] = okq ? H[(size_t)(q0 + pt) * 32 + c] : 0.0f;
     }
@@ -528,14 +531,17 @@ extern "C" int apn_sa_bwd_input_grad(int b, int n, int m, const float *G, const 
 extern "C" int apn_sa_bwd_weight_rows(int b, int n) { return (b * n + apn::WG_PTS - 1) / apn::WG_PTS; }
 
 extern "C" int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const float *H,
-                                      const void *ft, const float *xyz, const float *new_xyz,
-                                      float *partW, void *stream) {
+                                      const void *ft, int precision, const float *xyz,
+                                      const float *new_xyz, float *partW, void *stream) {
     if (b <= 0 || n <= 0 || m <= 0 || !G || !H || !ft || !xyz || !new_xyz || !partW) return APN_EINVAL;
+    if (precision != 1 && precision != 2) return APN_EINVAL;
+    const __bf16 *hi = (const __bf16 *)ft;
+    const __bf16 *lo = precision == 2 ? hi + (size_t)b * n * 32 : nullptr;
     const int blocks = apn_sa_bwd_weight_rows(b, n);
     const int qpb = (b * m + blocks - 1) / blocks;   // queries are spread evenly over the blocks
     if (qpb > apn::WG_PTS) return APN_EINVAL;        // needs m <= n (always true after sampling)
     hipLaunchKernelGGL(apn::bwd_weight_grad_kernel, dim3(blocks), dim3(256), 0, APN_ST, b * n, b * m, G,
-                       H, (const __bf16 *)ft, xyz, new_xyz, qpb, partW);
+                       H, hi, lo, xyz, new_xyz, qpb, partW);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

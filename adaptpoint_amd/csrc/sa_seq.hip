@@ -22,7 +22,7 @@
     } while (0)
 
 extern "C" int apn_sa_forward_seq(
-    int phases, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
+    int phases, int precision, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
     const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
     const float *ws, const float *bs,
     const float *g1, const float *b1, float *rm1, float *rv1, void *nbt1, float eps1, float mom1,
@@ -34,16 +34,16 @@ extern "C" int apn_sa_forward_seq(
     float *out, void *stream) {
     const int rows = apn_sa_grid_blocks(b, m);
     if (phases & 1) {
-        APN_TRY(apn_sa_prep_features(b, 32, n, f, ft, stream));
+        APN_TRY(apn_sa_prep_features(b, 32, n, f, ft, precision, stream));
         if (train1)
-            APN_TRY(apn_sa_fwd_stats1(b, n, m, 32, 32, 64, 32, radius, xyz, new_xyz, ft, idx, w1,
-                                      part1, stream));
+            APN_TRY(apn_sa_fwd_stats1(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx,
+                                      w1, part1, stream));
     }
     if (phases & 2) {
         APN_TRY(apn_sa_bn_fold(sums1 ? nullptr : part1, rows, sums1, 32, count, g1, b1, eps1, mom1,
                                rm1, rv1, nbt1, train1, pack1, g2, 64, sgn2, stream));
-        APN_TRY(apn_sa_fwd_main(b, n, m, 32, 32, 64, 32, radius, xyz, new_xyz, ft, idx, w1, w2, pack1,
-                                pack1 + 32, sgn2, ysel, ksel, part2, stream));
+        APN_TRY(apn_sa_fwd_main(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, w1,
+                                w2, pack1, pack1 + 32, sgn2, ysel, ksel, part2, stream));
     }
     if (phases & 4) {
         APN_TRY(apn_sa_bn_fold(sums2 ? nullptr : part2, rows, sums2, 64, count, g2, b2, eps2, mom2,
@@ -55,7 +55,7 @@ extern "C" int apn_sa_forward_seq(
 }
 
 extern "C" int apn_sa_backward_seq(
-    int phases, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
+    int phases, int precision, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
     const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
@@ -79,16 +79,16 @@ extern "C" int apn_sa_backward_seq(
     if (phases & 2) {
         APN_TRY(apn_sa_bwd_consts2(sumsS ? nullptr : partS, prow, sumsS, pack2, w2, count, train2,
                                    d2e2, qm, evec, g_g2, g_b2, stream));
-        APN_TRY(apn_sa_bwd_pass1(b, n, m, 32, 32, 64, 32, radius, xyz, new_xyz, ft, idx, w1, w2, pack1,
-                                 qm, evec, d2e2, goa, ksel, partT, g_w2, stream));
+        APN_TRY(apn_sa_bwd_pass1(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, w1,
+                                 w2, pack1, qm, evec, d2e2, goa, ksel, partT, g_w2, stream));
     }
     if (phases & 4) {
         APN_TRY(apn_sa_bwd_consts1(sumsT ? nullptr : partT, rows, sumsT, pack1, count, train1, cabc,
                                    g_g1, g_b1, stream));
-        APN_TRY(apn_sa_bwd_pass2(b, n, m, 32, 32, 64, 32, radius, xyz, new_xyz, ft, idx, w1, w2, pack1,
-                                 qm, evec, goa, ksel, cabc, G, H, stream));
+        APN_TRY(apn_sa_bwd_pass2(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, w1,
+                                 w2, pack1, qm, evec, goa, ksel, cabc, G, H, stream));
         APN_TRY(apn_sa_bwd_input_grad(b, n, m, G, H, w1, gip, radius, g_f, g_p, g_newp, stream));
-        APN_TRY(apn_sa_bwd_weight_grad(b, n, m, G, H, ft, xyz, new_xyz, partW, stream));
+        APN_TRY(apn_sa_bwd_weight_grad(b, n, m, G, H, ft, precision, xyz, new_xyz, partW, stream));
         APN_TRY(apn_sa_bwd_finalize(partW, apn_sa_bwd_weight_rows(b, n), radius, g_w1, partWs, prow,
                                     g_ws, partS, g_bs, stream));
     }

@@ -18,8 +18,8 @@ Two entry points over the same kernels:
 
 No (B, C, M, K) tensor is materialised, forward or backward.  BatchNorm follows the
 modules' training flag (batch statistics + running-buffer update, or the running
-buffers); the MFMA contractions are bf16 x bf16 -> f32 accumulate, every statistic is an
-f32 partial summed in f64.  Forward is 8 kernel launches, backward 9 (+ one memset),
+buffers); the MFMA contractions are bf16 x bf16 -> f32 accumulate on split (hi + lo) operands
+by default (`PRECISION`), every statistic is an f32 partial summed in f64.  Forward is 8 kernel launches, backward 9 (+ one memset),
 all on the current stream with no host reads, so a step can be captured in a HIP graph.
 With sync_bn=True the per-channel float64 sums are all-reduced across ranks
 (SyncBatchNorm semantics) at the four points where statistics leave the kernels.
@@ -31,6 +31,13 @@ import torch.nn as nn
 from . import _lib
 
 C_IN, C_MID, C_OUT, K_NS = 32, 32, 64, 32
+
+# Operand precision of the MFMA contractions:
+#   "bf16x3" (default) every f32 operand is split into hi + lo bf16 parts and each product is
+#            three MFMAs (hi*hi + hi*lo + lo*hi): agrees with an fp32 chain to ~1e-5;
+#   "bf16"   operands rounded to bf16 (8 significant bits): fastest, ~3e-3 mean deviation.
+PRECISION = "bf16x3"
+_PREC = {"bf16": 1, "bf16x3": 2}
 
 # Diagnostics: True issues every kernel as its own foreign call (the Python mirror of
 # csrc/sa_seq.hip below) so that per-kernel HIP events can be placed around them
@@ -155,6 +162,7 @@ class _Forward:
         self.radius = float(radius)
         self.sync = sync_bn
         self.relu = 1 if relu else 0
+        self.prec = prec = _PREC[PRECISION]
         w1 = _mat(conv1.weight, C_MID, C_IN + 3)
         w2 = _mat(conv2.weight, C_OUT, C_MID)
         ws = bs = None
@@ -164,7 +172,7 @@ class _Forward:
         world = _world(sync_bn)
         count = float(B * M * K_NS) * world
         rows = lib.apn_sa_grid_blocks(B, M)
-        v, _buf = _carve(dev, [("ft", B * N * C // 2), ("pack1", 4 * C_MID), ("pack2", 4 * C_OUT),
+        v, _buf = _carve(dev, [("ft", prec * B * N * C // 2), ("pack1", 4 * C_MID), ("pack2", 4 * C_OUT),
                                ("sgn2", C_OUT), ("ysel", B * M * C_OUT), ("ksel", B * M * C_OUT // 4),
                                ("part1", rows * 64), ("part2", rows * 128)])
         out = torch.empty(B, C_OUT, M, dtype=torch.float32, device=dev)
@@ -173,10 +181,10 @@ class _Forward:
 
         def run(phases, sums1=None, sums2=None):
             if PER_KERNEL_LAUNCH:
-                return _forward_per_kernel(call, phases, B, N, M, self.radius, p, new_p, f, idx, fidx,
+                return _forward_per_kernel(call, phases, prec, B, N, M, self.radius, p, new_p, f, idx, fidx,
                                            w1, w2, ws, bs, bn1a, bn2a, count, self.relu, v, sums1,
                                            sums2, out, rows)
-            call("apn_sa_forward_seq", phases, B, N, M, self.radius, p.data_ptr(), new_p.data_ptr(),
+            call("apn_sa_forward_seq", phases, prec, B, N, M, self.radius, p.data_ptr(), new_p.data_ptr(),
                  f.data_ptr(), idx.data_ptr(), _ptr(fidx), w1.data_ptr(), w2.data_ptr(), _ptr(ws),
                  _ptr(bs), *bn1a, *bn2a, count, self.relu, v["ft"].data_ptr(),
                  v["part1"].data_ptr(), v["part2"].data_ptr(), _ptr(sums1), _ptr(sums2),
@@ -234,7 +242,7 @@ def _backward(fw, g_out, need_p, need_newp):
         if PER_KERNEL_LAUNCH:
             return _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, sumsS,
                                         sumsT, g_f, g_p, g_newp, rows, prow, wrows, has_skip)
-        call("apn_sa_backward_seq", phases, B, N, M, fw.radius, sv["p"].data_ptr(),
+        call("apn_sa_backward_seq", phases, fw.prec, B, N, M, fw.radius, sv["p"].data_ptr(),
              sv["new_p"].data_ptr(), sv["f"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["fidx"]),
              w1.data_ptr(), w2.data_ptr(), _ptr(ws), sv["ft"].data_ptr(), sv["pack1"].data_ptr(),
              sv["pack2"].data_ptr(), sv["ysel"].data_ptr(), sv["ksel"].data_ptr(),
@@ -264,13 +272,13 @@ def _backward(fw, g_out, need_p, need_newp):
                 bs=g["bs"] if (has_skip and sv["has_bs"]) else None)
 
 
-def _forward_per_kernel(call, phases, B, N, M, radius, p, new_p, f, idx, fidx, w1, w2, ws, bs, bn1a,
-                        bn2a, count, relu, v, sums1, sums2, out, rows):
+def _forward_per_kernel(call, phases, prec, B, N, M, radius, p, new_p, f, idx, fidx, w1, w2, ws, bs,
+                        bn1a, bn2a, count, relu, v, sums1, sums2, out, rows):
     """Python mirror of apn_sa_forward_seq (csrc/sa_seq.hip), one foreign call per kernel."""
-    hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, radius, p.data_ptr(), new_p.data_ptr(),
+    hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, prec, radius, p.data_ptr(), new_p.data_ptr(),
            v["ft"].data_ptr(), idx.data_ptr(), w1.data_ptr())
     if phases & 1:
-        call("apn_sa_prep_features", B, C_IN, N, f.data_ptr(), v["ft"].data_ptr())
+        call("apn_sa_prep_features", B, C_IN, N, f.data_ptr(), v["ft"].data_ptr(), prec)
         if bn1a[7]:
             call("apn_sa_fwd_stats1", *hdr, v["part1"].data_ptr())
     if phases & 2:
@@ -295,9 +303,9 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
     B, N, M = fw.dims
     w1, w2, ws, P = sv["w1"], sv["w2"], sv["ws"], float(sv["count"])
     gip = v["gip"].data_ptr() if has_skip else None
-    hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, fw.radius, sv["p"].data_ptr(), sv["new_p"].data_ptr(),
-           sv["ft"].data_ptr(), sv["idx"].data_ptr(), w1.data_ptr(), w2.data_ptr(),
-           sv["pack1"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr())
+    hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, fw.prec, fw.radius, sv["p"].data_ptr(),
+           sv["new_p"].data_ptr(), sv["ft"].data_ptr(), sv["idx"].data_ptr(), w1.data_ptr(),
+           w2.data_ptr(), sv["pack1"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr())
     if phases & 1:
         buf[:zero_floats].zero_()
         call("apn_sa_bwd_prep", B, N, M, g_out.data_ptr(), fw.out.data_ptr(), fw.relu,
@@ -320,7 +328,8 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
         call("apn_sa_bwd_input_grad", B, N, M, v["G"].data_ptr(), v["H"].data_ptr(), w1.data_ptr(), gip,
              fw.radius, g_f.data_ptr(), _ptr(g_p), _ptr(g_newp))
         call("apn_sa_bwd_weight_grad", B, N, M, v["G"].data_ptr(), v["H"].data_ptr(),
-             sv["ft"].data_ptr(), sv["p"].data_ptr(), sv["new_p"].data_ptr(), v["partW"].data_ptr())
+             sv["ft"].data_ptr(), fw.prec, sv["p"].data_ptr(), sv["new_p"].data_ptr(),
+             v["partW"].data_ptr())
         call("apn_sa_bwd_finalize", v["partW"].data_ptr(), wrows, fw.radius, g["w1"].data_ptr(),
              v["partWs"].data_ptr() if has_skip else None, prow,
              g["ws"].data_ptr() if has_skip else None, v["partS"].data_ptr(),

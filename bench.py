@@ -188,9 +188,10 @@ def main():
                          "index stage depends on coordinates only); fused path only")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from a captured HIP graph (auto: on at 1 GPU)")
-    ap.add_argument("--mlp", choices=["fused-bf16", "torch-f32"], default="fused-bf16",
-                    help="grouped shared-MLP: fused bf16-MFMA kernels (csrc/sa_fused.hip) or the "
-                         "unfused drop-in path (nine extension ops + PyTorch conv/BN in fp32)")
+    ap.add_argument("--mlp", choices=["fused-bf16x3", "fused-bf16", "torch-f32"], default="fused-bf16x3",
+                    help="grouped shared-MLP: fused bf16-MFMA kernels (csrc/sa_fused.hip) with split "
+                         "hi+lo operands (fp32-grade, default) or plain bf16 operands, or the unfused "
+                         "drop-in path (nine extension ops + PyTorch conv/BN in fp32)")
     args = ap.parse_args()
 
     from adaptpoint_amd import dp
@@ -217,7 +218,10 @@ def main():
 
     torch.manual_seed(0)                          # identical initial weights on every rank
     sync_bn = distributed and args.sync_bn != "off"
-    fused_mlp = args.mlp == "fused-bf16"
+    fused_mlp = args.mlp.startswith("fused")
+    if fused_mlp:
+        from adaptpoint_amd import fused as _f
+        _f.PRECISION = args.mlp.split("-", 1)[1]
     blk = make_block(fused=fused_mlp, sync_bn=sync_bn).to(dev)
     blk.train()
     if sync_bn and not fused_mlp:
@@ -341,8 +345,12 @@ def main():
         "config": {"workload": "PointNeXt-S stage-1 SetAbstraction fwd+bwd, B=32/GPU N=1024 "
                                "npoint=512 nsample=32 r=0.15 C 32->64 (BASELINE configs[1]); "
                                "clouds: uniform cube centred+scaled to the unit sphere (D1)",
-                   "mlp": ("fused bf16 MFMA (f32 accumulate, f32 BatchNorm statistics)" if fused_mlp
-                           else "unfused: extension ops + PyTorch fp32 conv/BN"),
+                   "mlp": ({"fused-bf16x3": "fused bf16 MFMA on split hi+lo operands (3 MFMAs per product, "
+                                            "f32 accumulate; forward within 7e-5 of an fp32 chain), "
+                                            "f32 BatchNorm statistics summed in f64",
+                            "fused-bf16": "fused bf16 MFMA (operands rounded to bf16, f32 accumulate), "
+                                          "f32 BatchNorm statistics summed in f64",
+                            "torch-f32": "unfused: extension ops + PyTorch fp32 conv/BN"}[args.mlp]),
                    "launch": "hipGraph replay" if use_graph else "eager",
                    "pipeline": ("index stage (FPS + ball query) of batch k+1 on a second stream "
                                 "beside the MLP fwd+bwd of batch k" if pipelined else "none"),

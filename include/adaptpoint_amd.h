@@ -136,12 +136,18 @@ APN_API int apn_ball_query_zero(int b, int n, int m, float radius, int nsample,
 /* Workgroups (= partial rows) the fused passes launch for B clouds x M queries. */
 APN_API int apn_sa_grid_blocks(int b, int m);
 
-/* f (B,C,N) f32 -> ft (B,N,C) bf16 (C must be 32). */
-APN_API int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, void *stream);
+/* `precision` (every function that takes ft): 1 = operands rounded to bf16; 2 = operands split
+ * into hi + lo bf16 parts, each product three MFMAs (hi*hi + hi*lo + lo*hi, "bf16x3"): fp32-grade
+ * results (~1e-5) at 3x the (small) MFMA cost.  ft then holds `precision` tables of (B,N,32)
+ * bf16 back to back: [hi] or [hi][lo]. */
+
+/* f (B,C,N) f32 -> ft (C must be 32). */
+APN_API int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, int precision,
+                                 void *stream);
 
 /* Forward pass 1: part[rows][64] = {sum, sumsq}[32] of y1 = conv1(cat(dp, f[idx])). */
 APN_API int apn_sa_fwd_stats1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                              float radius, const float *xyz, const float *new_xyz,
+                              int precision, float radius, const float *xyz, const float *new_xyz,
                               const void *ft, const int *idx, const float *w1, float *part,
                               void *stream);
 
@@ -164,7 +170,7 @@ APN_API int apn_sa_bn_fold(const float *part, int rows, const double *sums, int 
  * (max where sgn2 = +1, min where sgn2 = -1) and the neighbour slot holding it;
  * part[rows][128] = {sum[64], sumsq[64]} of y2. */
 APN_API int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                            float radius, const float *xyz, const float *new_xyz, const void *ft,
+                            int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
                             const int *idx, const float *w1, const float *w2,
                             const float *scale1, const float *shift1, const float *sgn2,
                             float *ysel, void *ksel, float *part, void *stream);
@@ -195,7 +201,7 @@ APN_API int apn_sa_bwd_consts2(const float *partS, int rows, const double *S, co
 /* Backward pass 1 -> part[rows][64] = {sum g_u, sum g_u*yhat1}[32]; gw2_acc[64*32] += dL/dW2.
  *   bn1 = pack1 [4][32]. */
 APN_API int apn_sa_bwd_pass1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                             float radius, const float *xyz, const float *new_xyz, const void *ft,
+                             int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
                              const int *idx, const float *w1, const float *w2, const float *bn1,
                              const float *qm, const float *evec, const float *d2e2,
                              const float *goa, const void *ksel, float *part, float *gw2_acc,
@@ -209,7 +215,7 @@ APN_API int apn_sa_bwd_consts1(const float *partT, int rows, const double *T, co
 /* Backward pass 2 -> G (B,N,32) += per-source-point sums of dL/dy1 (caller-zeroed, float
  * atomics), H (B,M,32) = per-query sums of dL/dy1. */
 APN_API int apn_sa_bwd_pass2(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                             float radius, const float *xyz, const float *new_xyz, const void *ft,
+                             int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
                              const int *idx, const float *w1, const float *w2, const float *bn1,
                              const float *qm, const float *evec, const float *goa,
                              const void *ksel, const float *cabc, float *G, float *H,
@@ -224,8 +230,8 @@ APN_API int apn_sa_bwd_input_grad(int b, int n, int m, const float *G, const flo
 /* partW[apn_sa_bwd_weight_rows(b, n)][32*38]: per-block products for dL/dW1 (sa_glue.hip). */
 APN_API int apn_sa_bwd_weight_rows(int b, int n);
 APN_API int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const float *H,
-                                   const void *ft, const float *xyz, const float *new_xyz,
-                                   float *partW, void *stream);
+                                   const void *ft, int precision, const float *xyz,
+                                   const float *new_xyz, float *partW, void *stream);
 
 /* Column sums in float64 -> g_w1 (32,35) from partW; optional g_ws (64,32) from partWs and
  * g_bs [64] from partS (rows_s rows each). */
@@ -240,7 +246,7 @@ APN_API int apn_sa_bwd_finalize(const float *partW, int rows_w, float radius, fl
  * 1 = zero+prep, 2 = consts2+pass1, 4 = consts1+pass2+input/weight grads+finalize.
  * sums* (float64, reduced over ranks) replace the partial rows when non-NULL. */
 APN_API int apn_sa_forward_seq(
-    int phases, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
+    int phases, int precision, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
     const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
     const float *ws, const float *bs,
     const float *g1, const float *b1, float *rm1, float *rv1, void *nbt1, float eps1, float mom1,
@@ -251,7 +257,7 @@ APN_API int apn_sa_forward_seq(
     const double *sums2, float *pack1, float *pack2, float *sgn2, float *ysel, void *ksel,
     float *out, void *stream);
 APN_API int apn_sa_backward_seq(
-    int phases, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
+    int phases, int precision, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
     const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,

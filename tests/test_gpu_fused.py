@@ -18,6 +18,15 @@ from fused_reference import chain
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["bf16x3", "bf16"])
+def precision(request):
+    from adaptpoint_amd import fused
+    old = fused.PRECISION
+    fused.PRECISION = request.param
+    yield request.param
+    fused.PRECISION = old
+
+
 def _setup(dev, B=4, seed=0, neg_gamma=False):
     from adaptpoint_amd.layers import ball_query, furthest_point_sample
     p = torch.from_numpy(GI.unit_sphere_cloud(B, 1024, seed=seed)).to(dev)
@@ -41,7 +50,7 @@ def _setup(dev, B=4, seed=0, neg_gamma=False):
 
 
 @pytest.mark.parametrize("neg_gamma", [False, True])
-def test_fused_forward_matches_pytorch(dev, neg_gamma):
+def test_fused_forward_matches_pytorch(dev, neg_gamma, precision):
     from adaptpoint_amd.fused import grouped_mlp_max, supported
     p, new_p, f, idx, conv1, bn1, conv2, bn2 = _setup(dev, neg_gamma=neg_gamma)
     assert supported(p, f, idx, conv1, conv2)
@@ -56,8 +65,13 @@ def test_fused_forward_matches_pytorch(dev, neg_gamma):
     e_32 = (out.double() - ref_32).abs()
     print("fused fwd err vs bf16-emulation max %.3e mean %.3e | vs fp32 max %.3e mean %.3e"
           % (e_bf.max(), e_bf.mean(), e_32.max(), e_32.mean()))
-    assert e_bf.max() <= 2e-2 and e_bf.mean() <= 5e-4
-    assert e_32.max() <= 1.5e-1 and e_32.mean() <= 1e-2
+    if precision == "bf16":
+        assert e_bf.max() <= 2e-2 and e_bf.mean() <= 5e-4
+        assert e_32.max() <= 1.5e-1 and e_32.mean() <= 1e-2
+    else:
+        # split operands: fp32-grade.  max 2e-3 allows the rare arg-max flip between two
+        # neighbours closer than 1e-5; the mean is the real measure.
+        assert e_32.max() <= 2e-3 and e_32.mean() <= 2e-5
 
 
 def test_fused_forward_updates_running_stats(dev):
@@ -84,7 +98,7 @@ def _rel_l2(a, b):
 
 
 @pytest.mark.parametrize("neg_gamma", [False, True])
-def test_fused_backward_matches_autograd(dev, neg_gamma):
+def test_fused_backward_matches_autograd(dev, neg_gamma, precision):
     """Gradients of the fused op vs torch autograd through the plain chain.
     Tolerance: max |err| / max |ref| <= 2e-2 against the bf16-rounding reference (the fused
     backward additionally rounds dL/dy2 and the one-hot operand to bf16 for its MFMAs).
@@ -104,7 +118,7 @@ def test_fused_backward_matches_autograd(dev, neg_gamma):
                w1=conv1.weight.grad.view(32, 35).clone(), w2=conv2.weight.grad.view(64, 32).clone(),
                g1=bn1.weight.grad.clone(), b1=bn1.bias.grad.clone(),
                g2=bn2.weight.grad.clone(), b2=bn2.bias.grad.clone())
-    for emu, tol in ((True, 2e-2), (False, None)):
+    for emu, tol in (((True, 2e-2), (False, None)) if precision == "bf16" else ((False, 5e-3),)):
         leaves = [t.detach().clone().requires_grad_(True) for t in
                   (p, new_p, f, conv1.weight.view(32, 35), bn1.weight, bn1.bias,
                    conv2.weight.view(64, 32), bn2.weight, bn2.bias)]
@@ -113,13 +127,27 @@ def test_fused_backward_matches_autograd(dev, neg_gamma):
         (ref * wts.double()).sum().backward()
         want = dict(f=rf.grad, p=rp.grad, newp=rq.grad, w1=rw1.grad, w2=rw2.grad,
                     g1=rg1.grad, b1=rb1.grad, g2=rg2.grad, b2=rb2.grad)
+        if precision == "bf16x3":
+            # Split operands against the plain fp32 chain (float64 accumulation).  Per-term
+            # precision is ~1e-5 (the dropped lo*lo product); BatchNorm's backward sums 524k
+            # signed terms that cancel ~700-fold, and an arg-max that flips between two
+            # neighbours closer than the forward error (7e-5) moves one whole gradient entry
+            # (~1 in 2000 pooled values), so the bars are relative L2 <= 5e-3 and max-norm
+            # <= 5e-2 (observed: L2 2e-3 through the pool, 8e-6 for dL/dW2 which bypasses it).
+            errs = {k: _rel(got[k], want[k]) for k in got}
+            l2 = {k: _rel_l2(got[k], want[k]) for k in got}
+            print("bf16x3 vs fp32 max-norm", {k: "%.2e" % v for k, v in errs.items()})
+            print("bf16x3 vs fp32 rel-L2  ", {k: "%.2e" % v for k, v in l2.items()})
+            for k in got:
+                assert errs[k] <= 5e-2 and l2[k] <= 5e-3, (k, errs[k], l2[k])
+            continue
         errs = {k: (_rel if emu else _rel_l2)(got[k], want[k]) for k in got}
         print(("bf16-emu max-norm" if emu else "fp32 rel-L2      "), {k: "%.2e" % v for k, v in errs.items()})
         for k, v in errs.items():
             assert v <= (tol if emu else (0.25 if k in ("f", "p", "newp") else 0.15)), (k, v, emu)
 
 
-def test_set_abstraction_fused_equals_unfused(dev):
+def test_set_abstraction_fused_equals_unfused(dev, precision):
     """The block with fused=True against the same block over the nine unfused operators
     (the drop-in path): same weights, same input."""
     from adaptpoint_amd.set_abstraction import SetAbstraction
@@ -138,10 +166,12 @@ def test_set_abstraction_fused_equals_unfused(dev):
     pb, ob = b([p, f2])
     assert torch.equal(pa, pb)
     oa.sum().backward(); ob.sum().backward()
-    assert (oa - ob).abs().max() <= 1.5e-1 and (oa - ob).abs().mean() <= 1e-2
-    assert _rel_l2(f2.grad, f1.grad) <= 0.25
+    # the unfused side is MIOpen fp32 (Winograd-class kernels, ~1e-3); bf16x3 sits at that level
+    fo, fg, fw_ = (1.5e-1, 0.25, 0.15) if precision == "bf16" else (1e-2, 2e-2, 2e-2)
+    assert (oa - ob).abs().max() <= fo and (oa - ob).abs().mean() <= fo / 15
+    assert _rel_l2(f2.grad, f1.grad) <= fg
     for (k, qa), (_, qb) in zip(a.named_parameters(), b.named_parameters()):
-        assert _rel_l2(qb.grad, qa.grad) <= 0.15, k
+        assert _rel_l2(qb.grad, qa.grad) <= fw_, k
     for (k, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         assert torch.allclose(ba.float(), bb.float(), rtol=2e-2, atol=2e-3), k
 
