@@ -37,9 +37,11 @@ SIGNATURES = {
                        _c_float, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                        _c_void_p, _c_int, _c_void_p, _c_void_p],
     "apn_sa_fwd_main": [_c_int] * 8 + [_c_float] + [_c_void_p] * 13,
-    "apn_sa_fwd_out": [_c_int] * 3 + [_c_void_p] * 6 + [_c_int] + [_c_void_p] * 2,
+    "apn_sa_fwd_out": [_c_int] * 3 + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 3 + [_c_int]
+                      + [_c_void_p] * 2,
     "apn_sa_bwd_prep_rows": [_c_int] * 2,
-    "apn_sa_bwd_prep": [_c_int] * 3 + [_c_void_p] * 2 + [_c_int] + [_c_void_p] * 10,
+    "apn_sa_bwd_prep": [_c_int] * 3 + [_c_void_p] * 2 + [_c_int] + [_c_void_p] * 3 + [_c_int]
+                       + [_c_void_p] * 7,
     "apn_sa_bwd_consts2": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_double, _c_int] + [_c_void_p] * 6,
     "apn_sa_bwd_pass1": [_c_int] * 8 + [_c_float] + [_c_void_p] * 15,
     "apn_sa_bwd_consts1": [_c_void_p, _c_int] + [_c_void_p] * 2 + [_c_double, _c_int] + [_c_void_p] * 4,

@@ -333,8 +333,10 @@ struct SaBwdArgs {
     const float *ca, *cb, *cc;  // [32] pass 2: dL/dy1 = g_u*ca + yhat1*cb + cc
 };
 
+// Pass 2 is asked to fit two waves per SIMD (<= 256 registers incl. accumulators): it is
+// VALU/latency bound, and a lone wave issues a vector instruction only every 4+ cycles.
 template <int PASS, int NS>
-__global__ __launch_bounds__(SA_WAVES * 64) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
+__global__ __launch_bounds__(SA_WAVES * 64, PASS == 2 ? 2 : 1) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
                                                                float *__restrict__ part,
                                                                float *__restrict__ gw2_acc,
                                                                float *__restrict__ G,

@@ -97,9 +97,12 @@ __global__ __launch_bounds__(1024) void bn_fold_kernel(
 // out[b][c][m] = act( ysel[b][m][c] * scale2[c] + shift2[c] + identity[b][c][m] )   (C = 64)
 // identity = Ws * f[b][:, fidx[b][m]] + bs  (the block's skip Conv1d on the sampled points,
 // pointnext.py:157-161) when ws != null; act = ReLU when relu != 0 (pointnext.py:167-168).
+// The sampled points' features come from the point-major bf16 table(s) of the block
+// (hi [+ lo]): one contiguous 64-byte row per query instead of 32 strided 4-byte loads.
 __global__ __launch_bounds__(256) void fwd_out_kernel(int n, int m, const float *__restrict__ ysel,
                                                       const float *__restrict__ pack2,
-                                                      const float *__restrict__ f,
+                                                      const __bf16 *__restrict__ ft,
+                                                      const __bf16 *__restrict__ ft_lo,
                                                       const int *__restrict__ fidx,
                                                       const float *__restrict__ ws,
                                                       const float *__restrict__ bs, int relu,
@@ -110,12 +113,17 @@ __global__ __launch_bounds__(256) void fwd_out_kernel(int n, int m, const float 
     const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     if (ws) {
-        for (int e = threadIdx.x; e < 64 * 32; e += 256) sws[e >> 5][e & 31] = ws[e];
-        // fi[q][i] = f[b][i][fidx[b][q]]: lanes over queries, loop over channels
-        const int q = m0 + tx;
-        const int src = q < m ? fidx[(size_t)cloud * m + q] : 0;
-        for (int i = ty; i < 32; i += 4)
-            sfi[tx][i] = q < m ? f[((size_t)cloud * 32 + i) * n + src] : 0.0f;
+        for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+            sws[e >> 5][e & 31] = ws[e];
+            const int q = m0 + (e >> 5), i = e & 31;     // fi[q][i] = f[b][i][fidx[b][q]]
+            float v = 0.0f;
+            if (q < m) {
+                const size_t o = ((size_t)cloud * n + fidx[(size_t)cloud * m + q]) * 32 + i;
+                v = (float)ft[o];
+                if (ft_lo) v += (float)ft_lo[o];
+            }
+            sfi[e >> 5][i] = v;
+        }
     }
     for (int j = ty; j < 64; j += 4) {   // j = query within tile, tx = channel
         const int q = m0 + j;
@@ -147,7 +155,8 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(int n, int m, const float
                                                        const float *__restrict__ out, int relu,
                                                        const float *__restrict__ ysel,
                                                        const float *__restrict__ pack2,
-                                                       const float *__restrict__ f,
+                                                       const __bf16 *__restrict__ ft,
+                                                       const __bf16 *__restrict__ ft_lo,
                                                        const int *__restrict__ fidx,
                                                        const float *__restrict__ ws,
                                                        float *__restrict__ goa,
@@ -171,12 +180,19 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(int n, int m, const float
         tile[tx][c] = g;
     }
     if (ws) {
-        for (int e = threadIdx.x; e < 64 * 32; e += 256) sws[e >> 5][e & 31] = ws[e];
-        const int q = m0 + tx;
-        const int src = q < m ? fidx[(size_t)cloud * m + q] : 0;
-        if (ty == 0) ssrc[tx] = src;
-        for (int i = ty; i < 32; i += 4)
-            sfi[tx][i] = q < m ? f[((size_t)cloud * 32 + i) * n + src] : 0.0f;
+        for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+            sws[e >> 5][e & 31] = ws[e];
+            const int q = m0 + (e >> 5), i = e & 31;
+            const int src = q < m ? fidx[(size_t)cloud * m + q] : 0;
+            if (i == 0) ssrc[e >> 5] = src;
+            float v = 0.0f;
+            if (q < m) {
+                const size_t o = ((size_t)cloud * n + src) * 32 + i;
+                v = (float)ft[o];
+                if (ft_lo) v += (float)ft_lo[o];
+            }
+            sfi[e >> 5][i] = v;
+        }
     }
     __syncthreads();
     const float sc = pack2[tx], mu = pack2[128 + tx], iv = pack2[192 + tx];
@@ -327,15 +343,16 @@ __global__ __launch_bounds__(256) void bwd_query_grad_kernel(int total_q, const 
     for (int d = 0; d < 3; ++d) g_q[(size_t)q * 3 + d] = -s[d] * inv_r;
 }
 
-// Products over points for dL/dW1: partW[block][mid][38], columns
+// Products over points for dL/dW1: partW[replica][mid][38] (CALLER-ZEROED, float atomics), columns
 //   0..2   sum_n G[n][mid] * xyz[n][d]
 //   3..5   sum_q H[q][mid] * new_xyz[q][d]
 //   6..37  sum_n G[n][mid] * ft[n][i]
-// over the block's tile of WG_PTS points and its share of queries.  bwd_finalize sums the
+// over the block's tiles of WG_PTS points (and the query tiles of the same index).  bwd_finalize sums the
 // blocks in float64 and forms (col0-2 - col3-5)/r.  256 threads = 32 mid x 8 column
 // groups; column group g owns columns {g, g+8, g+16, g+24, g+32}: every wave (two groups)
 // then runs the same instruction stream, and the staged tile is read as sB[pt][col].
 constexpr int WG_PTS = 64;
+constexpr int WG_REPLICAS = 16;     // partial rows the workgroups fold into (float atomics)
 __global__ __launch_bounds__(256) void bwd_weight_grad_kernel(int total_n, int total_q,
                                                               const float *__restrict__ G,
                                                               const float *__restrict__ H,
@@ -343,47 +360,52 @@ __global__ __launch_bounds__(256) void bwd_weight_grad_kernel(int total_n, int t
                                                               const __bf16 *__restrict__ ft_lo,
                                                               const float *__restrict__ xyz,
                                                               const float *__restrict__ new_xyz,
-                                                              int q_per_block,
                                                               float *__restrict__ partW) {
     __shared__ float sG[WG_PTS][33];    // G [point][mid]
     __shared__ float sH[WG_PTS][33];    // H [query][mid]
     __shared__ float sB[WG_PTS][41];    // columns 0..2 xyz, 3..5 new_xyz (query rows), 6..37 ft
     const int tid = threadIdx.x;
-    const int n0 = blockIdx.x * WG_PTS, q0 = blockIdx.x * q_per_block;
-    for (int e = tid; e < WG_PTS * 32; e += 256) {
-        const int pt = e >> 5, c = e & 31;
-        const bool ok = n0 + pt < total_n;
-        sG[pt][c] = ok ? G[(size_t)(n0 + pt) * 32 + c] : 0.0f;
-        float fv = ok ? (float)ft[(size_t)(n0 + pt) * 32 + c] : 0.0f;
-        if (ft_lo && ok) fv += (float)ft_lo[(size_t)(n0 + pt) * 32 + c];     // split mode: hi + lo
-        sB[pt][6 + c] = fv;
-        const bool okq = pt < q_per_block && q0 + pt < total_q;
-        sH[pt][c] = okq ? H[(size_t)(q0 + pt) * 32 + c] : 0.0f;
-    }
-    for (int e = tid; e < WG_PTS * 3; e += 256) {
-        const int pt = e / 3, d = e % 3;
-        sB[pt][d] = n0 + pt < total_n ? xyz[(size_t)(n0 + pt) * 3 + d] : 0.0f;
-        sB[pt][3 + d] = (pt < q_per_block && q0 + pt < total_q) ? new_xyz[(size_t)(q0 + pt) * 3 + d] : 0.0f;
-    }
-    for (int e = tid; e < WG_PTS * 2; e += 256) sB[e >> 1][38 + (e & 1)] = 0.0f;   // pad columns 38, 39
-    __syncthreads();
     const int mid = tid & 31, grp = tid >> 5;
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     // column grp + 8 j; only j = 0 can be a query column (3..5), and only for grp in {3,4,5}
     const bool qcol = grp >= 3 && grp <= 5;
+    const int n_tiles = (total_n + WG_PTS - 1) / WG_PTS, q_tiles = (total_q + WG_PTS - 1) / WG_PTS;
+    const int tiles = n_tiles > q_tiles ? n_tiles : q_tiles;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int r0 = tile * WG_PTS;
+        __syncthreads();
+        for (int e = tid; e < WG_PTS * 32; e += 256) {
+            const int pt = e >> 5, c = e & 31;
+            const bool ok = r0 + pt < total_n;
+            sG[pt][c] = ok ? G[(size_t)(r0 + pt) * 32 + c] : 0.0f;
+            float fv = ok ? (float)ft[(size_t)(r0 + pt) * 32 + c] : 0.0f;
+            if (ft_lo && ok) fv += (float)ft_lo[(size_t)(r0 + pt) * 32 + c];     // split mode: hi + lo
+            sB[pt][6 + c] = fv;
+            sH[pt][c] = r0 + pt < total_q ? H[(size_t)(r0 + pt) * 32 + c] : 0.0f;
+        }
+        for (int e = tid; e < WG_PTS * 3; e += 256) {
+            const int pt = e / 3, d = e % 3;
+            sB[pt][d] = r0 + pt < total_n ? xyz[(size_t)(r0 + pt) * 3 + d] : 0.0f;
+            sB[pt][3 + d] = r0 + pt < total_q ? new_xyz[(size_t)(r0 + pt) * 3 + d] : 0.0f;
+        }
+        for (int e = tid; e < WG_PTS * 2; e += 256) sB[e >> 1][38 + (e & 1)] = 0.0f;   // pad columns
+        __syncthreads();
 #pragma unroll 4
-    for (int pt = 0; pt < WG_PTS; ++pt) {
-        const float g = sG[pt][mid];
-        const float a0 = qcol ? sH[pt][mid] : g;
-        acc[0] += a0 * sB[pt][grp];
+        for (int pt = 0; pt < WG_PTS; ++pt) {
+            const float g = sG[pt][mid];
+            const float a0 = qcol ? sH[pt][mid] : g;
+            acc[0] += a0 * sB[pt][grp];
 #pragma unroll
-        for (int j = 1; j < 5; ++j) acc[j] += g * sB[pt][grp + 8 * j];
+            for (int j = 1; j < 5; ++j) acc[j] += g * sB[pt][grp + 8 * j];
+        }
     }
-    float *row = partW + (size_t)blockIdx.x * 32 * 38;
+    // one workgroup per tile; the 512 partial results fold into WG_REPLICAS caller-zeroed rows
+    // (32 adders per address), which bwd_finalize then sums in float64
+    float *row = partW + (size_t)(blockIdx.x % WG_REPLICAS) * 32 * 38;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int col = grp + 8 * j;
-        if (col < 38) row[mid * 38 + col] = acc[j];
+        if (col < 38) atomicAdd(row + mid * 38 + col, acc[j]);
     }
 }
 
@@ -466,12 +488,14 @@ extern "C" int apn_sa_bn_fold(const float *part, int rows, const double *sums, i
 }
 
 extern "C" int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const float *pack2,
-                              const float *f, const int *fidx, const float *ws, const float *bs,
-                              int relu, float *out, void *stream) {
+                              const void *ft, int precision, const int *fidx, const float *ws,
+                              const float *bs, int relu, float *out, void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || !ysel || !pack2 || !out) return APN_EINVAL;
-    if (ws && (!f || !fidx || n <= 0)) return APN_EINVAL;
+    if (ws && (!ft || !fidx || n <= 0 || (precision != 1 && precision != 2))) return APN_EINVAL;
+    const __bf16 *hi = (const __bf16 *)ft;
+    const __bf16 *lo = (ws && precision == 2) ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::fwd_out_kernel, dim3((m + 63) / 64, b), dim3(256), 0, APN_ST, n, m, ysel,
-                       pack2, f, fidx, ws, bs, relu, out);
+                       pack2, hi, lo, fidx, ws, bs, relu, out);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -479,14 +503,17 @@ extern "C" int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const floa
 extern "C" int apn_sa_bwd_prep_rows(int b, int m) { return b * ((m + 63) / 64); }
 
 extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, const float *out, int relu,
-                               const float *ysel, const float *pack2, const float *f,
+                               const float *ysel, const float *pack2, const void *ft, int precision,
                                const int *fidx, const float *ws, float *goa, float *partS,
                                float *partWs, float *gip, void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || !g_out || !ysel || !pack2 || !goa || !partS) return APN_EINVAL;
     if (relu && !out) return APN_EINVAL;
-    if (ws && (!f || !fidx || !partWs || !gip || n <= 0)) return APN_EINVAL;
+    if (ws && (!ft || !fidx || !partWs || !gip || n <= 0 || (precision != 1 && precision != 2)))
+        return APN_EINVAL;
+    const __bf16 *hi = (const __bf16 *)ft;
+    const __bf16 *lo = (ws && precision == 2) ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::bwd_prep_kernel, dim3((m + 63) / 64, b), dim3(256), 0, APN_ST, n, m, g_out,
-                       out, relu, ysel, pack2, f, fidx, ws, goa, partS, partWs, gip);
+                       out, relu, ysel, pack2, hi, lo, fidx, ws, goa, partS, partWs, gip);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -528,7 +555,7 @@ extern "C" int apn_sa_bwd_input_grad(int b, int n, int m, const float *G, const 
     return APN_OK;
 }
 
-extern "C" int apn_sa_bwd_weight_rows(int b, int n) { return (b * n + apn::WG_PTS - 1) / apn::WG_PTS; }
+extern "C" int apn_sa_bwd_weight_rows(int b, int n) { (void)b; (void)n; return apn::WG_REPLICAS; }
 
 extern "C" int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const float *H,
                                       const void *ft, int precision, const float *xyz,
@@ -537,11 +564,10 @@ extern "C" int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const
     if (precision != 1 && precision != 2) return APN_EINVAL;
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = precision == 2 ? hi + (size_t)b * n * 32 : nullptr;
-    const int blocks = apn_sa_bwd_weight_rows(b, n);
-    const int qpb = (b * m + blocks - 1) / blocks;   // queries are spread evenly over the blocks
-    if (qpb > apn::WG_PTS) return APN_EINVAL;        // needs m <= n (always true after sampling)
+    if (m > n) return APN_EINVAL;                    // query tiles are walked with the point tiles
+    const int blocks = (b * n + apn::WG_PTS - 1) / apn::WG_PTS;
     hipLaunchKernelGGL(apn::bwd_weight_grad_kernel, dim3(blocks), dim3(256), 0, APN_ST, b * n, b * m, G,
-                       H, hi, lo, xyz, new_xyz, qpb, partW);
+                       H, hi, lo, xyz, new_xyz, partW);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

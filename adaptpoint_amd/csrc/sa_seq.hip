@@ -48,8 +48,8 @@ extern "C" int apn_sa_forward_seq(
     if (phases & 4) {
         APN_TRY(apn_sa_bn_fold(sums2 ? nullptr : part2, rows, sums2, 64, count, g2, b2, eps2, mom2,
                                rm2, rv2, nbt2, train2, pack2, nullptr, 0, nullptr, stream));
-        APN_TRY(apn_sa_fwd_out(b, n, m, ysel, pack2, ws ? f : nullptr, ws ? fidx : nullptr, ws, bs,
-                               relu, out, stream));
+        APN_TRY(apn_sa_fwd_out(b, n, m, ysel, pack2, ws ? ft : nullptr, precision,
+                               ws ? fidx : nullptr, ws, bs, relu, out, stream));
     }
     return APN_OK;
 }
@@ -73,7 +73,7 @@ extern "C" int apn_sa_backward_seq(
     if (phases & 1) {
         hipError_t me = hipMemsetAsync(zero_base, 0, zero_bytes, (hipStream_t)stream);
         if (me != hipSuccess) return (int)me;
-        APN_TRY(apn_sa_bwd_prep(b, n, m, g_out, out, relu, ysel, pack2, ws ? f : nullptr,
+        APN_TRY(apn_sa_bwd_prep(b, n, m, g_out, out, relu, ysel, pack2, ws ? ft : nullptr, precision,
                                 ws ? fidx : nullptr, ws, goa, partS, partWs, gip, stream));
     }
     if (phases & 2) {

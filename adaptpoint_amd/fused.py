@@ -222,10 +222,11 @@ def _backward(fw, g_out, need_p, need_newp):
     wrows = lib.apn_sa_bwd_weight_rows(B, N)
 
     # scratch: the zero-filled (atomically accumulated) region first, contiguous
-    zsizes = [("G", B * N * C_MID)] + ([("gip", B * N * C_MID)] if has_skip else [])
+    zsizes = ([("G", B * N * C_MID)] + ([("gip", B * N * C_MID)] if has_skip else [])
+              + [("partW", wrows * 32 * 38)])
     sizes = zsizes + [("goa", B * M * C_OUT), ("partS", prow * 128),
                       ("partWs", prow * C_OUT * C_IN if has_skip else 0), ("partT", rows * 64),
-                      ("partW", wrows * 32 * 38), ("d2e2", 2 * C_OUT), ("qm", C_MID * C_MID),
+                      ("d2e2", 2 * C_OUT), ("qm", C_MID * C_MID),
                       ("evec", C_MID), ("cabc", 3 * C_MID), ("H", B * M * C_MID)]
     v, buf = _carve(dev, sizes)
     zero_floats = sum((nfl + 63) // 64 * 64 for _, nfl in zsizes)
@@ -293,8 +294,8 @@ def _forward_per_kernel(call, phases, prec, B, N, M, radius, p, new_p, f, idx, f
              C_OUT, count, bn2a[0], bn2a[1], bn2a[5], bn2a[6], bn2a[2], bn2a[3], bn2a[4], bn2a[7],
              v["pack2"].data_ptr(), None, 0, None)
         call("apn_sa_fwd_out", B, N, M, v["ysel"].data_ptr(), v["pack2"].data_ptr(),
-             f.data_ptr() if ws is not None else None, _ptr(fidx) if ws is not None else None,
-             _ptr(ws), _ptr(bs), relu, out.data_ptr())
+             v["ft"].data_ptr() if ws is not None else None, prec,
+             _ptr(fidx) if ws is not None else None, _ptr(ws), _ptr(bs), relu, out.data_ptr())
 
 
 def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, sumsS, sumsT, g_f, g_p,
@@ -309,8 +310,8 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
     if phases & 1:
         buf[:zero_floats].zero_()
         call("apn_sa_bwd_prep", B, N, M, g_out.data_ptr(), fw.out.data_ptr(), fw.relu,
-             sv["ysel"].data_ptr(), sv["pack2"].data_ptr(), sv["f"].data_ptr() if has_skip else None,
-             _ptr(sv["fidx"]) if has_skip else None, _ptr(ws), v["goa"].data_ptr(),
+             sv["ysel"].data_ptr(), sv["pack2"].data_ptr(), sv["ft"].data_ptr() if has_skip else None,
+             fw.prec, _ptr(sv["fidx"]) if has_skip else None, _ptr(ws), v["goa"].data_ptr(),
              v["partS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None, gip)
     if phases & 2:
         call("apn_sa_bwd_consts2", None if sumsS is not None else v["partS"].data_ptr(), prow,

@@ -175,11 +175,12 @@ APN_API int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out,
                             const float *scale1, const float *shift1, const float *sgn2,
                             float *ysel, void *ksel, float *part, void *stream);
 
-/* out (B,64,M) = act(ysel*scale2 + shift2 + Ws f[:, fidx] + bs); ws/bs/f/fidx may be null
- * (no skip branch), relu = 0/1.  f (B,32,N), fidx (B,M), ws (64,32), bs (64). */
+/* out (B,64,M) = act(ysel*scale2 + shift2 + Ws f[:, fidx] + bs); ws/bs/ft/fidx may be null
+ * (no skip branch), relu = 0/1.  f is read from the point-major table(s) ft; fidx (B,M),
+ * ws (64,32), bs (64). */
 APN_API int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const float *pack2,
-                           const float *f, const int *fidx, const float *ws, const float *bs,
-                           int relu, float *out, void *stream);
+                           const void *ft, int precision, const int *fidx, const float *ws,
+                           const float *bs, int relu, float *out, void *stream);
 
 /* Backward entry: g = g_out * [out > 0] (relu) ; goa (B,M,64) = g * scale2;
  * partS[rows][128] = {sum g, sum g*yhat_sel} per block of 64 queries
@@ -187,7 +188,7 @@ APN_API int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const float *
  * per block and gip (B,N,32) += Ws^T g at the sampled points (caller-zeroed). */
 APN_API int apn_sa_bwd_prep_rows(int b, int m);
 APN_API int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, const float *out, int relu,
-                            const float *ysel, const float *pack2, const float *f,
+                            const float *ysel, const float *pack2, const void *ft, int precision,
                             const int *fidx, const float *ws, float *goa, float *partS,
                             float *partWs, float *gip, void *stream);
 
@@ -227,7 +228,7 @@ APN_API int apn_sa_bwd_input_grad(int b, int n, int m, const float *G, const flo
                                   const float *w1, const float *gip, float radius, float *g_f,
                                   float *g_p, float *g_newp, void *stream);
 
-/* partW[apn_sa_bwd_weight_rows(b, n)][32*38]: per-block products for dL/dW1 (sa_glue.hip). */
+/* partW[apn_sa_bwd_weight_rows(b, n)][32*38] += products for dL/dW1 (caller-zeroed; sa_glue.hip). */
 APN_API int apn_sa_bwd_weight_rows(int b, int n);
 APN_API int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const float *H,
                                    const void *ft, int precision, const float *xyz,

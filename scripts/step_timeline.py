@@ -5,7 +5,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'fps_reg' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'fps_' in r['Kernel_Name']]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) - 10
 a, b = idx[k], idx[k + 1]
 tot = 0
