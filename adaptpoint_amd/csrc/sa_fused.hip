@@ -395,6 +395,13 @@ __global__ __launch_bounds__(SA_WAVES * 64, PASS == 2 ? 2 : 1) void sa_bwd_kerne
     if (PASS == 2) { ca = g.ca[r]; cb = g.cb[r]; cc = g.cc[r]; }
     float st[2] = {0.0f, 0.0f};
 
+    // wave-private LDS image of the sparse operand: [hi | lo] tiles of 32 rows x 72 bf16
+    // (64 channels + 8 pad: 144-byte rows keep the 16-byte fragment reads conflict-free)
+    constexpr int SP_ROW = 72, SP_TILE = 32 * SP_ROW;
+    __shared__ __attribute__((aligned(16))) __bf16 sp_lds[SA_WAVES][NS * SP_TILE];
+    __bf16 *sp_img = sp_lds[wave];
+    for (int e = lane; e < NS * SP_TILE; e += 64) sp_img[e] = (__bf16)0.0f;
+
     const int tiles = a.b * a.m;
     for (int tile = blockIdx.x * SA_WAVES + wave; tile < tiles; tile += gridDim.x * SA_WAVES) {
         Frag<NS> x[3];
@@ -411,25 +418,29 @@ __global__ __launch_bounds__(SA_WAVES * 64, PASS == 2 ? 2 : 1) void sa_bwd_kerne
             yT[i] = __builtin_fmaxf(__builtin_fmaf(yT[i], sc1v[i], sh1v[i]), 0.0f);
         const Frag<NS> a0 = pack8<NS>(yT, 0), a1 = pack8<NS>(yT, 8);
 
-        // one-hot-weighted operand of the sparse part: lane (pos r, h), step s, element j
-        // <-> channel c = 16 s + 8 h + j
+        // One-hot-weighted operand of the sparse part, S[pos][c] = goa[c] * [ksel[c] == pos]
+        // (64 nonzeros in a 32 x 64 tile).  Built through a wave-private LDS image instead of
+        // 2048 compare/selects: lane c drops its value into row ksel[c], every lane reads its
+        // fragment rows back (ds_read_b128, conflict-free with 144-byte rows), and lane c
+        // zeroes its element again.  LDS executes one wave's instructions in order, so the
+        // image needs no barrier; it starts zeroed and is left zeroed.
         Frag<NS> sp[4];
         {
-            const float *go = g.goa + (size_t)tile * SA_C2 + 8 * h;
-            const unsigned char *ks = g.ksel + (size_t)tile * SA_C2 + 8 * h;
+            const float gv = g.goa[(size_t)tile * SA_C2 + lane];
+            const int kc = g.ksel[(size_t)tile * SA_C2 + lane];
+            const __bf16 ghi = (__bf16)gv;
+            const __bf16 glo = (__bf16)(gv - (float)ghi);
+            __bf16 *cell = sp_img + kc * SP_ROW + lane;
+            cell[0] = ghi;
+            if (NS == 2) cell[SP_TILE] = glo;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float4 v0 = *reinterpret_cast<const float4 *>(go + 16 * s);
-                const float4 v1 = *reinterpret_cast<const float4 *>(go + 16 * s + 4);
-                const uint2 kb = *reinterpret_cast<const uint2 *>(ks + 16 * s);
-                float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const unsigned kk = ((j < 4 ? kb.x : kb.y) >> (8 * (j & 3))) & 0xffu;
-                    vv[j] = kk == (unsigned)r ? vv[j] : 0.0f;
-                }
-                sp[s] = make_frag<NS>(vv);
+                const __bf16 *src = sp_img + r * SP_ROW + 16 * s + 8 * h;
+                sp[s].p[0] = *reinterpret_cast<const bf16x8 *>(src);
+                if (NS == 2) sp[s].p[NS - 1] = *reinterpret_cast<const bf16x8 *>(src + SP_TILE);
             }
+            cell[0] = (__bf16)0.0f;
+            if (NS == 2) cell[SP_TILE] = (__bf16)0.0f;
         }
         // dL/da1 [lane = mid, register = position]
         f32x16 ga;
