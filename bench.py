@@ -180,7 +180,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="auto",
-                    help="SyncBatchNorm at world_size>1 (auto = on, as the reference)")
+                    help="BatchNorm statistics at world_size>1.  auto = off: per-rank statistics and "
+                         "ONE exchange per step, the gradient all-reduce BASELINE.json's north_star "
+                         "names; on: SyncBatchNorm as the reference forces "
+                         "(examples/classification/main.py:27), four more small all-reduces per step")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--pipeline", choices=["on", "off"], default="on",
                     help="software-pipeline the index stage: FPS + ball query of batch k+1 run on "
@@ -217,7 +220,7 @@ def main():
         _fused.FORCE_PHASED = True
 
     torch.manual_seed(0)                          # identical initial weights on every rank
-    sync_bn = distributed and args.sync_bn != "off"
+    sync_bn = distributed and args.sync_bn == "on"
     fused_mlp = args.mlp.startswith("fused")
     if fused_mlp:
         from adaptpoint_amd import fused as _f
@@ -227,7 +230,12 @@ def main():
     if sync_bn and not fused_mlp:
         blk = torch.nn.SyncBatchNorm.convert_sync_batchnorm(blk)
     model = blk
-    if distributed:
+    # Gradient exchange.  With SyncBatchNorm the step runs eagerly under DistributedDataParallel
+    # (collectives sit inside forward and backward).  Without it forward+backward contain no
+    # collective, so the step is the same captured hipGraph as at one GPU, followed by ONE
+    # flat-bucket all-reduce of the block's gradients (adaptpoint_amd.dp.allreduce_mean_).
+    use_ddp = distributed and sync_bn
+    if use_ddp:
         model = torch.nn.parallel.DistributedDataParallel(blk, device_ids=[local_rank],
                                                           output_device=local_rank)
     p, f = make_inputs(B_PER_GPU, seed=dp.shard_seed(0, rank))   # each rank its own shard of clouds
@@ -236,7 +244,7 @@ def main():
     params = [q for q in blk.parameters()]
 
     # the two-stream pipeline pays only when the step is GPU-bound, i.e. under graph replay
-    pipelined = fused_mlp and args.pipeline == "on" and not distributed
+    pipelined = fused_mlp and args.pipeline == "on" and not use_ddp
     if pipelined:
         from adaptpoint_amd.fused import Sampling
         side_stream = torch.cuda.Stream()
@@ -263,7 +271,7 @@ def main():
             q.grad = None
         fwd_bwd()
 
-    use_graph = (args.graph == "on") or (args.graph == "auto" and not distributed)
+    use_graph = (args.graph == "on") or (args.graph == "auto" and not use_ddp)
     eager_step = step
     if use_graph:
         # Whole-step capture: every launch of the step (extension kernels through ctypes on the
@@ -281,6 +289,12 @@ def main():
         with torch.cuda.graph(graph):
             fwd_bwd()
         step = graph.replay
+    if distributed and not use_ddp:
+        local_step = step
+
+        def step():
+            local_step()
+            dp.allreduce_mean_([q.grad for q in params if q.grad is not None])
 
     # W warm-up steps, barrier + synchronize, K timed steps, barrier + synchronize, MAX over ranks
     elapsed = dp.timed_steps(step, args.steps, args.warmup, dev)
@@ -355,7 +369,8 @@ def main():
                    "pipeline": ("index stage (FPS + ball query) of batch k+1 on a second stream "
                                 "beside the MLP fwd+bwd of batch k" if pipelined else "none"),
                    "global_batch": B_PER_GPU * world,
-                   "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else "")},
+                   "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else "")
+                                  + ("+ddp" if use_ddp else ("+flat-allreduce" if distributed else ""))},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

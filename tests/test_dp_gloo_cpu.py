@@ -75,7 +75,15 @@ def _worker(rank, world, port, out_dir):
             out.sum().backward()
     elapsed = dp.timed_steps(step, steps=2, warmup=1)
     grads = [q.grad.clone() for q in blk.parameters()]
-    torch.save({"elapsed": elapsed, "grads": grads}, os.path.join(out_dir, f"rank{rank}.pt"))
+    # the bench's other exchange: local backward (no DDP) + one flat-bucket all-reduce
+    torch.manual_seed(0)
+    blk2 = CB.build_cpu_block(_block)
+    blk2.train()
+    CB.run_step(blk2, p, f.detach())
+    flat_grads = [q.grad for q in blk2.parameters()]
+    dp.allreduce_mean_(flat_grads)
+    torch.save({"elapsed": elapsed, "grads": grads, "flat": [g.clone() for g in flat_grads]},
+               os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -96,6 +104,10 @@ def test_world2_gloo_shards_and_allreduces(tmp_path):
     want = [(_a + _b) / 2 for _a, _b in zip(_local_grads(dp.shard_seed(0, 0)), _local_grads(dp.shard_seed(0, 1)))]
     for got, w in zip(res[0]["grads"], want):
         np.testing.assert_allclose(got.numpy(), w.numpy(), rtol=1e-4, atol=1e-5)  # f32 sums in a different order
+    # the flat-bucket all-reduce leaves the same averaged gradients as DDP, on every rank
+    for a, b, w in zip(res[0]["flat"], res[1]["flat"], want):
+        assert torch.equal(a, b)
+        np.testing.assert_allclose(a.numpy(), w.numpy(), rtol=1e-4, atol=1e-5)
 
 
 def test_shards_are_distinct():

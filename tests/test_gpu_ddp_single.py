@@ -13,15 +13,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_distributed_path_world1(dev):
+def _run(extra, port):
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT="29731", APN_BENCH_FORCE_DISTRIBUTED="1")
+               MASTER_PORT=str(port), APN_BENCH_FORCE_DISTRIBUTED="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10",
-                          "--warmup", "3", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
-                         timeout=600)
+                          "--warmup", "3", "--no-cpu-baseline"] + extra, env=env, capture_output=True,
+                         text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    return json.loads(line)
+
+
+def test_bench_distributed_default_path_world1(dev):
+    """default at N>1: hipGraph step + one flat-bucket gradient all-reduce over RCCL"""
+    d = _run([], 29731)
     assert d["n_gpus"] == 1 and d["value"] > 0
-    assert "syncbn" in d["config"]["parallelism"]
+    assert "flat-allreduce" in d["config"]["parallelism"] and "syncbn" not in d["config"]["parallelism"]
+    assert d["config"]["launch"] == "hipGraph replay"
+
+
+def test_bench_distributed_syncbn_path_world1(dev):
+    """--sync-bn on: eager, DistributedDataParallel, phased SyncBatchNorm all-reduces"""
+    d = _run(["--sync-bn", "on"], 29732)
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert "syncbn" in d["config"]["parallelism"] and "ddp" in d["config"]["parallelism"]
     assert d["config"]["launch"] == "eager"
