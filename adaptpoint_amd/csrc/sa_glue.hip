@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void bwd_query_grad_kernel(int total_q, const 
     for (int d = 0; d < 3; ++d) g_q[(size_t)q * 3 + d] = -s[d] * inv_r;
 }
 
-// Products over points for dL/dW1: partW[replica][mid][38] (CALLER-ZEROED, float atomics), columns
+// Products over points for dL/dW1: partW[block][mid][38], columns
 //   0..2   sum_n G[n][mid] * xyz[n][d]
 //   3..5   sum_q H[q][mid] * new_xyz[q][d]
 //   6..37  sum_n G[n][mid] * ft[n][i]
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void bwd_query_grad_kernel(int total_q, const 
 // groups; column group g owns columns {g, g+8, g+16, g+24, g+32}: every wave (two groups)
 // then runs the same instruction stream, and the staged tile is read as sB[pt][col].
 constexpr int WG_PTS = 64;
-constexpr int WG_REPLICAS = 16;     // partial rows the workgroups fold into (float atomics)
+
 __global__ __launch_bounds__(256) void bwd_weight_grad_kernel(int total_n, int total_q,
                                                               const float *__restrict__ G,
                                                               const float *__restrict__ H,
@@ -399,13 +399,12 @@ __global__ __launch_bounds__(256) void bwd_weight_grad_kernel(int total_n, int t
             for (int j = 1; j < 5; ++j) acc[j] += g * sB[pt][grp + 8 * j];
         }
     }
-    // one workgroup per tile; the 512 partial results fold into WG_REPLICAS caller-zeroed rows
-    // (32 adders per address), which bwd_finalize then sums in float64
-    float *row = partW + (size_t)(blockIdx.x % WG_REPLICAS) * 32 * 38;
+    // one workgroup per tile, one partial row per workgroup; bwd_finalize sums them in float64
+    float *row = partW + (size_t)blockIdx.x * 32 * 38;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int col = grp + 8 * j;
-        if (col < 38) atomicAdd(row + mid * 38 + col, acc[j]);
+        if (col < 38) row[mid * 38 + col] = acc[j];
     }
 }
 
@@ -413,19 +412,19 @@ __global__ __launch_bounds__(256) void bwd_weight_grad_kernel(int total_n, int t
 //   g_w1[mid][0..2] = (W[mid][0..2] - W[mid][3..5]) / r ; g_w1[mid][3+i] = W[mid][6+i],
 //        W = sum_rows partW[row][32*38]
 //   g_ws[c][i] = sum_rows partWs[row][64*32] ;  g_bs[c] = sum_rows partS[row][c]
-// A workgroup owns 64 output elements x 4 row groups; loads are issued 8 deep.
+// A workgroup owns 16 output elements x 16 row groups; loads are issued 8 deep.
 __device__ __forceinline__ double col_sum(const float *__restrict__ base, int rows, int stride,
                                           int col, int g) {
     double s = 0.0;
     int r = g;
-    for (; r + 28 < rows; r += 32) {
+    for (; r + 7 * 16 < rows; r += 8 * 16) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r + 4 * u) * stride + col];
+        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r + 16 * u) * stride + col];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += (double)v[u];
     }
-    for (; r < rows; r += 4) s += (double)base[(size_t)r * stride + col];
+    for (; r < rows; r += 16) s += (double)base[(size_t)r * stride + col];
     return s;
 }
 
@@ -433,9 +432,9 @@ __global__ __launch_bounds__(256) void bwd_finalize_kernel(
     const float *__restrict__ partW, int rowsW, double inv_r, float *__restrict__ g_w1,
     const float *__restrict__ partWs, int rowsS, float *__restrict__ g_ws,
     const float *__restrict__ partS, float *__restrict__ g_bs) {
-    __shared__ double red[4][64];
-    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + o;
+    __shared__ double red[16][16];
+    const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + o;
     double v = 0.0;
     int kind = 0;   // 1: g_w1, 2: g_ws, 3: g_bs
     if (e < 32 * 35) {
@@ -454,7 +453,10 @@ __global__ __launch_bounds__(256) void bwd_finalize_kernel(
     red[g][o] = v;
     __syncthreads();
     if (g == 0 && kind) {
-        const float r = (float)(red[0][o] + red[1][o] + red[2][o] + red[3][o]);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += red[k][o];
+        const float r = (float)acc;
         if (kind == 1) g_w1[e] = r;
         else if (kind == 2) g_ws[e - 32 * 35] = r;
         else g_bs[e - 32 * 35 - 2048] = r;
@@ -555,7 +557,7 @@ extern "C" int apn_sa_bwd_input_grad(int b, int n, int m, const float *G, const 
     return APN_OK;
 }
 
-extern "C" int apn_sa_bwd_weight_rows(int b, int n) { (void)b; (void)n; return apn::WG_REPLICAS; }
+extern "C" int apn_sa_bwd_weight_rows(int b, int n) { return (b * n + apn::WG_PTS - 1) / apn::WG_PTS; }
 
 extern "C" int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const float *H,
                                       const void *ft, int precision, const float *xyz,
@@ -577,7 +579,7 @@ extern "C" int apn_sa_bwd_finalize(const float *partW, int rows_w, float radius,
                                    const float *partS, float *g_bs, void *stream) {
     if (!partW || !g_w1 || (g_ws && !partWs) || (g_bs && !partS)) return APN_EINVAL;
     const int total = 32 * 35 + 2048 + 64;
-    hipLaunchKernelGGL(apn::bwd_finalize_kernel, dim3((total + 63) / 64), dim3(256), 0, APN_ST, partW,
+    hipLaunchKernelGGL(apn::bwd_finalize_kernel, dim3((total + 15) / 16), dim3(256), 0, APN_ST, partW,
                        rows_w, 1.0 / (double)radius, g_w1, partWs, rows_s, g_ws, partS, g_bs);
     APN_LAUNCH_CHECK();
     return APN_OK;

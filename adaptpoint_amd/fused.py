@@ -222,11 +222,10 @@ def _backward(fw, g_out, need_p, need_newp):
     wrows = lib.apn_sa_bwd_weight_rows(B, N)
 
     # scratch: the zero-filled (atomically accumulated) region first, contiguous
-    zsizes = ([("G", B * N * C_MID)] + ([("gip", B * N * C_MID)] if has_skip else [])
-              + [("partW", wrows * 32 * 38)])
+    zsizes = [("G", B * N * C_MID)] + ([("gip", B * N * C_MID)] if has_skip else [])
     sizes = zsizes + [("goa", B * M * C_OUT), ("partS", prow * 128),
                       ("partWs", prow * C_OUT * C_IN if has_skip else 0), ("partT", rows * 64),
-                      ("d2e2", 2 * C_OUT), ("qm", C_MID * C_MID),
+                      ("partW", wrows * 32 * 38), ("d2e2", 2 * C_OUT), ("qm", C_MID * C_MID),
                       ("evec", C_MID), ("cabc", 3 * C_MID), ("H", B * M * C_MID)]
     v, buf = _carve(dev, sizes)
     zero_floats = sum((nfl + 63) // 64 * 64 for _, nfl in zsizes)

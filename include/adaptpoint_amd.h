@@ -228,7 +228,7 @@ APN_API int apn_sa_bwd_input_grad(int b, int n, int m, const float *G, const flo
                                   const float *w1, const float *gip, float radius, float *g_f,
                                   float *g_p, float *g_newp, void *stream);
 
-/* partW[apn_sa_bwd_weight_rows(b, n)][32*38] += products for dL/dW1 (caller-zeroed; sa_glue.hip). */
+/* partW[apn_sa_bwd_weight_rows(b, n)][32*38]: per-block products for dL/dW1 (sa_glue.hip). */
 APN_API int apn_sa_bwd_weight_rows(int b, int n);
 APN_API int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const float *H,
                                    const void *ft, int precision, const float *xyz,
