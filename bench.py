@@ -276,19 +276,26 @@ def main():
     if use_graph:
         # Whole-step capture: every launch of the step (extension kernels through ctypes on the
         # capture stream, PyTorch ops, autograd) becomes one hipGraph; replay has no host work.
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                eager_step()
-        torch.cuda.current_stream().wait_stream(side)
-        f.grad = None
-        for q in params:
-            q.grad = None
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            fwd_bwd()
-        step = graph.replay
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            f.grad = None
+            for q in params:
+                q.grad = None
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fwd_bwd()
+            step = graph.replay
+        except Exception as exc:                      # capture is an optimisation, never a requirement
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly",
+                  file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            use_graph = False
+            step = eager_step
     if distributed and not use_ddp:
         local_step = step
 

@@ -282,3 +282,28 @@ def test_per_kernel_diagnostic_path_equals_sequences(dev):
         fused.PER_KERNEL_LAUNCH = False
     assert torch.equal(oa, ob)
     assert _rel(f2.grad, f1.grad) <= 1e-4          # float-atomic sums: order effects only
+
+
+@pytest.mark.parametrize("B,N,stride", [(3, 777, 3), (1, 64, 2), (5, 2048, 2), (2, 4100, 4)])
+def test_fused_block_odd_sizes(dev, B, N, stride):
+    """Sizes that are not multiples of the kernels' tiles (64-point / 64-query tiles, 4-wave
+    workgroups), both FPS step algorithms (n <= 4096 and above)."""
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    kw = dict(layers=2, stride=stride, group_args={'NAME': 'ballquery', 'radius': 0.2, 'nsample': 32,
+                                                   'normalize_dp': True},
+              norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+              use_res=True)
+    torch.manual_seed(7)
+    a = SetAbstraction(32, 64, **kw).to(dev)
+    b = SetAbstraction(32, 64, fused=True, **kw).to(dev)
+    b.load_state_dict(a.state_dict())
+    p = torch.from_numpy(GI.unit_sphere_cloud(B, N, seed=N)).to(dev)
+    f1 = torch.from_numpy(GI.seeded_normal((B, 32, N), seed=N + 1)).to(dev).requires_grad_(True)
+    f2 = f1.detach().clone().requires_grad_(True)
+    pa, oa = a([p, f1]); oa.sum().backward()
+    pb, ob = b([p, f2]); ob.sum().backward()
+    assert pb.shape == (B, N // stride, 3) and torch.equal(pa, pb)
+    assert (oa - ob).abs().max() <= 2e-2
+    assert _rel_l2(f2.grad, f1.grad) <= 3e-2
+    for (k, qa), (_, qb) in zip(a.named_parameters(), b.named_parameters()):
+        assert _rel_l2(qb.grad, qa.grad) <= 3e-2, k
