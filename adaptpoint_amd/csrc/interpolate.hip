@@ -6,9 +6,9 @@
 //   three_interpolate_kernel_fast       :84-124
 //   three_interpolate_grad_kernel_fast  :127-168
 //
-// three_nn: one lane per unknown point; the known cloud is staged per workgroup
-// into LDS as x/y/z planes and every lane walks it in index order -- the read
-// address is wave-uniform, so each ds_read_b32 is a broadcast.  The reference
+// three_nn: a DPP quad of four lanes per unknown point; the known cloud is staged per
+// workgroup into LDS as float4 and each lane of the quad walks one contiguous quarter
+// in index order (one ds_read_b128 per candidate), then the quad merges.  The reference
 // keeps its three bests as doubles initialised to 1e40 and compares the float
 // distance against them (:37,44-56), then narrows to float on store (:57).
 // Every value ever stored in a best is a float, and 1e40 both compares above
@@ -27,18 +27,61 @@
 namespace apn {
 
 constexpr int NN_THREADS = 256;
-constexpr int NN_CHUNK = 4096;  // known points staged per pass (48 KiB)
+constexpr int NN_SPLIT = 4;     // lanes that share one unknown point (a DPP quad)
+constexpr int NN_CHUNK = 2048;  // known points staged per pass (float4 each: 32 KiB + padding)
 
+struct Top3 {
+    float d1, d2, d3;
+    int i1, i2, i3;
+};
+
+// The reference's strict-< insertion cascade (interpolate_gpu.cu:44-56): an element equal to
+// an existing best is placed AFTER it, so earlier candidates win ties.
+__device__ __forceinline__ void top3_insert(Top3 &t, float d, int k) {
+    if (d < t.d1) {
+        t.d3 = t.d2; t.i3 = t.i2; t.d2 = t.d1; t.i2 = t.i1; t.d1 = d; t.i1 = k;
+    } else if (d < t.d2) {
+        t.d3 = t.d2; t.i3 = t.i2; t.d2 = d; t.i2 = k;
+    } else if (d < t.d3) {
+        t.d3 = d; t.i3 = k;
+    }
+}
+
+// `early` holds candidates with lower indices than `late`; both sorted by (distance, index).
+// Feeding late's triple through the cascade after early's is exactly what the sequential scan
+// would have done with those six survivors.
+__device__ __forceinline__ Top3 top3_merge(Top3 early, const Top3 &late) {
+    top3_insert(early, late.d1, late.i1);
+    top3_insert(early, late.d2, late.i2);
+    top3_insert(early, late.d3, late.i3);
+    return early;
+}
+
+template <int CTRL>
+__device__ __forceinline__ Top3 top3_from_partner(const Top3 &t) {
+    Top3 o;
+    o.d1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t.d1), CTRL, 0xF, 0xF, true));
+    o.d2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t.d2), CTRL, 0xF, 0xF, true));
+    o.d3 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t.d3), CTRL, 0xF, 0xF, true));
+    o.i1 = __builtin_amdgcn_mov_dpp(t.i1, CTRL, 0xF, 0xF, true);
+    o.i2 = __builtin_amdgcn_mov_dpp(t.i2, CTRL, 0xF, 0xF, true);
+    o.i3 = __builtin_amdgcn_mov_dpp(t.i3, CTRL, 0xF, 0xF, true);
+    return o;
+}
+
+// Four adjacent lanes (a DPP quad) share one unknown point: each scans one contiguous quarter
+// of the staged known points in index order, then the quad merges its four sorted triples
+// pairwise (earlier quarter first), which reproduces the sequential scan's result exactly.
+// The known cloud is staged per workgroup as float4 {x,y,z,-}; quarter q starts at element
+// q*(quarter+1), the +1 keeping the four streams on different LDS banks.
 __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(
     int n, int m, const float *__restrict__ unknown, const float *__restrict__ known,
     float *__restrict__ out_dist2, int *__restrict__ idx) {
-    extern __shared__ float s_dyn[];
-    const int chunk = min(m, NN_CHUNK);
-    float *sx = s_dyn, *sy = s_dyn + chunk, *sz = s_dyn + 2 * chunk;
-
+    extern __shared__ float4 s_kn[];
     const int cloud = blockIdx.y;
     const int tid = threadIdx.x;
-    const int pt = blockIdx.x * NN_THREADS + tid;
+    const int sub = tid & (NN_SPLIT - 1);
+    const int pt = blockIdx.x * (NN_THREADS / NN_SPLIT) + (tid >> 2);
     known += (size_t)cloud * m * 3;
     const bool live = pt < n;
     float ux = 0.f, uy = 0.f, uz = 0.f;
@@ -47,35 +90,36 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(
         ux = u[0]; uy = u[1]; uz = u[2];
     }
     const float inf = __builtin_huge_valf();
-    float b1 = inf, b2 = inf, b3 = inf;
-    int i1 = 0, i2 = 0, i3 = 0;
+    Top3 best{inf, inf, inf, 0, 0, 0};
     for (int base = 0; base < m; base += NN_CHUNK) {
         const int len = min(NN_CHUNK, m - base);
+        const int quarter = (len + NN_SPLIT - 1) / NN_SPLIT;
         __syncthreads();
-        for (int i = tid; i < 3 * len; i += NN_THREADS) {
-            const float v = known[(size_t)base * 3 + i];
-            const int p = i / 3, c = i - p * 3;
-            (c == 0 ? sx : c == 1 ? sy : sz)[p] = v;
+        for (int i = tid; i < len; i += NN_THREADS) {
+            const float *kp = known + (size_t)(base + i) * 3;
+            const int q = i / quarter;
+            s_kn[i + q] = make_float4(kp[0], kp[1], kp[2], 0.0f);
         }
         __syncthreads();
-        for (int k = 0; k < len; ++k) {
-            const float d = dist2(ux - sx[k], uy - sy[k], uz - sz[k]);
-            const int kk = base + k;
-            // strict-< insertion cascade (:44-56)
-            if (d < b1) {
-                b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk;
-            } else if (d < b2) {
-                b3 = b2; i3 = i2; b2 = d; i2 = kk;
-            } else if (d < b3) {
-                b3 = d; i3 = kk;
-            }
+        Top3 mine{inf, inf, inf, 0, 0, 0};
+        const int k0 = sub * quarter, k1 = min(k0 + quarter, len);
+        const float4 *src = s_kn + sub;            // + sub: the per-quarter bank shift
+        for (int k = k0; k < k1; ++k) {
+            const float4 p = src[k];
+            top3_insert(mine, dist2(ux - p.x, uy - p.y, uz - p.z), base + k);
         }
+        // quad merge: lanes 2q,2q+1 first (xor 1), then the two pairs (xor 2)
+        Top3 other = top3_from_partner<DPP_QUAD_XOR1>(mine);
+        mine = (sub & 1) ? top3_merge(other, mine) : top3_merge(mine, other);
+        other = top3_from_partner<DPP_QUAD_XOR2>(mine);
+        mine = (sub & 2) ? top3_merge(other, mine) : top3_merge(mine, other);
+        best = top3_merge(best, mine);             // chunks arrive in index order
     }
-    if (live) {
+    if (live && sub == 0) {
         float *o = out_dist2 + ((size_t)cloud * n + pt) * 3;
         int *oi = idx + ((size_t)cloud * n + pt) * 3;
-        o[0] = b1; o[1] = b2; o[2] = b3;
-        oi[0] = i1; oi[1] = i2; oi[2] = i3;
+        o[0] = best.d1; o[1] = best.d2; o[2] = best.d3;
+        oi[0] = best.i1; oi[1] = best.i2; oi[2] = best.i3;
     }
 }
 
@@ -154,9 +198,10 @@ extern "C" int apn_three_nn(int b, int n, int m, const float *unknown, const flo
     if (b < 0 || n < 0 || m < 0 || b > 65535) return APN_EINVAL;
     if (b == 0 || n == 0) return APN_OK;
     if (!unknown || !dist2 || !idx || (m > 0 && !known)) return APN_EINVAL;
-    dim3 grid((n + NN_THREADS - 1) / NN_THREADS, b);
+    const int per_block = NN_THREADS / NN_SPLIT;
+    dim3 grid((n + per_block - 1) / per_block, b);
     const int chunk = m < NN_CHUNK ? m : NN_CHUNK;
-    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(NN_THREADS), sizeof(float) * 3 * chunk,
+    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(NN_THREADS), sizeof(float4) * (chunk + NN_SPLIT),
                        (hipStream_t)stream, n, m, unknown, known, dist2, idx);
     APN_LAUNCH_CHECK();
     return APN_OK;
