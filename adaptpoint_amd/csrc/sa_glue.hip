@@ -94,6 +94,41 @@ __global__ __launch_bounds__(1024) void bn_fold_kernel(
     pack[3 * c + i] = (float)inv;
 }
 
+// Stage the skip branch's operands of one 64-query tile: sws = Ws (64x32) and
+// sfi[q][i] = f[b][i][fidx[b][m0+q]] read from the point-major table(s).  Loads are issued in
+// three independent batches (indices, then rows) so that the dependent index -> row chain is
+// paid once, not once per loop iteration.  Optionally records the source point of each query.
+__device__ __forceinline__ void stage_skip_operands(int cloud, int n, int m, int m0,
+                                                    const __bf16 *__restrict__ ft,
+                                                    const __bf16 *__restrict__ ft_lo,
+                                                    const int *__restrict__ fidx,
+                                                    const float *__restrict__ ws,
+                                                    float (*sws)[33], float (*sfi)[33], int *ssrc) {
+    const int tid = threadIdx.x, i = tid & 31, q0 = tid >> 5;     // 8 queries per thread: q0 + 8 t
+    int src[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int q = m0 + q0 + 8 * t;
+        src[t] = q < m ? fidx[(size_t)cloud * m + q] : -1;
+    }
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        v[t] = 0.0f;
+        if (src[t] >= 0) {
+            const size_t o = ((size_t)cloud * n + src[t]) * 32 + i;
+            v[t] = (float)ft[o];
+            if (ft_lo) v[t] += (float)ft_lo[o];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        sfi[q0 + 8 * t][i] = v[t];
+        if (ssrc && i == 0) ssrc[q0 + 8 * t] = src[t] < 0 ? 0 : src[t];
+        sws[q0 + 8 * t][i] = ws[(q0 + 8 * t) * 32 + i];
+    }
+}
+
 // out[b][c][m] = act( ysel[b][m][c] * scale2[c] + shift2[c] + identity[b][c][m] )   (C = 64)
 // identity = Ws * f[b][:, fidx[b][m]] + bs  (the block's skip Conv1d on the sampled points,
 // pointnext.py:157-161) when ws != null; act = ReLU when relu != 0 (pointnext.py:167-168).
@@ -112,19 +147,7 @@ __global__ __launch_bounds__(256) void fwd_out_kernel(int n, int m, const float 
     __shared__ float sws[64][33];
     const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if (ws) {
-        for (int e = threadIdx.x; e < 64 * 32; e += 256) {
-            sws[e >> 5][e & 31] = ws[e];
-            const int q = m0 + (e >> 5), i = e & 31;     // fi[q][i] = f[b][i][fidx[b][q]]
-            float v = 0.0f;
-            if (q < m) {
-                const size_t o = ((size_t)cloud * n + fidx[(size_t)cloud * m + q]) * 32 + i;
-                v = (float)ft[o];
-                if (ft_lo) v += (float)ft_lo[o];
-            }
-            sfi[e >> 5][i] = v;
-        }
-    }
+    if (ws) stage_skip_operands(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, nullptr);
     for (int j = ty; j < 64; j += 4) {   // j = query within tile, tx = channel
         const int q = m0 + j;
         tile[j][tx] = q < m ? ysel[((size_t)cloud * m + q) * 64 + tx] * pack2[tx] + pack2[64 + tx] : 0.f;
@@ -179,21 +202,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(int n, int m, const float
         }
         tile[tx][c] = g;
     }
-    if (ws) {
-        for (int e = threadIdx.x; e < 64 * 32; e += 256) {
-            sws[e >> 5][e & 31] = ws[e];
-            const int q = m0 + (e >> 5), i = e & 31;
-            const int src = q < m ? fidx[(size_t)cloud * m + q] : 0;
-            if (i == 0) ssrc[e >> 5] = src;
-            float v = 0.0f;
-            if (q < m) {
-                const size_t o = ((size_t)cloud * n + src) * 32 + i;
-                v = (float)ft[o];
-                if (ft_lo) v += (float)ft_lo[o];
-            }
-            sfi[e >> 5][i] = v;
-        }
-    }
+    if (ws) stage_skip_operands(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, ssrc);
     __syncthreads();
     const float sc = pack2[tx], mu = pack2[128 + tx], iv = pack2[192 + tx];
     float s1 = 0.0f, s2 = 0.0f;
