@@ -546,9 +546,18 @@ static int sa_grid(int tiles) {
     return g < 512 ? (g < 1 ? 1 : g) : 512;
 }
 
+// Backward pass 1 holds one wave per SIMD (register file): one workgroup per CU in a single
+// round beats two rounds of half the length (57 vs 64 us at B*M = 16384), the per-wave
+// constant setup being paid once.
+static int sa_grid_pass1(int tiles) {
+    int g = sa_grid(tiles);
+    return g < 256 ? g : 256;
+}
+
 }  // namespace apn
 
 extern "C" int apn_sa_grid_blocks(int b, int m) { return apn::sa_grid(b * m); }
+extern "C" int apn_sa_bwd_pass1_rows(int b, int m) { return apn::sa_grid_pass1(b * m); }
 
 // ft holds `precision` tables of (B,N,32) bf16 back to back: [hi] or [hi][lo].
 extern "C" int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, int precision,
@@ -642,11 +651,11 @@ extern "C" int apn_sa_bwd_pass1(int b, int n, int m, int c_in, int c_mid, int c_
     SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius);
     SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, d2e2, goa, ksel, nullptr);
     if (precision == 2)
-        hipLaunchKernelGGL((sa_bwd_kernel<1, 2>), dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+        hipLaunchKernelGGL((sa_bwd_kernel<1, 2>), dim3(sa_grid_pass1(b * m)), dim3(SA_WAVES * 64), 0,
                            (hipStream_t)stream, a, g, part, gw2_acc, (float *)nullptr,
                            (float *)nullptr);
     else
-        hipLaunchKernelGGL((sa_bwd_kernel<1, 1>), dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
+        hipLaunchKernelGGL((sa_bwd_kernel<1, 1>), dim3(sa_grid_pass1(b * m)), dim3(SA_WAVES * 64), 0,
                            (hipStream_t)stream, a, g, part, gw2_acc, (float *)nullptr,
                            (float *)nullptr);
     APN_LAUNCH_CHECK();

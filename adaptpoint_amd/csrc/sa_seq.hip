@@ -68,7 +68,7 @@ extern "C" int apn_sa_backward_seq(
     // gradients out
     float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_g1, float *g_b1, float *g_g2,
     float *g_b2, float *g_ws, float *g_bs, void *stream) {
-    const int rows = apn_sa_grid_blocks(b, m);
+    const int rows_t = apn_sa_bwd_pass1_rows(b, m);
     const int prow = apn_sa_bwd_prep_rows(b, m);
     if (phases & 1) {
         hipError_t me = hipMemsetAsync(zero_base, 0, zero_bytes, (hipStream_t)stream);
@@ -83,7 +83,7 @@ extern "C" int apn_sa_backward_seq(
                                  w2, pack1, qm, evec, d2e2, goa, ksel, partT, g_w2, stream));
     }
     if (phases & 4) {
-        APN_TRY(apn_sa_bwd_consts1(sumsT ? nullptr : partT, rows, sumsT, pack1, count, train1, cabc,
+        APN_TRY(apn_sa_bwd_consts1(sumsT ? nullptr : partT, rows_t, sumsT, pack1, count, train1, cabc,
                                    g_g1, g_b1, stream));
         APN_TRY(apn_sa_bwd_pass2(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, w1,
                                  w2, pack1, qm, evec, goa, ksel, cabc, G, H, stream));

@@ -217,7 +217,7 @@ def _backward(fw, g_out, need_p, need_newp):
     has_skip = ws is not None
     lib = _lib.load()
     call = _Launcher(dev)
-    rows = lib.apn_sa_grid_blocks(B, M)
+    rows = lib.apn_sa_bwd_pass1_rows(B, M)
     prow = lib.apn_sa_bwd_prep_rows(B, M)
     wrows = lib.apn_sa_bwd_weight_rows(B, N)
 

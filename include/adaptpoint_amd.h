@@ -135,6 +135,8 @@ APN_API int apn_ball_query_zero(int b, int n, int m, float radius, int nsample,
 
 /* Workgroups (= partial rows) the fused passes launch for B clouds x M queries. */
 APN_API int apn_sa_grid_blocks(int b, int m);
+/* rows of backward pass 1's partial sums (partT) */
+APN_API int apn_sa_bwd_pass1_rows(int b, int m);
 
 /* `precision` (every function that takes ft): 1 = operands rounded to bf16; 2 = operands split
  * into hi + lo bf16 parts, each product three MFMAs (hi*hi + hi*lo + lo*hi, "bf16x3"): fp32-grade
