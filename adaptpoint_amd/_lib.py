@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libadaptpoint_amd.so")
 
 _c_int, _c_float, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _c_double = ctypes.c_double
+_c_longlong = ctypes.c_longlong
 
 # name -> argtypes, exactly the prototypes of include/adaptpoint_amd.h
 SIGNATURES = {
@@ -41,15 +42,15 @@ SIGNATURES = {
     "apn_sa_fwd_out": [_c_int] * 3 + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 3 + [_c_int]
                       + [_c_void_p] * 2,
     "apn_sa_bwd_prep_rows": [_c_int] * 2,
-    "apn_sa_bwd_prep": [_c_int] * 3 + [_c_void_p] * 2 + [_c_int] + [_c_void_p] * 3 + [_c_int]
-                       + [_c_void_p] * 7,
-    "apn_sa_bwd_consts2": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_double, _c_int] + [_c_void_p] * 6,
+    "apn_sa_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] + [_c_int]
+                       + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 7,
+    "apn_sa_bwd_consts2": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_double, _c_int] + [_c_void_p] * 7,
     "apn_sa_bwd_pass1": [_c_int] * 8 + [_c_float] + [_c_void_p] * 15,
     "apn_sa_bwd_consts1": [_c_void_p, _c_int] + [_c_void_p] * 2 + [_c_double, _c_int] + [_c_void_p] * 4,
     "apn_sa_bwd_pass2": [_c_int] * 8 + [_c_float] + [_c_void_p] * 15,
-    "apn_sa_bwd_input_grad": [_c_int] * 3 + [_c_void_p] * 4 + [_c_float] + [_c_void_p] * 4,
     "apn_sa_bwd_weight_rows": [_c_int] * 2,
-    "apn_sa_bwd_weight_grad": [_c_int] * 3 + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 4,
+    "apn_sa_bwd_point_grads": [_c_int] * 3 + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 4 + [_c_float]
+                              + [_c_void_p] * 5,
     "apn_sa_bwd_finalize": [_c_void_p, _c_int, _c_float, _c_void_p, _c_void_p, _c_int, _c_void_p,
                             _c_void_p, _c_void_p, _c_void_p],
     "apn_sa_forward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 9
@@ -57,7 +58,8 @@ SIGNATURES = {
                            + [_c_void_p] * 5 + [_c_float, _c_float, _c_int]
                            + [_c_double, _c_int] + [_c_void_p] * 12),
     "apn_sa_backward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 14 + [_c_int] * 3
-                            + [_c_double] + [_c_void_p] * 2 + [ctypes.c_size_t]
+                            + [_c_double] + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p]
+                            + [ctypes.c_size_t]
                             + [_c_void_p] * 26),
     "apn_sa_sample_seq": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 6,
 }

@@ -39,6 +39,9 @@ struct FpsOrder {
     int n, bs, L, full, rem;
 };
 
+// 1e10f, the value callers pre-fill `temp` with (subsample.py:94).
+constexpr unsigned FPS_BIG_BITS = 0x501502F9u;
+
 // Number of points owned by reference threads whose L-bit reversed id is < R.
 __device__ __forceinline__ int fps_rank_start(const FpsOrder &o, int R) {
     int g = 0;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(W * 64) void fps_reg_kernel(FpsOrder o, int m,
     const int n = o.n;
     const int cloud = blockIdx.x;
     xyz += (size_t)cloud * n * 3;
-    temp += (size_t)cloud * n;
+    if (temp) temp += (size_t)cloud * n;   // null: start from 1e10 everywhere, no write-back
     idxs += (size_t)cloud * m;
     if (new_xyz) new_xyz += (size_t)cloud * m * 3;   // optional: coordinates of the picks
 
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(W * 64) void fps_reg_kernel(FpsOrder o, int m,
             px[s] = xyz[p * 3 + 0];
             py[s] = xyz[p * 3 + 1];
             pz[s] = xyz[p * 3 + 2];
-            dmin[s] = __float_as_uint(temp[p]);
+            dmin[s] = temp ? __float_as_uint(temp[p]) : FPS_BIG_BITS;
         } else {
             // Padding: min-distance stays +0.0 and sits at the highest
             // positions, so it can only tie, and a tie goes to a real point.
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(W * 64) void fps_reg_kernel(FpsOrder o, int m,
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int q = tid * S + s;
-        if (q < n) temp[pid[s]] = __uint_as_float(dmin[s]);
+        if (temp && q < n) temp[pid[s]] = __uint_as_float(dmin[s]);
     }
 }
 
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(W * 64) void fps_atomic_kernel(FpsOrder o, int m,
     const int n = o.n;
     const int cloud = blockIdx.x;
     xyz += (size_t)cloud * n * 3;
-    temp += (size_t)cloud * n;
+    if (temp) temp += (size_t)cloud * n;   // null: start from 1e10 everywhere, no write-back
     idxs += (size_t)cloud * m;
     if (new_xyz) new_xyz += (size_t)cloud * m * 3;
     const int tid = threadIdx.x;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(W * 64) void fps_atomic_kernel(FpsOrder o, int m,
             px[s] = xyz[p * 3 + 0];
             py[s] = xyz[p * 3 + 1];
             pz[s] = xyz[p * 3 + 2];
-            dmin[s] = __float_as_uint(temp[p]);
+            dmin[s] = temp ? __float_as_uint(temp[p]) : FPS_BIG_BITS;
             tab[q] = make_float4(px[s], py[s], pz[s], __int_as_float(p));
         } else {
             px[s] = py[s] = pz[s] = 0.0f;      // padding: distance stays +0.0 at the highest ranks
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(W * 64) void fps_atomic_kernel(FpsOrder o, int m,
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int q = tid * S + s;
-        if (q < n) temp[__float_as_int(tab[q].w)] = __uint_as_float(dmin[s]);
+        if (temp && q < n) temp[__float_as_int(tab[q].w)] = __uint_as_float(dmin[s]);
     }
 }
 
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(512) void fps_stamp_kernel(FpsOrder o, int m, const
     const int n = o.n;
     const int cloud = blockIdx.x;
     xyz += (size_t)cloud * n * 3;
-    temp += (size_t)cloud * n;
+    if (temp) temp += (size_t)cloud * n;   // null: start from 1e10 everywhere, no write-back
     idxs += (size_t)cloud * m;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(512) void fps_stamp_kernel(FpsOrder o, int m, const
         px[s] = q < n ? xyz[p * 3 + 0] : 0.f;
         py[s] = q < n ? xyz[p * 3 + 1] : 0.f;
         pz[s] = q < n ? xyz[p * 3 + 2] : 0.f;
-        dmin[s] = q < n ? __float_as_uint(temp[p]) : 0u;
+        dmin[s] = q < n ? (temp ? __float_as_uint(temp[p]) : FPS_BIG_BITS) : 0u;
     }
     __shared__ float4 rec[2][W];
     __shared__ int rec_pid[2][W];
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(512) void fps_stamp_kernel(FpsOrder o, int m, const
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int q = tid * S + s;
-        if (q < n) temp[pid[s]] = __uint_as_float(dmin[s]);
+        if (temp && q < n) temp[pid[s]] = __uint_as_float(dmin[s]);
     }
 }
 
@@ -524,7 +527,8 @@ static int fps_impl(int b, int n, int m, const float *xyz, float *temp, int *idx
     using namespace apn;
     if (b < 0) return APN_EINVAL;
     if (b == 0 || m <= 0) return APN_OK;  // sampling_gpu.cu:110
-    if (n <= 0 || !xyz || !temp || !idxs) return APN_EINVAL;
+    if (n <= 0 || !xyz || !idxs) return APN_EINVAL;
+    if (!temp && (!new_xyz || n > 16384)) return APN_EINVAL;   // only the _xyz entry may omit temp
     hipStream_t st = (hipStream_t)stream;
 
     FpsOrder o;

@@ -13,36 +13,50 @@ namespace apn {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 // sums[c] = sum_rows part[row][c] in float64, for a workgroup of 1024 threads and
-// ncol <= 128 (ncol a power of two): threads = ncol columns x (1024/ncol) row groups.
-// With part == null the caller's `sums` (already reduced, e.g. all-reduced over ranks)
-// are copied instead.  Result valid in `out` after the trailing barrier.
+// ncol a power of two in 4..128 (rows 16-byte aligned): threads = ncol/4 column quads x row groups, 16-byte loads
+// 8 deep (a single workgroup pulls ~1 us per 16 KB when its loads are narrow and serial:
+// 128 KB of rows was 8 us), then a tree over the row groups in LDS.  Fixed summation
+// order: deterministic.  With part == null the caller's `sums` (already reduced, e.g.
+// all-reduced over ranks) are copied instead.  Result valid in `out` after the trailing
+// barrier.
 __device__ __forceinline__ void block_sum_rows(const float *__restrict__ part, int rows, int ncol,
                                                const double *__restrict__ sums, double *out) {
-    __shared__ double red[1024];
+    __shared__ double red[1024 * 4];
     const int t = threadIdx.x;
     if (!part) {
         if (t < ncol) out[t] = sums[t];
         __syncthreads();
         return;
     }
-    const int c = t % ncol, g = t / ncol, groups = 1024 / ncol;
-    double s = 0.0;
+    const int quads = ncol >> 2, q = t % quads, g = t / quads, groups = 1024 / quads;
+    const float4 *__restrict__ p4 = (const float4 *)part;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int r = g;
-    for (; r + 7 * groups < rows; r += 8 * groups) {   // 8 independent loads in flight
-        float v[8];
+    for (; r + 7 * groups < rows; r += 8 * groups) {   // 8 independent 16-byte loads in flight
+        float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(r + u * groups) * ncol + c];
+        for (int u = 0; u < 8; ++u) v[u] = p4[(size_t)(r + u * groups) * quads + q];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += (double)v[u];
+        for (int u = 0; u < 8; ++u) {
+            s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w;
+        }
     }
-    for (; r < rows; r += groups) s += (double)part[(size_t)r * ncol + c];
-    red[t] = s;
+    for (; r < rows; r += groups) {
+        const float4 v = p4[(size_t)r * quads + q];
+        s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+    }
+    double *mine = red + (size_t)g * ncol + 4 * q;
+    mine[0] = s0; mine[1] = s1; mine[2] = s2; mine[3] = s3;
     __syncthreads();
-    if (t < ncol) {
-        double acc = 0.0;
-        for (int k = 0; k < groups; ++k) acc += red[k * ncol + t];
-        out[t] = acc;
+    for (int st = groups >> 1; st > 0; st >>= 1) {
+        if (g < st) {
+            const double *other = mine + (size_t)st * ncol;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mine[j] += other[j];
+        }
+        __syncthreads();
     }
+    if (t < ncol) out[t] = red[t];
     __syncthreads();
 }
 
@@ -175,6 +189,7 @@ __global__ __launch_bounds__(256) void fwd_out_kernel(int n, int m, const float 
 //   gip[b][n][i]   += sum_c ws[c][i] * g[q][c]  at n = fidx[b][q]   (dL/df through the skip,
 //                     point-major rows: 128-byte atomic segments)
 __global__ __launch_bounds__(256) void bwd_prep_kernel(int n, int m, const float *__restrict__ g_out,
+                                                       long long gs_b, long long gs_c, long long gs_m,
                                                        const float *__restrict__ out, int relu,
                                                        const float *__restrict__ ysel,
                                                        const float *__restrict__ pack2,
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(int n, int m, const float
         float g = 0.0f;
         if (m0 + tx < m) {
             const size_t o = ((size_t)cloud * 64 + c) * m + m0 + tx;
-            g = g_out[o];
+            g = g_out[cloud * gs_b + c * gs_c + (m0 + tx) * gs_m];
             if (relu && !(out[o] > 0.0f)) g = 0.0f;
         }
         tile[tx][c] = g;
@@ -256,8 +271,13 @@ __global__ __launch_bounds__(1024) void bwd_consts2_kernel(const float *__restri
                                                            float *__restrict__ qm,
                                                            float *__restrict__ evec,
                                                            float *__restrict__ g_gamma2,
-                                                           float *__restrict__ g_beta2) {
+                                                           float *__restrict__ g_beta2,
+                                                           float *__restrict__ zero_w2) {
     __shared__ double D[64], E[64], S[128];
+    if (zero_w2) {   // dL/dW2 (64x32) is accumulated atomically by pass 1, the next launch
+        zero_w2[threadIdx.x] = 0.0f;
+        zero_w2[1024 + threadIdx.x] = 0.0f;
+    }
     block_sum_rows(partS, rows, 128, S_in, S);
     const int t = threadIdx.x;
     if (t < 64) {
@@ -303,102 +323,62 @@ __global__ __launch_bounds__(1024) void bwd_consts1_kernel(
     if (g_beta1) g_beta1[i] = (float)T[i];
 }
 
-// dL/df[b][i][n] = sum_mid G[b][n][mid] * W1[mid][3+i]  (+ gip[b][n][i], the skip branch);  optionally
-// dL/dp[b][n][d] = sum_mid G[b][n][mid] * W1[mid][d] / r  (accumulated: +=).
-__global__ __launch_bounds__(256) void bwd_input_grad_kernel(int n, const float *__restrict__ G,
-                                                             const float *__restrict__ w1,
-                                                             const float *__restrict__ gip,
-                                                             float inv_r, float *__restrict__ g_f,
-                                                             float *__restrict__ g_p) {
-    __shared__ float sw[32][36];     // W1[mid][35]
-    __shared__ float sg[64][33];     // G tile [point][mid]
-    __shared__ float si[64][33];     // gip tile [point][i]
-    const int cloud = blockIdx.y, n0 = blockIdx.x * 64;
-    for (int e = threadIdx.x; e < 32 * 35; e += 256) sw[e / 35][e % 35] = w1[e];
-    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
-        const int pt = e >> 5, mid = e & 31;
-        sg[pt][mid] = n0 + pt < n ? G[((size_t)cloud * n + n0 + pt) * 32 + mid] : 0.0f;
-        si[pt][mid] = (gip && n0 + pt < n) ? gip[((size_t)cloud * n + n0 + pt) * 32 + mid] : 0.0f;
-    }
-    __syncthreads();
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // tx = point, ty = channel group
-    for (int i = ty; i < 32; i += 4) {
-        float s = si[tx][i];
-#pragma unroll
-        for (int mid = 0; mid < 32; ++mid) s += sg[tx][mid] * sw[mid][3 + i];
-        if (n0 + tx < n) g_f[((size_t)cloud * 32 + i) * n + n0 + tx] = s;
-    }
-    if (g_p && ty < 3 && n0 + tx < n) {
-        float s = 0.0f;
-#pragma unroll
-        for (int mid = 0; mid < 32; ++mid) s += sg[tx][mid] * sw[mid][ty];
-        g_p[((size_t)cloud * n + n0 + tx) * 3 + ty] += s * inv_r;
-    }
-}
-
-// dL/dnew_p[q][d] = -sum_mid H[q][mid] * W1[mid][d] / r
-__global__ __launch_bounds__(256) void bwd_query_grad_kernel(int total_q, const float *__restrict__ H,
-                                                             const float *__restrict__ w1,
-                                                             float inv_r, float *__restrict__ g_q) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= total_q) return;
-    float s[3] = {0.f, 0.f, 0.f};
-    for (int mid = 0; mid < 32; ++mid) {
-        const float hv = H[(size_t)q * 32 + mid];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) s[d] += hv * w1[mid * 35 + d];
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) g_q[(size_t)q * 3 + d] = -s[d] * inv_r;
-}
-
-// Products over points for dL/dW1: partW[block][mid][38], columns
-//   0..2   sum_n G[n][mid] * xyz[n][d]
-//   3..5   sum_q H[q][mid] * new_xyz[q][d]
-//   6..37  sum_n G[n][mid] * ft[n][i]
-// over the block's tiles of WG_PTS points (and the query tiles of the same index).  bwd_finalize sums the
-// blocks in float64 and forms (col0-2 - col3-5)/r.  256 threads = 32 mid x 8 column
-// groups; column group g owns columns {g, g+8, g+16, g+24, g+32}: every wave (two groups)
-// then runs the same instruction stream, and the staged tile is read as sB[pt][col].
+// Everything that is linear in G (dL/dy1 summed per source point) and H (per query), one
+// workgroup per tile of WG_PTS points of one cloud, the tiles staged in LDS once:
+//   partW[block][mid][38]  products over the tile for dL/dW1, columns
+//       0..2   sum_n G[n][mid] * xyz[n][d]
+//       3..5   sum_q H[q][mid] * new_xyz[q][d]     (query tile of the same flat index)
+//       6..37  sum_n G[n][mid] * ft[n][i]
+//     bwd_finalize sums the blocks in float64 and forms (col0-2 - col3-5)/r;
+//   dL/df[b][i][n]  = sum_mid G[b][n][mid] * W1[mid][3+i]  (+ gip[b][n][i], the skip branch);
+//   dL/dp[b][n][d] += sum_mid G[b][n][mid] * W1[mid][d] / r          (optional)
+//   dL/dnew_p[q][d] = -sum_mid H[q][mid] * W1[mid][d] / r            (optional)
+// For the products 256 threads = 32 mid x 8 column groups; group g owns columns
+// {g, g+8, g+16, g+24, g+32}: every wave (two groups) runs the same instruction stream and
+// the staged tile is read as sB[pt][col].
 constexpr int WG_PTS = 64;
 
-__global__ __launch_bounds__(256) void bwd_weight_grad_kernel(int total_n, int total_q,
-                                                              const float *__restrict__ G,
-                                                              const float *__restrict__ H,
-                                                              const __bf16 *__restrict__ ft,
-                                                              const __bf16 *__restrict__ ft_lo,
-                                                              const float *__restrict__ xyz,
-                                                              const float *__restrict__ new_xyz,
-                                                              float *__restrict__ partW) {
+__global__ __launch_bounds__(256) void bwd_point_grads_kernel(
+    int n, int total_q, const float *__restrict__ G, const float *__restrict__ H,
+    const __bf16 *__restrict__ ft, const __bf16 *__restrict__ ft_lo, const float *__restrict__ xyz,
+    const float *__restrict__ new_xyz, const float *__restrict__ w1, const float *__restrict__ gip,
+    float inv_r, float *__restrict__ partW, float *__restrict__ g_f, float *__restrict__ g_p,
+    float *__restrict__ g_q) {
+    __shared__ float sw[32][36];        // W1[mid][35]
     __shared__ float sG[WG_PTS][33];    // G [point][mid]
     __shared__ float sH[WG_PTS][33];    // H [query][mid]
+    __shared__ float sI[WG_PTS][33];    // gip [point][i]
     __shared__ float sB[WG_PTS][41];    // columns 0..2 xyz, 3..5 new_xyz (query rows), 6..37 ft
     const int tid = threadIdx.x;
-    const int mid = tid & 31, grp = tid >> 5;
-    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    // column grp + 8 j; only j = 0 can be a query column (3..5), and only for grp in {3,4,5}
-    const bool qcol = grp >= 3 && grp <= 5;
-    const int n_tiles = (total_n + WG_PTS - 1) / WG_PTS, q_tiles = (total_q + WG_PTS - 1) / WG_PTS;
-    const int tiles = n_tiles > q_tiles ? n_tiles : q_tiles;
-    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int r0 = tile * WG_PTS;
-        __syncthreads();
-        for (int e = tid; e < WG_PTS * 32; e += 256) {
-            const int pt = e >> 5, c = e & 31;
-            const bool ok = r0 + pt < total_n;
-            sG[pt][c] = ok ? G[(size_t)(r0 + pt) * 32 + c] : 0.0f;
-            float fv = ok ? (float)ft[(size_t)(r0 + pt) * 32 + c] : 0.0f;
-            if (ft_lo && ok) fv += (float)ft_lo[(size_t)(r0 + pt) * 32 + c];     // split mode: hi + lo
-            sB[pt][6 + c] = fv;
-            sH[pt][c] = r0 + pt < total_q ? H[(size_t)(r0 + pt) * 32 + c] : 0.0f;
-        }
-        for (int e = tid; e < WG_PTS * 3; e += 256) {
-            const int pt = e / 3, d = e % 3;
-            sB[pt][d] = r0 + pt < total_n ? xyz[(size_t)(r0 + pt) * 3 + d] : 0.0f;
-            sB[pt][3 + d] = r0 + pt < total_q ? new_xyz[(size_t)(r0 + pt) * 3 + d] : 0.0f;
-        }
-        for (int e = tid; e < WG_PTS * 2; e += 256) sB[e >> 1][38 + (e & 1)] = 0.0f;   // pad columns
-        __syncthreads();
+    const int cloud = blockIdx.y, n0 = blockIdx.x * WG_PTS;
+    const int block = cloud * gridDim.x + blockIdx.x;
+    const size_t p0 = (size_t)cloud * n + n0;            // first point row of the tile
+    const int q0 = block * WG_PTS;                       // first query row (flat)
+    const int n_here = n - n0 < WG_PTS ? n - n0 : WG_PTS;
+    for (int e = tid; e < 32 * 35; e += 256) sw[e / 35][e % 35] = w1[e];
+    for (int e = tid; e < WG_PTS * 32; e += 256) {
+        const int pt = e >> 5, c = e & 31;
+        const bool ok = pt < n_here;
+        sG[pt][c] = ok ? G[(p0 + pt) * 32 + c] : 0.0f;
+        float fv = ok ? (float)ft[(p0 + pt) * 32 + c] : 0.0f;
+        if (ft_lo && ok) fv += (float)ft_lo[(p0 + pt) * 32 + c];     // split mode: hi + lo
+        sB[pt][6 + c] = fv;
+        sI[pt][c] = (gip && ok) ? gip[(p0 + pt) * 32 + c] : 0.0f;
+        sH[pt][c] = q0 + pt < total_q ? H[(size_t)(q0 + pt) * 32 + c] : 0.0f;
+    }
+    for (int e = tid; e < WG_PTS * 3; e += 256) {
+        const int pt = e / 3, d = e % 3;
+        sB[pt][d] = pt < n_here ? xyz[(p0 + pt) * 3 + d] : 0.0f;
+        sB[pt][3 + d] = q0 + pt < total_q ? new_xyz[(size_t)(q0 + pt) * 3 + d] : 0.0f;
+    }
+    for (int e = tid; e < WG_PTS * 2; e += 256) sB[e >> 1][38 + (e & 1)] = 0.0f;   // pad columns
+    __syncthreads();
+
+    {   // products for dL/dW1
+        const int mid = tid & 31, grp = tid >> 5;
+        // column grp + 8 j; only j = 0 can be a query column (3..5), and only for grp in {3,4,5}
+        const bool qcol = grp >= 3 && grp <= 5;
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int pt = 0; pt < WG_PTS; ++pt) {
             const float g = sG[pt][mid];
@@ -407,13 +387,34 @@ __global__ __launch_bounds__(256) void bwd_weight_grad_kernel(int total_n, int t
 #pragma unroll
             for (int j = 1; j < 5; ++j) acc[j] += g * sB[pt][grp + 8 * j];
         }
-    }
-    // one workgroup per tile, one partial row per workgroup; bwd_finalize sums them in float64
-    float *row = partW + (size_t)blockIdx.x * 32 * 38;
+        float *row = partW + (size_t)block * 32 * 38;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int col = grp + 8 * j;
-        if (col < 38) row[mid * 38 + col] = acc[j];
+        for (int j = 0; j < 5; ++j) {
+            const int col = grp + 8 * j;
+            if (col < 38) row[mid * 38 + col] = acc[j];
+        }
+    }
+
+    const int tx = tid & 63, ty = tid >> 6;              // tx = point / query, ty = channel group
+    for (int i = ty; i < 32; i += 4) {
+        float s = sI[tx][i];
+#pragma unroll
+        for (int mid = 0; mid < 32; ++mid) s += sG[tx][mid] * sw[mid][3 + i];
+        if (tx < n_here) g_f[((size_t)cloud * 32 + i) * n + n0 + tx] = s;
+    }
+    if (ty < 3) {
+        if (g_p && tx < n_here) {
+            float s = 0.0f;
+#pragma unroll
+            for (int mid = 0; mid < 32; ++mid) s += sG[tx][mid] * sw[mid][ty];
+            g_p[(p0 + tx) * 3 + ty] += s * inv_r;
+        }
+        if (g_q && q0 + tx < total_q) {
+            float s = 0.0f;
+#pragma unroll
+            for (int mid = 0; mid < 32; ++mid) s += sH[tx][mid] * sw[mid][ty];
+            g_q[(size_t)(q0 + tx) * 3 + ty] = -s * inv_r;
+        }
     }
 }
 
@@ -477,7 +478,8 @@ __global__ __launch_bounds__(256) void bwd_finalize_kernel(
 #define APN_ST ((hipStream_t)stream)
 
 extern "C" int apn_sa_reduce_rows(const float *part, int rows, int ncol, double *out, void *stream) {
-    if (rows < 0 || ncol <= 0 || ncol > 128 || (1024 % ncol) || !part || !out) return APN_EINVAL;
+    if (rows < 0 || ncol < 4 || ncol > 128 || (1024 % ncol) || !part || !out) return APN_EINVAL;
+    if ((uintptr_t)part & 15) return APN_EINVAL;
     hipLaunchKernelGGL(apn::reduce_rows_kernel, dim3(1), dim3(1024), 0, APN_ST, part, rows, ncol, out);
     APN_LAUNCH_CHECK();
     return APN_OK;
@@ -513,7 +515,8 @@ extern "C" int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const floa
 
 extern "C" int apn_sa_bwd_prep_rows(int b, int m) { return b * ((m + 63) / 64); }
 
-extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, const float *out, int relu,
+extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long long gs_b,
+                               long long gs_c, long long gs_m, const float *out, int relu,
                                const float *ysel, const float *pack2, const void *ft, int precision,
                                const int *fidx, const float *ws, float *goa, float *partS,
                                float *partWs, float *gip, void *stream) {
@@ -524,7 +527,7 @@ extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, const fl
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = (ws && precision == 2) ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::bwd_prep_kernel, dim3((m + 63) / 64, b), dim3(256), 0, APN_ST, n, m, g_out,
-                       out, relu, ysel, pack2, hi, lo, fidx, ws, goa, partS, partWs, gip);
+                       gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, partS, partWs, gip);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -532,10 +535,10 @@ extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, const fl
 extern "C" int apn_sa_bwd_consts2(const float *partS, int rows, const double *S, const float *pack2,
                                   const float *w2, double count, int training, float *d2e2,
                                   float *qm, float *evec, float *g_gamma2, float *g_beta2,
-                                  void *stream) {
+                                  float *zero_w2, void *stream) {
     if ((!partS && !S) || !pack2 || !w2 || !d2e2 || !qm || !evec) return APN_EINVAL;
     hipLaunchKernelGGL(apn::bwd_consts2_kernel, dim3(1), dim3(1024), 0, APN_ST, partS, rows, S, pack2,
-                       w2, count, training, d2e2, qm, evec, g_gamma2, g_beta2);
+                       w2, count, training, d2e2, qm, evec, g_gamma2, g_beta2, zero_w2);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -550,35 +553,22 @@ extern "C" int apn_sa_bwd_consts1(const float *partT, int rows, const double *T,
     return APN_OK;
 }
 
-extern "C" int apn_sa_bwd_input_grad(int b, int n, int m, const float *G, const float *H,
-                                     const float *w1, const float *gip, float radius, float *g_f,
-                                     float *g_p, float *g_newp, void *stream) {
-    if (b <= 0 || n <= 0 || b > 65535 || !G || !w1 || !g_f) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::bwd_input_grad_kernel, dim3((n + 63) / 64, b), dim3(256), 0, APN_ST, n, G,
-                       w1, gip, 1.0f / radius, g_f, g_p);
-    APN_LAUNCH_CHECK();
-    if (g_newp) {
-        if (!H || m <= 0) return APN_EINVAL;
-        hipLaunchKernelGGL(apn::bwd_query_grad_kernel, dim3((b * m + 255) / 256), dim3(256), 0, APN_ST,
-                           b * m, H, w1, 1.0f / radius, g_newp);
-        APN_LAUNCH_CHECK();
-    }
-    return APN_OK;
-}
+extern "C" int apn_sa_bwd_weight_rows(int b, int n) { return b * ((n + apn::WG_PTS - 1) / apn::WG_PTS); }
 
-extern "C" int apn_sa_bwd_weight_rows(int b, int n) { return (b * n + apn::WG_PTS - 1) / apn::WG_PTS; }
-
-extern "C" int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const float *H,
+extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const float *G, const float *H,
                                       const void *ft, int precision, const float *xyz,
-                                      const float *new_xyz, float *partW, void *stream) {
-    if (b <= 0 || n <= 0 || m <= 0 || !G || !H || !ft || !xyz || !new_xyz || !partW) return APN_EINVAL;
+                                      const float *new_xyz, const float *w1, const float *gip,
+                                      float radius, float *partW, float *g_f, float *g_p,
+                                      float *g_newp, void *stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || b > 65535) return APN_EINVAL;
+    if (!G || !H || !ft || !xyz || !new_xyz || !w1 || !partW || !g_f) return APN_EINVAL;
     if (precision != 1 && precision != 2) return APN_EINVAL;
+    if (m > n) return APN_EINVAL;                    // query tiles are walked with the point tiles
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = precision == 2 ? hi + (size_t)b * n * 32 : nullptr;
-    if (m > n) return APN_EINVAL;                    // query tiles are walked with the point tiles
-    const int blocks = (b * n + apn::WG_PTS - 1) / apn::WG_PTS;
-    hipLaunchKernelGGL(apn::bwd_weight_grad_kernel, dim3(blocks), dim3(256), 0, APN_ST, b * n, b * m, G,
-                       H, hi, lo, xyz, new_xyz, partW);
+    hipLaunchKernelGGL(apn::bwd_point_grads_kernel, dim3((n + apn::WG_PTS - 1) / apn::WG_PTS, b),
+                       dim3(256), 0, APN_ST, n, b * m, G, H, hi, lo, xyz, new_xyz, w1, gip,
+                       1.0f / radius, partW, g_f, g_p, g_newp);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

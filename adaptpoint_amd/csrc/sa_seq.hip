@@ -59,8 +59,9 @@ extern "C" int apn_sa_backward_seq(
     const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
-    const float *g_out,
-    // zero-filled here (phase 1): g_w2 (64*32) | G (B*N*32) | gip (B*N*32, only with ws)
+    const float *g_out, long long gs_b, long long gs_c, long long gs_m,
+    // zero-filled here: G (B*N*32) | gip (B*N*32, only with ws) by one memset (phase 1);
+    // g_w2 (64*32) by the consts2 launch (phase 2)
     float *zero_base, size_t zero_bytes, float *g_w2, float *G, float *gip,
     // scratch
     float *goa, float *partS, float *partWs, float *partT, float *partW, const double *sumsS,
@@ -73,12 +74,12 @@ extern "C" int apn_sa_backward_seq(
     if (phases & 1) {
         hipError_t me = hipMemsetAsync(zero_base, 0, zero_bytes, (hipStream_t)stream);
         if (me != hipSuccess) return (int)me;
-        APN_TRY(apn_sa_bwd_prep(b, n, m, g_out, out, relu, ysel, pack2, ws ? ft : nullptr, precision,
+        APN_TRY(apn_sa_bwd_prep(b, n, m, g_out, gs_b, gs_c, gs_m, out, relu, ysel, pack2, ws ? ft : nullptr, precision,
                                 ws ? fidx : nullptr, ws, goa, partS, partWs, gip, stream));
     }
     if (phases & 2) {
         APN_TRY(apn_sa_bwd_consts2(sumsS ? nullptr : partS, prow, sumsS, pack2, w2, count, train2,
-                                   d2e2, qm, evec, g_g2, g_b2, stream));
+                                   d2e2, qm, evec, g_g2, g_b2, g_w2, stream));
         APN_TRY(apn_sa_bwd_pass1(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, w1,
                                  w2, pack1, qm, evec, d2e2, goa, ksel, partT, g_w2, stream));
     }
@@ -87,8 +88,8 @@ extern "C" int apn_sa_backward_seq(
                                    g_g1, g_b1, stream));
         APN_TRY(apn_sa_bwd_pass2(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, w1,
                                  w2, pack1, qm, evec, goa, ksel, cabc, G, H, stream));
-        APN_TRY(apn_sa_bwd_input_grad(b, n, m, G, H, w1, gip, radius, g_f, g_p, g_newp, stream));
-        APN_TRY(apn_sa_bwd_weight_grad(b, n, m, G, H, ft, precision, xyz, new_xyz, partW, stream));
+        APN_TRY(apn_sa_bwd_point_grads(b, n, m, G, H, ft, precision, xyz, new_xyz, w1, gip, radius,
+                                       partW, g_f, g_p, g_newp, stream));
         APN_TRY(apn_sa_bwd_finalize(partW, apn_sa_bwd_weight_rows(b, n), radius, g_w1, partWs, prow,
                                     g_ws, partS, g_bs, stream));
     }
@@ -96,15 +97,16 @@ extern "C" int apn_sa_backward_seq(
 }
 
 // FPS (+ sampled coordinates) and ball query back-to-back: the index stage of a block.
-// temp (B,N) is filled with 1e10 here (subsample.py:94).
+// temp (B,N) is filled with 1e10 here (subsample.py:94); with temp == null (n <= 16384) the
+// sampler starts from 1e10 in registers and leaves no min-distances behind: one launch less.
 extern "C" int apn_sa_sample_seq(int b, int n, int m, float radius, int nsample, const float *xyz,
                                  float *temp, int *fidx, float *new_xyz, int *idx, void *stream) {
-    if (b <= 0 || n <= 0 || m <= 0 || !temp) return APN_EINVAL;
-    // 1e10f = 0x501502F9: not a byte pattern, so fill with a tiny kernel-free trick is not
-    // available; hipMemsetD32Async writes 32-bit words.
-    hipError_t me = hipMemsetD32Async((hipDeviceptr_t)temp, 0x501502F9, (size_t)b * n,
-                                      (hipStream_t)stream);
-    if (me != hipSuccess) return (int)me;
+    if (b <= 0 || n <= 0 || m <= 0) return APN_EINVAL;
+    if (temp) {   // 1e10f = 0x501502F9 as 32-bit words
+        hipError_t me = hipMemsetD32Async((hipDeviceptr_t)temp, 0x501502F9, (size_t)b * n,
+                                          (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+    }
     APN_TRY(apn_furthest_point_sampling_xyz(b, n, m, xyz, temp, fidx, new_xyz, stream));
     APN_TRY(apn_ball_query_zero(b, n, m, radius, nsample, new_xyz, xyz, idx, stream));
     return APN_OK;

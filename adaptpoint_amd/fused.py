@@ -212,7 +212,11 @@ def _backward(fw, g_out, need_p, need_newp):
     dev = g_out.device
     P, sync = sv["count"], fw.sync
     f32 = dict(dtype=torch.float32, device=dev)
-    g_out = g_out.contiguous()
+    if g_out is None:                 # only the other output was used downstream
+        g_out = torch.zeros_like(fw.out)
+    if g_out.dtype != torch.float32:
+        g_out = g_out.float()
+    gs = g_out.stride()               # read with strides: a broadcast gradient is never materialised
     w1, w2, ws = sv["w1"], sv["w2"], sv["ws"]
     has_skip = ws is not None
     lib = _lib.load()
@@ -233,7 +237,7 @@ def _backward(fw, g_out, need_p, need_newp):
     gsz = [("w2", C_OUT * C_MID), ("w1", C_MID * (C_IN + 3)), ("g1", C_MID), ("b1", C_MID),
            ("g2", C_OUT), ("b2", C_OUT), ("ws", C_OUT * C_IN if has_skip else 0),
            ("bs", C_OUT if (has_skip and sv["has_bs"]) else 0)]
-    g, _gbuf = _carve(dev, gsz, zero=True)
+    g, _gbuf = _carve(dev, gsz)           # every view is fully written (w2: cleared by consts2)
     g_f = torch.empty(B, C_IN, N, **f32)
     g_p = torch.zeros(B, N, 3, **f32) if need_p else None
     g_newp = torch.empty(B, M, 3, **f32) if need_newp else None
@@ -247,7 +251,8 @@ def _backward(fw, g_out, need_p, need_newp):
              w1.data_ptr(), w2.data_ptr(), _ptr(ws), sv["ft"].data_ptr(), sv["pack1"].data_ptr(),
              sv["pack2"].data_ptr(), sv["ysel"].data_ptr(), sv["ksel"].data_ptr(),
              fw.out.data_ptr(), fw.relu, 1 if fw.train1 else 0, 1 if fw.train2 else 0, float(P),
-             g_out.data_ptr(), buf.data_ptr(), zero_floats * 4, g["w2"].data_ptr(),
+             g_out.data_ptr(), gs[0], gs[1], gs[2], buf.data_ptr(), zero_floats * 4,
+             g["w2"].data_ptr(),
              v["G"].data_ptr(), v["gip"].data_ptr() if has_skip else None, v["goa"].data_ptr(),
              v["partS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None,
              v["partT"].data_ptr(), v["partW"].data_ptr(), _ptr(sumsS), _ptr(sumsT),
@@ -308,7 +313,7 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
            w2.data_ptr(), sv["pack1"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr())
     if phases & 1:
         buf[:zero_floats].zero_()
-        call("apn_sa_bwd_prep", B, N, M, g_out.data_ptr(), fw.out.data_ptr(), fw.relu,
+        call("apn_sa_bwd_prep", B, N, M, g_out.data_ptr(), *g_out.stride(), fw.out.data_ptr(), fw.relu,
              sv["ysel"].data_ptr(), sv["pack2"].data_ptr(), sv["ft"].data_ptr() if has_skip else None,
              fw.prec, _ptr(sv["fidx"]) if has_skip else None, _ptr(ws), v["goa"].data_ptr(),
              v["partS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None, gip)
@@ -316,7 +321,7 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
         call("apn_sa_bwd_consts2", None if sumsS is not None else v["partS"].data_ptr(), prow,
              _ptr(sumsS), sv["pack2"].data_ptr(), w2.data_ptr(), P, 1 if fw.train2 else 0,
              v["d2e2"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr(), g["g2"].data_ptr(),
-             g["b2"].data_ptr())
+             g["b2"].data_ptr(), g["w2"].data_ptr())
         call("apn_sa_bwd_pass1", *hdr, v["d2e2"].data_ptr(), v["goa"].data_ptr(),
              sv["ksel"].data_ptr(), v["partT"].data_ptr(), g["w2"].data_ptr())
     if phases & 4:
@@ -325,11 +330,9 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
              g["g1"].data_ptr(), g["b1"].data_ptr())
         call("apn_sa_bwd_pass2", *hdr, v["goa"].data_ptr(), sv["ksel"].data_ptr(),
              v["cabc"].data_ptr(), v["G"].data_ptr(), v["H"].data_ptr())
-        call("apn_sa_bwd_input_grad", B, N, M, v["G"].data_ptr(), v["H"].data_ptr(), w1.data_ptr(), gip,
-             fw.radius, g_f.data_ptr(), _ptr(g_p), _ptr(g_newp))
-        call("apn_sa_bwd_weight_grad", B, N, M, v["G"].data_ptr(), v["H"].data_ptr(),
-             sv["ft"].data_ptr(), fw.prec, sv["p"].data_ptr(), sv["new_p"].data_ptr(),
-             v["partW"].data_ptr())
+        call("apn_sa_bwd_point_grads", B, N, M, v["G"].data_ptr(), v["H"].data_ptr(),
+             sv["ft"].data_ptr(), fw.prec, sv["p"].data_ptr(), sv["new_p"].data_ptr(), w1.data_ptr(),
+             gip, fw.radius, v["partW"].data_ptr(), g_f.data_ptr(), _ptr(g_p), _ptr(g_newp))
         call("apn_sa_bwd_finalize", v["partW"].data_ptr(), wrows, fw.radius, g["w1"].data_ptr(),
              v["partWs"].data_ptr() if has_skip else None, prow,
              g["ws"].data_ptr() if has_skip else None, v["partS"].data_ptr(),
@@ -343,6 +346,7 @@ class _GroupedMlpMax(torch.autograd.Function):
         fw = _Forward(p.contiguous(), f.contiguous(), new_p.contiguous(), idx.contiguous(), None,
                       radius, conv1, bn1, conv2, bn2, None, False, sync_bn)
         ctx.fw = fw
+        ctx.set_materialize_grads(False)
         ctx.flags = (p.requires_grad, new_p.requires_grad,
                      g1 is not None, b1 is not None, g2 is not None, b2 is not None)
         return fw.out
@@ -394,14 +398,13 @@ def sample_and_query(p, npoint, radius, nsample=K_NS, out=None):
     assert smp.shape == (B, npoint, nsample)
     call = _Launcher(dev)
     if PER_KERNEL_LAUNCH:
-        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=dev)
-        call("apn_furthest_point_sampling_xyz", B, N, npoint, p.data_ptr(), temp.data_ptr(),
+        call("apn_furthest_point_sampling_xyz", B, N, npoint, p.data_ptr(), None,
              smp.fidx.data_ptr(), smp.new_p.data_ptr())
         call("apn_ball_query_zero", B, N, npoint, float(radius), nsample, smp.new_p.data_ptr(),
              p.data_ptr(), smp.idx.data_ptr())
         return smp
-    temp = torch.empty(B, N, dtype=torch.float32, device=dev)       # filled with 1e10 by the call
-    call("apn_sa_sample_seq", B, N, npoint, float(radius), nsample, p.data_ptr(), temp.data_ptr(),
+    # temp = None: the sampler starts from 1e10 in registers (no fill launch, no min-distances kept)
+    call("apn_sa_sample_seq", B, N, npoint, float(radius), nsample, p.data_ptr(), None,
          smp.fidx.data_ptr(), smp.new_p.data_ptr(), smp.idx.data_ptr())
     return smp
 
@@ -419,6 +422,7 @@ class _SetAbstraction(torch.autograd.Function):
         fw = _Forward(p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
                       sync_bn)
         ctx.fw = fw
+        ctx.set_materialize_grads(False)   # an unused output's gradient arrives as None, not as zeros
         ctx.flags = (p.requires_grad, g1 is not None, b1 is not None, g2 is not None,
                      b2 is not None, ws is not None, bs is not None)
         ctx.mark_non_differentiable(new_p) if not p.requires_grad else None

@@ -191,6 +191,9 @@ def main():
                          "index stage depends on coordinates only); fused path only")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from a captured HIP graph (auto: on at 1 GPU)")
+    ap.add_argument("--steps-per-graph", type=int, default=0,
+                    help="whole steps captured per hipGraph (0 = auto: the largest of 20, 10, 4, 2 dividing --steps "
+                         "and --warmup, single GPU; 1 = one step per replay)")
     ap.add_argument("--mlp", choices=["fused-bf16x3", "fused-bf16", "torch-f32"], default="fused-bf16x3",
                     help="grouped shared-MLP: fused bf16-MFMA kernels (csrc/sa_fused.hip) with split "
                          "hi+lo operands (fp32-grade, default) or plain bf16 operands, or the unfused "
@@ -248,10 +251,13 @@ def main():
     if pipelined:
         from adaptpoint_amd.fused import Sampling
         side_stream = torch.cuda.Stream()
-        cur_smp = blk.sample(p)                       # prologue: index stage of batch 0
-        nxt_smp = Sampling(*cur_smp.shape, dev)
+        # double buffer: step k consumes smp[k % 2] and fills smp[(k + 1) % 2]
+        smp = [blk.sample(p), None]                   # prologue: index stage of batch 0
+        smp[1] = Sampling(*smp[0].shape, dev)
+    parity = [0]
+    graph_grads, last_grads = [], [None]
 
-    def fwd_bwd():
+    def fwd_bwd(cur=0):
         if not pipelined:
             new_p, out = model([p, f])
             out.sum().backward()
@@ -259,52 +265,88 @@ def main():
         main = torch.cuda.current_stream()
         side_stream.wait_stream(main)                 # fork
         with torch.cuda.stream(side_stream):
-            blk.sample(p, out=nxt_smp)                # index stage of batch k+1 (32 CUs busy)
-        new_p, out = model([p, f], sampling=cur_smp)  # MLP forward+backward of batch k
+            blk.sample(p, out=smp[1 - cur])           # index stage of batch k+1 (32 CUs busy)
+        new_p, out = model([p, f], sampling=smp[cur])  # MLP forward+backward of batch k
         out.sum().backward()
         main.wait_stream(side_stream)                 # join
-        cur_smp.buf.copy_(nxt_smp.buf)                # rotate the double buffer (2.3 MB)
 
-    def step():
+    def clear_grads():
         f.grad = None
         for q in params:
             q.grad = None
-        fwd_bwd()
+
+    def step():
+        clear_grads()
+        fwd_bwd(parity[0])
+        parity[0] ^= 1
 
     use_graph = (args.graph == "on") or (args.graph == "auto" and not use_ddp)
     eager_step = step
+    # steps per graph: several whole steps per replay when no collective sits between steps
+    spg = 1
+    if use_graph and not distributed and args.steps_per_graph != 1:
+        for cand in ((args.steps_per_graph,) if args.steps_per_graph else (20, 10, 4, 2)):
+            if cand > 1 and args.steps % cand == 0 and args.warmup % cand == 0 and cand % 2 == 0:
+                spg = cand
+                break
     if use_graph:
         # Whole-step capture: every launch of the step (extension kernels through ctypes on the
         # capture stream, PyTorch ops, autograd) becomes one hipGraph; replay has no host work.
+        # The pipelined step is captured twice, once per orientation of the double buffer, and
+        # the two graphs alternate -- no buffer rotation copy on the critical path.
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(3):
+                for _ in range(4):
                     eager_step()
             torch.cuda.current_stream().wait_stream(side)
-            f.grad = None
-            for q in params:
-                q.grad = None
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                fwd_bwd()
-            step = graph.replay
+            graphs = []
+            if spg > 1:
+                # spg consecutive steps (alternating orientations) in ONE graph: the ~20-30 us
+                # the GPU idles between two graph launches is paid once per spg steps.
+                clear_grads()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for i in range(spg):
+                        if i:
+                            clear_grads()
+                        fwd_bwd(i % 2)
+                graphs.append(g)
+                graph_grads.append([q.grad for q in params if q.grad is not None])
+            else:
+                for cur in ((0, 1) if pipelined else (0,)):
+                    clear_grads()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        fwd_bwd(cur)
+                    graphs.append(g)
+                    # each capture owns its gradient tensors; a replay refreshes them in place
+                    graph_grads.append([q.grad for q in params if q.grad is not None])
+            parity[0] = 0
+
+            def step():
+                graphs[parity[0]].replay()
+                last_grads[0] = graph_grads[parity[0]]
+                parity[0] = (parity[0] + 1) % len(graphs)
         except Exception as exc:                      # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly",
                   file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             use_graph = False
+            spg = 1
             step = eager_step
     if distributed and not use_ddp:
         local_step = step
 
         def step():
             local_step()
-            dp.allreduce_mean_([q.grad for q in params if q.grad is not None])
+            dp.allreduce_mean_(last_grads[0] if use_graph
+                               else [q.grad for q in params if q.grad is not None])
 
     # W warm-up steps, barrier + synchronize, K timed steps, barrier + synchronize, MAX over ranks
-    elapsed = dp.timed_steps(step, args.steps, args.warmup, dev)
+    # (a replay of an spg-step graph counts as spg steps: exactly args.steps steps are timed)
+    elapsed = dp.timed_steps(step, args.steps // spg, args.warmup // spg, dev)
     # The timed step issues whole launch sequences (one C call per direction, or one hipGraph),
     # which cannot carry per-kernel events.  The dominant kernel is therefore timed right after
     # the timed region: the same launch, same inputs, same stream, HIP events around it.
@@ -372,7 +414,7 @@ def main():
                             "fused-bf16": "fused bf16 MFMA (operands rounded to bf16, f32 accumulate), "
                                           "f32 BatchNorm statistics summed in f64",
                             "torch-f32": "unfused: extension ops + PyTorch fp32 conv/BN"}[args.mlp]),
-                   "launch": "hipGraph replay" if use_graph else "eager",
+                   "launch": (f"hipGraph replay, {spg} step(s) per graph" if use_graph else "eager"),
                    "pipeline": ("index stage (FPS + ball query) of batch k+1 on a second stream "
                                 "beside the MLP fwd+bwd of batch k" if pipelined else "none"),
                    "global_batch": B_PER_GPU * world,

@@ -125,7 +125,9 @@ APN_API int apn_three_interpolate_grad(int b, int c, int n, int m, const float *
  * Everything below only enqueues kernels (graph-capturable).
  * ------------------------------------------------------------------------ */
 
-/* FPS that also writes new_xyz (B,M,3) = xyz[idx] (pointnext.py:146-147); n <= 16384. */
+/* FPS that also writes new_xyz (B,M,3) = xyz[idx] (pointnext.py:146-147); n <= 16384.
+ * temp == NULL: start from 1e10 everywhere (what callers fill temp with, subsample.py:94)
+ * and leave no min-distances behind. */
 APN_API int apn_furthest_point_sampling_xyz(int b, int n, int m, const float *xyz, float *temp,
                                             int *idxs, float *new_xyz, void *stream);
 
@@ -185,21 +187,25 @@ APN_API int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const float *
                            const float *bs, int relu, float *out, void *stream);
 
 /* Backward entry: g = g_out * [out > 0] (relu) ; goa (B,M,64) = g * scale2;
+ * g_out (B,64,M) is read with element strides (gs_b, gs_c, gs_m) -- a broadcast upstream
+ * gradient (stride 0, e.g. from loss = out.sum()) needs no materialised copy;
  * partS[rows][128] = {sum g, sum g*yhat_sel} per block of 64 queries
  * (rows = apn_sa_bwd_prep_rows(b, m)); with the skip branch partWs[rows][64*32] = dL/dWs
  * per block and gip (B,N,32) += Ws^T g at the sampled points (caller-zeroed). */
 APN_API int apn_sa_bwd_prep_rows(int b, int m);
-APN_API int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, const float *out, int relu,
+APN_API int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long long gs_b,
+                            long long gs_c, long long gs_m, const float *out, int relu,
                             const float *ysel, const float *pack2, const void *ft, int precision,
                             const int *fidx, const float *ws, float *goa, float *partS,
                             float *partWs, float *gip, void *stream);
 
 /* Constants of dL/dy2 = goa*[pos==ksel] + y2*D2 + E2: d2e2 [2][64], qm (32,32) =
- * W2^T diag(D2) W2, evec [32] = E2 W2; g_gamma2 = S2, g_beta2 = S1. */
+ * W2^T diag(D2) W2, evec [32] = E2 W2; g_gamma2 = S2, g_beta2 = S1.  Optional zero_w2
+ * [64*32] is cleared (the dL/dW2 accumulator of the pass-1 launch that follows). */
 APN_API int apn_sa_bwd_consts2(const float *partS, int rows, const double *S, const float *pack2,
                                const float *w2, double count, int training, float *d2e2,
                                float *qm, float *evec, float *g_gamma2, float *g_beta2,
-                               void *stream);
+                               float *zero_w2, void *stream);
 
 /* Backward pass 1 -> part[rows][64] = {sum g_u, sum g_u*yhat1}[32]; gw2_acc[64*32] += dL/dW2.
  *   bn1 = pack1 [4][32]. */
@@ -224,17 +230,16 @@ APN_API int apn_sa_bwd_pass2(int b, int n, int m, int c_in, int c_mid, int c_out
                              const void *ksel, const float *cabc, float *G, float *H,
                              void *stream);
 
-/* g_f (B,32,N) = G W1[:,3:] (+ gip); optional g_p (B,N,3) += G W1[:,:3]/r and
- * g_newp (B,M,3) = -H W1[:,:3]/r. */
-APN_API int apn_sa_bwd_input_grad(int b, int n, int m, const float *G, const float *H,
-                                  const float *w1, const float *gip, float radius, float *g_f,
-                                  float *g_p, float *g_newp, void *stream);
-
-/* partW[apn_sa_bwd_weight_rows(b, n)][32*38]: per-block products for dL/dW1 (sa_glue.hip). */
+/* Everything linear in G (B,N,32) and H (B,M,32), one workgroup per 64-point tile:
+ * g_f (B,32,N) = G W1[:,3:] (+ gip); optional g_p (B,N,3) += G W1[:,:3]/r and
+ * g_newp (B,M,3) = -H W1[:,:3]/r; partW[apn_sa_bwd_weight_rows(b, n)][32*38] = per-block
+ * products for dL/dW1 (sa_glue.hip). */
 APN_API int apn_sa_bwd_weight_rows(int b, int n);
-APN_API int apn_sa_bwd_weight_grad(int b, int n, int m, const float *G, const float *H,
+APN_API int apn_sa_bwd_point_grads(int b, int n, int m, const float *G, const float *H,
                                    const void *ft, int precision, const float *xyz,
-                                   const float *new_xyz, float *partW, void *stream);
+                                   const float *new_xyz, const float *w1, const float *gip,
+                                   float radius, float *partW, float *g_f, float *g_p,
+                                   float *g_newp, void *stream);
 
 /* Column sums in float64 -> g_w1 (32,35) from partW; optional g_ws (64,32) from partWs and
  * g_bs [64] from partS (rows_s rows each). */
@@ -264,12 +269,14 @@ APN_API int apn_sa_backward_seq(
     const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
-    const float *g_out, float *zero_base, size_t zero_bytes, float *g_w2, float *G, float *gip,
+    const float *g_out, long long gs_b, long long gs_c, long long gs_m,
+    float *zero_base, size_t zero_bytes, float *g_w2, float *G, float *gip,
     float *goa, float *partS, float *partWs, float *partT, float *partW, const double *sumsS,
     const double *sumsT, float *d2e2, float *qm, float *evec, float *cabc, float *H,
     float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_g1, float *g_b1, float *g_g2,
     float *g_b2, float *g_ws, float *g_bs, void *stream);
-/* Index stage: temp := 1e10, FPS (+ sampled coordinates), ball query (zero-filling). */
+/* Index stage: temp := 1e10, FPS (+ sampled coordinates), ball query (zero-filling).
+ * temp may be NULL (no min-distances kept). */
 APN_API int apn_sa_sample_seq(int b, int n, int m, float radius, int nsample, const float *xyz,
                               float *temp, int *fidx, float *new_xyz, int *idx, void *stream);
 

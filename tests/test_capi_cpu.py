@@ -56,6 +56,8 @@ def test_ctypes_signatures_match_header_arity():
                 assert at is ctypes.c_double, (name, decl)
             elif decl.startswith("size_t"):
                 assert at is ctypes.c_size_t, (name, decl)
+            elif decl.startswith("long long"):
+                assert at is ctypes.c_longlong, (name, decl)
             else:
                 assert at is ctypes.c_int, (name, decl)
 
