@@ -159,9 +159,11 @@ __device__ __forceinline__ void load_w1_frags(const float *__restrict__ w1, int 
 
 // Gather one tile: lane (pos, h) fetches 2 x 16 bytes of its neighbour's bf16 row (and of
 // the remainder row in split mode), and (h = 0) the normalised relative position.
+// Returns the neighbour index of `pos`; deff (optional) receives, in BOTH halves, the
+// relative position as the MFMA sees it (rounded to the operand precision).
 template <int NS>
-__device__ __forceinline__ void gather_tile(const SaArgs &a, int tile, int pos, int h,
-                                            Frag<NS> (&x)[3]) {
+__device__ __forceinline__ int gather_tile(const SaArgs &a, int tile, int pos, int h,
+                                           Frag<NS> (&x)[3], float *deff = nullptr) {
     const int cloud = tile / a.m;
     const int nb = a.idx[(size_t)tile * SA_K + pos];
     const size_t rowoff = ((size_t)cloud * a.n + nb) * SA_C;
@@ -176,13 +178,23 @@ __device__ __forceinline__ void gather_tile(const SaArgs &a, int tile, int pos, 
     const float *q = a.new_xyz + (size_t)tile * 3;           // wave-uniform
     const float *p = a.xyz + ((size_t)cloud * a.n + nb) * 3;
     float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (h == 0) {
+    if (h == 0 || deff) {
         // group.py:250-253: (grouped_xyz - query) then /= radius
         d[0] = (p[0] - q[0]) / a.radius;
         d[1] = (p[1] - q[1]) / a.radius;
         d[2] = (p[2] - q[2]) / a.radius;
     }
+    if (deff) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const __bf16 hi = (__bf16)d[j];
+            deff[j] = (float)hi;
+            if (NS == 2) deff[j] += (float)(__bf16)(d[j] - (float)hi);
+        }
+        if (h != 0) d[0] = d[1] = d[2] = 0.0f;
+    }
     x[2] = make_frag<NS>(d);
+    return nb;
 }
 
 // Workgroup-level fold of per-lane statistics into ONE partial row per workgroup:
@@ -307,21 +319,27 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
 // tensors only, BN2's two reduction terms S1 = sum g, S2 = sum g*yhat_sel and the
 // per-channel constants of
 //     dL/dy2 = goa[q,c] * [pos == ksel[q,c]]  +  y2 * D2[c] + E2[c]
-// (goa = g * gamma2*invstd2; the dense part is BN's mean/variance feedback).  Two
-// passes re-run the chain per tile:
-//   pass 1  -> dL/dW2 (64x32, an MFMA over positions), and BN1's reduction terms
-//              T1 = sum g_u, T2 = sum g_u * yhat1 with g_u = (dL/da1) * [a1 > 0]
-//   pass 2  -> dL/dy1 = g_u*ca + yhat1*cb + cc per position, summed per source point
-//              into G (B,N,32) (float atomics, de-duplicated) and per query into
-//              H (B,M,32).  Everything downstream of dL/dy1 is linear in it, so
-//              dL/df = G * W1f, dL/dW1f = G^T * f, and the relative-position
-//              columns follow from G, H and the coordinates (fused.py): three tiny
-//              GEMMs instead of a (B,35,M,K) gradient tensor.
+// (goa = g * gamma2*invstd2; the dense part is BN's mean/variance feedback).  ONE
+// pass re-runs the chain per tile and produces
+//   dL/dW2 (64x32, an MFMA over positions),
+//   BN1's reduction terms T1 = sum g_u, T2 = sum g_u * yhat1, g_u = (dL/da1) * [a1 > 0],
+//   A (B,N,32)  = g_u summed per SOURCE POINT (float atomics, de-duplicated),
+//   geo (B,N,4) = {count, sum of relative positions} of each source point's occurrences,
+//   HA, HB (B,M,32) = g_u and yhat1 summed per QUERY.
+// dL/dy1 = g_u*ca + yhat1*cb + cc needs T1, T2 of the WHOLE batch (ca, cb, cc), but only its
+// sums per point (G) and per query (H) are ever used -- everything downstream is linear in
+// it: dL/df = G W1f, dL/dW1f = G^T f, the coordinate columns from G, H and the
+// coordinates.  Those sums are linear in {g_u, yhat1, 1} too, and yhat1 is affine in the
+// tile's inputs, so
+//   G[n] = ca*A[n] + cb*inv1*(W1 [geo_xyz[n]; count[n] f_n] - count[n] mean1) + cc*count[n]
+//   H[q] = ca*HA[q] + cb*HB[q] + cc*K
+// are formed per point / per query by the consumer (sa_glue.hip: bwd_point_grads) once the
+// batch constants exist: no second pass over the positions.
 // dL/da1 = dL/dy2 * W2 never needs y2 transposed: the dense part folds to
 // a1 * (W2^T diag(D2) W2) + E2*W2 (a 32x32 matrix Qm and a vector, built by the
 // caller), and the sparse part is a one-hot-weighted (pos x channel) operand built
-// from ksel/goa by compares -- both land as MFMAs in the [lane = mid channel,
-// register = position] layout that the ReLU mask and BN1 terms already use.
+// from ksel/goa -- both land as MFMAs in the [lane = mid channel, register = position]
+// layout that the ReLU mask and BN1 terms already use.
 struct SaBwdArgs {
     const float *w2;        // (64,32)
     const float *scale1, *shift1, *mean1, *inv1;   // BN1 fold and statistics [32]
@@ -330,17 +348,18 @@ struct SaBwdArgs {
     const float *d2, *e2;   // [64]
     const float *goa;       // (B,M,64)
     const unsigned char *ksel;  // (B,M,64)
-    const float *ca, *cb, *cc;  // [32] pass 2: dL/dy1 = g_u*ca + yhat1*cb + cc
 };
 
-// Pass 2 is asked to fit two waves per SIMD (<= 256 registers incl. accumulators): it is
-// VALU/latency bound, and a lone wave issues a vector instruction only every 4+ cycles.
-template <int PASS, int NS>
-__global__ __launch_bounds__(SA_WAVES * 64, PASS == 2 ? 2 : 1) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
+// One wave per SIMD (the register file holds the chain's constants, two MFMA accumulators
+// of dL/dW2 and the tile): one workgroup per CU.
+template <int NS>
+__global__ __launch_bounds__(SA_WAVES * 64, 1) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
                                                                float *__restrict__ part,
                                                                float *__restrict__ gw2_acc,
-                                                               float *__restrict__ G,
-                                                               float *__restrict__ H) {
+                                                               float *__restrict__ A,
+                                                               float *__restrict__ geo,
+                                                               float *__restrict__ HA,
+                                                               float *__restrict__ HB) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     Frag<NS> w1f[3];
@@ -375,24 +394,20 @@ __global__ __launch_bounds__(SA_WAVES * 64, PASS == 2 ? 2 : 1) void sa_bwd_kerne
     Frag<NS> w2f[2][2];
     float d2v[2], e2v[2];
     f32x16 gw2[2];
-    if (PASS == 1) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float tmp[8];
+        for (int s = 0; s < 2; ++s) {
+            float tmp[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tmp[j] = g.w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
-                w2f[t][s] = make_frag<NS>(tmp);
-            }
-            d2v[t] = g.d2[32 * t + r];
-            e2v[t] = g.e2[32 * t + r];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) gw2[t][i] = 0.0f;
+            for (int j = 0; j < 8; ++j) tmp[j] = g.w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
+            w2f[t][s] = make_frag<NS>(tmp);
         }
+        d2v[t] = g.d2[32 * t + r];
+        e2v[t] = g.e2[32 * t + r];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gw2[t][i] = 0.0f;
     }
-    float ca = 0.f, cb = 0.f, cc = 0.f;
-    if (PASS == 2) { ca = g.ca[r]; cb = g.cb[r]; cc = g.cc[r]; }
     float st[2] = {0.0f, 0.0f};
 
     // wave-private LDS image of the sparse operand: [hi | lo] tiles of 32 rows x 72 bf16
@@ -405,7 +420,8 @@ __global__ __launch_bounds__(SA_WAVES * 64, PASS == 2 ? 2 : 1) void sa_bwd_kerne
     const int tiles = a.b * a.m;
     for (int tile = blockIdx.x * SA_WAVES + wave; tile < tiles; tile += gridDim.x * SA_WAVES) {
         Frag<NS> x[3];
-        gather_tile<NS>(a, tile, r, h, x);
+        float deff[3];
+        const int nb = gather_tile<NS>(a, tile, r, h, x, deff);
         // conv1 in both layouts (3 + 3 k-steps on the same fragments)
         f32x16 yT = {0}, y1 = {0};
 #pragma unroll
@@ -451,92 +467,92 @@ __global__ __launch_bounds__(SA_WAVES * 64, PASS == 2 ? 2 : 1) void sa_bwd_kerne
 #pragma unroll
         for (int s = 0; s < 4; ++s) ga = mfma<NS>(sp[s], w2tf[s], ga);
 
-        float yhat[16];
-        f32x16 an;   // a1 in the [lane = mid] layout (pass 1: B operand of dL/dW2)
-        float s1 = 0.0f, s2 = 0.0f;
+        f32x16 an;   // a1 in the [lane = mid] layout: B operand of dL/dW2
+        float s1 = 0.0f, s2 = 0.0f, hb = 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float u = __builtin_fmaf(y1[i], sc1, sh1);
-            yhat[i] = (y1[i] - mu1) * iv1;
+            const float yhat = (y1[i] - mu1) * iv1;
             an[i] = __builtin_fmaxf(u, 0.0f);
             ga[i] = u > 0.0f ? ga[i] : 0.0f;   // g_u
             s1 += ga[i];
-            s2 += ga[i] * yhat[i];
+            s2 += ga[i] * yhat;
+            hb += yhat;
         }
+        st[0] += s1;
+        st[1] += s2;
 
-        if (PASS == 1) {
-            st[0] += s1;
-            st[1] += s2;
-            const Frag<NS> b0 = pack8<NS>(an, 0), b1 = pack8<NS>(an, 8);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x16 y2 = {0};
-                y2 = mfma<NS>(a0, w2f[t][0], y2);
-                y2 = mfma<NS>(a1, w2f[t][1], y2);
-                const int c = 32 * t + r;
-                const float gsel = g.goa[(size_t)tile * SA_C2 + c];
-                const int ksl = g.ksel[(size_t)tile * SA_C2 + c];
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    y2[i] = __builtin_fmaf(y2[i], d2v[t], e2v[t]) + (acc_row(i, h) == ksl ? gsel : 0.0f);
-                // dL/dW2[out][mid] += sum_pos dL/dy2[pos][out] * a1[pos][mid]
-                gw2[t] = mfma<NS>(pack8<NS>(y2, 0), b0, gw2[t]);
-                gw2[t] = mfma<NS>(pack8<NS>(y2, 8), b1, gw2[t]);
+        {   // sums per query and per source point
+            const float ha = s1 + __shfl_xor(s1, 32);
+            hb += __shfl_xor(hb, 32);
+            if (h == 0) {
+                HA[(size_t)tile * SA_C1 + r] = ha;
+                HB[(size_t)tile * SA_C1 + r] = hb;
             }
-        } else {
-            // dL/dy1 and its two scatters
-            float gy[16];
-            float hs = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                gy[i] = __builtin_fmaf(ga[i], ca, __builtin_fmaf(yhat[i], cb, cc));
-                hs += gy[i];
-            }
-            hs += __shfl_xor(hs, 32);
-            if (h == 0) H[(size_t)tile * SA_C1 + r] = hs;
             // Rows produced by ball query end in a run of slots that repeat slot 0
             // (ball_query_gpu.cu:41-45): fold that run into slot 0 before the atomics.
-            const int nb = a.idx[(size_t)tile * SA_K + r];
             const int nb0 = __builtin_amdgcn_readfirstlane(nb);
             const unsigned eq = (unsigned)__ballot(nb == nb0);          // lanes 0..31 = positions
             const int tail = (~eq == 0u) ? 32 : __builtin_clz(~eq);      // leading ones of eq
-            int cnt = SA_K - tail;
-            if (cnt < 1) cnt = 1;
+            int live = SA_K - tail;
+            if (live < 1) live = 1;
             float extra = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) extra += acc_row(i, h) >= cnt ? gy[i] : 0.0f;
+            for (int i = 0; i < 16; ++i) extra += acc_row(i, h) >= live ? ga[i] : 0.0f;
             extra += __shfl_xor(extra, 32);
-            if (h == 0) gy[0] += extra;
             const int cloud = tile / a.m;
-            float *Gc = G + (size_t)cloud * a.n * SA_C1 + r;
+            float *Ac = A + (size_t)cloud * a.n * SA_C1 + r;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                if (acc_row(i, 0) < cnt) {   // wave-uniform: is any lane's position live?
+                if (acc_row(i, 0) < live) {   // wave-uniform: is any lane's position live?
                     const int n0 = __builtin_amdgcn_readlane(nb, acc_row(i, 0));
                     const int n1 = __builtin_amdgcn_readlane(nb, acc_row(i, 1));
                     const int nn = h ? n1 : n0;
-                    if (acc_row(i, h) < cnt) atomicAdd(Gc + (size_t)nn * SA_C1, gy[i]);
+                    const float v = (i == 0 && h == 0) ? ga[0] + extra : ga[i];
+                    if (acc_row(i, h) < live) atomicAdd(Ac + (size_t)nn * SA_C1, v);
                 }
             }
+            // occurrences and relative positions: lane (pos = r, h) adds {count, dx} or {dy, dz}
+            if (r < live) {
+                const float mult = r == 0 ? (float)(SA_K - live + 1) : 1.0f;
+                float *gp = geo + ((size_t)cloud * a.n + nb) * 4 + 2 * h;
+                atomicAdd(gp, (h ? deff[1] : 1.0f) * mult);
+                atomicAdd(gp + 1, (h ? deff[2] : deff[0]) * mult);
+            }
         }
-    }
-    if (PASS == 1) {
-        write_partials<2>(st, part, lane, wave);
-        // dL/dW2 of this workgroup, D[row = out row(i,h) + 32 t][col = mid r]: fold the four
-        // waves in LDS, then one float atomic per element into the zeroed (64,32) gradient.
-        __shared__ float wred[SA_WAVES][SA_C2 * SA_C1];
+
+        const Frag<NS> b0 = pack8<NS>(an, 0), b1 = pack8<NS>(an, 8);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            f32x16 y2 = {0};
+            y2 = mfma<NS>(a0, w2f[t][0], y2);
+            y2 = mfma<NS>(a1, w2f[t][1], y2);
+            const int c = 32 * t + r;
+            const float gsel = g.goa[(size_t)tile * SA_C2 + c];
+            const int ksl = g.ksel[(size_t)tile * SA_C2 + c];
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                wred[wave][(32 * t + acc_row(i, h)) * SA_C1 + r] = gw2[t][i];
-        __syncthreads();
-        for (int e = threadIdx.x; e < SA_C2 * SA_C1; e += SA_WAVES * 64) {
-            float sum = 0.0f;
-#pragma unroll
-            for (int w = 0; w < SA_WAVES; ++w) sum += wred[w][e];
-            atomicAdd(gw2_acc + e, sum);
+                y2[i] = __builtin_fmaf(y2[i], d2v[t], e2v[t]) + (acc_row(i, h) == ksl ? gsel : 0.0f);
+            // dL/dW2[out][mid] += sum_pos dL/dy2[pos][out] * a1[pos][mid]
+            gw2[t] = mfma<NS>(pack8<NS>(y2, 0), b0, gw2[t]);
+            gw2[t] = mfma<NS>(pack8<NS>(y2, 8), b1, gw2[t]);
         }
+    }
+    write_partials<2>(st, part, lane, wave);
+    // dL/dW2 of this workgroup, D[row = out row(i,h) + 32 t][col = mid r]: fold the four
+    // waves in LDS, then one float atomic per element into the zeroed (64,32) gradient.
+    __shared__ float wred[SA_WAVES][SA_C2 * SA_C1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            wred[wave][(32 * t + acc_row(i, h)) * SA_C1 + r] = gw2[t][i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < SA_C2 * SA_C1; e += SA_WAVES * 64) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < SA_WAVES; ++w) sum += wred[w][e];
+        atomicAdd(gw2_acc + e, sum);
     }
 }
 
@@ -546,10 +562,10 @@ static int sa_grid(int tiles) {
     return g < 512 ? (g < 1 ? 1 : g) : 512;
 }
 
-// Backward pass 1 holds one wave per SIMD (register file): one workgroup per CU in a single
+// The backward pass holds one wave per SIMD (register file): one workgroup per CU in a single
 // round beats two rounds of half the length (57 vs 64 us at B*M = 16384), the per-wave
 // constant setup being paid once.
-static int sa_grid_pass1(int tiles) {
+static int sa_grid_bwd(int tiles) {
     int g = sa_grid(tiles);
     return g < 256 ? g : 256;
 }
@@ -557,7 +573,7 @@ static int sa_grid_pass1(int tiles) {
 }  // namespace apn
 
 extern "C" int apn_sa_grid_blocks(int b, int m) { return apn::sa_grid(b * m); }
-extern "C" int apn_sa_bwd_pass1_rows(int b, int m) { return apn::sa_grid_pass1(b * m); }
+extern "C" int apn_sa_bwd_main_rows(int b, int m) { return apn::sa_grid_bwd(b * m); }
 
 // ft holds `precision` tables of (B,N,32) bf16 back to back: [hi] or [hi][lo].
 extern "C" int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, int precision,
@@ -629,55 +645,36 @@ extern "C" int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_o
 
 static apn::SaBwdArgs sa_bwd_args(const float *w2, const float *bn1 /* [4][32]: scale, shift, mean, inv */,
                                   const float *qm, const float *evec, const float *d2e2 /* [2][64] */,
-                                  const float *goa, const void *ksel, const float *cabc /* [3][32] or null */) {
+                                  const float *goa, const void *ksel) {
     apn::SaBwdArgs g;
     g.w2 = w2;
     g.scale1 = bn1; g.shift1 = bn1 + 32; g.mean1 = bn1 + 64; g.inv1 = bn1 + 96;
     g.qm = qm; g.evec = evec;
-    g.d2 = d2e2; g.e2 = d2e2 ? d2e2 + 64 : nullptr;
+    g.d2 = d2e2; g.e2 = d2e2 + 64;
     g.goa = goa; g.ksel = (const unsigned char *)ksel;
-    g.ca = cabc; g.cb = cabc ? cabc + 32 : nullptr; g.cc = cabc ? cabc + 64 : nullptr;
     return g;
 }
 
-extern "C" int apn_sa_bwd_pass1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                                int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                                const int *idx, const float *w1, const float *w2, const float *bn1,
-                                const float *qm, const float *evec, const float *d2e2,
-                                const float *goa, const void *ksel, float *part,
-                                float *gw2_acc, void *stream) {
+extern "C" int apn_sa_bwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
+                               int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
+                               const int *idx, const float *w1, const float *w2, const float *bn1,
+                               const float *qm, const float *evec, const float *d2e2,
+                               const float *goa, const void *ksel, float *part,
+                               float *gw2_acc, float *A, float *geo, float *HA, float *HB,
+                               void *stream) {
     using namespace apn;
     if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
+    if (!w2 || !bn1 || !qm || !evec || !d2e2 || !goa || !ksel || !part || !gw2_acc || !A || !geo ||
+        !HA || !HB)
+        return APN_EINVAL;
     SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius);
-    SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, d2e2, goa, ksel, nullptr);
+    SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, d2e2, goa, ksel);
     if (precision == 2)
-        hipLaunchKernelGGL((sa_bwd_kernel<1, 2>), dim3(sa_grid_pass1(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, g, part, gw2_acc, (float *)nullptr,
-                           (float *)nullptr);
+        hipLaunchKernelGGL((sa_bwd_kernel<2>), dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0,
+                           (hipStream_t)stream, a, g, part, gw2_acc, A, geo, HA, HB);
     else
-        hipLaunchKernelGGL((sa_bwd_kernel<1, 1>), dim3(sa_grid_pass1(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, g, part, gw2_acc, (float *)nullptr,
-                           (float *)nullptr);
-    APN_LAUNCH_CHECK();
-    return APN_OK;
-}
-
-extern "C" int apn_sa_bwd_pass2(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                                int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                                const int *idx, const float *w1, const float *w2, const float *bn1,
-                                const float *qm, const float *evec, const float *goa,
-                                const void *ksel, const float *cabc, float *G, float *H,
-                                void *stream) {
-    using namespace apn;
-    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
-    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius);
-    SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, nullptr, goa, ksel, cabc);
-    if (precision == 2)
-        hipLaunchKernelGGL((sa_bwd_kernel<2, 2>), dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, g, (float *)nullptr, (float *)nullptr, G, H);
-    else
-        hipLaunchKernelGGL((sa_bwd_kernel<2, 1>), dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, g, (float *)nullptr, (float *)nullptr, G, H);
+        hipLaunchKernelGGL((sa_bwd_kernel<1>), dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0,
+                           (hipStream_t)stream, a, g, part, gw2_acc, A, geo, HA, HB);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

@@ -323,8 +323,15 @@ __global__ __launch_bounds__(1024) void bwd_consts1_kernel(
     if (g_beta1) g_beta1[i] = (float)T[i];
 }
 
-// Everything that is linear in G (dL/dy1 summed per source point) and H (per query), one
-// workgroup per tile of WG_PTS points of one cloud, the tiles staged in LDS once:
+// Everything downstream of dL/dy1 = g_u*ca + yhat1*cb + cc, which is only ever needed summed
+// per source point (G) and per query (H).  The backward pass (sa_fused.hip) left the sums of
+// g_u (A per point, HA per query), of yhat1 per query (HB) and the occurrence statistics of
+// every point (geo = {count, sum of relative positions}); with the batch constants ca, cb,
+// cc (cabc) now known,
+//   G[n][mid] = ca*A[n][mid] + cb*inv1*(W1[mid] . [geo_xyz[n]; count f_n] - count*mean1) + cc*count
+//   H[q][mid] = ca*HA[q][mid] + cb*HB[q][mid] + cc*K
+// (W1, f as the MFMA saw them: rounded to the operand precision).  One workgroup per tile of
+// WG_PTS points of one cloud forms them in LDS and emits
 //   partW[block][mid][38]  products over the tile for dL/dW1, columns
 //       0..2   sum_n G[n][mid] * xyz[n][d]
 //       3..5   sum_q H[q][mid] * new_xyz[q][d]     (query tile of the same flat index)
@@ -339,32 +346,55 @@ __global__ __launch_bounds__(1024) void bwd_consts1_kernel(
 constexpr int WG_PTS = 64;
 
 __global__ __launch_bounds__(256) void bwd_point_grads_kernel(
-    int n, int total_q, const float *__restrict__ G, const float *__restrict__ H,
-    const __bf16 *__restrict__ ft, const __bf16 *__restrict__ ft_lo, const float *__restrict__ xyz,
+    int n, int total_q, int split, const float *__restrict__ A, const float *__restrict__ geo,
+    const float *__restrict__ HA, const float *__restrict__ HB, const float *__restrict__ cabc,
+    const float *__restrict__ pack1, const __bf16 *__restrict__ ft,
+    const __bf16 *__restrict__ ft_lo, const float *__restrict__ xyz,
     const float *__restrict__ new_xyz, const float *__restrict__ w1, const float *__restrict__ gip,
     float inv_r, float *__restrict__ partW, float *__restrict__ g_f, float *__restrict__ g_p,
     float *__restrict__ g_q) {
     __shared__ float sw[32][36];        // W1[mid][35]
-    __shared__ float sG[WG_PTS][33];    // G [point][mid]
+    __shared__ float swr[32][36];       // W1 rounded to the operand precision
+    __shared__ float sG[WG_PTS][33];    // A, then G [point][mid]
     __shared__ float sH[WG_PTS][33];    // H [query][mid]
     __shared__ float sI[WG_PTS][33];    // gip [point][i]
     __shared__ float sB[WG_PTS][41];    // columns 0..2 xyz, 3..5 new_xyz (query rows), 6..37 ft
+    __shared__ float sGeo[WG_PTS][4];   // count, sum of relative positions
+    __shared__ float sc[5][32];         // ca, cb, cc, mean1, inv1
     const int tid = threadIdx.x;
     const int cloud = blockIdx.y, n0 = blockIdx.x * WG_PTS;
     const int block = cloud * gridDim.x + blockIdx.x;
     const size_t p0 = (size_t)cloud * n + n0;            // first point row of the tile
     const int q0 = block * WG_PTS;                       // first query row (flat)
     const int n_here = n - n0 < WG_PTS ? n - n0 : WG_PTS;
-    for (int e = tid; e < 32 * 35; e += 256) sw[e / 35][e % 35] = w1[e];
-    for (int e = tid; e < WG_PTS * 32; e += 256) {
-        const int pt = e >> 5, c = e & 31;
-        const bool ok = pt < n_here;
-        sG[pt][c] = ok ? G[(p0 + pt) * 32 + c] : 0.0f;
-        float fv = ok ? (float)ft[(p0 + pt) * 32 + c] : 0.0f;
-        if (ft_lo && ok) fv += (float)ft_lo[(p0 + pt) * 32 + c];     // split mode: hi + lo
-        sB[pt][6 + c] = fv;
-        sI[pt][c] = (gip && ok) ? gip[(p0 + pt) * 32 + c] : 0.0f;
-        sH[pt][c] = q0 + pt < total_q ? H[(size_t)(q0 + pt) * 32 + c] : 0.0f;
+    for (int e = tid; e < 32 * 35; e += 256) {
+        const float w = w1[e];
+        const __bf16 hi = (__bf16)w;
+        float wr = (float)hi;
+        if (split) wr += (float)(__bf16)(w - wr);
+        sw[e / 35][e % 35] = w;
+        swr[e / 35][e % 35] = wr;
+    }
+    if (tid < 96) sc[tid >> 5][tid & 31] = cabc[tid];
+    else if (tid < 160) sc[3 + ((tid - 96) >> 5)][tid & 31] = pack1[64 + tid - 96];   // mean1, inv1
+    {
+        const int c = tid & 31;                           // fixed per thread: e = tid + 256 k
+        const float ca = cabc[c], cb = cabc[32 + c], cc = cabc[64 + c];
+        for (int e = tid; e < WG_PTS * 32; e += 256) {
+            const int pt = e >> 5;
+            const bool ok = pt < n_here;
+            sG[pt][c] = ok ? A[(p0 + pt) * 32 + c] : 0.0f;
+            float fv = ok ? (float)ft[(p0 + pt) * 32 + c] : 0.0f;
+            if (ft_lo && ok) fv += (float)ft_lo[(p0 + pt) * 32 + c];     // split mode: hi + lo
+            sB[pt][6 + c] = fv;
+            sI[pt][c] = (gip && ok) ? gip[(p0 + pt) * 32 + c] : 0.0f;
+            float hv = 0.0f;
+            if (q0 + pt < total_q) {
+                const size_t o = (size_t)(q0 + pt) * 32 + c;
+                hv = __builtin_fmaf(ca, HA[o], __builtin_fmaf(cb, HB[o], cc * 32.0f));
+            }
+            sH[pt][c] = hv;
+        }
     }
     for (int e = tid; e < WG_PTS * 3; e += 256) {
         const int pt = e / 3, d = e % 3;
@@ -372,6 +402,29 @@ __global__ __launch_bounds__(256) void bwd_point_grads_kernel(
         sB[pt][3 + d] = q0 + pt < total_q ? new_xyz[(size_t)(q0 + pt) * 3 + d] : 0.0f;
     }
     for (int e = tid; e < WG_PTS * 2; e += 256) sB[e >> 1][38 + (e & 1)] = 0.0f;   // pad columns
+    {
+        const int pt = tid >> 2, j = tid & 3;
+        sGeo[pt][j] = pt < n_here ? geo[(p0 + pt) * 4 + j] : 0.0f;
+    }
+    __syncthreads();
+
+    {   // G in place of A: thread (point tx, 8 mid channels of wave ty)
+        const int tx = tid & 63, ty = tid >> 6;
+        const float cnt = sGeo[tx][0], gx = sGeo[tx][1], gy = sGeo[tx][2], gz = sGeo[tx][3];
+        float fx[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) fx[i] = sB[tx][6 + i];
+#pragma unroll 2
+        for (int mm = 0; mm < 8; ++mm) {
+            const int mid = ty * 8 + mm;
+            float accf = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) accf = __builtin_fmaf(swr[mid][3 + i], fx[i], accf);
+            const float ys = swr[mid][0] * gx + swr[mid][1] * gy + swr[mid][2] * gz + cnt * accf;
+            const float yhs = sc[4][mid] * (ys - cnt * sc[3][mid]);
+            sG[tx][mid] = sc[0][mid] * sG[tx][mid] + sc[1][mid] * yhs + sc[2][mid] * cnt;
+        }
+    }
     __syncthreads();
 
     {   // products for dL/dW1
@@ -555,20 +608,22 @@ extern "C" int apn_sa_bwd_consts1(const float *partT, int rows, const double *T,
 
 extern "C" int apn_sa_bwd_weight_rows(int b, int n) { return b * ((n + apn::WG_PTS - 1) / apn::WG_PTS); }
 
-extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const float *G, const float *H,
-                                      const void *ft, int precision, const float *xyz,
-                                      const float *new_xyz, const float *w1, const float *gip,
-                                      float radius, float *partW, float *g_f, float *g_p,
-                                      float *g_newp, void *stream) {
+extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const float *A, const float *geo,
+                                      const float *HA, const float *HB, const float *cabc,
+                                      const float *pack1, const void *ft, int precision,
+                                      const float *xyz, const float *new_xyz, const float *w1,
+                                      const float *gip, float radius, float *partW, float *g_f,
+                                      float *g_p, float *g_newp, void *stream) {
     if (b <= 0 || n <= 0 || m <= 0 || b > 65535) return APN_EINVAL;
-    if (!G || !H || !ft || !xyz || !new_xyz || !w1 || !partW || !g_f) return APN_EINVAL;
+    if (!A || !geo || !HA || !HB || !cabc || !pack1 || !ft || !xyz || !new_xyz || !w1 || !partW || !g_f)
+        return APN_EINVAL;
     if (precision != 1 && precision != 2) return APN_EINVAL;
     if (m > n) return APN_EINVAL;                    // query tiles are walked with the point tiles
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = precision == 2 ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::bwd_point_grads_kernel, dim3((n + apn::WG_PTS - 1) / apn::WG_PTS, b),
-                       dim3(256), 0, APN_ST, n, b * m, G, H, hi, lo, xyz, new_xyz, w1, gip,
-                       1.0f / radius, partW, g_f, g_p, g_newp);
+                       dim3(256), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, A, geo, HA, HB, cabc,
+                       pack1, hi, lo, xyz, new_xyz, w1, gip, 1.0f / radius, partW, g_f, g_p, g_newp);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

@@ -9,7 +9,7 @@
 // `phases` selects which part of the direction to enqueue, so that the caller can place
 // an all-reduce of the BatchNorm sums between them (SyncBatchNorm):
 //   forward : 1 = prep + stats1          | 2 = fold1 + main     | 4 = fold2 + out
-//   backward: 1 = zero + prep            | 2 = consts2 + pass1  | 4 = consts1 + pass2 + tail
+//   backward: 1 = zero + prep            | 2 = consts2 + main   | 4 = consts1 + point grads + finalize
 // With part pointers the consumer kernels sum the partial rows themselves (single rank:
 // phases = 7, one call); with `sums*` pointers (float64, already reduced over ranks) they
 // use those instead.
@@ -60,16 +60,16 @@ extern "C" int apn_sa_backward_seq(
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
-    // zero-filled here: G (B*N*32) | gip (B*N*32, only with ws) by one memset (phase 1);
-    // g_w2 (64*32) by the consts2 launch (phase 2)
-    float *zero_base, size_t zero_bytes, float *g_w2, float *G, float *gip,
+    // zero-filled here: A (B*N*32) | geo (B*N*4) | gip (B*N*32, only with ws) by one memset
+    // (phase 1); g_w2 (64*32) by the consts2 launch (phase 2)
+    float *zero_base, size_t zero_bytes, float *g_w2, float *A, float *geo, float *gip,
     // scratch
     float *goa, float *partS, float *partWs, float *partT, float *partW, const double *sumsS,
-    const double *sumsT, float *d2e2, float *qm, float *evec, float *cabc, float *H,
+    const double *sumsT, float *d2e2, float *qm, float *evec, float *cabc, float *HA, float *HB,
     // gradients out
     float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_g1, float *g_b1, float *g_g2,
     float *g_b2, float *g_ws, float *g_bs, void *stream) {
-    const int rows_t = apn_sa_bwd_pass1_rows(b, m);
+    const int rows_t = apn_sa_bwd_main_rows(b, m);
     const int prow = apn_sa_bwd_prep_rows(b, m);
     if (phases & 1) {
         hipError_t me = hipMemsetAsync(zero_base, 0, zero_bytes, (hipStream_t)stream);
@@ -80,16 +80,15 @@ extern "C" int apn_sa_backward_seq(
     if (phases & 2) {
         APN_TRY(apn_sa_bwd_consts2(sumsS ? nullptr : partS, prow, sumsS, pack2, w2, count, train2,
                                    d2e2, qm, evec, g_g2, g_b2, g_w2, stream));
-        APN_TRY(apn_sa_bwd_pass1(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, w1,
-                                 w2, pack1, qm, evec, d2e2, goa, ksel, partT, g_w2, stream));
+        APN_TRY(apn_sa_bwd_main(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, w1,
+                                w2, pack1, qm, evec, d2e2, goa, ksel, partT, g_w2, A, geo, HA, HB,
+                                stream));
     }
     if (phases & 4) {
         APN_TRY(apn_sa_bwd_consts1(sumsT ? nullptr : partT, rows_t, sumsT, pack1, count, train1, cabc,
                                    g_g1, g_b1, stream));
-        APN_TRY(apn_sa_bwd_pass2(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, w1,
-                                 w2, pack1, qm, evec, goa, ksel, cabc, G, H, stream));
-        APN_TRY(apn_sa_bwd_point_grads(b, n, m, G, H, ft, precision, xyz, new_xyz, w1, gip, radius,
-                                       partW, g_f, g_p, g_newp, stream));
+        APN_TRY(apn_sa_bwd_point_grads(b, n, m, A, geo, HA, HB, cabc, pack1, ft, precision, xyz,
+                                       new_xyz, w1, gip, radius, partW, g_f, g_p, g_newp, stream));
         APN_TRY(apn_sa_bwd_finalize(partW, apn_sa_bwd_weight_rows(b, n), radius, g_w1, partWs, prow,
                                     g_ws, partS, g_bs, stream));
     }

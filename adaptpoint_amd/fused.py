@@ -221,16 +221,17 @@ def _backward(fw, g_out, need_p, need_newp):
     has_skip = ws is not None
     lib = _lib.load()
     call = _Launcher(dev)
-    rows = lib.apn_sa_bwd_pass1_rows(B, M)
+    rows = lib.apn_sa_bwd_main_rows(B, M)
     prow = lib.apn_sa_bwd_prep_rows(B, M)
     wrows = lib.apn_sa_bwd_weight_rows(B, N)
 
     # scratch: the zero-filled (atomically accumulated) region first, contiguous
-    zsizes = [("G", B * N * C_MID)] + ([("gip", B * N * C_MID)] if has_skip else [])
+    zsizes = [("A", B * N * C_MID), ("geo", B * N * 4)] + ([("gip", B * N * C_MID)] if has_skip else [])
     sizes = zsizes + [("goa", B * M * C_OUT), ("partS", prow * 128),
                       ("partWs", prow * C_OUT * C_IN if has_skip else 0), ("partT", rows * 64),
                       ("partW", wrows * 32 * 38), ("d2e2", 2 * C_OUT), ("qm", C_MID * C_MID),
-                      ("evec", C_MID), ("cabc", 3 * C_MID), ("H", B * M * C_MID)]
+                      ("evec", C_MID), ("cabc", 3 * C_MID), ("HA", B * M * C_MID),
+                      ("HB", B * M * C_MID)]
     v, buf = _carve(dev, sizes)
     zero_floats = sum((nfl + 63) // 64 * 64 for _, nfl in zsizes)
     # small gradients in one buffer (kept alive by the parameters' .grad), g_w2 zero-filled
@@ -253,11 +254,13 @@ def _backward(fw, g_out, need_p, need_newp):
              fw.out.data_ptr(), fw.relu, 1 if fw.train1 else 0, 1 if fw.train2 else 0, float(P),
              g_out.data_ptr(), gs[0], gs[1], gs[2], buf.data_ptr(), zero_floats * 4,
              g["w2"].data_ptr(),
-             v["G"].data_ptr(), v["gip"].data_ptr() if has_skip else None, v["goa"].data_ptr(),
+             v["A"].data_ptr(), v["geo"].data_ptr(), v["gip"].data_ptr() if has_skip else None,
+             v["goa"].data_ptr(),
              v["partS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None,
              v["partT"].data_ptr(), v["partW"].data_ptr(), _ptr(sumsS), _ptr(sumsT),
              v["d2e2"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr(), v["cabc"].data_ptr(),
-             v["H"].data_ptr(), g_f.data_ptr(), _ptr(g_p), _ptr(g_newp), g["w1"].data_ptr(),
+             v["HA"].data_ptr(), v["HB"].data_ptr(), g_f.data_ptr(), _ptr(g_p), _ptr(g_newp),
+             g["w1"].data_ptr(),
              g["g1"].data_ptr(), g["b1"].data_ptr(), g["g2"].data_ptr(), g["b2"].data_ptr(),
              g["ws"].data_ptr() if has_skip else None,
              g["bs"].data_ptr() if (has_skip and sv["has_bs"]) else None)
@@ -322,15 +325,15 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
              _ptr(sumsS), sv["pack2"].data_ptr(), w2.data_ptr(), P, 1 if fw.train2 else 0,
              v["d2e2"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr(), g["g2"].data_ptr(),
              g["b2"].data_ptr(), g["w2"].data_ptr())
-        call("apn_sa_bwd_pass1", *hdr, v["d2e2"].data_ptr(), v["goa"].data_ptr(),
-             sv["ksel"].data_ptr(), v["partT"].data_ptr(), g["w2"].data_ptr())
+        call("apn_sa_bwd_main", *hdr, v["d2e2"].data_ptr(), v["goa"].data_ptr(),
+             sv["ksel"].data_ptr(), v["partT"].data_ptr(), g["w2"].data_ptr(), v["A"].data_ptr(),
+             v["geo"].data_ptr(), v["HA"].data_ptr(), v["HB"].data_ptr())
     if phases & 4:
         call("apn_sa_bwd_consts1", None if sumsT is not None else v["partT"].data_ptr(), rows,
              _ptr(sumsT), sv["pack1"].data_ptr(), P, 1 if fw.train1 else 0, v["cabc"].data_ptr(),
              g["g1"].data_ptr(), g["b1"].data_ptr())
-        call("apn_sa_bwd_pass2", *hdr, v["goa"].data_ptr(), sv["ksel"].data_ptr(),
-             v["cabc"].data_ptr(), v["G"].data_ptr(), v["H"].data_ptr())
-        call("apn_sa_bwd_point_grads", B, N, M, v["G"].data_ptr(), v["H"].data_ptr(),
+        call("apn_sa_bwd_point_grads", B, N, M, v["A"].data_ptr(), v["geo"].data_ptr(),
+             v["HA"].data_ptr(), v["HB"].data_ptr(), v["cabc"].data_ptr(), sv["pack1"].data_ptr(),
              sv["ft"].data_ptr(), fw.prec, sv["p"].data_ptr(), sv["new_p"].data_ptr(), w1.data_ptr(),
              gip, fw.radius, v["partW"].data_ptr(), g_f.data_ptr(), _ptr(g_p), _ptr(g_newp))
         call("apn_sa_bwd_finalize", v["partW"].data_ptr(), wrows, fw.radius, g["w1"].data_ptr(),

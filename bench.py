@@ -69,9 +69,9 @@ def algorithmic_bytes(batch):
         # fused passes: xyz + queries + idx + bf16 feature table in; pooled outputs / G, H out
         "sa_fwd_stats1": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64),
         "sa_fwd_main": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64 + NPOINT * 64 * 5),
-        "sa_bwd_pass1": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64 + NPOINT * 64 * 5),
-        "sa_bwd_pass2": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64 + NPOINT * 64 * 5
-                                 + N_PTS * 128 + NPOINT * 128),
+        # + goa, ksel in; per-point sums A (128 B) + geo (16 B), per-query sums HA, HB out
+        "sa_bwd_main": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64 + NPOINT * 64 * 5
+                                + N_PTS * 144 + NPOINT * 256),
     }
 
 

@@ -137,8 +137,8 @@ APN_API int apn_ball_query_zero(int b, int n, int m, float radius, int nsample,
 
 /* Workgroups (= partial rows) the fused passes launch for B clouds x M queries. */
 APN_API int apn_sa_grid_blocks(int b, int m);
-/* rows of backward pass 1's partial sums (partT) */
-APN_API int apn_sa_bwd_pass1_rows(int b, int m);
+/* rows of the backward pass's partial sums (partT) */
+APN_API int apn_sa_bwd_main_rows(int b, int m);
 
 /* `precision` (every function that takes ft): 1 = operands rounded to bf16; 2 = operands split
  * into hi + lo bf16 parts, each product three MFMAs (hi*hi + hi*lo + lo*hi, "bf16x3"): fp32-grade
@@ -207,39 +207,35 @@ APN_API int apn_sa_bwd_consts2(const float *partS, int rows, const double *S, co
                                float *qm, float *evec, float *g_gamma2, float *g_beta2,
                                float *zero_w2, void *stream);
 
-/* Backward pass 1 -> part[rows][64] = {sum g_u, sum g_u*yhat1}[32]; gw2_acc[64*32] += dL/dW2.
- *   bn1 = pack1 [4][32]. */
-APN_API int apn_sa_bwd_pass1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                             int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                             const int *idx, const float *w1, const float *w2, const float *bn1,
-                             const float *qm, const float *evec, const float *d2e2,
-                             const float *goa, const void *ksel, float *part, float *gw2_acc,
-                             void *stream);
+/* The backward pass over the positions -> part[apn_sa_bwd_main_rows(b, m)][64] =
+ *   {sum g_u, sum g_u*yhat1}[32] (g_u = dL/da1 * [a1 > 0]); gw2_acc[64*32] += dL/dW2;
+ *   A (B,N,32) += g_u summed per source point, geo (B,N,4) += {count, sum of relative
+ *   positions} of each point's occurrences (both caller-zeroed, float atomics);
+ *   HA, HB (B,M,32) = g_u and yhat1 summed per query.  bn1 = pack1 [4][32]. */
+APN_API int apn_sa_bwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
+                            int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
+                            const int *idx, const float *w1, const float *w2, const float *bn1,
+                            const float *qm, const float *evec, const float *d2e2,
+                            const float *goa, const void *ksel, float *part, float *gw2_acc,
+                            float *A, float *geo, float *HA, float *HB, void *stream);
 
 /* cabc [3][32]: dL/dy1 = g_u*ca + yhat1*cb + cc ; g_gamma1 = T2, g_beta1 = T1. */
 APN_API int apn_sa_bwd_consts1(const float *partT, int rows, const double *T, const float *pack1,
                                double count, int training, float *cabc, float *g_gamma1,
                                float *g_beta1, void *stream);
 
-/* Backward pass 2 -> G (B,N,32) += per-source-point sums of dL/dy1 (caller-zeroed, float
- * atomics), H (B,M,32) = per-query sums of dL/dy1. */
-APN_API int apn_sa_bwd_pass2(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                             int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                             const int *idx, const float *w1, const float *w2, const float *bn1,
-                             const float *qm, const float *evec, const float *goa,
-                             const void *ksel, const float *cabc, float *G, float *H,
-                             void *stream);
-
-/* Everything linear in G (B,N,32) and H (B,M,32), one workgroup per 64-point tile:
- * g_f (B,32,N) = G W1[:,3:] (+ gip); optional g_p (B,N,3) += G W1[:,:3]/r and
+/* dL/dy1 = g_u*ca + yhat1*cb + cc summed per source point (G) and per query (H), formed from
+ * A, geo, HA, HB and the batch constants, and everything linear in them, one workgroup per
+ * 64-point tile: g_f (B,32,N) = G W1[:,3:] (+ gip); optional g_p (B,N,3) += G W1[:,:3]/r and
  * g_newp (B,M,3) = -H W1[:,:3]/r; partW[apn_sa_bwd_weight_rows(b, n)][32*38] = per-block
- * products for dL/dW1 (sa_glue.hip). */
+ * products for dL/dW1 (sa_glue.hip).  pack1 = BN1's {scale, shift, mean, invstd}[32]. */
 APN_API int apn_sa_bwd_weight_rows(int b, int n);
-APN_API int apn_sa_bwd_point_grads(int b, int n, int m, const float *G, const float *H,
-                                   const void *ft, int precision, const float *xyz,
-                                   const float *new_xyz, const float *w1, const float *gip,
-                                   float radius, float *partW, float *g_f, float *g_p,
-                                   float *g_newp, void *stream);
+APN_API int apn_sa_bwd_point_grads(int b, int n, int m, const float *A, const float *geo,
+                                   const float *HA, const float *HB, const float *cabc,
+                                   const float *pack1, const void *ft, int precision,
+                                   const float *xyz, const float *new_xyz, const float *w1,
+                                   const float *gip, float radius, float *partW, float *g_f,
+                                   float *g_p, float *g_newp, void *stream);
 
 /* Column sums in float64 -> g_w1 (32,35) from partW; optional g_ws (64,32) from partWs and
  * g_bs [64] from partS (rows_s rows each). */
@@ -270,9 +266,9 @@ APN_API int apn_sa_backward_seq(
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
-    float *zero_base, size_t zero_bytes, float *g_w2, float *G, float *gip,
+    float *zero_base, size_t zero_bytes, float *g_w2, float *A, float *geo, float *gip,
     float *goa, float *partS, float *partWs, float *partT, float *partW, const double *sumsS,
-    const double *sumsT, float *d2e2, float *qm, float *evec, float *cabc, float *H,
+    const double *sumsT, float *d2e2, float *qm, float *evec, float *cabc, float *HA, float *HB,
     float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_g1, float *g_b1, float *g_g2,
     float *g_b2, float *g_ws, float *g_bs, void *stream);
 /* Index stage: temp := 1e10, FPS (+ sampled coordinates), ball query (zero-filling).
