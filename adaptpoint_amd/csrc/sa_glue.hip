@@ -108,26 +108,29 @@ __global__ __launch_bounds__(1024) void bn_fold_kernel(
     pack[3 * c + i] = (float)inv;
 }
 
-// Stage the skip branch's operands of one 64-query tile: sws = Ws (64x32) and
-// sfi[q][i] = f[b][i][fidx[b][m0+q]] read from the point-major table(s).  Loads are issued in
-// three independent batches (indices, then rows) so that the dependent index -> row chain is
-// paid once, not once per loop iteration.  Optionally records the source point of each query.
+// Stage the skip branch's operands of one 64-query tile with NT threads: sws = Ws (64x32,
+// row stride WST) and sfi[q][i] = f[b][i][fidx[b][m0+q]] read from the point-major table(s).
+// Loads are issued in independent batches (indices, then rows) so that the dependent
+// index -> row chain is paid once, not once per loop iteration.  Optionally records the source
+// point of each query.
+template <int NT, int WST>
 __device__ __forceinline__ void stage_skip_operands(int cloud, int n, int m, int m0,
                                                     const __bf16 *__restrict__ ft,
                                                     const __bf16 *__restrict__ ft_lo,
                                                     const int *__restrict__ fidx,
                                                     const float *__restrict__ ws,
-                                                    float (*sws)[33], float (*sfi)[33], int *ssrc) {
-    const int tid = threadIdx.x, i = tid & 31, q0 = tid >> 5;     // 8 queries per thread: q0 + 8 t
-    int src[8];
+                                                    float (*sws)[WST], float (*sfi)[33], int *ssrc) {
+    constexpr int G = NT / 32, QPT = 64 / G;        // row groups, queries per thread
+    const int tid = threadIdx.x, i = tid & 31, q0 = tid >> 5;     // queries q0 + G t
+    int src[QPT];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int q = m0 + q0 + 8 * t;
+    for (int t = 0; t < QPT; ++t) {
+        const int q = m0 + q0 + G * t;
         src[t] = q < m ? fidx[(size_t)cloud * m + q] : -1;
     }
-    float v[8];
+    float v[QPT];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < QPT; ++t) {
         v[t] = 0.0f;
         if (src[t] >= 0) {
             const size_t o = ((size_t)cloud * n + src[t]) * 32 + i;
@@ -136,10 +139,10 @@ __device__ __forceinline__ void stage_skip_operands(int cloud, int n, int m, int
         }
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        sfi[q0 + 8 * t][i] = v[t];
-        if (ssrc && i == 0) ssrc[q0 + 8 * t] = src[t] < 0 ? 0 : src[t];
-        sws[q0 + 8 * t][i] = ws[(q0 + 8 * t) * 32 + i];
+    for (int t = 0; t < QPT; ++t) {
+        sfi[q0 + G * t][i] = v[t];
+        if (ssrc && i == 0) ssrc[q0 + G * t] = src[t] < 0 ? 0 : src[t];
+        sws[q0 + G * t][i] = ws[(q0 + G * t) * 32 + i];
     }
 }
 
@@ -148,31 +151,53 @@ __device__ __forceinline__ void stage_skip_operands(int cloud, int n, int m, int
 // pointnext.py:157-161) when ws != null; act = ReLU when relu != 0 (pointnext.py:167-168).
 // The sampled points' features come from the point-major bf16 table(s) of the block
 // (hi [+ lo]): one contiguous 64-byte row per query instead of 32 strided 4-byte loads.
-__global__ __launch_bounds__(256) void fwd_out_kernel(int n, int m, const float *__restrict__ ysel,
-                                                      const float *__restrict__ pack2,
-                                                      const __bf16 *__restrict__ ft,
-                                                      const __bf16 *__restrict__ ft_lo,
-                                                      const int *__restrict__ fidx,
-                                                      const float *__restrict__ ws,
-                                                      const float *__restrict__ bs, int relu,
-                                                      float *__restrict__ out) {
+// One workgroup of 1024 threads per 64-query tile (there are only B*M/64 tiles, about one
+// per CU: sixteen waves keep enough loads in flight and split the 64x64x32 product);
+// thread = (query tx, 4 channels of wave ty): the query's 32 inputs sit in registers, the
+// weight rows are wave-uniform 16-byte LDS broadcasts.
+__global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float *__restrict__ ysel,
+                                                       const float *__restrict__ pack2,
+                                                       const __bf16 *__restrict__ ft,
+                                                       const __bf16 *__restrict__ ft_lo,
+                                                       const int *__restrict__ fidx,
+                                                       const float *__restrict__ ws,
+                                                       const float *__restrict__ bs, int relu,
+                                                       float *__restrict__ out) {
     __shared__ float tile[64][65];
     __shared__ float sfi[64][33];
-    __shared__ float sws[64][33];
+    __shared__ __attribute__((aligned(16))) float sws[64][36];
     const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if (ws) stage_skip_operands(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, nullptr);
-    for (int j = ty; j < 64; j += 4) {   // j = query within tile, tx = channel
-        const int q = m0 + j;
-        tile[j][tx] = q < m ? ysel[((size_t)cloud * m + q) * 64 + tx] * pack2[tx] + pack2[64 + tx] : 0.f;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..15
+    if (ws) stage_skip_operands<1024, 36>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, nullptr);
+    {
+        const float sc = pack2[tx], sh = pack2[64 + tx];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {   // j = query within tile, tx = channel
+            const int j = ty + 16 * k, q = m0 + j;
+            tile[j][tx] = q < m ? ysel[((size_t)cloud * m + q) * 64 + tx] * sc + sh : 0.f;
+        }
     }
     __syncthreads();
-    for (int c = ty; c < 64; c += 4) {   // c = channel, tx = query
+    float fi[32];
+    if (ws) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) fi[i] = sfi[tx][i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {        // c = channel (wave-uniform), tx = query
+        const int c = 4 * ty + k;
         float v = tile[tx][c];
         if (ws) {
             float idn = bs ? bs[c] : 0.0f;
+            const float4 *wrow = reinterpret_cast<const float4 *>(sws[c]);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) idn += sws[c][i] * sfi[tx][i];
+            for (int i4 = 0; i4 < 8; ++i4) {
+                const float4 w = wrow[i4];
+                idn = __builtin_fmaf(w.x, fi[4 * i4], idn);
+                idn = __builtin_fmaf(w.y, fi[4 * i4 + 1], idn);
+                idn = __builtin_fmaf(w.z, fi[4 * i4 + 2], idn);
+                idn = __builtin_fmaf(w.w, fi[4 * i4 + 3], idn);
+            }
             v += idn;
         }
         if (relu) v = fmaxf(v, 0.0f);
@@ -217,7 +242,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(int n, int m, const float
         }
         tile[tx][c] = g;
     }
-    if (ws) stage_skip_operands(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, ssrc);
+    if (ws) stage_skip_operands<256, 33>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, ssrc);
     __syncthreads();
     const float sc = pack2[tx], mu = pack2[128 + tx], iv = pack2[192 + tx];
     float s1 = 0.0f, s2 = 0.0f;
@@ -560,7 +585,7 @@ extern "C" int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const floa
     if (ws && (!ft || !fidx || n <= 0 || (precision != 1 && precision != 2))) return APN_EINVAL;
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = (ws && precision == 2) ? hi + (size_t)b * n * 32 : nullptr;
-    hipLaunchKernelGGL(apn::fwd_out_kernel, dim3((m + 63) / 64, b), dim3(256), 0, APN_ST, n, m, ysel,
+    hipLaunchKernelGGL(apn::fwd_out_kernel, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, ysel,
                        pack2, hi, lo, fidx, ws, bs, relu, out);
     APN_LAUNCH_CHECK();
     return APN_OK;
