@@ -113,13 +113,13 @@ __global__ __launch_bounds__(1024) void bn_fold_kernel(
 // Loads are issued in independent batches (indices, then rows) so that the dependent
 // index -> row chain is paid once, not once per loop iteration.  Optionally records the source
 // point of each query.
-template <int NT, int WST>
+template <int NT, int WST, int FST>
 __device__ __forceinline__ void stage_skip_operands(int cloud, int n, int m, int m0,
                                                     const __bf16 *__restrict__ ft,
                                                     const __bf16 *__restrict__ ft_lo,
                                                     const int *__restrict__ fidx,
                                                     const float *__restrict__ ws,
-                                                    float (*sws)[WST], float (*sfi)[33], int *ssrc) {
+                                                    float (*sws)[WST], float (*sfi)[FST], int *ssrc) {
     constexpr int G = NT / 32, QPT = 64 / G;        // row groups, queries per thread
     const int tid = threadIdx.x, i = tid & 31, q0 = tid >> 5;     // queries q0 + G t
     int src[QPT];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float
     __shared__ __attribute__((aligned(16))) float sws[64][36];
     const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..15
-    if (ws) stage_skip_operands<1024, 36>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, nullptr);
+    if (ws) stage_skip_operands<1024, 36, 33>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, nullptr);
     {
         const float sc = pack2[tx], sh = pack2[64 + tx];
 #pragma unroll
@@ -213,27 +213,30 @@ __global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float
 //   partWs[blk][64*32] = sum_q g[q][c] * fi[q][i]        (dL/dWs of the block's queries)
 //   gip[b][n][i]   += sum_c ws[c][i] * g[q][c]  at n = fidx[b][q]   (dL/df through the skip,
 //                     point-major rows: 128-byte atomic segments)
-__global__ __launch_bounds__(256) void bwd_prep_kernel(int n, int m, const float *__restrict__ g_out,
-                                                       long long gs_b, long long gs_c, long long gs_m,
-                                                       const float *__restrict__ out, int relu,
-                                                       const float *__restrict__ ysel,
-                                                       const float *__restrict__ pack2,
-                                                       const __bf16 *__restrict__ ft,
-                                                       const __bf16 *__restrict__ ft_lo,
-                                                       const int *__restrict__ fidx,
-                                                       const float *__restrict__ ws,
-                                                       float *__restrict__ goa,
-                                                       float *__restrict__ partS,
-                                                       float *__restrict__ partWs,
-                                                       float *__restrict__ gip) {
+__global__ __launch_bounds__(1024) void bwd_prep_kernel(int n, int m, const float *__restrict__ g_out,
+                                                        long long gs_b, long long gs_c, long long gs_m,
+                                                        const float *__restrict__ out, int relu,
+                                                        const float *__restrict__ ysel,
+                                                        const float *__restrict__ pack2,
+                                                        const __bf16 *__restrict__ ft,
+                                                        const __bf16 *__restrict__ ft_lo,
+                                                        const int *__restrict__ fidx,
+                                                        const float *__restrict__ ws,
+                                                        float *__restrict__ goa,
+                                                        float *__restrict__ partS,
+                                                        float *__restrict__ partWs,
+                                                        float *__restrict__ gip) {
+    // 1024 threads per 64-query tile (about one tile per CU), as in fwd_out_kernel
     __shared__ float tile[64][65];       // g[q][c]
-    __shared__ float red[4][2][64];
-    __shared__ float sfi[64][33];
+    __shared__ float red[16][2][64];
+    __shared__ __attribute__((aligned(8))) float sfi[64][34];
     __shared__ float sws[64][33];
     __shared__ int ssrc[64];
     const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int c = ty; c < 64; c += 4) {   // read (c, query tx): coalesced over queries
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..15
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {        // read (c, query tx): coalesced over queries
+        const int c = ty + 16 * k;
         float g = 0.0f;
         if (m0 + tx < m) {
             const size_t o = ((size_t)cloud * 64 + c) * m + m0 + tx;
@@ -242,46 +245,58 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(int n, int m, const float
         }
         tile[tx][c] = g;
     }
-    if (ws) stage_skip_operands<256, 33>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, ssrc);
+    float ys[4];                         // ysel of (query ty + 16 k, channel tx), used after the barrier
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = m0 + ty + 16 * k;
+        ys[k] = q < m ? ysel[((size_t)cloud * m + q) * 64 + tx] : 0.0f;
+    }
+    if (ws) stage_skip_operands<1024, 33, 34>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, ssrc);
     __syncthreads();
     const float sc = pack2[tx], mu = pack2[128 + tx], iv = pack2[192 + tx];
     float s1 = 0.0f, s2 = 0.0f;
-    for (int j = ty; j < 64; j += 4) {   // (query j, channel tx): coalesced over channels
-        const int q = m0 + j;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {        // (query j, channel tx): coalesced over channels
+        const int j = ty + 16 * k, q = m0 + j;
         if (q < m) {
             const float g = tile[j][tx];
-            const size_t o = ((size_t)cloud * m + q) * 64 + tx;
-            goa[o] = g * sc;
+            goa[((size_t)cloud * m + q) * 64 + tx] = g * sc;
             s1 += g;
-            s2 += g * ((ysel[o] - mu) * iv);
+            s2 += g * ((ys[k] - mu) * iv);
         }
     }
     red[ty][0][tx] = s1;
     red[ty][1][tx] = s2;
     __syncthreads();
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    if (ty < 2)
-        partS[blk * 128 + ty * 64 + tx] = red[0][ty][tx] + red[1][ty][tx] + red[2][ty][tx] + red[3][ty][tx];
+    if (ty < 2) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += red[k][ty][tx];
+        partS[blk * 128 + ty * 64 + tx] = acc;
+    }
     if (ws) {
-        // dL/dWs[c][i]: thread (c = tx, 8 inputs i = 8*ty..)
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // dL/dWs[c][i]: thread (c = tx, inputs i = 2 ty, 2 ty + 1)
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll 8
         for (int q = 0; q < 64; ++q) {
             const float g = tile[q][tx];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] += g * sfi[q][8 * ty + j];
+            const float2 fv = *reinterpret_cast<const float2 *>(&sfi[q][2 * ty]);
+            a0 = __builtin_fmaf(g, fv.x, a0);
+            a1 = __builtin_fmaf(g, fv.y, a1);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) partWs[blk * 2048 + tx * 32 + 8 * ty + j] = a[j];
-        // dL/dfi[q][i] -> point-major gip rows: thread (i = tid & 31, 8 queries)
+        *reinterpret_cast<float2 *>(partWs + blk * 2048 + tx * 32 + 2 * ty) = make_float2(a0, a1);
+        // dL/dfi[q][i] -> point-major gip rows: thread (i = tid & 31, queries qg, qg + 32)
         const int i = threadIdx.x & 31, qg = threadIdx.x >> 5;
-        for (int q = qg; q < 64; q += 8) {
-            if (m0 + q < m) {
-                float v = 0.0f;
+        float v0 = 0.0f, v1 = 0.0f;
 #pragma unroll 8
-                for (int c = 0; c < 64; ++c) v += sws[c][i] * tile[q][c];
-                atomicAdd(gip + ((size_t)cloud * n + ssrc[q]) * 32 + i, v);
-            }
+        for (int c = 0; c < 64; ++c) {
+            const float w = sws[c][i];
+            v0 = __builtin_fmaf(w, tile[qg][c], v0);
+            v1 = __builtin_fmaf(w, tile[qg + 32][c], v1);
         }
+        if (m0 + qg < m) atomicAdd(gip + ((size_t)cloud * n + ssrc[qg]) * 32 + i, v0);
+        if (m0 + qg + 32 < m) atomicAdd(gip + ((size_t)cloud * n + ssrc[qg + 32]) * 32 + i, v1);
     }
 }
 
@@ -365,12 +380,10 @@ __global__ __launch_bounds__(1024) void bwd_consts1_kernel(
 //   dL/df[b][i][n]  = sum_mid G[b][n][mid] * W1[mid][3+i]  (+ gip[b][n][i], the skip branch);
 //   dL/dp[b][n][d] += sum_mid G[b][n][mid] * W1[mid][d] / r          (optional)
 //   dL/dnew_p[q][d] = -sum_mid H[q][mid] * W1[mid][d] / r            (optional)
-// For the products 256 threads = 32 mid x 8 column groups; group g owns columns
-// {g, g+8, g+16, g+24, g+32}: every wave (two groups) runs the same instruction stream and
-// the staged tile is read as sB[pt][col].
+// One workgroup of 1024 threads per tile (there are B*N/64 tiles, two per CU).
 constexpr int WG_PTS = 64;
 
-__global__ __launch_bounds__(256) void bwd_point_grads_kernel(
+__global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
     int n, int total_q, int split, const float *__restrict__ A, const float *__restrict__ geo,
     const float *__restrict__ HA, const float *__restrict__ HB, const float *__restrict__ cabc,
     const float *__restrict__ pack1, const __bf16 *__restrict__ ft,
@@ -378,8 +391,8 @@ __global__ __launch_bounds__(256) void bwd_point_grads_kernel(
     const float *__restrict__ new_xyz, const float *__restrict__ w1, const float *__restrict__ gip,
     float inv_r, float *__restrict__ partW, float *__restrict__ g_f, float *__restrict__ g_p,
     float *__restrict__ g_q) {
-    __shared__ float sw[32][36];        // W1[mid][35]
-    __shared__ float swr[32][36];       // W1 rounded to the operand precision
+    __shared__ __attribute__((aligned(16))) float swt[35][36];   // W1 transposed: [input col][mid]
+    __shared__ __attribute__((aligned(16))) float swr[32][36];   // W1 rounded to the operand precision: [mid][f 0..31 | xyz]
     __shared__ float sG[WG_PTS][33];    // A, then G [point][mid]
     __shared__ float sH[WG_PTS][33];    // H [query][mid]
     __shared__ float sI[WG_PTS][33];    // gip [point][i]
@@ -392,21 +405,23 @@ __global__ __launch_bounds__(256) void bwd_point_grads_kernel(
     const size_t p0 = (size_t)cloud * n + n0;            // first point row of the tile
     const int q0 = block * WG_PTS;                       // first query row (flat)
     const int n_here = n - n0 < WG_PTS ? n - n0 : WG_PTS;
-    for (int e = tid; e < 32 * 35; e += 256) {
+    for (int e = tid; e < 32 * 35; e += 1024) {
+        const int mid = e / 35, col = e % 35;
         const float w = w1[e];
         const __bf16 hi = (__bf16)w;
         float wr = (float)hi;
         if (split) wr += (float)(__bf16)(w - wr);
-        sw[e / 35][e % 35] = w;
-        swr[e / 35][e % 35] = wr;
+        swt[col][mid] = w;
+        swr[mid][col < 3 ? 32 + col : col - 3] = wr;
     }
     if (tid < 96) sc[tid >> 5][tid & 31] = cabc[tid];
     else if (tid < 160) sc[3 + ((tid - 96) >> 5)][tid & 31] = pack1[64 + tid - 96];   // mean1, inv1
     {
-        const int c = tid & 31;                           // fixed per thread: e = tid + 256 k
+        const int c = tid & 31;                           // fixed per thread: e = tid + 1024 k
         const float ca = cabc[c], cb = cabc[32 + c], cc = cabc[64 + c];
-        for (int e = tid; e < WG_PTS * 32; e += 256) {
-            const int pt = e >> 5;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int pt = (tid >> 5) + 32 * k;
             const bool ok = pt < n_here;
             sG[pt][c] = ok ? A[(p0 + pt) * 32 + c] : 0.0f;
             float fv = ok ? (float)ft[(p0 + pt) * 32 + c] : 0.0f;
@@ -421,78 +436,93 @@ __global__ __launch_bounds__(256) void bwd_point_grads_kernel(
             sH[pt][c] = hv;
         }
     }
-    for (int e = tid; e < WG_PTS * 3; e += 256) {
-        const int pt = e / 3, d = e % 3;
+    if (tid < WG_PTS * 3) {
+        const int pt = tid / 3, d = tid % 3;
         sB[pt][d] = pt < n_here ? xyz[(p0 + pt) * 3 + d] : 0.0f;
         sB[pt][3 + d] = q0 + pt < total_q ? new_xyz[(size_t)(q0 + pt) * 3 + d] : 0.0f;
-    }
-    for (int e = tid; e < WG_PTS * 2; e += 256) sB[e >> 1][38 + (e & 1)] = 0.0f;   // pad columns
-    {
-        const int pt = tid >> 2, j = tid & 3;
+    } else if (tid < WG_PTS * 3 + WG_PTS * 3) {
+        const int e = tid - WG_PTS * 3;
+        sB[e / 3][38 + e % 3] = 0.0f;                     // pad columns
+    } else if (tid < WG_PTS * 6 + WG_PTS * 4) {
+        const int e = tid - WG_PTS * 6, pt = e >> 2, j = e & 3;
         sGeo[pt][j] = pt < n_here ? geo[(p0 + pt) * 4 + j] : 0.0f;
     }
     __syncthreads();
 
-    {   // G in place of A: thread (point tx, 8 mid channels of wave ty)
-        const int tx = tid & 63, ty = tid >> 6;
+    const int tx = tid & 63, ty = tid >> 6;               // ty = 0..15, wave-uniform
+    {   // G in place of A: thread (point tx, mid channels 2 ty, 2 ty + 1)
         const float cnt = sGeo[tx][0], gx = sGeo[tx][1], gy = sGeo[tx][2], gz = sGeo[tx][3];
         float fx[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) fx[i] = sB[tx][6 + i];
-#pragma unroll 2
-        for (int mm = 0; mm < 8; ++mm) {
-            const int mid = ty * 8 + mm;
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+            const int mid = 2 * ty + mm;
+            const float4 *wrow = reinterpret_cast<const float4 *>(swr[mid]);
             float accf = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) accf = __builtin_fmaf(swr[mid][3 + i], fx[i], accf);
-            const float ys = swr[mid][0] * gx + swr[mid][1] * gy + swr[mid][2] * gz + cnt * accf;
+            for (int i4 = 0; i4 < 8; ++i4) {
+                const float4 w = wrow[i4];
+                accf = __builtin_fmaf(w.x, fx[4 * i4], accf);
+                accf = __builtin_fmaf(w.y, fx[4 * i4 + 1], accf);
+                accf = __builtin_fmaf(w.z, fx[4 * i4 + 2], accf);
+                accf = __builtin_fmaf(w.w, fx[4 * i4 + 3], accf);
+            }
+            const float4 wx = wrow[8];
+            const float ys = wx.x * gx + wx.y * gy + wx.z * gz + cnt * accf;
             const float yhs = sc[4][mid] * (ys - cnt * sc[3][mid]);
             sG[tx][mid] = sc[0][mid] * sG[tx][mid] + sc[1][mid] * yhs + sc[2][mid] * cnt;
         }
     }
     __syncthreads();
 
-    {   // products for dL/dW1
+    {   // products for dL/dW1: thread (mid, column group grp 0..31) owns columns grp, grp + 32
         const int mid = tid & 31, grp = tid >> 5;
-        // column grp + 8 j; only j = 0 can be a query column (3..5), and only for grp in {3,4,5}
-        const bool qcol = grp >= 3 && grp <= 5;
-        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+        const bool qcol = grp >= 3 && grp <= 5;           // query columns: new_xyz x H
+        const bool two = grp + 32 < 38;
+        float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll 8
         for (int pt = 0; pt < WG_PTS; ++pt) {
             const float g = sG[pt][mid];
             const float a0 = qcol ? sH[pt][mid] : g;
-            acc[0] += a0 * sB[pt][grp];
-#pragma unroll
-            for (int j = 1; j < 5; ++j) acc[j] += g * sB[pt][grp + 8 * j];
+            acc0 = __builtin_fmaf(a0, sB[pt][grp], acc0);
+            if (two) acc1 = __builtin_fmaf(g, sB[pt][grp + 32], acc1);
         }
         float *row = partW + (size_t)block * 32 * 38;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int col = grp + 8 * j;
-            if (col < 38) row[mid * 38 + col] = acc[j];
-        }
+        row[mid * 38 + grp] = acc0;
+        if (two) row[mid * 38 + grp + 32] = acc1;
     }
 
-    const int tx = tid & 63, ty = tid >> 6;              // tx = point / query, ty = channel group
-    for (int i = ty; i < 32; i += 4) {
-        float s = sI[tx][i];
+    // dL/df (2 channels per thread), dL/dp, dL/dnew_p: the point's / query's 32 mid values in
+    // registers, W1 columns as wave-uniform 16-byte broadcasts
+    float gr[32];
 #pragma unroll
-        for (int mid = 0; mid < 32; ++mid) s += sG[tx][mid] * sw[mid][3 + i];
+    for (int mid = 0; mid < 32; ++mid) gr[mid] = sG[tx][mid];
+    auto dot_col = [&](const float (&v)[32], int col) {
+        const float4 *wcol = reinterpret_cast<const float4 *>(swt[col]);
+        float s = 0.0f;
+#pragma unroll
+        for (int i4 = 0; i4 < 8; ++i4) {
+            const float4 w = wcol[i4];
+            s = __builtin_fmaf(v[4 * i4], w.x, s);
+            s = __builtin_fmaf(v[4 * i4 + 1], w.y, s);
+            s = __builtin_fmaf(v[4 * i4 + 2], w.z, s);
+            s = __builtin_fmaf(v[4 * i4 + 3], w.w, s);
+        }
+        return s;
+    };
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = ty + 16 * k;
+        const float s = sI[tx][i] + dot_col(gr, 3 + i);
         if (tx < n_here) g_f[((size_t)cloud * 32 + i) * n + n0 + tx] = s;
     }
-    if (ty < 3) {
-        if (g_p && tx < n_here) {
-            float s = 0.0f;
+    if (ty < 3 && g_p && tx < n_here) g_p[(p0 + tx) * 3 + ty] += dot_col(gr, ty) * inv_r;
+    if (ty >= 4 && ty < 7 && g_q && q0 + tx < total_q) {
+        float hr[32];
 #pragma unroll
-            for (int mid = 0; mid < 32; ++mid) s += sG[tx][mid] * sw[mid][ty];
-            g_p[(p0 + tx) * 3 + ty] += s * inv_r;
-        }
-        if (g_q && q0 + tx < total_q) {
-            float s = 0.0f;
-#pragma unroll
-            for (int mid = 0; mid < 32; ++mid) s += sH[tx][mid] * sw[mid][ty];
-            g_q[(size_t)(q0 + tx) * 3 + ty] = -s * inv_r;
-        }
+        for (int mid = 0; mid < 32; ++mid) hr[mid] = sH[tx][mid];
+        g_q[(size_t)(q0 + tx) * 3 + ty - 4] = -dot_col(hr, ty - 4) * inv_r;
     }
 }
 
@@ -604,7 +634,7 @@ extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long lon
         return APN_EINVAL;
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = (ws && precision == 2) ? hi + (size_t)b * n * 32 : nullptr;
-    hipLaunchKernelGGL(apn::bwd_prep_kernel, dim3((m + 63) / 64, b), dim3(256), 0, APN_ST, n, m, g_out,
+    hipLaunchKernelGGL(apn::bwd_prep_kernel, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, g_out,
                        gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, partS, partWs, gip);
     APN_LAUNCH_CHECK();
     return APN_OK;
@@ -647,7 +677,7 @@ extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const float *A, const
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = precision == 2 ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::bwd_point_grads_kernel, dim3((n + apn::WG_PTS - 1) / apn::WG_PTS, b),
-                       dim3(256), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, A, geo, HA, HB, cabc,
+                       dim3(1024), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, A, geo, HA, HB, cabc,
                        pack1, hi, lo, xyz, new_xyz, w1, gip, 1.0f / radius, partW, g_f, g_p, g_newp);
     APN_LAUNCH_CHECK();
     return APN_OK;
