@@ -248,52 +248,83 @@ def main():
 
     # the two-stream pipeline pays only when the step is GPU-bound, i.e. under graph replay
     pipelined = fused_mlp and args.pipeline == "on" and not use_ddp
+    use_graph = (args.graph == "on") or (args.graph == "auto" and not use_ddp)
+    # steps per graph: several whole steps per replay when no collective sits between steps
+    spg = 1
+    if use_graph and not distributed and args.steps_per_graph != 1:
+        for cand in ((args.steps_per_graph,) if args.steps_per_graph else (20, 10, 4, 2)):
+            if cand > 1 and args.steps % cand == 0 and args.warmup % cand == 0:
+                spg = cand
+                break
     if pipelined:
         from adaptpoint_amd.fused import Sampling
         side_stream = torch.cuda.Stream()
-        # double buffer: step k consumes smp[k % 2] and fills smp[(k + 1) % 2]
-        smp = [blk.sample(p), None]                   # prologue: index stage of batch 0
-        smp[1] = Sampling(*smp[0].shape, dev)
-    parity = [0]
-    graph_grads, last_grads = [], [None]
-
-    def fwd_bwd(cur=0):
-        if not pipelined:
-            new_p, out = model([p, f])
-            out.sum().backward()
-            return
-        main = torch.cuda.current_stream()
-        side_stream.wait_stream(main)                 # fork
-        with torch.cuda.stream(side_stream):
-            blk.sample(p, out=smp[1 - cur])           # index stage of batch k+1 (32 CUs busy)
-        new_p, out = model([p, f], sampling=smp[cur])  # MLP forward+backward of batch k
-        out.sum().backward()
-        main.wait_stream(side_stream)                 # join
+        # Two sets of spg index-stage results: a launch of spg steps consumes set `cur` on the
+        # main stream while the side stream fills the other set for the NEXT launch -- the
+        # streams meet once per launch (fork at its start, join at its end), not once per step:
+        # inside a hipGraph every cross-queue dependency costs ~10 us of idle queue.
+        first = blk.sample(p)                         # prologue: index stage of the first batches
+        sets = [[first] + [Sampling(*first.shape, dev) for _ in range(spg - 1)],
+                [Sampling(*first.shape, dev) for _ in range(spg)]]
+        for smp_i in sets[0][1:] + sets[1]:
+            smp_i.buf.copy_(first.buf)
+    cur_set = [0]
+    graph_grads, last_grads = {}, [None]
 
     def clear_grads():
         f.grad = None
         for q in params:
             q.grad = None
 
-    def step():
-        clear_grads()
-        fwd_bwd(parity[0])
-        parity[0] ^= 1
+    def mlp_steps(count, cur):
+        """`count` consecutive MLP forward+backward steps on the current stream; pipelined: step i
+        takes its index stage from sets[cur][i], else the block computes it in line."""
+        for i in range(count):
+            clear_grads()
+            new_p, out = model([p, f], sampling=sets[cur][i]) if pipelined else model([p, f])
+            out.sum().backward()
 
-    use_graph = (args.graph == "on") or (args.graph == "auto" and not use_ddp)
+    def index_steps(count, dst):
+        for i in range(count):
+            blk.sample(p, out=sets[dst][i])           # FPS + ball query of one batch (32 CUs busy)
+
+    # Pipelined launch of `count` steps: the MLP steps consume set `cur` on the main stream while
+    # the side stream fills the other set for the NEXT launch.  mlp_done / index_done order a
+    # launch after the previous launch of the OTHER stream, whose set it is about to touch.
+    mlp_done, index_done = torch.cuda.Event(), torch.cuda.Event()
+
+    def launch(count, cur, run_mlp, run_index):
+        main = torch.cuda.current_stream()
+        if not pipelined:
+            run_mlp(count, cur)
+            return
+        side_stream.wait_event(mlp_done)              # the set to refill was read by the last launch
+        with torch.cuda.stream(side_stream):
+            run_index(count, 1 - cur)
+            next_index_done = torch.cuda.Event()
+            next_index_done.record(side_stream)
+        main.wait_event(index_done_box[0])            # the set to read was filled by the last launch
+        run_mlp(count, cur)
+        mlp_done.record(main)
+        index_done_box[0] = next_index_done
+
+    index_done_box = [index_done]
+    index_done.record(torch.cuda.current_stream())    # prologue above filled set 0
+    mlp_done.record(torch.cuda.current_stream())
+
+    def step():
+        launch(1, cur_set[0], mlp_steps, index_steps)
+        cur_set[0] ^= 1
+
     eager_step = step
-    # steps per graph: several whole steps per replay when no collective sits between steps
-    spg = 1
-    if use_graph and not distributed and args.steps_per_graph != 1:
-        for cand in ((args.steps_per_graph,) if args.steps_per_graph else (20, 10, 4, 2)):
-            if cand > 1 and args.steps % cand == 0 and args.warmup % cand == 0 and cand % 2 == 0:
-                spg = cand
-                break
     if use_graph:
-        # Whole-step capture: every launch of the step (extension kernels through ctypes on the
-        # capture stream, PyTorch ops, autograd) becomes one hipGraph; replay has no host work.
-        # The pipelined step is captured twice, once per orientation of the double buffer, and
-        # the two graphs alternate -- no buffer rotation copy on the critical path.
+        # Whole-step capture: every launch of spg steps (extension kernels through ctypes on the
+        # capture stream, PyTorch ops, autograd) becomes one hipGraph; replay has no host work,
+        # and the ~20-30 us the GPU idles between two graph launches is paid once per spg steps.
+        # Pipelined: the MLP steps and the index stages are SEPARATE single-branch graphs (one per
+        # orientation of the two sets), replayed side by side on the two streams -- a two-branch
+        # graph is not reliably run on two queues, and every cross-queue edge inside a graph
+        # costs ~10 us of idle queue.
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -301,34 +332,29 @@ def main():
                 for _ in range(4):
                     eager_step()
             torch.cuda.current_stream().wait_stream(side)
-            graphs = []
-            if spg > 1:
-                # spg consecutive steps (alternating orientations) in ONE graph: the ~20-30 us
-                # the GPU idles between two graph launches is paid once per spg steps.
+            torch.cuda.synchronize()
+            mlp_graphs, index_graphs = {}, {}
+            for cur in ((0, 1) if pipelined else (0,)):
                 clear_grads()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    for i in range(spg):
-                        if i:
-                            clear_grads()
-                        fwd_bwd(i % 2)
-                graphs.append(g)
-                graph_grads.append([q.grad for q in params if q.grad is not None])
-            else:
-                for cur in ((0, 1) if pipelined else (0,)):
-                    clear_grads()
+                    mlp_steps(spg, cur)
+                mlp_graphs[cur] = g
+                # each capture owns its gradient tensors; a replay refreshes them in place
+                graph_grads[cur] = [q.grad for q in params if q.grad is not None]
+                if pipelined:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        fwd_bwd(cur)
-                    graphs.append(g)
-                    # each capture owns its gradient tensors; a replay refreshes them in place
-                    graph_grads.append([q.grad for q in params if q.grad is not None])
-            parity[0] = 0
+                        index_steps(spg, cur)
+                    index_graphs[cur] = g
 
             def step():
-                graphs[parity[0]].replay()
-                last_grads[0] = graph_grads[parity[0]]
-                parity[0] = (parity[0] + 1) % len(graphs)
+                cur = cur_set[0]
+                launch(spg, cur, lambda n, c: mlp_graphs[c].replay(),
+                       lambda n, d: index_graphs[d].replay())
+                last_grads[0] = graph_grads[cur]
+                if pipelined:
+                    cur_set[0] ^= 1
         except Exception as exc:                      # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly",
                   file=sys.stderr, flush=True)
@@ -415,8 +441,9 @@ def main():
                                           "f32 BatchNorm statistics summed in f64",
                             "torch-f32": "unfused: extension ops + PyTorch fp32 conv/BN"}[args.mlp]),
                    "launch": (f"hipGraph replay, {spg} step(s) per graph" if use_graph else "eager"),
-                   "pipeline": ("index stage (FPS + ball query) of batch k+1 on a second stream "
-                                "beside the MLP fwd+bwd of batch k" if pipelined else "none"),
+                   "pipeline": ("index stage (FPS + ball query) of the NEXT launch's batches on a second stream "
+                                "beside the MLP fwd+bwd of the current batch(es); the two streams meet "
+                                "once per launch" if pipelined else "none"),
                    "global_batch": B_PER_GPU * world,
                    "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else "")
                                   + ("+ddp" if use_ddp else ("+flat-allreduce" if distributed else ""))},
