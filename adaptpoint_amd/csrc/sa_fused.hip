@@ -157,32 +157,55 @@ __device__ __forceinline__ void load_w1_frags(const float *__restrict__ w1, int 
     }
 }
 
-// Gather one tile: lane (pos, h) fetches 2 x 16 bytes of its neighbour's bf16 row (and of
-// the remainder row in split mode), and (h = 0) the normalised relative position.
-// Returns the neighbour index of `pos`; deff (optional) receives, in BOTH halves, the
-// relative position as the MFMA sees it (rounded to the operand precision).
+// Gathering one tile.  Lane (pos, h) fetches 2 x 16 bytes of its neighbour's bf16 row (and of
+// the remainder row in split mode) and the neighbour's coordinates.  The loads of tile t+1
+// are ISSUED (fetch_tile) before the arithmetic of tile t and only consumed (build_frags) one
+// iteration later, and the neighbour indices are read two tiles ahead: the dependent
+// idx -> row chain (two L2 round trips) is off the critical path of the tile loop.
 template <int NS>
-__device__ __forceinline__ int gather_tile(const SaArgs &a, int tile, int pos, int h,
-                                           Frag<NS> (&x)[3], float *deff = nullptr) {
+struct TileRaw {
+    uint4 f[2], fl[NS];   // feature-row slices (fl: remainder row, split mode)
+    float px, py, pz;     // neighbour coordinates
+    float qx, qy, qz;     // query coordinates (wave-uniform)
+    int nb;               // neighbour index of this lane's position
+};
+
+template <int NS>
+__device__ __forceinline__ void fetch_tile(const SaArgs &a, int tile, int nb, int h, TileRaw<NS> &t) {
     const int cloud = tile / a.m;
-    const int nb = a.idx[(size_t)tile * SA_K + pos];
     const size_t rowoff = ((size_t)cloud * a.n + nb) * SA_C;
     const uint4 *row = reinterpret_cast<const uint4 *>(a.ft + rowoff);
-    x[0].p[0] = __builtin_bit_cast(bf16x8, row[h]);
-    x[1].p[0] = __builtin_bit_cast(bf16x8, row[2 + h]);
+    t.f[0] = row[h];
+    t.f[1] = row[2 + h];
     if (NS == 2) {
         const uint4 *rl = reinterpret_cast<const uint4 *>(a.ft_lo + rowoff);
-        x[0].p[NS - 1] = __builtin_bit_cast(bf16x8, rl[h]);
-        x[1].p[NS - 1] = __builtin_bit_cast(bf16x8, rl[2 + h]);
+        t.fl[0] = rl[h];
+        t.fl[NS - 1] = rl[2 + h];
     }
-    const float *q = a.new_xyz + (size_t)tile * 3;           // wave-uniform
     const float *p = a.xyz + ((size_t)cloud * a.n + nb) * 3;
+    t.px = p[0]; t.py = p[1]; t.pz = p[2];
+    const float *q = a.new_xyz + (size_t)tile * 3;
+    t.qx = q[0]; t.qy = q[1]; t.qz = q[2];
+    t.nb = nb;
+}
+
+// Operand fragments of a fetched tile.  deff (optional) receives, in BOTH halves, the relative
+// position as the MFMA sees it (rounded to the operand precision).
+template <int NS>
+__device__ __forceinline__ void build_frags(const SaArgs &a, const TileRaw<NS> &t, int h,
+                                            Frag<NS> (&x)[3], float *deff = nullptr) {
+    x[0].p[0] = __builtin_bit_cast(bf16x8, t.f[0]);
+    x[1].p[0] = __builtin_bit_cast(bf16x8, t.f[1]);
+    if (NS == 2) {
+        x[0].p[NS - 1] = __builtin_bit_cast(bf16x8, t.fl[0]);
+        x[1].p[NS - 1] = __builtin_bit_cast(bf16x8, t.fl[NS - 1]);
+    }
     float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (h == 0 || deff) {
         // group.py:250-253: (grouped_xyz - query) then /= radius
-        d[0] = (p[0] - q[0]) / a.radius;
-        d[1] = (p[1] - q[1]) / a.radius;
-        d[2] = (p[2] - q[2]) / a.radius;
+        d[0] = (t.px - t.qx) / a.radius;
+        d[1] = (t.py - t.qy) / a.radius;
+        d[2] = (t.pz - t.qz) / a.radius;
     }
     if (deff) {
 #pragma unroll
@@ -194,7 +217,26 @@ __device__ __forceinline__ int gather_tile(const SaArgs &a, int tile, int pos, i
         if (h != 0) d[0] = d[1] = d[2] = 0.0f;
     }
     x[2] = make_frag<NS>(d);
-    return nb;
+}
+
+// The tile loop of a wave, software-pipelined as described above.  BODY(tile, raw) consumes one
+// fetched tile.
+template <int NS, typename Body>
+__device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Body body) {
+    const int tiles = a.b * a.m, stride = gridDim.x * SA_WAVES;
+    int tile = blockIdx.x * SA_WAVES + wave;
+    if (tile >= tiles) return;
+    TileRaw<NS> cur, nxt;
+    fetch_tile<NS>(a, tile, a.idx[(size_t)tile * SA_K + r], h, cur);
+    int nb_nxt = tile + stride < tiles ? a.idx[(size_t)(tile + stride) * SA_K + r] : 0;
+    for (; tile < tiles; tile += stride) {
+        const bool more = tile + stride < tiles;               // wave-uniform
+        if (more) fetch_tile<NS>(a, tile + stride, nb_nxt, h, nxt);
+        const int nb_nxt2 = tile + 2 * stride < tiles ? a.idx[(size_t)(tile + 2 * stride) * SA_K + r] : 0;
+        body(tile, cur);
+        if (more) cur = nxt;
+        nb_nxt = nb_nxt2;
+    }
 }
 
 // Workgroup-level fold of per-lane statistics into ONE partial row per workgroup:
@@ -229,16 +271,15 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
     Frag<NS> w1f[3];
     load_w1_frags<NS>(a.w1, r, h, w1f);
     float st[2] = {0.0f, 0.0f};
-    const int tiles = a.b * a.m;
-    for (int tile = blockIdx.x * SA_WAVES + wave; tile < tiles; tile += gridDim.x * SA_WAVES) {
+    for_each_tile<NS>(a, wave, r, h, [&](int, const TileRaw<NS> &raw) {
         Frag<NS> x[3];
-        gather_tile<NS>(a, tile, r, h, x);
+        build_frags<NS>(a, raw, h, x);
         f32x16 y = {0};
 #pragma unroll
         for (int s = 0; s < 3; ++s) y = mfma<NS>(x[s], w1f[s], y);  // Y1: lane = mid channel
 #pragma unroll
         for (int i = 0; i < 16; ++i) { st[0] += y[i]; st[1] += y[i] * y[i]; }
-    }
+    });
     write_partials<2>(st, part, lane, wave);
 }
 
@@ -274,10 +315,9 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
     const float sg[2] = {sgn2[r], sgn2[32 + r]};
     float st[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum t0, sum t1, sumsq t0, sumsq t1
 
-    const int tiles = a.b * a.m;
-    for (int tile = blockIdx.x * SA_WAVES + wave; tile < tiles; tile += gridDim.x * SA_WAVES) {
+    for_each_tile<NS>(a, wave, r, h, [&](int tile, const TileRaw<NS> &raw) {
         Frag<NS> x[3];
-        gather_tile<NS>(a, tile, r, h, x);
+        build_frags<NS>(a, raw, h, x);
         f32x16 y1 = {0};
 #pragma unroll
         for (int s = 0; s < 3; ++s) y1 = mfma<NS>(w1f[s], x[s], y1);  // Y1^T: lane = position
@@ -310,7 +350,7 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
                 ksel[(size_t)tile * SA_C2 + 32 * t + r] = (unsigned char)kpos;
             }
         }
-    }
+    });
     write_partials<4>(st, part, lane, wave);
 }
 
@@ -417,11 +457,11 @@ __global__ __launch_bounds__(SA_WAVES * 64, 1) void sa_bwd_kernel(SaArgs a, SaBw
     __bf16 *sp_img = sp_lds[wave];
     for (int e = lane; e < NS * SP_TILE; e += 64) sp_img[e] = (__bf16)0.0f;
 
-    const int tiles = a.b * a.m;
-    for (int tile = blockIdx.x * SA_WAVES + wave; tile < tiles; tile += gridDim.x * SA_WAVES) {
+    for_each_tile<NS>(a, wave, r, h, [&](int tile, const TileRaw<NS> &raw) {
         Frag<NS> x[3];
         float deff[3];
-        const int nb = gather_tile<NS>(a, tile, r, h, x, deff);
+        build_frags<NS>(a, raw, h, x, deff);
+        const int nb = raw.nb;
         // conv1 in both layouts (3 + 3 k-steps on the same fragments)
         f32x16 yT = {0}, y1 = {0};
 #pragma unroll
@@ -537,7 +577,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 1) void sa_bwd_kernel(SaArgs a, SaBw
             gw2[t] = mfma<NS>(pack8<NS>(y2, 0), b0, gw2[t]);
             gw2[t] = mfma<NS>(pack8<NS>(y2, 8), b1, gw2[t]);
         }
-    }
+    });
     write_partials<2>(st, part, lane, wave);
     // dL/dW2 of this workgroup, D[row = out row(i,h) + 32 t][col = mid r]: fold the four
     // waves in LDS, then one float atomic per element into the zeroed (64,32) gradient.
