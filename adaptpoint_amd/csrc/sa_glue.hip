@@ -81,10 +81,21 @@ __global__ __launch_bounds__(1024) void bn_fold_kernel(
     int training, float *__restrict__ pack, const float *__restrict__ sgn_gamma, int sgn_c,
     float *__restrict__ sgn_out) {
     __shared__ double sums[128];
-    if (training) block_sum_rows(part, rows, 2 * c, sums_in, sums);
     const int i = threadIdx.x;
-    if (i == 0 && training && nbt) *nbt += 1;
-    if (sgn_out && i < sgn_c) sgn_out[i] = (!sgn_gamma || sgn_gamma[i] >= 0.0f) ? 1.0f : -1.0f;
+    // everything this thread will need from memory is requested BEFORE the row sums, so that
+    // its latency hides behind them (a lone workgroup: nothing else would)
+    float g32 = 1.0f, b32 = 0.0f, rm = 0.0f, rv = 1.0f;
+    if (i < c) {
+        if (gamma) g32 = gamma[i];
+        if (beta) b32 = beta[i];
+        if (running_mean) { rm = running_mean[i]; rv = running_var[i]; }
+    }
+    long long nb = (i == 0 && training && nbt) ? *nbt : 0;
+    float sg = 1.0f;
+    if (sgn_out && i < sgn_c && sgn_gamma) sg = sgn_gamma[i];
+    if (training) block_sum_rows(part, rows, 2 * c, sums_in, sums);
+    if (i == 0 && training && nbt) *nbt = nb + 1;
+    if (sgn_out && i < sgn_c) sgn_out[i] = sg >= 0.0f ? 1.0f : -1.0f;
     if (i >= c) return;
     double mean, var;
     if (training) {
@@ -93,15 +104,15 @@ __global__ __launch_bounds__(1024) void bn_fold_kernel(
         if (var < 0.0) var = 0.0;
         if (running_mean) {
             const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
-            running_mean[i] = (float)((1.0 - momentum) * running_mean[i] + momentum * mean);
-            running_var[i] = (float)((1.0 - momentum) * running_var[i] + momentum * unbiased);
+            running_mean[i] = (float)((1.0 - momentum) * rm + momentum * mean);
+            running_var[i] = (float)((1.0 - momentum) * rv + momentum * unbiased);
         }
     } else {
-        mean = running_mean[i];
-        var = running_var[i];
+        mean = rm;
+        var = rv;
     }
     const double inv = 1.0 / sqrt(var + (double)eps);
-    const double g = gamma ? (double)gamma[i] : 1.0, b = beta ? (double)beta[i] : 0.0;
+    const double g = g32, b = b32;
     pack[i] = (float)(g * inv);
     pack[c + i] = (float)(b - mean * g * inv);
     pack[2 * c + i] = (float)mean;
@@ -314,14 +325,21 @@ __global__ __launch_bounds__(1024) void bwd_consts2_kernel(const float *__restri
                                                            float *__restrict__ g_beta2,
                                                            float *__restrict__ zero_w2) {
     __shared__ double D[64], E[64], S[128];
-    if (zero_w2) {   // dL/dW2 (64x32) is accumulated atomically by pass 1, the next launch
-        zero_w2[threadIdx.x] = 0.0f;
-        zero_w2[1024 + threadIdx.x] = 0.0f;
-    }
-    block_sum_rows(partS, rows, 128, S_in, S);
+    __shared__ float sw2[64][33];
     const int t = threadIdx.x;
+    if (zero_w2) {   // dL/dW2 (64x32) is accumulated atomically by the backward pass, the next launch
+        zero_w2[t] = 0.0f;
+        zero_w2[1024 + t] = 0.0f;
+    }
+    // operands requested before the row sums: their latency hides behind them
+    const float wa = w2[t], wb = w2[1024 + t];
+    float p_sc = 0.0f, p_mu = 0.0f, p_iv = 0.0f;
+    if (t < 64) { p_sc = pack2[t]; p_mu = pack2[128 + t]; p_iv = pack2[192 + t]; }
+    block_sum_rows(partS, rows, 128, S_in, S);
+    sw2[t >> 5][t & 31] = wa;
+    sw2[32 + (t >> 5)][t & 31] = wb;
     if (t < 64) {
-        const double sc = pack2[t], mu = pack2[128 + t], iv = pack2[192 + t];
+        const double sc = p_sc, mu = p_mu, iv = p_iv;
         const double s1 = S[t], s2 = S[64 + t];
         double d = 0.0, e = 0.0;
         if (training) {
@@ -337,11 +355,12 @@ __global__ __launch_bounds__(1024) void bwd_consts2_kernel(const float *__restri
     __syncthreads();
     const int k = t >> 5, mid = t & 31;   // 32 x 32
     double q = 0.0;
-    for (int c = 0; c < 64; ++c) q += (double)w2[c * 32 + k] * D[c] * (double)w2[c * 32 + mid];
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) q += (double)sw2[c][k] * D[c] * (double)sw2[c][mid];
     qm[k * 32 + mid] = (float)q;
     if (t < 32) {
         double e = 0.0;
-        for (int c = 0; c < 64; ++c) e += E[c] * (double)w2[c * 32 + t];
+        for (int c = 0; c < 64; ++c) e += E[c] * (double)sw2[c][t];
         evec[t] = (float)e;
     }
 }
@@ -352,10 +371,11 @@ __global__ __launch_bounds__(1024) void bwd_consts1_kernel(
     const float *__restrict__ pack1, double count, int training, float *__restrict__ cabc,
     float *__restrict__ g_gamma1, float *__restrict__ g_beta1) {
     __shared__ double T[64];
-    block_sum_rows(partT, rows, 64, T_in, T);
     const int i = threadIdx.x;
+    const float sc32 = i < 32 ? pack1[i] : 0.0f;      // requested before the row sums
+    block_sum_rows(partT, rows, 64, T_in, T);
     if (i >= 32) return;
-    const double sc = pack1[i];
+    const double sc = sc32;
     cabc[i] = (float)sc;
     cabc[32 + i] = training ? (float)(-sc * T[32 + i] / count) : 0.0f;
     cabc[64 + i] = training ? (float)(-sc * T[i] / count) : 0.0f;
