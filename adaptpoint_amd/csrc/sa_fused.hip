@@ -102,6 +102,26 @@ __device__ __forceinline__ f32x16 mfma(const Frag<NS> &a, const Frag<NS> &b, f32
     return mfma(a.p[0], b.p[0], c);
 }
 
+// Constant operand fragments kept in LDS instead of registers: fragment f of lane l is the
+// 16-byte word [(f * NS + part) * 64 + l] -- one conflict-free ds_read_b128 per use.  The
+// per-wave register footprint of the chain's constants (weights in both orientations, BN
+// folds: ~130 VGPRs in the backward pass) is what pushed the kernels past 256 registers, i.e.
+// to one wave per SIMD with a quarter of the vector instructions moving values to and from
+// accumulator registers.
+template <int NS>
+__device__ __forceinline__ void put_frag(uint4 *base, int f, int lane, const Frag<NS> &v) {
+#pragma unroll
+    for (int p = 0; p < NS; ++p) base[(f * NS + p) * 64 + lane] = __builtin_bit_cast(uint4, v.p[p]);
+}
+
+template <int NS>
+__device__ __forceinline__ Frag<NS> get_frag(const uint4 *base, int f, int lane) {
+    Frag<NS> v;
+#pragma unroll
+    for (int p = 0; p < NS; ++p) v.p[p] = __builtin_bit_cast(bf16x8, base[(f * NS + p) * 64 + lane]);
+    return v;
+}
+
 // (B,C,N) f32 channel-major  ->  (B,N,C) bf16 point-major, C = 32: one 64-byte row per point.
 // ft_lo (optional): the bf16 remainder f - float(ft), for the split-operand mode.
 __global__ __launch_bounds__(256) void sa_prep_features_kernel(int n, const float *__restrict__ f,
@@ -390,10 +410,8 @@ struct SaBwdArgs {
     const unsigned char *ksel;  // (B,M,64)
 };
 
-// One wave per SIMD (the register file holds the chain's constants, two MFMA accumulators
-// of dL/dW2 and the tile): one workgroup per CU.
 template <int NS>
-__global__ __launch_bounds__(SA_WAVES * 64, 1) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
+__global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
                                                                float *__restrict__ part,
                                                                float *__restrict__ gw2_acc,
                                                                float *__restrict__ A,
@@ -402,47 +420,60 @@ __global__ __launch_bounds__(SA_WAVES * 64, 1) void sa_bwd_kernel(SaArgs a, SaBw
                                                                float *__restrict__ HB) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    Frag<NS> w1f[3];
-    load_w1_frags<NS>(a.w1, r, h, w1f);
-    float sc1v[16], sh1v[16];
+    // constant fragments, built once per workgroup (wave w builds every fourth) into LDS
+    enum { F_W1 = 0, F_QM = 3, F_W2T = 5, F_W2 = 9, F_COUNT = 13 };
+    __shared__ uint4 cfrag[F_COUNT * NS * 64];
+    __shared__ __attribute__((aligned(16))) float bn1v[2][2][16];   // {scale, shift}[h][register]
+    {
+        Frag<NS> w1f[3];
+        load_w1_frags<NS>(a.w1, r, h, w1f);
+        if (wave == 0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        sc1v[i] = g.scale1[acc_row(i, h)];
-        sh1v[i] = g.shift1[acc_row(i, h)];
+            for (int s = 0; s < 3; ++s) put_frag<NS>(cfrag, F_W1 + s, lane, w1f[s]);
+        }
+        if (wave == 1) {
+            // term 1 of dL/da1: B fragments of Qm, k slot (h,j) of step s <-> mid' = row(8s+j,h)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float tmp[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tmp[j] = g.qm[acc_row(8 * s + j, h) * SA_C1 + r];
+                put_frag<NS>(cfrag, F_QM + s, lane, make_frag<NS>(tmp));
+            }
+            if (lane < 32) {
+                bn1v[0][lane >> 4][lane & 15] = g.scale1[acc_row(lane & 15, lane >> 4)];
+                bn1v[1][lane >> 4][lane & 15] = g.shift1[acc_row(lane & 15, lane >> 4)];
+            }
+        }
+        if (wave == 2) {
+            // term 3: B fragments of W2 with k = output channel in natural order 16 s + 8 h + j
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float tmp[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tmp[j] = g.w2[(16 * s + 8 * h + j) * SA_C1 + r];
+                put_frag<NS>(cfrag, F_W2T + s, lane, make_frag<NS>(tmp));
+            }
+        }
+        if (wave == 3) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float tmp[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        tmp[j] = g.w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
+                    put_frag<NS>(cfrag, F_W2 + 2 * t + s, lane, make_frag<NS>(tmp));
+                }
+        }
     }
     const float sc1 = g.scale1[r], sh1 = g.shift1[r], mu1 = g.mean1[r], iv1 = g.inv1[r];
-    // term 1 of dL/da1: B fragments of Qm, k slot (h,j) of step s <-> mid' = row(8s+j,h)
-    Frag<NS> qf[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        float tmp[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tmp[j] = g.qm[acc_row(8 * s + j, h) * SA_C1 + r];
-        qf[s] = make_frag<NS>(tmp);
-    }
-    // term 3: B fragments of W2 with k = output channel in natural order 16 s + 8 h + j
-    Frag<NS> w2tf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        float tmp[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tmp[j] = g.w2[(16 * s + 8 * h + j) * SA_C1 + r];
-        w2tf[s] = make_frag<NS>(tmp);
-    }
     const float ev = g.evec[r];
-
-    Frag<NS> w2f[2][2];
     float d2v[2], e2v[2];
     f32x16 gw2[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float tmp[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) tmp[j] = g.w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
-            w2f[t][s] = make_frag<NS>(tmp);
-        }
         d2v[t] = g.d2[32 * t + r];
         e2v[t] = g.e2[32 * t + r];
 #pragma unroll
@@ -453,11 +484,17 @@ __global__ __launch_bounds__(SA_WAVES * 64, 1) void sa_bwd_kernel(SaArgs a, SaBw
     // wave-private LDS image of the sparse operand: [hi | lo] tiles of 32 rows x 72 bf16
     // (64 channels + 8 pad: 144-byte rows keep the 16-byte fragment reads conflict-free)
     constexpr int SP_ROW = 72, SP_TILE = 32 * SP_ROW;
-    __shared__ __attribute__((aligned(16))) __bf16 sp_lds[SA_WAVES][NS * SP_TILE];
-    __bf16 *sp_img = sp_lds[wave];
+    constexpr int SP_BYTES = SA_WAVES * NS * SP_TILE * 2, WRED_BYTES = SA_WAVES * SA_C2 * SA_C1 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char sp_raw[SP_BYTES > WRED_BYTES ? SP_BYTES : WRED_BYTES];
+    __bf16 *sp_img = reinterpret_cast<__bf16 *>(sp_raw) + wave * NS * SP_TILE;
     for (int e = lane; e < NS * SP_TILE; e += 64) sp_img[e] = (__bf16)0.0f;
+    __syncthreads();
 
     for_each_tile<NS>(a, wave, r, h, [&](int tile, const TileRaw<NS> &raw) {
+        // the constant fragments are READ PER USE: an opaque copy of the lane id keeps the
+        // compiler from hoisting these loop-invariant LDS reads back into ~130 registers
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
         Frag<NS> x[3];
         float deff[3];
         build_frags<NS>(a, raw, h, x, deff);
@@ -466,12 +503,22 @@ __global__ __launch_bounds__(SA_WAVES * 64, 1) void sa_bwd_kernel(SaArgs a, SaBw
         f32x16 yT = {0}, y1 = {0};
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            yT = mfma<NS>(w1f[s], x[s], yT);   // lane = position, register = mid channel
-            y1 = mfma<NS>(x[s], w1f[s], y1);   // lane = mid channel, register = position
+            const Frag<NS> w = get_frag<NS>(cfrag, F_W1 + s, lane_o);
+            yT = mfma<NS>(w, x[s], yT);   // lane = position, register = mid channel
+            y1 = mfma<NS>(x[s], w, y1);   // lane = mid channel, register = position
         }
+        {
+            const float4 *scv = reinterpret_cast<const float4 *>(bn1v[0][lane_o >> 5]);
+            const float4 *shv = reinterpret_cast<const float4 *>(bn1v[1][lane_o >> 5]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            yT[i] = __builtin_fmaxf(__builtin_fmaf(yT[i], sc1v[i], sh1v[i]), 0.0f);
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const float4 sc = scv[i4], sh = shv[i4];
+                yT[4 * i4] = __builtin_fmaxf(__builtin_fmaf(yT[4 * i4], sc.x, sh.x), 0.0f);
+                yT[4 * i4 + 1] = __builtin_fmaxf(__builtin_fmaf(yT[4 * i4 + 1], sc.y, sh.y), 0.0f);
+                yT[4 * i4 + 2] = __builtin_fmaxf(__builtin_fmaf(yT[4 * i4 + 2], sc.z, sh.z), 0.0f);
+                yT[4 * i4 + 3] = __builtin_fmaxf(__builtin_fmaf(yT[4 * i4 + 3], sc.w, sh.w), 0.0f);
+            }
+        }
         const Frag<NS> a0 = pack8<NS>(yT, 0), a1 = pack8<NS>(yT, 8);
 
         // One-hot-weighted operand of the sparse part, S[pos][c] = goa[c] * [ksel[c] == pos]
@@ -502,10 +549,10 @@ __global__ __launch_bounds__(SA_WAVES * 64, 1) void sa_bwd_kernel(SaArgs a, SaBw
         f32x16 ga;
 #pragma unroll
         for (int i = 0; i < 16; ++i) ga[i] = ev;
-        ga = mfma<NS>(a0, qf[0], ga);
-        ga = mfma<NS>(a1, qf[1], ga);
+        ga = mfma<NS>(a0, get_frag<NS>(cfrag, F_QM, lane_o), ga);
+        ga = mfma<NS>(a1, get_frag<NS>(cfrag, F_QM + 1, lane_o), ga);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ga = mfma<NS>(sp[s], w2tf[s], ga);
+        for (int s = 0; s < 4; ++s) ga = mfma<NS>(sp[s], get_frag<NS>(cfrag, F_W2T + s, lane_o), ga);
 
         f32x16 an;   // a1 in the [lane = mid] layout: B operand of dL/dW2
         float s1 = 0.0f, s2 = 0.0f, hb = 0.0f;
@@ -565,8 +612,8 @@ __global__ __launch_bounds__(SA_WAVES * 64, 1) void sa_bwd_kernel(SaArgs a, SaBw
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 y2 = {0};
-            y2 = mfma<NS>(a0, w2f[t][0], y2);
-            y2 = mfma<NS>(a1, w2f[t][1], y2);
+            y2 = mfma<NS>(a0, get_frag<NS>(cfrag, F_W2 + 2 * t, lane_o), y2);
+            y2 = mfma<NS>(a1, get_frag<NS>(cfrag, F_W2 + 2 * t + 1, lane_o), y2);
             const int c = 32 * t + r;
             const float gsel = g.goa[(size_t)tile * SA_C2 + c];
             const int ksl = g.ksel[(size_t)tile * SA_C2 + c];
@@ -581,7 +628,8 @@ __global__ __launch_bounds__(SA_WAVES * 64, 1) void sa_bwd_kernel(SaArgs a, SaBw
     write_partials<2>(st, part, lane, wave);
     // dL/dW2 of this workgroup, D[row = out row(i,h) + 32 t][col = mid r]: fold the four
     // waves in LDS, then one float atomic per element into the zeroed (64,32) gradient.
-    __shared__ float wred[SA_WAVES][SA_C2 * SA_C1];
+    float (*wred)[SA_C2 * SA_C1] = reinterpret_cast<float (*)[SA_C2 * SA_C1]>(sp_raw);   // images are dead
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -607,7 +655,9 @@ static int sa_grid(int tiles) {
 // constant setup being paid once.
 static int sa_grid_bwd(int tiles) {
     int g = sa_grid(tiles);
-    return g < 256 ? g : 256;
+    static int cap = 0;
+    if (!cap) { const char *e = getenv("APN_SA_GRID_CAP_BWD"); cap = e ? atoi(e) : 256; }
+    return g < cap ? g : cap;
 }
 
 }  // namespace apn
