@@ -288,15 +288,23 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
                                                                       float *__restrict__ part) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    Frag<NS> w1f[3];
-    load_w1_frags<NS>(a.w1, r, h, w1f);
+    __shared__ uint4 cfrag[3 * NS * 64];
+    if (wave == 0) {
+        Frag<NS> w1f[3];
+        load_w1_frags<NS>(a.w1, r, h, w1f);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) put_frag<NS>(cfrag, s, lane, w1f[s]);
+    }
+    __syncthreads();
     float st[2] = {0.0f, 0.0f};
     for_each_tile<NS>(a, wave, r, h, [&](int, const TileRaw<NS> &raw) {
+        int lane_o = lane;                       // see sa_bwd_kernel: fragments are read per use
+        asm volatile("" : "+v"(lane_o));
         Frag<NS> x[3];
         build_frags<NS>(a, raw, h, x);
         f32x16 y = {0};
 #pragma unroll
-        for (int s = 0; s < 3; ++s) y = mfma<NS>(x[s], w1f[s], y);  // Y1: lane = mid channel
+        for (int s = 0; s < 3; ++s) y = mfma<NS>(x[s], get_frag<NS>(cfrag, s, lane_o), y);  // Y1: lane = mid channel
 #pragma unroll
         for (int i = 0; i < 16; ++i) { st[0] += y[i]; st[1] += y[i] * y[i]; }
     });
@@ -313,42 +321,60 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
     unsigned char *__restrict__ ksel, float *__restrict__ part) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    Frag<NS> w1f[3];
-    load_w1_frags<NS>(a.w1, r, h, w1f);
-    // conv2 B fragments: lane (out channel 32 t + r, h), step s, element j <-> mid channel row(8s+j, h)
-    Frag<NS> w2f[2][2];
+    enum { F_W1 = 0, F_W2 = 3, F_COUNT = 7 };
+    __shared__ uint4 cfrag[F_COUNT * NS * 64];
+    __shared__ __attribute__((aligned(16))) float bn1v[2][2][16];   // {scale, shift}[h][register]
+    if (wave == 0) {
+        Frag<NS> w1f[3];
+        load_w1_frags<NS>(a.w1, r, h, w1f);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int s = 0; s < 3; ++s) put_frag<NS>(cfrag, F_W1 + s, lane, w1f[s]);
+        if (lane < 32) {
+            bn1v[0][lane >> 4][lane & 15] = scale1[acc_row(lane & 15, lane >> 4)];
+            bn1v[1][lane >> 4][lane & 15] = shift1[acc_row(lane & 15, lane >> 4)];
+        }
+    }
+    if (wave == 1 || wave == 2) {
+        // conv2 B fragments: lane (out channel 32 t + r, h), step s, element j <-> mid channel row(8s+j, h)
+        const int t = wave - 1;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float tmp[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) tmp[j] = w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
-            w2f[t][s] = make_frag<NS>(tmp);
+            put_frag<NS>(cfrag, F_W2 + 2 * t + s, lane, make_frag<NS>(tmp));
         }
-    float sc1[16], sh1[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        sc1[i] = scale1[acc_row(i, h)];
-        sh1[i] = shift1[acc_row(i, h)];
     }
+    __syncthreads();
     const float sg[2] = {sgn2[r], sgn2[32 + r]};
     float st[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum t0, sum t1, sumsq t0, sumsq t1
 
     for_each_tile<NS>(a, wave, r, h, [&](int tile, const TileRaw<NS> &raw) {
+        int lane_o = lane;                       // see sa_bwd_kernel: fragments are read per use
+        asm volatile("" : "+v"(lane_o));
         Frag<NS> x[3];
         build_frags<NS>(a, raw, h, x);
         f32x16 y1 = {0};
 #pragma unroll
-        for (int s = 0; s < 3; ++s) y1 = mfma<NS>(w1f[s], x[s], y1);  // Y1^T: lane = position
+        for (int s = 0; s < 3; ++s) y1 = mfma<NS>(get_frag<NS>(cfrag, F_W1 + s, lane_o), x[s], y1);  // Y1^T: lane = position
+        {
+            const float4 *scv = reinterpret_cast<const float4 *>(bn1v[0][lane_o >> 5]);
+            const float4 *shv = reinterpret_cast<const float4 *>(bn1v[1][lane_o >> 5]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) y1[i] = __builtin_fmaxf(__builtin_fmaf(y1[i], sc1[i], sh1[i]), 0.0f);
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const float4 sc = scv[i4], sh = shv[i4];
+                y1[4 * i4] = __builtin_fmaxf(__builtin_fmaf(y1[4 * i4], sc.x, sh.x), 0.0f);
+                y1[4 * i4 + 1] = __builtin_fmaxf(__builtin_fmaf(y1[4 * i4 + 1], sc.y, sh.y), 0.0f);
+                y1[4 * i4 + 2] = __builtin_fmaxf(__builtin_fmaf(y1[4 * i4 + 2], sc.z, sh.z), 0.0f);
+                y1[4 * i4 + 3] = __builtin_fmaxf(__builtin_fmaf(y1[4 * i4 + 3], sc.w, sh.w), 0.0f);
+            }
+        }
         const Frag<NS> a0 = pack8<NS>(y1, 0), a1 = pack8<NS>(y1, 8);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 y2 = {0};
-            y2 = mfma<NS>(a0, w2f[t][0], y2);  // Y2: lane = out channel 32 t + r, register = position
-            y2 = mfma<NS>(a1, w2f[t][1], y2);
+            y2 = mfma<NS>(a0, get_frag<NS>(cfrag, F_W2 + 2 * t, lane_o), y2);  // Y2: lane = out channel 32 t + r, register = position
+            y2 = mfma<NS>(a1, get_frag<NS>(cfrag, F_W2 + 2 * t + 1, lane_o), y2);
             float best = sg[t] * y2[0];
             int bpos = 0;
             float s1 = 0.0f, s2 = 0.0f;
@@ -650,14 +676,11 @@ static int sa_grid(int tiles) {
     return g < 512 ? (g < 1 ? 1 : g) : 512;
 }
 
-// The backward pass holds one wave per SIMD (register file): one workgroup per CU in a single
-// round beats two rounds of half the length (57 vs 64 us at B*M = 16384), the per-wave
-// constant setup being paid once.
+// The backward pass: one workgroup per CU.  Two per CU fit and run the kernel alone ~8 % faster,
+// but they slow the index stage running beside it (bench.py's pipeline) by more than that.
 static int sa_grid_bwd(int tiles) {
     int g = sa_grid(tiles);
-    static int cap = 0;
-    if (!cap) { const char *e = getenv("APN_SA_GRID_CAP_BWD"); cap = e ? atoi(e) : 256; }
-    return g < cap ? g : cap;
+    return g < 256 ? g : 256;
 }
 
 }  // namespace apn
