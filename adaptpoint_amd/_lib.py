@@ -60,6 +60,7 @@ SIGNATURES = {
                             + [_c_double] + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p]
                             + [ctypes.c_size_t]
                             + [_c_void_p] * 28),
+    "apn_sa_sample_overlap": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 7,
     "apn_sa_sample_seq": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 6,
 }
 

@@ -19,89 +19,19 @@
 // scan stops once nsample hits are stored; a query with no hit writes nothing
 // (its row keeps the caller's zeros, group.py:194).
 #include "apn_common.h"
+#include "ball_query_body.h"
 
 namespace apn {
 
 constexpr int BQ_WAVES = 4;                // waves per workgroup
-constexpr int BQ_CHUNK = 4096;             // support points staged per LDS pass (48 KiB)
 
-// Grid: (ceil(M / queries_per_block), B).  Each wave owns queries
-// q0 + wave, q0 + wave + BQ_WAVES, ... of its block's tile.
+// Grid: (ceil(M / queries_per_block), B).
 __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
     int n, int m, float radius2, int nsample, int q_per_block, int zero_empty,
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, int *__restrict__ idx) {
-    // Dynamic LDS: three coordinate planes of `chunk` floats, then per query of
-    // the tile its hit count so far and its first hit.
     extern __shared__ float s_dyn[];
-    const int chunk = min(n, BQ_CHUNK);
-    float *sx = s_dyn, *sy = s_dyn + chunk, *sz = s_dyn + 2 * chunk;
-    int *s_cnt = reinterpret_cast<int *>(s_dyn + 3 * chunk);
-
-    const int cloud = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q_begin = blockIdx.x * q_per_block;
-    const int q_end = min(q_begin + q_per_block, m);
-
-    xyz += (size_t)cloud * n * 3;
-    new_xyz += (size_t)cloud * m * 3;
-    idx += (size_t)cloud * m * nsample;
-
-    int *cnt_of = s_cnt;
-    int *first_of = s_cnt + q_per_block;
-    for (int i = tid; i < q_per_block; i += BQ_WAVES * 64) { cnt_of[i] = 0; first_of[i] = 0; }
-
-    for (int base = 0; base < n; base += BQ_CHUNK) {
-        const int len = min(BQ_CHUNK, n - base);
-        __syncthreads();  // previous pass done with the planes (and cnt init visible)
-        // Coalesced staging: the chunk is 3*len consecutive floats.
-        for (int i = tid; i < 3 * len; i += BQ_WAVES * 64) {
-            const float v = xyz[(size_t)base * 3 + i];
-            const int p = i / 3, c = i - p * 3;
-            (c == 0 ? sx : c == 1 ? sy : sz)[p] = v;
-        }
-        __syncthreads();
-
-        for (int q = q_begin + wave; q < q_end; q += BQ_WAVES) {
-            const int ql = q - q_begin;
-            int cnt = __builtin_amdgcn_readfirstlane(cnt_of[ql]);  // wave-uniform
-            if (cnt >= nsample) continue;
-            int first = __builtin_amdgcn_readfirstlane(first_of[ql]);
-            const float qx = new_xyz[q * 3 + 0];
-            const float qy = new_xyz[q * 3 + 1];
-            const float qz = new_xyz[q * 3 + 2];
-            int *row = idx + (size_t)q * nsample;
-            for (int k0 = 0; k0 < len && cnt < nsample; k0 += 64) {
-                const int k = k0 + lane;
-                bool hit = false;
-                if (k < len) {
-                    const float d2 = dist2(qx - sx[k], qy - sy[k], qz - sz[k]);
-                    hit = d2 < radius2;
-                }
-                const unsigned long long mask = __ballot(hit);
-                if (mask == 0ull) continue;
-                if (cnt == 0) first = base + k0 + (int)__builtin_ctzll(mask);
-                const int slot = cnt + (int)__builtin_amdgcn_mbcnt_hi(
-                                           (unsigned)(mask >> 32),
-                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (hit && slot < nsample) row[slot] = base + k;
-                cnt += (int)__builtin_popcountll(mask);
-            }
-            if (lane == 0) { cnt_of[ql] = cnt; first_of[ql] = first; }
-        }
-    }
-
-    // Tail of each row: slots the scan never reached repeat the first hit
-    // (ball_query_gpu.cu:41-45).  Rows of empty balls stay untouched.
-    for (int q = q_begin + wave; q < q_end; q += BQ_WAVES) {
-        const int ql = q - q_begin;
-        const int cnt = __builtin_amdgcn_readfirstlane(cnt_of[ql]);
-        if ((cnt == 0 && !zero_empty) || cnt >= nsample) continue;
-        const int first = __builtin_amdgcn_readfirstlane(first_of[ql]);   // 0 for an empty ball
-        int *row = idx + (size_t)q * nsample;
-        for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;
-    }
+    ball_query_body<BQ_WAVES>(n, m, radius2, nsample, q_per_block, zero_empty, new_xyz, xyz, idx,
+                              blockIdx.y, blockIdx.x, s_dyn);
 }
 
 }  // namespace apn

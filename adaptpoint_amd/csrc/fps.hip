@@ -27,6 +27,7 @@
 // wins" -- which ballot + find-first-set gives for free at every level --
 // reproduces the reference order exactly, with no key compares in the loop.
 #include "apn_common.h"
+#include "ball_query_body.h"
 
 #include <cmath>
 
@@ -225,15 +226,14 @@ __global__ __launch_bounds__(W * 64) void fps_reg_kernel(FpsOrder o, int m,
 // barrier j-1 proved that every wave finished reading it and before barrier j lets
 // anyone use it again.
 template <int W, int S>
-__global__ __launch_bounds__(W * 64) void fps_atomic_kernel(FpsOrder o, int m,
-                                                            const float *__restrict__ xyz,
-                                                            float *__restrict__ temp,
-                                                            int *__restrict__ idxs,
-                                                            float *__restrict__ new_xyz) {
-    extern __shared__ float4 tab[];            // [n] {x, y, z, id} by priority rank
+__device__ __forceinline__ void fps_atomic_body(const FpsOrder &o, int m,
+                                                const float *__restrict__ xyz,
+                                                float *__restrict__ temp,
+                                                int *__restrict__ idxs,
+                                                float *__restrict__ new_xyz, int cloud,
+                                                float4 *tab /* LDS [n] {x, y, z, id} by priority rank */) {
     __shared__ unsigned long long slot[3];
     const int n = o.n;
-    const int cloud = blockIdx.x;
     xyz += (size_t)cloud * n * 3;
     if (temp) temp += (size_t)cloud * n;   // null: start from 1e10 everywhere, no write-back
     idxs += (size_t)cloud * m;
@@ -311,6 +311,44 @@ __global__ __launch_bounds__(W * 64) void fps_atomic_kernel(FpsOrder o, int m,
     for (int s = 0; s < S; ++s) {
         const int q = tid * S + s;
         if (temp && q < n) temp[__float_as_int(tab[q].w)] = __uint_as_float(dmin[s]);
+    }
+}
+
+template <int W, int S>
+__global__ __launch_bounds__(W * 64) void fps_atomic_kernel(FpsOrder o, int m,
+                                                            const float *__restrict__ xyz,
+                                                            float *__restrict__ temp,
+                                                            int *__restrict__ idxs,
+                                                            float *__restrict__ new_xyz) {
+    extern __shared__ float4 tab[];
+    fps_atomic_body<W, S>(o, m, xyz, temp, idxs, new_xyz, blockIdx.x, tab);
+}
+
+// The index stage of the fused set-abstraction block as ONE launch with two roles: workgroups
+// [0, b_fps) run farthest point sampling of one batch (one cloud each, ~160 us of dependent
+// steps on b_fps CUs), the rest run the ball query of ANOTHER batch whose samples already exist
+// (~20 us on the other CUs).  Back to back on one queue the two kernels cost their sum; here
+// the search hides inside the sampler's latency.  Workgroups are dispatched in index order, so
+// the samplers start first.
+struct BallArgs {
+    int b, n, m, nsample, q_per_block, blocks_x;
+    float radius2;
+    const float *new_xyz, *xyz;
+    int *idx;
+};
+
+template <int S>
+__global__ __launch_bounds__(512) void fps_ball_kernel(FpsOrder o, int b_fps, int m,
+                                                       const float *__restrict__ xyz,
+                                                       int *__restrict__ idxs,
+                                                       float *__restrict__ new_xyz, BallArgs q) {
+    extern __shared__ float4 dyn4[];
+    if ((int)blockIdx.x < b_fps) {
+        fps_atomic_body<8, S>(o, m, xyz, nullptr, idxs, new_xyz, blockIdx.x, dyn4);
+    } else {
+        const int t = blockIdx.x - b_fps;
+        ball_query_body<8>(q.n, q.m, q.radius2, q.nsample, q.q_per_block, 1, q.new_xyz, q.xyz, q.idx,
+                           t / q.blocks_x, t % q.blocks_x, reinterpret_cast<float *>(dyn4));
     }
 }
 
@@ -522,16 +560,8 @@ extern "C" int apn_fps_set_waves(int waves) {
     return APN_OK;
 }
 
-static int fps_impl(int b, int n, int m, const float *xyz, float *temp, int *idxs, float *new_xyz,
-                    void *stream) {
-    using namespace apn;
-    if (b < 0) return APN_EINVAL;
-    if (b == 0 || m <= 0) return APN_OK;  // sampling_gpu.cu:110
-    if (n <= 0 || !xyz || !idxs) return APN_EINVAL;
-    if (!temp && (!new_xyz || n > 16384)) return APN_EINVAL;   // only the _xyz entry may omit temp
-    hipStream_t st = (hipStream_t)stream;
-
-    FpsOrder o;
+static apn::FpsOrder fps_order(int n) {
+    apn::FpsOrder o;
     o.n = n;
     {   // cuda_utils.h:10-14, same double arithmetic
         const int pow_2 = (int)(std::log((double)n) / std::log(2.0));
@@ -544,6 +574,19 @@ static int fps_impl(int b, int n, int m, const float *xyz, float *temp, int *idx
     while ((1 << o.L) < o.bs) ++o.L;
     o.full = n / o.bs;
     o.rem = n % o.bs;
+    return o;
+}
+
+static int fps_impl(int b, int n, int m, const float *xyz, float *temp, int *idxs, float *new_xyz,
+                    void *stream) {
+    using namespace apn;
+    if (b < 0) return APN_EINVAL;
+    if (b == 0 || m <= 0) return APN_OK;  // sampling_gpu.cu:110
+    if (n <= 0 || !xyz || !idxs) return APN_EINVAL;
+    if (!temp && (!new_xyz || n > 16384)) return APN_EINVAL;   // only the _xyz entry may omit temp
+    hipStream_t st = (hipStream_t)stream;
+
+    const FpsOrder o = fps_order(n);
 
     if (n > 16384) {
         hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(o.bs), 0, st, o, m, xyz, temp, idxs);
@@ -573,6 +616,53 @@ extern "C" int apn_furthest_point_sampling_xyz(int b, int n, int m, const float 
                                                int *idxs, float *new_xyz, void *stream) {
     if (n > 16384 || !new_xyz) return APN_EINVAL;
     return fps_impl(b, n, m, xyz, temp, idxs, new_xyz, stream);
+}
+
+// FPS (+ sampled coordinates) of batch A and, in the same launch, the zero-filling ball query of
+// batch B (whose new_xyz_b already exists).  Either half may be absent (xyz_a / xyz_b null).
+// Shapes the fused kernel does not cover fall back to the two launches back to back.
+extern "C" int apn_sa_sample_overlap(int b, int n, int m, float radius, int nsample,
+                                     const float *xyz_a, int *fidx_a, float *new_xyz_a,
+                                     const float *xyz_b, const float *new_xyz_b, int *idx_b,
+                                     void *stream) {
+    using namespace apn;
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0) return APN_EINVAL;
+    if (xyz_a && (!fidx_a || !new_xyz_a)) return APN_EINVAL;
+    if (xyz_b && (!new_xyz_b || !idx_b)) return APN_EINVAL;
+    const int need = (n + 511) / 512;               // slots per lane with 8 waves
+    const bool fusable = xyz_a && xyz_b && n > 512 && n <= 4096 && need <= 8 && g_fps_algo == 0 &&
+                         g_fps_waves_override == 0;
+    if (!fusable) {
+        if (xyz_a)
+            if (int rc = apn_furthest_point_sampling_xyz(b, n, m, xyz_a, nullptr, fidx_a, new_xyz_a, stream))
+                return rc;
+        if (xyz_b) return apn_ball_query_zero(b, n, m, radius, nsample, new_xyz_b, xyz_b, idx_b, stream);
+        return APN_OK;
+    }
+    const FpsOrder o = fps_order(n);
+    BallArgs q;
+    q.b = b; q.n = n; q.m = m; q.nsample = nsample;
+    q.q_per_block = 32;
+    q.blocks_x = (m + q.q_per_block - 1) / q.q_per_block;
+    q.radius2 = radius * radius;                    // ball_query_gpu.cu:29 (float32 product)
+    q.new_xyz = new_xyz_b; q.xyz = xyz_b; q.idx = idx_b;
+    const size_t dyn_fps = sizeof(float4) * (size_t)n;
+    const size_t dyn_bq = sizeof(float) * 3 * (size_t)(n < BQ_CHUNK ? n : BQ_CHUNK) + sizeof(int) * 2 * q.q_per_block;
+    const size_t dyn = dyn_fps > dyn_bq ? dyn_fps : dyn_bq;
+    const dim3 grid(b + b * q.blocks_x);
+    hipStream_t st = (hipStream_t)stream;
+#define APN_FB_CASE(SS)                                                                          \
+    if (need <= SS) {                                                                            \
+        hipLaunchKernelGGL((fps_ball_kernel<SS>), grid, dim3(512), dyn, st, o, b, m, xyz_a, fidx_a, \
+                           new_xyz_a, q);                                                        \
+        APN_LAUNCH_CHECK();                                                                      \
+        return APN_OK;                                                                           \
+    }
+    APN_FB_CASE(2)
+    APN_FB_CASE(4)
+    APN_FB_CASE(8)
+#undef APN_FB_CASE
+    return APN_EINVAL;
 }
 
 // Diagnostic only (see fps_stamp_kernel): n must be 1024; dbg receives 6 cycle sums.

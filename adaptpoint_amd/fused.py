@@ -412,6 +412,32 @@ def sample_and_query(p, npoint, radius, nsample=K_NS, out=None):
     return smp
 
 
+@torch.no_grad()
+def sample_and_query_many(ps, npoint, radius, nsample=K_NS, outs=None):
+    """Index stages of consecutive batches `ps` (each (B,N,3)) on the current stream, overlapped:
+    the FPS of batch i shares its launch with the ball query of batch i-1 (which needs ~1/8 of
+    the sampler's time on the CUs the sampler leaves idle), so a batch costs one FPS, not
+    FPS + ball query.  Returns the list of `Sampling`."""
+    ps = [p.contiguous() for p in ps]
+    B, N, _ = ps[0].shape
+    dev = ps[0].device
+    if outs is None:
+        outs = [Sampling(B, npoint, nsample, dev) for _ in ps]
+    assert len(outs) == len(ps) and all(o.shape == (B, npoint, nsample) for o in outs)
+    call = _Launcher(dev)
+    for i in range(len(ps) + 1):
+        a = i if i < len(ps) else None               # sampler role
+        b = i - 1 if i >= 1 else None                # search role
+        call("apn_sa_sample_overlap", B, N, npoint, float(radius), nsample,
+             ps[a].data_ptr() if a is not None else None,
+             outs[a].fidx.data_ptr() if a is not None else None,
+             outs[a].new_p.data_ptr() if a is not None else None,
+             ps[b].data_ptr() if b is not None else None,
+             outs[b].new_p.data_ptr() if b is not None else None,
+             outs[b].idx.data_ptr() if b is not None else None)
+    return outs
+
+
 class _SetAbstraction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, f, w1, g1, b1, w2, g2, b2, ws, bs, mods):

@@ -121,6 +121,13 @@ class SetAbstraction(nn.Module):
         return fused.sample_and_query(p, p.shape[1] // self.stride, self.grouper.radius,
                                       self.grouper.nsample, out=out)
 
+    def sample_many(self, ps, outs=None):
+        """Index stages of several batches, FPS of one sharing its launch with the ball query of
+        the previous one (adaptpoint_amd.fused.sample_and_query_many)."""
+        from . import fused
+        return fused.sample_and_query_many(ps, ps[0].shape[1] // self.stride, self.grouper.radius,
+                                           self.grouper.nsample, outs=outs)
+
     def _fused_block(self, p, f, sampling=None):
         """The whole block (FPS, ball query, grouped MLP, pool, skip, ReLU) through
         adaptpoint_amd.fused, or None when the configuration / shapes are not covered."""

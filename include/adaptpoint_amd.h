@@ -271,6 +271,14 @@ APN_API int apn_sa_backward_seq(
     const double *sumsT, float *d2e2, float *qm, float *evec, float *cabc, float *HA, float *HB,
     float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_g1, float *g_b1, float *g_g2,
     float *g_b2, float *g_ws, float *g_bs, void *stream);
+/* Index stages of consecutive batches, overlapped: FPS (+ sampled coordinates) of batch A and,
+ * in the SAME launch, the zero-filling ball query of batch B, whose new_xyz_b an earlier call
+ * produced (csrc/fps.hip: fps_ball_kernel; 512 < n <= 4096, else the two launches back to
+ * back).  Either half may be absent: xyz_a == NULL or xyz_b == NULL. */
+APN_API int apn_sa_sample_overlap(int b, int n, int m, float radius, int nsample,
+                                  const float *xyz_a, int *fidx_a, float *new_xyz_a,
+                                  const float *xyz_b, const float *new_xyz_b, int *idx_b,
+                                  void *stream);
 /* Index stage: temp := 1e10, FPS (+ sampled coordinates), ball query (zero-filling).
  * temp may be NULL (no min-distances kept). */
 APN_API int apn_sa_sample_seq(int b, int n, int m, float radius, int nsample, const float *xyz,

@@ -196,6 +196,26 @@ def test_fused_block_new_p_and_idx_are_exact(dev, oracle):
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(0.15, 32, xyz, far.cpu().numpy()))
 
 
+@pytest.mark.parametrize("B,N,M", [(4, 1024, 512), (3, 1200, 300), (2, 4096, 1024), (2, 512, 128),
+                                   (2, 6000, 64)])
+def test_overlapped_index_stages_are_exact(dev, oracle, B, N, M):
+    """sample_and_query_many: FPS of batch i and ball query of batch i-1 share a launch (fused
+    kernel for 512 < N <= 4096, the two launches back to back otherwise) -- same indices as the
+    oracle, for every batch, including the first and last (single-role launches)."""
+    from adaptpoint_amd.fused import sample_and_query_many
+    clouds = [GI.unit_sphere_cloud(B, N, seed=20 + i) for i in range(3)]
+    clouds[1][:, N // 2:] = clouds[1][:, :1]            # half the points duplicated: ties + empty-ish balls
+    ps = [torch.from_numpy(c).to(dev) for c in clouds]
+    outs = sample_and_query_many(ps, M, 0.15, 32)
+    torch.cuda.synchronize()
+    for c, o in zip(clouds, outs):
+        o_idx = oracle.furthest_point_sampling(c, M)
+        assert np.array_equal(o.fidx.cpu().numpy(), o_idx)
+        q = GI.take_points(c, o_idx)
+        assert np.array_equal(o.new_p.cpu().numpy(), q)
+        assert np.array_equal(o.idx.cpu().numpy(), oracle.ball_query(0.15, 32, c, q))
+
+
 def test_fused_block_eval_mode_and_xyz_grad(dev):
     """eval-mode BatchNorm (running statistics) forward+backward, with gradient flowing to the
     coordinates -- the AdaptPoint feedback path (function_adaptpoint/ganloss_cls.py:31-65)."""
