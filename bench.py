@@ -57,11 +57,12 @@ def make_inputs(batch, seed):
 
 # Algorithmic bytes one launch of each kernel must move (per cloud
 # x the clouds of one launch); see DESIGN.md "Kernels and rooflines".
-def algorithmic_bytes(batch):
+def algorithmic_bytes(batch, fused=True):
     mk = NPOINT * NSAMPLE
     return {
-        # xyz in, temp in+out (the reference's scratch, part of its contract), idx + sampled xyz out
-        "fps": batch * (N_PTS * 12 + 2 * N_PTS * 4 + NPOINT * 4 + NPOINT * 12),
+        # xyz in, idx + sampled xyz out; the drop-in op also reads and writes temp (the reference's
+        # scratch, part of its contract), the fused block's sampler keeps it in registers
+        "fps": batch * (N_PTS * 12 + (0 if fused else 2 * N_PTS * 4) + NPOINT * 4 + NPOINT * 12),
         "ball_query": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4),         # xyz, queries, idx out
         "group_xyz": batch * (3 * N_PTS * 4 + mk * 4 + 3 * mk * 4),        # rows, idx, out
         "group_feat": batch * (C_IN * N_PTS * 4 + mk * 4 + C_IN * mk * 4),
@@ -407,7 +408,7 @@ def main():
 
     total_clouds = B_PER_GPU * world * args.steps
     value = total_clouds / elapsed
-    ab = algorithmic_bytes(B_PER_GPU)
+    ab = algorithmic_bytes(B_PER_GPU, fused=fused_mlp)
     kernels = {}
     for k, us in sorted(per_kernel_us.items()):
         ent = {"avg_us": round(us, 2)}

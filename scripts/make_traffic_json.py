@@ -1,0 +1,31 @@
+"""profiles/r01_traffic.json from the FETCH_SIZE / WRITE_SIZE summary (scripts/pmc_summary.py).
+
+    python scripts/make_traffic_json.py profiles/r01_pmc_fetch_write_summary.csv profiles/r01_traffic.json
+
+HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes): MI355X_MICROARCH.md, section
+HBM -- on gfx950 FETCH_SIZE reports half of the bytes of a coalesced read, WRITE_SIZE is exact.
+"""
+import csv
+import json
+import sys
+
+ALIAS = {"fps_atomic_kernel": "fps", "ball_query_kernel": "ball_query",
+         "sa_prep_features_kernel": "sa_prep_features", "sa_fwd_stats1_kernel": "sa_fwd_stats1",
+         "sa_fwd_main_kernel": "sa_fwd_main", "fwd_out_kernel": "sa_fwd_out",
+         "bwd_prep_kernel": "sa_bwd_prep", "sa_bwd_kernel": "sa_bwd_main",
+         "bwd_point_grads_kernel": "sa_bwd_point_grads", "bwd_finalize_kernel": "sa_bwd_finalize",
+         "bn_fold_kernel": "sa_bn_fold", "bwd_consts1_kernel": "sa_bwd_consts1",
+         "bwd_consts2_kernel": "sa_bwd_consts2"}
+
+out = {}
+for r in csv.DictReader(open(sys.argv[1])):
+    k = ALIAS.get(r["kernel"])
+    if k and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
+        out[k] = int(round((2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024))
+json.dump({"_note": "HBM bytes per launch at B=32 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
+                    "passes, bench.py --steps 20 --warmup 5 --graph off --pipeline off, default bf16x3 "
+                    "precision), averaged over all dispatches of the pass; FETCH_SIZE doubled as "
+                    "MI355X_MICROARCH.md section HBM prescribes for gfx950, WRITE_SIZE taken as is. "
+                    "Summary: profiles/r01_pmc_fetch_write_summary.csv",
+           "bytes_per_launch": out}, open(sys.argv[2], "w"), indent=1)
+print(out)
