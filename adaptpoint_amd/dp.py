@@ -77,14 +77,42 @@ def host_threads(cap=None):
     return max(1, n)
 
 
+def _common_span(tensors):
+    """One 1-D view covering all `tensors` when they are contiguous views of ONE storage packed
+    closely together (the fused block's backward carves every parameter gradient out of a
+    single buffer), else None."""
+    t0 = tensors[0]
+    base = t0.untyped_storage().data_ptr()
+    for t in tensors:
+        if (t.untyped_storage().data_ptr() != base or not t.is_contiguous() or t.dtype != t0.dtype
+                or t.device != t0.device):
+            return None
+    lo = min(t.storage_offset() for t in tensors)
+    hi = max(t.storage_offset() + t.numel() for t in tensors)
+    payload = sum(t.numel() for t in tensors)
+    if hi - lo > 2 * payload + 4096:
+        return None
+    return torch.empty(0, dtype=t0.dtype, device=t0.device).set_(t0.untyped_storage(), lo, (hi - lo,))
+
+
 def allreduce_mean_(tensors):
-    """Average a list of gradient tensors over ranks in place with ONE collective: flatten
-    into a bucket, all-reduce (RCCL over xGMI on ROCm), divide, copy back.  The whole parameter
-    set of a set-abstraction block is ~22 KB, so a single latency-bound message per step is the
-    right shape for point-to-point xGMI links (no bucketing, no overlap machinery)."""
+    """Average a list of gradient tensors over ranks in place with ONE collective (RCCL over
+    xGMI on ROCm).  The whole parameter set of a set-abstraction block is ~22 KB, so a single
+    latency-bound message per step is the right shape for point-to-point xGMI links (no
+    bucketing, no overlap machinery).  Gradients that already share one buffer are reduced in
+    place (no flatten / copy-back launches); otherwise: flatten, all-reduce, copy back."""
     if not dist.is_initialized() or not tensors:
         return
     world = dist.get_world_size()
+    span = _common_span(tensors)
+    if span is not None:
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(span, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(span)
+            if world > 1:
+                span.div_(world)
+        return
     flat = torch.cat([t.reshape(-1) for t in tensors])
     dist.all_reduce(flat)
     if world > 1:

@@ -82,7 +82,14 @@ def _worker(rank, world, port, out_dir):
     CB.run_step(blk2, p, f.detach())
     flat_grads = [q.grad for q in blk2.parameters()]
     dp.allreduce_mean_(flat_grads)
-    torch.save({"elapsed": elapsed, "grads": grads, "flat": [g.clone() for g in flat_grads]},
+    # gradients carved out of ONE buffer (what the fused block's backward produces): reduced in
+    # place, padding between the views included
+    buf = torch.full((300,), float(rank + 1))
+    shared = [buf[0:100].view(10, 10), buf[128:178], buf[192:292].view(4, 25)]
+    assert dp._common_span(shared) is not None and dp._common_span(flat_grads) is None
+    dp.allreduce_mean_(shared)
+    torch.save({"elapsed": elapsed, "grads": grads, "flat": [g.clone() for g in flat_grads],
+                "shared": buf.clone()},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -104,6 +111,8 @@ def test_world2_gloo_shards_and_allreduces(tmp_path):
     want = [(_a + _b) / 2 for _a, _b in zip(_local_grads(dp.shard_seed(0, 0)), _local_grads(dp.shard_seed(0, 1)))]
     for got, w in zip(res[0]["grads"], want):
         np.testing.assert_allclose(got.numpy(), w.numpy(), rtol=1e-4, atol=1e-5)  # f32 sums in a different order
+    for r in range(world):     # mean of (1, 2) over the whole span 0..292, untouched beyond it
+        assert torch.all(res[r]["shared"][:292] == 1.5) and torch.all(res[r]["shared"][292:] == r + 1)
     # the flat-bucket all-reduce leaves the same averaged gradients as DDP, on every rank
     for a, b, w in zip(res[0]["flat"], res[1]["flat"], want):
         assert torch.equal(a, b)
