@@ -60,6 +60,9 @@ SIGNATURES = {
                             + [_c_double] + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p]
                             + [ctypes.c_size_t]
                             + [_c_void_p] * 28),
+    "apn_pointset_group_rows": [_c_int] * 3,
+    "apn_pointset_group_max": [_c_int] * 5 + [_c_void_p] * 8,
+    "apn_pointset_group_max_grad": [_c_int] * 5 + [_c_void_p] * 9,
     "apn_sa_sample_overlap": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 7,
     "apn_sa_sample_seq": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 6,
 }

@@ -284,6 +284,27 @@ APN_API int apn_sa_sample_overlap(int b, int n, int m, float radius, int nsample
 APN_API int apn_sa_sample_seq(int b, int n, int m, float radius, int nsample, const float *xyz,
                               float *temp, int *fidx, float *new_xyz, int *idx, void *stream);
 
+/* ------------------------------------------------------------------------
+ * the grouping stage of the imitator's PointsetGrouper
+ * (openpoints/models_adaptpoint/generator_component4_15.py:394-431, normalize = "anchor"):
+ *   out[b][ch][q] = max_k ( alpha[ch] * (points[b][idx[b][q][k]][ch] - points[b][fidx[b][q]][ch]) + beta[ch] )
+ * without the (B, np, K, C) intermediates.  points (B,N,C) f32 point-major as in the reference,
+ * idx (B,M,K) from apn_ball_query, fidx (B,M) from apn_furthest_point_sampling, alpha/beta [C];
+ * out (B,C,M); ksel (B,M,C) uint8 = position of the (first) maximum, kept for the backward.
+ * C a power of two in 4..1024, K <= 255.
+ * Backward: g_points (B,N,C) += alpha*g at the selected neighbour, -= alpha*g at the anchor
+ * (caller-zeroed, float atomics); part[apn_pointset_group_rows(b, m, c)][2C] = per-workgroup
+ * {sum g*(x_sel - anchor), sum g} = dL/dalpha, dL/dbeta partial rows.
+ * ------------------------------------------------------------------------ */
+APN_API int apn_pointset_group_rows(int b, int m, int c);
+APN_API int apn_pointset_group_max(int b, int n, int m, int c, int k, const float *points,
+                                   const int *idx, const int *fidx, const float *alpha,
+                                   const float *beta, float *out, void *ksel, void *stream);
+APN_API int apn_pointset_group_max_grad(int b, int n, int m, int c, int k, const float *points,
+                                        const int *idx, const int *fidx, const float *alpha,
+                                        const void *ksel, const float *g_out, float *g_points,
+                                        float *part, void *stream);
+
 /* Tuning / diagnostic hook, NOT part of the reference boundary: force the number
  * of wavefronts that cooperate on one cloud in apn_furthest_point_sampling
  * (1, 2, 4, 8 or 16; 0 restores the built-in heuristic).  Results do not depend

@@ -169,3 +169,41 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     lib().apo_three_interpolate_grad(b, c, n, int(m), pg, pi, pw,
                                      gp.ctypes.data_as(ctypes.c_void_p))
     return gp
+
+
+# --- PointsetGrouper's grouping stage (numpy, float32) ---------------
+
+def pointset_group_max(points, idx, fidx, alpha, beta):
+    """points (B,N,C), idx (B,M,K), fidx (B,M), alpha/beta [C] -> (out (B,C,M), ksel (B,M,C) u8).
+    generator_component4_15.py:413 (index_points), :422-427 (anchor normalisation + affine, three
+    separately rounded float32 operations), :429 (max over K; first maximal position)."""
+    points = np.ascontiguousarray(points, dtype=np.float32)
+    idx = np.asarray(idx).astype(np.int64)
+    fidx = np.asarray(fidx).astype(np.int64)
+    al = np.asarray(alpha, dtype=np.float32).reshape(1, 1, 1, -1)
+    be = np.asarray(beta, dtype=np.float32).reshape(1, 1, 1, -1)
+    bi = np.arange(points.shape[0])[:, None, None]
+    grouped = points[bi, idx, :]                                         # (B,M,K,C)
+    mean = points[np.arange(points.shape[0])[:, None], fidx, :][:, :, None, :]
+    grouped = (al * (grouped - mean)).astype(np.float32) + be
+    ksel = grouped.argmax(axis=2).astype(np.uint8)                       # first occurrence
+    return np.ascontiguousarray(grouped.max(axis=2).transpose(0, 2, 1)), ksel
+
+
+def pointset_group_max_grad(points, idx, fidx, alpha, ksel, grad_out):
+    """-> (g_points (B,N,C), g_alpha [C], g_beta [C]) in float64 accumulation."""
+    points = np.asarray(points, dtype=np.float64)
+    B, N, C = points.shape
+    idx = np.asarray(idx).astype(np.int64)
+    fidx = np.asarray(fidx).astype(np.int64)
+    al = np.asarray(alpha, dtype=np.float64).reshape(-1)
+    g = np.asarray(grad_out, dtype=np.float64).transpose(0, 2, 1)        # (B,M,C)
+    sel = np.take_along_axis(idx, np.asarray(ksel).astype(np.int64), axis=2)   # (B,M,C) source point
+    gp = np.zeros((B, N, C))
+    bi = np.arange(B)[:, None, None]
+    ci = np.arange(C)[None, None, :]
+    np.add.at(gp, (bi, sel, ci), g * al)
+    np.add.at(gp, (bi, fidx[:, :, None], ci), -g * al)
+    x_sel = points[bi, sel, ci]
+    anchor = points[np.arange(B)[:, None], fidx, :]
+    return gp, (g * (x_sel - anchor)).sum((0, 1)), g.sum((0, 1))

@@ -296,6 +296,25 @@ def main():
     out["g5_grad_x_checksum"] = np.array([xt.grad.double().sum().item(), xt.grad.double().abs().sum().item()])
     out["g5_grad_stem_w"] = ref_model.encoder.encoder[0][0].convs[0][0].weight.grad.numpy()
 
+    # ---- G6: SURVEY 8(f) row 1 -- the imitator's PointsetGrouper, reference module over oracle ops
+    import openpoints.models_adaptpoint.generator_component4_15 as ref_gen
+    ref_gen.furthest_point_sample = _OracleOps.furthest_point_sample
+    ref_gen.ball_query = _OracleOps.ball_query
+    grouper = ref_gen.PointsetGrouper(channel=64, reduce=2, kneighbors=24, radi=0.2, normalize="anchor")
+    with torch.no_grad():
+        grouper.affine_alpha.copy_(_t(GI.seeded_normal((1, 1, 1, 64), seed=61)))   # both signs
+        grouper.affine_beta.copy_(_t(GI.seeded_normal((1, 1, 1, 64), seed=62)))
+    g6_xyz = _t(GI.unit_sphere_cloud(2, 512, seed=63))
+    g6_pts = _t(GI.seeded_normal((2, 512, 64), seed=64)).requires_grad_(True)
+    g6_newxyz, g6_out = grouper(g6_xyz, g6_pts)
+    g6_w = _t(GI.seeded_normal(tuple(g6_out.shape), seed=65))
+    (g6_out * g6_w).sum().backward()
+    out["g6_pg_new_xyz"] = g6_newxyz.detach().numpy()
+    out["g6_pg_out"] = g6_out.detach().numpy()
+    out["g6_pg_grad_points"] = g6_pts.grad.numpy()
+    out["g6_pg_grad_alpha"] = grouper.affine_alpha.grad.numpy()
+    out["g6_pg_grad_beta"] = grouper.affine_beta.grad.numpy()
+
     path = os.path.join(HERE, "pointnet2_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")

@@ -151,3 +151,24 @@ def test_empty_and_degenerate(oracle):
     assert oracle.furthest_point_sampling(xyz, 0).shape == (1, 0)
     assert np.array_equal(oracle.furthest_point_sampling(xyz, 1), np.zeros((1, 1), np.int32))
     assert (oracle.ball_query(1e-6, 4, xyz, xyz + 5) == 0).all()
+
+
+def test_pointset_group_oracle_reproduces_reference_module(golden, oracle):
+    """oracle FPS + ball query + numpy group-max == the reference's
+    PointsetGrouper (generator_component4_15.py:394-431) run in the build container (G6)."""
+    import golden_inputs as GI
+    xyz = GI.unit_sphere_cloud(2, 512, seed=63)
+    pts = GI.seeded_normal((2, 512, 64), seed=64)
+    alpha = GI.seeded_normal((1, 1, 1, 64), seed=61).reshape(-1)
+    beta = GI.seeded_normal((1, 1, 1, 64), seed=62).reshape(-1)
+    fidx = oracle.furthest_point_sampling(xyz, 256)
+    new_xyz = GI.take_points(xyz, fidx)
+    assert np.array_equal(new_xyz, golden["g6_pg_new_xyz"])
+    idx = oracle.ball_query(0.2, 24, xyz, new_xyz)
+    out, ksel = oracle.pointset_group_max(pts, idx, fidx, alpha, beta)
+    assert np.array_equal(out, golden["g6_pg_out"])
+    w = GI.seeded_normal(tuple(out.shape), seed=65)
+    gp, ga, gb = oracle.pointset_group_max_grad(pts, idx, fidx, alpha, ksel, w)
+    assert np.abs(gp - golden["g6_pg_grad_points"]).max() < 1e-5
+    assert np.abs(ga - golden["g6_pg_grad_alpha"].reshape(-1)).max() < 1e-4
+    assert np.abs(gb - golden["g6_pg_grad_beta"].reshape(-1)).max() < 1e-4
