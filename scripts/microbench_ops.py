@@ -87,8 +87,33 @@ def bench_ops():
     print("three_interp_g %8.1f us" % time_us(lambda: ops.three_interpolate_grad_wrapper(B, 64, N, M, go, i3, w, gm))[0])
 
 
-if __name__ == "__main__" and (len(sys.argv) < 2 or sys.argv[1] in ("fps", "ops")):
-    {"fps": bench_fps, "ops": bench_ops}[sys.argv[1] if len(sys.argv) > 1 else "fps"]()
+def bench_seg():
+    """the segmentation decoder's feature propagation (three_nn +
+    three_interpolate fwd/bwd) at S3DIS level sizes, B=16 clouds of 15000 points."""
+    dev = torch.device("cuda:0")
+    B = 16
+    gen = torch.Generator(dev).manual_seed(0)
+    for n, m, c in [(15000, 3750, 64), (3750, 937, 128), (937, 234, 256), (234, 58, 512)]:
+        u = torch.rand(B, n, 3, device=dev, generator=gen)
+        kn = u[:, ::n // m][:, :m].contiguous()
+        d2 = torch.empty(B, n, 3, device=dev)
+        i3 = torch.empty(B, n, 3, dtype=torch.int32, device=dev)
+        t_nn = time_us(lambda: ops.three_nn_wrapper(B, n, m, u, kn, d2, i3))[0]
+        w = torch.rand(B, n, 3, device=dev)
+        fm = torch.randn(B, c, m, device=dev)
+        o = torch.empty(B, c, n, device=dev)
+        t_i = time_us(lambda: ops.three_interpolate_wrapper(B, c, m, n, fm, i3, w, o))[0]
+        go = torch.randn(B, c, n, device=dev)
+        gm = torch.zeros(B, c, m, device=dev)
+        t_g = time_us(lambda: ops.three_interpolate_grad_wrapper(B, c, n, m, go, i3, w, gm))[0]
+        tests = B * n * m
+        ib = B * (c * m * 4 + n * 24 + c * n * 4)
+        print(f"n={n:6d} m={m:5d} c={c:4d}: three_nn {t_nn:8.1f} us ({tests / t_nn / 1e3:7.1f} G dist/s)  "
+              f"interp {t_i:7.1f} us ({ib / t_i / 1e3:6.0f} GB/s)  interp_grad {t_g:7.1f} us")
+
+
+if __name__ == "__main__" and (len(sys.argv) < 2 or sys.argv[1] in ("fps", "ops", "seg")):
+    {"fps": bench_fps, "ops": bench_ops, "seg": bench_seg}[sys.argv[1] if len(sys.argv) > 1 else "fps"]()
 
 
 def fps_stamps():

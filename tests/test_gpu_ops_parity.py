@@ -307,6 +307,33 @@ def test_three_interpolate_adjoint_large_c(dev, oracle):
                                rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,m,c", [(15000, 3750, 64), (3750, 937, 128)])
+def test_feature_propagation_at_segmentation_sizes(dev, oracle, n, m, c):
+    """the decoder's three_nn + three_interpolate (pointnext.py:173-226,
+    upsampling.py:11-102) at the S3DIS level sizes (15000 -> 3750 -> 937 points per cloud):
+    indices and squared distances exact, interpolation and its gradient to 1e-5."""
+    import pointnet2_batch_cuda as ext
+    b = 2
+    u = GI.seeded_uniform((b, n, 3), seed=700 + n).astype(np.float32)
+    kn = np.ascontiguousarray(u[:, ::n // m][:, :m])            # the known points are a subset, as in a decoder
+    d2 = torch.empty(b, n, 3, device=dev)
+    idx = torch.empty(b, n, 3, dtype=torch.int32, device=dev)
+    ext.three_nn_wrapper(b, n, m, _cu(u, dev), _cu(kn, dev), d2, idx)
+    od2, oidx = oracle.three_nn(u, kn)
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    assert np.array_equal(d2.cpu().numpy(), od2)
+    w = GI.three_nn_weights(od2)
+    f = GI.seeded_normal((b, c, m), seed=71)
+    out = torch.empty(b, c, n, device=dev)
+    ext.three_interpolate_wrapper(b, c, m, n, _cu(f, dev), idx, _cu(w, dev), out)
+    np.testing.assert_allclose(out.cpu().numpy(), oracle.three_interpolate(f, oidx, w), rtol=1e-5, atol=1e-6)
+    g = GI.seeded_normal((b, c, n), seed=72)
+    gp = torch.zeros(b, c, m, device=dev)
+    ext.three_interpolate_grad_wrapper(b, c, n, m, _cu(g, dev), idx, _cu(w, dev), gp)
+    ref = oracle.three_interpolate_grad(g, oidx, w, m)
+    assert np.abs(gp.cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_wrappers_raise_instead_of_exit(dev):
     import pointnet2_batch_cuda as ext
