@@ -68,39 +68,85 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float *__restri
     if (threadIdx.x < ncol) out[threadIdx.x] = s[threadIdx.x];
 }
 
+// Float64 sums over the partial rows of TWO column quads (16-byte column groups qa and qb of a
+// row of `quads` quads), for a workgroup of 256 threads: thread = (row group t >> 1, quad
+// t & 1), four 16-byte loads in flight, then a fixed tree over the 128 row groups
+// (deterministic).  Result: red[0][0..3] = quad qa, red[1][0..3] = quad qb, valid after return.
+// The per-channel folds below are sliced this way -- one workgroup per 4 channels instead of
+// one workgroup pulling every column -- because a lone workgroup reads ~16 KB per microsecond:
+// the whole 128-256 KB row set took 6-8 us, a 16 KB slice takes ~1.
+__device__ __forceinline__ void slice_sum_rows(const float *__restrict__ part, int rows, int quads,
+                                               int qa, int qb, double (*red)[4]) {
+    const int t = threadIdx.x, grp = t >> 1;
+    const float4 *__restrict__ p4 = reinterpret_cast<const float4 *>(part) + ((t & 1) ? qb : qa);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int r = grp;
+    for (; r + 3 * 128 < rows; r += 4 * 128) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = p4[(size_t)(r + 128 * u) * quads];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w;
+        }
+    }
+    for (; r < rows; r += 128) {
+        const float4 v = p4[(size_t)r * quads];
+        s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+    }
+    red[t][0] = s0; red[t][1] = s1; red[t][2] = s2; red[t][3] = s3;
+    __syncthreads();
+    for (int st = 64; st > 0; st >>= 1) {
+        if (grp < st) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[t][j] += red[t + 2 * st][j];
+        }
+        __syncthreads();
+    }
+}
+
 // BatchNorm fold.  {sum[C], sumsq[C]} over `count` positions come as partial rows
 // (part, rows) or as reduced sums.  pack = {scale, shift, mean, invstd}[C].
 // training: batch statistics (biased variance), running buffers updated with the
 // unbiased variance (torch.nn.BatchNorm semantics); otherwise the running buffers.
 // Rider: sgn_out[i] = sign (+1/-1) of ANOTHER BatchNorm's gamma -- which extreme of y2
-// the K-pool keeps.
-__global__ __launch_bounds__(1024) void bn_fold_kernel(
+// the K-pool keeps.  Grid: C/4 workgroups of 256 threads, workgroup b owns channels 4b..4b+3.
+__global__ __launch_bounds__(256) void bn_fold_kernel(
     const float *__restrict__ part, int rows, const double *__restrict__ sums_in, int c, double count,
     const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
     float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ nbt,
     int training, float *__restrict__ pack, const float *__restrict__ sgn_gamma, int sgn_c,
     float *__restrict__ sgn_out) {
-    __shared__ double sums[128];
-    const int i = threadIdx.x;
+    __shared__ double red[256][4];
+    const int t = threadIdx.x, i = blockIdx.x * 4 + t;          // i: this thread's channel (t < 4)
     // everything this thread will need from memory is requested BEFORE the row sums, so that
-    // its latency hides behind them (a lone workgroup: nothing else would)
+    // its latency hides behind them
     float g32 = 1.0f, b32 = 0.0f, rm = 0.0f, rv = 1.0f;
-    if (i < c) {
+    if (t < 4) {
         if (gamma) g32 = gamma[i];
         if (beta) b32 = beta[i];
         if (running_mean) { rm = running_mean[i]; rv = running_var[i]; }
     }
-    long long nb = (i == 0 && training && nbt) ? *nbt : 0;
-    float sg = 1.0f;
-    if (sgn_out && i < sgn_c && sgn_gamma) sg = sgn_gamma[i];
-    if (training) block_sum_rows(part, rows, 2 * c, sums_in, sums);
-    if (i == 0 && training && nbt) *nbt = nb + 1;
-    if (sgn_out && i < sgn_c) sgn_out[i] = sg >= 0.0f ? 1.0f : -1.0f;
-    if (i >= c) return;
+    if (blockIdx.x == 0) {
+        if (t == 0 && training && nbt) *nbt += 1;
+        if (sgn_out)
+            for (int k = t; k < sgn_c; k += 256) sgn_out[k] = (!sgn_gamma || sgn_gamma[k] >= 0.0f) ? 1.0f : -1.0f;
+    }
+    double sum = 0.0, sumsq = 0.0;
+    if (training) {
+        if (part) {
+            slice_sum_rows(part, rows, c / 2, blockIdx.x, c / 4 + blockIdx.x, red);
+            if (t < 4) { sum = red[0][t]; sumsq = red[1][t]; }
+        } else if (t < 4) {
+            sum = sums_in[i];
+            sumsq = sums_in[c + i];
+        }
+    }
+    if (t >= 4) return;
     double mean, var;
     if (training) {
-        mean = sums[i] / count;
-        var = sums[c + i] / count - mean * mean;
+        mean = sum / count;
+        var = sumsq / count - mean * mean;
         if (var < 0.0) var = 0.0;
         if (running_mean) {
             const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
@@ -366,21 +412,29 @@ __global__ __launch_bounds__(1024) void bwd_consts2_kernel(const float *__restri
 }
 
 // dL/dy1 = g_u*ca + yhat1*cb + cc ; dL/dgamma1 = T2, dL/dbeta1 = T1.
-__global__ __launch_bounds__(1024) void bwd_consts1_kernel(
+__global__ __launch_bounds__(256) void bwd_consts1_kernel(
     const float *__restrict__ partT, int rows, const double *__restrict__ T_in,
     const float *__restrict__ pack1, double count, int training, float *__restrict__ cabc,
     float *__restrict__ g_gamma1, float *__restrict__ g_beta1) {
-    __shared__ double T[64];
-    const int i = threadIdx.x;
-    const float sc32 = i < 32 ? pack1[i] : 0.0f;      // requested before the row sums
-    block_sum_rows(partT, rows, 64, T_in, T);
-    if (i >= 32) return;
+    // grid: 8 workgroups, workgroup b owns mid channels 4b..4b+3 (columns 4b.. and 32+4b..)
+    __shared__ double red[256][4];
+    const int t = threadIdx.x, i = blockIdx.x * 4 + t;
+    const float sc32 = t < 4 ? pack1[i] : 0.0f;      // requested before the row sums
+    double t1 = 0.0, t2 = 0.0;
+    if (partT) {
+        slice_sum_rows(partT, rows, 16, blockIdx.x, 8 + blockIdx.x, red);
+        if (t < 4) { t1 = red[0][t]; t2 = red[1][t]; }
+    } else if (t < 4) {
+        t1 = T_in[i];
+        t2 = T_in[32 + i];
+    }
+    if (t >= 4) return;
     const double sc = sc32;
     cabc[i] = (float)sc;
-    cabc[32 + i] = training ? (float)(-sc * T[32 + i] / count) : 0.0f;
-    cabc[64 + i] = training ? (float)(-sc * T[i] / count) : 0.0f;
-    if (g_gamma1) g_gamma1[i] = (float)T[32 + i];
-    if (g_beta1) g_beta1[i] = (float)T[i];
+    cabc[32 + i] = training ? (float)(-sc * t2 / count) : 0.0f;
+    cabc[64 + i] = training ? (float)(-sc * t1 / count) : 0.0f;
+    if (g_gamma1) g_gamma1[i] = (float)t2;
+    if (g_beta1) g_beta1[i] = (float)t1;
 }
 
 // Everything downstream of dL/dy1 = g_u*ca + yhat1*cb + cc, which is only ever needed summed
@@ -621,7 +675,8 @@ extern "C" int apn_sa_bn_fold(const float *part, int rows, const double *sums, i
     if ((c != 32 && c != 64) || !pack || sgn_c > 1024) return APN_EINVAL;
     if (training && !part && !sums) return APN_EINVAL;
     if (!training && (!running_mean || !running_var)) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::bn_fold_kernel, dim3(1), dim3(1024), 0, APN_ST, part, rows, sums, c, count,
+    if (part && ((uintptr_t)part & 15)) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::bn_fold_kernel, dim3(c / 4), dim3(256), 0, APN_ST, part, rows, sums, c, count,
                        gamma, beta, eps, momentum, running_mean, running_var,
                        (long long *)num_batches_tracked, training, pack, sgn_gamma, sgn_c, sgn_out);
     APN_LAUNCH_CHECK();
@@ -675,7 +730,8 @@ extern "C" int apn_sa_bwd_consts1(const float *partT, int rows, const double *T,
                                   double count, int training, float *cabc, float *g_gamma1,
                                   float *g_beta1, void *stream) {
     if ((!partT && !T) || !pack1 || !cabc) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::bwd_consts1_kernel, dim3(1), dim3(1024), 0, APN_ST, partT, rows, T, pack1,
+    if (partT && ((uintptr_t)partT & 15)) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::bwd_consts1_kernel, dim3(8), dim3(256), 0, APN_ST, partT, rows, T, pack1,
                        count, training, cabc, g_gamma1, g_beta1);
     APN_LAUNCH_CHECK();
     return APN_OK;
