@@ -35,6 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 B_PER_GPU, N_PTS, NPOINT, NSAMPLE, C_IN, C_OUT, RADIUS = 32, 1024, 512, 32, 32, 64, 0.15
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -438,6 +439,22 @@ def main():
         "fps_step_ns": round(fps_us * 1e3 / (NPOINT - 1), 1),
         "kernels": kernels,
     }
+    if fused_mlp and "sa_bwd_main" in per_kernel_us:
+        # The sampler is the longest launch but runs beside the MLP stream, which is the stream
+        # that bounds `value`; that stream's longest kernel is the backward pass (MFMA chain).
+        # Algorithmic flops per position: conv1 in both orientations 2*(2*35*32), dL/da1 =
+        # a1*Qm (2*32*32) + sparse*W2^T (2*64*32), y2 again (2*32*64), dL/dW2 (2*64*32).
+        flops = B_PER_GPU * NPOINT * NSAMPLE * (2 * 2 * 35 * 32 + 2 * 32 * 32 + 3 * 2 * 64 * 32)
+        us = per_kernel_us["sa_bwd_main"]
+        tf = flops / us * 1e-6
+        split = 3 if args.mlp.endswith("x3") else 1
+        roofline["critical_stream_kernel"] = {
+            "kernel": "sa_bwd_main", "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "avg_launch_us": round(us, 2),
+            "algorithmic_flops": flops,
+            "note": (f"every product issued as {split} bf16 MFMA(s): MFMA issue = {split} x this fraction; "
+                     "the kernel is VALU-issue bound (operand splitting, BN/ReLU, scatter), "
+                     "profiles/r01_pmc_sq_summary.csv")}
 
     result = {
         "metric": "set-abstraction fwd+bwd point-clouds/sec (B=32,N=1024)",
