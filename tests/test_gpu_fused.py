@@ -327,3 +327,33 @@ def test_fused_block_odd_sizes(dev, B, N, stride):
     assert _rel_l2(f2.grad, f1.grad) <= 3e-2
     for (k, qa), (_, qb) in zip(a.named_parameters(), b.named_parameters()):
         assert _rel_l2(qb.grad, qa.grad) <= 3e-2, k
+
+
+def test_full_size_batch_is_cloud_independent_in_eval_mode(dev):
+    """BASELINE configs[1] size (B=32, N=1024): with running BatchNorm statistics nothing couples
+    the clouds of a batch, so the fused block on 32 clouds must equal, bit for bit, the same block
+    on any single cloud of the batch -- the property that makes sharding by cloud
+    exact.  Also checks the fused block against the unfused drop-in path at full size."""
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    kw = dict(layers=2, stride=2, group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32,
+                                              'normalize_dp': True},
+              norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+              use_res=True)
+    torch.manual_seed(7)
+    blk = SetAbstraction(32, 64, fused=True, **kw).to(dev)
+    ref = SetAbstraction(32, 64, **kw).to(dev)
+    ref.load_state_dict(blk.state_dict())
+    p = torch.from_numpy(GI.unit_sphere_cloud(32, 1024, seed=40)).to(dev)
+    f = torch.from_numpy(GI.seeded_normal((32, 32, 1024), seed=41)).to(dev)
+    blk.train(); ref.train()
+    with torch.no_grad():                       # one training-mode pass: non-trivial running statistics
+        _, o_train = blk([p, f])
+        _, r_train = ref([p, f])
+    assert (o_train - r_train).abs().max() <= 1e-2 and (o_train - r_train).abs().mean() <= 1e-3
+    blk.eval()
+    with torch.no_grad():
+        new_p, out = blk([p, f])
+        for i in (0, 13, 31):
+            np_i, out_i = blk([p[i:i + 1].contiguous(), f[i:i + 1].contiguous()])
+            assert torch.equal(np_i[0], new_p[i])
+            assert torch.equal(out_i[0], out[i])
