@@ -244,11 +244,14 @@ def main():
     if sync_bn and not fused_mlp:
         blk = torch.nn.SyncBatchNorm.convert_sync_batchnorm(blk)
     model = blk
-    # Gradient exchange.  With SyncBatchNorm the step runs eagerly under DistributedDataParallel
-    # (collectives sit inside forward and backward).  Without it forward+backward contain no
-    # collective, so the step is the same captured hipGraph as at one GPU, followed by ONE
-    # flat-bucket all-reduce of the block's gradients (adaptpoint_amd.dp.allreduce_mean_).
-    use_ddp = distributed and sync_bn
+    # Gradient exchange.  Without SyncBatchNorm forward+backward contain no collective, so the
+    # step is the same captured hipGraph as at one GPU, followed by ONE flat-bucket all-reduce of
+    # the block's gradients (adaptpoint_amd.dp.allreduce_mean_).  With SyncBatchNorm collectives sit
+    # inside forward and backward: the fused block runs eagerly (its four statistics all-reduces
+    # between the launch phases) with the same flat gradient all-reduce; the unfused PyTorch path
+    # runs under DistributedDataParallel with torch.nn.SyncBatchNorm.
+    use_ddp = distributed and sync_bn and not fused_mlp
+    eager_collectives = distributed and sync_bn
     if use_ddp:
         model = torch.nn.parallel.DistributedDataParallel(blk, device_ids=[local_rank],
                                                           output_device=local_rank)
@@ -259,7 +262,7 @@ def main():
 
     # the two-stream pipeline pays only when the step is GPU-bound, i.e. under graph replay
     pipelined = fused_mlp and args.pipeline == "on" and not use_ddp
-    use_graph = (args.graph == "on") or (args.graph == "auto" and not use_ddp)
+    use_graph = ((args.graph == "on") or (args.graph == "auto")) and not eager_collectives
     # steps per graph: several whole steps per replay when no collective sits between steps
     spg = 1
     if use_graph and not distributed and args.steps_per_graph != 1:

@@ -33,8 +33,11 @@ def test_bench_distributed_default_path_world1(dev):
 
 
 def test_bench_distributed_syncbn_path_world1(dev):
-    """--sync-bn on: eager, DistributedDataParallel, phased SyncBatchNorm all-reduces"""
+    """--sync-bn on: eager, phased SyncBatchNorm all-reduces inside the fused block, flat gradient
+    all-reduce; the unfused path (--mlp torch-f32) under DistributedDataParallel"""
     d = _run(["--sync-bn", "on"], 29732)
     assert d["n_gpus"] == 1 and d["value"] > 0
-    assert "syncbn" in d["config"]["parallelism"] and "ddp" in d["config"]["parallelism"]
+    assert "syncbn" in d["config"]["parallelism"] and "flat-allreduce" in d["config"]["parallelism"]
     assert d["config"]["launch"] == "eager"
+    d = _run(["--sync-bn", "on", "--mlp", "torch-f32", "--steps", "10", "--warmup", "2"], 29733)
+    assert "syncbn" in d["config"]["parallelism"] and "ddp" in d["config"]["parallelism"]
