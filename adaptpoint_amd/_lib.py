@@ -60,6 +60,9 @@ SIGNATURES = {
                             + [_c_double] + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p]
                             + [ctypes.c_size_t]
                             + [_c_void_p] * 28),
+    "apn_attention_prep": [_c_int] * 3 + [_c_void_p] * 4 + [_c_int, _c_void_p],
+    "apn_attention_fwd": [_c_int] * 3 + [_c_void_p] * 4,
+    "apn_attention_bwd": [_c_int] * 3 + [_c_void_p] * 9,
     "apn_pointset_group_rows": [_c_int] * 3,
     "apn_pointset_group_max": [_c_int] * 5 + [_c_void_p] * 8,
     "apn_pointset_group_max_grad": [_c_int] * 5 + [_c_void_p] * 9,

@@ -46,61 +46,15 @@
 // + out 2 x 4.2 MB ~ 13 MB (1.6 us at 8 TB/s); bf16 MFMA work 7 x 32 cycles per tile.
 // Both are far below the per-tile VALU/gather latency, which is what bounds it.
 #include "apn_common.h"
+#include "apn_mfma.h"
 
 namespace apn {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int SA_C = 32;     // feature channels in
 constexpr int SA_C1 = 32;    // mid channels
 constexpr int SA_C2 = 64;    // out channels
 constexpr int SA_K = 32;     // neighbours per query = positions per tile
 constexpr int SA_WAVES = 4;  // waves per workgroup
-
-__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
-
-__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// Operand precision.  NS = 1: operands rounded to bf16 (8 significant bits).  NS = 2: every
-// f32 operand is split into hi + lo bf16 parts (16 significant bits) and a product is three
-// MFMAs, hi*hi + hi*lo + lo*hi ("bf16x3"; the dropped lo*lo term is 2^-18 relative): the
-// contraction then agrees with an fp32 one to ~1e-5 at 3x the (small) MFMA cost.
-template <int NS>
-struct Frag {
-    bf16x8 p[NS];
-};
-
-template <int NS>
-__device__ __forceinline__ Frag<NS> make_frag(const float (&v)[8]) {
-    Frag<NS> o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 hi = (__bf16)v[j];
-        o.p[0][j] = hi;
-        if (NS == 2) o.p[NS - 1][j] = (__bf16)(v[j] - (float)hi);
-    }
-    return o;
-}
-
-template <int NS>
-__device__ __forceinline__ Frag<NS> pack8(const f32x16 &v, int base) {
-    float t[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = v[base + j];
-    return make_frag<NS>(t);
-}
-
-template <int NS>
-__device__ __forceinline__ f32x16 mfma(const Frag<NS> &a, const Frag<NS> &b, f32x16 c) {
-    if (NS == 2) {                       // small terms first, the hi*hi term last
-        c = mfma(a.p[NS - 1], b.p[0], c);
-        c = mfma(a.p[0], b.p[NS - 1], c);
-    }
-    return mfma(a.p[0], b.p[0], c);
-}
 
 // Constant operand fragments kept in LDS instead of registers: fragment f of lane l is the
 // 16-byte word [(f * NS + part) * 64 + l] -- one conflict-free ds_read_b128 per use.  The

@@ -305,6 +305,26 @@ APN_API int apn_pointset_group_max_grad(int b, int n, int m, int c, int k, const
                                         const void *ksel, const float *g_out, float *g_points,
                                         float *part, void *stream);
 
+/* ------------------------------------------------------------------------
+ * multi-head self-attention over the M points of a cloud with
+ * head_dim 16 (the imitator's Anchor_selfattention,
+ * openpoints/models_adaptpoint/generator_component4_15.py:467-474) without the (B,H,M,M)
+ * score tensor:  out = softmax(q k^T / 4) v  per head.  q, k, v, out: (B, M, heads*16) f32 (the
+ * layout the reference holds them in before its reshape/permute); M % 32 == 0.
+ * apn_attention_prep writes the bf16 hi|lo operand images into `images`: 3 (forward only) or 6
+ * (for_backward != 0) blocks of b*heads*m*32 bf16 = 64 bytes per point and head each.
+ * apn_attention_fwd also returns lse (B,heads,M), the log2-domain log-sum-exp of every query.
+ * apn_attention_bwd: g_out = dL/d out -> dq, dk, dv (B,M,heads*16); scratch = 2 * b*heads*m*32
+ * bf16 + b*heads*m floats.
+ * ------------------------------------------------------------------------ */
+APN_API int apn_attention_prep(int b, int m, int heads, const float *q, const float *k,
+                               const float *v, void *images, int for_backward, void *stream);
+APN_API int apn_attention_fwd(int b, int m, int heads, const void *images, float *out, float *lse,
+                              void *stream);
+APN_API int apn_attention_bwd(int b, int m, int heads, const void *images, const float *out,
+                              const float *lse, const float *g_out, void *scratch, float *dq,
+                              float *dk, float *dv, void *stream);
+
 /* Tuning / diagnostic hook, NOT part of the reference boundary: force the number
  * of wavefronts that cooperate on one cloud in apn_furthest_point_sampling
  * (1, 2, 4, 8 or 16; 0 restores the built-in heuristic).  Results do not depend

@@ -207,3 +207,38 @@ def pointset_group_max_grad(points, idx, fidx, alpha, ksel, grad_out):
     x_sel = points[bi, sel, ci]
     anchor = points[np.arange(B)[:, None], fidx, :]
     return gp, (g * (x_sel - anchor)).sum((0, 1)), g.sum((0, 1))
+
+
+# --- Anchor_selfattention's core (numpy, float64) ---------------------
+
+def attention(q, k, v, heads):
+    """q, k, v (B,M,heads*d) -> softmax(q k^T / sqrt(d)) v, (B,M,heads*d), in float64.
+    generator_component4_15.py:460-474."""
+    q, k, v = (np.asarray(t, dtype=np.float64) for t in (q, k, v))
+    B, M, C = q.shape
+    d = C // heads
+    qh, kh, vh = (t.reshape(B, M, heads, d).transpose(0, 2, 1, 3) for t in (q, k, v))
+    s = qh @ kh.transpose(0, 1, 3, 2) / np.sqrt(d)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    return (p @ vh).transpose(0, 2, 1, 3).reshape(B, M, C)
+
+
+def attention_grad(q, k, v, heads, grad_out):
+    """-> (dq, dk, dv), float64."""
+    q, k, v, g = (np.asarray(t, dtype=np.float64) for t in (q, k, v, grad_out))
+    B, M, C = q.shape
+    d = C // heads
+    qh, kh, vh, gh = (t.reshape(B, M, heads, d).transpose(0, 2, 1, 3) for t in (q, k, v, g))
+    s = qh @ kh.transpose(0, 1, 3, 2) / np.sqrt(d)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    dv = p.transpose(0, 1, 3, 2) @ gh
+    dp = gh @ vh.transpose(0, 1, 3, 2)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) / np.sqrt(d)
+    dq = ds @ kh
+    dk = ds.transpose(0, 1, 3, 2) @ qh
+    back = lambda t: t.transpose(0, 2, 1, 3).reshape(B, M, C)
+    return back(dq), back(dk), back(dv)

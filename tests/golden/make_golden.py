@@ -315,6 +315,20 @@ def main():
     out["g6_pg_grad_alpha"] = grouper.affine_alpha.grad.numpy()
     out["g6_pg_grad_beta"] = grouper.affine_beta.grad.numpy()
 
+    # ---- G7: SURVEY 8(f) row 2 -- the imitator's Anchor_selfattention (plain PyTorch in the reference)
+    torch.manual_seed(7)
+    att = ref_gen.Anchor_selfattention(dim=64, head_num=4)
+    att.train()
+    for k_, v_ in att.state_dict().items():
+        out["g7_att_state/" + k_] = v_.detach().clone().numpy()
+    g7_x = _t(GI.seeded_normal((2, 64, 64), seed=71)).requires_grad_(True)
+    g7_xyz = _t(GI.unit_sphere_cloud(2, 64, seed=72))
+    g7_out = att(g7_x, g7_xyz)
+    (g7_out * _t(GI.seeded_normal(tuple(g7_out.shape), seed=73))).sum().backward()
+    out["g7_att_out"] = g7_out.detach().numpy()
+    out["g7_att_grad_x"] = g7_x.grad.numpy()
+    out["g7_att_grad_qkv_w"] = att.to_qkv.weight.grad.numpy()
+
     path = os.path.join(HERE, "pointnet2_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")

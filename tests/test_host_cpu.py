@@ -103,3 +103,29 @@ def test_grouper_factory_and_channel_map():
     assert isinstance(create_grouper({'NAME': 'ballquery', 'radius': 0.1, 'nsample': 8}), QueryAndGroup)
     assert isinstance(create_grouper({'NAME': 'ballquery', 'radius': None, 'nsample': None}), GroupAll)
     assert CHANNEL_MAP['dp_fj'](32) == 35
+
+
+def test_anchor_self_attention_mirror_reproduces_reference_on_cpu(golden):
+    """the mirror module with the reference's state_dict equals the reference
+    module (G7).  The product's attention core refuses CPU tensors, so the test substitutes the
+    composition of the reference (`attention._reference`) for it."""
+    import numpy as np
+    import pytest
+    import torch
+    import golden_inputs as GI
+    from adaptpoint_amd import attention as A
+    from adaptpoint_amd.attention import AnchorSelfAttention
+    with pytest.raises(RuntimeError):
+        A.attention(torch.zeros(1, 32, 64), torch.zeros(1, 32, 64), torch.zeros(1, 32, 64), 4)
+    monkey = pytest.MonkeyPatch()
+    monkey.setattr(A, "attention", A._reference)
+    m = AnchorSelfAttention(dim=64, head_num=4)
+    m.load_state_dict({k.split("/", 1)[1]: torch.from_numpy(np.asarray(golden[k]))
+                       for k in golden.files if k.startswith("g7_att_state/")})
+    m.train()
+    x = torch.from_numpy(GI.seeded_normal((2, 64, 64), seed=71)).requires_grad_(True)
+    try:
+        out = m(x, torch.from_numpy(GI.unit_sphere_cloud(2, 64, seed=72)))
+    finally:
+        monkey.undo()
+    np.testing.assert_allclose(out.detach().numpy(), golden["g7_att_out"], rtol=1e-5, atol=1e-6)
