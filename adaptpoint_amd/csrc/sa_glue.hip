@@ -4,8 +4,10 @@
 // sampled points, add, ReLU) and its backward folded in, the per-channel constants of
 // the backward, and the "everything downstream of dL/dy1 is linear" products.  They
 // replace ~150 tiny PyTorch launches per step (and two pathological long-K rocBLAS
-// GEMMs) with a fixed sequence of 8, all graph-capturable: no host reads, no
-// allocation.  Cross-workgroup sums are float64 atomics into caller-zeroed accumulators.
+// GEMMs) with a fixed sequence of 9, all graph-capturable: no host reads, no
+// allocation.  Cross-workgroup sums leave the producers as one partial row per workgroup and
+// are summed in float64, in a fixed order, by the consumer (deterministic; float atomics are
+// used only for the scatters into per-point buffers).
 #include "apn_common.h"
 
 namespace apn {
