@@ -78,8 +78,9 @@ def attention(q, k, v, heads):
 class AnchorSelfAttention(nn.Module):
     """generator_component4_15.py:434-481 (`Anchor_selfattention`)."""
 
-    def __init__(self, dim, head_num):
+    def __init__(self, dim, head_num, fused=True):
         super().__init__()
+        self.fused = fused            # False: the reference's composition (materialised scores), on the GPU
         self.dim = dim
         self.head_num = head_num
         self.head_dim = int(self.dim // self.head_num)
@@ -94,5 +95,8 @@ class AnchorSelfAttention(nn.Module):
         emb = self.pos_embedding(relative_xyz.permute(0, 2, 1)).permute(0, 2, 1)
         q, k, v = self.to_qkv(x).chunk(3, dim=-1)
         q, k, v = q + emb, k + emb, v + emb
-        o = attention(q, k, v, self.head_num)          # raises on CPU tensors: no CPU fallback
+        if self.fused or not x.is_cuda:
+            o = attention(q, k, v, self.head_num)      # raises on CPU tensors: no CPU fallback
+        else:
+            o = _reference(q, k, v, self.head_num)
         return self.res(o.permute(0, 2, 1)).permute(0, 2, 1)

@@ -70,8 +70,9 @@ def group_max_supported(points, k):
 class PointsetGrouper(nn.Module):
     """generator_component4_15.py:368-431."""
 
-    def __init__(self, channel, reduce, kneighbors, radi, normalize="anchor", **kwargs):
+    def __init__(self, channel, reduce, kneighbors, radi, normalize="anchor", fused=True, **kwargs):
         super().__init__()
+        self.fused = fused            # False: the reference's composition (on the GPU) after FPS / ball query
         self.reduce = reduce
         self.kneighbors = kneighbors
         self.radi = radi
@@ -88,7 +89,7 @@ class PointsetGrouper(nn.Module):
         fps_idx = furthest_point_sample(xyz, xyz.shape[1] // self.reduce)               # :406
         new_xyz = torch.gather(xyz, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3))   # :407
         idx = ball_query(self.radi, self.kneighbors, xyz, new_xyz)                       # :412
-        if self.normalize == "anchor" and group_max_supported(points, self.kneighbors):
+        if self.fused and self.normalize == "anchor" and group_max_supported(points, self.kneighbors):
             return new_xyz, group_max(points, idx, fps_idx, self.affine_alpha, self.affine_beta)
         # the other modes, as the reference composes them (:413-429)
         B, N, C = points.shape
