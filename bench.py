@@ -203,8 +203,8 @@ def main():
                          "one, an always-busy sampler only slows the MLP kernels it shares CUs with "
                          "(measured -3 %)")
     ap.add_argument("--steps-per-graph", type=int, default=0,
-                    help="whole steps captured per hipGraph (0 = auto: the largest of 20, 10, 4, 2 dividing --steps "
-                         "and --warmup, single GPU; 1 = one step per replay)")
+                    help="whole steps captured per hipGraph (0 = auto: the largest of 20, 10, 4, 2 dividing --steps, "
+                         "single GPU; warm-up is rounded up to whole replays; 1 = one step per replay)")
     ap.add_argument("--mlp", choices=["fused-bf16x3", "fused-bf16", "torch-f32"], default="fused-bf16x3",
                     help="grouped shared-MLP: fused bf16-MFMA kernels (csrc/sa_fused.hip) with split "
                          "hi+lo operands (fp32-grade, default) or plain bf16 operands, or the unfused "
@@ -267,7 +267,7 @@ def main():
     spg = 1
     if use_graph and not distributed and args.steps_per_graph != 1:
         for cand in ((args.steps_per_graph,) if args.steps_per_graph else (20, 10, 4, 2)):
-            if cand > 1 and args.steps % cand == 0 and args.warmup % cand == 0:
+            if cand > 1 and args.steps % cand == 0:
                 spg = cand
                 break
     if pipelined:
@@ -391,7 +391,8 @@ def main():
 
     # W warm-up steps, barrier + synchronize, K timed steps, barrier + synchronize, MAX over ranks
     # (a replay of an spg-step graph counts as spg steps: exactly args.steps steps are timed)
-    elapsed = dp.timed_steps(step, args.steps // spg, args.warmup // spg, dev)
+    # (warm-up is rounded UP to whole replays: at least args.warmup untimed steps)
+    elapsed = dp.timed_steps(step, args.steps // spg, -(-args.warmup // spg), dev)
     # The timed step issues whole launch sequences (one C call per direction, or one hipGraph),
     # which cannot carry per-kernel events.  The dominant kernel is therefore timed right after
     # the timed region: the same launch, same inputs, same stream, HIP events around it.
