@@ -329,6 +329,24 @@ def main():
     out["g7_att_grad_x"] = g7_x.grad.numpy()
     out["g7_att_grad_qkv_w"] = att.to_qkv.weight.grad.numpy()
 
+    # ---- G8: the imitator's predictor network SAComponent (rows 1, 2 and the 8a operators together)
+    ref_gen.three_nn = _OracleOps.three_nn
+    ref_gen.three_interpolate = _OracleOps._Interp.apply
+    sac = fill_parameters_by_name(ref_gen.SAComponent())
+    assert sum(q.numel() for q in sac.parameters()) == 5998062
+    sac.train()
+    g8_logits = {}
+    sac.fuse_masking.register_forward_hook(lambda mod, inp, outp: g8_logits.__setitem__("v", outp))
+    g8_x = _t(GI.unit_sphere_cloud(2, 512, seed=81))
+    g8_anchor = _t(O.furthest_point_sampling(g8_x.numpy(), 4)).long()
+    torch.manual_seed(0)
+    g8_prob, g8_mask = sac(g8_x, g8_anchor)
+    (g8_prob.sum() + (g8_logits["v"] * _t(GI.seeded_normal(tuple(g8_logits["v"].shape), seed=82))).sum()).backward()
+    out["g8_sac_prob"] = g8_prob.detach().numpy()
+    out["g8_sac_mask_logits"] = g8_logits["v"].detach().permute(0, 2, 1).numpy()
+    out["g8_sac_grad_embed_w"] = sac.embedding.net[0].weight.grad.numpy()
+    out["g8_sac_grad_alpha0"] = sac.pointset_grouper_list[0].affine_alpha.grad.numpy()
+
     path = os.path.join(HERE, "pointnet2_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
