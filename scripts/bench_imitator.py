@@ -38,11 +38,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--graph", action="store_true", help="replay forward+backward from a hipGraph")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     xyz = torch.from_numpy(GI.unit_sphere_cloud(a.batch, a.points, seed=0)).to(dev)
     anchor = furthest_point_sample(xyz, 4).long()                  # AdaptPoint_Augmentor.forward, :150
-    res = {"B": a.batch, "N": a.points, "params": 5998062}
+    res = {"B": a.batch, "N": a.points, "params": 5998062, "launch": "hipGraph replay" if a.graph else "eager"}
     outs = {}
     for name, fused in (("fused", True), ("composed", False)):
         model = fill_parameters_by_name(SAComponent(fused=fused)).to(dev).train()
@@ -52,6 +53,20 @@ def main():
                 q.grad = None
             prob, logits = model(xyz, anchor, return_logits=True)
             (prob.sum() + logits.sum()).backward()
+        if a.graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            for q in model.parameters():
+                q.grad = None
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                prob, logits = model(xyz, anchor, return_logits=True)
+                (prob.sum() + logits.sum()).backward()
+            step = graph.replay
         torch.cuda.reset_peak_memory_stats()
         res[name + "_fwd_bwd_ms"] = round(time_us(step) / 1e3, 3)
         res[name + "_peak_GB"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
