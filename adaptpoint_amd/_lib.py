@@ -44,9 +44,9 @@ SIGNATURES = {
     "apn_sa_bwd_prep_rows": [_c_int] * 2,
     "apn_sa_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] + [_c_int]
                        + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 7,
-    "apn_sa_bwd_consts2": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_double, _c_int] + [_c_void_p] * 7,
+    "apn_sa_bwd_consts2": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_double, _c_int] + [_c_void_p] * 8,
     "apn_sa_bwd_main": [_c_int] * 8 + [_c_float] + [_c_void_p] * 19,
-    "apn_sa_bwd_consts1": [_c_void_p, _c_int] + [_c_void_p] * 2 + [_c_double, _c_int] + [_c_void_p] * 4,
+    "apn_sa_bwd_consts1": [_c_void_p, _c_int] + [_c_void_p] * 2 + [_c_double, _c_int] + [_c_void_p] * 8,
     "apn_sa_bwd_weight_rows": [_c_int] * 2,
     "apn_sa_bwd_point_grads": [_c_int] * 3 + [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 4 + [_c_float]
                               + [_c_void_p] * 5,
@@ -59,7 +59,7 @@ SIGNATURES = {
     "apn_sa_backward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 14 + [_c_int] * 3
                             + [_c_double] + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p]
                             + [ctypes.c_size_t]
-                            + [_c_void_p] * 28),
+                            + [_c_void_p] * 29),
     "apn_attention_prep": [_c_int] * 3 + [_c_void_p] * 4 + [_c_int, _c_void_p],
     "apn_attention_fwd": [_c_int] * 3 + [_c_void_p] * 4,
     "apn_attention_bwd": [_c_int] * 3 + [_c_void_p] * 9,

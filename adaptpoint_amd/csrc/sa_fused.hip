@@ -361,7 +361,7 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
 //     dL/dy2 = goa[q,c] * [pos == ksel[q,c]]  +  y2 * D2[c] + E2[c]
 // (goa = g * gamma2*invstd2; the dense part is BN's mean/variance feedback).  ONE
 // pass re-runs the chain per tile and produces
-//   dL/dW2 (64x32, an MFMA over positions),
+//   dL/dW2's three ingredients (see below),
 //   BN1's reduction terms T1 = sum g_u, T2 = sum g_u * yhat1, g_u = (dL/da1) * [a1 > 0],
 //   A (B,N,32)  = g_u summed per SOURCE POINT (float atomics, de-duplicated),
 //   geo (B,N,4) = {count, sum of relative positions} of each source point's occurrences,
@@ -375,6 +375,14 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
 //   H[q] = ca*HA[q] + cb*HB[q] + cc*K
 // are formed per point / per query by the consumer (sa_glue.hip: bwd_point_grads) once the
 // batch constants exist: no second pass over the positions.
+// dL/dW2[c][mid] = sum_pos dL/dy2[pos][c] a1[pos][mid] does not need y2 at all: with y2 = a1 W2^T,
+//   sum_pos (y2 D2 + E2)[c] a1[mid] = D2[c] (W2 Gram)[c][mid] + E2[c] suma[mid],
+//   Gram = sum_pos a1^T a1 (32x32: ONE MFMA product per tile, both operands the same registers),
+//   suma = sum_pos a1, and the sparse part is goa[q][c] * a1[q, ksel[q][c], :] -- lane c fetches
+//   that row of a1 from the lanes that hold it (ds_bpermute) into 32 exact f32 accumulators.
+// The consumer (sa_glue.hip: bwd_consts1) assembles dL/dW2 from the three.  This replaced the
+// recomputation of y2 and a (64 x 32 x positions) MFMA product: 42 instead of 60 MFMAs and about
+// 30 % fewer vector instructions per tile (no y2 epilogue, no hi/lo split of y2).
 // dL/da1 = dL/dy2 * W2 never needs y2 transposed: the dense part folds to
 // a1 * (W2^T diag(D2) W2) + E2*W2 (a 32x32 matrix Qm and a vector, built by the
 // caller), and the sparse part is a one-hot-weighted (pos x channel) operand built
@@ -385,7 +393,6 @@ struct SaBwdArgs {
     const float *scale1, *shift1, *mean1, *inv1;   // BN1 fold and statistics [32]
     const float *qm;        // (32,32)  W2^T diag(D2) W2, qm[k][mid]
     const float *evec;      // [32]     sum_c E2[c] W2[c][mid]
-    const float *d2, *e2;   // [64]
     const float *goa;       // (B,M,64)
     const unsigned char *ksel;  // (B,M,64)
 };
@@ -394,6 +401,7 @@ template <int NS>
 __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
                                                                float *__restrict__ part,
                                                                float *__restrict__ gw2_acc,
+                                                               float *__restrict__ gram_acc,
                                                                float *__restrict__ A,
                                                                float *__restrict__ geo,
                                                                float *__restrict__ HA,
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // constant fragments, built once per workgroup (wave w builds every fourth) into LDS
-    enum { F_W1 = 0, F_QM = 3, F_W2T = 5, F_W2 = 9, F_COUNT = 13 };
+    enum { F_W1 = 0, F_QM = 3, F_W2T = 5, F_COUNT = 9 };
     __shared__ uint4 cfrag[F_COUNT * NS * 64];
     __shared__ __attribute__((aligned(16))) float bn1v[2][2][16];   // {scale, shift}[h][register]
     {
@@ -435,30 +443,14 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 put_frag<NS>(cfrag, F_W2T + s, lane, make_frag<NS>(tmp));
             }
         }
-        if (wave == 3) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float tmp[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        tmp[j] = g.w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
-                    put_frag<NS>(cfrag, F_W2 + 2 * t + s, lane, make_frag<NS>(tmp));
-                }
-        }
     }
     const float sc1 = g.scale1[r], sh1 = g.shift1[r], mu1 = g.mean1[r], iv1 = g.inv1[r];
     const float ev = g.evec[r];
-    float d2v[2], e2v[2];
-    f32x16 gw2[2];
+    float sacc[32];           // lane c: sparse part of dL/dW2[c][mid], mid = acc_row(i, 0) | acc_row(i, 1)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        d2v[t] = g.d2[32 * t + r];
-        e2v[t] = g.e2[32 * t + r];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) gw2[t][i] = 0.0f;
-    }
+    for (int i = 0; i < 32; ++i) sacc[i] = 0.0f;
+    f32x16 gram = {0};        // sum_pos a1^T a1: row mid' = acc_row(i, h), column mid = r
+    float suma = 0.0f;        // sum_pos a1[pos][mid = r] (this half's positions)
     float st[2] = {0.0f, 0.0f};
 
     // wave-private LDS image of the sparse operand: [hi | lo] tiles of 32 rows x 72 bf16
@@ -508,9 +500,9 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         // zeroes its element again.  LDS executes one wave's instructions in order, so the
         // image needs no barrier; it starts zeroed and is left zeroed.
         Frag<NS> sp[4];
+        const float gv = g.goa[(size_t)tile * SA_C2 + lane];      // lane = out channel c
+        const int kc = g.ksel[(size_t)tile * SA_C2 + lane];
         {
-            const float gv = g.goa[(size_t)tile * SA_C2 + lane];
-            const int kc = g.ksel[(size_t)tile * SA_C2 + lane];
             const __bf16 ghi = (__bf16)gv;
             const __bf16 glo = (__bf16)(gv - (float)ghi);
             __bf16 *cell = sp_img + kc * SP_ROW + lane;
@@ -525,6 +517,17 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             cell[0] = (__bf16)0.0f;
             if (NS == 2) cell[SP_TILE] = (__bf16)0.0f;
         }
+        // sparse part of dL/dW2: lane c adds goa[c] * a1[pos = ksel[c]][:]; that row of a1 sits in
+        // lanes ksel[c] (mids acc_row(i, 0)) and ksel[c] + 32 (mids acc_row(i, 1)), register i
+        {
+            const int src0 = kc << 2, src1 = (kc + 32) << 2;      // ds_bpermute takes byte addresses
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int bits = __float_as_int(yT[i]);
+                sacc[i] = __builtin_fmaf(gv, __int_as_float(__builtin_amdgcn_ds_bpermute(src0, bits)), sacc[i]);
+                sacc[16 + i] = __builtin_fmaf(gv, __int_as_float(__builtin_amdgcn_ds_bpermute(src1, bits)), sacc[16 + i]);
+            }
+        }
         // dL/da1 [lane = mid, register = position]
         f32x16 ga;
 #pragma unroll
@@ -534,13 +537,14 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
 #pragma unroll
         for (int s = 0; s < 4; ++s) ga = mfma<NS>(sp[s], get_frag<NS>(cfrag, F_W2T + s, lane_o), ga);
 
-        f32x16 an;   // a1 in the [lane = mid] layout: B operand of dL/dW2
+        f32x16 an;   // a1 in the [lane = mid] layout: both operands of the Gram product
         float s1 = 0.0f, s2 = 0.0f, hb = 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float u = __builtin_fmaf(y1[i], sc1, sh1);
             const float yhat = (y1[i] - mu1) * iv1;
             an[i] = __builtin_fmaxf(u, 0.0f);
+            suma += an[i];
             ga[i] = u > 0.0f ? ga[i] : 0.0f;   // g_u
             s1 += ga[i];
             s2 += ga[i] * yhat;
@@ -588,39 +592,42 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             }
         }
 
-        const Frag<NS> b0 = pack8<NS>(an, 0), b1 = pack8<NS>(an, 8);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x16 y2 = {0};
-            y2 = mfma<NS>(a0, get_frag<NS>(cfrag, F_W2 + 2 * t, lane_o), y2);
-            y2 = mfma<NS>(a1, get_frag<NS>(cfrag, F_W2 + 2 * t + 1, lane_o), y2);
-            const int c = 32 * t + r;
-            const float gsel = g.goa[(size_t)tile * SA_C2 + c];
-            const int ksl = g.ksel[(size_t)tile * SA_C2 + c];
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                y2[i] = __builtin_fmaf(y2[i], d2v[t], e2v[t]) + (acc_row(i, h) == ksl ? gsel : 0.0f);
-            // dL/dW2[out][mid] += sum_pos dL/dy2[pos][out] * a1[pos][mid]
-            gw2[t] = mfma<NS>(pack8<NS>(y2, 0), b0, gw2[t]);
-            gw2[t] = mfma<NS>(pack8<NS>(y2, 8), b1, gw2[t]);
+        // Gram += a1^T a1: the k index (positions, accumulator-row order) pairs the same registers
+        {
+            const Frag<NS> b0 = pack8<NS>(an, 0), b1 = pack8<NS>(an, 8);
+            gram = mfma<NS>(b0, b0, gram);
+            gram = mfma<NS>(b1, b1, gram);
         }
     });
     write_partials<2>(st, part, lane, wave);
-    // dL/dW2 of this workgroup, D[row = out row(i,h) + 32 t][col = mid r]: fold the four
-    // waves in LDS, then one float atomic per element into the zeroed (64,32) gradient.
+    // The workgroup's three ingredients of dL/dW2: fold the four waves in LDS, then one float atomic
+    // per element into the zeroed accumulators: gw2_acc (64,32) sparse part; gram_acc[0..1023]
+    // Gram[mid'][mid], gram_acc[1024..1055] suma[mid].
     float (*wred)[SA_C2 * SA_C1] = reinterpret_cast<float (*)[SA_C2 * SA_C1]>(sp_raw);   // images are dead
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            wred[wave][(32 * t + acc_row(i, h)) * SA_C1 + r] = gw2[t][i];
+    for (int i = 0; i < 16; ++i) {
+        wred[wave][lane * SA_C1 + acc_row(i, 0)] = sacc[i];
+        wred[wave][lane * SA_C1 + acc_row(i, 1)] = sacc[16 + i];
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < SA_C2 * SA_C1; e += SA_WAVES * 64) {
         float sum = 0.0f;
 #pragma unroll
         for (int w = 0; w < SA_WAVES; ++w) sum += wred[w][e];
         atomicAdd(gw2_acc + e, sum);
+    }
+    __syncthreads();
+    suma += __shfl_xor(suma, 32);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wred[wave][acc_row(i, h) * SA_C1 + r] = gram[i];
+    if (h == 0) wred[wave][SA_C1 * SA_C1 + r] = suma;
+    __syncthreads();
+    for (int e = threadIdx.x; e < SA_C1 * SA_C1 + SA_C1; e += SA_WAVES * 64) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < SA_WAVES; ++w) sum += wred[w][e];
+        atomicAdd(gram_acc + e, sum);
     }
 }
 
@@ -711,13 +718,12 @@ extern "C" int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_o
 }
 
 static apn::SaBwdArgs sa_bwd_args(const float *w2, const float *bn1 /* [4][32]: scale, shift, mean, inv */,
-                                  const float *qm, const float *evec, const float *d2e2 /* [2][64] */,
-                                  const float *goa, const void *ksel) {
+                                  const float *qm, const float *evec, const float *goa,
+                                  const void *ksel) {
     apn::SaBwdArgs g;
     g.w2 = w2;
     g.scale1 = bn1; g.shift1 = bn1 + 32; g.mean1 = bn1 + 64; g.inv1 = bn1 + 96;
     g.qm = qm; g.evec = evec;
-    g.d2 = d2e2; g.e2 = d2e2 + 64;
     g.goa = goa; g.ksel = (const unsigned char *)ksel;
     return g;
 }
@@ -725,23 +731,22 @@ static apn::SaBwdArgs sa_bwd_args(const float *w2, const float *bn1 /* [4][32]: 
 extern "C" int apn_sa_bwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                                int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
                                const int *idx, const float *w1, const float *w2, const float *bn1,
-                               const float *qm, const float *evec, const float *d2e2,
-                               const float *goa, const void *ksel, float *part,
-                               float *gw2_acc, float *A, float *geo, float *HA, float *HB,
-                               void *stream) {
+                               const float *qm, const float *evec, const float *goa,
+                               const void *ksel, float *part, float *gw2_acc, float *gram_acc,
+                               float *A, float *geo, float *HA, float *HB, void *stream) {
     using namespace apn;
     if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
-    if (!w2 || !bn1 || !qm || !evec || !d2e2 || !goa || !ksel || !part || !gw2_acc || !A || !geo ||
+    if (!w2 || !bn1 || !qm || !evec || !goa || !ksel || !part || !gw2_acc || !gram_acc || !A || !geo ||
         !HA || !HB)
         return APN_EINVAL;
     SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius);
-    SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, d2e2, goa, ksel);
+    SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, goa, ksel);
     if (precision == 2)
         hipLaunchKernelGGL((sa_bwd_kernel<2>), dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, g, part, gw2_acc, A, geo, HA, HB);
+                           (hipStream_t)stream, a, g, part, gw2_acc, gram_acc, A, geo, HA, HB);
     else
         hipLaunchKernelGGL((sa_bwd_kernel<1>), dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, g, part, gw2_acc, A, geo, HA, HB);
+                           (hipStream_t)stream, a, g, part, gw2_acc, gram_acc, A, geo, HA, HB);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

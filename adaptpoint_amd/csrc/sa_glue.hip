@@ -371,13 +371,18 @@ __global__ __launch_bounds__(1024) void bwd_consts2_kernel(const float *__restri
                                                            float *__restrict__ evec,
                                                            float *__restrict__ g_gamma2,
                                                            float *__restrict__ g_beta2,
-                                                           float *__restrict__ zero_w2) {
+                                                           float *__restrict__ zero_w2,
+                                                           float *__restrict__ zero_gram) {
     __shared__ double D[64], E[64], S[128];
     __shared__ float sw2[64][33];
     const int t = threadIdx.x;
     if (zero_w2) {   // dL/dW2 (64x32) is accumulated atomically by the backward pass, the next launch
         zero_w2[t] = 0.0f;
         zero_w2[1024 + t] = 0.0f;
+    }
+    if (zero_gram) {   // Gram (32x32) + suma (32), same launch
+        zero_gram[t] = 0.0f;
+        if (t < 32) zero_gram[1024 + t] = 0.0f;
     }
     // operands requested before the row sums: their latency hides behind them
     const float wa = w2[t], wb = w2[1024 + t];
@@ -417,9 +422,19 @@ __global__ __launch_bounds__(1024) void bwd_consts2_kernel(const float *__restri
 __global__ __launch_bounds__(256) void bwd_consts1_kernel(
     const float *__restrict__ partT, int rows, const double *__restrict__ T_in,
     const float *__restrict__ pack1, double count, int training, float *__restrict__ cabc,
-    float *__restrict__ g_gamma1, float *__restrict__ g_beta1) {
+    float *__restrict__ g_gamma1, float *__restrict__ g_beta1, const float *__restrict__ w2,
+    const float *__restrict__ d2e2, const float *__restrict__ gram, float *__restrict__ g_w2) {
     // grid: 8 workgroups, workgroup b owns mid channels 4b..4b+3 (columns 4b.. and 32+4b..)
     __shared__ double red[256][4];
+    if (g_w2) {
+        // dL/dW2[c][mid] = sparse part (already in g_w2) + D2[c] (W2 Gram)[c][mid] + E2[c] suma[mid]
+        // (sa_fused.hip); 8 x 256 threads = the 64 x 32 elements
+        const int e = blockIdx.x * 256 + threadIdx.x, c = e >> 5, mid = e & 31;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) acc += (double)w2[c * 32 + k] * (double)gram[k * 32 + mid];
+        g_w2[e] = (float)((double)g_w2[e] + (double)d2e2[c] * acc + (double)d2e2[64 + c] * (double)gram[1024 + mid]);
+    }
     const int t = threadIdx.x, i = blockIdx.x * 4 + t;
     const float sc32 = t < 4 ? pack1[i] : 0.0f;      // requested before the row sums
     double t1 = 0.0, t2 = 0.0;
@@ -720,21 +735,23 @@ extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long lon
 extern "C" int apn_sa_bwd_consts2(const float *partS, int rows, const double *S, const float *pack2,
                                   const float *w2, double count, int training, float *d2e2,
                                   float *qm, float *evec, float *g_gamma2, float *g_beta2,
-                                  float *zero_w2, void *stream) {
+                                  float *zero_w2, float *zero_gram, void *stream) {
     if ((!partS && !S) || !pack2 || !w2 || !d2e2 || !qm || !evec) return APN_EINVAL;
     hipLaunchKernelGGL(apn::bwd_consts2_kernel, dim3(1), dim3(1024), 0, APN_ST, partS, rows, S, pack2,
-                       w2, count, training, d2e2, qm, evec, g_gamma2, g_beta2, zero_w2);
+                       w2, count, training, d2e2, qm, evec, g_gamma2, g_beta2, zero_w2, zero_gram);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
 extern "C" int apn_sa_bwd_consts1(const float *partT, int rows, const double *T, const float *pack1,
                                   double count, int training, float *cabc, float *g_gamma1,
-                                  float *g_beta1, void *stream) {
+                                  float *g_beta1, const float *w2, const float *d2e2,
+                                  const float *gram, float *g_w2, void *stream) {
     if ((!partT && !T) || !pack1 || !cabc) return APN_EINVAL;
+    if (g_w2 && (!w2 || !d2e2 || !gram)) return APN_EINVAL;
     if (partT && ((uintptr_t)partT & 15)) return APN_EINVAL;
     hipLaunchKernelGGL(apn::bwd_consts1_kernel, dim3(8), dim3(256), 0, APN_ST, partT, rows, T, pack1,
-                       count, training, cabc, g_gamma1, g_beta1);
+                       count, training, cabc, g_gamma1, g_beta1, w2, d2e2, gram, g_w2);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

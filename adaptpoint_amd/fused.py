@@ -230,7 +230,7 @@ def _backward(fw, g_out, need_p, need_newp):
     sizes = zsizes + [("goa", B * M * C_OUT), ("partS", prow * 128),
                       ("partWs", prow * C_OUT * C_IN if has_skip else 0), ("partT", rows * 64),
                       ("partW", wrows * 32 * 38), ("d2e2", 2 * C_OUT), ("qm", C_MID * C_MID),
-                      ("evec", C_MID), ("cabc", 3 * C_MID), ("HA", B * M * C_MID),
+                      ("evec", C_MID), ("cabc", 3 * C_MID), ("gram", C_MID * C_MID + C_MID), ("HA", B * M * C_MID),
                       ("HB", B * M * C_MID)]
     v, buf = _carve(dev, sizes)
     zero_floats = sum((nfl + 63) // 64 * 64 for _, nfl in zsizes)
@@ -253,7 +253,7 @@ def _backward(fw, g_out, need_p, need_newp):
              sv["pack2"].data_ptr(), sv["ysel"].data_ptr(), sv["ksel"].data_ptr(),
              fw.out.data_ptr(), fw.relu, 1 if fw.train1 else 0, 1 if fw.train2 else 0, float(P),
              g_out.data_ptr(), gs[0], gs[1], gs[2], buf.data_ptr(), zero_floats * 4,
-             g["w2"].data_ptr(),
+             g["w2"].data_ptr(), v["gram"].data_ptr(),
              v["A"].data_ptr(), v["geo"].data_ptr(), v["gip"].data_ptr() if has_skip else None,
              v["goa"].data_ptr(),
              v["partS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None,
@@ -324,14 +324,16 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
         call("apn_sa_bwd_consts2", None if sumsS is not None else v["partS"].data_ptr(), prow,
              _ptr(sumsS), sv["pack2"].data_ptr(), w2.data_ptr(), P, 1 if fw.train2 else 0,
              v["d2e2"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr(), g["g2"].data_ptr(),
-             g["b2"].data_ptr(), g["w2"].data_ptr())
-        call("apn_sa_bwd_main", *hdr, v["d2e2"].data_ptr(), v["goa"].data_ptr(),
-             sv["ksel"].data_ptr(), v["partT"].data_ptr(), g["w2"].data_ptr(), v["A"].data_ptr(),
+             g["b2"].data_ptr(), g["w2"].data_ptr(), v["gram"].data_ptr())
+        call("apn_sa_bwd_main", *hdr, v["goa"].data_ptr(),
+             sv["ksel"].data_ptr(), v["partT"].data_ptr(), g["w2"].data_ptr(), v["gram"].data_ptr(),
+             v["A"].data_ptr(),
              v["geo"].data_ptr(), v["HA"].data_ptr(), v["HB"].data_ptr())
     if phases & 4:
         call("apn_sa_bwd_consts1", None if sumsT is not None else v["partT"].data_ptr(), rows,
              _ptr(sumsT), sv["pack1"].data_ptr(), P, 1 if fw.train1 else 0, v["cabc"].data_ptr(),
-             g["g1"].data_ptr(), g["b1"].data_ptr())
+             g["g1"].data_ptr(), g["b1"].data_ptr(), w2.data_ptr(), v["d2e2"].data_ptr(),
+             v["gram"].data_ptr(), g["w2"].data_ptr())
         call("apn_sa_bwd_point_grads", B, N, M, v["A"].data_ptr(), v["geo"].data_ptr(),
              v["HA"].data_ptr(), v["HB"].data_ptr(), v["cabc"].data_ptr(), sv["pack1"].data_ptr(),
              sv["ft"].data_ptr(), fw.prec, sv["p"].data_ptr(), sv["new_p"].data_ptr(), w1.data_ptr(),

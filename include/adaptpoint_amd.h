@@ -201,28 +201,33 @@ APN_API int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long long g
 
 /* Constants of dL/dy2 = goa*[pos==ksel] + y2*D2 + E2: d2e2 [2][64], qm (32,32) =
  * W2^T diag(D2) W2, evec [32] = E2 W2; g_gamma2 = S2, g_beta2 = S1.  Optional zero_w2
- * [64*32] is cleared (the dL/dW2 accumulator of the pass-1 launch that follows). */
+ * [64*32] and zero_gram [32*32 + 32] are cleared (accumulators of the backward pass that follows). */
 APN_API int apn_sa_bwd_consts2(const float *partS, int rows, const double *S, const float *pack2,
                                const float *w2, double count, int training, float *d2e2,
                                float *qm, float *evec, float *g_gamma2, float *g_beta2,
-                               float *zero_w2, void *stream);
+                               float *zero_w2, float *zero_gram, void *stream);
 
 /* The backward pass over the positions -> part[apn_sa_bwd_main_rows(b, m)][64] =
- *   {sum g_u, sum g_u*yhat1}[32] (g_u = dL/da1 * [a1 > 0]); gw2_acc[64*32] += dL/dW2;
+ *   {sum g_u, sum g_u*yhat1}[32] (g_u = dL/da1 * [a1 > 0]); the ingredients of dL/dW2:
+ *   gw2_acc[64*32] += its sparse (arg-max) part, gram_acc[0..1023] += sum a1^T a1,
+ *   gram_acc[1024..1055] += sum a1 (apn_sa_bwd_consts1 assembles dL/dW2 from them);
  *   A (B,N,32) += g_u summed per source point, geo (B,N,4) += {count, sum of relative
  *   positions} of each point's occurrences (both caller-zeroed, float atomics);
  *   HA, HB (B,M,32) = g_u and yhat1 summed per query.  bn1 = pack1 [4][32]. */
 APN_API int apn_sa_bwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                             int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
                             const int *idx, const float *w1, const float *w2, const float *bn1,
-                            const float *qm, const float *evec, const float *d2e2,
-                            const float *goa, const void *ksel, float *part, float *gw2_acc,
+                            const float *qm, const float *evec, const float *goa,
+                            const void *ksel, float *part, float *gw2_acc, float *gram_acc,
                             float *A, float *geo, float *HA, float *HB, void *stream);
 
-/* cabc [3][32]: dL/dy1 = g_u*ca + yhat1*cb + cc ; g_gamma1 = T2, g_beta1 = T1. */
+/* cabc [3][32]: dL/dy1 = g_u*ca + yhat1*cb + cc ; g_gamma1 = T2, g_beta1 = T1.  With g_w2:
+ * g_w2 (64,32) += D2 (W2 Gram) + E2 suma, i.e. dL/dW2 completed from the backward pass's
+ * accumulators (d2e2 from apn_sa_bwd_consts2). */
 APN_API int apn_sa_bwd_consts1(const float *partT, int rows, const double *T, const float *pack1,
                                double count, int training, float *cabc, float *g_gamma1,
-                               float *g_beta1, void *stream);
+                               float *g_beta1, const float *w2, const float *d2e2,
+                               const float *gram, float *g_w2, void *stream);
 
 /* dL/dy1 = g_u*ca + yhat1*cb + cc summed per source point (G) and per query (H), formed from
  * A, geo, HA, HB and the batch constants, and everything linear in them, one workgroup per
@@ -266,7 +271,7 @@ APN_API int apn_sa_backward_seq(
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
-    float *zero_base, size_t zero_bytes, float *g_w2, float *A, float *geo, float *gip,
+    float *zero_base, size_t zero_bytes, float *g_w2, float *gram, float *A, float *geo, float *gip,
     float *goa, float *partS, float *partWs, float *partT, float *partW, const double *sumsS,
     const double *sumsT, float *d2e2, float *qm, float *evec, float *cabc, float *HA, float *HB,
     float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_g1, float *g_b1, float *g_g2,
