@@ -447,8 +447,8 @@ def main():
         # The sampler is the longest launch but runs beside the MLP stream, which is the stream
         # that bounds `value`; that stream's longest kernel is the backward pass (MFMA chain).
         # Algorithmic flops per position: conv1 in both orientations 2*(2*35*32), dL/da1 =
-        # a1*Qm (2*32*32) + sparse*W2^T (2*64*32), y2 again (2*32*64), dL/dW2 (2*64*32).
-        flops = B_PER_GPU * NPOINT * NSAMPLE * (2 * 2 * 35 * 32 + 2 * 32 * 32 + 3 * 2 * 64 * 32)
+        # a1*Qm (2*32*32) + sparse*W2^T (2*64*32), the Gram product a1^T a1 (2*32*32).
+        flops = B_PER_GPU * NPOINT * NSAMPLE * (2 * 2 * 35 * 32 + 2 * 2 * 32 * 32 + 2 * 64 * 32)
         us = per_kernel_us["sa_bwd_main"]
         tf = flops / us * 1e-6
         split = 3 if args.mlp.endswith("x3") else 1
