@@ -1,0 +1,43 @@
+"""bench.py's launch variants on one GPU: every flag combination the design documents must keep
+producing the contract's JSON line (tests/test_gpu_ddp_single.py covers the N>1 code paths)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _bench(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + extra, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra,launch", [
+    (["--steps", "8", "--warmup", "3"], "hipGraph replay, 4 step(s) per graph"),
+    (["--steps", "7", "--warmup", "2"], "hipGraph replay, 1 step(s) per graph"),
+    (["--steps", "8", "--warmup", "2", "--index-overlap", "on"], "hipGraph replay, 4 step(s) per graph"),
+    (["--steps", "6", "--warmup", "2", "--pipeline", "off"], "hipGraph replay, 2 step(s) per graph"),
+    (["--steps", "6", "--warmup", "2", "--graph", "off"], "eager"),
+    (["--steps", "6", "--warmup", "2", "--mlp", "fused-bf16"], "hipGraph replay, 2 step(s) per graph"),
+    (["--steps", "4", "--warmup", "1", "--mlp", "torch-f32"], None),
+])
+def test_bench_variants_emit_the_contract_line(dev, extra, launch):
+    d = _bench(extra)
+    assert KEYS <= set(d) and d["value"] > 0 and d["n_gpus"] == 1 and d["higher_is_better"] is True
+    assert d["steps"] == int(extra[1]) and d["warmup"] == int(extra[3])
+    assert abs(d["ms_per_step"] - 1e3 * 32 / d["value"]) <= 1e-3 * d["ms_per_step"] + 1e-4
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["frac"] >= 0
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["scaling"] == "weak"
+    if launch is not None:
+        assert d["config"]["launch"] == launch
