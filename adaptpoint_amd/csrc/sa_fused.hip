@@ -637,11 +637,14 @@ static int sa_grid(int tiles) {
     return g < 512 ? (g < 1 ? 1 : g) : 512;
 }
 
-// The backward pass: one workgroup per CU.  Two per CU fit and run the kernel alone ~8 % faster,
-// but they slow the index stage running beside it (bench.py's pipeline) by more than that.
+// The backward pass fits two workgroups per CU (241 registers, 57 KB of LDS) and, alone, is
+// fastest with 512; beside the sampler of the other stream (bench.py's pipeline) the best total
+// is 448 -- most CUs doubly occupied, which hides the waits of this latency-bound kernel, with
+// some room left on the CUs the sampler lives on (256 / 448 / 512 workgroups: 161.5k / 166.5k /
+// 153k clouds/s, five interleaved runs each).
 static int sa_grid_bwd(int tiles) {
     int g = sa_grid(tiles);
-    return g < 256 ? g : 256;
+    return g < 448 ? g : 448;
 }
 
 }  // namespace apn
