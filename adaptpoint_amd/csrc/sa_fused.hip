@@ -195,8 +195,12 @@ __device__ __forceinline__ void build_frags(const SaArgs &a, const TileRaw<NS> &
 
 // The tile loop of a wave, software-pipelined as described above.  BODY(tile, raw) consumes one
 // fetched tile.
-template <int NS, typename Body>
-__device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Body body) {
+// PRE() runs at the top of every iteration BEFORE the next tile's loads are issued, and once more
+// after the last tile: the place for stores / atomics deferred from the previous tile.  The
+// memory counter is in order, so anything issued between a prefetch and the wait for it is
+// waited for too; deferred to here, the atomics of tile t have the whole of tile t+1 to retire.
+template <int NS, typename Pre, typename Body>
+__device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Pre pre, Body body) {
     const int tiles = a.b * a.m, stride = gridDim.x * SA_WAVES;
     int tile = blockIdx.x * SA_WAVES + wave;
     if (tile >= tiles) return;
@@ -205,12 +209,19 @@ __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, 
     int nb_nxt = tile + stride < tiles ? a.idx[(size_t)(tile + stride) * SA_K + r] : 0;
     for (; tile < tiles; tile += stride) {
         const bool more = tile + stride < tiles;               // wave-uniform
+        pre();
         if (more) fetch_tile<NS>(a, tile + stride, nb_nxt, h, nxt);
         const int nb_nxt2 = tile + 2 * stride < tiles ? a.idx[(size_t)(tile + 2 * stride) * SA_K + r] : 0;
         body(tile, cur);
         if (more) cur = nxt;
         nb_nxt = nb_nxt2;
     }
+    pre();
+}
+
+template <int NS, typename Body>
+__device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Body body) {
+    for_each_tile<NS>(a, wave, r, h, [] {}, body);
 }
 
 // Workgroup-level fold of per-lane statistics into ONE partial row per workgroup:
@@ -462,7 +473,30 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     for (int e = lane; e < NS * SP_TILE; e += 64) sp_img[e] = (__bf16)0.0f;
     __syncthreads();
 
-    for_each_tile<NS>(a, wave, r, h, [&](int tile, const TileRaw<NS> &raw) {
+    // the previous tile's per-point sums, scattered at the top of the next iteration (see for_each_tile)
+    float pend_g[16], pend_geo[2];
+    int pend_nb = 0, pend_live = 0, pend_cloud = 0;      // pend_live == 0: nothing pending
+    auto scatter_pending = [&]() {
+        if (pend_live == 0) return;                       // wave-uniform
+        float *Ac = A + (size_t)pend_cloud * a.n * SA_C1 + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (acc_row(i, 0) < pend_live) {              // wave-uniform: is any lane's position live?
+                const int n0 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 0));
+                const int n1 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 1));
+                const int nn = h ? n1 : n0;
+                if (acc_row(i, h) < pend_live) atomicAdd(Ac + (size_t)nn * SA_C1, pend_g[i]);
+            }
+        }
+        // occurrences and relative positions: lane (pos = r, h) adds {count, dx} or {dy, dz}
+        if (r < pend_live) {
+            float *gp = geo + ((size_t)pend_cloud * a.n + pend_nb) * 4 + 2 * h;
+            atomicAdd(gp, pend_geo[0]);
+            atomicAdd(gp + 1, pend_geo[1]);
+        }
+        pend_live = 0;
+    };
+    for_each_tile<NS>(a, wave, r, h, scatter_pending, [&](int tile, const TileRaw<NS> &raw) {
         // the constant fragments are READ PER USE: an opaque copy of the lane id keeps the
         // compiler from hoisting these loop-invariant LDS reads back into ~130 registers
         int lane_o = lane;
@@ -571,25 +605,15 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
 #pragma unroll
             for (int i = 0; i < 16; ++i) extra += acc_row(i, h) >= live ? ga[i] : 0.0f;
             extra += __shfl_xor(extra, 32);
-            const int cloud = tile / a.m;
-            float *Ac = A + (size_t)cloud * a.n * SA_C1 + r;
+            // hand the tile's sums to the deferred scatter
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (acc_row(i, 0) < live) {   // wave-uniform: is any lane's position live?
-                    const int n0 = __builtin_amdgcn_readlane(nb, acc_row(i, 0));
-                    const int n1 = __builtin_amdgcn_readlane(nb, acc_row(i, 1));
-                    const int nn = h ? n1 : n0;
-                    const float v = (i == 0 && h == 0) ? ga[0] + extra : ga[i];
-                    if (acc_row(i, h) < live) atomicAdd(Ac + (size_t)nn * SA_C1, v);
-                }
-            }
-            // occurrences and relative positions: lane (pos = r, h) adds {count, dx} or {dy, dz}
-            if (r < live) {
-                const float mult = r == 0 ? (float)(SA_K - live + 1) : 1.0f;
-                float *gp = geo + ((size_t)cloud * a.n + nb) * 4 + 2 * h;
-                atomicAdd(gp, (h ? deff[1] : 1.0f) * mult);
-                atomicAdd(gp + 1, (h ? deff[2] : deff[0]) * mult);
-            }
+            for (int i = 0; i < 16; ++i) pend_g[i] = (i == 0 && h == 0) ? ga[0] + extra : ga[i];
+            const float mult = r == 0 ? (float)(SA_K - live + 1) : 1.0f;
+            pend_geo[0] = (h ? deff[1] : 1.0f) * mult;
+            pend_geo[1] = (h ? deff[2] : deff[0]) * mult;
+            pend_nb = nb;
+            pend_live = live;
+            pend_cloud = tile / a.m;
         }
 
         // Gram += a1^T a1: the k index (positions, accumulator-row order) pairs the same registers
