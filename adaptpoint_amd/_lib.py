@@ -22,11 +22,11 @@ SIGNATURES = {
     "apn_group_points_grad": [_c_int] * 5 + [_c_void_p] * 4,
     "apn_gather_points": [_c_int] * 4 + [_c_void_p] * 4,
     "apn_gather_points_grad": [_c_int] * 4 + [_c_void_p] * 4,
+    "apn_resample_points": [_c_int] * 6 + [_c_void_p] * 6,
     "apn_three_nn": [_c_int] * 3 + [_c_void_p] * 5,
     "apn_three_interpolate": [_c_int] * 4 + [_c_void_p] * 5,
     "apn_three_interpolate_grad": [_c_int] * 4 + [_c_void_p] * 5,
-    "apn_fps_set_waves": [_c_int],
-    "apn_fps_set_algo": [_c_int],
+    "apn_furthest_point_sampling_tuned": [_c_int] * 3 + [_c_void_p] * 3 + [_c_int] * 2 + [_c_void_p],
     "apn_fps_debug_stamps": [_c_int] * 3 + [_c_void_p] * 5,
     "apn_furthest_point_sampling_xyz": [_c_int] * 3 + [_c_void_p] * 5,
     "apn_ball_query_zero": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 4,
@@ -34,7 +34,7 @@ SIGNATURES = {
     "apn_sa_bwd_main_rows": [_c_int] * 2,
     "apn_sa_prep_features": [_c_int] * 3 + [_c_void_p] * 2 + [_c_int, _c_void_p],
     "apn_sa_fwd_stats1": [_c_int] * 8 + [_c_float] + [_c_void_p] * 7,
-    "apn_sa_reduce_rows": [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
+    "apn_sa_reduce_rows": [_c_void_p, _c_int, _c_int, _c_double, _c_void_p, _c_void_p],
     "apn_sa_bn_fold": [_c_void_p, _c_int, _c_void_p, _c_int, _c_double, _c_void_p, _c_void_p,
                        _c_float, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                        _c_void_p, _c_int, _c_void_p, _c_void_p],

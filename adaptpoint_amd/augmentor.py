@@ -1,0 +1,140 @@
+"""The AdaptPoint imitator (generator): anchors -> predictor network -> per-anchor rigid/scale
+deformation -> kernel-regressed blend -> unit sphere -> point mask.
+
+Host-side mirror of `AdaptPoint_Augmentor`
+(openpoints/models_adaptpoint/generator_component4_15.py:119-327).  The predictor network is
+`adaptpoint_amd.imitator.SAComponent` (attribute `predict_prob_layer`, so a reference state_dict
+loads unchanged); what this file adds is the geometry that consumes its two outputs:
+
+    anchors  a_m   = x[FPS(x, M)]                                            (:150-151)
+    factors  R_m, s_m, t_m from prob (B,M,9) and the step's random draws     (:236-297)
+    moved    y_mn  = (x_n - a_m) R_m diag(s_m) + t_m + a_m                   (:295, :166)
+    weights  w_mn  = exp(-|(a_m - x_n) * axis|^2 / (2 sigma^2))              (:204-234)
+    blend    z_n   = sum_m w_mn y_mn / sum_m w_mn                            (:231-232)
+    output   mask_n * unit_sphere(z)_n                                       (:313-327, :173)
+
+It is written around ONE set of random draws per call (`Noise`), because that is what has to be
+pinned for parity: the reference draws them from the CPU generator in a fixed order
+(`torch.Tensor(B,M,3).uniform_` -> `torch.bernoulli` -> two `torch.randint(1, 8, ...)`, :245-247,
+:218, :308) after the Gumbel noise of the mask (:714).  `draw_noise` makes the same calls in the
+same order, so with the same CPU seed the mirror consumes the generator exactly like the
+reference on CPU; on the GPU the Gumbel noise comes from the device generator (as it does in the
+reference), or the whole `Noise` is passed in (tests do that to replay a CPU golden).
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .imitator import SAComponent, index_points
+from .layers import furthest_point_sample
+
+
+@dataclass
+class Noise:
+    """The random draws of one generator call.
+    gumbel_expo (B,N,2): Exp(1) samples behind the mask's Gumbel noise (None: drawn on the logits'
+    device at use); keep (B,M,3) in {0,1}: which of rotation / scaling / translation each anchor
+    applies; axes (B,M,3) in {0,1}: the axes its scaling and translation act on; kernel_axes
+    (B,1,3) in {0,1}: the axes the kernel-regression distance is measured along."""
+    keep: torch.Tensor
+    axes: torch.Tensor
+    kernel_axes: torch.Tensor
+    gumbel_expo: Optional[torch.Tensor] = None
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device)
+        return Noise(mv(self.keep), mv(self.axes), mv(self.kernel_axes), mv(self.gumbel_expo))
+
+
+def _axis_bits(code):
+    """1..7 -> its three bits, least significant first: (..., 3) int32 (:299-311)."""
+    return ((code.unsqueeze(-1) >> torch.arange(3)) & 1).int()
+
+
+def draw_noise(batch, n_points, n_anchor, with_gumbel=False):
+    """The reference's CPU-generator calls, in its order.  with_gumbel=True also draws the mask's
+    Exp(1) samples first -- where `F.gumbel_softmax` draws them when the logits live on the CPU."""
+    expo = torch.empty(batch, n_points, 2).exponential_() if with_gumbel else None
+    keep = torch.bernoulli(torch.empty(batch, n_anchor, 3).uniform_(0, 1))
+    axes = _axis_bits(torch.randint(1, 8, (batch, n_anchor)))
+    kernel_axes = _axis_bits(torch.randint(1, 8, (batch, 1)))
+    return Noise(keep, axes, kernel_axes, expo)
+
+
+def anchor_transforms(prob, noise, r_range, s_range, t_range):
+    """prob (B,M,9) -> A (B,M,3,3) = R diag(s) and t (B,M,3)   (:236-297).
+    Rotation angles tanh(.) * r_range degrees, scales 1 + sigmoid(.) * (s_range - 1), offsets
+    tanh(.) * t_range; each of the three switched per anchor by `keep`, scale and offset confined
+    to the anchor's `axes` (a scale of 0 means "axis not scaled": it becomes 1)."""
+    keep, axes = noise.keep.to(prob.dtype), noise.axes.to(prob.dtype)
+    pi = torch.tensor(math.pi, device=prob.device)
+    ang = pi * (torch.tanh(prob[..., 0:3]) * r_range) / 180.0 * keep[..., 0:1]
+    s = (torch.sigmoid(prob[..., 3:6]) * (s_range - 1) + 1) * keep[..., 1:2] * axes
+    s = s + (s == 0)
+    t = torch.tanh(prob[..., 6:9]) * t_range * keep[..., 2:3] * axes
+    sx, sy, sz = torch.sin(ang).unbind(-1)
+    cx, cy, cz = torch.cos(ang).unbind(-1)
+    # rows of the rotation the reference composes (:288-290; its centre entry is sz*sy*sx + cz*cy)
+    rot = torch.stack([cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
+                       sz * cy, sz * sy * sx + cz * cy, sz * sy * cx - cz * sx,
+                       -sy, cy * sx, cy * cx], dim=-1).unflatten(-1, (3, 3))
+    return rot * s.unsqueeze(-2), t
+
+
+def kernel_weights(x, anchors, kernel_axes, sigma):
+    """w (B,M,N) = exp(-|(a_m - x_n) * axes|^2 / (2 sigma^2))   (:204-229).  The reference takes a
+    square root and squares it again; the squared distance is used directly here (same value to an
+    ulp, and no 0/0 in the derivative at the anchors themselves)."""
+    d = (anchors.unsqueeze(2) - x.unsqueeze(1)) * kernel_axes.to(x.dtype).unsqueeze(2)
+    return torch.exp(-0.5 * d.square().sum(-1) / sigma ** 2)
+
+
+def deform(x, anchors, lin, off, w):
+    """z (B,N,3) = sum_m w_mn ((x_n - a_m) A_m + t_m + a_m) / sum_m w_mn   (:156-167, :231-232)."""
+    moved = torch.matmul(x.unsqueeze(1) - anchors.unsqueeze(2), lin) + (off + anchors).unsqueeze(2)
+    return (w.unsqueeze(-1) * moved).sum(1) / w.sum(1).unsqueeze(-1)
+
+
+def unit_sphere(z):
+    """Centre each cloud and scale it just inside the unit sphere (:313-327)."""
+    z = z - z.mean(dim=-2, keepdim=True)
+    r = z.square().sum(-1).sqrt().amax(dim=-1)
+    return z * ((1 / r) * 0.999999).view(-1, 1, 1)
+
+
+class AdaptPointAugmentor(nn.Module):
+    """generator_component4_15.py:119-181 (`AdaptPoint_Augmentor`; cfg keys of
+    cfgs/scanobjectnn/pointnext-s_adaptpoint_1.yaml:50-56)."""
+
+    def __init__(self, w_num_anchor=4, w_sigma=0.5, w_R_range=10, w_S_range=3, w_T_range=0.25, fused=True):
+        super().__init__()
+        self.num_anchor = w_num_anchor
+        self.sigma = w_sigma
+        self.w_R_range, self.w_S_range, self.w_T_range = w_R_range, w_S_range, w_T_range
+        self.predict_prob_layer = SAComponent(fused=fused)
+
+    def forward(self, xyz, noise: Optional[Noise] = None):
+        """xyz (B,N,3) -> (xyz, augmented (B,N,3)).  `noise`: the call's random draws (default:
+        drawn here the way the reference draws them)."""
+        B, N, _ = xyz.shape
+        xyz = xyz.contiguous()
+        anchor_idx = furthest_point_sample(xyz, self.num_anchor).long()
+        anchors = index_points(xyz, anchor_idx)
+        prob, logits = self.predict_prob_layer(xyz, anchor_idx, return_logits=True)
+        if noise is None:
+            # the reference's order: Gumbel noise of the mask (device generator), then the CPU draws
+            expo = torch.empty_like(logits, memory_format=torch.contiguous_format).exponential_()
+            noise = draw_noise(B, N, self.num_anchor)
+            noise.gumbel_expo = expo
+        noise = noise.to(xyz.device)
+        mask = self.predict_prob_layer.hard_mask(logits, noise.gumbel_expo)
+        lin, off = anchor_transforms(prob, noise, self.w_R_range, self.w_S_range, self.w_T_range)
+        w = kernel_weights(xyz, anchors, noise.kernel_axes, self.sigma)
+        out = unit_sphere(deform(xyz, anchors, lin, off, w))
+        return xyz, out * mask[:, :, 0:1]
+
+
+AdaptPoint_Augmentor = AdaptPointAugmentor          # the reference's registry name

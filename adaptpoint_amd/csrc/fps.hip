@@ -504,12 +504,12 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(FpsOrder o, int m,
     }
 }
 
-static int g_fps_algo = 0;   // 0: LDS-atomic step when it applies; 1: per-wave records (first generation)
-
+// algo: 0 = LDS-atomic step when it applies; 1 = per-wave records (first generation).  A per-call
+// argument (the tuned entry point below), never process state: the operators are re-entrant.
 template <int W, int S>
 static int launch_reg(const FpsOrder &o, int b, int m, const float *xyz, float *temp, int *idxs,
-                      float *new_xyz, hipStream_t st) {
-    if (W > 1 && o.n <= 4096 && g_fps_algo == 0) {
+                      float *new_xyz, int algo, hipStream_t st) {
+    if (W > 1 && o.n <= 4096 && algo == 0) {
         hipLaunchKernelGGL((fps_atomic_kernel<W, S>), dim3(b), dim3(W * 64), sizeof(float4) * o.n, st,
                            o, m, xyz, temp, idxs, new_xyz);
         APN_LAUNCH_CHECK();
@@ -523,10 +523,10 @@ static int launch_reg(const FpsOrder &o, int b, int m, const float *xyz, float *
 
 template <int W>
 static int dispatch_slots(const FpsOrder &o, int b, int m, const float *xyz, float *temp,
-                          int *idxs, float *new_xyz, hipStream_t st) {
+                          int *idxs, float *new_xyz, int algo, hipStream_t st) {
     const int need = (o.n + W * 64 - 1) / (W * 64);
 #define APN_FPS_CASE(SS) \
-    if (need <= SS) return launch_reg<W, SS>(o, b, m, xyz, temp, idxs, new_xyz, st);
+    if (need <= SS) return launch_reg<W, SS>(o, b, m, xyz, temp, idxs, new_xyz, algo, st);
     APN_FPS_CASE(1)
     APN_FPS_CASE(2)
     APN_FPS_CASE(3)
@@ -539,26 +539,7 @@ static int dispatch_slots(const FpsOrder &o, int b, int m, const float *xyz, flo
     return APN_EINVAL;
 }
 
-static int g_fps_waves_override = 0;  // tuning hook, see apn_fps_set_waves
-
 }  // namespace apn
-
-extern "C" int apn_fps_set_algo(int algo) {
-    // Tuning/diagnostic hook: 0 = default (LDS-atomic step for n <= 4096), 1 = force the
-    // first-generation per-wave-record step.  Results do not depend on it.
-    if (algo != 0 && algo != 1) return APN_EINVAL;
-    apn::g_fps_algo = algo;
-    return APN_OK;
-}
-
-extern "C" int apn_fps_set_waves(int waves) {
-    // Tuning/diagnostic hook (not part of the reference boundary): force the
-    // number of waves per cloud (1, 4, 8, 16); 0 restores the heuristic.
-    if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16)
-        return APN_EINVAL;
-    apn::g_fps_waves_override = waves;
-    return APN_OK;
-}
 
 static apn::FpsOrder fps_order(int n) {
     apn::FpsOrder o;
@@ -577,8 +558,9 @@ static apn::FpsOrder fps_order(int n) {
     return o;
 }
 
+// waves: 0 = heuristic, else the number of waves per cloud (1, 2, 4, 8, 16); algo: see launch_reg.
 static int fps_impl(int b, int n, int m, const float *xyz, float *temp, int *idxs, float *new_xyz,
-                    void *stream) {
+                    int waves, int algo, void *stream) {
     using namespace apn;
     if (b < 0) return APN_EINVAL;
     if (b == 0 || m <= 0) return APN_OK;  // sampling_gpu.cu:110
@@ -593,21 +575,32 @@ static int fps_impl(int b, int n, int m, const float *xyz, float *temp, int *idx
         APN_LAUNCH_CHECK();
         return APN_OK;
     }
-    int w = g_fps_waves_override;
+    if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16)
+        return APN_EINVAL;
+    if (algo != 0 && algo != 1) return APN_EINVAL;
+    int w = waves;
     if (w == 0) w = n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 4 : n <= 4096 ? 8 : 16;
     while (w < 16 && (n + w * 64 - 1) / (w * 64) > 16) w *= 2;
     switch (w) {
-    case 1: return dispatch_slots<1>(o, b, m, xyz, temp, idxs, new_xyz, st);
-    case 2: return dispatch_slots<2>(o, b, m, xyz, temp, idxs, new_xyz, st);
-    case 4: return dispatch_slots<4>(o, b, m, xyz, temp, idxs, new_xyz, st);
-    case 8: return dispatch_slots<8>(o, b, m, xyz, temp, idxs, new_xyz, st);
-    default: return dispatch_slots<16>(o, b, m, xyz, temp, idxs, new_xyz, st);
+    case 1: return dispatch_slots<1>(o, b, m, xyz, temp, idxs, new_xyz, algo, st);
+    case 2: return dispatch_slots<2>(o, b, m, xyz, temp, idxs, new_xyz, algo, st);
+    case 4: return dispatch_slots<4>(o, b, m, xyz, temp, idxs, new_xyz, algo, st);
+    case 8: return dispatch_slots<8>(o, b, m, xyz, temp, idxs, new_xyz, algo, st);
+    default: return dispatch_slots<16>(o, b, m, xyz, temp, idxs, new_xyz, algo, st);
     }
 }
 
 extern "C" int apn_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
                                            int *idxs, void *stream) {
-    return fps_impl(b, n, m, xyz, temp, idxs, nullptr, stream);
+    return fps_impl(b, n, m, xyz, temp, idxs, nullptr, 0, 0, stream);
+}
+
+// Tuning / diagnostic entry (not part of the reference boundary): the same sampler with the
+// number of waves per cloud (0 = heuristic; 1, 2, 4, 8, 16) and the step algorithm (0 = default,
+// 1 = first-generation per-wave records) chosen per call.  Results do not depend on either.
+extern "C" int apn_furthest_point_sampling_tuned(int b, int n, int m, const float *xyz, float *temp,
+                                                 int *idxs, int waves, int algo, void *stream) {
+    return fps_impl(b, n, m, xyz, temp, idxs, nullptr, waves, algo, stream);
 }
 
 // FPS that also writes the sampled coordinates new_xyz (B,M,3) = xyz[idx]
@@ -615,7 +608,7 @@ extern "C" int apn_furthest_point_sampling(int b, int n, int m, const float *xyz
 extern "C" int apn_furthest_point_sampling_xyz(int b, int n, int m, const float *xyz, float *temp,
                                                int *idxs, float *new_xyz, void *stream) {
     if (n > 16384 || !new_xyz) return APN_EINVAL;
-    return fps_impl(b, n, m, xyz, temp, idxs, new_xyz, stream);
+    return fps_impl(b, n, m, xyz, temp, idxs, new_xyz, 0, 0, stream);
 }
 
 // FPS (+ sampled coordinates) of batch A and, in the same launch, the zero-filling ball query of
@@ -630,8 +623,7 @@ extern "C" int apn_sa_sample_overlap(int b, int n, int m, float radius, int nsam
     if (xyz_a && (!fidx_a || !new_xyz_a)) return APN_EINVAL;
     if (xyz_b && (!new_xyz_b || !idx_b)) return APN_EINVAL;
     const int need = (n + 511) / 512;               // slots per lane with 8 waves
-    const bool fusable = xyz_a && xyz_b && n > 512 && n <= 4096 && need <= 8 && g_fps_algo == 0 &&
-                         g_fps_waves_override == 0;
+    const bool fusable = xyz_a && xyz_b && n > 512 && n <= 4096 && need <= 8;
     if (!fusable) {
         if (xyz_a)
             if (int rc = apn_furthest_point_sampling_xyz(b, n, m, xyz_a, nullptr, fidx_a, new_xyz_a, stream))

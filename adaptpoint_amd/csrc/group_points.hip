@@ -159,6 +159,48 @@ extern "C" int apn_group_points_grad(int b, int c, int n, int npoints, int nsamp
                                     (hipStream_t)stream);
 }
 
+namespace apn {
+
+// The training loop's resampler (examples/classification/train_autoaug.py:493-498, train.py:265):
+// from the rows picked by FPS, keep the random subset `choice` (one draw for the whole batch) and
+// emit the two layouts the classifier consumes -- pos (B,S,3) row-major and x (B,CX,S)
+// channel-major -- in ONE pass.  Thread = one kept point: its source row (c <= 8 floats) is read
+// once; the x stores are coalesced along s for every channel.
+__global__ __launch_bounds__(256) void resample_rows_kernel(int n, int c, int p_all, int s_cnt, int cx,
+                                                            const float *__restrict__ points,
+                                                            const int *__restrict__ fidx,
+                                                            const int *__restrict__ choice,
+                                                            float *__restrict__ pos,
+                                                            float *__restrict__ x) {
+    const int s = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (s >= s_cnt) return;
+    const int src = fidx[(size_t)b * p_all + choice[s]];
+    const float *__restrict__ row = points + ((size_t)b * n + src) * c;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = k < c ? row[k] : 0.0f;
+    float *__restrict__ po = pos + ((size_t)b * s_cnt + s) * 3;
+    po[0] = v[0]; po[1] = v[1]; po[2] = v[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < cx) x[((size_t)b * cx + k) * s_cnt + s] = v[k];
+}
+
+}  // namespace apn
+
+extern "C" int apn_resample_points(int b, int n, int c, int p_all, int s_cnt, int cx,
+                                   const float *points, const int *fidx, const int *choice,
+                                   float *pos, float *x, void *stream) {
+    if (b < 0 || n <= 0 || c < 3 || c > 8 || cx < 0 || cx > c || p_all <= 0 || s_cnt < 0)
+        return APN_EINVAL;
+    if (b == 0 || s_cnt == 0) return APN_OK;
+    if (b > 65535 || !points || !fidx || !choice || !pos || (cx && !x)) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::resample_rows_kernel, dim3((s_cnt + 255) / 256, b), dim3(256), 0,
+                       (hipStream_t)stream, n, c, p_all, s_cnt, cx, points, fidx, choice, pos, x);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
 extern "C" int apn_gather_points(int b, int c, int n, int npoints, const float *points,
                                  const int *idx, float *out, void *stream) {
     if (b < 0 || c < 0 || n < 0 || npoints < 0) return APN_EINVAL;

@@ -63,11 +63,16 @@ __device__ __forceinline__ void block_sum_rows(const float *__restrict__ part, i
 }
 
 // Row sums only (the SyncBatchNorm path: reduce -> all_reduce -> consumer with part == null).
+// out[ncol] = this rank's position count, out[ncol + 1] = 1: summed over ranks with the rest they
+// become the GLOBAL count and the world size, which the consumers below read from the reduced
+// vector (ranks may hold different batch sizes; no host-side count * world).
 __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float *__restrict__ part, int rows,
-                                                           int ncol, double *__restrict__ out) {
+                                                           int ncol, double count,
+                                                           double *__restrict__ out) {
     __shared__ double s[128];
     block_sum_rows(part, rows, ncol, nullptr, s);
     if (threadIdx.x < ncol) out[threadIdx.x] = s[threadIdx.x];
+    if (threadIdx.x == 0) { out[ncol] = count; out[ncol + 1] = 1.0; }
 }
 
 // Float64 sums over the partial rows of TWO column quads (16-byte column groups qa and qb of a
@@ -142,6 +147,7 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(
         } else if (t < 4) {
             sum = sums_in[i];
             sumsq = sums_in[c + i];
+            count = sums_in[2 * c];          // global count (reduce_rows_kernel)
         }
     }
     if (t >= 4) return;
@@ -389,6 +395,12 @@ __global__ __launch_bounds__(1024) void bwd_consts2_kernel(const float *__restri
     float p_sc = 0.0f, p_mu = 0.0f, p_iv = 0.0f;
     if (t < 64) { p_sc = pack2[t]; p_mu = pack2[128 + t]; p_iv = pack2[192 + t]; }
     block_sum_rows(partS, rows, 128, S_in, S);
+    // SyncBatchNorm (reduced sums): the statistics use the GLOBAL sums and count; dL/dgamma and
+    // dL/dbeta are reported as global / world = the mean over ranks of the rank-local sums, which
+    // is what torch.nn.SyncBatchNorm + DistributedDataParallel leave in .grad (the later
+    // gradient averaging over ranks then is the identity on them).
+    double gscale = 1.0;
+    if (!partS) { count = S_in[128]; gscale = 1.0 / S_in[129]; }
     sw2[t >> 5][t & 31] = wa;
     sw2[32 + (t >> 5)][t & 31] = wb;
     if (t < 64) {
@@ -402,8 +414,8 @@ __global__ __launch_bounds__(1024) void bwd_consts2_kernel(const float *__restri
         D[t] = d; E[t] = e;
         d2e2[t] = (float)d;
         d2e2[64 + t] = (float)e;
-        if (g_gamma2) g_gamma2[t] = (float)s2;
-        if (g_beta2) g_beta2[t] = (float)s1;
+        if (g_gamma2) g_gamma2[t] = (float)(s2 * gscale);
+        if (g_beta2) g_beta2[t] = (float)(s1 * gscale);
     }
     __syncthreads();
     const int k = t >> 5, mid = t & 31;   // 32 x 32
@@ -437,21 +449,23 @@ __global__ __launch_bounds__(256) void bwd_consts1_kernel(
     }
     const int t = threadIdx.x, i = blockIdx.x * 4 + t;
     const float sc32 = t < 4 ? pack1[i] : 0.0f;      // requested before the row sums
-    double t1 = 0.0, t2 = 0.0;
+    double t1 = 0.0, t2 = 0.0, gscale = 1.0;
     if (partT) {
         slice_sum_rows(partT, rows, 16, blockIdx.x, 8 + blockIdx.x, red);
         if (t < 4) { t1 = red[0][t]; t2 = red[1][t]; }
     } else if (t < 4) {
         t1 = T_in[i];
         t2 = T_in[32 + i];
+        count = T_in[64];                    // global count, world size (reduce_rows_kernel)
+        gscale = 1.0 / T_in[65];
     }
     if (t >= 4) return;
     const double sc = sc32;
     cabc[i] = (float)sc;
     cabc[32 + i] = training ? (float)(-sc * t2 / count) : 0.0f;
     cabc[64 + i] = training ? (float)(-sc * t1 / count) : 0.0f;
-    if (g_gamma1) g_gamma1[i] = (float)t2;
-    if (g_beta1) g_beta1[i] = (float)t1;
+    if (g_gamma1) g_gamma1[i] = (float)(t2 * gscale);
+    if (g_beta1) g_beta1[i] = (float)(t1 * gscale);
 }
 
 // Everything downstream of dL/dy1 = g_u*ca + yhat1*cb + cc, which is only ever needed summed
@@ -676,10 +690,12 @@ __global__ __launch_bounds__(256) void bwd_finalize_kernel(
 
 #define APN_ST ((hipStream_t)stream)
 
-extern "C" int apn_sa_reduce_rows(const float *part, int rows, int ncol, double *out, void *stream) {
+extern "C" int apn_sa_reduce_rows(const float *part, int rows, int ncol, double count, double *out,
+                                  void *stream) {
     if (rows < 0 || ncol < 4 || ncol > 128 || (1024 % ncol) || !part || !out) return APN_EINVAL;
     if ((uintptr_t)part & 15) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::reduce_rows_kernel, dim3(1), dim3(1024), 0, APN_ST, part, rows, ncol, out);
+    hipLaunchKernelGGL(apn::reduce_rows_kernel, dim3(1), dim3(1024), 0, APN_ST, part, rows, ncol, count,
+                       out);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

@@ -1,0 +1,64 @@
+"""The AdaptPoint discriminator: a group-all PointNet with spectral-normalised layers.
+
+Host-side mirror of `PointDiscriminator1` and its `PointNetSetAbstraction_SpectralNorm` stage
+(openpoints/models_adaptpoint/point_discriminator.py:17-73, 129-191; cfg
+cfgs/scanobjectnn/pointnext-s_adaptpoint_1.yaml:58-61): per-point 1x1 convolutions
+3 -> 64 -> 128 -> 1024 with ReLU, max over the N points, then 1024 -> 512 -> 256 -> num_classes -> 1
+with ReLU / dropout 0.4 and a final sigmoid.  No BatchNorm; every weight carries
+`torch.nn.utils.parametrizations.spectral_norm` (one power iteration per training-mode forward,
+state in the `_u` / `_v` buffers).  It uses none of the extension operators: the "group all"
+stage is the identity grouping, so the per-point MLP runs directly on (B,3,N).
+
+Module names and the convolution type (Conv2d with 1x1 kernels) are the reference's, so its
+state_dict -- `sa1.mlp_convs.<i>.parametrizations.weight.original`, `..._u`, `..._v`, `fc1...`,
+`prob_head.0...` -- loads unchanged (800,671 parameters at num_classes = 15).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils.parametrizations import spectral_norm
+
+
+class _GroupAllStage(nn.Module):
+    """point_discriminator.py:149-191 with group_all=True: the shared MLP over every point of
+    the cloud and a max over them.  `mlp_bns` exists (empty) because the reference registers it."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        for out_channel in mlp:
+            self.mlp_convs.append(spectral_norm(nn.Conv2d(in_channel, out_channel, 1)))
+            in_channel = out_channel
+
+    def forward(self, xyz):
+        """xyz (B,3,N) -> (B,C_last): the reference's (B,3,N,1) layout is (B,3,N) with a unit
+        trailing axis; the max over the "nsample" axis (:189) is the max over the points."""
+        x = xyz.unsqueeze(-1)
+        for conv in self.mlp_convs:
+            x = F.relu(conv(x))
+        return x.amax(dim=2).squeeze(-1)
+
+
+class PointDiscriminator1(nn.Module):
+    """point_discriminator.py:17-73."""
+
+    def __init__(self, num_classes=40, normal_channel=False, **kwargs):
+        super().__init__()
+        if normal_channel:
+            raise NotImplementedError("normal channels are not used by the AdaptPoint configs")
+        self.normal_channel = False
+        self.sa1 = _GroupAllStage(3, [64, 128, 1024])
+        self.fc1 = spectral_norm(nn.Linear(1024, 512))
+        self.drop1 = nn.Dropout(0.4)
+        self.fc2 = spectral_norm(nn.Linear(512, 256))
+        self.drop2 = nn.Dropout(0.4)
+        self.fc3 = spectral_norm(nn.Linear(256, num_classes))
+        self.prob_head = nn.Sequential(spectral_norm(nn.Linear(num_classes, 1)), nn.Sigmoid())
+
+    def forward(self, xyz):
+        """xyz (B,N,3) -> probability of "real" (B,1)."""
+        x = self.sa1(xyz.permute(0, 2, 1).contiguous())
+        x = self.drop1(F.relu(self.fc1(x)))
+        x = self.drop2(F.relu(self.fc2(x)))
+        return self.prob_head(self.fc3(x))

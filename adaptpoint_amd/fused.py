@@ -45,13 +45,20 @@ _PREC = {"bf16": 1, "bf16x3": 2}
 PER_KERNEL_LAUNCH = False
 
 
-def supported(p, f, idx_or_k, conv1, conv2):
+def supported(p, f, idx_or_k, conv1, conv2, bns=(), npoint=None):
+    """Whether the fused kernels cover this block: the 32 -> 32 -> 64, K = 32 shape, float32 CUDA
+    tensors, no more queries than support points (the backward walks query tiles alongside point
+    tiles), a batch that fits one grid dimension, and BatchNorms with a fixed momentum (the
+    cumulative-average mode `momentum=None` stays on the unfused path)."""
     k = idx_or_k.shape[2] if torch.is_tensor(idx_or_k) else int(idx_or_k)
+    m = idx_or_k.shape[1] if torch.is_tensor(idx_or_k) else npoint
     return (f.is_cuda and f.dtype == torch.float32 and p.dtype == torch.float32
             and f.shape[1] == C_IN and k == K_NS
             and tuple(conv1.weight.shape[:2]) == (C_MID, C_IN + 3)
             and tuple(conv2.weight.shape[:2]) == (C_OUT, C_MID)
-            and conv1.bias is None and conv2.bias is None)
+            and conv1.bias is None and conv2.bias is None
+            and (m is None or m <= p.shape[1]) and p.shape[0] <= 65535
+            and all(bn.momentum is not None for bn in bns))
 
 
 _FN = {}
@@ -108,6 +115,12 @@ def _world(sync):
     return 1
 
 
+def _allreduce_sum_(t):
+    """In-place sum over ranks (the one collective of the SyncBatchNorm exchange; a seam for tests)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t)
+
+
 def _phased(sync):
     return _world(sync) > 1 or (FORCE_PHASED and sync)
 
@@ -123,12 +136,13 @@ def _carve(dev, sizes, zero=False):
     return {name: buf[o:o + int(nfl)] for (name, nfl), o in zip(sizes, offs)}, buf
 
 
-def _all_reduce_rows(call, part, rows, ncol, dev):
-    """SyncBatchNorm exchange: float64 column sums of the partial rows, all-reduced."""
-    sums = torch.empty(ncol, dtype=torch.float64, device=dev)
-    call("apn_sa_reduce_rows", part.data_ptr(), rows, ncol, sums.data_ptr())
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(sums)
+def _all_reduce_rows(call, part, rows, ncol, count, dev):
+    """SyncBatchNorm exchange: float64 column sums of the partial rows + {this rank's position
+    count, 1}, all-reduced -> {global sums, global count, world size}: the consumers read the
+    count and the world size from the vector (ranks may hold different batch sizes)."""
+    sums = torch.empty(ncol + 2, dtype=torch.float64, device=dev)
+    call("apn_sa_reduce_rows", part.data_ptr(), rows, ncol, float(count), sums.data_ptr())
+    _allreduce_sum_(sums)
     return sums
 
 
@@ -136,7 +150,10 @@ def _bn_args(bn):
     """(gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, training)."""
     training = bn.training or not bn.track_running_stats
     track = bn.track_running_stats
-    mom = bn.momentum if bn.momentum is not None else 0.1
+    if bn.momentum is None:
+        raise RuntimeError("fused set abstraction: BatchNorm(momentum=None) is not covered "
+                           "(fused.supported() routes it to the unfused path)")
+    mom = bn.momentum
     return (_ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean) if track else None,
             _ptr(bn.running_var) if track else None,
             _ptr(bn.num_batches_tracked) if (track and bn.training) else None,
@@ -169,8 +186,7 @@ class _Forward:
         if skip_conv is not None:
             ws = _mat(skip_conv.weight, C_OUT, C_IN)
             bs = skip_conv.bias.detach() if skip_conv.bias is not None else None
-        world = _world(sync_bn)
-        count = float(B * M * K_NS) * world
+        count = float(B * M * K_NS)       # this rank's positions; SyncBatchNorm all-reduces it with the sums
         rows = lib.apn_sa_grid_blocks(B, M)
         v, _buf = _carve(dev, [("ft", prec * B * N * C // 2), ("pack1", 4 * C_MID), ("pack2", 4 * C_OUT),
                                ("sgn2", C_OUT), ("ysel", B * M * C_OUT), ("ksel", B * M * C_OUT // 4),
@@ -195,9 +211,9 @@ class _Forward:
             run(7)
         else:                                   # SyncBatchNorm: all-reduce between the phases
             run(1)
-            s1 = _all_reduce_rows(call, v["part1"], rows, 64, dev) if self.train1 else None
+            s1 = _all_reduce_rows(call, v["part1"], rows, 64, count, dev) if self.train1 else None
             run(2, sums1=s1)
-            s2 = _all_reduce_rows(call, v["part2"], rows, 128, dev) if self.train2 else None
+            s2 = _all_reduce_rows(call, v["part2"], rows, 128, count, dev) if self.train2 else None
             run(4, sums2=s2)
         self.out = out
         self.saved = dict(p=p, f=f, new_p=new_p, idx=idx, fidx=fidx, ft=v["ft"], w1=w1, w2=w2, ws=ws,
@@ -207,9 +223,12 @@ class _Forward:
 
 def _backward(fw, g_out, need_p, need_newp):
     """All gradients of the fused chain from g_out (B,64,M)."""
+    if fw is None:
+        raise RuntimeError("fused set abstraction: backward called a second time (its saved state is "
+                           "released after the first backward; retain_graph is not supported)")
     sv = fw.saved
     B, N, M = fw.dims
-    dev = g_out.device
+    dev = fw.out.device
     P, sync = sv["count"], fw.sync
     f32 = dict(dtype=torch.float32, device=dev)
     if g_out is None:                 # only the other output was used downstream
@@ -269,11 +288,13 @@ def _backward(fw, g_out, need_p, need_newp):
         run(7)
     else:
         run(1)
-        sS = _all_reduce_rows(call, v["partS"], prow, 128, dev)
+        sS = _all_reduce_rows(call, v["partS"], prow, 128, P, dev)
         run(2, sumsS=sS)
-        sT = _all_reduce_rows(call, v["partT"], rows, 64, dev)
+        sT = _all_reduce_rows(call, v["partT"], rows, 64, P, dev)
         run(4, sumsT=sT)
-    # weight gradients are per-rank sums here; DistributedDataParallel averages them
+    # conv-weight gradients are per-rank sums here and DistributedDataParallel (or
+    # dp.allreduce_mean_) averages them; under SyncBatchNorm dL/dgamma, dL/dbeta already are
+    # global / world on every rank (sa_glue.hip, bwd_consts*), which that averaging leaves as is
     return dict(f=g_f, p=g_p, new_p=g_newp, w1=g["w1"].view(C_MID, C_IN + 3, 1, 1),
                 w2=g["w2"].view(C_OUT, C_MID, 1, 1), g1=g["g1"], b1=g["b1"], g2=g["g2"], b2=g["b2"],
                 ws=g["ws"].view(C_OUT, C_IN, 1) if has_skip else None,
@@ -351,6 +372,7 @@ class _GroupedMlpMax(torch.autograd.Function):
         fw = _Forward(p.contiguous(), f.contiguous(), new_p.contiguous(), idx.contiguous(), None,
                       radius, conv1, bn1, conv2, bn2, None, False, sync_bn)
         ctx.fw = fw
+        ctx.save_for_backward(p, new_p, f, idx)     # autograd's in-place version checks cover the inputs
         ctx.set_materialize_grads(False)
         ctx.flags = (p.requires_grad, new_p.requires_grad,
                      g1 is not None, b1 is not None, g2 is not None, b2 is not None)
@@ -359,6 +381,7 @@ class _GroupedMlpMax(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         need_p, need_q, a1, a2, a3, a4 = ctx.flags
+        ctx.saved_tensors                           # raises if an input was modified in place since
         g = _backward(ctx.fw, g_out, need_p, need_q)
         ctx.fw = None
         return (g["p"], g["new_p"], g["f"], None, g["w1"], g["g1"] if a1 else None,
@@ -453,6 +476,7 @@ class _SetAbstraction(torch.autograd.Function):
         fw = _Forward(p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
                       sync_bn)
         ctx.fw = fw
+        ctx.save_for_backward(p, f)        # autograd's in-place version checks cover the inputs
         ctx.set_materialize_grads(False)   # an unused output's gradient arrives as None, not as zeros
         ctx.flags = (p.requires_grad, g1 is not None, b1 is not None, g2 is not None,
                      b2 is not None, ws is not None, bs is not None)
@@ -463,6 +487,7 @@ class _SetAbstraction(torch.autograd.Function):
     def backward(ctx, g_newp_in, g_out):
         need_p, a1, a2, a3, a4, a5, a6 = ctx.flags
         fw = ctx.fw
+        ctx.saved_tensors                  # raises if an input was modified in place since
         g = _backward(fw, g_out, need_p, need_p)
         g_p = g["p"]
         if need_p:

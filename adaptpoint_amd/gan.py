@@ -1,0 +1,158 @@
+"""The two training steps of AdaptPoint over the gfx950 operators (BASELINE configs[2]-[4]).
+
+Host-side restatement of what the reference's trainer does per batch
+(examples/classification/train_autoaug.py) -- only the per-iteration arithmetic, none of its data
+loading, logging, checkpointing or epoch control:
+
+  `resample`            the classifier loop's FPS(N -> 1200) + random 1024 + gather   (:481-501)
+  `ClassifierStep`      forward, SmoothCE, backward, grad-clip 10, AdamW, zero_grad   (:502-512)
+  `feedback_loss`       |1 - exp(L_fake - rho * L_real)| through the eval-mode classifier
+                        (openpoints/function_adaptpoint/ganloss_cls.py:31-65)
+  `GanStep`             generator step (BCE vs 0.9 through D + feedback), then discriminator step
+                        (BCE real vs 0.9, fake vs 0.1)                               (:133-204)
+
+Hyper-parameters default to cfgs/scanobjectnn/pointnext-s_adaptpoint_1.yaml:63-71 and
+cfgs/scanobjectnn/default.yaml:36-56.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .fused import _call
+from .layers import furthest_point_sample
+
+
+def resample(points, npoints, in_channels, choice=None):
+    """train_autoaug.py:481-501.  points (B,N,C): when N > npoints, FPS down to `point_all`
+    (1200 for 1024, 4800 for 4096, 8192 for 8192), keep a random `npoints` of those -- ONE draw
+    of `np.random.choice(point_all, npoints, False)` for the whole batch -- and return
+    pos (B,npoints,3), x (B,in_channels,npoints).  `choice` overrides the draw (tests)."""
+    B, N, C = points.shape
+    if N <= npoints:
+        return points[:, :, :3].contiguous(), points[:, :, :in_channels].transpose(1, 2).contiguous()
+    point_all = {1024: 1200, 4096: 4800, 8192: 8192}.get(npoints)
+    if point_all is None:
+        raise NotImplementedError(f"no resampling rule for npoints={npoints}")
+    point_all = min(point_all, N)
+    points = points.contiguous()
+    fidx = furthest_point_sample(points[:, :, :3].contiguous(), point_all)
+    if choice is None:
+        choice = np.random.choice(point_all, npoints, False)
+    choice = torch.as_tensor(np.asarray(choice), dtype=torch.int32).to(points.device)
+    if choice.numel() != npoints or int(choice.min()) < 0 or int(choice.max()) >= point_all:
+        raise RuntimeError("resample: choice must hold npoints indices in [0, point_all)")
+    pos = torch.empty(B, npoints, 3, dtype=torch.float32, device=points.device)
+    x = torch.empty(B, in_channels, npoints, dtype=torch.float32, device=points.device)
+    if not points.is_cuda:
+        raise RuntimeError("adaptpoint_amd.gan.resample needs CUDA/HIP tensors: the product path has "
+                           "no CPU fallback")
+    _lib.load()
+    _call("apn_resample_points", points.device, B, N, C, point_all, npoints, in_channels,
+          points.data_ptr(), fidx.data_ptr(), choice.data_ptr(), pos.data_ptr(), x.data_ptr())
+    return pos, x
+
+
+class ClassifierStep:
+    """One iteration of `train_one_epoch` (train_autoaug.py:471-512) for step_per_update = 1."""
+
+    def __init__(self, model, lr=2e-3, weight_decay=0.05, grad_norm_clip=10.0, npoints=1024,
+                 in_channels=4, optimizer=None):
+        self.model = model
+        self.npoints, self.in_channels, self.clip = npoints, in_channels, grad_norm_clip
+        self.opt = optimizer or torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+
+    def __call__(self, points, target, choice=None):
+        """points (B,N,C>=in_channels), target (B,) -> (logits, loss)."""
+        self.model.train()
+        pos, x = resample(points, self.npoints, self.in_channels, choice)
+        logits, loss = self.model.get_logits_loss({'pos': pos, 'x': x}, target)
+        loss.backward()
+        if self.clip is not None and self.clip > 0:
+            nn.utils.clip_grad_norm_(self.model.parameters(), self.clip, norm_type=2)
+        self.opt.step()
+        self.model.zero_grad()
+        return logits, loss
+
+
+def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=True):
+    """ganloss_cls.py:31-65: how much harder the augmented clouds are than the real ones for the
+    CURRENT classifier, pulled towards `hard_ratio`: |1 - exp(L(fake) - hard_ratio * L(real))|.
+    The classifier runs in eval mode (running BatchNorm statistics, no dropout), so every cloud
+    is processed independently of its batch: `batched` stacks fake and real into ONE 2B pass
+    (their FPS chains then run side by side) with the same result per cloud.
+    `real` / `fake`: dicts with 'pos' (B,N,3) and 'x' (B,C,N)."""
+    classifier.eval()
+    if batched:
+        both = classifier({'pos': torch.cat([fake['pos'], real['pos']], 0),
+                           'x': torch.cat([fake['x'], real['x']], 0)})
+        pred_fake, pred_real = both.chunk(2, 0)
+    else:
+        pred_fake = classifier(fake)
+        pred_real = classifier(real)
+    loss_fake = criterion(pred_fake, label.long())
+    loss_real = criterion(pred_real, label.long())
+    return torch.abs(1 - torch.exp(loss_fake - hard_ratio * loss_real)), loss_fake, loss_real
+
+
+def hard_ratio_at(epoch, epochs, start=3.0, end=3.0):
+    """ganloss_cls.py:35-36."""
+    return start + (end - start) * epoch / epochs
+
+
+class GanStep:
+    """One iteration of `train_gan` (train_autoaug.py:133-204).
+
+    Differences from the reference, none of them numerical for the three networks' updates:
+    the generator step differentiates with respect to the generator's parameters only (the
+    reference's `g_loss.backward()` also fills the discriminator's and the classifier's .grad,
+    which it then overwrites / zeroes without using); the 4th input channel keeps the real cloud's
+    height, as the in-place `points[:, :, :3] = gen_imgs` leaves it (:155)."""
+
+    def __init__(self, generator, discriminator, classifier, criterion, lr_generator=1e-4,
+                 lr_discriminator=4e-4, betas=(0.5, 0.999), hard_ratio=3.0, feedback_ratio=1.0,
+                 in_channels=4, batched_feedback=True):
+        self.G, self.D, self.C = generator, discriminator, classifier
+        self.criterion = criterion
+        self.opt_g = torch.optim.Adam(generator.parameters(), lr=lr_generator, betas=betas)
+        self.opt_d = torch.optim.Adam(discriminator.parameters(), lr=lr_discriminator, betas=betas)
+        self.bce = nn.BCELoss()
+        self.hard_ratio, self.feedback_ratio = hard_ratio, feedback_ratio
+        self.in_channels, self.batched_feedback = in_channels, batched_feedback
+
+    def __call__(self, points, label, noise=None):
+        """points (B,N,C>=in_channels) with xyz first, label (B,) -> dict of the step's scalars
+        (0-dim tensors, no host sync) and the generated clouds."""
+        G, D = self.G, self.D
+        G.train()
+        D.train()
+        self.C.eval()
+        B = points.shape[0]
+        xyz = points[:, :, :3].contiguous()
+        real_t = torch.full((B, 1), 0.9, device=points.device)
+        fake_t = torch.full((B, 1), 0.1, device=points.device)
+
+        # ---- generator
+        _, gen = G(xyz) if noise is None else G(xyz, noise)
+        g_raw = self.bce(D(gen), real_t)
+        g_loss, fb = g_raw, None
+        if self.feedback_ratio > 0:
+            tail = points[:, :, 3:self.in_channels]
+            fake = {'pos': gen, 'x': torch.cat([gen, tail], -1).transpose(1, 2).contiguous()}
+            real = {'pos': xyz, 'x': points[:, :, :self.in_channels].transpose(1, 2).contiguous()}
+            fb, _, _ = feedback_loss(self.C, self.criterion, real, fake, label, self.hard_ratio,
+                                     self.batched_feedback)
+            g_loss = g_raw + fb * self.feedback_ratio
+        self.opt_g.zero_grad()
+        torch.autograd.backward(g_loss, inputs=[q for q in G.parameters() if q.requires_grad])
+        self.opt_g.step()
+
+        # ---- discriminator (two forwards, as the reference: each is one spectral-norm power iteration)
+        real_loss = self.bce(D(xyz), real_t)
+        fake_loss = self.bce(D(gen.detach()), fake_t)
+        d_loss = (real_loss + fake_loss) / 2
+        self.opt_d.zero_grad()
+        d_loss.backward()
+        self.opt_d.step()
+        return {'g_loss_raw': g_raw.detach(), 'feedback_loss': None if fb is None else fb.detach(),
+                'g_loss': g_loss.detach(), 'd_loss': d_loss.detach(), 'gen': gen.detach()}

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .attention import AnchorSelfAttention
-from .layers import three_interpolate, three_nn
+from .layers import three_interpolation
 from .pointset import PointsetGrouper
 
 
@@ -58,10 +58,7 @@ class PointNetFeaturePropagation(nn.Module):
         self.fuse = ConvBNReLU1D(in_channel, out_channel, 1, bias=bias)
 
     def forward(self, xyz1, xyz2, points1, points2):
-        dists, idx = three_nn(xyz1.contiguous(), xyz2.contiguous())
-        dist_recip = 1.0 / (dists + 1e-8)
-        weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
-        interpolated = three_interpolate(points2.contiguous(), idx.int(), weight)
+        interpolated = three_interpolation(xyz1, xyz2, points2)
         new_points = interpolated if points1 is None else torch.cat([points1, interpolated], dim=1)
         return self.fuse(new_points)
 
@@ -146,4 +143,15 @@ class SAComponent(nn.Module):
         logits = self.masking_logits(x_list[0], x_list[-1], xyz_list[0])
         if return_logits:
             return prob, logits
-        return prob, F.gumbel_softmax(logits, tau=0.1, hard=True, eps=1e-10, dim=-1)
+        return prob, self.hard_mask(logits)
+
+    @staticmethod
+    def hard_mask(logits, expo=None, tau=0.1):
+        """(:714) `F.gumbel_softmax(logits, tau=0.1, hard=True)`: one-hot forward, soft-max
+        gradient.  `expo` (B,N,2): the Exp(1) samples behind the Gumbel noise; drawn from the
+        logits' device generator when absent -- exactly what torch.nn.functional does."""
+        if expo is None:
+            return F.gumbel_softmax(logits, tau=tau, hard=True, eps=1e-10, dim=-1)
+        y = ((logits - expo.log()) / tau).softmax(-1)
+        hard = torch.zeros_like(logits).scatter_(-1, y.argmax(-1, keepdim=True), 1.0)
+        return hard - y.detach() + y

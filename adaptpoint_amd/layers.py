@@ -1,15 +1,28 @@
-"""Host-side mirror of the reference's operator layer
-(openpoints/models/layers/subsample.py:76-144, group.py:76-272,322-353,
-upsampling.py:11-102): the same public names, argument meaning and autograd
-behaviour, over the gfx950 operators in `adaptpoint_amd.ops`.
+"""Operator layer of the hot path: tensors in, tensors out, autograd where the operator has a
+gradient -- over the nine C-ABI operators in `adaptpoint_amd.ops`.
 
-Outputs are allocated with torch.empty/zeros on the input's device (the
-reference uses the legacy torch.cuda.FloatTensor constructors, which allocate
-on the *current* device).
+The callable NAMES and argument orders are the contract the reference's models are written against
+(openpoints/models/layers/__init__.py:8-14: `furthest_point_sample(xyz, npoint)`,
+`ball_query(radius, nsample, xyz, new_xyz)`, `grouping_operation(features, idx)`,
+`gather_operation(features, idx)`, `three_nn(unknown, known)`,
+`three_interpolate(features, idx, weight)`, `three_interpolation(unknown_xyz, known_xyz, feat)`);
+what they compute follows subsample.py:76-144, group.py:76-200, upsampling.py:11-102.  Everything
+else here is this build's own shape:
+
+  * the three index operators have no gradient, so they are plain no-grad functions, not
+    autograd Functions;
+  * the two copy operators (rows selected by an index tensor, gradient = scatter-add) share one
+    autograd Function;
+  * neighbourhood grouping is two small modules, `BallGrouper` / `KnnGrouper`, that return the
+    neighbour indices separately from the grouped tensors, because the fused kernels
+    (adaptpoint_amd.fused, adaptpoint_amd.pointset) consume the indices and never materialise
+    the (B,C,M,K) tensors the unfused path needs.
+
+Buffers are allocated on the inputs' device and pre-initialised as the extension's contract asks
+(temp = 1e10, ball-query indices = 0, gradient targets = 0).  Calls go through the
+module attribute `ops.<wrapper>` at call time, so a test can stand the CPU oracle in for the
+extension underneath this whole layer.
 """
-import copy
-from typing import Tuple
-
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -17,285 +30,209 @@ from torch.autograd import Function
 from . import ops
 
 
-class FurthestPointSampling(Function):
-    """subsample.py:76-102."""
-
-    @staticmethod
-    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
-        assert xyz.is_contiguous()
-        B, N, _ = xyz.size()
-        output = torch.empty(B, npoint, dtype=torch.int32, device=xyz.device)
-        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
-        ops.furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
-        ctx.mark_non_differentiable(output)
-        return output
-
-    @staticmethod
-    def backward(ctx, a=None):
-        return None, None
+def _alloc(like, *shape, dtype=torch.float32):
+    return torch.empty(*shape, dtype=dtype, device=like.device)
 
 
-furthest_point_sample = FurthestPointSampling.apply
+def _need_contiguous(**tensors):
+    for name, t in tensors.items():
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} must be contiguous (the extension reads raw rows)")
 
 
-class GatherOperation(Function):
-    """subsample.py:108-141 / group.py:140-171."""
-
-    @staticmethod
-    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-        assert features.is_contiguous()
-        assert idx.is_contiguous()
-        B, npoint = idx.size()
-        _, C, N = features.size()
-        output = torch.empty(B, C, npoint, dtype=torch.float32, device=features.device)
-        ops.gather_points_wrapper(B, C, N, npoint, features, idx, output)
-        ctx.for_backwards = (idx, C, N)
-        return output
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        idx, C, N = ctx.for_backwards
-        B, npoint = idx.size()
-        grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
-        ops.gather_points_grad_wrapper(B, C, N, npoint, grad_out.contiguous(), idx, grad_features)
-        return grad_features, None
+# ---------------------------------------------------------------- index operators (no gradient)
+@torch.no_grad()
+def furthest_point_sample(xyz, npoint):
+    """xyz (B,N,3) -> (B,npoint) int32 indices, starting from point 0   (subsample.py:78-98)."""
+    _need_contiguous(xyz=xyz)
+    B, N = xyz.shape[:2]
+    picks = _alloc(xyz, B, npoint, dtype=torch.int32)
+    running_min = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+    ops.furthest_point_sampling_wrapper(B, N, npoint, xyz, running_min, picks)
+    return picks
 
 
-gather_operation = GatherOperation.apply
+@torch.no_grad()
+def ball_query(radius, nsample, xyz, new_xyz):
+    """The first `nsample` points of xyz (B,N,3) inside the ball around each new_xyz (B,M,3),
+    in index order, padded with the first hit; all-zero rows for empty balls: (B,M,nsample) int32
+    (group.py:179-196)."""
+    _need_contiguous(xyz=xyz, new_xyz=new_xyz)
+    B, N = xyz.shape[:2]
+    M = new_xyz.shape[1]
+    nbr = torch.zeros(B, M, nsample, dtype=torch.int32, device=xyz.device)
+    ops.ball_query_wrapper(B, N, M, radius, nsample, new_xyz, xyz, nbr)
+    return nbr
 
 
-class BallQuery(Function):
-    """group.py:177-200."""
-
-    @staticmethod
-    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor,
-                new_xyz: torch.Tensor) -> torch.Tensor:
-        assert new_xyz.is_contiguous()
-        assert xyz.is_contiguous()
-        B, N, _ = xyz.size()
-        npoint = new_xyz.size(1)
-        idx = torch.zeros(B, npoint, nsample, dtype=torch.int32, device=xyz.device)
-        ops.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx)
-        ctx.mark_non_differentiable(idx)
-        return idx
-
-    @staticmethod
-    def backward(ctx, a=None):
-        return None, None, None, None
+@torch.no_grad()
+def three_nn(unknown, known):
+    """The three nearest `known` (B,m,3) points of every `unknown` (B,n,3) point:
+    (distance (B,n,3) -- the square ROOT of what the kernel writes --, index (B,n,3) int32)
+    (upsampling.py:14-35)."""
+    _need_contiguous(unknown=unknown, known=known)
+    B, n = unknown.shape[:2]
+    d2 = _alloc(unknown, B, n, 3)
+    nearest = _alloc(unknown, B, n, 3, dtype=torch.int32)
+    ops.three_nn_wrapper(B, n, known.shape[1], unknown, known, d2, nearest)
+    return d2.sqrt_(), nearest
 
 
-ball_query = BallQuery.apply
-
-
-class GroupingOperation(Function):
-    """group.py:76-114 (float32 even under autocast, as custom_fwd(cast_inputs) there)."""
+# ---------------------------------------------------------------- copy operators (gradient = scatter-add)
+class _TakeRows(Function):
+    """out[b, c, ...] = features[b, c, idx[b, ...]] for idx (B,M) ("gather", subsample.py:108-141)
+    or idx (B,M,K) ("group", group.py:76-114).  float32 even under autocast, as the reference's
+    custom_fwd(cast_inputs=float32)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-        assert features.is_contiguous()
-        assert idx.is_contiguous()
-        B, nfeatures, nsample = idx.size()
-        _, C, N = features.size()
-        output = torch.empty(B, C, nfeatures, nsample, dtype=torch.float32, device=features.device)
-        ops.group_points_wrapper(B, C, N, nfeatures, nsample, features, idx, output)
-        ctx.for_backwards = (idx, N)
-        return output
+    def forward(ctx, features, idx):
+        _need_contiguous(features=features, idx=idx)
+        B, C, N = features.shape
+        out = _alloc(features, B, C, *idx.shape[1:])
+        if idx.dim() == 2:
+            ops.gather_points_wrapper(B, C, N, idx.shape[1], features, idx, out)
+        else:
+            ops.group_points_wrapper(B, C, N, idx.shape[1], idx.shape[2], features, idx, out)
+        ctx.save_for_backward(idx)
+        ctx.n_rows = N
+        return out
 
     @staticmethod
-    def backward(ctx, grad_out: torch.Tensor) -> Tuple[torch.Tensor, None]:
-        idx, N = ctx.for_backwards
-        B, C, npoint, nsample = grad_out.size()
-        grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
-        ops.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out.contiguous(), idx,
-                                      grad_features)
-        return grad_features, None
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, C = g.shape[:2]
+        acc = torch.zeros(B, C, ctx.n_rows, dtype=torch.float32, device=g.device)
+        g = g.contiguous()
+        if idx.dim() == 2:
+            ops.gather_points_grad_wrapper(B, C, ctx.n_rows, idx.shape[1], g, idx, acc)
+        else:
+            ops.group_points_grad_wrapper(B, C, ctx.n_rows, idx.shape[1], idx.shape[2], g, idx, acc)
+        return acc, None
 
 
-grouping_operation = GroupingOperation.apply
+def gather_operation(features, idx):
+    """features (B,C,N), idx (B,M) int32 -> (B,C,M)."""
+    if idx.dim() != 2:
+        raise RuntimeError("gather_operation takes idx of shape (B, M)")
+    return _TakeRows.apply(features, idx)
 
 
-class ThreeNN(Function):
-    """upsampling.py:11-37: returns (sqrt(dist2), idx)."""
-
-    @staticmethod
-    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor):
-        assert unknown.is_contiguous()
-        assert known.is_contiguous()
-        B, N, _ = unknown.size()
-        m = known.size(1)
-        dist2 = torch.empty(B, N, 3, dtype=torch.float32, device=unknown.device)
-        idx = torch.empty(B, N, 3, dtype=torch.int32, device=unknown.device)
-        ops.three_nn_wrapper(B, N, m, unknown, known, dist2, idx)
-        dist = torch.sqrt(dist2)
-        ctx.mark_non_differentiable(dist, idx)
-        return dist, idx
-
-    @staticmethod
-    def backward(ctx, a=None, b=None):
-        return None, None
+def grouping_operation(features, idx):
+    """features (B,C,N), idx (B,M,K) int32 -> (B,C,M,K)."""
+    if idx.dim() != 3:
+        raise RuntimeError("grouping_operation takes idx of shape (B, M, K)")
+    return _TakeRows.apply(features, idx)
 
 
-three_nn = ThreeNN.apply
-
-
-class ThreeInterpolate(Function):
-    """upsampling.py:43-86."""
+class _Blend3(Function):
+    """out[b,c,i] = sum_j weight[b,i,j] * features[b,c,idx[b,i,j]], j < 3   (upsampling.py:43-86)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor):
-        assert features.is_contiguous()
-        assert idx.is_contiguous()
-        assert weight.is_contiguous()
-        B, c, m = features.size()
-        n = idx.size(1)
-        ctx.three_interpolate_for_backward = (idx, weight, m)
-        output = torch.empty(B, c, n, dtype=torch.float32, device=features.device)
-        ops.three_interpolate_wrapper(B, c, m, n, features, idx, weight, output)
-        return output
+    def forward(ctx, features, idx, weight):
+        _need_contiguous(features=features, idx=idx, weight=weight)
+        B, C, m = features.shape
+        n = idx.shape[1]
+        out = _alloc(features, B, C, n)
+        ops.three_interpolate_wrapper(B, C, m, n, features, idx, weight, out)
+        ctx.save_for_backward(idx, weight)
+        ctx.m = m
+        return out
 
     @staticmethod
-    def backward(ctx, grad_out: torch.Tensor):
-        idx, weight, m = ctx.three_interpolate_for_backward
-        B, c, n = grad_out.size()
-        grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
-        ops.three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight,
-                                           grad_features)
-        return grad_features, None, None
+    def backward(ctx, g):
+        idx, weight = ctx.saved_tensors
+        B, C, n = g.shape
+        acc = torch.zeros(B, C, ctx.m, dtype=torch.float32, device=g.device)
+        ops.three_interpolate_grad_wrapper(B, C, n, ctx.m, g.contiguous(), idx, weight, acc)
+        return acc, None, None
 
 
-three_interpolate = ThreeInterpolate.apply
+three_interpolate = _Blend3.apply
+
+
+def inverse_distance_weights(dist, eps=1e-8):
+    """(B,n,3) distances -> weights proportional to 1 / (dist + eps), summing to 1 (upsampling.py:97-100)."""
+    inv = 1.0 / (dist + eps)
+    return inv / inv.sum(dim=2, keepdim=True)
 
 
 def three_interpolation(unknown_xyz, known_xyz, know_feat):
-    """upsampling.py:92-102: inverse-distance weights over the 3 nearest known points."""
-    dist, idx = three_nn(unknown_xyz, known_xyz)
-    dist_recip = 1.0 / (dist + 1e-8)
-    norm = torch.sum(dist_recip, dim=2, keepdim=True)
-    weight = dist_recip / norm
-    return three_interpolate(know_feat, idx, weight)
+    """Features (B,C,m) known at known_xyz (B,m,3), carried to unknown_xyz (B,n,3) by
+    inverse-distance weighting over the three nearest known points -> (B,C,n) (upsampling.py:92-102)."""
+    dist, nearest = three_nn(unknown_xyz.contiguous(), known_xyz.contiguous())
+    return three_interpolate(know_feat.contiguous(), nearest, inverse_distance_weights(dist))
 
 
-class QueryAndGroup(nn.Module):
-    """group.py:206-255 (ball query, relative positions, optional /radius)."""
+# ---------------------------------------------------------------- neighbourhood grouping
+def _relative_positions(support_xyz, query_xyz, idx):
+    """(B,3,M,K): neighbour positions minus their query (group.py:248-251)."""
+    rows = grouping_operation(support_xyz.transpose(1, 2).contiguous(), idx)
+    return rows - query_xyz.transpose(1, 2).unsqueeze(-1)
 
-    def __init__(self, radius: float, nsample: int, relative_xyz=True, normalize_dp=False,
-                 normalize_by_std=False, normalize_by_allstd=False, normalize_by_allstd2=False,
-                 return_only_idx=False, **kwargs):
+
+class BallGrouper(nn.Module):
+    """Ball-query neighbourhoods (`QueryAndGroup`, group.py:206-255, for relative positions):
+    forward -> (dp (B,3,M,K), fj (B,C,M,K) | None); `normalize_dp` divides dp by the radius.
+    `neighbours` alone gives the (B,M,K) indices the fused kernels take."""
+
+    def __init__(self, radius, nsample, normalize_dp=False):
         super().__init__()
-        self.radius, self.nsample = radius, nsample
-        self.normalize_dp = normalize_dp
-        self.normalize_by_std = normalize_by_std
-        self.normalize_by_allstd = normalize_by_allstd
-        self.normalize_by_allstd2 = normalize_by_allstd2
-        assert self.normalize_dp + self.normalize_by_std + self.normalize_by_allstd < 2
-        self.relative_xyz = relative_xyz
-        self.return_only_idx = return_only_idx
+        self.radius, self.nsample, self.normalize_dp = radius, nsample, normalize_dp
+
+    def neighbours(self, query_xyz, support_xyz):
+        return ball_query(self.radius, self.nsample, support_xyz, query_xyz)
 
     def forward(self, query_xyz, support_xyz, features=None):
-        idx = ball_query(self.radius, self.nsample, support_xyz, query_xyz)
-        if self.return_only_idx:
-            return idx
-        xyz_trans = support_xyz.transpose(1, 2).contiguous()
-        grouped_xyz = grouping_operation(xyz_trans, idx)  # (B, 3, npoint, nsample)
-        if self.relative_xyz:
-            grouped_xyz = grouped_xyz - query_xyz.transpose(1, 2).unsqueeze(-1)
-            if self.normalize_dp:
-                grouped_xyz /= self.radius
-        grouped_features = grouping_operation(features, idx) if features is not None else None
-        return grouped_xyz, grouped_features
+        idx = self.neighbours(query_xyz, support_xyz)
+        dp = _relative_positions(support_xyz, query_xyz, idx)
+        if self.normalize_dp:
+            dp = dp / self.radius
+        return dp, (None if features is None else grouping_operation(features, idx))
+
+
+class KnnGrouper(nn.Module):
+    """k-nearest-neighbour neighbourhoods (`KNNGroup` / `KNN`, group.py:12-28, 275-320): the same
+    two outputs; `normalize_dp` divides dp by each cloud's largest neighbour distance."""
+
+    def __init__(self, nsample, normalize_dp=False):
+        super().__init__()
+        self.nsample, self.normalize_dp = nsample, normalize_dp
+
+    @torch.no_grad()
+    def neighbours(self, query_xyz, support_xyz):
+        # distances laid out (B,N,M) and the k smallest taken along N, as the reference does: the
+        # order among near-equal distances then is the same
+        nearest = torch.cdist(support_xyz, query_xyz).topk(self.nsample, dim=1, largest=False).indices
+        return nearest.transpose(1, 2).contiguous().int()
+
+    def forward(self, query_xyz, support_xyz, features=None):
+        idx = self.neighbours(query_xyz, support_xyz)
+        dp = _relative_positions(support_xyz, query_xyz, idx)
+        if self.normalize_dp:
+            dp = dp / dp.square().sum(1).sqrt().amax(dim=(1, 2)).view(-1, 1, 1, 1)
+        return dp, (None if features is None else grouping_operation(features, idx))
 
 
 class GroupAll(nn.Module):
-    """group.py:258-272."""
-
-    def forward(self, new_xyz, xyz, features=None):
-        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
-        grouped_features = features.unsqueeze(2) if features is not None else None
-        return grouped_xyz, grouped_features
-
-
-class KNN(nn.Module):
-    """group.py:12-28 (cdist + topk; pure torch in the reference too)."""
-
-    def __init__(self, neighbors, transpose_mode=True):
-        super().__init__()
-        self.neighbors = neighbors
-
-    @torch.no_grad()
-    def forward(self, support, query):
-        dist = torch.cdist(support, query)
-        k_dist = dist.topk(k=self.neighbors, dim=1, largest=False)
-        return k_dist.values, k_dist.indices.transpose(1, 2).contiguous().int()
-
-
-class KNNGroup(nn.Module):
-    """group.py:275-320."""
-
-    def __init__(self, nsample: int, relative_xyz=True, normalize_dp=False,
-                 return_only_idx=False, **kwargs):
-        super().__init__()
-        self.nsample = nsample
-        self.knn = KNN(nsample, transpose_mode=True)
-        self.relative_xyz = relative_xyz
-        self.normalize_dp = normalize_dp
-        self.return_only_idx = return_only_idx
+    """One neighbourhood holding every point (group.py:258-272): dp (B,3,1,N), fj (B,C,1,N)."""
 
     def forward(self, query_xyz, support_xyz, features=None):
-        _, idx = self.knn(support_xyz, query_xyz)
-        if self.return_only_idx:
-            return idx
-        idx = idx.int()
-        xyz_trans = support_xyz.transpose(1, 2).contiguous()
-        grouped_xyz = grouping_operation(xyz_trans, idx)
-        if self.relative_xyz:
-            grouped_xyz -= query_xyz.transpose(1, 2).unsqueeze(-1)
-        if self.normalize_dp:
-            grouped_xyz /= torch.amax(torch.sqrt(torch.sum(grouped_xyz ** 2, dim=1)),
-                                      dim=(1, 2)).view(-1, 1, 1, 1)
-        if features is not None:
-            return grouped_xyz, grouping_operation(features, idx)
-        return grouped_xyz, None
+        dp = support_xyz.transpose(1, 2).unsqueeze(2)
+        return dp, (None if features is None else features.unsqueeze(2))
 
 
-def get_aggregation_feautres(p, dp, f, fj, feature_type='dp_fj'):
-    """group.py:323-335 (the reference's spelling is kept)."""
-    if feature_type == 'dp_fj':
-        fj = torch.cat([dp, fj], 1)
-    elif feature_type == 'dp_fj_df':
-        df = fj - f.unsqueeze(-1)
-        fj = torch.cat([dp, fj, df], 1)
-    elif feature_type == 'pi_dp_fj_df':
-        df = fj - f.unsqueeze(-1)
-        fj = torch.cat([p.transpose(1, 2).unsqueeze(-1).expand(-1, -1, -1, df.shape[-1]),
-                        dp, fj, df], 1)
-    elif feature_type == 'dp_df':
-        df = fj - f.unsqueeze(-1)
-        fj = torch.cat([dp, df], 1)
-    return fj
-
-
-# Channels entering a block's first conv for the feature types that
-# get_aggregation_feautres builds (cf. layers/local_aggregation.py:13-29).
-CHANNEL_MAP = {
-    'dp_fj': lambda x: 3 + x,
-    'dp_fj_df': lambda x: 2 * x + 3,
-    'pi_dp_fj_df': lambda x: 2 * x + 6,
-    'dp_df': lambda x: x + 3,
-}
-
-
-def create_grouper(group_args):
-    """group.py:338-353."""
-    group_args_copy = copy.deepcopy(dict(group_args))
-    method = group_args_copy.pop('NAME', 'ballquery')
-    radius = group_args_copy.pop('radius', 0.1)
-    nsample = group_args_copy.pop('nsample', 20)
-    if nsample is not None:
-        if method == 'ballquery':
-            return QueryAndGroup(radius, nsample, **group_args_copy)
-        if method == 'knn':
-            return KNNGroup(nsample, **group_args_copy)
-        raise NotImplementedError(f"grouper {method}")
-    return GroupAll()
+def make_grouper(group_args):
+    """The cfgs' `group_args` (NAME ballquery | knn, radius, nsample, normalize_dp;
+    cfgs/scanobjectnn/pointnext-s.yaml:22-24) -> a grouper; nsample None -> GroupAll
+    (what pointnext.py:130-133 asks for in its last stage)."""
+    args = dict(group_args)
+    kind = args.get('NAME', 'ballquery')
+    if args.get('nsample', 20) is None:
+        return GroupAll()
+    if kind == 'ballquery':
+        return BallGrouper(args.get('radius', 0.1), args.get('nsample', 20), args.get('normalize_dp', False))
+    if kind == 'knn':
+        return KnnGrouper(args.get('nsample', 20), args.get('normalize_dp', False))
+    raise NotImplementedError(f"grouper '{kind}' is outside the hot-path build")

@@ -8,11 +8,25 @@ pooling, optional residual.  Sub-module names and nesting match the reference
 (`convs.<i>.0` conv, `convs.<i>.1` norm, `skipconv.0`), so a reference
 state_dict loads unchanged.
 """
+import logging
+
 import torch
 import torch.nn as nn
 
-from .layers import (CHANNEL_MAP, create_grouper, furthest_point_sample,
-                     get_aggregation_feautres)
+from . import layers
+from .layers import BallGrouper, make_grouper
+
+_log = logging.getLogger("adaptpoint_amd")
+
+# fused=True requests that fall back to the unfused operators, by reason (bench.py reports the
+# total; each distinct reason is logged once).
+FUSED_FALLBACKS = {}
+
+
+def _note_fallback(reason):
+    if reason not in FUSED_FALLBACKS:
+        _log.warning("SetAbstraction(fused=True) runs UNFUSED: %s", reason)
+    FUSED_FALLBACKS[reason] = FUSED_FALLBACKS.get(reason, 0) + 1
 
 
 def _norm(norm_args, channels, dim):
@@ -76,7 +90,10 @@ class SetAbstraction(nn.Module):
 
         mid_channel = out_channels // 2 if stride > 1 else out_channels
         channels = [in_channels] + [mid_channel] * (layers - 1) + [out_channels]
-        channels[0] = in_channels if is_head else CHANNEL_MAP[feature_type](channels[0])
+        if feature_type != 'dp_fj':
+            raise NotImplementedError("only the 'dp_fj' aggregation (relative positions + neighbour "
+                                      "features; the cfgs in scope) is on the hot path")
+        channels[0] = in_channels if is_head else 3 + channels[0]
 
         if self.use_res:
             self.skipconv = (convblock(in_channels, channels[-1], 1)
@@ -96,17 +113,14 @@ class SetAbstraction(nn.Module):
             if self.all_aggr:
                 group_args['nsample'] = None
                 group_args['radius'] = None
-            self.grouper = create_grouper(group_args)
+            self.grouper = make_grouper(group_args)
             if sampler.lower() != 'fps':
                 raise NotImplementedError("only the FPS sampler is on the hot path")
-            self.sample_fn = furthest_point_sample
 
     def _fused_parts(self):
         """(conv1, bn1, conv2, bn2, relu_after_bn2) if the MLP has the fused kernels' structure."""
-        from .layers import QueryAndGroup
         g = self.grouper
-        if not (isinstance(g, QueryAndGroup) and g.relative_xyz and g.normalize_dp
-                and self.feature_type == 'dp_fj' and len(self.convs) == 2):
+        if not (isinstance(g, BallGrouper) and g.normalize_dp and len(self.convs) == 2):
             return None
         blk1, blk2 = self.convs[0], self.convs[1]
         if not (len(blk1) == 3 and isinstance(blk1[1], nn.BatchNorm2d) and isinstance(blk1[2], nn.ReLU)
@@ -137,7 +151,8 @@ class SetAbstraction(nn.Module):
             return None
         conv1, bn1, conv2, bn2, relu_after = parts
         g = self.grouper
-        if not fused.supported(p, f, g.nsample, conv1, conv2) or p.shape[1] > 16384:
+        if (not fused.supported(p, f, g.nsample, conv1, conv2, bns=(bn1, bn2),
+                               npoint=p.shape[1] // self.stride) or p.shape[1] > 16384):
             return None
         skip = None
         if self.use_res:
@@ -154,14 +169,13 @@ class SetAbstraction(nn.Module):
     def _fused_forward(self, new_p, p, f):
         """max_K convs(cat[dp, f[idx]]) through the fused kernels, or None if unsupported."""
         from . import fused
-        from .layers import ball_query
         parts = self._fused_parts()
         if parts is None:
             return None
         conv1, bn1, conv2, bn2, relu_after = parts
         g = self.grouper
-        idx = ball_query(g.radius, g.nsample, p, new_p)
-        if not fused.supported(p, f, idx, conv1, conv2):
+        idx = g.neighbours(new_p, p)
+        if not fused.supported(p, f, idx, conv1, conv2, bns=(bn1, bn2)):
             return None
         out = fused.grouped_mlp_max(p, new_p, f, idx, g.radius, conv1, bn1, conv2, bn2,
                                     sync_bn=self.sync_bn)
@@ -177,30 +191,27 @@ class SetAbstraction(nn.Module):
         p, f = pf
         if self.is_head:
             return p, self.convs(f)
-        if self.fused:
+        if self.fused and not self.all_aggr:
             res = self._fused_block(p, f, sampling)
             if res is not None:
                 return res
         if sampling is not None:
             raise NotImplementedError("a precomputed sampling needs the fused block path")
-        if not self.all_aggr:
-            idx = self.sample_fn(p, p.shape[1] // self.stride).long()
-            new_p = torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
-        else:
+        if self.all_aggr:
             new_p = p
-        if self.use_res or 'df' in self.feature_type:
-            fi = torch.gather(f, -1, idx.unsqueeze(1).expand(-1, f.shape[1], -1))
-            if self.use_res:
-                identity = self.skipconv(fi)
         else:
-            fi = None
-        fused_out = self._fused_forward(new_p, p, f) if self.fused else None
-        if fused_out is not None:
-            f = fused_out
-        else:
+            picks = layers.furthest_point_sample(p, p.shape[1] // self.stride).long()
+            new_p = torch.gather(p, 1, picks.unsqueeze(-1).expand(-1, -1, 3))
+        identity = None
+        if self.use_res:                 # the skip branch sees the sampled points' own features
+            identity = self.skipconv(torch.gather(f, -1, picks.unsqueeze(1).expand(-1, f.shape[1], -1)))
+        pooled = self._fused_forward(new_p, p, f) if (self.fused and not self.all_aggr) else None
+        if pooled is None:
+            if self.fused and not self.all_aggr:
+                _note_fallback(f"C_in={f.shape[1]} -> {[c[0].out_channels for c in self.convs]}, "
+                               f"K={getattr(self.grouper, 'nsample', None)}: no fused kernel for this shape")
             dp, fj = self.grouper(new_p, p, f)
-            fj = get_aggregation_feautres(new_p, dp, fi, fj, feature_type=self.feature_type)
-            f = self.pool(self.convs(fj))
-        if self.use_res:
-            f = self.act(f + identity)
-        return new_p, f
+            pooled = self.pool(self.convs(torch.cat([dp, fj], 1)))       # 'dp_fj' (group.py:325-326)
+        if identity is not None:
+            pooled = self.act(pooled + identity)
+        return new_p, pooled

@@ -86,6 +86,15 @@ APN_API int apn_gather_points(int b, int c, int n, int npoints, const float *poi
 APN_API int apn_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
                            const int *idx, float *grad_points, void *stream);
 
+/* The training loop's resampler (examples/classification/train_autoaug.py:493-498): points
+ * (B,N,C) rows (3 <= C <= 8), fidx (B,p_all) FPS picks, choice (s_cnt) a subset of 0..p_all-1
+ * shared by the batch -> pos (B,s_cnt,3) = points[b, fidx[b, choice[s]], :3] and
+ * x (B,cx,s_cnt) = the first cx channels, channel-major (what `data['pos']`, `data['x']`
+ * become at :500-501), one launch.  choice values must lie in [0, p_all). */
+APN_API int apn_resample_points(int b, int n, int c, int p_all, int s_cnt, int cx,
+                                const float *points, const int *fidx, const int *choice,
+                                float *pos, float *x, void *stream);
+
 /* Replaces three_nn_wrapper (pointnet2_api.cpp:20, interpolate.cpp:20-28 ->
  * interpolate_gpu.cu:16-81).  unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3)
  * SQUARED distances ascending, idx (B,n,3).  m < 3 leaves +inf / index 0 in
@@ -155,9 +164,14 @@ APN_API int apn_sa_fwd_stats1(int b, int n, int m, int c_in, int c_mid, int c_ou
                               const void *ft, const int *idx, const float *w1, float *part,
                               void *stream);
 
-/* out[ncol] = float64 column sums of part[rows][ncol] (ncol <= 128, a power of two): the
- * SyncBatchNorm path reduces, all-reduces, then calls the consumer with part == NULL. */
-APN_API int apn_sa_reduce_rows(const float *part, int rows, int ncol, double *out, void *stream);
+/* out[0..ncol) = float64 column sums of part[rows][ncol] (ncol <= 128, a power of two);
+ * out[ncol] = count (this rank's positions), out[ncol + 1] = 1.  The SyncBatchNorm path reduces,
+ * all-reduces the ncol + 2 values over ranks (sums, GLOBAL count, world size), then calls the
+ * consumer with part == NULL: apn_sa_bn_fold / apn_sa_bwd_consts2 / apn_sa_bwd_consts1 then take
+ * the count from the reduced vector (their `count` argument is ignored) and report dL/dgamma,
+ * dL/dbeta as global sum / world (what SyncBatchNorm + DistributedDataParallel leave in .grad). */
+APN_API int apn_sa_reduce_rows(const float *part, int rows, int ncol, double count, double *out,
+                               void *stream);
 
 /* BatchNorm fold: {sum, sumsq}[C] over `count` positions (part[rows][2C], or sums[2C] when
  * part == NULL) -> pack[4][C]; updates the running buffers / num_batches_tracked when
@@ -330,15 +344,13 @@ APN_API int apn_attention_bwd(int b, int m, int heads, const void *images, const
                               const float *lse, const float *g_out, void *scratch, float *dq,
                               float *dk, float *dv, void *stream);
 
-/* Tuning / diagnostic hook, NOT part of the reference boundary: force the number
- * of wavefronts that cooperate on one cloud in apn_furthest_point_sampling
- * (1, 2, 4, 8 or 16; 0 restores the built-in heuristic).  Results do not depend
- * on it.  Process-wide; not thread-safe against concurrent FPS launches. */
-APN_API int apn_fps_set_waves(int waves);
-
-/* Tuning / diagnostic hook: FPS step algorithm, 0 = default (one LDS 64-bit atomic max per
- * step, n <= 4096), 1 = per-wave records + second reduction.  Results do not depend on it. */
-APN_API int apn_fps_set_algo(int algo);
+/* Tuning / diagnostic entry, NOT part of the reference boundary: apn_furthest_point_sampling
+ * with the number of wavefronts that cooperate on one cloud (1, 2, 4, 8 or 16; 0 = the built-in
+ * heuristic) and the step algorithm (0 = default: one LDS 64-bit atomic max per step for
+ * n <= 4096; 1 = per-wave records + second reduction) chosen PER CALL.  No process-wide state:
+ * every entry point of this library is re-entrant.  Results do not depend on either argument. */
+APN_API int apn_furthest_point_sampling_tuned(int b, int n, int m, const float *xyz, float *temp,
+                                              int *idx, int waves, int algo, void *stream);
 
 /* Diagnostic only: the FPS step of the n = 1024 geometry with s_memtime stamps; dbg[0..5]
  * = cycles summed over the m-1 steps for {update, wave max, pick+LDS write, barrier,

@@ -37,22 +37,18 @@ def bench_fps():
         idx = torch.empty(b, m, dtype=torch.int32, device=dev)
         line = f"B={b:4d} N={n:5d} M={m:5d}: "
         for algo in (0, 1):
-          lib.apn_fps_set_algo(algo)
           line += f" [algo{algo}]"
           for w in (0, 2, 4, 8, 16):
             if w and (n + w * 64 - 1) // (w * 64) > 16:
                 line += f" w{w}=  n/a "
                 continue
-            lib.apn_fps_set_waves(w)
-
             def run():
                 temp.fill_(1e10)
-                ops.furthest_point_sampling_wrapper(b, n, m, xyz, temp, idx)
+                lib.apn_furthest_point_sampling_tuned(b, n, m, xyz.data_ptr(), temp.data_ptr(), idx.data_ptr(),
+                                                      w, algo, torch.cuda.current_stream().cuda_stream)
             med, mn = time_us(run)
             fill, _ = time_us(lambda: temp.fill_(1e10))
             line += f" w{w}={med - fill:6.1f}us({(med - fill) * 1e3 / max(m - 1, 1):4.0f})"
-        lib.apn_fps_set_waves(0)
-        lib.apn_fps_set_algo(0)
         print(line, flush=True)
 
 

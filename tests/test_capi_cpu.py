@@ -85,4 +85,9 @@ def test_argument_validation_needs_no_gpu(lib):
     g.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 4
     assert g(1, 4, 8, 0, 3, None, None, None, None) == 0
     assert g(1, 4, 8, 1 << 20, 1 << 20, None, None, None, None) == -1   # npoints*nsample overflows int
-    assert lib.apn_fps_set_waves(3) == -1 and lib.apn_fps_set_waves(0) == 0
+    t = lib.apn_furthest_point_sampling_tuned
+    t.restype = ctypes.c_int
+    t.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 2 + [ctypes.c_void_p]
+    assert t(2, 8, 0, None, None, None, 3, 0, None) == 0      # m <= 0 returns before anything is read
+    assert t(2, 8, 4, None, None, None, 0, 0, None) == -1
+    assert not hasattr(lib, "apn_fps_set_waves") and not hasattr(lib, "apn_fps_set_algo")   # no process-wide state

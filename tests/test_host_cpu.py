@@ -87,22 +87,25 @@ def test_set_abstraction_mirror_matches_reference_module(golden):
 
 def test_query_and_group_mirror(golden):
     from oracle import cpu_block as CB
-    from adaptpoint_amd.layers import QueryAndGroup
+    from adaptpoint_amd.layers import BallGrouper
     xyz = GI.config1_xyz()
     q = GI.take_points(xyz, golden["g1_fps512"])
     feats = GI.seeded_normal((2, 32, 1024), seed=11)
     with CB.CpuOps():
-        dp, fj = QueryAndGroup(0.15, 32, normalize_dp=True)(torch.from_numpy(q), torch.from_numpy(xyz), torch.from_numpy(feats))
+        dp, fj = BallGrouper(0.15, 32, normalize_dp=True)(torch.from_numpy(q), torch.from_numpy(xyz), torch.from_numpy(feats))
     np.testing.assert_allclose(dp.numpy(), golden["g4_qg_dp"], rtol=1e-6, atol=1e-7)
     chk = np.array([fj.double().sum().item(), fj.double().abs().sum().item()])
     np.testing.assert_allclose(chk, golden["g4_qg_fj_checksum"], rtol=1e-12)
 
 
-def test_grouper_factory_and_channel_map():
-    from adaptpoint_amd.layers import CHANNEL_MAP, GroupAll, QueryAndGroup, create_grouper
-    assert isinstance(create_grouper({'NAME': 'ballquery', 'radius': 0.1, 'nsample': 8}), QueryAndGroup)
-    assert isinstance(create_grouper({'NAME': 'ballquery', 'radius': None, 'nsample': None}), GroupAll)
-    assert CHANNEL_MAP['dp_fj'](32) == 35
+def test_grouper_factory():
+    from adaptpoint_amd.layers import BallGrouper, GroupAll, KnnGrouper, make_grouper
+    g = make_grouper({'NAME': 'ballquery', 'radius': 0.1, 'nsample': 8, 'normalize_dp': True})
+    assert isinstance(g, BallGrouper) and g.radius == 0.1 and g.nsample == 8 and g.normalize_dp
+    assert isinstance(make_grouper({'NAME': 'ballquery', 'radius': None, 'nsample': None}), GroupAll)
+    assert isinstance(make_grouper({'NAME': 'knn', 'nsample': 5}), KnnGrouper)
+    with pytest.raises(NotImplementedError):
+        make_grouper({'NAME': 'voxel', 'nsample': 5})
 
 
 def test_anchor_self_attention_mirror_reproduces_reference_on_cpu(golden):
