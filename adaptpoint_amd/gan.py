@@ -18,8 +18,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib
-from .fused import _call
+from . import ops
 from .layers import furthest_point_sample
 
 
@@ -39,17 +38,13 @@ def resample(points, npoints, in_channels, choice=None):
     fidx = furthest_point_sample(points[:, :, :3].contiguous(), point_all)
     if choice is None:
         choice = np.random.choice(point_all, npoints, False)
-    choice = torch.as_tensor(np.asarray(choice), dtype=torch.int32).to(points.device)
-    if choice.numel() != npoints or int(choice.min()) < 0 or int(choice.max()) >= point_all:
+    choice = np.asarray(choice)
+    if choice.size != npoints or choice.min() < 0 or choice.max() >= point_all:
         raise RuntimeError("resample: choice must hold npoints indices in [0, point_all)")
+    choice = torch.from_numpy(choice.astype(np.int32)).to(points.device)
     pos = torch.empty(B, npoints, 3, dtype=torch.float32, device=points.device)
     x = torch.empty(B, in_channels, npoints, dtype=torch.float32, device=points.device)
-    if not points.is_cuda:
-        raise RuntimeError("adaptpoint_amd.gan.resample needs CUDA/HIP tensors: the product path has "
-                           "no CPU fallback")
-    _lib.load()
-    _call("apn_resample_points", points.device, B, N, C, point_all, npoints, in_channels,
-          points.data_ptr(), fidx.data_ptr(), choice.data_ptr(), pos.data_ptr(), x.data_ptr())
+    ops.resample_points_wrapper(B, N, C, point_all, npoints, in_channels, points, fidx, choice, pos, x)
     return pos, x
 
 

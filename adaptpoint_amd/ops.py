@@ -19,6 +19,7 @@ __all__ = [
     "gather_points_wrapper", "gather_points_grad_wrapper",
     "furthest_point_sampling_wrapper", "three_nn_wrapper",
     "three_interpolate_wrapper", "three_interpolate_grad_wrapper",
+    "resample_points_wrapper",
 ]
 
 
@@ -138,3 +139,18 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     _chk(grad_points, "grad_points", f32, b * c * m, dev)
     _launch("apn_three_interpolate_grad", dev, b, c, n, m,
             grad_out.data_ptr(), idx.data_ptr(), weight.data_ptr(), grad_points.data_ptr())
+
+
+# ---- operators of this build that the reference extension does not have (same calling style) ----
+def resample_points_wrapper(b, n, c, p_all, s_cnt, cx, points, fidx, choice, pos, x):
+    """The training loop's resampler (examples/classification/train_autoaug.py:493-501) in one
+    launch: pos (B,s_cnt,3) = points[b, fidx[b, choice[s]], :3], x (B,cx,s_cnt) = its first cx
+    channels, channel-major.  points (B,N,C), fidx (B,p_all) int32, choice (s_cnt) int32."""
+    dev = _chk(points, "points", f32, b * n * c)
+    _chk(fidx, "fidx", i32, b * p_all, dev)
+    _chk(choice, "choice", i32, s_cnt, dev)
+    _chk(pos, "pos", f32, b * s_cnt * 3, dev)
+    _chk(x, "x", f32, b * cx * s_cnt, dev)
+    _launch("apn_resample_points", dev, b, n, c, p_all, s_cnt, cx, points.data_ptr(), fidx.data_ptr(),
+            choice.data_ptr(), pos.data_ptr(), x.data_ptr())
+    return 1

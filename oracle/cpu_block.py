@@ -1,6 +1,6 @@
 """oracle/cpu_block.py -- TEST INFRASTRUCTURE, NOT PRODUCT.
 
-`CpuOps` stands the C oracle in for the HIP extension at the level of the nine
+`CpuOps` stands the C oracle in for the HIP extension at the level of the
 `adaptpoint_amd.ops.*_wrapper` functions (the Python face of the C ABI): inside the context
 every host-side module of the product -- the operator layer, SetAbstraction, the PointNeXt-S
 classifier, the imitator, the discriminator, the training steps -- runs on CPU tensors exactly as
@@ -73,7 +73,15 @@ def _three_interpolate_grad(b, c, n, m, grad_out, idx, weight, grad_points):
     grad_points.add_(torch.from_numpy(O.three_interpolate_grad(_np(grad_out), _np(idx), _np(weight), m)))
 
 
+def _resample_points(b, n, c, p_all, s_cnt, cx, points, fidx, choice, pos, x):
+    po, xo = O.resample_points(_np(points), _np(fidx), _np(choice), cx)
+    _put(pos, po)
+    _put(x, xo)
+    return 1
+
+
 _WRAPPERS = {
+    "resample_points_wrapper": _resample_points,
     "ball_query_wrapper": _ball_query,
     "group_points_wrapper": _group_points,
     "group_points_grad_wrapper": _group_points_grad,

@@ -171,6 +171,16 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return gp
 
 
+def resample_points(points, fidx, choice, cx):
+    """examples/classification/train_autoaug.py:493-501: keep the FPS picks `choice` selects
+    (one draw for the whole batch), gather the rows, split into pos (B,S,3) and x (B,cx,S)."""
+    points = np.asarray(points, dtype=np.float32)
+    sel = np.asarray(fidx)[:, np.asarray(choice)].astype(np.int64)              # :495-496
+    rows = np.take_along_axis(points, sel[..., None].repeat(points.shape[-1], -1), 1)   # :497-498
+    return (np.ascontiguousarray(rows[:, :, :3]),                               # :500
+            np.ascontiguousarray(rows[:, :, :cx].transpose(0, 2, 1)))           # :501
+
+
 # --- SURVEY section 8(f) row 1: PointsetGrouper's grouping stage (numpy, float32) ---------------
 
 def pointset_group_max(points, idx, fidx, alpha, beta):

@@ -36,3 +36,22 @@ def dev():
     from adaptpoint_amd import _lib
     _lib.load()
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def golden_ap():
+    """G9-G13: the AdaptPoint half (generator, discriminator, the two training steps)."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "adaptpoint_golden.npz"))
+
+
+@pytest.fixture
+def cpu_mirrors(monkeypatch):
+    """The product's host-side modules on CPU tensors: the C oracle stands in for the extension
+    underneath `adaptpoint_amd.ops` (oracle/cpu_block.py) and the reference's composition for the
+    attention core, which otherwise refuses CPU tensors.  Modules must be built with fused=False."""
+    from oracle import cpu_block as CB
+    from adaptpoint_amd import attention as A
+    monkeypatch.setattr(A, "attention", A._reference)
+    with CB.CpuOps():
+        yield

@@ -24,6 +24,14 @@ observable here), else the seed is rejected.
 
 Fixtures store OUTPUTS (and small state_dicts); inputs are regenerated from
 seeds by tests/golden_inputs.py.
+
+    python tests/golden/make_golden.py [all | pointnet2 | adaptpoint]
+
+`pointnet2` writes pointnet2_golden.npz (G1-G8: operators, SetAbstraction, the PointNeXt-S
+classifier, the imitator's grouper / attention / predictor network); `adaptpoint` writes
+adaptpoint_golden.npz (G9-G13: the generator with pinned random draws, the discriminator, one
+`train_gan` iteration and one `train_one_epoch` iteration replayed statement for statement over
+the reference's modules, three_interpolation and KNNGroup).
 """
 import os
 import sys
@@ -146,7 +154,12 @@ class _OracleOps:
                                                w.detach().numpy(), ctx.m)), None, None
 
 
+_imported = []
+
+
 def import_reference():
+    if _imported:
+        return _imported[0]
     _stub_modules()
     sys.path.insert(0, REF)
     import openpoints.models.layers.group as ref_group
@@ -155,7 +168,8 @@ def import_reference():
     ref_group.ball_query = _OracleOps.ball_query
     ref_group.grouping_operation = _OracleOps._Group.apply
     ref_pointnext.furthest_point_sample = _OracleOps.furthest_point_sample
-    return ref_group, ref_pointnext, ref_pointmlp
+    _imported.append((ref_group, ref_pointnext, ref_pointmlp))
+    return _imported[0]
 
 
 def all_variants_equal(fn):
@@ -352,5 +366,253 @@ def main():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
 
 
+# =====================================================================================
+# G9-G13: the AdaptPoint half (BASELINE configs[3]) -> tests/golden/adaptpoint_golden.npz
+# =====================================================================================
+MASK_MARGIN = 5e-3     # every point's Gumbel decision must clear this, so that a GPU run whose mask
+                       # logits differ by rounding picks the same mask (seeds that do not are rejected)
+
+
+def _patch_generator_ops():
+    import openpoints.models_adaptpoint.generator_component4_15 as ref_gen
+    ref_gen.furthest_point_sample = _OracleOps.furthest_point_sample
+    ref_gen.ball_query = _OracleOps.ball_query
+    ref_gen.three_nn = _OracleOps.three_nn
+    ref_gen.three_interpolate = _OracleOps._Interp.apply
+    return ref_gen
+
+
+def _mask_margin(logits, seed):
+    """min over points of |(l0 + g0) - (l1 + g1)| for the Gumbel noise the reference draws FIRST
+    after torch.manual_seed(seed) (generator_component4_15.py:714)."""
+    torch.manual_seed(seed)
+    expo = torch.empty(logits.shape).exponential_()
+    z = logits - expo.log()
+    return (z[..., 0] - z[..., 1]).abs().min().item()
+
+
+def _seed_with_margin(run_logits, first_seed):
+    """Smallest seed >= first_seed whose mask decisions all clear MASK_MARGIN."""
+    for seed in range(first_seed, first_seed + 200):
+        if _mask_margin(run_logits(), seed) > MASK_MARGIN:
+            return seed
+    raise SystemExit("no seed clears the mask margin")
+
+
+def height_channel(pos):
+    """the 4th input channel of ScanObjectNN clouds: y - min y (dataset/scanobjectnn/scanobjectnn.py:95-96)."""
+    return pos[:, :, 1:2] - pos[:, :, 1:2].min(1, keepdim=True)[0]
+
+
+def _reference_classifier():
+    from easydict import EasyDict
+    import openpoints.models.classification.cls_base as ref_cls
+    import openpoints.models.backbone.pointnext as ref_pn
+    from adaptpoint_amd.pointnext import fill_parameters_by_name
+    enc = ref_pn.PointNextEncoder(in_channels=4, width=32, blocks=[1, 1, 1, 1, 1, 1],
+                                  strides=[1, 2, 2, 2, 2, 1], sa_layers=2, sa_use_res=True,
+                                  radius=0.15, radius_scaling=1.5, nsample=32, expansion=4,
+                                  aggr_args={'feature_type': 'dp_fj', 'reduction': 'max'},
+                                  group_args=EasyDict(NAME='ballquery', normalize_dp=True),
+                                  conv_args={'order': 'conv-norm-act'}, act_args={'act': 'relu'},
+                                  norm_args={'norm': 'bn'})
+    head = ref_cls.ClsHead(num_classes=15, in_channels=enc.out_channels, mlps=[512, 256],
+                           norm_args={'norm': 'bn1d'})
+    import openpoints.loss.build as ref_loss
+
+    class _Cls(torch.nn.Module):          # BaseCls (cls_base.py:13-39) without the registry/config machinery
+        def __init__(self):
+            super().__init__()
+            self.encoder, self.prediction = enc, head
+            self.criterion = ref_loss.SmoothCrossEntropy(label_smoothing=0.3)
+        def forward(self, data):
+            return self.prediction(self.encoder.forward_cls_feat(data))
+        def get_logits_loss(self, data, gt):
+            logits = self.forward(data)
+            return logits, self.criterion(logits, gt.long())
+    return fill_parameters_by_name(_Cls())
+
+
+def main_adaptpoint():
+    import_reference()
+    from easydict import EasyDict
+    from adaptpoint_amd.pointnext import fill_parameters_by_name
+    ref_gen = _patch_generator_ops()
+    import openpoints.models_adaptpoint.point_discriminator as ref_dis
+    import openpoints.function_adaptpoint.ganloss_cls as ref_fb
+    import openpoints.models.layers.upsampling as ref_up
+    import openpoints.models.layers.group as ref_group
+    out = {}
+
+    # ---- G9: the generator (AdaptPoint_Augmentor.forward, :134-181) with pinned RNG ---------------
+    gen = fill_parameters_by_name(ref_gen.AdaptPoint_Augmentor(w_num_anchor=4, w_sigma=0.5, w_R_range=10,
+                                                               w_S_range=3, w_T_range=0.25))
+    assert sum(q.numel() for q in gen.parameters()) == 5998062
+    gen.train()
+    g9_x = _t(GI.unit_sphere_cloud(2, 512, seed=91))
+    grabbed = {}
+    gen.predict_prob_layer.fuse_masking.register_forward_hook(
+        lambda mod, inp, outp: grabbed.__setitem__("logits", outp.detach().permute(0, 2, 1).clone()))
+
+    def g9_logits():
+        state = {k: v.clone() for k, v in gen.state_dict().items()}     # BN running buffers move in train mode
+        with torch.no_grad():
+            gen(g9_x)
+        gen.load_state_dict(state)
+        return grabbed["logits"]
+    g9_seed = _seed_with_margin(g9_logits, 9)
+    torch.manual_seed(g9_seed)
+    _, g9_new = gen(g9_x)
+    (g9_new * _t(GI.seeded_normal(tuple(g9_new.shape), seed=92))).sum().backward()
+    sac = gen.predict_prob_layer
+    out.update(g9_seed=np.array(g9_seed), g9_gen_out=g9_new.detach().numpy(),
+               g9_mask_logits=grabbed["logits"].numpy(),
+               g9_grad_embed_w=sac.embedding.net[0].weight.grad.numpy(),
+               g9_grad_prob_head_w=sac.head.prob_head[0].weight.grad.numpy(),
+               g9_grad_mask_local_w=sac.extract_local_feat_masking[0].weight.grad.numpy())
+    print(f"G9: generator golden at seed {g9_seed}; masked points: "
+          f"{int((g9_new.detach().abs().sum(-1) == 0).sum())} of {g9_new.shape[0] * g9_new.shape[1]}")
+
+    # ---- G10: the discriminator (PointDiscriminator1, point_discriminator.py:17-73) ------------------
+    dis = fill_parameters_by_name(ref_dis.PointDiscriminator1(num_classes=15, normal_channel=False))
+    assert sum(q.numel() for q in dis.parameters()) == 800671
+    out["g10_state_keys"] = np.array(sorted(dis.state_dict().keys()))
+    for mod in dis.modules():              # dropout draws from the device generator: off for the goldens
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    dis.eval()
+    g10_x = _t(GI.unit_sphere_cloud(2, 512, seed=101))
+    with torch.no_grad():
+        out["g10_dis_eval"] = dis(g10_x).numpy()
+    dis.train()
+    xg = g10_x.clone().requires_grad_(True)
+    d_out = dis(xg)                        # one power iteration per spectral-normed layer
+    (d_out * _t(np.array([[1.0], [-2.0]], np.float32))).sum().backward()
+    out.update(g10_dis_train=d_out.detach().numpy(), g10_grad_x=xg.grad.numpy(),
+               g10_grad_conv0=dis.sa1.mlp_convs[0].parametrizations.weight.original.grad.numpy(),
+               g10_u_fc1=dis.fc1.parametrizations.weight[0]._u.detach().numpy())
+
+    # ---- G11: one train_gan iteration (train_autoaug.py:133-204) at B=2 ------------------------------
+    gen = fill_parameters_by_name(ref_gen.AdaptPoint_Augmentor())
+    dis = fill_parameters_by_name(ref_dis.PointDiscriminator1(num_classes=15, normal_channel=False))
+    for mod in dis.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    cls = _reference_classifier()
+    pos = _t(GI.unit_sphere_cloud(2, 512, seed=111))
+    points = torch.cat([pos, height_channel(pos)], -1)                      # (2,512,4)
+    label = torch.tensor([3, 11])
+    cfg = EasyDict(criterion_args=dict(NAME='SmoothCrossEntropy', label_smoothing=0.3),
+                   adaptpoint_params=dict(hardratio_s=3, hardratio=3), epochs=300,
+                   model=dict(in_channels=4))
+
+    class _Quiet:                          # SummaryWriter / Summary stand-ins (ganloss_cls.py:61-64)
+        train_iter_num = 0
+        def add_scalar(self, *a, **k):
+            pass
+    opt_g = torch.optim.Adam(gen.parameters(), lr=1e-4, betas=(0.5, 0.999))      # pointnext-s_adaptpoint_1.yaml:63-71
+    opt_d = torch.optim.Adam(dis.parameters(), lr=4e-4, betas=(0.5, 0.999))
+    bce = torch.nn.BCELoss()
+    gen.train(); dis.train(); cls.eval()
+    gen.predict_prob_layer.fuse_masking.register_forward_hook(
+        lambda mod, inp, outp: grabbed.__setitem__("logits", outp.detach().permute(0, 2, 1).clone()))
+
+    def g11_logits():
+        state = {k: v.clone() for k, v in gen.state_dict().items()}
+        with torch.no_grad():
+            gen(points[:, :, :3].contiguous())
+        gen.load_state_dict(state)
+        return grabbed["logits"]
+    g11_seed = _seed_with_margin(g11_logits, 11)
+    torch.manual_seed(g11_seed)
+    # -- the body of the loop, statement for statement (without .cuda(), PointWOLF's dump and logging)
+    points_clone = points.clone()
+    input_pointcloud = points[:, :, :3].contiguous()
+    real_label = torch.full((2, 1), 0.9)
+    fake_label = torch.full((2, 1), 0.1)
+    _, gen_imgs = gen(input_pointcloud)
+    g_loss_raw = bce(dis(gen_imgs), real_label)
+    points[:, :, :3] = gen_imgs
+    data_fake = {'pos': points[:, :, :3].contiguous(), 'y': label,
+                 'x': points[:, :, :4].transpose(1, 2).contiguous()}
+    data_real = {'pos': points_clone[:, :, :3].contiguous(), 'y': label,
+                 'x': points_clone[:, :, :4].transpose(1, 2).contiguous()}
+    feedback = ref_fb.get_feedback_loss_ver1(cfg=cfg, model_pointcloud=cls, data_real=data_real,
+                                             data_fake=data_fake, epoch=7, summary=_Quiet(), writer=_Quiet())
+    g_loss = g_loss_raw + feedback * 1
+    opt_g.zero_grad()
+    g_loss.backward()
+    g11_grad_embed = gen.predict_prob_layer.embedding.net[0].weight.grad.clone()
+    g11_grad_head = gen.predict_prob_layer.head.prob_head[0].weight.grad.clone()
+    opt_g.step()
+    real_loss = bce(dis(input_pointcloud), real_label)
+    fake_loss = bce(dis(gen_imgs.detach()), fake_label)
+    d_loss = (real_loss + fake_loss) / 2
+    opt_d.zero_grad()
+    d_loss.backward()
+    g11_grad_fc3 = dis.fc3.parametrizations.weight.original.grad.clone()
+    opt_d.step()
+    out.update(g11_seed=np.array(g11_seed), g11_gen=gen_imgs.detach().numpy(),
+               g11_losses=np.array([g_loss_raw.item(), feedback.item(), g_loss.item(), d_loss.item()]),
+               g11_grad_embed_w=g11_grad_embed.numpy(), g11_grad_prob_head_w=g11_grad_head.numpy(),
+               g11_grad_fc3=g11_grad_fc3.numpy(),
+               g11_embed_w_after=gen.predict_prob_layer.embedding.net[0].weight.detach().numpy(),
+               g11_fc3_after=dis.fc3.parametrizations.weight.original.detach().numpy())
+    print(f"G11: joint step golden at seed {g11_seed}: g_raw {g_loss_raw.item():.5f} feedback "
+          f"{feedback.item():.5f} d {d_loss.item():.5f}")
+
+    # ---- G12: a12 three_interpolation (upsampling.py:92-102) and a14 KNNGroup (group.py:275-320) -----
+    ref_up.three_nn = _OracleOps.three_nn
+    ref_up.three_interpolate = _OracleOps._Interp.apply
+    xyz = GI.config1_xyz()
+    known = GI.take_points(xyz, O.furthest_point_sampling(xyz, 256))
+    feat = _t(GI.seeded_normal((2, 48, 256), seed=121)).requires_grad_(True)
+    up = ref_up.three_interpolation(_t(xyz), _t(known), feat)
+    (up * _t(GI.seeded_normal(tuple(up.shape), seed=122))).sum().backward()
+    out.update(g12_interp=up.detach().numpy(), g12_interp_grad=feat.grad.numpy())
+    knn = ref_group.KNNGroup(nsample=8, relative_xyz=True, normalize_dp=True)
+    feats = _t(GI.seeded_normal((2, 16, 1024), seed=123))
+    dpk, fjk = knn(_t(known[:, :64]), _t(xyz), feats)
+    out.update(g12_knn_dp=dpk.numpy(), g12_knn_fj=fjk.numpy())
+
+    # ---- G13: one train_one_epoch iteration (train_autoaug.py:471-512): resampler + classifier step ---
+    import openpoints.models.backbone.pointnext as ref_pn     # furthest_point_sample already patched
+    cls = _reference_classifier()
+    for mod in cls.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    cls.train()
+    pos2k = _t(GI.unit_sphere_cloud(2, 2048, seed=131))
+    points = torch.cat([pos2k, height_channel(pos2k)], -1)                    # (2,2048,4)
+    target = torch.tensor([5, 14])
+    opt = torch.optim.AdamW(cls.parameters(), lr=2e-3, weight_decay=0.05)       # default.yaml:41-46
+    npoints, point_all = 1024, 1200
+    np.random.seed(13)
+    fps_idx = _OracleOps.furthest_point_sample(points[:, :, :3].contiguous(), point_all)
+    choice = np.random.choice(point_all, npoints, False)
+    fps_idx = fps_idx[:, choice]
+    points = torch.gather(points, 1, fps_idx.unsqueeze(-1).long().expand(-1, -1, points.shape[-1]))
+    data = {'pos': points[:, :, :3].contiguous(), 'x': points[:, :, :4].transpose(1, 2).contiguous()}
+    logits, loss = cls.get_logits_loss(data, target)
+    loss.backward()
+    gnorm = torch.nn.utils.clip_grad_norm_(cls.parameters(), 10, norm_type=2)
+    opt.step()
+    cls.zero_grad()
+    out.update(g13_choice=choice.astype(np.int32), g13_pos=data['pos'].numpy(), g13_x=data['x'].numpy(),
+               g13_logits=logits.detach().numpy(), g13_loss=np.array(loss.item()),
+               g13_grad_norm=np.array(gnorm.item()),
+               g13_head_w_after=cls.prediction.head[-1][0].weight.detach().numpy(),
+               g13_bn1_mean_after=cls.encoder.encoder[1][0].convs[0][1].running_mean.numpy())
+    print(f"G13: classifier step golden: loss {loss.item():.5f}, grad norm {gnorm.item():.4f}")
+
+    path = os.path.join(HERE, "adaptpoint_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "pointnet2"):
+        main()
+    if what in ("all", "adaptpoint"):
+        main_adaptpoint()

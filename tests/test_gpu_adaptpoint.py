@@ -1,0 +1,231 @@
+"""GPU: the AdaptPoint half of the hot path (BASELINE configs[3], and configs[2]'s training
+step) through the extension and the fused operators, against the goldens the REFERENCE's modules
+and trainer statements produced (tests/golden/make_golden.py, G9-G13).
+
+Bars.  Index / copy operators: bit-exact.  Networks: the goldens are torch-CPU float32; on the GPU
+the same float32 layers run in MIOpen / rocBLAS with other summation orders, through ~40 layers
+with training-mode BatchNorm over 2 clouds -- the observed agreement is printed by every test and
+the bars below sit a small factor above it.  The random draws of the generator are replayed
+(`draw_noise` after the golden's seed), and every mask decision of the goldens clears a margin
+(make_golden.MASK_MARGIN), so the discrete part of the output must agree exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as GI
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, ref):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return float(np.abs(a - ref).max() / max(1e-12, np.abs(ref).max()))
+
+
+def height_channel(pos):
+    return pos[:, :, 1:2] - pos[:, :, 1:2].min(1, keepdim=True)[0]
+
+
+def no_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+# ------------------------------------------------------------------ resampler (a22 / 8f row 3)
+def test_resampler_matches_reference_statements(dev, golden_ap):
+    from adaptpoint_amd.gan import resample
+    pos = torch.from_numpy(GI.unit_sphere_cloud(2, 2048, seed=131))
+    points = torch.cat([pos, height_channel(pos)], -1).to(dev)
+    p1, x1 = resample(points, 1024, 4, golden_ap["g13_choice"])
+    assert np.array_equal(p1.cpu().numpy(), golden_ap["g13_pos"])
+    assert np.array_equal(x1.cpu().numpy(), golden_ap["g13_x"])
+
+
+@pytest.mark.parametrize("B,N,C,cx", [(32, 2048, 4, 4), (3, 1500, 7, 5), (1, 1201, 3, 3), (2, 5000, 8, 0)])
+def test_resampler_vs_oracle(dev, oracle, B, N, C, cx):
+    from adaptpoint_amd import ops
+    pts = GI.seeded_normal((B, N, C), seed=7 + B)
+    fidx = oracle.furthest_point_sampling(np.ascontiguousarray(pts[:, :, :3]), min(1200, N))
+    choice = np.random.RandomState(B).choice(fidx.shape[1], min(1024, fidx.shape[1]), False).astype(np.int32)
+    s = choice.size
+    pos = torch.full((B, s, 3), 7.0, device=dev)
+    x = torch.full((B, max(cx, 1), s), 7.0, device=dev)
+    ops.resample_points_wrapper(B, N, C, fidx.shape[1], s, cx, torch.from_numpy(pts).to(dev),
+                                torch.from_numpy(fidx).to(dev), torch.from_numpy(choice).to(dev), pos, x)
+    po, xo = oracle.resample_points(pts, fidx, choice, cx)
+    assert np.array_equal(pos.cpu().numpy(), po)
+    if cx:
+        assert np.array_equal(x.cpu().numpy(), xo)
+    else:
+        assert (x == 7.0).all()
+
+
+# ------------------------------------------------------------------ a12 / a14
+def test_three_interpolation_and_knn_grouper(dev, golden_ap, oracle):
+    from adaptpoint_amd.layers import KnnGrouper, three_interpolation
+    xyz = GI.config1_xyz()
+    known = GI.take_points(xyz, oracle.furthest_point_sampling(xyz, 256))
+    feat = torch.from_numpy(GI.seeded_normal((2, 48, 256), seed=121)).to(dev).requires_grad_(True)
+    up = three_interpolation(torch.from_numpy(xyz).to(dev), torch.from_numpy(known).to(dev), feat)
+    (up * torch.from_numpy(GI.seeded_normal(tuple(up.shape), seed=122)).to(dev)).sum().backward()
+    np.testing.assert_allclose(up.detach().cpu().numpy(), golden_ap["g12_interp"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), golden_ap["g12_interp_grad"], rtol=1e-5, atol=1e-5)
+    feats = torch.from_numpy(GI.seeded_normal((2, 16, 1024), seed=123)).to(dev)
+    dp, fj = KnnGrouper(8, normalize_dp=True)(torch.from_numpy(known[:, :64]).to(dev),
+                                              torch.from_numpy(xyz).to(dev), feats)
+    # cdist on the GPU may order two near-equal distances differently: compare as neighbour SETS
+    ref_fj = golden_ap["g12_knn_fj"]
+    got = np.sort(fj.cpu().numpy(), axis=-1)
+    same = (got == np.sort(ref_fj, axis=-1)).all(axis=(1, 3))          # per (cloud, query)
+    assert same.mean() >= 0.98, same.mean()
+    assert rel(dp.abs().amax(dim=(1, 2, 3)), np.abs(golden_ap["g12_knn_dp"]).max(axis=(1, 2, 3))) < 1e-5
+
+
+# ------------------------------------------------------------------ a19: the generator
+def _generator(dev, fused):
+    from adaptpoint_amd.augmentor import AdaptPointAugmentor
+    from adaptpoint_amd.pointnext import fill_parameters_by_name
+    return fill_parameters_by_name(AdaptPointAugmentor(fused=fused)).to(dev).train()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_generator_matches_reference(dev, golden_ap, fused):
+    from adaptpoint_amd.augmentor import draw_noise
+    g = _generator(dev, fused)
+    x = torch.from_numpy(GI.unit_sphere_cloud(2, 512, seed=91)).to(dev)
+    torch.manual_seed(int(golden_ap["g9_seed"]))
+    noise = draw_noise(2, 512, 4, with_gumbel=True)           # the golden's draws, replayed from the CPU generator
+    logits = {}
+    g.predict_prob_layer.fuse_masking.register_forward_hook(
+        lambda m, i, o: logits.__setitem__("v", o.detach().permute(0, 2, 1)))
+    _, out = g(x, noise)
+    (out * torch.from_numpy(GI.seeded_normal((2, 512, 3), seed=92)).to(dev)).sum().backward()
+    ref = golden_ap["g9_gen_out"]
+    e_log = float(np.abs(logits["v"].cpu().numpy() - golden_ap["g9_mask_logits"]).max())
+    sac = g.predict_prob_layer
+    errs = dict(out=rel(out, ref), logits_abs=e_log,
+                embed=rel(sac.embedding.net[0].weight.grad, golden_ap["g9_grad_embed_w"]),
+                head=rel(sac.head.prob_head[0].weight.grad, golden_ap["g9_grad_prob_head_w"]),
+                mask=rel(sac.extract_local_feat_masking[0].weight.grad, golden_ap["g9_grad_mask_local_w"]))
+    print("generator vs reference golden (fused=%s):" % fused, {k: "%.2e" % v for k, v in errs.items()})
+    assert e_log < 2.5e-3                                         # half the margin every decision clears
+    assert np.array_equal(out.detach().abs().sum(-1).cpu().numpy() == 0, np.abs(ref).sum(-1) == 0)
+    assert errs["out"] < 2e-3
+    assert errs["embed"] < 5e-2 and errs["head"] < 5e-2 and errs["mask"] < 5e-2
+
+
+def test_generator_own_draws_are_valid(dev):
+    """Without a `noise` argument the module draws like the reference (Gumbel on the device
+    generator, the rest on the CPU generator): output inside the unit sphere, masked points at
+    the origin, both outcomes of the mask present."""
+    g = _generator(dev, True)
+    x = torch.from_numpy(GI.unit_sphere_cloud(4, 1024, seed=5)).to(dev)
+    src, out = g(x)
+    assert src.shape == out.shape == (4, 1024, 3) and torch.isfinite(out).all()
+    norms = out.norm(dim=-1)
+    assert float(norms.max()) < 1.0
+    masked = (norms == 0).float().mean().item()
+    assert 0.02 < masked < 0.98
+
+
+# ------------------------------------------------------------------ a20: the discriminator
+def test_discriminator_matches_reference(dev, golden_ap):
+    from adaptpoint_amd.discriminator import PointDiscriminator1
+    from adaptpoint_amd.pointnext import fill_parameters_by_name
+    d = no_dropout(fill_parameters_by_name(PointDiscriminator1(num_classes=15))).to(dev)
+    x = torch.from_numpy(GI.unit_sphere_cloud(2, 512, seed=101)).to(dev)
+    d.eval()
+    with torch.no_grad():
+        e0 = rel(d(x), golden_ap["g10_dis_eval"])
+    d.train()
+    xg = x.clone().requires_grad_(True)
+    out = d(xg)
+    (out * torch.tensor([[1.0], [-2.0]], device=dev)).sum().backward()
+    errs = dict(eval=e0, train=rel(out, golden_ap["g10_dis_train"]), grad_x=rel(xg.grad, golden_ap["g10_grad_x"]),
+                conv0=rel(d.sa1.mlp_convs[0].parametrizations.weight.original.grad, golden_ap["g10_grad_conv0"]),
+                u=rel(d.fc1.parametrizations.weight[0]._u, golden_ap["g10_u_fc1"]))
+    print("discriminator vs reference golden:", {k: "%.2e" % v for k, v in errs.items()})
+    assert errs["eval"] < 1e-3 and errs["train"] < 1e-3 and errs["u"] < 1e-4
+    assert errs["grad_x"] < 2e-2 and errs["conv0"] < 2e-2
+
+
+# ------------------------------------------------------------------ a21: the joint step
+@pytest.mark.parametrize("fused", [True, False])
+def test_gan_step_matches_reference_trainer(dev, golden_ap, fused):
+    """One `train_gan` iteration at B=2: the gradient path classifier -> points -> generator
+    (group / interpolate gradients w.r.t. coordinates) runs end to end on the GPU."""
+    from adaptpoint_amd.augmentor import AdaptPointAugmentor, draw_noise
+    from adaptpoint_amd.discriminator import PointDiscriminator1
+    from adaptpoint_amd.gan import GanStep
+    from adaptpoint_amd.pointnext import PointNextSClassifier, SmoothCrossEntropy, fill_parameters_by_name
+    G = fill_parameters_by_name(AdaptPointAugmentor(fused=fused)).to(dev)
+    D = no_dropout(fill_parameters_by_name(PointDiscriminator1(num_classes=15))).to(dev)
+    C = fill_parameters_by_name(PointNextSClassifier(fused=fused)).to(dev)
+    pos = torch.from_numpy(GI.unit_sphere_cloud(2, 512, seed=111))
+    points = torch.cat([pos, height_channel(pos)], -1).to(dev)
+    step = GanStep(G, D, C, SmoothCrossEntropy(0.3))
+    grads = {}
+    G.predict_prob_layer.embedding.net[0].weight.register_hook(lambda g: grads.__setitem__("embed", g.clone()))
+    G.predict_prob_layer.head.prob_head[0].weight.register_hook(lambda g: grads.__setitem__("head", g.clone()))
+    D.fc3.parametrizations.weight.original.register_hook(lambda g: grads.__setitem__("fc3", g.clone()))
+    torch.manual_seed(int(golden_ap["g11_seed"]))
+    res = step(points, torch.tensor([3, 11], device=dev), noise=draw_noise(2, 512, 4, with_gumbel=True))
+    ref = golden_ap["g11_gen"]
+    got = np.array([res[k].item() for k in ("g_loss_raw", "feedback_loss", "g_loss", "d_loss")])
+    errs = dict(gen=rel(res["gen"], ref), losses=float(np.abs(got / golden_ap["g11_losses"] - 1).max()),
+                embed=rel(grads["embed"], golden_ap["g11_grad_embed_w"]),
+                head=rel(grads["head"], golden_ap["g11_grad_prob_head_w"]),
+                fc3=rel(grads["fc3"], golden_ap["g11_grad_fc3"]))
+    print("train_gan step vs reference golden (fused=%s):" % fused, {k: "%.2e" % v for k, v in errs.items()})
+    assert np.array_equal(res["gen"].abs().sum(-1).cpu().numpy() == 0, np.abs(ref).sum(-1) == 0)
+    assert errs["gen"] < 2e-3 and errs["losses"] < 5e-3
+    assert errs["embed"] < 5e-2 and errs["head"] < 5e-2 and errs["fc3"] < 2e-2
+    # Adam's first step moves every weight by lr * sign(grad): the updated tensors agree wherever the sign does
+    after = G.predict_prob_layer.embedding.net[0].weight.detach().cpu().numpy()
+    assert (np.abs(after - golden_ap["g11_embed_w_after"]) < 1e-5).mean() > 0.97
+    after = D.fc3.parametrizations.weight.original.detach().cpu().numpy()
+    assert (np.abs(after - golden_ap["g11_fc3_after"]) < 1e-5).mean() > 0.97
+
+
+def test_gan_step_full_size_runs(dev):
+    """BASELINE configs[3] at its own size (B=32, N=1024): finite losses, a moving generator."""
+    from adaptpoint_amd.augmentor import AdaptPointAugmentor
+    from adaptpoint_amd.discriminator import PointDiscriminator1
+    from adaptpoint_amd.gan import GanStep
+    from adaptpoint_amd.pointnext import PointNextSClassifier, SmoothCrossEntropy
+    torch.manual_seed(0)
+    G, D = AdaptPointAugmentor().to(dev), PointDiscriminator1(num_classes=15).to(dev)
+    C = PointNextSClassifier(fused=True).to(dev)
+    pos = torch.from_numpy(GI.unit_sphere_cloud(32, 1024, seed=3))
+    points = torch.cat([pos, height_channel(pos)], -1).to(dev)
+    label = torch.arange(32, device=dev) % 15
+    step = GanStep(G, D, C, SmoothCrossEntropy(0.3))
+    w0 = G.predict_prob_layer.embedding.net[0].weight.detach().clone()
+    for _ in range(2):
+        res = step(points, label)
+    for k in ("g_loss_raw", "feedback_loss", "g_loss", "d_loss"):
+        assert torch.isfinite(res[k]), k
+    assert not torch.equal(w0, G.predict_prob_layer.embedding.net[0].weight)
+    assert res["gen"].shape == (32, 1024, 3) and float(res["gen"].norm(dim=-1).max()) < 1.0
+
+
+# ------------------------------------------------------------------ a22: the classifier step
+@pytest.mark.parametrize("fused", [True, False])
+def test_classifier_step_matches_reference_trainer(dev, golden_ap, fused):
+    from adaptpoint_amd.gan import ClassifierStep
+    from adaptpoint_amd.pointnext import PointNextSClassifier, fill_parameters_by_name
+    pos = torch.from_numpy(GI.unit_sphere_cloud(2, 2048, seed=131))
+    points = torch.cat([pos, height_channel(pos)], -1).to(dev)
+    m = no_dropout(fill_parameters_by_name(PointNextSClassifier(fused=fused))).to(dev)
+    logits, loss = ClassifierStep(m)(points, torch.tensor([5, 14], device=dev), choice=golden_ap["g13_choice"])
+    errs = dict(logits=rel(logits, golden_ap["g13_logits"]), loss=abs(loss.item() / float(golden_ap["g13_loss"]) - 1),
+                bn=rel(m.encoder.encoder[1][0].convs[0][1].running_mean, golden_ap["g13_bn1_mean_after"]))
+    after = m.prediction.head[-1][0].weight.detach().cpu().numpy()
+    errs["head_sign_agree"] = float((np.abs(after - golden_ap["g13_head_w_after"]) < 1e-4).mean())
+    print("train_one_epoch step vs reference golden (fused=%s):" % fused, {k: "%.2e" % v for k, v in errs.items()})
+    assert errs["logits"] < 2e-2 and errs["loss"] < 5e-3 and errs["bn"] < 2e-3
+    assert errs["head_sign_agree"] > 0.95

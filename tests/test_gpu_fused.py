@@ -357,3 +357,153 @@ def test_full_size_batch_is_cloud_independent_in_eval_mode(dev):
             np_i, out_i = blk([p[i:i + 1].contiguous(), f[i:i + 1].contiguous()])
             assert torch.equal(np_i[0], new_p[i])
             assert torch.equal(out_i[0], out[i])
+
+
+SA_KW = dict(layers=2, stride=2, group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32,
+                                             'normalize_dp': True},
+             norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+             use_res=True)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_set_abstraction_matches_reference_golden_on_gpu(dev, golden, fused):
+    """G4: the REFERENCE's SetAbstraction (openpoints/models/backbone/pointnext.py:82-170, run in the
+    build container over the oracle operators) against this block on the GPU, unfused (nine
+    extension operators + PyTorch conv/BN) and fused, with the reference's state_dict."""
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    blk = SetAbstraction(32, 64, fused=fused, **SA_KW).to(dev)
+    blk.load_state_dict({k.split("/", 1)[1]: torch.from_numpy(golden[k]) for k in golden.files
+                         if k.startswith("g4_sa_state/")})
+    blk.train()
+    p = torch.from_numpy(GI.unit_sphere_cloud(2, 1024, seed=3)).to(dev)
+    f = torch.from_numpy(GI.seeded_normal((2, 32, 1024), seed=4)).to(dev).requires_grad_(True)
+    new_p, out = blk([p, f])
+    (out * torch.from_numpy(GI.seeded_normal(tuple(out.shape), seed=5)).to(dev)).sum().backward()
+    assert np.array_equal(new_p.cpu().numpy(), golden["g4_sa_new_p"])
+    ref_out, ref_gf = torch.from_numpy(golden["g4_sa_out"]), torch.from_numpy(golden["g4_sa_grad_f"])
+    e_out = float((out.detach().cpu() - ref_out).abs().max())
+    errs = {"out_max": e_out, "out_mean": float((out.detach().cpu() - ref_out).abs().mean()),
+            "grad_f_l2": _rel_l2(f.grad.cpu(), ref_gf)}
+    for k, prm in blk.named_parameters():
+        errs[k] = _rel_l2(prm.grad.cpu(), torch.from_numpy(golden["g4_sa_grad/" + k]))
+    print("SetAbstraction(fused=%s) vs reference golden:" % fused, {k: "%.2e" % v for k, v in errs.items()})
+    # unfused: fp32 everywhere (MIOpen's summation order); fused: split-bf16 MFMA (1e-5-level terms,
+    # a K-pool arg-max may flip between two neighbours closer than that)
+    assert errs["out_max"] <= 5e-3 and errs["out_mean"] <= 1e-4
+    assert all(v <= 1e-2 for k, v in errs.items() if k not in ("out_max", "out_mean")), errs
+
+
+def test_pool_flips_explain_the_gradient_residual(dev):
+    """VERDICT weak #3.  The split-operand (bf16x3) gradients through the K-pool differ from the
+    fp32 chain by ~2e-3 relative L2; the claim is that arg-max flips -- and nothing else -- cause it.
+    Test: mask the pooled positions whose two largest candidates lie closer than 1e-4 (where the
+    forward's ~1e-5 error can change the winner) out of the LOSS on both sides; what remains must
+    agree to 1e-5-level."""
+    from adaptpoint_amd import fused
+    from adaptpoint_amd.fused import grouped_mlp_max
+    from fused_reference import chain_grad
+    assert fused.PRECISION == "bf16x3"
+    p, new_p, f, idx, conv1, bn1, conv2, bn2 = _setup(dev, seed=5)
+    wts = torch.randn(4, 64, 512, device=dev, generator=torch.Generator(dev).manual_seed(9))
+    leaves = [t.detach().clone().requires_grad_(True) for t in
+              (p, new_p, f, conv1.weight.view(32, 35), bn1.weight, bn1.bias,
+               conv2.weight.view(64, 32), bn2.weight, bn2.bias)]
+    rp, rq, rf, rw1, rg1, rb1, rw2, rg2, rb2 = leaves
+    ref, mid = chain_grad(rp, rq, rf, idx, 0.15, rw1, rg1, rb1, rw2, rg2, rb2)
+    with torch.no_grad():      # z over K: gap between the best and the second best candidate
+        z = ((mid["y2"] - mid["m2"]) / torch.sqrt(mid["v2"] + 1e-5) * bn2.weight.double().view(1, -1, 1, 1)
+             + bn2.bias.double().view(1, -1, 1, 1))
+        top2 = z.topk(2, dim=-1).values
+        # duplicated neighbours (the ball-query fill) tie exactly: a flip between copies of the SAME
+        # point moves nothing, so only gaps between distinct values count
+        uniq_gap = torch.where(top2[..., 0] == top2[..., 1], torch.full_like(top2[..., 0], 1.0),
+                               top2[..., 0] - top2[..., 1])
+        keep = (uniq_gap > 1e-4).to(wts.dtype)
+    frac = 1.0 - keep.mean().item()
+    (ref * (wts * keep).double()).sum().backward()
+    p.requires_grad_(True); new_p.requires_grad_(True); f.requires_grad_(True)
+    out = grouped_mlp_max(p, new_p, f, idx, 0.15, conv1, bn1, conv2, bn2)
+    (out * wts * keep).sum().backward()
+    got = dict(f=f.grad, p=p.grad, newp=new_p.grad, w1=conv1.weight.grad.view(32, 35),
+               w2=conv2.weight.grad.view(64, 32), g1=bn1.weight.grad, b1=bn1.bias.grad,
+               g2=bn2.weight.grad, b2=bn2.bias.grad)
+    want = dict(f=rf.grad, p=rp.grad, newp=rq.grad, w1=rw1.grad, w2=rw2.grad, g1=rg1.grad, b1=rb1.grad,
+                g2=rg2.grad, b2=rb2.grad)
+    l2 = {k: _rel_l2(got[k], want[k]) for k in got}
+    print("masked %.3f%% of the pooled values; rel-L2 of the rest:" % (100 * frac), {k: "%.2e" % v for k, v in l2.items()})
+    assert frac < 0.02
+    for k, v in l2.items():
+        assert v <= 1e-4, (k, v)
+
+
+def test_syncbn_two_ranks_equal_one_double_batch(dev):
+    """ADVICE (high): SyncBatchNorm semantics of the fused block, checked numerically on one GPU.
+    Two "ranks" hold uneven shards (3 and 5 clouds) of one batch.  The block's statistics exchange
+    (`fused._allreduce_sum_`, four per step) is replaced by a replaying stub: pass k re-runs both
+    ranks with exchanges 0..k-1 returning the true global sums found by the earlier passes, and
+    records both ranks' local contribution to exchange k -- after five passes every exchange saw
+    what a real all-reduce would have delivered.  Property: outputs and input gradients equal the
+    single-process run on the concatenated batch with loss L0 + L1; parameter gradients, averaged
+    over the ranks as DistributedDataParallel does, equal that run's divided by the world size --
+    for the convolution weights AND the BatchNorm affine parameters (torch.nn.SyncBatchNorm keeps
+    those rank-local; the fused block reports global / world)."""
+    import copy
+    from adaptpoint_amd import fused
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    torch.manual_seed(12)
+    full = SetAbstraction(32, 64, fused=True, **SA_KW).to(dev)
+    state0 = copy.deepcopy(full.state_dict())
+    halves = [SetAbstraction(32, 64, fused=True, sync_bn=True, **SA_KW).to(dev) for _ in range(2)]
+    sizes = (3, 5)                                   # uneven shards: the count rides with the sums
+    p = torch.from_numpy(GI.unit_sphere_cloud(sum(sizes), 1024, seed=50)).to(dev)
+    f = torch.from_numpy(GI.seeded_normal((sum(sizes), 32, 1024), seed=51)).to(dev)
+    wts = torch.randn(sum(sizes), 64, 512, device=dev, generator=torch.Generator(dev).manual_seed(3))
+    f_full = f.clone().requires_grad_(True)
+    _, o_full = full([p, f_full])
+    (o_full * wts).sum().backward()
+
+    known, res = [], [None, None]
+
+    def stub_for(log):
+        def stub(t):
+            k = len(log)
+            log.append(t.clone())
+            if k < len(known):
+                t.copy_(known[k])
+        return stub
+
+    old = (fused._allreduce_sum_, fused.FORCE_PHASED)
+    try:
+        fused.FORCE_PHASED = True
+        for it in range(5):
+            logs = [[], []]
+            for rank in range(2):
+                lo = sum(sizes[:rank])
+                sl = slice(lo, lo + sizes[rank])
+                halves[rank].load_state_dict(copy.deepcopy(state0))
+                halves[rank].zero_grad(set_to_none=True)
+                fused._allreduce_sum_ = stub_for(logs[rank])
+                fi = f[sl].clone().requires_grad_(True)
+                _, o = halves[rank]([p[sl].contiguous(), fi])
+                (o * wts[sl]).sum().backward()
+                res[rank] = (o.detach(), fi.grad)
+                assert len(logs[rank]) == 4           # two exchanges per direction
+            if it < 4:
+                known.append(logs[0][it] + logs[1][it])
+    finally:
+        fused._allreduce_sum_, fused.FORCE_PHASED = old
+    # the reduced vectors carry {sums, global count, world size}
+    assert known[0].numel() == 64 + 2 and float(known[0][-1]) == 2.0
+    assert float(known[0][-2]) == sum(sizes) * 512 * 32
+    o_cat = torch.cat([res[0][0], res[1][0]])
+    g_cat = torch.cat([res[0][1], res[1][1]])
+    assert torch.allclose(o_cat, o_full, rtol=1e-5, atol=1e-5)
+    assert _rel(g_cat, f_full.grad) <= 1e-4
+    for (k, q), (_, q0), (_, q1) in zip(full.named_parameters(), halves[0].named_parameters(),
+                                        halves[1].named_parameters()):
+        ddp = (q0.grad + q1.grad) / 2             # what DDP's averaging leaves on every rank
+        assert _rel(ddp, q.grad / 2) <= 1e-3, k
+    for (k, b), (_, b0), (_, b1) in zip(full.named_buffers(), halves[0].named_buffers(),
+                                        halves[1].named_buffers()):
+        assert torch.allclose(b.float(), b0.float(), rtol=1e-5, atol=1e-6), k   # running stats: global
+        assert torch.equal(b0, b1), k
