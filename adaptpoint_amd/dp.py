@@ -123,3 +123,100 @@ def allreduce_mean_(tensors):
         views.append(flat[off:off + t.numel()].view_as(t))
         off += t.numel()
     torch._foreach_copy_(list(tensors), views)
+
+
+# ---------------------------------------------------------------------------------------------
+# SyncBatchNorm for the UNFUSED path, built for latency-bound links.
+#
+# The reference forces torch.nn.SyncBatchNorm at world_size > 1 (examples/classification/main.py:27,
+# train_autoaug.py:275-276).  That module all-GATHERS (mean, invstd, count) per layer and is
+# GPU-only.  The statistics exchange of a BatchNorm layer is two tiny vectors, so here it is ONE
+# all-reduce(SUM) of [sum, sum of squares, count] in the forward and ONE of [sum dy, sum dy*(x-mean)]
+# in the backward -- the same exchange the fused block performs (adaptpoint_amd.fused) -- on
+# whatever backend the process group has (RCCL over xGMI; gloo in the CPU tests).  Gradient
+# semantics are torch.nn.SyncBatchNorm's: dL/dx uses the global sums; dL/dgamma, dL/dbeta stay
+# rank-local and are averaged with the other parameters' gradients.
+# ---------------------------------------------------------------------------------------------
+def _sum_over_ranks_(t):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t)
+    return t
+
+
+class _SyncBNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        C = x.shape[1]
+        dims = [0] + list(range(2, x.dim()))
+        xd = x.double()
+        stat = torch.cat([xd.sum(dims), (xd * xd).sum(dims),
+                          torch.tensor([x.numel() // C], dtype=torch.float64, device=x.device)])
+        _sum_over_ranks_(stat)
+        count = stat[-1]
+        mean = stat[:C] / count
+        var = (stat[C:2 * C] / count - mean * mean).clamp_min_(0.0)
+        invstd = torch.rsqrt(var + eps)
+        shape = [1, C] + [1] * (x.dim() - 2)
+        xhat = ((xd - mean.view(shape)) * invstd.view(shape)).to(x.dtype)
+        ctx.save_for_backward(xhat, weight, invstd.to(x.dtype))
+        ctx.count, ctx.dims, ctx.shape = count, dims, shape
+        y = xhat if weight is None else xhat * weight.view(shape)
+        if bias is not None:
+            y = y + bias.view(shape)
+        ctx.mark_non_differentiable(mean, var, count)
+        return y, mean, var, count
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        xhat, weight, invstd = ctx.saved_tensors
+        C = xhat.shape[1]
+        shape, dims = ctx.shape, ctx.dims
+        dyd = dy.double()
+        local = torch.cat([dyd.sum(dims), (dyd * xhat.double()).sum(dims)])
+        g_weight = local[C:].to(dy.dtype) if weight is not None else None
+        g_bias = local[:C].to(dy.dtype)
+        glob = _sum_over_ranks_(local.clone())
+        m_dy = (glob[:C] / ctx.count).to(dy.dtype).view(shape)
+        m_dyx = (glob[C:] / ctx.count).to(dy.dtype).view(shape)
+        scale = invstd if weight is None else invstd * weight
+        dx = (dy - m_dy - xhat * m_dyx) * scale.view(shape)
+        return dx, g_weight, g_bias, None
+
+
+class SyncBatchNormAllReduce(torch.nn.modules.batchnorm._BatchNorm):
+    """Drop-in for BatchNorm1d/2d whose batch statistics span all ranks (see the note above)."""
+
+    def _check_input_dim(self, x):
+        if x.dim() < 2:
+            raise ValueError(f"expected at least 2D input (got {x.dim()}D)")
+
+    def forward(self, x):
+        if not (self.training or not self.track_running_stats):
+            return torch.nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight,
+                                                  self.bias, False, 0.0, self.eps)
+        y, mean, var, count = _SyncBNFn.apply(x, self.weight, self.bias, self.eps)
+        if self.training and self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                mom = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                unbiased = var * (count / (count - 1).clamp_min(1.0))
+                self.running_mean.mul_(1 - mom).add_(mean.to(self.running_mean.dtype), alpha=mom)
+                self.running_var.mul_(1 - mom).add_(unbiased.to(self.running_var.dtype), alpha=mom)
+        return y
+
+
+def convert_sync_batchnorm(module):
+    """Replace every BatchNorm1d/2d/3d under `module` by SyncBatchNormAllReduce (parameters and
+    buffers are shared, names unchanged), as torch.nn.SyncBatchNorm.convert_sync_batchnorm does."""
+    out = module
+    if isinstance(module, torch.nn.modules.batchnorm._BatchNorm) and not isinstance(module, SyncBatchNormAllReduce):
+        out = SyncBatchNormAllReduce(module.num_features, module.eps, module.momentum, module.affine,
+                                     module.track_running_stats)
+        if module.affine:
+            out.weight, out.bias = module.weight, module.bias
+        out.running_mean, out.running_var = module.running_mean, module.running_var
+        out.num_batches_tracked = module.num_batches_tracked
+        out.training = module.training
+    for name, child in module.named_children():
+        out.add_module(name, convert_sync_batchnorm(child))
+    return out

@@ -414,6 +414,15 @@ class Sampling:
         o += B * M * 3
         self.idx = self.buf[o:o + B * M * K].view(B, M, K)
 
+    def clouds(self, lo, hi):
+        """The index stage of clouds lo..hi-1 as a `Sampling`-like view (no copy): index stages of
+        several batches computed in ONE launch over the stacked clouds are handed out per batch."""
+        v = object.__new__(Sampling)
+        v.shape = (hi - lo,) + self.shape[1:]
+        v.buf = None
+        v.fidx, v.new_p, v.idx = self.fidx[lo:hi], self.new_p[lo:hi], self.idx[lo:hi]
+        return v
+
 
 @torch.no_grad()
 def sample_and_query(p, npoint, radius, nsample=K_NS, out=None):

@@ -16,7 +16,9 @@ weights.  A "step" is one such pass over one batch of 32 synthetic clouds per GP
 
 Multi-GPU: one process per GPU, batch sharded by cloud (weak scaling, 32 per
 GPU), SyncBatchNorm + gradient all-reduce over RCCL as the reference does at
-world_size > 1 (examples/classification/main.py:27, train_autoaug.py:275-282).
+world_size > 1 (examples/classification/main.py:27, train_autoaug.py:275-282):
+`--sync-bn auto` is ON at world_size > 1; the per-rank-BatchNorm figure (not what the
+reference runs) is reported beside it as `value_no_syncbn`.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description).
 """
@@ -49,11 +51,19 @@ def make_block(fused=False, sync_bn=False):
                           feature_type='dp_fj', use_res=True)
 
 
-def make_inputs(batch, seed):
+def make_inputs(batch, seed, distribution="D1"):
+    """SURVEY 8d: D1 = uniform cube, centred, scaled to the unit sphere (~9 neighbours in r=0.15);
+    D2 = unit-sphere surface + N(0, 0.01) jitter (scan-like, ~6)."""
     import golden_inputs as GI
-    p = torch.from_numpy(GI.unit_sphere_cloud(batch, N_PTS, seed=seed))
+    cloud = GI.unit_sphere_cloud if distribution == "D1" else GI.sphere_surface_cloud
+    p = torch.from_numpy(cloud(batch, N_PTS, seed=seed))
     f = torch.from_numpy(GI.seeded_normal((batch, C_IN, N_PTS), seed=seed + 7))
     return p, f
+
+
+# SURVEY 8d, per cloud through config 2 (fwd+bwd): compulsory HBM bytes and shared-MLP flops
+STEP_BYTES_PER_CLOUD = 14336 + 83968 + 346112 + 458752          # FPS + ball query + fused fwd + fused bwd
+STEP_FLOPS_PER_CLOUD = 3 * (2 * NPOINT * NSAMPLE * (35 * 32 + 32 * 64) + 2 * NPOINT * 32 * 64)
 
 
 # Algorithmic bytes one launch of each kernel must move (SURVEY.md section 8d, per cloud
@@ -149,127 +159,99 @@ def instrument(timer, only=None):
     return restore
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The oracle port of the same block on the host cores: bounded sample."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seconds_budget=14.0):
+    """The oracle port of the same block on the host cores: bounded samples, all threads and 1 thread."""
     from oracle import cpu_block as CB
     from oracle import oracle as O
     from adaptpoint_amd import dp
     threads = dp.host_threads(cap=64)            # affinity / cgroup aware, not os.cpu_count()
-    torch.set_num_threads(threads)
-    O.set_threads(threads)
-    torch.manual_seed(0)
-    blk = CB.build_cpu_block(make_block)
-    blk.train()
     p, f = make_inputs(B_PER_GPU, seed=0)
-    CB.run_step(blk, p, f)                       # warm-up (page-in, thread pools)
-    t0 = time.perf_counter()
-    iters = 0
-    while True:
-        CB.run_step(blk, p, f)
-        iters += 1
-        el = time.perf_counter() - t0
-        if el >= seconds_budget or iters >= 60:
-            break
-    return {"value": B_PER_GPU * iters / el, "unit": "point-clouds/s", "cores": threads,
-            "kind": "port",
-            "sample": f"{iters} fwd+bwd steps of the same block (B={B_PER_GPU}, N={N_PTS}, "
-                      f"npoint={NPOINT}, nsample={NSAMPLE}) after 1 warm-up: C oracle "
-                      f"(OpenMP, {threads} threads) for FPS/ball/group, torch-CPU "
-                      f"({torch.get_num_threads()} threads) for conv/BN/max; {el:.1f} s"}
+
+    def sample(nthreads, budget):
+        torch.set_num_threads(nthreads)
+        O.set_threads(nthreads)
+        torch.manual_seed(0)
+        blk = CB.build_cpu_block(make_block)
+        blk.train()
+        CB.run_step(blk, p, f)                   # warm-up (page-in, thread pools)
+        t0 = time.perf_counter()
+        iters = 0
+        while True:
+            CB.run_step(blk, p, f)
+            iters += 1
+            el = time.perf_counter() - t0
+            if el >= budget or iters >= 60:
+                return B_PER_GPU * iters / el, iters, el
+    v_all, it_all, el_all = sample(threads, seconds_budget * 0.6)
+    v_one, it_one, el_one = sample(1, seconds_budget * 0.4)
+    torch.set_num_threads(threads)
+    return {"value": v_all, "unit": "point-clouds/s", "cores": threads, "kind": "port",
+            "value_1_thread": v_one, "cpu_model": cpu_model(),
+            "sample": f"{it_all} fwd+bwd steps ({el_all:.1f} s) at {threads} threads and {it_one} "
+                      f"({el_one:.1f} s) at 1 thread of the same block (B={B_PER_GPU}, N={N_PTS}, "
+                      f"npoint={NPOINT}, nsample={NSAMPLE}), 1 warm-up each: C oracle (OpenMP) for "
+                      f"FPS/ball/group, torch-CPU for conv/BN/max"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="auto",
-                    help="BatchNorm statistics at world_size>1.  auto = off: per-rank statistics and "
-                         "ONE exchange per step, the gradient all-reduce BASELINE.json's north_star "
-                         "names; on: SyncBatchNorm as the reference forces "
-                         "(examples/classification/main.py:27), four more small all-reduces per step")
-    ap.add_argument("--backend", default="nccl")
-    ap.add_argument("--pipeline", choices=["on", "off"], default="on",
-                    help="software-pipeline the index stage: FPS + ball query of batch k+1 run on "
-                         "a second HIP stream beside the MLP forward+backward of batch k (the "
-                         "index stage depends on coordinates only); fused path only")
-    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the step from a captured HIP graph (auto: on at 1 GPU)")
-    ap.add_argument("--index-overlap", choices=["on", "off"], default="off",
-                    help="pipelined index stage: FPS of one batch and ball query of the previous one "
-                         "in ONE launch (on: 167 instead of 184 us per batch on the index stream) or "
-                         "back to back (off).  Off by default: while the MLP stream is the longer "
-                         "one, an always-busy sampler only slows the MLP kernels it shares CUs with "
-                         "(measured -3 %)")
-    ap.add_argument("--steps-per-graph", type=int, default=0,
-                    help="whole steps captured per hipGraph (0 = auto: the largest of 20, 10, 4, 2 dividing --steps, "
-                         "single GPU; warm-up is rounded up to whole replays; 1 = one step per replay)")
-    ap.add_argument("--mlp", choices=["fused-bf16x3", "fused-bf16", "torch-f32"], default="fused-bf16x3",
-                    help="grouped shared-MLP: fused bf16-MFMA kernels (csrc/sa_fused.hip) with split "
-                         "hi+lo operands (fp32-grade, default) or plain bf16 operands, or the unfused "
-                         "drop-in path (nine extension ops + PyTorch conv/BN in fp32)")
-    args = ap.parse_args()
+class Measured:
+    pass
 
+
+def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps, warmup):
+    """Build the block for one configuration, time `steps` steps per the contract, and return the
+    elapsed seconds plus the eager single-step closure (for the per-kernel passes)."""
     from adaptpoint_amd import dp
-    world, rank, local_rank = dp.env_world()
-    # APN_BENCH_FORCE_DISTRIBUTED=1: take the N>1 code path (process group, DDP, SyncBatchNorm
-    # phases, eager launch) even at world_size 1 -- lets a one-GPU box exercise it.
-    force_dist = os.environ.get("APN_BENCH_FORCE_DISTRIBUTED") == "1"
-    distributed = world > 1 or force_dist
-    if distributed and args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not distributed and args.gpus != 1:
-        raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
-
-    from adaptpoint_amd import _lib
-    _lib.load()                                   # the HIP extension or nothing
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dp.init(args.backend, dev, force=force_dist)
-    if force_dist:
-        from adaptpoint_amd import fused as _fused
-        _fused.FORCE_PHASED = True
-
+    r = Measured()
     torch.manual_seed(0)                          # identical initial weights on every rank
-    sync_bn = distributed and args.sync_bn == "on"
-    fused_mlp = args.mlp.startswith("fused")
+    fused_mlp = mlp.startswith("fused")
     if fused_mlp:
         from adaptpoint_amd import fused as _f
-        _f.PRECISION = args.mlp.split("-", 1)[1]
+        _f.PRECISION = mlp.split("-", 1)[1]
     blk = make_block(fused=fused_mlp, sync_bn=sync_bn).to(dev)
     blk.train()
-    if sync_bn and not fused_mlp:
-        blk = torch.nn.SyncBatchNorm.convert_sync_batchnorm(blk)
-    model = blk
     # Gradient exchange.  Without SyncBatchNorm forward+backward contain no collective, so the
     # step is the same captured hipGraph as at one GPU, followed by ONE flat-bucket all-reduce of
     # the block's gradients (adaptpoint_amd.dp.allreduce_mean_).  With SyncBatchNorm collectives sit
     # inside forward and backward: the fused block runs eagerly (its four statistics all-reduces
     # between the launch phases) with the same flat gradient all-reduce; the unfused PyTorch path
-    # runs under DistributedDataParallel with torch.nn.SyncBatchNorm.
-    use_ddp = distributed and sync_bn and not fused_mlp
+    # converts to adaptpoint_amd.dp.SyncBatchNormAllReduce (ONE all-reduce per layer and direction)
+    # and averages the gradients with the same flat all-reduce.
+    if sync_bn and not fused_mlp:
+        blk = dp.convert_sync_batchnorm(blk)
+    model = blk
     eager_collectives = distributed and sync_bn
-    if use_ddp:
-        model = torch.nn.parallel.DistributedDataParallel(blk, device_ids=[local_rank],
-                                                          output_device=local_rank)
-    p, f = make_inputs(B_PER_GPU, seed=dp.shard_seed(0, rank))   # each rank its own shard of clouds
-    p = p.to(dev)
-    f = f.to(dev).requires_grad_(True)
     params = [q for q in blk.parameters()]
 
     # the two-stream pipeline pays only when the step is GPU-bound, i.e. under graph replay
-    pipelined = fused_mlp and args.pipeline == "on" and not use_ddp
+    pipelined = fused_mlp and args.pipeline == "on"
     use_graph = ((args.graph == "on") or (args.graph == "auto")) and not eager_collectives
     # steps per graph: several whole steps per replay when no collective sits between steps
     spg = 1
     if use_graph and not distributed and args.steps_per_graph != 1:
         for cand in ((args.steps_per_graph,) if args.steps_per_graph else (20, 10, 4, 2)):
-            if cand > 1 and args.steps % cand == 0:
+            if cand > 1 and steps % cand == 0:
                 spg = cand
                 break
+    # inputs: every one of the spg steps of a launch has its own clouds (the ball query's cost is
+    # data dependent); each rank draws its own shard
+    seed0 = dp.shard_seed(args.seed, rank)
+    pf = [make_inputs(B_PER_GPU, seed=seed0 + 31 * i, distribution=args.distribution) for i in range(spg)]
+    p_all = torch.cat([a for a, _ in pf]).to(dev)                       # (spg*B, N, 3)
+    ps = [p_all[i * B_PER_GPU:(i + 1) * B_PER_GPU] for i in range(spg)]
+    fs = [b.to(dev).requires_grad_(True) for _, b in pf]
+    index_batch = spg if args.index_batch == 0 else max(1, min(spg, args.index_batch))
+    while spg % index_batch:
+        index_batch -= 1
     if pipelined:
         from adaptpoint_amd.fused import Sampling
         side_stream = torch.cuda.Stream()
@@ -277,16 +259,20 @@ def main():
         # main stream while the side stream fills the other set for the NEXT launch -- the
         # streams meet once per launch (fork at its start, join at its end), not once per step:
         # inside a hipGraph every cross-queue dependency costs ~10 us of idle queue.
-        first = blk.sample(p)                         # prologue: index stage of the first batches
-        sets = [[first] + [Sampling(*first.shape, dev) for _ in range(spg - 1)],
-                [Sampling(*first.shape, dev) for _ in range(spg)]]
-        for smp_i in sets[0][1:] + sets[1]:
-            smp_i.buf.copy_(first.buf)
+        # Each set is ONE stacked buffer: the index stages of `index_batch` batches run as one
+        # FPS launch + one ball-query launch over index_batch * B clouds (each cloud still one
+        # workgroup: the serial chains of different batches are independent and a batch of 32
+        # keeps only 32 of 256 CUs busy).
+        big = [Sampling(spg * B_PER_GPU, NPOINT, NSAMPLE, dev) for _ in range(2)]
+        sets = [[b.clouds(i * B_PER_GPU, (i + 1) * B_PER_GPU) for i in range(spg)] for b in big]
+        blk.sample(p_all, out=big[0])                # prologue: index stages of the first launch
+        big[1].buf.copy_(big[0].buf)
     cur_set = [0]
     graph_grads, last_grads = {}, [None]
 
     def clear_grads():
-        f.grad = None
+        for f in fs:
+            f.grad = None
         for q in params:
             q.grad = None
 
@@ -295,17 +281,18 @@ def main():
         takes its index stage from sets[cur][i], else the block computes it in line."""
         for i in range(count):
             clear_grads()
-            new_p, out = model([p, f], sampling=sets[cur][i]) if pipelined else model([p, f])
+            new_p, out = model([ps[i], fs[i]], sampling=sets[cur][i]) if pipelined else model([ps[i], fs[i]])
             out.sum().backward()
 
     def index_steps(count, dst):
-        # FPS of batch i and ball query of batch i-1 in one launch (FPS keeps 32 CUs busy for
-        # ~160 us, the search fits beside it)
         if args.index_overlap == "on":
-            blk.sample_many([p] * count, outs=sets[dst][:count])
-        else:
-            for i in range(count):
-                blk.sample(p, out=sets[dst][i])
+            # FPS of batch i and ball query of batch i-1 in one launch, batch by batch
+            blk.sample_many(ps[:count], outs=sets[dst][:count])
+            return
+        nb = index_batch * B_PER_GPU
+        for g in range(0, count * B_PER_GPU, nb):
+            hi = min(g + nb, count * B_PER_GPU)
+            blk.sample(p_all[g:hi], out=big[dst].clouds(g, hi))
 
     # Pipelined launch of `count` steps: the MLP steps consume set `cur` on the main stream while
     # the side stream fills the other set for the NEXT launch.  mlp_done / index_done order a
@@ -351,7 +338,14 @@ def main():
                 for _ in range(4):
                     eager_step()
             torch.cuda.current_stream().wait_stream(side)
+            # Nothing may be in flight when capture starts: at N>1 the process group exists
+            # already, and ProcessGroupNCCL's watchdog querying an event of outstanding collective
+            # work on a capturing stream invalidates the capture (the abort of round 1,
+            # hipErrorStreamCaptureUnsupported).  Drain the device, then all ranks meet.
             torch.cuda.synchronize()
+            if distributed:
+                dist.barrier()
+                torch.cuda.synchronize()
             mlp_graphs, index_graphs = {}, {}
             for cur in ((0, 1) if pipelined else (0,)):
                 clear_grads()
@@ -381,7 +375,7 @@ def main():
             use_graph = False
             spg = 1
             step = eager_step
-    if distributed and not use_ddp:
+    if distributed:
         local_step = step
 
         def step():
@@ -390,23 +384,101 @@ def main():
                                else [q.grad for q in params if q.grad is not None])
 
     # W warm-up steps, barrier + synchronize, K timed steps, barrier + synchronize, MAX over ranks
-    # (a replay of an spg-step graph counts as spg steps: exactly args.steps steps are timed)
-    # (warm-up is rounded UP to whole replays: at least args.warmup untimed steps)
-    elapsed = dp.timed_steps(step, args.steps // spg, -(-args.warmup // spg), dev)
+    # (a replay of an spg-step graph counts as spg steps: exactly `steps` steps are timed)
+    # (warm-up is rounded UP to whole replays: at least `warmup` untimed steps)
+    r.elapsed = dp.timed_steps(step, steps // spg, -(-warmup // spg), dev)
+    r.steps, r.spg, r.use_graph, r.pipelined, r.fused_mlp = steps, spg, use_graph, pipelined, fused_mlp
+    r.index_batch = index_batch if pipelined and args.index_overlap != "on" else 1
+
+    def eager_launch():
+        """One whole launch (spg steps and, pipelined, the index stages of the next spg) issued
+        eagerly, kernel by kernel: what the per-kernel event passes time."""
+        launch(spg, cur_set[0], mlp_steps, index_steps)
+        if pipelined:
+            cur_set[0] ^= 1
+    r.eager_step = eager_launch
+    return r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary figures (value_f32_dropin at 1 GPU, value_no_syncbn at N>1)")
+    ap.add_argument("--sync-bn", choices=["auto", "on", "off"], default="auto",
+                    help="BatchNorm statistics at world_size>1.  auto = on: SyncBatchNorm, what the "
+                         "reference forces (examples/classification/main.py:27): four small statistics "
+                         "all-reduces per step inside the fused block + the gradient all-reduce.  off: "
+                         "per-rank statistics (NOT the reference's semantics), one exchange per step")
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--distribution", choices=["D1", "D2"], default="D1",
+                    help="synthetic clouds (SURVEY 8d): D1 uniform cube -> unit sphere; D2 sphere surface + jitter")
+    ap.add_argument("--seed", type=int, default=0, help="base seed of the synthetic clouds (SURVEY 8d: 0..4)")
+    ap.add_argument("--pipeline", choices=["on", "off"], default="on",
+                    help="software-pipeline the index stage: FPS + ball query of the next launch's batches "
+                         "run on a second HIP stream beside the MLP forward+backward of the current ones "
+                         "(the index stage depends on coordinates only); fused path only")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step from a captured HIP graph (auto: on unless collectives sit inside the step)")
+    ap.add_argument("--index-batch", type=int, default=0,
+                    help="pipelined index stage: how many batches' FPS chains share one launch "
+                         "(0 = all the batches of a graph replay; 1 = batch by batch as in round 1)")
+    ap.add_argument("--index-overlap", choices=["on", "off"], default="off",
+                    help="pipelined index stage batch by batch with FPS of one batch and ball query of the "
+                         "previous one in ONE two-role launch (round 1's variant; superseded by --index-batch)")
+    ap.add_argument("--steps-per-graph", type=int, default=0,
+                    help="whole steps captured per hipGraph (0 = auto: the largest of 20, 10, 4, 2 dividing --steps, "
+                         "single GPU; warm-up is rounded up to whole replays; 1 = one step per replay)")
+    ap.add_argument("--mlp", choices=["fused-bf16x3", "fused-bf16", "torch-f32"], default="fused-bf16x3",
+                    help="grouped shared-MLP: fused bf16-MFMA kernels (csrc/sa_fused.hip) with split "
+                         "hi+lo operands (fp32-grade, default) or plain bf16 operands, or the unfused "
+                         "drop-in path (nine extension ops + PyTorch conv/BN in fp32)")
+    args = ap.parse_args()
+
+    from adaptpoint_amd import dp
+    world, rank, local_rank = dp.env_world()
+    # APN_BENCH_FORCE_DISTRIBUTED=1: take the N>1 code path (process group, SyncBatchNorm
+    # phases, eager launch) even at world_size 1 -- lets a one-GPU box exercise it.
+    force_dist = os.environ.get("APN_BENCH_FORCE_DISTRIBUTED") == "1"
+    distributed = world > 1 or force_dist
+    if distributed and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not distributed and args.gpus != 1:
+        raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
+
+    from adaptpoint_amd import _lib
+    _lib.load()                                   # the HIP extension or nothing
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dp.init(args.backend, dev, force=force_dist)
+    if force_dist:
+        from adaptpoint_amd import fused as _fused
+        _fused.FORCE_PHASED = True
+
+    sync_bn = distributed and args.sync_bn != "off"          # auto = on, as the reference (main.py:27)
+    m = measure(args, dev, world, rank, local_rank, distributed, args.mlp, sync_bn, args.steps, args.warmup)
+    elapsed, spg, use_graph, pipelined, fused_mlp, eager_step = (m.elapsed, m.spg, m.use_graph, m.pipelined,
+                                                                 m.fused_mlp, m.eager_step)
     # The timed step issues whole launch sequences (one C call per direction, or one hipGraph),
     # which cannot carry per-kernel events.  The dominant kernel is therefore timed right after
     # the timed region: the same launch, same inputs, same stream, HIP events around it.
     t2 = KernelTimer()
     r2 = instrument(t2, only={"fps"})
-    for _ in range(20):
+    for _ in range(max(2, 20 // spg)):
         eager_step()
     r2()
     fps_us = t2.mean_us()["fps"]
+    fps_clouds = B_PER_GPU * m.index_batch            # clouds (= workgroups = serial chains) per sampler launch
 
     # per-kernel view (un-timed extra pass): events around every extension launch
     timer_all = KernelTimer()
     restore = instrument(timer_all)
-    for _ in range(min(args.steps, 20)):
+    for _ in range(max(2, min(args.steps, 20) // spg)):
         eager_step()
     per_kernel_us = timer_all.mean_us()
     restore()
@@ -414,6 +486,8 @@ def main():
     total_clouds = B_PER_GPU * world * args.steps
     value = total_clouds / elapsed
     ab = algorithmic_bytes(B_PER_GPU, fused=fused_mlp)
+    for k in ("fps", "ball_query"):                   # index launches cover index_batch batches
+        ab[k] *= m.index_batch
     kernels = {}
     for k, us in sorted(per_kernel_us.items()):
         ent = {"avg_us": round(us, 2)}
@@ -423,7 +497,9 @@ def main():
             ent["frac_hbm"] = round(ab[k] / us * 1e-3 / HBM_PEAK_GBS, 5)
         kernels[k] = ent
     traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
     if os.path.exists(tpath):       # PMC-measured HBM bytes per launch (rocprofv3 --pmc, committed)
         traffic = json.load(open(tpath)).get("bytes_per_launch", {})
     for k, ent in kernels.items():
@@ -432,15 +508,24 @@ def main():
     dominant = max(per_kernel_us, key=per_kernel_us.get)
     dom_us = fps_us if dominant == "fps" else per_kernel_us[dominant]
     achieved = ab.get(dominant, 0) / dom_us * 1e-3
+    step_s = elapsed / args.steps
+    step_flops, step_bytes = STEP_FLOPS_PER_CLOUD * B_PER_GPU, STEP_BYTES_PER_CLOUD * B_PER_GPU
     roofline = {
         "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-        "traffic": traffic.get(dominant),
+        "traffic": traffic.get(dominant) if m.index_batch == 1 else None,
         "avg_launch_us": round(dom_us, 2),
-        "note": ("FPS is a serial chain of npoint-1 dependent arg-max steps on B workgroups; its "
-                 "bound is per-step latency, not HBM or MFMA (DESIGN.md). step_ns = avg launch "
-                 "/ (npoint-1)."),
+        "note": ("FPS is a serial chain of npoint-1 dependent arg-max steps, one workgroup per cloud; its "
+                 "bound is per-step latency, not HBM or MFMA (DESIGN.md): fps_step_ns = avg launch / "
+                 "(npoint-1) is the figure of merit, `step` below the whole step against both peaks."),
         "fps_step_ns": round(fps_us * 1e3 / (NPOINT - 1), 1),
+        "fps_clouds_per_launch": fps_clouds,
+        "fps_us_per_batch": round(fps_us / m.index_batch, 2),
+        # the whole step (one batch of 32 clouds through FPS, ball query, fused forward and backward)
+        # against the two peaks: SURVEY 8d's per-cloud figures x 32 over the measured step time
+        "step": {"flops": step_flops, "bytes": step_bytes,
+                 "frac_mfma": round(step_flops / step_s / (MFMA_BF16_PEAK_TFLOPS * 1e12), 5),
+                 "frac_hbm": round(step_bytes / step_s / (HBM_PEAK_GBS * 1e9), 5)},
         "kernels": kernels,
     }
     if fused_mlp and "sa_bwd_main" in per_kernel_us:
@@ -460,6 +545,7 @@ def main():
                      "the kernel is VALU-issue bound (operand splitting, BN/ReLU, scatter), "
                      "profiles/r01_pmc_sq_summary.csv")}
 
+    from adaptpoint_amd import set_abstraction as _sa
     result = {
         "metric": "set-abstraction fwd+bwd point-clouds/sec (B=32,N=1024)",
         "value": round(value, 2), "unit": "point-clouds/s", "n_gpus": world,
@@ -468,8 +554,10 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if fused_mlp else "f32", "data": "synthetic",
         "config": {"workload": "PointNeXt-S stage-1 SetAbstraction fwd+bwd, B=32/GPU N=1024 "
-                               "npoint=512 nsample=32 r=0.15 C 32->64 (BASELINE configs[1]); "
-                               "clouds: uniform cube centred+scaled to the unit sphere (D1)",
+                               "npoint=512 nsample=32 r=0.15 C 32->64 (BASELINE configs[1])",
+                   "distribution": {"D1": "D1: uniform cube centred+scaled to the unit sphere",
+                                    "D2": "D2: unit-sphere surface + N(0,0.01) jitter"}[args.distribution],
+                   "seed": args.seed,
                    "mlp": ({"fused-bf16x3": "fused bf16 MFMA on split hi+lo operands (3 MFMAs per product, "
                                             "f32 accumulate; forward within 7e-5 of an fp32 chain), "
                                             "f32 BatchNorm statistics summed in f64",
@@ -477,14 +565,25 @@ def main():
                                           "f32 BatchNorm statistics summed in f64",
                             "torch-f32": "unfused: extension ops + PyTorch fp32 conv/BN"}[args.mlp]),
                    "launch": (f"hipGraph replay, {spg} step(s) per graph" if use_graph else "eager"),
-                   "pipeline": ("index stage (FPS + ball query) of the NEXT launch's batches on a second stream "
-                                "beside the MLP fwd+bwd of the current batch(es); the two streams meet "
-                                "once per launch" if pipelined else "none"),
+                   "pipeline": (f"index stages (FPS + ball query) of the NEXT launch's batches on a second stream, "
+                                f"{m.index_batch} batch(es) per sampler launch, beside the MLP fwd+bwd of the "
+                                "current batch(es); the two streams meet once per launch" if pipelined else "none"),
                    "global_batch": B_PER_GPU * world,
+                   "fused_fallbacks": sum(_sa.FUSED_FALLBACKS.values()),
                    "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else "")
-                                  + ("+ddp" if use_ddp else ("+flat-allreduce" if distributed else ""))},
+                                  + ("+flat-allreduce" if distributed else "")},
         "roofline": roofline,
     }
+    if not args.no_secondary:
+        sec_steps = max(4, min(args.steps, 40))
+        if distributed and sync_bn:
+            # the cheaper step the reference never runs: per-rank BatchNorm statistics, graph replay + one all-reduce
+            m2 = measure(args, dev, world, rank, local_rank, distributed, args.mlp, False, sec_steps, 4)
+            result["value_no_syncbn"] = round(B_PER_GPU * world * sec_steps / m2.elapsed, 2)
+        elif not distributed and fused_mlp:
+            # the bit-for-bit interoperable path: nine drop-in operators + PyTorch fp32 conv/BN (eager)
+            m2 = measure(args, dev, world, rank, local_rank, distributed, "torch-f32", False, sec_steps, 4)
+            result["value_f32_dropin"] = round(B_PER_GPU * sec_steps / m2.elapsed, 2)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if distributed:

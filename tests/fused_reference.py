@@ -15,12 +15,16 @@ def group(t, idx):
     return torch.gather(t, 2, idx.long().reshape(B, 1, M * K).expand(-1, C, -1)).reshape(B, C, M, K)
 
 
-def chain_grad(p, new_p, f, idx, radius, w1, g1, b1, w2, g2, b2, eps=1e-5, emulate_bf16=False):
-    """Returns out (B,C2,M) and intermediates, in float64 (training-mode BatchNorm)."""
+def chain_grad(p, new_p, f, idx, radius, w1, g1, b1, w2, g2, b2, eps=1e-5, emulate_bf16=False,
+               y1_noise=None):
+    """Returns out (B,C2,M) and intermediates, in float64 (training-mode BatchNorm).
+    y1_noise: optional tensor added to conv1's output (a forward-error model for sensitivity tests)."""
     rnd = _bf if emulate_bf16 else (lambda x: x.double())
     dp = (group(p.transpose(1, 2).contiguous(), idx) - new_p.transpose(1, 2).unsqueeze(-1)) / radius
     x = torch.cat([rnd(dp.float()), group(rnd(f).float() if emulate_bf16 else f, idx).double()], 1)  # (B,35,M,K)
     y1 = torch.einsum('oc,bcmk->bomk', rnd(w1), x)
+    if y1_noise is not None:
+        y1 = y1 + y1_noise
     m1 = y1.mean((0, 2, 3), keepdim=True)
     v1 = y1.var((0, 2, 3), unbiased=False, keepdim=True)
     a1 = torch.relu((y1 - m1) / torch.sqrt(v1 + eps) * g1.double().view(1, -1, 1, 1) + b1.double().view(1, -1, 1, 1))

@@ -112,10 +112,12 @@ def test_generator_matches_reference(dev, golden_ap, fused):
                 head=rel(sac.head.prob_head[0].weight.grad, golden_ap["g9_grad_prob_head_w"]),
                 mask=rel(sac.extract_local_feat_masking[0].weight.grad, golden_ap["g9_grad_mask_local_w"]))
     print("generator vs reference golden (fused=%s):" % fused, {k: "%.2e" % v for k, v in errs.items()})
-    assert e_log < 2.5e-3                                         # half the margin every decision clears
+    # measured on MI355X: out 8e-7, mask logits 2e-4 (of a 5e-3 margin), head 7e-6, mask branch 5e-4,
+    # embedding (gradient through all ~40 layers, train-mode BatchNorm over 2 clouds) 4e-3
+    assert e_log < 1e-3                                           # a fifth of the margin every decision clears
     assert np.array_equal(out.detach().abs().sum(-1).cpu().numpy() == 0, np.abs(ref).sum(-1) == 0)
-    assert errs["out"] < 2e-3
-    assert errs["embed"] < 5e-2 and errs["head"] < 5e-2 and errs["mask"] < 5e-2
+    assert errs["out"] < 1e-5
+    assert errs["head"] < 2e-4 and errs["mask"] < 5e-3 and errs["embed"] < 2e-2
 
 
 def test_generator_own_draws_are_valid(dev):
@@ -149,8 +151,8 @@ def test_discriminator_matches_reference(dev, golden_ap):
                 conv0=rel(d.sa1.mlp_convs[0].parametrizations.weight.original.grad, golden_ap["g10_grad_conv0"]),
                 u=rel(d.fc1.parametrizations.weight[0]._u, golden_ap["g10_u_fc1"]))
     print("discriminator vs reference golden:", {k: "%.2e" % v for k, v in errs.items()})
-    assert errs["eval"] < 1e-3 and errs["train"] < 1e-3 and errs["u"] < 1e-4
-    assert errs["grad_x"] < 2e-2 and errs["conv0"] < 2e-2
+    assert errs["eval"] < 1e-5 and errs["train"] < 1e-5 and errs["u"] < 1e-5      # measured: 0, 0, 3e-7
+    assert errs["grad_x"] < 1e-4 and errs["conv0"] < 1e-4                         # measured: 9e-7, 8e-7
 
 
 # ------------------------------------------------------------------ a21: the joint step
@@ -182,8 +184,9 @@ def test_gan_step_matches_reference_trainer(dev, golden_ap, fused):
                 fc3=rel(grads["fc3"], golden_ap["g11_grad_fc3"]))
     print("train_gan step vs reference golden (fused=%s):" % fused, {k: "%.2e" % v for k, v in errs.items()})
     assert np.array_equal(res["gen"].abs().sum(-1).cpu().numpy() == 0, np.abs(ref).sum(-1) == 0)
-    assert errs["gen"] < 2e-3 and errs["losses"] < 5e-3
-    assert errs["embed"] < 5e-2 and errs["head"] < 5e-2 and errs["fc3"] < 2e-2
+    # measured: gen 5e-7, losses 2e-7, head 1e-5, fc3 1e-6, embedding (the deepest gradient) 1e-2
+    assert errs["gen"] < 1e-5 and errs["losses"] < 1e-5
+    assert errs["head"] < 2e-4 and errs["fc3"] < 1e-4 and errs["embed"] < 4e-2
     # Adam's first step moves every weight by lr * sign(grad): the updated tensors agree wherever the sign does
     after = G.predict_prob_layer.embedding.net[0].weight.detach().cpu().numpy()
     assert (np.abs(after - golden_ap["g11_embed_w_after"]) < 1e-5).mean() > 0.97
@@ -227,5 +230,6 @@ def test_classifier_step_matches_reference_trainer(dev, golden_ap, fused):
     after = m.prediction.head[-1][0].weight.detach().cpu().numpy()
     errs["head_sign_agree"] = float((np.abs(after - golden_ap["g13_head_w_after"]) < 1e-4).mean())
     print("train_one_epoch step vs reference golden (fused=%s):" % fused, {k: "%.2e" % v for k, v in errs.items()})
-    assert errs["logits"] < 2e-2 and errs["loss"] < 5e-3 and errs["bn"] < 2e-3
+    # measured: unfused logits 1e-4 / loss 3e-5; fused 2e-3 / 5e-4 (four fused stages' discontinuities at B=2)
+    assert errs["logits"] < (1e-2 if fused else 1e-3) and errs["loss"] < (2e-3 if fused else 2e-4) and errs["bn"] < 1e-5
     assert errs["head_sign_agree"] > 0.95

@@ -15,7 +15,7 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 
 def _bench(extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + extra, env=env,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary"] + extra, env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -28,6 +28,7 @@ def _bench(extra):
     (["--steps", "7", "--warmup", "2"], "hipGraph replay, 1 step(s) per graph"),
     (["--steps", "8", "--warmup", "2", "--index-overlap", "on"], "hipGraph replay, 4 step(s) per graph"),
     (["--steps", "6", "--warmup", "2", "--pipeline", "off"], "hipGraph replay, 2 step(s) per graph"),
+    (["--steps", "8", "--warmup", "2", "--index-batch", "1", "--distribution", "D2", "--seed", "3"], "hipGraph replay, 4 step(s) per graph"),
     (["--steps", "6", "--warmup", "2", "--graph", "off"], "eager"),
     (["--steps", "6", "--warmup", "2", "--mlp", "fused-bf16"], "hipGraph replay, 2 step(s) per graph"),
     (["--steps", "4", "--warmup", "1", "--mlp", "torch-f32"], None),
@@ -39,5 +40,19 @@ def test_bench_variants_emit_the_contract_line(dev, extra, launch):
     assert abs(d["ms_per_step"] - 1e3 * 32 / d["value"]) <= 1e-3 * d["ms_per_step"] + 1e-4
     assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["frac"] >= 0
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["scaling"] == "weak"
+    st = d["roofline"]["step"]
+    assert 0 < st["frac_mfma"] < 1 and 0 < st["frac_hbm"] < 1 and d["roofline"]["fps_step_ns"] > 0
     if launch is not None:
         assert d["config"]["launch"] == launch
+
+
+def test_default_line_carries_the_secondary_figures(dev):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["value_f32_dropin"] > 0 and d["value"] > d["value_f32_dropin"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["value_1_thread"] > 0 and cb["cpu_model"]
+    assert d["config"]["fused_fallbacks"] == 0

@@ -389,51 +389,92 @@ def test_set_abstraction_matches_reference_golden_on_gpu(dev, golden, fused):
     print("SetAbstraction(fused=%s) vs reference golden:" % fused, {k: "%.2e" % v for k, v in errs.items()})
     # unfused: fp32 everywhere (MIOpen's summation order); fused: split-bf16 MFMA (1e-5-level terms,
     # a K-pool arg-max may flip between two neighbours closer than that)
-    assert errs["out_max"] <= 5e-3 and errs["out_mean"] <= 1e-4
-    assert all(v <= 1e-2 for k, v in errs.items() if k not in ("out_max", "out_mean")), errs
+    # measured: unfused 2e-6 / 3e-6 everywhere (fp32 end to end); fused 5e-5 max, 6e-6 mean in the output and
+    # <= 2e-3 in the gradients upstream of the ReLU gates (test_discontinuities_explain_the_gradient_residual)
+    if fused:
+        assert errs["out_max"] <= 5e-4 and errs["out_mean"] <= 2e-5
+        assert all(v <= 5e-3 for k, v in errs.items() if k not in ("out_max", "out_mean")), errs
+    else:
+        assert errs["out_max"] <= 2e-5 and errs["out_mean"] <= 1e-6
+        assert all(v <= 2e-5 for k, v in errs.items() if k not in ("out_max", "out_mean")), errs
 
 
-def test_pool_flips_explain_the_gradient_residual(dev):
-    """VERDICT weak #3.  The split-operand (bf16x3) gradients through the K-pool differ from the
-    fp32 chain by ~2e-3 relative L2; the claim is that arg-max flips -- and nothing else -- cause it.
-    Test: mask the pooled positions whose two largest candidates lie closer than 1e-4 (where the
-    forward's ~1e-5 error can change the winner) out of the LOSS on both sides; what remains must
-    agree to 1e-5-level."""
-    from adaptpoint_amd import fused
+def _grads_vs_chain(dev, bn1_bias_shift, mask_pool, y1_noise_std=None):
+    """Gradients of the fused op (bf16x3) and of the float64 chain for the same loss; optionally the
+    pooled positions whose two best DISTINCT candidates lie within 1e-4 are taken out of the loss on
+    both sides.  With y1_noise_std the comparison is chain-vs-chain: the second chain sees conv1's
+    output perturbed by N(0, std) -- a model of a 1e-5-level forward error."""
     from adaptpoint_amd.fused import grouped_mlp_max
     from fused_reference import chain_grad
-    assert fused.PRECISION == "bf16x3"
     p, new_p, f, idx, conv1, bn1, conv2, bn2 = _setup(dev, seed=5)
+    with torch.no_grad():
+        bn1.bias += bn1_bias_shift
     wts = torch.randn(4, 64, 512, device=dev, generator=torch.Generator(dev).manual_seed(9))
-    leaves = [t.detach().clone().requires_grad_(True) for t in
-              (p, new_p, f, conv1.weight.view(32, 35), bn1.weight, bn1.bias,
-               conv2.weight.view(64, 32), bn2.weight, bn2.bias)]
-    rp, rq, rf, rw1, rg1, rb1, rw2, rg2, rb2 = leaves
-    ref, mid = chain_grad(rp, rq, rf, idx, 0.15, rw1, rg1, rb1, rw2, rg2, rb2)
-    with torch.no_grad():      # z over K: gap between the best and the second best candidate
-        z = ((mid["y2"] - mid["m2"]) / torch.sqrt(mid["v2"] + 1e-5) * bn2.weight.double().view(1, -1, 1, 1)
-             + bn2.bias.double().view(1, -1, 1, 1))
-        top2 = z.topk(2, dim=-1).values
-        # duplicated neighbours (the ball-query fill) tie exactly: a flip between copies of the SAME
-        # point moves nothing, so only gaps between distinct values count
-        uniq_gap = torch.where(top2[..., 0] == top2[..., 1], torch.full_like(top2[..., 0], 1.0),
-                               top2[..., 0] - top2[..., 1])
-        keep = (uniq_gap > 1e-4).to(wts.dtype)
-    frac = 1.0 - keep.mean().item()
+
+    def reference(noise=None):
+        leaves = [t.detach().clone().requires_grad_(True) for t in
+                  (p, new_p, f, conv1.weight.view(32, 35), bn1.weight, bn1.bias,
+                   conv2.weight.view(64, 32), bn2.weight, bn2.bias)]
+        out, mid = chain_grad(leaves[0], leaves[1], leaves[2], idx, 0.15, *leaves[3:], y1_noise=noise)
+        return out, mid, leaves
+    ref, mid, leaves = reference()
+    keep = torch.ones_like(wts)
+    if mask_pool:
+        with torch.no_grad():
+            z = ((mid["y2"] - mid["m2"]) / torch.sqrt(mid["v2"] + 1e-5) * bn2.weight.double().view(1, -1, 1, 1)
+                 + bn2.bias.double().view(1, -1, 1, 1))
+            top2 = z.topk(2, dim=-1).values
+            # copies of one neighbour (the ball-query fill) tie exactly and a flip between them moves
+            # nothing: only gaps between distinct values count
+            gap = torch.where(top2[..., 0] == top2[..., 1], torch.ones_like(top2[..., 0]),
+                              top2[..., 0] - top2[..., 1])
+            keep = (gap > 1e-4).to(wts.dtype)
     (ref * (wts * keep).double()).sum().backward()
-    p.requires_grad_(True); new_p.requires_grad_(True); f.requires_grad_(True)
-    out = grouped_mlp_max(p, new_p, f, idx, 0.15, conv1, bn1, conv2, bn2)
-    (out * wts * keep).sum().backward()
-    got = dict(f=f.grad, p=p.grad, newp=new_p.grad, w1=conv1.weight.grad.view(32, 35),
-               w2=conv2.weight.grad.view(64, 32), g1=bn1.weight.grad, b1=bn1.bias.grad,
-               g2=bn2.weight.grad, b2=bn2.bias.grad)
-    want = dict(f=rf.grad, p=rp.grad, newp=rq.grad, w1=rw1.grad, w2=rw2.grad, g1=rg1.grad, b1=rb1.grad,
-                g2=rg2.grad, b2=rb2.grad)
-    l2 = {k: _rel_l2(got[k], want[k]) for k in got}
-    print("masked %.3f%% of the pooled values; rel-L2 of the rest:" % (100 * frac), {k: "%.2e" % v for k, v in l2.items()})
-    assert frac < 0.02
-    for k, v in l2.items():
-        assert v <= 1e-4, (k, v)
+    names = ("p", "newp", "f", "w1", "g1", "b1", "w2", "g2", "b2")
+    want = {k: t.grad for k, t in zip(names, leaves)}
+    if y1_noise_std is not None:
+        noise = torch.randn(mid["y1"].shape, device=dev, dtype=torch.float64,
+                            generator=torch.Generator(dev).manual_seed(77)) * y1_noise_std
+        ref2, _, leaves2 = reference(noise)
+        (ref2 * (wts * keep).double()).sum().backward()
+        got = {k: t.grad for k, t in zip(names, leaves2)}
+    else:
+        p.requires_grad_(True); new_p.requires_grad_(True); f.requires_grad_(True)
+        out = grouped_mlp_max(p, new_p, f, idx, 0.15, conv1, bn1, conv2, bn2)
+        (out * wts * keep).sum().backward()
+        got = dict(f=f.grad, p=p.grad, newp=new_p.grad, w1=conv1.weight.grad.view(32, 35),
+                   w2=conv2.weight.grad.view(64, 32), g1=bn1.weight.grad, b1=bn1.bias.grad,
+                   g2=bn2.weight.grad, b2=bn2.bias.grad)
+    gate_near_zero = float((((mid["y1"] - mid["m1"]) / torch.sqrt(mid["v1"] + 1e-5) * bn1.weight.double().view(1, -1, 1, 1)
+                             + bn1.bias.double().view(1, -1, 1, 1)).abs() < 2e-5).double().mean())
+    return {k: _rel_l2(got[k], want[k]) for k in names}, 1.0 - keep.mean().item(), gate_near_zero
+
+
+def test_discontinuities_explain_the_gradient_residual(dev):
+    """VERDICT weak #3.  The split-operand (bf16x3) gradients upstream of BatchNorm-1 differ from
+    the fp32 chain by ~2e-3 relative L2 although every product is good to ~1e-5.  Claim: the
+    residual is the chain's own discontinuities -- mostly ReLU gates that a 1e-5-level forward error
+    switches -- not arithmetic.  Two measurements on the same inputs:
+      (b) fused vs float64 chain with the near-tie K-pool winners taken out of the loss on both
+          sides: the residual stays (measured f 1.9e-3, w1 1.5e-3), so pool flips are not its
+          main source; what bypasses the gates (dL/dW2, dL/dgamma2, dL/dbeta2) agrees to 6e-6;
+      (c) the float64 chain compared WITH ITSELF under a N(0, 1e-5) perturbation of conv1's
+          output shows a residual of the same size (f 3.3e-3, w1 3.1e-3): a fraction eps of
+          switched gates moves the gradient by ~sqrt(eps) in relative L2 (1.4e-5 of the
+          pre-activations lie within 2e-5 of zero here: sqrt = 3.8e-3).
+    (Holding the gates open with a large BatchNorm-1 bias is no cleaner a probe: the offset costs the
+    hi+lo split its dynamic range.)"""
+    from adaptpoint_amd import fused
+    assert fused.PRECISION == "bf16x3"
+    b, frac_b, near0 = _grads_vs_chain(dev, bn1_bias_shift=0.0, mask_pool=True)
+    print("(b) normal block, pool masked (%.3f%%), gates within 2e-5 of zero: %.2e:" % (100 * frac_b, near0),
+          {k: "%.1e" % v for k, v in b.items()})
+    c, _, _ = _grads_vs_chain(dev, bn1_bias_shift=0.0, mask_pool=True, y1_noise_std=1e-5)
+    print("(c) float64 chain vs itself with conv1 output perturbed by 1e-5:", {k: "%.1e" % v for k, v in c.items()})
+    for k in ("f", "p", "newp", "w1", "g1", "b1"):       # everything upstream of the ReLU gates
+        assert b[k] <= 5e-3 and b[k] <= 4 * c[k] + 1e-4, (k, b[k], c[k])
+    for k in ("g2", "b2"):                                # bypass gates and (masked) pool: arithmetic only
+        assert b[k] <= 1e-4, (k, b[k])
 
 
 def test_syncbn_two_ranks_equal_one_double_batch(dev):
