@@ -23,6 +23,15 @@ _log = logging.getLogger("adaptpoint_amd")
 FUSED_FALLBACKS = {}
 
 
+# True: the width-generic kernels (csrc/sa_wide.hip) also take the 32 -> 32 -> 64 shape that the
+# register-resident kernels of csrc/sa_fused.hip specialise in (A/B switch for benchmarks and tests).
+PREFER_WIDE = False
+
+
+def fused_wide_first():
+    return PREFER_WIDE
+
+
 def _note_fallback(reason):
     if reason not in FUSED_FALLBACKS:
         _log.warning("SetAbstraction(fused=True) runs UNFUSED: %s", reason)
@@ -152,7 +161,8 @@ class SetAbstraction(nn.Module):
         conv1, bn1, conv2, bn2, relu_after = parts
         g = self.grouper
         if (not fused.supported(p, f, g.nsample, conv1, conv2, bns=(bn1, bn2),
-                               npoint=p.shape[1] // self.stride) or p.shape[1] > 16384):
+                               npoint=p.shape[1] // self.stride) or p.shape[1] > 16384
+                or fused_wide_first()):
             return None
         skip = None
         if self.use_res:
@@ -174,11 +184,16 @@ class SetAbstraction(nn.Module):
             return None
         conv1, bn1, conv2, bn2, relu_after = parts
         g = self.grouper
+        from . import fused_wide
         idx = g.neighbours(new_p, p)
-        if not fused.supported(p, f, idx, conv1, conv2, bns=(bn1, bn2)):
+        if fused.supported(p, f, idx, conv1, conv2, bns=(bn1, bn2)) and not fused_wide_first():
+            out = fused.grouped_mlp_max(p, new_p, f, idx, g.radius, conv1, bn1, conv2, bn2,
+                                        sync_bn=self.sync_bn)
+        elif fused_wide.supported(p, f, idx, conv1, conv2, bns=(bn1, bn2)):
+            out = fused_wide.grouped_mlp_max(p, new_p, f, idx, g.radius, conv1, bn1, conv2, bn2,
+                                             sync_bn=self.sync_bn)
+        else:
             return None
-        out = fused.grouped_mlp_max(p, new_p, f, idx, g.radius, conv1, bn1, conv2, bn2,
-                                    sync_bn=self.sync_bn)
         if relu_after:          # activation after the last BN commutes with the max
             out = self.convs[1][2](out)
         return out

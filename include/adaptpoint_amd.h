@@ -344,6 +344,40 @@ APN_API int apn_attention_bwd(int b, int m, int heads, const void *images, const
                               const float *lse, const float *g_out, void *scratch, float *dq,
                               float *dk, float *dv, void *stream);
 
+/* ---- width-generic fused grouped MLP (csrc/sa_wide.hip): C_mid = H in {32,64,128,256}, C_out = 2H,
+ * K = 32.  conv1 is hoisted to the points by the caller: U (B,N,H) = W1f f + W1p p / r per point,
+ * V (B,M,H) = W1p new_p / r per query, so that y1[q,k] = U[idx[q,k]] - V[q]
+ * (openpoints/models/backbone/pointnext.py:157-166 with group.py:248-254).  pack1 = BatchNorm-1's
+ * {scale, shift, mean, invstd}[H].  Weight operands are "B images" (bf16 hi/lo parts in MFMA
+ * fragment order, adaptpoint_amd/fused_wide.py::mfma_b_image). ---- */
+APN_API int apn_sa_wide_grid(int b, int m);          /* workgroups = partial rows of the three passes */
+/* out[ncol] (float64) = column sums of part[rows][ncol] (float32) in a fixed order */
+APN_API int apn_sa_wide_colsum(const float *part, int rows, int ncol, double *out, void *stream);
+/* part[grid][2H] = {sum, sumsq} of y1 */
+APN_API int apn_sa_wide_stats1(int b, int n, int m, int c_mid, const float *U, const float *V,
+                               const int *idx, float *part, void *stream);
+/* a1 = relu(scale1 y1 + shift1), y2 = a1 W2^T (w2_image: B image of W2^T, H x O, min(4, O/32) column
+ * tiles per block) -> ysel/ksel (B,M,O): per (query, channel) the extreme of y2 over the K slots
+ * (max where sgn2 = +1, min where -1; first slot among equals) and that slot;
+ * part[grid][2*O] = {sum, sumsq} of y2 */
+APN_API int apn_sa_wide_fwd_main(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
+                                 const int *idx, const void *w2_image, const float *pack1,
+                                 const float *sgn2, float *ysel, void *ksel, float *part, void *stream);
+/* dL/da1 = S W2 + a1 Qm + evec (z_image: B image of [W2 ; Qm], (O+H) x H, min(4, H/32) column tiles
+ * per block; S[pos,c] = goa[q,c] [ksel[q,c] == pos]), g_u = dL/da1 [a1 > 0]:
+ * A (B,N,H) += g_u per gathered point (caller-zeroed, float atomics), HA (B,M,H) = sum_k g_u,
+ * HB (B,M,H) = sum_k yhat1, part[grid][2H] = {sum g_u, sum g_u yhat1} */
+APN_API int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
+                                 const int *idx, const void *z_image, const float *pack1,
+                                 const float *evec, const float *goa, const void *ksel, float *A,
+                                 float *HA, float *HB, float *part, void *stream);
+/* r_part[splits][(O+H)][H] = partial [S^T ; a1^T] a1 (rows < O: the sparse part of dL/dW2; the rest:
+ * the Gram matrix of a1), suma_part[splits][H] = partial sum of a1; the caller sums the splits */
+APN_API int apn_sa_wide_wgrad_splits(int b, int m, int c_mid);
+APN_API int apn_sa_wide_wgrad(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
+                              const int *idx, const float *pack1, const float *goa, const void *ksel,
+                              int splits, float *r_part, float *suma_part, void *stream);
+
 /* Tuning / diagnostic entry, NOT part of the reference boundary: apn_furthest_point_sampling
  * with the number of wavefronts that cooperate on one cloud (1, 2, 4, 8 or 16; 0 = the built-in
  * heuristic) and the step algorithm (0 = default: one LDS 64-bit atomic max per step for

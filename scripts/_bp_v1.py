@@ -65,17 +65,17 @@ def main():
         # two branches at every one of them
         with torch.cuda.graph(graph, stream=side if not a.fork else None):
             loss_g = step()
-        eager = step
-
-        def step():
+        def rstep():
             graph.replay()
             return loss_g
+    else:
+        rstep = step
     for _ in range(a.warmup):
-        step()
+        rstep()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        loss = step()
+        loss = rstep()
         if a.sync_each:
             torch.cuda.synchronize()
             if i % 5 == 0:

@@ -41,6 +41,7 @@ def main():
     pos = torch.from_numpy(GI.unit_sphere_cloud(a.batch, 1024, seed=0)).to(dev)
     x = torch.cat([pos, pos[:, :, 1:2] - pos[:, :, 1:2].min(1, keepdim=True)[0]], -1).transpose(1, 2).contiguous()
     gt = torch.randint(0, 15, (a.batch,), device=dev, generator=torch.Generator(dev).manual_seed(0))
+    print("dtypes", pos.dtype, x.dtype, gt.dtype, pos.shape, x.shape, file=sys.stderr)
 
     def step():
         opt.zero_grad(set_to_none=True)

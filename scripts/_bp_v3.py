@@ -70,8 +70,14 @@ def main():
         def step():
             graph.replay()
             return loss_g
-    for _ in range(a.warmup):
-        step()
+    torch.cuda.synchronize()
+    snap = {k: q.detach().clone() for k, q in model.named_parameters()}
+    step(); torch.cuda.synchronize()
+    snap2 = {k: q.detach().clone() for k, q in model.named_parameters()}
+    step(); torch.cuda.synchronize()
+    for k, q in model.named_parameters():
+        d1 = (snap2[k] - snap[k]).abs().max().item(); d2 = (q.detach() - snap2[k]).abs().max().item()
+        print("DELTA %-45s %.2e %.2e" % (k, d1, d2), file=sys.stderr)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):

@@ -70,8 +70,13 @@ def main():
         def step():
             graph.replay()
             return loss_g
-    for _ in range(a.warmup):
-        step()
+    torch.cuda.synchronize()
+    names = ["encoder.encoder.1.0.convs.0.0.weight", "encoder.encoder.2.0.convs.1.0.weight", "encoder.encoder.5.0.convs.0.0.weight", "prediction.head.4.0.weight"]
+    P = dict(model.named_parameters())
+    for i in range(4):
+        l = step(); torch.cuda.synchronize()
+        print("GRAD replay", i, "loss %.4f" % float(l.detach()), " ".join("%s=%.3e" % (n.split(".")[2] + n.split(".")[-2], P[n].grad.norm().item()) for n in names),
+              "ptr", P[names[0]].grad.data_ptr() % 100000, file=sys.stderr)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):

@@ -1,0 +1,82 @@
+"""Debug aid: every output of the csrc/sa_wide.hip kernels against a float64 torch evaluation."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import golden_inputs as GI
+from adaptpoint_amd import _lib
+from adaptpoint_amd.fused import _call
+from adaptpoint_amd.fused_wide import mfma_b_image
+from adaptpoint_amd.layers import ball_query, furthest_point_sample
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+for H, N, M, radius in ((32, 1024, 512, 0.15), (64, 512, 256, 0.225), (128, 256, 128, 0.34), (256, 128, 64, 0.5)):
+    B, O = 2, 2 * H
+    p = torch.from_numpy(GI.unit_sphere_cloud(B, N, seed=1)).to(dev)
+    fidx = furthest_point_sample(p, M).long()
+    new_p = torch.gather(p, 1, fidx.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx = ball_query(radius, 32, p, new_p)
+    g = torch.Generator(dev).manual_seed(0)
+    U = torch.randn(B, N, H, device=dev, generator=g)
+    V = 0.3 * torch.randn(B, M, H, device=dev, generator=g)
+    scale1 = 0.5 + torch.rand(H, device=dev, generator=g)
+    shift1 = 0.2 * torch.randn(H, device=dev, generator=g)
+    mean1 = 0.1 * torch.randn(H, device=dev, generator=g)
+    inv1 = 0.5 + torch.rand(H, device=dev, generator=g)
+    pack1 = torch.cat([scale1, shift1, mean1, inv1]).contiguous()
+    W2 = torch.randn(O, H, device=dev, generator=g) / H ** 0.5
+    sgn2 = torch.where(torch.randn(O, device=dev, generator=g) > -0.5, 1.0, -1.0)
+    grid = lib.apn_sa_wide_grid(B, M)
+    # references (float64, materialised)
+    bi = torch.arange(B, device=dev).view(B, 1, 1)
+    y1 = U.double()[bi, idx.long()] - V.double().unsqueeze(2)                      # (B,M,K,H)
+    part1 = torch.empty(grid, 2 * H, device=dev)
+    _call("apn_sa_wide_stats1", dev, B, N, M, H, U.data_ptr(), V.data_ptr(), idx.data_ptr(), part1.data_ptr())
+    s = part1.double().sum(0)
+    print(f"H={H}: stats1 sum {rel(s[:H], y1.sum((0,1,2))):.1e} sumsq {rel(s[H:], (y1*y1).sum((0,1,2))):.1e}", end=" | ")
+    a1 = torch.relu(y1 * scale1.double() + shift1.double())
+    y2 = a1 @ W2.double().t()                                                       # (B,M,K,O)
+    ysel = torch.empty(B, M, O, device=dev); ksel = torch.empty(B, M, O, dtype=torch.uint8, device=dev)
+    part2 = torch.empty(grid, 2 * O, device=dev)
+    w2img = mfma_b_image(W2.t().contiguous(), min(4, O // 32))
+    _call("apn_sa_wide_fwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(), w2img.data_ptr(),
+          pack1.data_ptr(), sgn2.data_ptr(), ysel.data_ptr(), ksel.data_ptr(), part2.data_ptr())
+    s2 = part2.double().sum(0)
+    ext = (y2 * sgn2.double()).max(2)[0] * sgn2.double()
+    print(f"fwd ysel {rel(ysel, ext):.1e} sum {rel(s2[:O], y2.sum((0,1,2))):.1e} sumsq {rel(s2[O:], (y2*y2).sum((0,1,2))):.1e}", end=" | ")
+    # backward
+    goa = torch.randn(B, M, O, device=dev, generator=g)
+    Qm = torch.randn(H, H, device=dev, generator=g) / H
+    evec = 0.1 * torch.randn(H, device=dev, generator=g)
+    S = torch.zeros(B, M, 32, O, dtype=torch.float64, device=dev)
+    S.scatter_(2, ksel.long().unsqueeze(2), goa.double().unsqueeze(2))
+    dA = S @ W2.double() + a1 @ Qm.double() + evec.double()
+    gu = dA * (a1 > 0)
+    yh = (y1 - mean1.double()) * inv1.double()
+    A_ref = torch.zeros(B, N, H, dtype=torch.float64, device=dev)
+    A_ref.scatter_add_(1, idx.long().view(B, M * 32, 1).expand(-1, -1, H), gu.view(B, M * 32, H))
+    zimg = mfma_b_image(torch.cat([W2, Qm], 0).contiguous(), min(4, H // 32))
+    A = torch.zeros(B, N, H, device=dev); HA = torch.empty(B, M, H, device=dev); HB = torch.empty(B, M, H, device=dev)
+    partT = torch.empty(grid, 2 * H, device=dev)
+    _call("apn_sa_wide_bwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(), zimg.data_ptr(),
+          pack1.data_ptr(), evec.data_ptr(), goa.data_ptr(), ksel.data_ptr(), A.data_ptr(), HA.data_ptr(),
+          HB.data_ptr(), partT.data_ptr())
+    T = partT.double().sum(0)
+    print(f"bwd A {rel(A, A_ref):.1e} HA {rel(HA, gu.sum(2)):.1e} HB {rel(HB, yh.sum(2)):.1e} T1 {rel(T[:H], gu.sum((0,1,2))):.1e} "
+          f"T2 {rel(T[H:], (gu*yh).sum((0,1,2))):.1e}", end=" | ")
+    rows = O + H
+    groups = (rows // 32 + 7) // 8
+    splits = max(1, min(512 // groups, (B * M) // 4, (16 << 20) // (rows * H * 4)))
+    Rpart = torch.empty(splits, rows, H, device=dev); sp = torch.empty(splits, H, device=dev)
+    _call("apn_sa_wide_wgrad", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(), pack1.data_ptr(),
+          goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr(), sp.data_ptr())
+    R = Rpart.double().sum(0)
+    a1f = a1.view(-1, H)
+    print(f"wgrad sparse {rel(R[:O], S.view(-1, O).t() @ a1f):.1e} gram {rel(R[O:], a1f.t() @ a1f):.1e} suma {rel(sp.double().sum(0), a1f.sum(0)):.1e}")
