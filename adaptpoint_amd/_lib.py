@@ -67,7 +67,8 @@ SIGNATURES = {
     "apn_pointset_group_max": [_c_int] * 5 + [_c_void_p] * 8,
     "apn_pointset_group_max_grad": [_c_int] * 5 + [_c_void_p] * 9,
     "apn_sa_wide_grid": [_c_int] * 2,
-    "apn_sa_wide_colsum": [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
+    "apn_sa_wide_colsum_chunks": [_c_int] * 2,
+    "apn_sa_wide_colsum": [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "apn_sa_wide_stats1": [_c_int] * 4 + [_c_void_p] * 5,
     "apn_sa_wide_fwd_main": [_c_int] * 5 + [_c_void_p] * 10,
     "apn_sa_wide_bwd_main": [_c_int] * 5 + [_c_void_p] * 13,

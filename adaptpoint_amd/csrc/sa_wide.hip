@@ -504,23 +504,28 @@ __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const f
 // (a library reduction with cross-block semaphores is avoided on purpose: the step must replay
 // identically from a hipGraph).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wide_colsum_kernel(const float *__restrict__ part, int rows, int ncol,
+template <typename T>
+__global__ __launch_bounds__(256) void wide_colsum_kernel(const T *__restrict__ part, int rows, int ncol,
                                                           double *__restrict__ out) {
+    // grid = (column blocks of 64, row chunks): out[blockIdx.y][ncol] = sums over this chunk's rows
     __shared__ double red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int per = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (c < ncol) {
-        int r = g;
-        for (; r + 12 < rows; r += 16) {
-            const float a = part[(size_t)r * ncol + c], b = part[(size_t)(r + 4) * ncol + c];
-            const float d = part[(size_t)(r + 8) * ncol + c], e = part[(size_t)(r + 12) * ncol + c];
+        int r = r0 + g;
+        for (; r + 12 < r1; r += 16) {
+            const T a = part[(size_t)r * ncol + c], b = part[(size_t)(r + 4) * ncol + c];
+            const T d = part[(size_t)(r + 8) * ncol + c], e = part[(size_t)(r + 12) * ncol + c];
             s0 += (double)a; s1 += (double)b; s2 += (double)d; s3 += (double)e;
         }
-        for (; r < rows; r += 4) s0 += (double)part[(size_t)r * ncol + c];
+        for (; r < r1; r += 4) s0 += (double)part[(size_t)r * ncol + c];
     }
     red[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (g == 0 && c < ncol) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (g == 0 && c < ncol)
+        out[(size_t)blockIdx.y * ncol + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -568,11 +573,29 @@ extern "C" int apn_sa_wide_grid(int b, int m) {
     default: return APN_EINVAL;      \
     }
 
-extern "C" int apn_sa_wide_colsum(const float *part, int rows, int ncol, double *out, void *stream) {
+extern "C" int apn_sa_wide_colsum_chunks(int rows, int ncol) {
+    // row chunks of the first pass: enough workgroups to fill the chip, at least 64 rows each
+    if (rows <= 0 || ncol <= 0) return 1;
+    const int colblocks = (ncol + 63) / 64;
+    int chunks = (512 + colblocks - 1) / colblocks;
+    if (chunks > (rows + 63) / 64) chunks = (rows + 63) / 64;
+    return chunks < 1 ? 1 : chunks;
+}
+
+extern "C" int apn_sa_wide_colsum(const float *part, int rows, int ncol, double *scratch, double *out,
+                                  void *stream) {
     if (rows < 0 || ncol <= 0 || !part || !out) return APN_EINVAL;
-    hipLaunchKernelGGL(wide_colsum_kernel, dim3((ncol + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, rows,
-                       ncol, out);
+    const int chunks = apn_sa_wide_colsum_chunks(rows, ncol);
+    if (chunks > 1 && !scratch) return APN_EINVAL;
+    const dim3 g1((ncol + 63) / 64, chunks);
+    hipLaunchKernelGGL(wide_colsum_kernel<float>, g1, dim3(256), 0, (hipStream_t)stream, part, rows, ncol,
+                       chunks > 1 ? scratch : out);
     APN_LAUNCH_CHECK();
+    if (chunks > 1) {
+        hipLaunchKernelGGL(wide_colsum_kernel<double>, dim3((ncol + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream,
+                           (const double *)scratch, chunks, ncol, out);
+        APN_LAUNCH_CHECK();
+    }
     return APN_OK;
 }
 

@@ -60,8 +60,11 @@ def _colsum(rows2d):
     (torch's multi-block reductions rely on semaphores that did not survive hipGraph replay here:
     `x.double().sum(0)` returned stale values from the second replay on.)"""
     rows2d = rows2d.contiguous()
-    out = torch.empty(rows2d.shape[1], dtype=torch.float64, device=rows2d.device)
-    _call("apn_sa_wide_colsum", rows2d.device, rows2d.data_ptr(), rows2d.shape[0], rows2d.shape[1], out.data_ptr())
+    rows, ncol = rows2d.shape
+    chunks = _lib.load().apn_sa_wide_colsum_chunks(rows, ncol)
+    buf = torch.empty((chunks + 1) * ncol, dtype=torch.float64, device=rows2d.device)
+    out = buf[:ncol]
+    _call("apn_sa_wide_colsum", rows2d.device, rows2d.data_ptr(), rows, ncol, buf[ncol:].data_ptr(), out.data_ptr())
     return out
 
 
@@ -192,7 +195,7 @@ class _WideMlpMax(torch.autograd.Function):
         # weight-gradient products over the positions
         rows = O + H
         groups = (rows // 32 + 7) // 8
-        splits = max(1, min(512 // groups, (B * M) // 4, (16 << 20) // (rows * H * 4)))
+        splits = max(1, min(512 // groups, (B * M) // 4, (64 << 20) // (rows * H * 4)))
         Rpart = torch.empty(splits, rows, H, dtype=torch.float32, device=dev)
         sumapart = torch.empty(splits, H, dtype=torch.float32, device=dev)
         _call("apn_sa_wide_wgrad", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),

@@ -351,8 +351,11 @@ APN_API int apn_attention_bwd(int b, int m, int heads, const void *images, const
  * {scale, shift, mean, invstd}[H].  Weight operands are "B images" (bf16 hi/lo parts in MFMA
  * fragment order, adaptpoint_amd/fused_wide.py::mfma_b_image). ---- */
 APN_API int apn_sa_wide_grid(int b, int m);          /* workgroups = partial rows of the three passes */
-/* out[ncol] (float64) = column sums of part[rows][ncol] (float32) in a fixed order */
-APN_API int apn_sa_wide_colsum(const float *part, int rows, int ncol, double *out, void *stream);
+/* out[ncol] (float64) = column sums of part[rows][ncol] (float32) in a fixed order; two passes
+ * through scratch[apn_sa_wide_colsum_chunks(rows, ncol)][ncol] (float64) when there is more than one chunk */
+APN_API int apn_sa_wide_colsum_chunks(int rows, int ncol);
+APN_API int apn_sa_wide_colsum(const float *part, int rows, int ncol, double *scratch, double *out,
+                               void *stream);
 /* part[grid][2H] = {sum, sumsq} of y1 */
 APN_API int apn_sa_wide_stats1(int b, int n, int m, int c_mid, const float *U, const float *V,
                                const int *idx, float *part, void *stream);
