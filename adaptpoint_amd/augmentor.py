@@ -64,14 +64,27 @@ def draw_noise(batch, n_points, n_anchor, with_gumbel=False):
     return Noise(keep, axes, kernel_axes, expo)
 
 
+def draw_noise_on(device, batch, n_points, n_anchor):
+    """The same distributions drawn from the DEVICE generator (no host-to-device copy: a captured
+    hipGraph replays fresh draws).  Not the reference's CPU stream of numbers -- use `draw_noise`
+    (or the module's default) when the reference's draws are to be reproduced."""
+    expo = torch.empty(batch, n_points, 2, device=device).exponential_()
+    keep = torch.bernoulli(torch.rand(batch, n_anchor, 3, device=device))
+    bits = torch.arange(3, device=device)
+    axes = ((torch.randint(1, 8, (batch, n_anchor), device=device).unsqueeze(-1) >> bits) & 1).int()
+    kernel_axes = ((torch.randint(1, 8, (batch, 1), device=device).unsqueeze(-1) >> bits) & 1).int()
+    return Noise(keep, axes, kernel_axes, expo)
+
+
 def anchor_transforms(prob, noise, r_range, s_range, t_range):
     """prob (B,M,9) -> A (B,M,3,3) = R diag(s) and t (B,M,3)   (:236-297).
     Rotation angles tanh(.) * r_range degrees, scales 1 + sigmoid(.) * (s_range - 1), offsets
     tanh(.) * t_range; each of the three switched per anchor by `keep`, scale and offset confined
     to the anchor's `axes` (a scale of 0 means "axis not scaled": it becomes 1)."""
     keep, axes = noise.keep.to(prob.dtype), noise.axes.to(prob.dtype)
-    pi = torch.tensor(math.pi, device=prob.device)
-    ang = pi * (torch.tanh(prob[..., 0:3]) * r_range) / 180.0 * keep[..., 0:1]
+    # (the reference multiplies by a float32 tensor holding pi; a Python scalar is rounded to float32 by the
+    # same multiplication and needs no host-to-device copy, so the step stays hipGraph-capturable)
+    ang = math.pi * (torch.tanh(prob[..., 0:3]) * r_range) / 180.0 * keep[..., 0:1]
     s = (torch.sigmoid(prob[..., 3:6]) * (s_range - 1) + 1) * keep[..., 1:2] * axes
     s = s + (s == 0)
     t = torch.tanh(prob[..., 6:9]) * t_range * keep[..., 2:3] * axes

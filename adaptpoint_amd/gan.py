@@ -106,18 +106,22 @@ class GanStep:
 
     def __init__(self, generator, discriminator, classifier, criterion, lr_generator=1e-4,
                  lr_discriminator=4e-4, betas=(0.5, 0.999), hard_ratio=3.0, feedback_ratio=1.0,
-                 in_channels=4, batched_feedback=True):
+                 in_channels=4, batched_feedback=True, capturable=False):
         self.G, self.D, self.C = generator, discriminator, classifier
         self.criterion = criterion
-        self.opt_g = torch.optim.Adam(generator.parameters(), lr=lr_generator, betas=betas)
-        self.opt_d = torch.optim.Adam(discriminator.parameters(), lr=lr_discriminator, betas=betas)
+        # capturable: optimizer state on the device, so that the whole step can be a hipGraph
+        self.opt_g = torch.optim.Adam(generator.parameters(), lr=lr_generator, betas=betas, capturable=capturable)
+        self.opt_d = torch.optim.Adam(discriminator.parameters(), lr=lr_discriminator, betas=betas,
+                                      capturable=capturable)
         self.bce = nn.BCELoss()
         self.hard_ratio, self.feedback_ratio = hard_ratio, feedback_ratio
         self.in_channels, self.batched_feedback = in_channels, batched_feedback
 
-    def __call__(self, points, label, noise=None):
+    def __call__(self, points, label, noise=None, device_noise=False):
         """points (B,N,C>=in_channels) with xyz first, label (B,) -> dict of the step's scalars
-        (0-dim tensors, no host sync) and the generated clouds."""
+        (0-dim tensors, no host sync) and the generated clouds.  device_noise: draw the generator's
+        random switches from the device generator instead of the CPU one (same distributions; no
+        host-to-device copy, so the step can be captured in a hipGraph)."""
         G, D = self.G, self.D
         G.train()
         D.train()
@@ -128,6 +132,9 @@ class GanStep:
         fake_t = torch.full((B, 1), 0.1, device=points.device)
 
         # ---- generator
+        if noise is None and device_noise:
+            from .augmentor import draw_noise_on
+            noise = draw_noise_on(xyz.device, B, xyz.shape[1], G.num_anchor)
         _, gen = G(xyz) if noise is None else G(xyz, noise)
         g_raw = self.bce(D(gen), real_t)
         g_loss, fb = g_raw, None

@@ -52,7 +52,8 @@ class _GroupMax(torch.autograd.Function):
         _call("apn_pointset_group_max_grad", points.device, B, N, M, C, K, points.data_ptr(),
               idx.data_ptr(), fidx.data_ptr(), al.data_ptr(), ksel.data_ptr(), g.data_ptr(),
               g_points.data_ptr(), part.data_ptr())
-        sums = part.double().sum(0).float()
+        from .fused_wide import _colsum           # fixed-order float64 column sums (hipGraph-replay safe)
+        sums = _colsum(part).float()
         return (g_points, None, None, sums[:C].reshape(ctx.shapes[0]), sums[C:].reshape(ctx.shapes[1]))
 
 

@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--mode", default="both", choices=["fused", "composed", "both"])
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole joint step from a hipGraph (random draws of the generator then come "
+                         "from the device generator, capturable Adam)")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     a = ap.parse_args()
@@ -58,16 +61,30 @@ def main():
         G = AdaptPointAugmentor(fused=fused).to(dev)
         D = PointDiscriminator1(num_classes=15).to(dev)
         C = PointNextSClassifier(fused=fused).to(dev)
-        step = GanStep(G, D, C, SmoothCrossEntropy(0.3), batched_feedback=fused)
+        step = GanStep(G, D, C, SmoothCrossEntropy(0.3), batched_feedback=fused, capturable=a.graph)
+        run = lambda: step(points, label)
+        if a.graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step(points, label, device_noise=True)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                captured = step(points, label, device_noise=True)
+            run = graph.replay
         torch.cuda.reset_peak_memory_stats()
-        sec = timed(lambda: step(points, label), a.iters, a.warmup)
+        sec = timed(run, a.iters, a.warmup)
         res = {"config": "train_gan step (BASELINE configs[3])", "mode": mode, "B": a.batch, "N": a.points,
                "ms_per_step": round(sec * 1e3, 3), "clouds_per_s": round(a.batch / sec, 1),
-               "peak_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "launch": "eager"}
-        out = step(points, label)
+               "peak_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+               "launch": "hipGraph replay" if a.graph else "eager"}
+        out = captured if a.graph else step(points, label)
         res["losses"] = {k: round(float(out[k]), 5) for k in ("g_loss_raw", "feedback_loss", "d_loss")}
         print(json.dumps(res), flush=True)
-        if a.points > 1024:
+        if a.points > 1024 and not a.graph:
             cstep = ClassifierStep(C)
             sec = timed(lambda: cstep(points, label), a.iters, a.warmup)
             print(json.dumps({"config": "train_one_epoch step with resampler (BASELINE configs[2] as trained)",
