@@ -72,6 +72,13 @@ SIGNATURES = {
     "apn_sa_wide_stats1": [_c_int] * 4 + [_c_void_p] * 5,
     "apn_sa_wide_fwd_main": [_c_int] * 5 + [_c_void_p] * 10,
     "apn_sa_wide_bwd_main": [_c_int] * 5 + [_c_void_p] * 13,
+    "apn_sa_wide_image": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
+    "apn_sa_wide_bwd_prep_rows": [_c_int] * 2,
+    "apn_sa_wide_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] * 5,
+    "apn_sa_wide_consts2": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_double, _c_int] + [_c_void_p] * 4,
+    "apn_sa_wide_consts1": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_double, _c_int] + [_c_void_p] * 4,
+    "apn_sa_wide_geo": [_c_int] * 3 + [_c_void_p] * 4,
+    "apn_sa_wide_point_terms": [_c_int] * 4 + [_c_void_p] * 5 + [_c_int, _c_float] + [_c_void_p] * 4,
     "apn_sa_wide_wgrad_splits": [_c_int] * 3,
     "apn_sa_wide_wgrad": [_c_int] * 5 + [_c_void_p] * 6 + [_c_int] + [_c_void_p] * 3,
     "apn_sa_sample_overlap": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 7,

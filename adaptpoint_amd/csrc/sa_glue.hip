@@ -705,7 +705,7 @@ extern "C" int apn_sa_bn_fold(const float *part, int rows, const double *sums, i
                               float *running_mean, float *running_var, void *num_batches_tracked,
                               int training, float *pack, const float *sgn_gamma, int sgn_c,
                               float *sgn_out, void *stream) {
-    if ((c != 32 && c != 64) || !pack || sgn_c > 1024) return APN_EINVAL;
+    if (c < 4 || c > 1024 || (c & 3) || !pack || sgn_c > 1024) return APN_EINVAL;
     if (training && !part && !sums) return APN_EINVAL;
     if (!training && (!running_mean || !running_var)) return APN_EINVAL;
     if (part && ((uintptr_t)part & 15)) return APN_EINVAL;

@@ -1,0 +1,286 @@
+// sa_wide_glue.hip -- the small kernels around the width-generic fused passes (csrc/sa_wide.hip):
+// operand images, the upstream gradient's layout change with BatchNorm-2's row sums, the
+// per-channel constants of the two BatchNorm backwards, the occurrence statistics of the points
+// and the per-point / per-query terms of dL/dy1.  Each replaces a chain of 5-20 tiny tensor ops
+// (an eager step of one block was ~200 launches, most of them 3-5 us of launch latency).
+// Dense products whose contraction runs over points or channels (U = W1f f, dL/df = G W1f,
+// dL/dW1 = G^T f, Qm = W2^T D2 W2, W2 Gram) stay library GEMMs in the caller.
+#include "apn_common.h"
+#include "apn_mfma.h"
+
+namespace apn {
+
+// ------------------------------------------------------------------------------------------
+// B image of Bm (Kd x Nc): rows k < K0 from src0, the rest from src1 (both row-major with Nc
+// columns; trans0: src0 is stored (Nc x K0) and read transposed).  One thread per 16-byte word
+// [cb][kc][j][s][part][lane] (layout: adaptpoint_amd/fused_wide.py::mfma_b_image).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wide_image_kernel(const float *__restrict__ src0, int K0, int trans0,
+                                                         const float *__restrict__ src1, int Kd, int Nc, int ct,
+                                                         uint4 *__restrict__ img) {
+    const int nkc = Kd / 32, ncb = Nc / (32 * ct);
+    const int total = ncb * nkc * ct * 2 * 2 * 64;
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= total) return;
+    const int lane = w & 63, part = (w >> 6) & 1, s = (w >> 7) & 1;
+    int rest = w >> 8;
+    const int j = rest % ct; rest /= ct;
+    const int kc = rest % nkc;
+    const int cb = rest / nkc;
+    const int col = (cb * ct + j) * 32 + (lane & 31), k0 = kc * 32 + s * 16 + (lane >> 5) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        float v;
+        if (k < K0) v = trans0 ? src0[(size_t)col * K0 + k] : src0[(size_t)k * Nc + col];
+        else v = src1[(size_t)(k - K0) * Nc + col];
+        const __bf16 hi = (__bf16)v;
+        o[e] = part == 0 ? hi : (__bf16)(v - (float)hi);
+    }
+    img[w] = __builtin_bit_cast(uint4, o);
+}
+
+// ------------------------------------------------------------------------------------------
+// Upstream gradient g (B,O,M; any strides, a broadcast is never materialised) ->
+//   goa (B,M,O) = g * scale2 (the gradient that reaches y2 at the pooled slot),
+//   partS[b * mt + tile][2*O] = {sum_m g, sum_m g * yhat_sel}, yhat_sel = (ysel - mean2) * invstd2.
+// Block = 64 queries x 64 channels through an LDS tile (reads coalesced along m, writes along c).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wide_bwd_prep_kernel(int m, int O, const float *__restrict__ g,
+                                                            long long gs_b, long long gs_c, long long gs_m,
+                                                            const float *__restrict__ ysel,
+                                                            const float *__restrict__ pack2,
+                                                            float *__restrict__ goa, float *__restrict__ partS) {
+    __shared__ float tile[64][65];
+    __shared__ float red[2][4][64];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int cc = ty; cc < 64; cc += 4) {          // tile[c][m]: coalesced along m
+        const int q = m0 + tx;
+        tile[cc][tx] = q < m ? g[b * gs_b + (long long)(c0 + cc) * gs_c + q * gs_m] : 0.0f;
+    }
+    __syncthreads();
+    const int c = c0 + tx;                          // this thread's channel; queries ty, ty+4, ...
+    const float sc = pack2[c], mu = pack2[2 * O + c], iv = pack2[3 * O + c];
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int qq = ty; qq < 64; qq += 4) {
+        const int q = m0 + qq;
+        if (q < m) {
+            const float gv = tile[tx][qq];
+            const size_t o = ((size_t)b * m + q) * O + c;
+            goa[o] = gv * sc;
+            s1 += gv;
+            s2 = __builtin_fmaf(gv, (ysel[o] - mu) * iv, s2);
+        }
+    }
+    red[0][ty][tx] = s1;
+    red[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0) {
+        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+        partS[row * 2 * O + c] = (red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx]);
+        partS[row * 2 * O + O + c] = (red[1][0][tx] + red[1][1][tx]) + (red[1][2][tx] + red[1][3][tx]);
+    }
+}
+
+// Fixed-order float64 sum over the rows of column c of part[rows][stride] for one 256-thread block
+// (thread = (column tx < 64, row group ty < 4)); result valid for ty == 0 after the call.
+__device__ __forceinline__ double block_col_sum(const float *__restrict__ part, int rows, int stride, int c,
+                                                bool ok, double (*red)[64]) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double s = 0.0;
+    if (ok)
+        for (int r = ty; r < rows; r += 4) s += (double)part[(size_t)r * stride + c];
+    __syncthreads();
+    red[ty][tx] = s;
+    __syncthreads();
+    return (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+// BatchNorm-2 backward constants from partS: dL/dy2 = goa [slot == ksel] + y2 * D2 + E2.
+//   d2e2 = {D2[O], E2[O]} (float32), dgamma2 = S2, dbeta2 = S1.  Grid: O/64 blocks.
+// With `sums` (float64 {S1[O], S2[O], global count, world}: the rows summed and all-reduced over ranks,
+// SyncBatchNorm) the statistics use the global values and dgamma / dbeta are reported as global / world.
+__global__ __launch_bounds__(256) void wide_consts2_kernel(const float *__restrict__ partS, int rows, int O,
+                                                           const double *__restrict__ sums,
+                                                           const float *__restrict__ pack2, double count,
+                                                           int training, float *__restrict__ d2e2,
+                                                           float *__restrict__ g_gamma2, float *__restrict__ g_beta2) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, c = blockIdx.x * 64 + tx;
+    double s1, s2, gscale = 1.0;
+    if (sums) {
+        s1 = c < O ? sums[c] : 0.0;
+        s2 = c < O ? sums[O + c] : 0.0;
+        count = sums[2 * O];
+        gscale = 1.0 / sums[2 * O + 1];
+    } else {
+        s1 = block_col_sum(partS, rows, 2 * O, c, c < O, red);
+        s2 = block_col_sum(partS, rows, 2 * O, O + c, c < O, red);
+    }
+    if (threadIdx.x >= 64 || c >= O) return;
+    const double sc = pack2[c], mu = pack2[2 * O + c], iv = pack2[3 * O + c];
+    double d = 0.0, e = 0.0;
+    if (training) {
+        d = -sc * iv * s2 / count;
+        e = -sc * s1 / count + sc * mu * iv * s2 / count;
+    }
+    d2e2[c] = (float)d;
+    d2e2[O + c] = (float)e;
+    if (g_gamma2) g_gamma2[c] = (float)(s2 * gscale);
+    if (g_beta2) g_beta2[c] = (float)(s1 * gscale);
+}
+
+// BatchNorm-1 backward constants from partT = {T1 = sum g_u, T2 = sum g_u yhat1}[H]:
+//   dL/dy1 = ca g_u + cb yhat1 + cc;  cabc = {ca, cb, cc}[H]; dgamma1 = T2, dbeta1 = T1.
+__global__ __launch_bounds__(256) void wide_consts1_kernel(const float *__restrict__ partT, int rows, int H,
+                                                           const double *__restrict__ sums,
+                                                           const float *__restrict__ pack1, double count,
+                                                           int training, float *__restrict__ cabc,
+                                                           float *__restrict__ g_gamma1, float *__restrict__ g_beta1) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, c = blockIdx.x * 64 + tx;
+    double t1, t2, gscale = 1.0;
+    if (sums) {
+        t1 = c < H ? sums[c] : 0.0;
+        t2 = c < H ? sums[H + c] : 0.0;
+        count = sums[2 * H];
+        gscale = 1.0 / sums[2 * H + 1];
+    } else {
+        t1 = block_col_sum(partT, rows, 2 * H, c, c < H, red);
+        t2 = block_col_sum(partT, rows, 2 * H, H + c, c < H, red);
+    }
+    if (threadIdx.x >= 64 || c >= H) return;
+    const double sc = pack1[c];
+    cabc[c] = (float)sc;
+    cabc[H + c] = training ? (float)(-sc * t2 / count) : 0.0f;
+    cabc[2 * H + c] = training ? (float)(-sc * t1 / count) : 0.0f;
+    if (g_gamma1) g_gamma1[c] = (float)(t2 * gscale);
+    if (g_beta1) g_beta1[c] = (float)(t1 * gscale);
+}
+
+// Occurrence statistics of the points (coordinates only): geo[b][n] = {how often point n is
+// gathered, sum of the gathering queries' coordinates}.  One wave per query, lane = slot; the
+// ball-query fill run (copies of slot 0) is folded into ONE atomic per component.  geo caller-zeroed.
+__global__ __launch_bounds__(256) void wide_geo_kernel(int ntiles, int n, int m, const int *__restrict__ idx,
+                                                       const float *__restrict__ new_xyz, float *__restrict__ geo) {
+    const int lane = lane_id(), tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int cloud = tile / m;
+    const int k = lane & 31, comp = lane >> 5;                 // two lanes per slot: components {0,1} / {2,3}
+    const int nn = idx[(size_t)tile * 32 + k];
+    const int first = __builtin_amdgcn_readfirstlane(nn);
+    const bool dup = k > 0 && nn == first;
+    const unsigned long long dups = __ballot(dup && comp == 0);
+    const float mult = k == 0 ? 1.0f + (float)__popcll(dups) : 1.0f;
+    if (dup) return;
+    const float *q = new_xyz + (size_t)tile * 3;
+    float *dst = geo + ((size_t)cloud * n + nn) * 4 + 2 * comp;
+    atomicAdd(dst, mult * (comp == 0 ? 1.0f : q[1]));
+    atomicAdd(dst + 1, mult * (comp == 0 ? q[0] : q[2]));
+}
+
+// dL/dU per point and (minus) dL/dV per query from dL/dy1 = ca g_u + cb yhat1 + cc:
+//   G[b,n,h]  = ca A + cb inv1 (occ (U - mean1) - (SP . W1p[h]) / r) + cc occ          (in place over A)
+//   Hq[b,q,h] = ca HA + cb HB + 32 cc                                                  (in place over HA)
+// W1 (H x ldw): its first three columns are W1p.  Blocks [0, pblocks) do points, the rest queries.
+__global__ __launch_bounds__(256) void wide_point_terms_kernel(long long npts, long long nqry, int H, int pblocks,
+                                                               const float *__restrict__ cabc,
+                                                               const float *__restrict__ pack1,
+                                                               const float *__restrict__ U,
+                                                               const float *__restrict__ geo,
+                                                               const float *__restrict__ w1, int ldw, float inv_r,
+                                                               float *__restrict__ A, float *__restrict__ HA,
+                                                               const float *__restrict__ HB) {
+    if ((int)blockIdx.x < pblocks) {
+        const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (e >= npts * H) return;
+        const int h = (int)(e % H);
+        const long long pt = e / H;
+        const float4 ge = *reinterpret_cast<const float4 *>(geo + pt * 4);
+        const float occ = ge.x;
+        const float spw = __builtin_fmaf(ge.w, w1[(size_t)h * ldw + 2],
+                                         __builtin_fmaf(ge.z, w1[(size_t)h * ldw + 1], ge.y * w1[(size_t)h * ldw]));
+        const float yh = pack1[3 * H + h] * (occ * (U[e] - pack1[2 * H + h]) - spw * inv_r);
+        A[e] = __builtin_fmaf(cabc[h], A[e], __builtin_fmaf(cabc[H + h], yh, cabc[2 * H + h] * occ));
+    } else {
+        const long long e = (long long)(blockIdx.x - pblocks) * 256 + threadIdx.x;
+        if (e >= nqry * H) return;
+        const int h = (int)(e % H);
+        HA[e] = __builtin_fmaf(cabc[h], HA[e], __builtin_fmaf(cabc[H + h], HB[e], 32.0f * cabc[2 * H + h]));
+    }
+}
+
+}  // namespace apn
+
+using namespace apn;
+
+extern "C" int apn_sa_wide_image(const float *src0, int k0, int trans0, const float *src1, int kd, int nc, int ct,
+                                 void *image, void *stream) {
+    if (!src0 || !image || kd <= 0 || nc <= 0 || ct < 1 || ct > 4 || (kd % 32) || (nc % (32 * ct)) || k0 < 0 ||
+        k0 > kd || (k0 < kd && !src1))
+        return APN_EINVAL;
+    const int total = (nc / 32) * (kd / 32) * 256;
+    hipLaunchKernelGGL(wide_image_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src0, k0,
+                       trans0, src1, kd, nc, ct, (uint4 *)image);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_wide_bwd_prep_rows(int b, int m) { return b * ((m + 63) / 64); }
+
+extern "C" int apn_sa_wide_bwd_prep(int b, int m, int c_out, const float *g, long long gs_b, long long gs_c,
+                                    long long gs_m, const float *ysel, const float *pack2, float *goa,
+                                    float *part_s, void *stream) {
+    if (b <= 0 || m <= 0 || b > 65535 || c_out <= 0 || (c_out % 64) || !g || !ysel || !pack2 || !goa || !part_s)
+        return APN_EINVAL;
+    hipLaunchKernelGGL(wide_bwd_prep_kernel, dim3((m + 63) / 64, c_out / 64, b), dim3(256), 0, (hipStream_t)stream,
+                       m, c_out, g, gs_b, gs_c, gs_m, ysel, pack2, goa, part_s);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_wide_consts2(const float *part_s, int rows, const double *sums, int c_out,
+                                   const float *pack2, double count, int training, float *d2e2,
+                                   float *g_gamma2, float *g_beta2, void *stream) {
+    if ((!part_s && !sums) || rows < 0 || c_out <= 0 || !pack2 || !d2e2) return APN_EINVAL;
+    hipLaunchKernelGGL(wide_consts2_kernel, dim3((c_out + 63) / 64), dim3(256), 0, (hipStream_t)stream, part_s, rows,
+                       c_out, sums, pack2, count, training, d2e2, g_gamma2, g_beta2);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_wide_consts1(const float *part_t, int rows, const double *sums, int c_mid,
+                                   const float *pack1, double count, int training, float *cabc,
+                                   float *g_gamma1, float *g_beta1, void *stream) {
+    if ((!part_t && !sums) || rows < 0 || c_mid <= 0 || !pack1 || !cabc) return APN_EINVAL;
+    hipLaunchKernelGGL(wide_consts1_kernel, dim3((c_mid + 63) / 64), dim3(256), 0, (hipStream_t)stream, part_t, rows,
+                       c_mid, sums, pack1, count, training, cabc, g_gamma1, g_beta1);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_wide_geo(int b, int n, int m, const int *idx, const float *new_xyz, float *geo, void *stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || !idx || !new_xyz || !geo) return APN_EINVAL;
+    const int ntiles = b * m;
+    hipLaunchKernelGGL(wide_geo_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, ntiles, n, m, idx,
+                       new_xyz, geo);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_wide_point_terms(int b, int n, int m, int c_mid, const float *cabc, const float *pack1,
+                                       const float *U, const float *geo, const float *w1, int ldw, float radius,
+                                       float *A, float *HA, const float *HB, void *stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || c_mid <= 0 || !cabc || !pack1 || !U || !geo || !w1 || ldw < 3 || !A || !HA ||
+        !HB || !(radius > 0.0f))
+        return APN_EINVAL;
+    const long long npts = (long long)b * n, nqry = (long long)b * m;
+    const long long pb = (npts * c_mid + 255) / 256, qb = (nqry * c_mid + 255) / 256;
+    if (pb + qb > 0x7fffffffLL) return APN_EINVAL;
+    hipLaunchKernelGGL(wide_point_terms_kernel, dim3((unsigned)(pb + qb)), dim3(256), 0, (hipStream_t)stream, npts,
+                       nqry, c_mid, (int)pb, cabc, pack1, U, geo, w1, ldw, 1.0f / radius, A, HA, HB);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}

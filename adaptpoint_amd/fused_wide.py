@@ -68,35 +68,32 @@ def _colsum(rows2d):
     return out
 
 
-def _stats_to_pack(sums, count, bn, C, training, sync):
-    """{sum[C], sumsq[C]} (float64) -> pack {scale, shift, mean, invstd}[C] (float32 (4C,)), with the
-    running-buffer update of torch.nn.BatchNorm when training; the running buffers when not."""
-    dev = bn.weight.device if bn.weight is not None else bn.running_mean.device
-    if training:
-        if sync:
-            vec = torch.cat([sums, torch.full((1,), float(count), dtype=torch.float64, device=dev),
-                             torch.ones(1, dtype=torch.float64, device=dev)])
-            _fz._allreduce_sum_(vec)
-            sums, count_t = vec[:2 * C], vec[2 * C]
-        else:
-            count_t = torch.full((), float(count), dtype=torch.float64, device=dev)   # (a fill: graph-capturable)
-        mean = sums[:C] / count_t
-        var = (sums[C:] / count_t - mean * mean).clamp_min(0.0)
-        if bn.track_running_stats and bn.training:
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
-                mom = bn.momentum
-                unbiased = var * (count_t / (count_t - 1).clamp_min(1.0))
-                bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(unbiased.to(bn.running_var.dtype), alpha=mom)
-    else:
-        mean, var = bn.running_mean.double(), bn.running_var.double()
-        count_t = torch.full((), float(count), dtype=torch.float64, device=dev)
-    inv = torch.rsqrt(var + bn.eps)
-    gamma = bn.weight.detach().double() if bn.weight is not None else torch.ones_like(mean)
-    beta = bn.bias.detach().double() if bn.bias is not None else torch.zeros_like(mean)
-    scale = gamma * inv
-    return torch.cat([scale, beta - mean * scale, mean, inv]).float().contiguous(), count_t
+def _bn_pack(part, rows, C, count, bn, dev, training, sync, sgn_from=None, sgn_c=0):
+    """BatchNorm fold by the extension's `apn_sa_bn_fold` (csrc/sa_glue.hip): the partial rows
+    {sum[C], sumsq[C]} -> pack {scale, shift, mean, invstd}[C] (float32, (4C,)), running buffers and
+    num_batches_tracked updated as torch.nn.BatchNorm does; with `sync` the float64 sums, the position
+    count and a 1 are all-reduced over ranks first.  Rider: sgn (sign of another BatchNorm's gamma)."""
+    pack = torch.empty(4 * C, dtype=torch.float32, device=dev)
+    sgn = torch.empty(sgn_c, dtype=torch.float32, device=dev) if sgn_c else None
+    sums = None
+    if training and sync:
+        sums = torch.cat([_colsum(part), torch.full((1,), float(count), dtype=torch.float64, device=dev),
+                          torch.ones(1, dtype=torch.float64, device=dev)])
+        _fz._allreduce_sum_(sums)
+    args = _fz._bn_args(bn)      # (gamma, beta, running_mean, running_var, nbt, eps, momentum, training)
+    _call("apn_sa_bn_fold", dev, _fz._ptr(part) if (training and sums is None) else None, rows, _fz._ptr(sums), C,
+          float(count), args[0], args[1], args[5], args[6], args[2], args[3], args[4], 1 if training else 0,
+          pack.data_ptr(), _fz._ptr(sgn_from), sgn_c, _fz._ptr(sgn))
+    return pack, sgn, sums
+
+
+def _image(src0, k0, trans0, src1, kd, nc, ct):
+    """B image (bf16 hi/lo, MFMA fragment order) of the (kd x nc) operand whose first k0 rows come from
+    src0 and the rest from src1 -- one launch (`mfma_b_image` is the tensor-op statement of the layout)."""
+    img = torch.empty(nc // (32 * ct), kd // 32, ct, 2, 2, 64, 8, dtype=torch.bfloat16, device=src0.device)
+    _call("apn_sa_wide_image", src0.device, src0.data_ptr(), k0, 1 if trans0 else 0, _fz._ptr(src1), kd, nc, ct,
+          img.data_ptr())
+    return img
 
 
 def _training(bn):
@@ -114,47 +111,43 @@ class _WideMlpMax(torch.autograd.Function):
         H, O = w1.shape[0], w2.shape[0]
         sync = sync_bn and (_fz._world(True) > 1 or _fz.FORCE_PHASED)
         with torch.no_grad():
-            W1 = w1.detach().reshape(H, C + 3)
+            W1 = w1.detach().reshape(H, C + 3).contiguous()
             W1p, W1f = W1[:, :3], W1[:, 3:]
-            W2 = w2.detach().reshape(O, H)
-            # conv1 at the points: one row per support point, one per query
+            W2 = w2.detach().reshape(O, H).contiguous()
+            # conv1 at the points: one row per support point, one per query (plain dense products)
             U = torch.baddbmm(torch.matmul(p, W1p.t()) / radius, f.transpose(1, 2), W1f.t().expand(B, C, H))
             V = (torch.matmul(new_p, W1p.t()) / radius).contiguous()
             U = U.contiguous()
             grid = _lib.load().apn_sa_wide_grid(B, M)
             count = float(B * M * K_NS)
             tr1, tr2 = _training(bn1), _training(bn2)
-            sums1 = None
+            part1 = None
             if tr1:
                 part1 = torch.empty(grid, 2 * H, dtype=torch.float32, device=dev)
                 _call("apn_sa_wide_stats1", dev, B, N, M, H, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
                       part1.data_ptr())
-                sums1 = _colsum(part1)
-            pack1, cnt1 = _stats_to_pack(sums1, count, bn1, H, tr1, sync)
-            sgn2 = (torch.where(g2.detach() >= 0, 1.0, -1.0).float() if g2 is not None
-                    else torch.ones(O, device=dev))
-            w2img = mfma_b_image(W2.t(), min(4, O // 32))
+            pack1, sgn2, _ = _bn_pack(part1, grid, H, count, bn1, dev, tr1, sync, sgn_from=g2, sgn_c=O)
+            w2img = _image(W2, H, True, None, H, O, min(4, O // 32))          # W2^T (H x O)
             ysel = torch.empty(B, M, O, dtype=torch.float32, device=dev)
             ksel = torch.empty(B, M, O, dtype=torch.uint8, device=dev)
             part2 = torch.empty(grid, 2 * O, dtype=torch.float32, device=dev)
             _call("apn_sa_wide_fwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
                   w2img.data_ptr(), pack1.data_ptr(), sgn2.data_ptr(), ysel.data_ptr(), ksel.data_ptr(),
                   part2.data_ptr())
-            pack2, cnt2 = _stats_to_pack(_colsum(part2) if tr2 else None, count, bn2, O, tr2, sync)
+            pack2, _, _ = _bn_pack(part2 if tr2 else None, grid, O, count, bn2, dev, tr2, sync)
             out = torch.addcmul(pack2[O:2 * O], ysel, pack2[:O]).transpose(1, 2).contiguous()
             if _DEBUG is not None:
                 _DEBUG.update(U=U, V=V, pack1=pack1, w2img=w2img, ysel=ysel, ksel=ksel, part2=part2, pack2=pack2,
-                              sgn2=sgn2, sums1=sums1)
+                              sgn2=sgn2)
         ctx.save_for_backward(p, new_p, f, idx, U, V, pack1, pack2, ysel, ksel, W1, W2)
-        ctx.cfg = (radius, tr1, tr2, sync, cnt1, cnt2, g1 is not None, b1 is not None, g2 is not None,
-                   b2 is not None)
+        ctx.cfg = (radius, tr1, tr2, sync, count, g1 is not None, b1 is not None, g2 is not None, b2 is not None)
         ctx.need = (p.requires_grad, new_p.requires_grad)
         return out
 
     @staticmethod
     def backward(ctx, g):
         p, new_p, f, idx, U, V, pack1, pack2, ysel, ksel, W1, W2 = ctx.saved_tensors
-        radius, tr1, tr2, sync, cnt1, cnt2, a1, a2, a3, a4 = ctx.cfg
+        radius, tr1, tr2, sync, count, a1, a2, a3, a4 = ctx.cfg
         need_p, need_q = ctx.need
         dev = f.device
         B, C, N = f.shape
@@ -162,33 +155,38 @@ class _WideMlpMax(torch.autograd.Function):
         H, O = W1.shape[0], W2.shape[0]
         W1p, W1f = W1[:, :3], W1[:, 3:]
         lib = _lib.load()
-        gz = g.transpose(1, 2).contiguous().float()                        # (B,M,O)
-        scale2, mean2, inv2 = pack2[:O], pack2[2 * O:3 * O], pack2[3 * O:]
-        yh_sel = (ysel - mean2) * inv2
-        # BatchNorm-2 backward: only the pooled positions carry upstream gradient
-        s = torch.stack([_colsum(gz.view(B * M, O)), _colsum((gz * yh_sel).view(B * M, O))])       # (2,O)
-        world = 1.0
-        if sync:
-            vec = torch.cat([s.reshape(-1), torch.ones(1, dtype=torch.float64, device=dev)])
-            _fz._allreduce_sum_(vec)
-            s, world = vec[:2 * O].view(2, O), vec[2 * O]
-        g_gamma2, g_beta2 = (s[1] / world).float(), (s[0] / world).float()
-        if tr2:
-            D2 = -scale2.double() * inv2.double() * s[1] / cnt2
-            E2 = -scale2.double() * s[0] / cnt2 + scale2.double() * mean2.double() * inv2.double() * s[1] / cnt2
-        else:
-            D2 = torch.zeros(O, dtype=torch.float64, device=dev)
-            E2 = torch.zeros(O, dtype=torch.float64, device=dev)
-        goa = (gz * scale2).contiguous()
-        W2d = W2.double()
-        Qm = (W2d.t() * D2) @ W2d                                            # W2^T diag(D2) W2  (H,H)
-        evec = (E2 @ W2d).float().contiguous()
-        zimg = mfma_b_image(torch.cat([W2, Qm.float()], 0), min(4, H // 32))
+        if g.dtype != torch.float32:
+            g = g.float()
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def reduced(part):
+            """SyncBatchNorm: the rows summed, with {count, 1} appended, all-reduced over ranks."""
+            v = torch.cat([_colsum(part), torch.full((1,), count, dtype=torch.float64, device=dev),
+                           torch.ones(1, dtype=torch.float64, device=dev)])
+            _fz._allreduce_sum_(v)
+            return v
+        # the upstream gradient in query-major layout, BatchNorm-2's row sums (only pooled slots carry gradient)
+        prow = lib.apn_sa_wide_bwd_prep_rows(B, M)
+        goa = torch.empty(B, M, O, **f32)
+        partS = torch.empty(prow, 2 * O, **f32)
+        gs = g.stride()
+        _call("apn_sa_wide_bwd_prep", dev, B, M, O, g.data_ptr(), gs[0], gs[1], gs[2], ysel.data_ptr(),
+              pack2.data_ptr(), goa.data_ptr(), partS.data_ptr())
+        small = torch.empty(2 * O + O + O + 3 * H + 2 * H, **f32)      # d2e2 | g_gamma2 | g_beta2 | cabc | g_gamma1, g_beta1
+        d2e2, g_gamma2, g_beta2 = small[:2 * O], small[2 * O:3 * O], small[3 * O:4 * O]
+        cabc, g_gamma1, g_beta1 = small[4 * O:4 * O + 3 * H], small[4 * O + 3 * H:4 * O + 4 * H], small[4 * O + 4 * H:]
+        sS = reduced(partS) if sync else None
+        _call("apn_sa_wide_consts2", dev, None if sync else partS.data_ptr(), prow, _fz._ptr(sS), O, pack2.data_ptr(),
+              count, 1 if tr2 else 0, d2e2.data_ptr(), g_gamma2.data_ptr(), g_beta2.data_ptr())
+        D2, E2 = d2e2[:O], d2e2[O:]
+        Qm = torch.matmul(W2.t() * D2, W2)                                   # W2^T diag(D2) W2  (H,H)
+        evec = torch.mv(W2.t(), E2)
+        zimg = _image(W2, O, False, Qm, O + H, H, min(4, H // 32))          # [W2 ; Qm]  ((O+H) x H)
         grid = lib.apn_sa_wide_grid(B, M)
-        A = torch.zeros(B, N, H, dtype=torch.float32, device=dev)
-        HA = torch.empty(B, M, H, dtype=torch.float32, device=dev)
-        HB = torch.empty(B, M, H, dtype=torch.float32, device=dev)
-        partT = torch.empty(grid, 2 * H, dtype=torch.float32, device=dev)
+        A = torch.zeros(B, N, H, **f32)
+        HA = torch.empty(B, M, H, **f32)
+        HB = torch.empty(B, M, H, **f32)
+        partT = torch.empty(grid, 2 * H, **f32)
         _call("apn_sa_wide_bwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
               zimg.data_ptr(), pack1.data_ptr(), evec.data_ptr(), goa.data_ptr(), ksel.data_ptr(),
               A.data_ptr(), HA.data_ptr(), HB.data_ptr(), partT.data_ptr())
@@ -196,44 +194,26 @@ class _WideMlpMax(torch.autograd.Function):
         rows = O + H
         groups = (rows // 32 + 7) // 8
         splits = max(1, min(512 // groups, (B * M) // 4, (64 << 20) // (rows * H * 4)))
-        Rpart = torch.empty(splits, rows, H, dtype=torch.float32, device=dev)
-        sumapart = torch.empty(splits, H, dtype=torch.float32, device=dev)
+        Rpart = torch.empty(splits, rows, H, **f32)
+        sumapart = torch.empty(splits, H, **f32)
         _call("apn_sa_wide_wgrad", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
               pack1.data_ptr(), goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr(),
               sumapart.data_ptr())
         R = _colsum(Rpart.view(splits, rows * H)).view(rows, H)
         suma = _colsum(sumapart)
         if _DEBUG is not None:
-            _DEBUG.update(goa=goa, zimg=zimg, A=A, HA=HA, HB=HB, partT=partT, Rpart=Rpart, sumapart=sumapart, R=R,
-                          suma=suma, D2=D2, E2=E2, s=s, gz=gz, evec=evec)
-        g_w2 = (R[:O] + D2[:, None] * (W2d @ R[O:]) + E2[:, None] * suma[None, :]).float()
-        # BatchNorm-1 backward constants
-        T = _colsum(partT)
-        if sync:
-            vec = torch.cat([T, torch.ones(1, dtype=torch.float64, device=dev)])
-            _fz._allreduce_sum_(vec)
-            T_glob = vec[:2 * H]
-        else:
-            T_glob = T
-        g_gamma1, g_beta1 = (T_glob[H:] / world).float(), (T_glob[:H] / world).float()
-        scale1, mean1, inv1 = pack1[:H], pack1[2 * H:3 * H], pack1[3 * H:]
-        ca = scale1
-        if tr1:
-            cb = (-scale1.double() * T_glob[H:] / cnt1).float()
-            cc = (-scale1.double() * T_glob[:H] / cnt1).float()
-        else:
-            cb = torch.zeros_like(scale1)
-            cc = torch.zeros_like(scale1)
-        # how often, and from which queries, every point is gathered (coordinates only)
-        flat = idx.view(B, M * K_NS).long()
-        occ = torch.zeros(B, N, dtype=torch.float32, device=dev).scatter_add_(
-            1, flat, torch.ones(B, M * K_NS, dtype=torch.float32, device=dev))
-        SP = torch.zeros(B, N, 3, dtype=torch.float32, device=dev).scatter_add_(
-            1, flat.unsqueeze(-1).expand(-1, -1, 3), new_p.repeat_interleave(K_NS, dim=1))
-        # dL/dU per point and -dL/dV per query: dL/dy1 = ca g_u + cb yhat1 + cc summed over the positions
-        yh_pts = inv1 * (occ.unsqueeze(-1) * (U - mean1) - torch.matmul(SP, W1p.t()) / radius)
-        G = ca * A + cb * yh_pts + cc * occ.unsqueeze(-1)                    # (B,N,H)
-        Hq = ca * HA + cb * HB + float(K_NS) * cc                            # (B,M,H)
+            _DEBUG.update(goa=goa, zimg=zimg, A=A.clone(), HA=HA.clone(), HB=HB, partT=partT, Rpart=Rpart, R=R,
+                          suma=suma, d2e2=d2e2.clone(), evec=evec)
+        g_w2 = (R[:O] + D2.double()[:, None] * (W2.double() @ R[O:]) + E2.double()[:, None] * suma[None, :]).float()
+        # BatchNorm-1 backward constants, then dL/dU per point (in place over A) and -dL/dV per query (over HA)
+        sT = reduced(partT) if sync else None
+        _call("apn_sa_wide_consts1", dev, None if sync else partT.data_ptr(), grid, _fz._ptr(sT), H,
+              pack1.data_ptr(), count, 1 if tr1 else 0, cabc.data_ptr(), g_gamma1.data_ptr(), g_beta1.data_ptr())
+        geo = torch.zeros(B, N, 4, **f32)
+        _call("apn_sa_wide_geo", dev, B, N, M, idx.data_ptr(), new_p.data_ptr(), geo.data_ptr())
+        _call("apn_sa_wide_point_terms", dev, B, N, M, H, cabc.data_ptr(), pack1.data_ptr(), U.data_ptr(),
+              geo.data_ptr(), W1.data_ptr(), C + 3, float(radius), A.data_ptr(), HA.data_ptr(), HB.data_ptr())
+        G, Hq = A, HA
         g_f = torch.matmul(G, W1f).transpose(1, 2).contiguous()              # (B,C,N)
         g_p = torch.matmul(G, W1p) / radius if need_p else None
         g_q = -torch.matmul(Hq, W1p) / radius if need_q else None

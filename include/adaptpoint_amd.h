@@ -176,7 +176,7 @@ APN_API int apn_sa_reduce_rows(const float *part, int rows, int ncol, double cou
 /* BatchNorm fold: {sum, sumsq}[C] over `count` positions (part[rows][2C], or sums[2C] when
  * part == NULL) -> pack[4][C]; updates the running buffers / num_batches_tracked when
  * training (torch.nn.BatchNorm semantics); uses the running buffers when not training.
- * Rider: sgn_out[i] = sign(sgn_gamma[i]), i < sgn_c.  C = 32 or 64. */
+ * Rider: sgn_out[i] = sign(sgn_gamma[i]), i < sgn_c.  C a multiple of 4, <= 1024. */
 APN_API int apn_sa_bn_fold(const float *part, int rows, const double *sums, int c, double count,
                            const float *gamma, const float *beta, float eps, float momentum,
                            float *running_mean, float *running_var, void *num_batches_tracked,
@@ -374,6 +374,33 @@ APN_API int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, cons
                                  const int *idx, const void *z_image, const float *pack1,
                                  const float *evec, const float *goa, const void *ksel, float *A,
                                  float *HA, float *HB, float *part, void *stream);
+/* The small kernels around those passes (csrc/sa_wide_glue.hip).
+ * image: B image of Bm (kd x nc): rows < k0 from src0 (row-major kd x nc, or nc x k0 read transposed when
+ *   trans0), the rest from src1 ((kd - k0) x nc); ct column tiles per block.
+ * bwd_prep: g (B,O,M; element strides gs_*) -> goa (B,M,O) = g scale2 and
+ *   part_s[apn_sa_wide_bwd_prep_rows(b, m)][2*O] = {sum g, sum g yhat_sel}.
+ * consts2 / consts1: the BatchNorm backward constants from those rows (or from `sums`: float64
+ *   {S[2C], global count, world} all-reduced over ranks): d2e2 = {D2, E2}[O]; cabc = {ca, cb, cc}[H];
+ *   dgamma, dbeta (global / world with `sums`).
+ * geo: (B,N,4) += {occurrences, sum of the gathering queries' coordinates} per point (caller-zeroed).
+ * point_terms: A <- dL/dU = ca A + cb inv1 (occ (U - mean1) - SP . W1p / r) + cc occ (B,N,H);
+ *   HA <- -dL/dV = ca HA + cb HB + 32 cc (B,M,H); w1 (H x ldw) with W1p in its first three columns. */
+APN_API int apn_sa_wide_image(const float *src0, int k0, int trans0, const float *src1, int kd, int nc, int ct,
+                              void *image, void *stream);
+APN_API int apn_sa_wide_bwd_prep_rows(int b, int m);
+APN_API int apn_sa_wide_bwd_prep(int b, int m, int c_out, const float *g, long long gs_b, long long gs_c,
+                                 long long gs_m, const float *ysel, const float *pack2, float *goa,
+                                 float *part_s, void *stream);
+APN_API int apn_sa_wide_consts2(const float *part_s, int rows, const double *sums, int c_out,
+                                const float *pack2, double count, int training, float *d2e2,
+                                float *g_gamma2, float *g_beta2, void *stream);
+APN_API int apn_sa_wide_consts1(const float *part_t, int rows, const double *sums, int c_mid,
+                                const float *pack1, double count, int training, float *cabc,
+                                float *g_gamma1, float *g_beta1, void *stream);
+APN_API int apn_sa_wide_geo(int b, int n, int m, const int *idx, const float *new_xyz, float *geo, void *stream);
+APN_API int apn_sa_wide_point_terms(int b, int n, int m, int c_mid, const float *cabc, const float *pack1,
+                                    const float *U, const float *geo, const float *w1, int ldw, float radius,
+                                    float *A, float *HA, const float *HB, void *stream);
 /* r_part[splits][(O+H)][H] = partial [S^T ; a1^T] a1 (rows < O: the sparse part of dL/dW2; the rest:
  * the Gram matrix of a1), suma_part[splits][H] = partial sum of a1; the caller sums the splits */
 APN_API int apn_sa_wide_wgrad_splits(int b, int m, int c_mid);
