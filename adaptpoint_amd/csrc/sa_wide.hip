@@ -138,6 +138,24 @@ __device__ __forceinline__ void stage_chunk(const uint4 *__restrict__ img, int c
     for (int i = 0; i < Chunk<CT>::WORDS / 256; ++i) slot[threadIdx.x + 256 * i] = src[threadIdx.x + 256 * i];
 }
 
+// Streaming form of the same copy, split around the MFMAs of the current chunk: the global loads of
+// chunk ci+1 are issued before them (registers), the LDS stores after them.
+template <int CT>
+struct ChunkRegs {
+    uint4 v[Chunk<CT>::WORDS / 256];
+};
+template <int CT>
+__device__ __forceinline__ void fetch_chunk(const uint4 *__restrict__ img, int ci, ChunkRegs<CT> &r) {
+    const uint4 *__restrict__ src = img + (size_t)ci * Chunk<CT>::WORDS;
+#pragma unroll
+    for (int i = 0; i < Chunk<CT>::WORDS / 256; ++i) r.v[i] = src[threadIdx.x + 256 * i];
+}
+template <int CT>
+__device__ __forceinline__ void store_chunk(const ChunkRegs<CT> &r, uint4 *slot) {
+#pragma unroll
+    for (int i = 0; i < Chunk<CT>::WORDS / 256; ++i) slot[threadIdx.x + 256 * i] = r.v[i];
+}
+
 template <int CT>
 __device__ __forceinline__ Frag<2> chunk_frag(const uint4 *slot, int j, int s, int lane) {
     Frag<2> f;
@@ -174,6 +192,14 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
     float *mine = st + w * 2 * O;
     const int step = gridDim.x * WIDE_WAVES;
     const int rounds = (a.ntiles + step - 1) / step;
+    // streaming: chunk ci of the (cyclic) sequence lives in slot ci & 1; the first one is staged here and
+    // every iteration prefetches its successor (the sequence wraps from the last chunk of a tile to chunk 0)
+    ChunkRegs<CT> pre;
+    if (!RES) {
+        stage_chunk<CT>(img, 0, wl);
+        __syncthreads();
+    }
+    int seq = 0;                                   // running chunk counter (parity = slot)
     for (int it = 0; it < rounds; ++it) {
         const int tile_raw = blockIdx.x * WIDE_WAVES + w + it * step;
         const bool valid = tile_raw < a.ntiles;
@@ -196,10 +222,8 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
                 if (RES) {
                     slot = wl + ci * Chunk<CT>::WORDS;
                 } else {
-                    __syncthreads();                       // every wave is done with this slot's previous chunk
-                    stage_chunk<CT>(img, ci, wl + (ci & 1) * Chunk<CT>::WORDS);
-                    __syncthreads();
-                    slot = wl + (ci & 1) * Chunk<CT>::WORDS;
+                    slot = wl + (seq & 1) * Chunk<CT>::WORDS;
+                    fetch_chunk<CT>(img, ci + 1 == NCH ? 0 : ci + 1, pre);      // in flight behind the MFMAs
                 }
                 Frag<2> af[2];
 #pragma unroll
@@ -208,6 +232,13 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
                 for (int j = 0; j < CT; ++j)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) acc[j] = mfma<2>(af[s], chunk_frag<CT>(slot, j, s, lane), acc[j]);
+                if (!RES) {
+                    // the other slot held chunk seq-1: every wave finished reading it before the barrier
+                    // that ended the previous iteration, so it can be overwritten now
+                    store_chunk<CT>(pre, wl + ((seq + 1) & 1) * Chunk<CT>::WORDS);
+                    __syncthreads();
+                    ++seq;
+                }
             }
             // epilogue of this column block: lane = channel, register = position acc_row(i, h)
 #pragma unroll
@@ -275,6 +306,12 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
     float *mine = st + w * 2 * H;
     const int step = gridDim.x * WIDE_WAVES;
     const int rounds = (a.ntiles + step - 1) / step;
+    ChunkRegs<CT> pre;
+    if (!RES) {
+        stage_chunk<CT>(img, 0, wl);
+        __syncthreads();
+    }
+    int seq = 0;
     for (int it = 0; it < rounds; ++it) {
         const int tile_raw = blockIdx.x * WIDE_WAVES + w + it * step;
         const bool valid = tile_raw < a.ntiles;
@@ -309,10 +346,8 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
                 if (RES) {
                     slot = wl + ci * Chunk<CT>::WORDS;
                 } else {
-                    __syncthreads();
-                    stage_chunk<CT>(img, ci, wl + (ci & 1) * Chunk<CT>::WORDS);
-                    __syncthreads();
-                    slot = wl + (ci & 1) * Chunk<CT>::WORDS;
+                    slot = wl + (seq & 1) * Chunk<CT>::WORDS;
+                    fetch_chunk<CT>(img, ci + 1 == NCH ? 0 : ci + 1, pre);
                 }
                 Frag<2> af[2];
                 if (kc < NKS) {            // rows of S: the upstream gradient at the pooled slot
@@ -339,6 +374,11 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
                 for (int j = 0; j < CT; ++j)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) acc[j] = mfma<2>(af[s], chunk_frag<CT>(slot, j, s, lane), acc[j]);
+                if (!RES) {
+                    store_chunk<CT>(pre, wl + ((seq + 1) & 1) * Chunk<CT>::WORDS);
+                    __syncthreads();
+                    ++seq;
+                }
             }
             // epilogue: lane = mid channel, register = position
 #pragma unroll

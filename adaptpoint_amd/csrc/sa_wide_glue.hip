@@ -90,8 +90,17 @@ __device__ __forceinline__ double block_col_sum(const float *__restrict__ part, 
                                                 bool ok, double (*red)[64]) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     double s = 0.0;
-    if (ok)
-        for (int r = ty; r < rows; r += 4) s += (double)part[(size_t)r * stride + c];
+    if (ok) {
+        int r = ty;
+        for (; r + 28 < rows; r += 32) {           // 8 independent loads in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(r + 4 * u) * stride + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; r < rows; r += 4) s += (double)part[(size_t)r * stride + c];
+    }
     __syncthreads();
     red[ty][tx] = s;
     __syncthreads();

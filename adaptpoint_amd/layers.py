@@ -184,8 +184,10 @@ class BallGrouper(nn.Module):
     def neighbours(self, query_xyz, support_xyz):
         return ball_query(self.radius, self.nsample, support_xyz, query_xyz)
 
-    def forward(self, query_xyz, support_xyz, features=None):
-        idx = self.neighbours(query_xyz, support_xyz)
+    def forward(self, query_xyz, support_xyz, features=None, idx=None):
+        """`idx`: neighbours computed ahead of time (the index stage depends on coordinates only)."""
+        if idx is None:
+            idx = self.neighbours(query_xyz, support_xyz)
         dp = _relative_positions(support_xyz, query_xyz, idx)
         if self.normalize_dp:
             dp = dp / self.radius

@@ -48,13 +48,34 @@ class PointNextEncoderS(nn.Module):
         self.out_channels = channels[-1]
         self.radii = radii
 
-    def forward_cls_feat(self, p0, f0=None):
+    @torch.no_grad()
+    def index_pyramid(self, p0, out=None):
+        """The index stages of ALL blocks -- FPS (+ sampled coordinates) and ball query per
+        down-sampling block -- for a batch of coordinates p0 (B,N,3).  They depend on coordinates
+        only (block k samples from block k-1's samples), so the whole pyramid can be computed ahead of
+        the feature path: on another stream, for the next batch (scripts/bench_pointnext.py --pipeline).
+        Returns one `adaptpoint_amd.fused.Sampling` (or None) per block; `out`: buffers to fill."""
+        from . import fused
+        res, p = [], p0.contiguous()
+        for i, stage in enumerate(self.encoder):
+            sa = stage[0]
+            if sa.is_head or sa.all_aggr:
+                res.append(None)
+                continue
+            smp = fused.sample_and_query(p, p.shape[1] // sa.stride, sa.grouper.radius, sa.grouper.nsample,
+                                         out=None if out is None else out[i])
+            res.append(smp)
+            p = smp.new_p
+        return res
+
+    def forward_cls_feat(self, p0, f0=None, pyramid=None):
         if hasattr(p0, 'keys'):
             p0, f0 = p0['pos'], p0.get('x', None)
         if f0 is None:
             f0 = p0.clone().transpose(1, 2).contiguous()
-        for stage in self.encoder:
-            p0, f0 = stage[0]([p0, f0])
+        for i, stage in enumerate(self.encoder):
+            smp = None if pyramid is None else pyramid[i]
+            p0, f0 = stage[0]([p0, f0], sampling=smp) if smp is not None else stage[0]([p0, f0])
         return f0.squeeze(-1)
 
 
@@ -100,11 +121,11 @@ class PointNextSClassifier(nn.Module):
         self.prediction = ClsHead(num_classes, self.encoder.out_channels)
         self.criterion = SmoothCrossEntropy(0.3)
 
-    def forward(self, data):
-        return self.prediction(self.encoder.forward_cls_feat(data))
+    def forward(self, data, pyramid=None):
+        return self.prediction(self.encoder.forward_cls_feat(data, pyramid=pyramid))
 
-    def get_logits_loss(self, data, gt):
-        logits = self.forward(data)
+    def get_logits_loss(self, data, gt, pyramid=None):
+        logits = self.forward(data, pyramid=pyramid)
         return logits, self.criterion(logits, gt.long())
 
 

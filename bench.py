@@ -432,6 +432,9 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=0,
                     help="whole steps captured per hipGraph (0 = auto: the largest of 20, 10, 4, 2 dividing --steps, "
                          "single GPU; warm-up is rounded up to whole replays; 1 = one step per replay)")
+    ap.add_argument("--kernels", choices=["resident", "wide"], default="resident",
+                    help="fused grouped MLP: the register-resident 32->32->64 kernels (csrc/sa_fused.hip) or the "
+                         "width-generic ones with conv1 hoisted to the points (csrc/sa_wide.hip)")
     ap.add_argument("--mlp", choices=["fused-bf16x3", "fused-bf16", "torch-f32"], default="fused-bf16x3",
                     help="grouped shared-MLP: fused bf16-MFMA kernels (csrc/sa_fused.hip) with split "
                          "hi+lo operands (fp32-grade, default) or plain bf16 operands, or the unfused "
@@ -460,6 +463,9 @@ def main():
         from adaptpoint_amd import fused as _fused
         _fused.FORCE_PHASED = True
 
+    if args.kernels == "wide":
+        from adaptpoint_amd import set_abstraction as _sa_mod
+        _sa_mod.PREFER_WIDE = True
     sync_bn = distributed and args.sync_bn != "off"          # auto = on, as the reference (main.py:27)
     m = measure(args, dev, world, rank, local_rank, distributed, args.mlp, sync_bn, args.steps, args.warmup)
     elapsed, spg, use_graph, pipelined, fused_mlp, eager_step = (m.elapsed, m.spg, m.use_graph, m.pipelined,
@@ -564,6 +570,7 @@ def main():
                             "fused-bf16": "fused bf16 MFMA (operands rounded to bf16, f32 accumulate), "
                                           "f32 BatchNorm statistics summed in f64",
                             "torch-f32": "unfused: extension ops + PyTorch fp32 conv/BN"}[args.mlp]),
+                   "kernels": args.kernels,
                    "launch": (f"hipGraph replay, {spg} step(s) per graph" if use_graph else "eager"),
                    "pipeline": (f"index stages (FPS + ball query) of the NEXT launch's batches on a second stream, "
                                 f"{m.index_batch} batch(es) per sampler launch, beside the MLP fwd+bwd of the "

@@ -24,8 +24,9 @@ def main():
     ap.add_argument("--fused", action="store_true", help="fused kernels in all four grouped stages")
     ap.add_argument("--wide-first", action="store_true", help="stage 1 on the width-generic kernels too")
     ap.add_argument("--graph", action="store_true", help="replay the whole step from a hipGraph")
-    ap.add_argument("--fork", action="store_true", help="(debug) capture on a stream other than the warm-up's")
-    ap.add_argument("--sync-each", action="store_true", help="(debug) synchronize after every step")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="index pyramid (FPS + ball query of all four blocks: coordinates only) of the NEXT batch on a "
+                         "second stream beside the current step; needs --graph")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
@@ -42,9 +43,14 @@ def main():
     x = torch.cat([pos, pos[:, :, 1:2] - pos[:, :, 1:2].min(1, keepdim=True)[0]], -1).transpose(1, 2).contiguous()
     gt = torch.randint(0, 15, (a.batch,), device=dev, generator=torch.Generator(dev).manual_seed(0))
 
-    def step():
+    data = {'pos': pos, 'x': x}
+    pyr = [None, None]
+    if a.pipeline:
+        pyr = [model.encoder.index_pyramid(pos) for _ in range(2)]
+
+    def step(cur=0):
         opt.zero_grad(set_to_none=True)
-        logits, loss = model.get_logits_loss({'pos': pos, 'x': x}, gt)
+        logits, loss = model.get_logits_loss(data, gt, pyramid=pyr[cur])
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10, norm_type=2)     # train_autoaug.py:505-508
         opt.step()
@@ -58,34 +64,54 @@ def main():
                 step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        opt.zero_grad(set_to_none=True)
-        # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes run on the stream
-        # their leaves were first used on, and a capture on any OTHER stream forks the graph into
-        # two branches at every one of them
-        with torch.cuda.graph(graph, stream=side if not a.fork else None):
-            loss_g = step()
-        eager = step
+        graphs, losses, igraphs = {}, {}, {}
+        for cur in ((0, 1) if a.pipeline else (0,)):
+            g = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g):
+                losses[cur] = step(cur)
+            graphs[cur] = g
+            if a.pipeline:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    model.encoder.index_pyramid(pos, out=pyr[cur])
+                igraphs[cur] = g
+        state = {"cur": 0}
+        index_stream = torch.cuda.Stream()
+        main_done, index_done = torch.cuda.Event(), torch.cuda.Event()
+        main_done.record(); index_done.record()
+        box = [index_done]
 
         def step():
-            graph.replay()
-            return loss_g
+            cur = state["cur"]
+            main = torch.cuda.current_stream()
+            if a.pipeline:
+                # the side stream refills the OTHER set (read by the previous step) while this step consumes `cur`
+                index_stream.wait_event(main_done)
+                with torch.cuda.stream(index_stream):
+                    igraphs[1 - cur].replay()
+                    nxt = torch.cuda.Event()
+                    nxt.record(index_stream)
+                main.wait_event(box[0])
+                box[0] = nxt
+            graphs[cur].replay()
+            if a.pipeline:
+                main_done.record(main)
+                state["cur"] = 1 - cur
+            return losses[cur]
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step()
-        if a.sync_each:
-            torch.cuda.synchronize()
-            if i % 5 == 0:
-                print("step", i, float(loss.detach()), file=sys.stderr)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     print(json.dumps({"config": "PointNeXt-S classifier train step, B=%d N=1024" % a.batch,
                       "stages": ("fused (1: %s kernels; 2-4: width-generic kernels)" % ("width-generic" if a.wide_first else "register-resident")
                                  if a.fused else "unfused ops + PyTorch fp32"),
-                      "launch": "hipGraph replay" if a.graph else "eager",
+                      "launch": ("hipGraph replay" + (", index pyramid of the next batch on a second stream" if a.pipeline else "")
+                                 if a.graph else "eager"),
                       "ms_per_step": round(1e3 * el / a.steps, 3),
                       "clouds_per_s": round(a.batch * a.steps / el, 1), "loss": float(loss)}))
 
