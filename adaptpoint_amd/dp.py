@@ -150,7 +150,7 @@ class _SyncBNFn(torch.autograd.Function):
         dims = [0] + list(range(2, x.dim()))
         xd = x.double()
         stat = torch.cat([xd.sum(dims), (xd * xd).sum(dims),
-                          torch.tensor([x.numel() // C], dtype=torch.float64, device=x.device)])
+                          torch.full((1,), float(x.numel() // C), dtype=torch.float64, device=x.device)])
         _sum_over_ranks_(stat)
         count = stat[-1]
         mean = stat[:C] / count

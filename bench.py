@@ -229,7 +229,12 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
     if sync_bn and not fused_mlp:
         blk = dp.convert_sync_batchnorm(blk)
     model = blk
-    eager_collectives = distributed and sync_bn
+    # --graph-collectives on: the statistics all-reduces and the gradient all-reduce are captured INTO the
+    # hipGraph (RCCL kernels are ordinary stream work).  Capture runs with capture_error_mode="thread_local":
+    # in the default "global" mode ProcessGroupNCCL's watchdog thread querying an event while any stream
+    # captures invalidates the capture and aborts the process (round 1, hipErrorStreamCaptureUnsupported).
+    capture_collectives = distributed and args.graph_collectives != "off"
+    eager_collectives = distributed and sync_bn and not capture_collectives
     params = [q for q in blk.parameters()]
 
     # the two-stream pipeline pays only when the step is GPU-bound, i.e. under graph replay
@@ -237,7 +242,7 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
     use_graph = ((args.graph == "on") or (args.graph == "auto")) and not eager_collectives
     # steps per graph: several whole steps per replay when no collective sits between steps
     spg = 1
-    if use_graph and not distributed and args.steps_per_graph != 1:
+    if use_graph and (not distributed or capture_collectives) and args.steps_per_graph != 1:
         for cand in ((args.steps_per_graph,) if args.steps_per_graph else (20, 10, 4, 2)):
             if cand > 1 and steps % cand == 0:
                 spg = cand
@@ -276,10 +281,10 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
         for q in params:
             q.grad = None
 
-    def mlp_steps(count, cur):
+    def mlp_steps(count, cur, first=0):
         """`count` consecutive MLP forward+backward steps on the current stream; pipelined: step i
         takes its index stage from sets[cur][i], else the block computes it in line."""
-        for i in range(count):
+        for i in range(first, first + count):
             clear_grads()
             new_p, out = model([ps[i], fs[i]], sampling=sets[cur][i]) if pipelined else model([ps[i], fs[i]])
             out.sum().backward()
@@ -350,8 +355,13 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
             for cur in ((0, 1) if pipelined else (0,)):
                 clear_grads()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    mlp_steps(spg, cur)
+                with torch.cuda.graph(g, capture_error_mode="thread_local" if distributed else "global"):
+                    if capture_collectives:
+                        for i in range(spg):          # every step: fwd + bwd (+ statistics exchanges) + gradient all-reduce
+                            mlp_steps(1, cur, first=i)
+                            dp.allreduce_mean_([q.grad for q in params if q.grad is not None])
+                    else:
+                        mlp_steps(spg, cur)
                 mlp_graphs[cur] = g
                 # each capture owns its gradient tensors; a replay refreshes them in place
                 graph_grads[cur] = [q.grad for q in params if q.grad is not None]
@@ -375,7 +385,8 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
             use_graph = False
             spg = 1
             step = eager_step
-    if distributed:
+    r.capture_collectives = capture_collectives and use_graph
+    if distributed and not r.capture_collectives:
         local_step = step
 
         def step():
@@ -423,6 +434,10 @@ def main():
                          "(the index stage depends on coordinates only); fused path only")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from a captured HIP graph (auto: on unless collectives sit inside the step)")
+    ap.add_argument("--graph-collectives", choices=["auto", "on", "off"], default="auto",
+                    help="N>1: capture the SyncBatchNorm statistics all-reduces and the gradient all-reduce into the "
+                         "hipGraph (thread-local capture mode; auto = on) instead of running the step eagerly around "
+                         "them (off: round 1's launch structure, ~2.4x slower at world_size 1)")
     ap.add_argument("--index-batch", type=int, default=0,
                     help="pipelined index stage: how many batches' FPS chains share one launch "
                          "(0 = all the batches of a graph replay; 1 = batch by batch as in round 1)")
@@ -458,6 +473,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if distributed and args.graph_collectives != "off":
+        # collectives inside hipGraphs: the watchdog must not poll events of in-flight work (PyTorch's
+        # documented requirement for capturing NCCL work), set before the process group exists
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
     dp.init(args.backend, dev, force=force_dist)
     if force_dist:
         from adaptpoint_amd import fused as _fused
@@ -578,7 +597,8 @@ def main():
                    "global_batch": B_PER_GPU * world,
                    "fused_fallbacks": sum(_sa.FUSED_FALLBACKS.values()),
                    "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else "")
-                                  + ("+flat-allreduce" if distributed else "")},
+                                  + ("+flat-allreduce" if distributed else "")
+                                  + ("+collectives-in-graph" if getattr(m, "capture_collectives", False) else "")},
         "roofline": roofline,
     }
     if not args.no_secondary:

@@ -31,8 +31,12 @@ def test_bench_distributed_default_is_syncbn_world1(dev):
     d = _run([], 29731)
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert "syncbn" in d["config"]["parallelism"] and "flat-allreduce" in d["config"]["parallelism"]
-    assert d["config"]["launch"] == "eager"
-    assert d["value_no_syncbn"] > d["value"]
+    # the collectives are captured into the hipGraph (thread-local capture mode)
+    assert "collectives-in-graph" in d["config"]["parallelism"] and d["config"]["launch"].startswith("hipGraph replay")
+    assert d["value_no_syncbn"] > 0
+    e = _run(["--graph-collectives", "off", "--no-secondary"], 29734)       # round 1's structure: eager around them
+    assert e["config"]["launch"] == "eager" and "collectives-in-graph" not in e["config"]["parallelism"]
+    assert d["value"] > e["value"]
 
 
 def test_bench_distributed_other_paths_world1(dev):
@@ -41,5 +45,5 @@ def test_bench_distributed_other_paths_world1(dev):
     d = _run(["--sync-bn", "off"], 29732)
     assert "flat-allreduce" in d["config"]["parallelism"] and "syncbn" not in d["config"]["parallelism"]
     assert d["config"]["launch"].startswith("hipGraph replay") and "value_no_syncbn" not in d
-    d = _run(["--mlp", "torch-f32", "--steps", "10", "--warmup", "2", "--no-secondary"], 29733)
+    d = _run(["--mlp", "torch-f32", "--steps", "10", "--warmup", "2", "--no-secondary", "--graph-collectives", "off"], 29733)
     assert "syncbn" in d["config"]["parallelism"] and d["value"] > 0
