@@ -273,6 +273,7 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
         blk.sample(p_all, out=big[0])                # prologue: index stages of the first launch
         big[1].buf.copy_(big[0].buf)
     cur_set = [0]
+    ones = torch.ones(1, 1, 1, device=dev)
     graph_grads, last_grads = {}, [None]
 
     def clear_grads():
@@ -287,7 +288,13 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
         for i in range(first, first + count):
             clear_grads()
             new_p, out = model([ps[i], fs[i]], sampling=sets[cur][i]) if pipelined else model([ps[i], fs[i]])
-            out.sum().backward()
+            if fused_mlp:
+                # loss = out.sum(): its gradient is a constant 1 for every element, handed to the backward
+                # entry as a stride-0 broadcast (the fused backward reads the upstream gradient with its
+                # strides); the scalar itself is not formed -- no PyTorch reduce / fill launch in the step
+                torch.autograd.backward([out], [ones.expand_as(out)])
+            else:
+                out.sum().backward()
 
     def index_steps(count, dst):
         if args.index_overlap == "on":
