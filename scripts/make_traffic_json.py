@@ -16,6 +16,9 @@ ALIAS = {"fps_atomic_kernel": "fps", "ball_query_kernel": "ball_query",
          "bwd_point_grads_kernel": "sa_bwd_point_grads", "bwd_finalize_kernel": "sa_bwd_finalize",
          "bn_fold_kernel": "sa_bn_fold", "bwd_consts1_kernel": "sa_bwd_consts1",
          "bwd_consts2_kernel": "sa_bwd_consts2"}
+ALIAS.update({k: k.replace("_kernel", "") for k in (
+    "wide_stats1_kernel", "wide_fwd_main_kernel", "wide_bwd_main_kernel", "wide_wgrad_kernel", "wide_bwd_prep_kernel",
+    "wide_point_terms_kernel", "wide_geo_kernel", "wide_colsum_kernel", "wide_image_kernel")})
 
 out = {}
 for r in csv.DictReader(open(sys.argv[1])):
@@ -24,8 +27,8 @@ for r in csv.DictReader(open(sys.argv[1])):
         out[k] = int(round((2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024))
 json.dump({"_note": "HBM bytes per launch at B=32 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
                     "passes, bench.py --steps 20 --warmup 5 --graph off --pipeline off, default bf16x3 "
-                    "precision), averaged over all dispatches of the pass; FETCH_SIZE doubled as "
-                    "MI355X_MICROARCH.md section HBM prescribes for gfx950, WRITE_SIZE taken as is. "
-                    "Summary: profiles/r01_pmc_fetch_write_summary.csv",
+                    "precision; scripts/collect_profiles.sh pmc), averaged over all dispatches of the pass; "
+                    "FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950, WRITE_SIZE "
+                    "taken as is. Summary: " + sys.argv[1],
            "bytes_per_launch": out}, open(sys.argv[2], "w"), indent=1)
 print(out)
