@@ -68,6 +68,19 @@ class PointNextEncoderS(nn.Module):
             p = smp.new_p
         return res
 
+    def forward_seg_feat(self, p0, f0=None):
+        """Every level's (points, features): what the segmentation decoder consumes (pointnext.py:443-453)."""
+        if hasattr(p0, 'keys'):
+            p0, f0 = p0['pos'], p0.get('x', None)
+        if f0 is None:
+            f0 = p0.clone().transpose(1, 2).contiguous()
+        p, f = [p0], [f0]
+        for stage in self.encoder:
+            _p, _f = stage[0]([p[-1], f[-1]])
+            p.append(_p)
+            f.append(_f)
+        return p, f
+
     def forward_cls_feat(self, p0, f0=None, pyramid=None):
         if hasattr(p0, 'keys'):
             p0, f0 = p0['pos'], p0.get('x', None)
@@ -77,6 +90,67 @@ class PointNextEncoderS(nn.Module):
             smp = None if pyramid is None else pyramid[i]
             p0, f0 = stage[0]([p0, f0], sampling=smp) if smp is not None else stage[0]([p0, f0])
         return f0.squeeze(-1)
+
+
+class FeaturePropagation(nn.Module):
+    """PointNet++ feature propagation (`FeaturePropogation`, pointnext.py:173-226):
+    features known at the coarse points p2 are carried to the dense points p1 by inverse-distance
+    weighting over the three nearest coarse points (`three_nn` + `three_interpolate`, the operators of
+    section 8a), concatenated with the dense level's own features and passed through Conv1d-BN-ReLU
+    blocks.  `upsample=False` is the global variant (mean-pooled feature broadcast back).  Sub-module
+    names (`convs.<i>.0/1`, `linear1`, `linear2`) are the reference's."""
+
+    def __init__(self, mlp, upsample=True, norm_args=None, act_args=None):
+        super().__init__()
+        from .set_abstraction import convblock
+        norm_args = {'norm': 'bn1d'} if norm_args is None else norm_args
+        act_args = {'act': 'relu'} if act_args is None else act_args
+        mlp = list(mlp)
+        self.upsample = upsample
+        if not upsample:
+            self.linear2 = nn.Sequential(nn.Linear(mlp[0], mlp[1]), nn.ReLU(inplace=True))
+            mlp[1] *= 2
+            self.linear1 = nn.Sequential(*[convblock(mlp[i], mlp[i + 1], 1, norm_args=norm_args, act_args=act_args)
+                                           for i in range(1, len(mlp) - 1)])
+        else:
+            self.convs = nn.Sequential(*[convblock(mlp[i], mlp[i + 1], 1, norm_args=norm_args, act_args=act_args)
+                                         for i in range(len(mlp) - 1)])
+
+    def forward(self, pf1, pf2=None):
+        from .layers import three_interpolation
+        if pf2 is None:
+            _, f = pf1
+            g = self.linear2(f.mean(dim=-1))
+            return self.linear1(torch.cat((f, g.unsqueeze(-1).expand(-1, -1, f.shape[-1])), dim=1))
+        (p1, f1), (p2, f2) = pf1, pf2
+        up = three_interpolation(p1, p2, f2)
+        return self.convs(up if f1 is None else torch.cat((f1, up), dim=1))
+
+
+class PointNextDecoder(nn.Module):
+    """`PointNextDecoder` (pointnext.py:461-500) for decoder_layers Conv1d blocks per level: walks the
+    encoder's levels from coarse to dense, one FeaturePropagation per level (`decoder.<i>.0`)."""
+
+    def __init__(self, encoder_channel_list, decoder_layers=2, decoder_stages=4, in_channels=3):
+        super().__init__()
+        chans = list(encoder_channel_list)
+        cur = chans[-1]
+        skip = chans[:-1]
+        if len(skip) < decoder_stages:
+            skip.insert(0, in_channels)
+        fp = chans[:decoder_stages]
+        stages = [None] * len(fp)
+        for i in range(-1, -len(fp) - 1, -1):
+            stages[i] = nn.Sequential(FeaturePropagation([skip[i] + cur] + [fp[i]] * decoder_layers))
+            cur = fp[i]
+        self.decoder = nn.Sequential(*stages)
+        self.out_channels = fp[-len(fp)]
+
+    def forward(self, p, f):
+        f = list(f)
+        for i in range(-1, -len(self.decoder) - 1, -1):
+            f[i - 1] = self.decoder[i][0]([p[i - 1], f[i - 1]], [p[i], f[i]])
+        return f[-len(self.decoder) - 1]
 
 
 class ClsHead(nn.Module):

@@ -605,6 +605,33 @@ def main_adaptpoint():
                g13_bn1_mean_after=cls.encoder.encoder[1][0].convs[0][1].running_mean.numpy())
     print(f"G13: classifier step golden: loss {loss.item():.5f}, grad norm {gnorm.item():.4f}")
 
+    # ---- G14: SURVEY 8f row 4 -- FeaturePropogation and the segmentation decoder (pointnext.py:173-226, 461-500) ----
+    import openpoints.models.backbone.pointnext as ref_pn2
+    ref_pn2.three_interpolation = ref_up.three_interpolation          # the reference function over the oracle ops
+    fp = fill_parameters_by_name(ref_pn2.FeaturePropogation([64 + 32, 32, 32]))
+    fp.train()
+    p1 = GI.unit_sphere_cloud(2, 512, seed=141)
+    p2 = GI.take_points(p1, O.furthest_point_sampling(p1, 128))
+    f1 = _t(GI.seeded_normal((2, 32, 512), seed=142)).requires_grad_(True)
+    f2 = _t(GI.seeded_normal((2, 64, 128), seed=143)).requires_grad_(True)
+    fo = fp([_t(p1), f1], [_t(p2), f2])
+    (fo * _t(GI.seeded_normal(tuple(fo.shape), seed=144))).sum().backward()
+    out.update(g14_fp_out=fo.detach().numpy(), g14_fp_grad_f1=f1.grad.numpy(), g14_fp_grad_f2=f2.grad.numpy(),
+               g14_fp_grad_w0=fp.convs[0][0].weight.grad.numpy())
+    fpg = fill_parameters_by_name(ref_pn2.FeaturePropogation([32, 32, 24], upsample=False))
+    fpg.train()
+    out["g14_fp_global_out"] = fpg([None, _t(GI.seeded_normal((2, 32, 100), seed=145))]).detach().numpy()
+    dec = fill_parameters_by_name(ref_pn2.PointNextDecoder(encoder_channel_list=[32, 64, 128, 256, 512], decoder_layers=2,
+                                                           decoder_stages=4))
+    dec.train()
+    out["g14_dec_keys"] = np.array(sorted(dec.state_dict().keys()))
+    pl = [GI.unit_sphere_cloud(2, 256, seed=146)]
+    for m in (128, 64, 32, 16):
+        pl.append(GI.take_points(pl[-1], O.furthest_point_sampling(pl[-1], m)))
+    fl = [_t(GI.seeded_normal((2, c, n), seed=147 + i)) for i, (c, n) in enumerate(zip((32, 64, 128, 256, 512), (256, 128, 64, 32, 16)))]
+    out["g14_dec_out"] = dec([_t(q) for q in pl], fl).detach().numpy()
+    print("G14: FeaturePropogation / PointNextDecoder goldens")
+
     path = os.path.join(HERE, "adaptpoint_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")

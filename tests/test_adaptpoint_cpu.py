@@ -204,3 +204,32 @@ def test_classifier_step_with_resampler_matches_reference_trainer(golden_ap, cpu
     np.testing.assert_allclose(m.encoder.encoder[1][0].convs[0][1].running_mean.numpy(),
                                golden_ap["g13_bn1_mean_after"], rtol=1e-5, atol=1e-6)
     assert all(q.grad is None or not q.grad.any() for q in m.parameters())      # model.zero_grad() (:508)
+
+
+def test_feature_propagation_and_decoder_match_reference(golden_ap, cpu_mirrors, oracle):
+    """FeaturePropogation (pointnext.py:173-226), both variants, and the
+    segmentation decoder (pointnext.py:461-500) over three_nn / three_interpolate."""
+    from adaptpoint_amd.pointnext import FeaturePropagation, PointNextDecoder, fill_parameters_by_name
+    fp = fill_parameters_by_name(FeaturePropagation([64 + 32, 32, 32])).train()
+    p1 = GI.unit_sphere_cloud(2, 512, seed=141)
+    p2 = GI.take_points(p1, oracle.furthest_point_sampling(p1, 128))
+    f1 = torch.from_numpy(GI.seeded_normal((2, 32, 512), seed=142)).requires_grad_(True)
+    f2 = torch.from_numpy(GI.seeded_normal((2, 64, 128), seed=143)).requires_grad_(True)
+    out = fp([torch.from_numpy(p1), f1], [torch.from_numpy(p2), f2])
+    (out * torch.from_numpy(GI.seeded_normal(tuple(out.shape), seed=144))).sum().backward()
+    np.testing.assert_allclose(out.detach().numpy(), golden_ap["g14_fp_out"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(f1.grad.numpy(), golden_ap["g14_fp_grad_f1"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(f2.grad.numpy(), golden_ap["g14_fp_grad_f2"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(fp.convs[0][0].weight.grad.numpy(), golden_ap["g14_fp_grad_w0"], rtol=1e-4, atol=1e-5)
+    fpg = fill_parameters_by_name(FeaturePropagation([32, 32, 24], upsample=False)).train()
+    og = fpg([None, torch.from_numpy(GI.seeded_normal((2, 32, 100), seed=145))])
+    np.testing.assert_allclose(og.detach().numpy(), golden_ap["g14_fp_global_out"], rtol=1e-5, atol=1e-5)
+    dec = fill_parameters_by_name(PointNextDecoder([32, 64, 128, 256, 512], decoder_layers=2, decoder_stages=4)).train()
+    assert sorted(dec.state_dict().keys()) == list(golden_ap["g14_dec_keys"])
+    pl = [GI.unit_sphere_cloud(2, 256, seed=146)]
+    for m in (128, 64, 32, 16):
+        pl.append(GI.take_points(pl[-1], oracle.furthest_point_sampling(pl[-1], m)))
+    fl = [torch.from_numpy(GI.seeded_normal((2, c, n), seed=147 + i))
+          for i, (c, n) in enumerate(zip((32, 64, 128, 256, 512), (256, 128, 64, 32, 16)))]
+    od = dec([torch.from_numpy(q) for q in pl], fl)
+    np.testing.assert_allclose(od.detach().numpy(), golden_ap["g14_dec_out"], rtol=1e-4, atol=1e-5)

@@ -233,3 +233,35 @@ def test_classifier_step_matches_reference_trainer(dev, golden_ap, fused):
     # measured: unfused logits 1e-4 / loss 3e-5; fused 2e-3 / 5e-4 (four fused stages' discontinuities at B=2)
     assert errs["logits"] < (1e-2 if fused else 1e-3) and errs["loss"] < (2e-3 if fused else 2e-4) and errs["bn"] < 1e-5
     assert errs["head_sign_agree"] > 0.95
+
+
+# ------------------------------------------------------------------ 8f row 4: the segmentation decoder path
+def test_feature_propagation_and_decoder_match_reference(dev, golden_ap, oracle):
+    from adaptpoint_amd.pointnext import FeaturePropagation, PointNextDecoder, PointNextEncoderS, fill_parameters_by_name
+    fp = fill_parameters_by_name(FeaturePropagation([64 + 32, 32, 32])).to(dev).train()
+    p1 = GI.unit_sphere_cloud(2, 512, seed=141)
+    p2 = GI.take_points(p1, oracle.furthest_point_sampling(p1, 128))
+    f1 = torch.from_numpy(GI.seeded_normal((2, 32, 512), seed=142)).to(dev).requires_grad_(True)
+    f2 = torch.from_numpy(GI.seeded_normal((2, 64, 128), seed=143)).to(dev).requires_grad_(True)
+    out = fp([torch.from_numpy(p1).to(dev), f1], [torch.from_numpy(p2).to(dev), f2])
+    (out * torch.from_numpy(GI.seeded_normal(tuple(out.shape), seed=144)).to(dev)).sum().backward()
+    errs = dict(out=rel(out, golden_ap["g14_fp_out"]), f1=rel(f1.grad, golden_ap["g14_fp_grad_f1"]),
+                f2=rel(f2.grad, golden_ap["g14_fp_grad_f2"]), w0=rel(fp.convs[0][0].weight.grad, golden_ap["g14_fp_grad_w0"]))
+    print("FeaturePropagation vs reference golden:", {k: "%.2e" % v for k, v in errs.items()})
+    assert all(v < 1e-4 for v in errs.values()), errs
+    dec = fill_parameters_by_name(PointNextDecoder([32, 64, 128, 256, 512])).to(dev).train()
+    pl = [GI.unit_sphere_cloud(2, 256, seed=146)]
+    for m in (128, 64, 32, 16):
+        pl.append(GI.take_points(pl[-1], oracle.furthest_point_sampling(pl[-1], m)))
+    fl = [torch.from_numpy(GI.seeded_normal((2, c, n), seed=147 + i)).to(dev)
+          for i, (c, n) in enumerate(zip((32, 64, 128, 256, 512), (256, 128, 64, 32, 16)))]
+    od = dec([torch.from_numpy(q).to(dev) for q in pl], fl)
+    assert rel(od, golden_ap["g14_dec_out"]) < 1e-3
+    # encoder levels + decoder end to end at a segmentation-like size (shapes and finiteness)
+    enc = PointNextEncoderS(in_channels=4, strides=(1, 4, 4, 4, 4), fused=True).to(dev).train()
+    pos = torch.from_numpy(GI.unit_sphere_cloud(2, 4096, seed=148)).to(dev)
+    x = torch.cat([pos, pos[:, :, 1:2]], -1).transpose(1, 2).contiguous()
+    p, f = enc.forward_seg_feat(pos, x)
+    seg = PointNextDecoder([q.shape[1] for q in f[1:]], in_channels=4).to(dev).train()
+    o = seg(p[1:], f[1:])
+    assert o.shape == (2, 32, 4096) and torch.isfinite(o).all()

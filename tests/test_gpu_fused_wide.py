@@ -199,3 +199,41 @@ def test_classifier_with_every_stage_fused(dev, golden):
           "loss %.2e, grad cosine %.5f" % (e_eval, e_tr, abs(lossm.item() - lossu.item()), cos))
     assert e_eval <= 2e-3
     assert e_tr <= 1e-2 and abs(lossm.item() - lossu.item()) <= 2.5e-3 and cos >= 0.98
+
+
+@pytest.mark.parametrize("cin,N,M,radius", [STAGES[0], STAGES[3]])
+def test_wide_block_replays_identically_from_a_hipgraph(dev, cin, N, M, radius):
+    """A captured forward+backward must give the eager result on EVERY replay.  (Regression: the
+    partial rows were once summed with `x.double().sum(0)`; PyTorch's cross-block reduction returned
+    stale values from the second replay on, and a whole-model graph trained to NaN.)"""
+    from adaptpoint_amd.fused_wide import grouped_mlp_max
+    p, new_p, f, idx, conv1, bn1, conv2, bn2 = _setup(dev, cin, N, M, radius, B=8, seed=5)
+    f.requires_grad_(True)
+    params = [conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias]
+
+    def fb():
+        f.grad = None
+        for q in params:
+            q.grad = None
+        out = grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2)
+        out.square().sum().backward()
+        return out
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fb()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fb()
+    res = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        res.append([out.detach().clone(), f.grad.clone()] + [q.grad.clone() for q in params])
+    ref = [fb().detach().clone(), f.grad.clone()] + [q.grad.clone() for q in params]
+    for r in res:
+        for a, b in zip(r, ref):
+            assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) <= 1e-5   # float atomics order only
