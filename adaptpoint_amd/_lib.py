@@ -69,9 +69,11 @@ SIGNATURES = {
     "apn_sa_wide_grid": [_c_int] * 2,
     "apn_sa_wide_colsum_chunks": [_c_int] * 2,
     "apn_sa_wide_colsum": [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
-    "apn_sa_wide_stats1": [_c_int] * 4 + [_c_void_p] * 5,
-    "apn_sa_wide_fwd_main": [_c_int] * 5 + [_c_void_p] * 10,
-    "apn_sa_wide_bwd_main": [_c_int] * 5 + [_c_void_p] * 13,
+    "apn_sa_wide_tilemap_ints": [_c_int] * 2,
+    "apn_sa_wide_tilemap": [_c_int] * 3 + [_c_void_p] * 3,
+    "apn_sa_wide_stats1": [_c_int] * 4 + [_c_void_p] * 6,
+    "apn_sa_wide_fwd_main": [_c_int] * 5 + [_c_void_p] * 11,
+    "apn_sa_wide_bwd_main": [_c_int] * 5 + [_c_void_p] * 14,
     "apn_sa_wide_image": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "apn_sa_wide_bwd_prep_rows": [_c_int] * 2,
     "apn_sa_wide_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] * 5,
@@ -80,7 +82,7 @@ SIGNATURES = {
     "apn_sa_wide_geo": [_c_int] * 3 + [_c_void_p] * 4,
     "apn_sa_wide_point_terms": [_c_int] * 4 + [_c_void_p] * 5 + [_c_int, _c_float] + [_c_void_p] * 4,
     "apn_sa_wide_wgrad_splits": [_c_int] * 3,
-    "apn_sa_wide_wgrad": [_c_int] * 5 + [_c_void_p] * 6 + [_c_int] + [_c_void_p] * 3,
+    "apn_sa_wide_wgrad": [_c_int] * 5 + [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 3,
     "apn_sa_sample_overlap": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 7,
     "apn_sa_sample_seq": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 6,
 }

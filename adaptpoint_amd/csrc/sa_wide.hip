@@ -36,12 +36,24 @@
 namespace apn {
 
 struct WideArgs {
-    int ntiles;          // B * M query tiles (32 positions each)
+    int ntiles;          // B * M queries = upper bound of the tiles in use
     int n, m;            // support points / queries per cloud
     const float *U;      // (B,N,H)
     const float *V;      // (B,M,H)
     const int *idx;      // (B,M,32)
+    const int *tmap;     // tile map (csrc/sa_wide_glue.hip: apn_sa_wide_tilemap): 32 ROWS per tile, a row = one
+                         // distinct neighbour of one query with its multiplicity
 };
+
+// Tile-map accessors.  rowinfo = qlocal | slot << 8 | mult << 16 (| queries of the tile << 24 in row 0).
+__device__ __forceinline__ int tm_tiles(const WideArgs &a) { return a.tmap[0]; }
+__device__ __forceinline__ const int *tm_tq0(const WideArgs &a) { return a.tmap + 4; }
+__device__ __forceinline__ const unsigned *tm_rows(const WideArgs &a) {
+    return reinterpret_cast<const unsigned *>(a.tmap + 4 + ((a.ntiles + 3) & ~3));
+}
+__device__ __forceinline__ int ri_q(unsigned info) { return (int)(info & 0xffu); }
+__device__ __forceinline__ int ri_slot(unsigned info) { return (int)((info >> 8) & 0xffu); }
+__device__ __forceinline__ int ri_mult(unsigned info) { return (int)((info >> 16) & 0xffu); }
 
 constexpr int WIDE_WAVES = 4;
 
@@ -64,22 +76,28 @@ __global__ __launch_bounds__(256) void wide_stats1_kernel(WideArgs a, float *__r
     float s[CPL], ss[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) s[j] = ss[j] = 0.0f;
-    for (int tile = blockIdx.x * WIDE_WAVES + w; tile < a.ntiles; tile += gridDim.x * WIDE_WAVES) {
-        const int cloud = tile / a.m;
-        const int *__restrict__ ip = a.idx + (size_t)tile * 32;
-        const float *__restrict__ ub = a.U + (size_t)cloud * a.n * H;
-        float vq[CPL];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) vq[j] = a.V[(size_t)tile * H + (PP == 2 ? (lane & 31) : lane + 64 * j)];
+    const int nt = tm_tiles(a);
+    const int *__restrict__ tq0 = tm_tq0(a);
+    const unsigned *__restrict__ rows = tm_rows(a);
+    for (int tile = blockIdx.x * WIDE_WAVES + w; tile < nt; tile += gridDim.x * WIDE_WAVES) {
+        const int q0 = tq0[tile];
+        const unsigned *__restrict__ ri = rows + (size_t)tile * 32;
+        const float *__restrict__ ub = a.U + (size_t)(q0 / a.m) * a.n * H;
 #pragma unroll 8
         for (int p0 = 0; p0 < 32; p0 += PP) {
-            const int nn = ip[p0 + (PP == 2 ? (lane >> 5) : 0)];
+            const unsigned info = ri[p0 + (PP == 2 ? (lane >> 5) : 0)];
+            const int q = q0 + ri_q(info);
+            const float wgt = (float)ri_mult(info);              // 0: padding row
+            const int nn = a.idx[(size_t)q * 32 + ri_slot(info)];
             const float *__restrict__ row = ub + (size_t)nn * H;
+            const float *__restrict__ vr = a.V + (size_t)q * H;
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
-                const float y = row[PP == 2 ? (lane & 31) : lane + 64 * j] - vq[j];
-                s[j] += y;
-                ss[j] = __builtin_fmaf(y, y, ss[j]);
+                const int ch = PP == 2 ? (lane & 31) : lane + 64 * j;
+                const float y = row[ch] - vr[ch];
+                const float wy = wgt * y;
+                s[j] += wy;
+                ss[j] = __builtin_fmaf(wy, y, ss[j]);
             }
         }
     }
@@ -105,7 +123,8 @@ __global__ __launch_bounds__(256) void wide_stats1_kernel(WideArgs a, float *__r
 // ------------------------------------------------------------------------------------------
 // A fragment of a1 = relu(scale1 * (U[n] - V[q]) + shift1): lane (pos r, h), 8 channels from ch0.
 __device__ __forceinline__ Frag<2> a1_frag(const float *__restrict__ row, const float *__restrict__ vq,
-                                           const float *__restrict__ pack1, int H, int ch0) {
+                                           const float *__restrict__ pack1, int H, int ch0, float wgt = 1.0f,
+                                           bool weighted = false) {
     const float4 u0 = *reinterpret_cast<const float4 *>(row + ch0);
     const float4 u1 = *reinterpret_cast<const float4 *>(row + ch0 + 4);
     const float4 v0 = *reinterpret_cast<const float4 *>(vq + ch0);
@@ -121,7 +140,20 @@ __device__ __forceinline__ Frag<2> a1_frag(const float *__restrict__ row, const 
     t[6] = __builtin_fmaf(u1.z - v1.z, c1.z, d1.z); t[7] = __builtin_fmaf(u1.w - v1.w, c1.w, d1.w);
 #pragma unroll
     for (int e = 0; e < 8; ++e) t[e] = t[e] > 0.0f ? t[e] : 0.0f;
+    if (weighted) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] *= wgt;
+    }
     return make_frag<2>(t);
+}
+
+// The metadata of this lane's 16 accumulator rows acc_row(i, h): 4 runs of 4 consecutive rows.
+__device__ __forceinline__ void load_row_meta(const unsigned *__restrict__ ri, int h, unsigned (&meta)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(ri + 8 * g + 4 * h);
+        meta[4 * g] = v.x; meta[4 * g + 1] = v.y; meta[4 * g + 2] = v.z; meta[4 * g + 3] = v.w;
+    }
 }
 
 // One chunk of a B image = CT column tiles x 2 k-steps x {hi, lo} x 64 lanes x 16 bytes.
@@ -190,8 +222,11 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
     }
     __syncthreads();
     float *mine = st + w * 2 * O;
+    const int nt = tm_tiles(a);
+    const int *__restrict__ tq0 = tm_tq0(a);
+    const unsigned *__restrict__ rows = tm_rows(a);
     const int step = gridDim.x * WIDE_WAVES;
-    const int rounds = (a.ntiles + step - 1) / step;
+    const int rounds = (nt + step - 1) / step;
     // streaming: chunk ci of the (cyclic) sequence lives in slot ci & 1; the first one is staged here and
     // every iteration prefetches its successor (the sequence wraps from the last chunk of a tile to chunk 0)
     ChunkRegs<CT> pre;
@@ -202,12 +237,18 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
     int seq = 0;                                   // running chunk counter (parity = slot)
     for (int it = 0; it < rounds; ++it) {
         const int tile_raw = blockIdx.x * WIDE_WAVES + w + it * step;
-        const bool valid = tile_raw < a.ntiles;
-        const int tile = valid ? tile_raw : a.ntiles - 1;
-        const int cloud = tile / a.m;
-        const int nn = a.idx[(size_t)tile * 32 + r];
-        const float *__restrict__ row = a.U + ((size_t)cloud * a.n + nn) * H;
-        const float *__restrict__ vq = a.V + (size_t)tile * H;
+        const bool valid = tile_raw < nt;
+        const int tile = valid ? tile_raw : nt - 1;
+        const unsigned *__restrict__ ri = rows + (size_t)tile * 32;
+        const unsigned info = ri[r];
+        const int q0 = tq0[tile];
+        const int nq = __builtin_amdgcn_readfirstlane((int)(info >> 24));      // lane 0 holds row 0
+        const int ql = q0 + ri_q(info);
+        const int nn = a.idx[(size_t)ql * 32 + ri_slot(info)];
+        const float *__restrict__ row = a.U + ((size_t)(q0 / a.m) * a.n + nn) * H;
+        const float *__restrict__ vq = a.V + (size_t)ql * H;
+        unsigned meta[16];
+        load_row_meta(ri, h, meta);
 #pragma unroll 1
         for (int cb = 0; cb < NCB; ++cb) {
             f32x16 acc[CT];
@@ -240,31 +281,43 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
                     ++seq;
                 }
             }
-            // epilogue of this column block: lane = channel, register = position acc_row(i, h)
+            // epilogue of this column block: lane = channel, register = row acc_row(i, h) of the tile
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
                 const int col = (cb * CT + j) * 32 + r;
                 const float sg = sgn2[col];
-                float s1 = 0.0f, s2 = 0.0f, best = -__builtin_inff();
-                int bpos = 0;
+                float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float y = acc[j][i];
-                    s1 += y;
-                    s2 = __builtin_fmaf(y, y, s2);
-                    const float v = y * sg;
-                    if (v > best) { best = v; bpos = acc_row(i, h); }     // ascending positions: first maximum
+                    const float wy = (float)ri_mult(meta[i]) * y;            // the row stands for `mult` positions
+                    s1 += wy;
+                    s2 = __builtin_fmaf(wy, y, s2);
                 }
                 s1 += shfl_xor32(s1);
                 s2 += shfl_xor32(s2);
-                const float ob = shfl_xor32(best);
-                const int op = shfl_xor32i(bpos);
-                if (ob > best || (ob == best && op < bpos)) { best = ob; bpos = op; }
                 if (h == 0 && valid) {
                     mine[col] += s1;                     // this wave owns its row of `st`: plain update
                     mine[O + col] += s2;
-                    ysel[(size_t)tile * O + col] = best * sg;
-                    ksel[(size_t)tile * O + col] = (unsigned char)bpos;
+                }
+                // the pool, query by query: rows ascend with the slot, so the first maximum is the lowest slot
+#pragma unroll 1
+                for (int jq = 0; jq < nq; ++jq) {
+                    float best = -__builtin_inff();
+                    int bslot = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float v = acc[j][i] * sg;
+                        const bool in = (meta[i] & 0xff00ffu) > 0xffffu && ri_q(meta[i]) == jq;   // mult > 0, this query
+                        if (in && v > best) { best = v; bslot = ri_slot(meta[i]); }
+                    }
+                    const float ob = shfl_xor32(best);
+                    const int op = shfl_xor32i(bslot);
+                    if (ob > best || (ob == best && op < bslot)) { best = ob; bslot = op; }
+                    if (h == 0 && valid) {
+                        ysel[(size_t)(q0 + jq) * O + col] = best * sg;
+                        ksel[(size_t)(q0 + jq) * O + col] = (unsigned char)bslot;
+                    }
                 }
             }
         }
@@ -304,8 +357,11 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
     }
     __syncthreads();
     float *mine = st + w * 2 * H;
+    const int nt = tm_tiles(a);
+    const int *__restrict__ tq0 = tm_tq0(a);
+    const unsigned *__restrict__ rows = tm_rows(a);
     const int step = gridDim.x * WIDE_WAVES;
-    const int rounds = (a.ntiles + step - 1) / step;
+    const int rounds = (nt + step - 1) / step;
     ChunkRegs<CT> pre;
     if (!RES) {
         stage_chunk<CT>(img, 0, wl);
@@ -314,24 +370,28 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
     int seq = 0;
     for (int it = 0; it < rounds; ++it) {
         const int tile_raw = blockIdx.x * WIDE_WAVES + w + it * step;
-        const bool valid = tile_raw < a.ntiles;
-        const int tile = valid ? tile_raw : a.ntiles - 1;
-        const int cloud = tile / a.m;
-        const int *__restrict__ ip = a.idx + (size_t)tile * 32;
-        const int nn = ip[r];
+        const bool valid = tile_raw < nt;
+        const int tile = valid ? tile_raw : nt - 1;
+        const unsigned *__restrict__ ri = rows + (size_t)tile * 32;
+        const unsigned info = ri[r];
+        const int q0 = tq0[tile];
+        const int nq = __builtin_amdgcn_readfirstlane((int)(info >> 24));
+        const int cloud = q0 / a.m;
+        const int ql = q0 + ri_q(info), rslot = ri_slot(info);
+        const bool live = ri_mult(info) != 0;
+        const float wrow = (float)ri_mult(info);
+        const int nn = a.idx[(size_t)ql * 32 + rslot];
         const float *__restrict__ ub = a.U + (size_t)cloud * a.n * H;
         const float *__restrict__ row = ub + (size_t)nn * H;
-        const float *__restrict__ vq = a.V + (size_t)tile * H;
-        const float *__restrict__ gq = goa + (size_t)tile * O;
-        const unsigned char *__restrict__ kq = ksel + (size_t)tile * O;
-        // neighbour of every accumulator row of this lane: positions acc_row(i, h) = 4 runs of 4
+        const float *__restrict__ vq = a.V + (size_t)ql * H;
+        const float *__restrict__ gq = goa + (size_t)ql * O;
+        const unsigned char *__restrict__ kq = ksel + (size_t)ql * O;
+        // metadata and neighbour of every accumulator row of this lane (row p's neighbour sits in lane p)
+        unsigned meta[16];
+        load_row_meta(ri, h, meta);
         int nrow[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int4 v = *reinterpret_cast<const int4 *>(ip + 8 * g + 4 * h);
-            nrow[4 * g] = v.x; nrow[4 * g + 1] = v.y; nrow[4 * g + 2] = v.z; nrow[4 * g + 3] = v.w;
-        }
-        const int first = ip[0];
+        for (int i = 0; i < 16; ++i) nrow[i] = __builtin_amdgcn_ds_bpermute(acc_row(i, h) << 2, nn);
 #pragma unroll 1
         for (int cb = 0; cb < NCB; ++cb) {
             f32x16 acc[CT];
@@ -361,14 +421,14 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const unsigned sel = ((e < 4 ? kk.x : kk.y) >> (8 * (e & 3))) & 0xffu;
-                            t[e] = sel == (unsigned)r ? t[e] : 0.0f;
+                            t[e] = (live && sel == (unsigned)rslot) ? t[e] : 0.0f;
                         }
                         af[s] = make_frag<2>(t);
                     }
                 } else {
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
-                        af[s] = a1_frag(row, vq, pack1, H, (kc - NKS) * 32 + s * 16 + h * 8);
+                        af[s] = a1_frag(row, vq, pack1, H, (kc - NKS) * 32 + s * 16 + h * 8, wrow, true);
                 }
 #pragma unroll
                 for (int j = 0; j < CT; ++j)
@@ -380,37 +440,53 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
                     ++seq;
                 }
             }
-            // epilogue: lane = mid channel, register = position
+            // epilogue: lane = mid channel, register = row of the tile
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
                 const int mid = (cb * CT + j) * 32 + r;
                 const float sc = pack1[mid], sh = pack1[H + mid], mu = pack1[2 * H + mid], iv = pack1[3 * H + mid];
-                const float ev = evec[mid], vv = vq[mid];
-                float t1 = 0.0f, t2 = 0.0f, hb = 0.0f, gfirst = 0.0f;
-                float u[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) u[i] = ub[(size_t)nrow[i] * H + mid];
+                const float ev = evec[mid];
+                float t1 = 0.0f, t2 = 0.0f;
+                float u[16], vv[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float y1 = u[i] - vv;
+                    u[i] = ub[(size_t)nrow[i] * H + mid];
+                    vv[i] = a.V[(size_t)(q0 + ri_q(meta[i])) * H + mid];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float wgt = (float)ri_mult(meta[i]);
+                    const float y1 = u[i] - vv[i];
                     const float yh = (y1 - mu) * iv;
-                    const float gu = __builtin_fmaf(y1, sc, sh) > 0.0f ? acc[j][i] + ev : 0.0f;
+                    // the row's `mult` positions share a1; only one of them can hold a pooled slot (S)
+                    const float gu = __builtin_fmaf(y1, sc, sh) > 0.0f ? __builtin_fmaf(ev, wgt, acc[j][i]) : 0.0f;
                     t1 += gu;
                     t2 = __builtin_fmaf(gu, yh, t2);
-                    hb += yh;
-                    if (nrow[i] == first) gfirst += gu;          // slot 0 and the fill run behind the hits
-                    else if (valid) atomicAdd(A + ((size_t)cloud * a.n + nrow[i]) * H + mid, gu);
+                    if (valid && wgt != 0.0f) atomicAdd(A + ((size_t)cloud * a.n + nrow[i]) * H + mid, gu);
+                    u[i] = gu;                       // kept for the per-query sums
+                    vv[i] = wgt * yh;
                 }
                 t1 += shfl_xor32(t1);
                 t2 += shfl_xor32(t2);
-                hb += shfl_xor32(hb);
-                gfirst += shfl_xor32(gfirst);
                 if (h == 0 && valid) {
-                    atomicAdd(A + ((size_t)cloud * a.n + first) * H + mid, gfirst);
                     mine[mid] += t1;
                     mine[H + mid] += t2;
-                    HA[(size_t)tile * H + mid] = t1;
-                    HB[(size_t)tile * H + mid] = hb;
+                }
+#pragma unroll 1
+                for (int jq = 0; jq < nq; ++jq) {
+                    float ha = 0.0f, hb = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const bool in = ri_q(meta[i]) == jq;     // padding rows carry zeros
+                        ha += in ? u[i] : 0.0f;
+                        hb += in ? vv[i] : 0.0f;
+                    }
+                    ha += shfl_xor32(ha);
+                    hb += shfl_xor32(hb);
+                    if (h == 0 && valid) {
+                        HA[(size_t)(q0 + jq) * H + mid] = ha;
+                        HB[(size_t)(q0 + jq) * H + mid] = hb;
+                    }
                 }
             }
         }
@@ -437,8 +513,11 @@ __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const f
                                                              float *__restrict__ Rpart,
                                                              float *__restrict__ sumapart) {
     constexpr int NJ = H / 32, NT = NW * 64, NFRAG = NJ * 2 * 64;      // fragment-lanes per tile
-    __shared__ uint4 bl[NJ * 2 * 2 * 64];                              // [j][s][part][lane]
+    __shared__ uint4 bl[NJ * 2 * 2 * 64];                              // a1            [j][s][part][lane]
+    __shared__ uint4 blw[NJ * 2 * 2 * 64];                             // mult * a1 (the Gram product's other side)
     __shared__ float sred[NFRAG];
+    __shared__ unsigned rinfo[32];
+    __shared__ int rnb[32];
     const int lane = lane_id(), w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int rb = blockIdx.y * NW + w;                                // this wave's row block
     const bool rb_ok = rb < (O + H) / 32;
@@ -452,55 +531,68 @@ __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const f
     float suma[FPT];
 #pragma unroll
     for (int f = 0; f < FPT; ++f) suma[f] = 0.0f;
-    const int per = (a.ntiles + gridDim.x - 1) / gridDim.x;
-    const int t0 = blockIdx.x * per, t1 = min(a.ntiles, t0 + per);
+    const int nt = tm_tiles(a);
+    const int *__restrict__ tq0 = tm_tq0(a);
+    const unsigned *__restrict__ rows = tm_rows(a);
+    const int per = (nt + gridDim.x - 1) / gridDim.x;
+    const int t0 = blockIdx.x * per, t1 = min(nt, t0 + per);
     for (int tile = t0; tile < t1; ++tile) {
-        const int cloud = tile / a.m;
-        const int *__restrict__ ip = a.idx + (size_t)tile * 32;
-        const float *__restrict__ ub = a.U + (size_t)cloud * a.n * H;
-        const float *__restrict__ vq = a.V + (size_t)tile * H;
+        const int q0 = tq0[tile];
+        const float *__restrict__ ub = a.U + (size_t)(q0 / a.m) * a.n * H;
         __syncthreads();                                               // previous tile's reads are done
+        if (threadIdx.x < 32) {
+            const unsigned info = rows[(size_t)tile * 32 + threadIdx.x];
+            rinfo[threadIdx.x] = info;
+            rnb[threadIdx.x] = a.idx[(size_t)(q0 + ri_q(info)) * 32 + ri_slot(info)];
+        }
+        __syncthreads();
 #pragma unroll
         for (int f = 0; f < FPT; ++f) {
             const int fi = threadIdx.x + NT * f;                       // (j, s, lane') = fragment-lane
             if (fi < NFRAG) {
                 const int fl = fi & 63, s = (fi >> 6) & 1, j = fi >> 7;
                 const int mid = j * 32 + (fl & 31), p0 = s * 16 + (fl >> 5) * 8;
-                const float sc = pack1[mid], sh = pack1[H + mid], vv = vq[mid];
-                float t[8], sum = 0.0f;
+                const float sc = pack1[mid], sh = pack1[H + mid];
+                float t[8], tw[8], sum = 0.0f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float y1 = ub[(size_t)ip[p0 + e] * H + mid] - vv;
+                    const unsigned info = rinfo[p0 + e];
+                    const float y1 = ub[(size_t)rnb[p0 + e] * H + mid] - a.V[(size_t)(q0 + ri_q(info)) * H + mid];
                     const float v = __builtin_fmaf(y1, sc, sh);
                     t[e] = v > 0.0f ? v : 0.0f;
-                    sum += t[e];
+                    tw[e] = t[e] * (float)ri_mult(info);
+                    sum += tw[e];
                 }
                 suma[f] += sum;
-                const Frag<2> fr = make_frag<2>(t);
+                const Frag<2> fr = make_frag<2>(t), fw = make_frag<2>(tw);
                 bl[((j * 2 + s) * 2 + 0) * 64 + fl] = __builtin_bit_cast(uint4, fr.p[0]);
                 bl[((j * 2 + s) * 2 + 1) * 64 + fl] = __builtin_bit_cast(uint4, fr.p[1]);
+                blw[((j * 2 + s) * 2 + 0) * 64 + fl] = __builtin_bit_cast(uint4, fw.p[0]);
+                blw[((j * 2 + s) * 2 + 1) * 64 + fl] = __builtin_bit_cast(uint4, fw.p[1]);
             }
         }
         __syncthreads();
         if (!rb_ok) continue;
         Frag<2> af[2];
-        if (s_rows) {                   // A = S^T: row = channel c of this lane, k = position
+        if (s_rows) {                   // A = S^T: row = channel c of this lane, k = row of the tile
             const int c = rb * 32 + r;
-            const float gv = goa[(size_t)tile * O + c];
-            const int kp = ksel[(size_t)tile * O + c];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float t[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = (s * 16 + h * 8 + e) == kp ? gv : 0.0f;
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned info = rinfo[s * 16 + h * 8 + e];
+                    const size_t qc = (size_t)(q0 + ri_q(info)) * O + c;
+                    t[e] = (ri_mult(info) != 0 && (int)ksel[qc] == ri_slot(info)) ? goa[qc] : 0.0f;
+                }
                 af[s] = make_frag<2>(t);
             }
-        } else {                        // A = a1^T rows of mid block rb - O/32: the same fragments
+        } else {                        // A = (mult a1)^T rows of mid block rb - O/32
             const int j0 = rb - O / 32;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                af[s].p[0] = __builtin_bit_cast(bf16x8, bl[((j0 * 2 + s) * 2 + 0) * 64 + lane]);
-                af[s].p[1] = __builtin_bit_cast(bf16x8, bl[((j0 * 2 + s) * 2 + 1) * 64 + lane]);
+                af[s].p[0] = __builtin_bit_cast(bf16x8, blw[((j0 * 2 + s) * 2 + 0) * 64 + lane]);
+                af[s].p[1] = __builtin_bit_cast(bf16x8, blw[((j0 * 2 + s) * 2 + 1) * 64 + lane]);
             }
         }
 #pragma unroll
@@ -575,8 +667,8 @@ static bool wide_shape_ok(int H, int O) {
     return (H == 32 || H == 64 || H == 128 || H == 256) && O == 2 * H;
 }
 
-static bool wide_args_ok(int b, int n, int m, const void *U, const void *V, const void *idx) {
-    return b > 0 && n > 0 && m > 0 && (long long)b * m <= 0x7fffffffLL / 64 && U && V && idx;
+static bool wide_args_ok(int b, int n, int m, const void *U, const void *V, const void *idx, const void *tmap) {
+    return b > 0 && n > 0 && m > 0 && (long long)b * m <= 0x7fffffffLL / 64 && U && V && idx && tmap;
 }
 
 template <int H>
@@ -640,9 +732,9 @@ extern "C" int apn_sa_wide_colsum(const float *part, int rows, int ncol, double 
 }
 
 extern "C" int apn_sa_wide_stats1(int b, int n, int m, int c_mid, const float *U, const float *V,
-                                  const int *idx, float *part, void *stream) {
-    if (!wide_args_ok(b, n, m, U, V, idx) || !part) return APN_EINVAL;
-    WideArgs a{b * m, n, m, U, V, idx};
+                                  const int *idx, const int *tmap, float *part, void *stream) {
+    if (!wide_args_ok(b, n, m, U, V, idx, tmap) || !part) return APN_EINVAL;
+    WideArgs a{b * m, n, m, U, V, idx, tmap};
     const int grid = wide_grid(a.ntiles);
     APN_WIDE_DISPATCH(c_mid, hipLaunchKernelGGL((wide_stats1_kernel<H>), dim3(grid), dim3(256), 0,
                                                 (hipStream_t)stream, a, part));
@@ -651,11 +743,11 @@ extern "C" int apn_sa_wide_stats1(int b, int n, int m, int c_mid, const float *U
 }
 
 extern "C" int apn_sa_wide_fwd_main(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
-                                    const int *idx, const void *w2_image, const float *pack1,
+                                    const int *idx, const int *tmap, const void *w2_image, const float *pack1,
                                     const float *sgn2, float *ysel, void *ksel, float *part, void *stream) {
-    if (!wide_args_ok(b, n, m, U, V, idx) || !wide_shape_ok(c_mid, c_out)) return APN_EINVAL;
+    if (!wide_args_ok(b, n, m, U, V, idx, tmap) || !wide_shape_ok(c_mid, c_out)) return APN_EINVAL;
     if (!w2_image || !pack1 || !sgn2 || !ysel || !ksel || !part) return APN_EINVAL;
-    WideArgs a{b * m, n, m, U, V, idx};
+    WideArgs a{b * m, n, m, U, V, idx, tmap};
     const int grid = wide_grid(a.ntiles);
     APN_WIDE_DISPATCH(c_mid, {
         constexpr int O = 2 * H, CT = fwd_ct<H>();
@@ -671,12 +763,12 @@ extern "C" int apn_sa_wide_fwd_main(int b, int n, int m, int c_mid, int c_out, c
 }
 
 extern "C" int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
-                                    const int *idx, const void *z_image, const float *pack1,
+                                    const int *idx, const int *tmap, const void *z_image, const float *pack1,
                                     const float *evec, const float *goa, const void *ksel, float *A,
                                     float *HA, float *HB, float *part, void *stream) {
-    if (!wide_args_ok(b, n, m, U, V, idx) || !wide_shape_ok(c_mid, c_out)) return APN_EINVAL;
+    if (!wide_args_ok(b, n, m, U, V, idx, tmap) || !wide_shape_ok(c_mid, c_out)) return APN_EINVAL;
     if (!z_image || !pack1 || !evec || !goa || !ksel || !A || !HA || !HB || !part) return APN_EINVAL;
-    WideArgs a{b * m, n, m, U, V, idx};
+    WideArgs a{b * m, n, m, U, V, idx, tmap};
     const int grid = wide_grid(a.ntiles);
     APN_WIDE_DISPATCH(c_mid, {
         constexpr int O = 2 * H, CT = bwd_ct<H>();
@@ -701,11 +793,11 @@ extern "C" int apn_sa_wide_wgrad_splits(int b, int m, int c_mid) {
 }
 
 extern "C" int apn_sa_wide_wgrad(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
-                                 const int *idx, const float *pack1, const float *goa, const void *ksel,
-                                 int splits, float *r_part, float *suma_part, void *stream) {
-    if (!wide_args_ok(b, n, m, U, V, idx) || !wide_shape_ok(c_mid, c_out)) return APN_EINVAL;
+                                 const int *idx, const int *tmap, const float *pack1, const float *goa,
+                                 const void *ksel, int splits, float *r_part, float *suma_part, void *stream) {
+    if (!wide_args_ok(b, n, m, U, V, idx, tmap) || !wide_shape_ok(c_mid, c_out)) return APN_EINVAL;
     if (!pack1 || !goa || !ksel || !r_part || !suma_part || splits < 1) return APN_EINVAL;
-    WideArgs a{b * m, n, m, U, V, idx};
+    WideArgs a{b * m, n, m, U, V, idx, tmap};
     APN_WIDE_DISPATCH(c_mid, {
         constexpr int O = 2 * H, NRB = (O + H) / 32, NW = NRB < 8 ? NRB : 8;
         const dim3 grid(splits, (NRB + NW - 1) / NW);

@@ -293,3 +293,152 @@ extern "C" int apn_sa_wide_point_terms(int b, int n, int m, int c_mid, const flo
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Tile map: distinct-hit packing of the neighbourhoods (part of the INDEX stage: coordinates only).
+//
+// A ball query lists a query's cnt distinct hits in slots 0..cnt-1 and fills slots cnt..31 with copies
+// of slot 0 (ball_query_gpu.cu:41-48); at PointNeXt-S stage 1 cnt averages 7.6 of 32.  Every copy of a
+// position computes the same y1, a1, y2, so the fused passes only need ONE row per distinct hit plus its
+// multiplicity (slot 0: 33 - cnt, the others 1): statistics, Gram and gradient sums weight a row by it,
+// the max over K runs over the distinct rows.  Whole queries are packed greedily, in order, into 32-row
+// MFMA tiles (a cloud's tiles are contiguous, clouds in order): 557 tiles instead of 2048 per 4 clouds.
+//   rowinfo[tile][row] = qlocal | slot << 8 | mult << 16 | (row 0 only: queries in the tile) << 24;
+//   mult == 0 marks a padding row;  tq0[tile] = the tile's first query (global id b * M + q).
+// An index row that does not have the ball-query structure (any other grouper) is kept whole:
+// cnt = 32, every slot its own row.  mode 0 skips the analysis: one tile per query.
+// ------------------------------------------------------------------------------------------
+namespace apn {
+
+__global__ __launch_bounds__(256) void tilemap_count_kernel(int nq, int mode, const int *__restrict__ idx,
+                                                            unsigned char *__restrict__ cnt8) {
+    const int lane = lane_id(), q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    int cnt = 32;
+    if (mode) {
+        const int nn = idx[(size_t)q * 32 + (lane & 31)];
+        const int first = __builtin_amdgcn_readfirstlane(nn);
+        const unsigned differ = (unsigned)(__ballot(lane < 32 && lane > 0 && nn != first));   // bit k: slot k != slot 0
+        const int c = __popc(differ) + 1;
+        // ball-query structure: the differing slots are exactly 1..c-1 (and, being hits in index order, distinct)
+        if (differ == ((c >= 32 ? 0xffffffffu : ((1u << c) - 1u)) & ~1u)) cnt = c;
+    }
+    if (lane == 0) cnt8[q] = (unsigned char)cnt;
+}
+
+// one WAVE per cloud: greedy packing, 64 queries per round -- the counts arrive coalesced, the sequential
+// part runs on the scalar unit over v_readlane.  qmeta[q] = tile_local | row0 << 16 | starts_tile << 24 | number in its tile << 25
+__global__ __launch_bounds__(256) void tilemap_pack_kernel(int b, int m, const unsigned char *__restrict__ cnt8,
+                                                           unsigned *__restrict__ qmeta, int *__restrict__ tcount,
+                                                           unsigned short *__restrict__ tnq_local) {
+    const int lane = lane_id();
+    const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (c >= b) return;
+    int tile = 0, fill = 0, nq = 0;                       // wave-uniform
+    for (int base = 0; base < m; base += 64) {
+        const int mine = base + lane < m ? cnt8[(size_t)c * m + base + lane] : 0;
+        const int lim = m - base < 64 ? m - base : 64;
+        unsigned meta = 0;
+        for (int i = 0; i < lim; ++i) {
+            const int cn = __builtin_amdgcn_readlane(mine, i);
+            bool starts = base + i == 0;
+            if (fill + cn > 32) {
+                if (lane == 0) tnq_local[(size_t)c * m + tile] = (unsigned short)nq;
+                ++tile; fill = 0; nq = 0; starts = true;
+            }
+            const unsigned v = (unsigned)tile | ((unsigned)fill << 16) | (starts ? 1u << 24 : 0u) | ((unsigned)nq << 25);
+            meta = lane == i ? v : meta;
+            fill += cn;
+            ++nq;
+        }
+        if (lane < lim) qmeta[(size_t)c * m + base + lane] = meta;
+    }
+    if (lane == 0) {
+        tnq_local[(size_t)c * m + tile] = (unsigned short)nq;
+        tcount[c] = tile + 1;
+    }
+}
+
+// exclusive scan of the per-cloud tile counts (one block): toff[c], ntiles[0] = total
+__global__ __launch_bounds__(1024) void tilemap_scan_kernel(int b, const int *__restrict__ tcount,
+                                                            int *__restrict__ toff, int *__restrict__ ntiles) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x, per = (b + 1023) / 1024;
+    int s = 0;
+    for (int i = 0; i < per; ++i) {
+        const int c = t * per + i;
+        if (c < b) s += tcount[c];
+    }
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = 0; i < per; ++i) {
+        const int c = t * per + i;
+        if (c < b) { toff[c] = run; run += tcount[c]; }
+    }
+    if (t == 1023) ntiles[0] = part[1023];
+}
+
+// one wave per query: write its rows (and the padding behind a tile's last query)
+__global__ __launch_bounds__(256) void tilemap_fill_kernel(int nq, int m, const unsigned char *__restrict__ cnt8,
+                                                           const unsigned *__restrict__ qmeta,
+                                                           const int *__restrict__ toff,
+                                                           const unsigned short *__restrict__ tnq_local,
+                                                           int *__restrict__ tq0, unsigned *__restrict__ rowinfo) {
+    const int lane = lane_id(), q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq || lane >= 32) return;
+    const int c = q / m, cn = cnt8[q];
+    const unsigned meta = qmeta[q];
+    const int tl = meta & 0xffff, row0 = (meta >> 16) & 0xff;
+    const bool starts = (meta >> 24) & 1;
+    const bool ends = (q % m) == m - 1 || ((qmeta[q + 1] >> 24) & 1);       // the next query opens a tile
+    const int tile = toff[c] + tl;
+    const unsigned qlocal = (meta >> 25) & 0x3fu;
+    if (lane < cn) {
+        const unsigned mult = lane == 0 ? (unsigned)(33 - cn) : 1u;
+        unsigned v = qlocal | ((unsigned)lane << 8) | (mult << 16);
+        if (starts && lane == 0) v |= (unsigned)tnq_local[(size_t)c * m + tl] << 24;
+        rowinfo[(size_t)tile * 32 + row0 + lane] = v;
+    }
+    if (ends && row0 + cn + lane < 32 && lane < 32 - (row0 + cn)) rowinfo[(size_t)tile * 32 + row0 + cn + lane] = 0u;
+    if (starts && lane == 0) tq0[tile] = q;
+}
+
+}  // namespace apn
+
+// The map is ONE int32 blob (BM = b * m, BM4 = BM rounded up to 4):
+//   [0] tiles in use   [4, 4 + BM) tq0   [4 + BM4, 4 + BM4 + 32 BM) rowinfo   then scratch of this builder
+// (per-cloud tile counts and offsets, per-query packing records); apn_sa_wide_tilemap_ints(b, m) = its size.
+static size_t tilemap_rows_off(int bm) { return 4 + (size_t)((bm + 3) & ~3); }
+
+extern "C" int apn_sa_wide_tilemap_ints(int b, int m) {
+    if (b <= 0 || m <= 0 || (long long)b * m > 0x7fffffffLL / 64) return 0;
+    const size_t bm = (size_t)b * m;
+    return (int)(tilemap_rows_off((int)bm) + 32 * bm + 2 * (size_t)b + bm + (bm + 1) / 2 + (bm + 3) / 4 + 8);
+}
+
+extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *tmap, void *stream) {
+    if (b <= 0 || m <= 0 || m > 65535 || (long long)b * m > 0x7fffffffLL / 64 || !idx || !tmap) return APN_EINVAL;
+    const int nq = b * m;
+    int *tq0 = tmap + 4;
+    unsigned *rowinfo = (unsigned *)(tmap + tilemap_rows_off(nq));
+    int *tcount = (int *)(rowinfo + (size_t)32 * nq), *toff = tcount + b;
+    unsigned *qmeta = (unsigned *)(toff + b);
+    unsigned short *tnq_local = (unsigned short *)(qmeta + nq);
+    unsigned char *cnt8 = (unsigned char *)(tnq_local + 2 * (((size_t)nq + 1) / 2));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(apn::tilemap_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, nq, mode, idx, cnt8);
+    hipLaunchKernelGGL(apn::tilemap_pack_kernel, dim3((b + 3) / 4), dim3(256), 0, st, b, m, cnt8, qmeta, tcount,
+                       tnq_local);
+    hipLaunchKernelGGL(apn::tilemap_scan_kernel, dim3(1), dim3(1024), 0, st, b, tcount, toff, tmap);
+    hipLaunchKernelGGL(apn::tilemap_fill_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, nq, m, cnt8, qmeta, toff,
+                       tnq_local, tq0, rowinfo);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}

@@ -96,6 +96,18 @@ def _image(src0, k0, trans0, src1, kd, nc, ct):
     return img
 
 
+def tile_map(idx, fold=True):
+    """The distinct-hit tile map of neighbour indices idx (B,M,32) (csrc/sa_wide_glue.hip): an int32 device
+    blob the four position kernels read.  It depends on idx alone, so it belongs to the index stage and can
+    be built once per batch, off the feature stream (`Sampling.tmap`, `index_pyramid`).  fold=False: one
+    32-row tile per query (no use made of the ball-query structure)."""
+    B, M, K = idx.shape
+    assert K == K_NS and idx.dtype == torch.int32 and idx.is_contiguous()
+    tmap = torch.empty(_lib.load().apn_sa_wide_tilemap_ints(B, M), dtype=torch.int32, device=idx.device)
+    _call("apn_sa_wide_tilemap", idx.device, B, M, 1 if fold else 0, idx.data_ptr(), tmap.data_ptr())
+    return tmap
+
+
 def _training(bn):
     return bn.training or not bn.track_running_stats
 
@@ -103,7 +115,7 @@ def _training(bn):
 class _WideMlpMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, new_p, f, idx, w1, g1, b1, w2, g2, b2, mods):
-        radius, bn1, bn2, sync_bn = mods
+        radius, bn1, bn2, sync_bn, tmap = mods
         p, new_p, f, idx = p.contiguous(), new_p.contiguous(), f.contiguous(), idx.contiguous()
         dev = f.device
         B, C, N = f.shape
@@ -120,33 +132,35 @@ class _WideMlpMax(torch.autograd.Function):
             U = U.contiguous()
             grid = _lib.load().apn_sa_wide_grid(B, M)
             count = float(B * M * K_NS)
+            if tmap is None:
+                tmap = tile_map(idx)
             tr1, tr2 = _training(bn1), _training(bn2)
             part1 = None
             if tr1:
                 part1 = torch.empty(grid, 2 * H, dtype=torch.float32, device=dev)
                 _call("apn_sa_wide_stats1", dev, B, N, M, H, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
-                      part1.data_ptr())
+                      tmap.data_ptr(), part1.data_ptr())
             pack1, sgn2, _ = _bn_pack(part1, grid, H, count, bn1, dev, tr1, sync, sgn_from=g2, sgn_c=O)
             w2img = _image(W2, H, True, None, H, O, min(4, O // 32))          # W2^T (H x O)
             ysel = torch.empty(B, M, O, dtype=torch.float32, device=dev)
             ksel = torch.empty(B, M, O, dtype=torch.uint8, device=dev)
             part2 = torch.empty(grid, 2 * O, dtype=torch.float32, device=dev)
             _call("apn_sa_wide_fwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
-                  w2img.data_ptr(), pack1.data_ptr(), sgn2.data_ptr(), ysel.data_ptr(), ksel.data_ptr(),
+                  tmap.data_ptr(), w2img.data_ptr(), pack1.data_ptr(), sgn2.data_ptr(), ysel.data_ptr(), ksel.data_ptr(),
                   part2.data_ptr())
             pack2, _, _ = _bn_pack(part2 if tr2 else None, grid, O, count, bn2, dev, tr2, sync)
             out = torch.addcmul(pack2[O:2 * O], ysel, pack2[:O]).transpose(1, 2).contiguous()
             if _DEBUG is not None:
                 _DEBUG.update(U=U, V=V, pack1=pack1, w2img=w2img, ysel=ysel, ksel=ksel, part2=part2, pack2=pack2,
                               sgn2=sgn2)
-        ctx.save_for_backward(p, new_p, f, idx, U, V, pack1, pack2, ysel, ksel, W1, W2)
+        ctx.save_for_backward(p, new_p, f, idx, U, V, pack1, pack2, ysel, ksel, W1, W2, tmap)
         ctx.cfg = (radius, tr1, tr2, sync, count, g1 is not None, b1 is not None, g2 is not None, b2 is not None)
         ctx.need = (p.requires_grad, new_p.requires_grad)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        p, new_p, f, idx, U, V, pack1, pack2, ysel, ksel, W1, W2 = ctx.saved_tensors
+        p, new_p, f, idx, U, V, pack1, pack2, ysel, ksel, W1, W2, tmap = ctx.saved_tensors
         radius, tr1, tr2, sync, count, a1, a2, a3, a4 = ctx.cfg
         need_p, need_q = ctx.need
         dev = f.device
@@ -188,7 +202,7 @@ class _WideMlpMax(torch.autograd.Function):
         HB = torch.empty(B, M, H, **f32)
         partT = torch.empty(grid, 2 * H, **f32)
         _call("apn_sa_wide_bwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
-              zimg.data_ptr(), pack1.data_ptr(), evec.data_ptr(), goa.data_ptr(), ksel.data_ptr(),
+              tmap.data_ptr(), zimg.data_ptr(), pack1.data_ptr(), evec.data_ptr(), goa.data_ptr(), ksel.data_ptr(),
               A.data_ptr(), HA.data_ptr(), HB.data_ptr(), partT.data_ptr())
         # weight-gradient products over the positions
         rows = O + H
@@ -197,7 +211,7 @@ class _WideMlpMax(torch.autograd.Function):
         Rpart = torch.empty(splits, rows, H, **f32)
         sumapart = torch.empty(splits, H, **f32)
         _call("apn_sa_wide_wgrad", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
-              pack1.data_ptr(), goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr(),
+              tmap.data_ptr(), pack1.data_ptr(), goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr(),
               sumapart.data_ptr())
         R = _colsum(Rpart.view(splits, rows * H)).view(rows, H)
         suma = _colsum(sumapart)
@@ -224,7 +238,8 @@ class _WideMlpMax(torch.autograd.Function):
                 g_w2.view(O, H, 1, 1), g_gamma2 if a3 else None, g_beta2 if a4 else None, None)
 
 
-def grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2, sync_bn=False):
-    """out (B,O,M) = max_K bn2(conv2(relu(bn1(conv1(cat[(p[idx]-new_p)/r, f[idx]]))))), any PointNeXt-S width."""
+def grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2, sync_bn=False, tmap=None):
+    """out (B,O,M) = max_K bn2(conv2(relu(bn1(conv1(cat[(p[idx]-new_p)/r, f[idx]]))))), any PointNeXt-S width.
+    tmap: `tile_map(idx)` built ahead of time (default: built here, on the calling stream)."""
     return _WideMlpMax.apply(p, new_p, f, idx, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight,
-                             bn2.bias, (float(radius), bn1, bn2, sync_bn))
+                             bn2.bias, (float(radius), bn1, bn2, sync_bn, tmap))

@@ -351,6 +351,17 @@ APN_API int apn_attention_bwd(int b, int m, int heads, const void *images, const
  * {scale, shift, mean, invstd}[H].  Weight operands are "B images" (bf16 hi/lo parts in MFMA
  * fragment order, adaptpoint_amd/fused_wide.py::mfma_b_image). ---- */
 APN_API int apn_sa_wide_grid(int b, int m);          /* workgroups = partial rows of the three passes */
+/* Tile map (distinct-hit packing; part of the index stage: it depends on idx only).  A ball query lists a
+ * query's cnt distinct hits and fills the other 32 - cnt slots with copies of slot 0
+ * (ball_query_gpu.cu:41-48), and every copy computes the same y1, a1, y2: the passes below run over ROWS
+ * = (query, distinct slot, multiplicity), whole queries packed in order into 32-row MFMA tiles.
+ * tmap: int32[apn_sa_wide_tilemap_ints(b, m)], device memory:
+ *   [0] tiles in use; [4, 4 + b m) first query of each tile; [4 + roundup4(b m), ... + 32 b m) the rows,
+ *   qlocal | slot << 8 | mult << 16 | (row 0: queries in the tile) << 24, mult = 0 for padding; scratch.
+ * mode 1: fold the copies of slot 0 of every index row that has the ball-query structure (checked row
+ * by row; any other row is kept whole); mode 0: one tile per query, 32 rows of multiplicity 1. */
+APN_API int apn_sa_wide_tilemap_ints(int b, int m);
+APN_API int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *tmap, void *stream);
 /* out[ncol] (float64) = column sums of part[rows][ncol] (float32) in a fixed order; two passes
  * through scratch[apn_sa_wide_colsum_chunks(rows, ncol)][ncol] (float64) when there is more than one chunk */
 APN_API int apn_sa_wide_colsum_chunks(int rows, int ncol);
@@ -358,20 +369,20 @@ APN_API int apn_sa_wide_colsum(const float *part, int rows, int ncol, double *sc
                                void *stream);
 /* part[grid][2H] = {sum, sumsq} of y1 */
 APN_API int apn_sa_wide_stats1(int b, int n, int m, int c_mid, const float *U, const float *V,
-                               const int *idx, float *part, void *stream);
+                               const int *idx, const int *tmap, float *part, void *stream);
 /* a1 = relu(scale1 y1 + shift1), y2 = a1 W2^T (w2_image: B image of W2^T, H x O, min(4, O/32) column
  * tiles per block) -> ysel/ksel (B,M,O): per (query, channel) the extreme of y2 over the K slots
  * (max where sgn2 = +1, min where -1; first slot among equals) and that slot;
  * part[grid][2*O] = {sum, sumsq} of y2 */
 APN_API int apn_sa_wide_fwd_main(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
-                                 const int *idx, const void *w2_image, const float *pack1,
+                                 const int *idx, const int *tmap, const void *w2_image, const float *pack1,
                                  const float *sgn2, float *ysel, void *ksel, float *part, void *stream);
 /* dL/da1 = S W2 + a1 Qm + evec (z_image: B image of [W2 ; Qm], (O+H) x H, min(4, H/32) column tiles
  * per block; S[pos,c] = goa[q,c] [ksel[q,c] == pos]), g_u = dL/da1 [a1 > 0]:
  * A (B,N,H) += g_u per gathered point (caller-zeroed, float atomics), HA (B,M,H) = sum_k g_u,
  * HB (B,M,H) = sum_k yhat1, part[grid][2H] = {sum g_u, sum g_u yhat1} */
 APN_API int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
-                                 const int *idx, const void *z_image, const float *pack1,
+                                 const int *idx, const int *tmap, const void *z_image, const float *pack1,
                                  const float *evec, const float *goa, const void *ksel, float *A,
                                  float *HA, float *HB, float *part, void *stream);
 /* The small kernels around those passes (csrc/sa_wide_glue.hip).
@@ -405,8 +416,8 @@ APN_API int apn_sa_wide_point_terms(int b, int n, int m, int c_mid, const float 
  * the Gram matrix of a1), suma_part[splits][H] = partial sum of a1; the caller sums the splits */
 APN_API int apn_sa_wide_wgrad_splits(int b, int m, int c_mid);
 APN_API int apn_sa_wide_wgrad(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
-                              const int *idx, const float *pack1, const float *goa, const void *ksel,
-                              int splits, float *r_part, float *suma_part, void *stream);
+                              const int *idx, const int *tmap, const float *pack1, const float *goa,
+                              const void *ksel, int splits, float *r_part, float *suma_part, void *stream);
 
 /* Tuning / diagnostic entry, NOT part of the reference boundary: apn_furthest_point_sampling
  * with the number of wavefronts that cooperate on one cloud (1, 2, 4, 8 or 16; 0 = the built-in
