@@ -332,8 +332,9 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
 //   dL/da1[pos, :] = S[pos, :] W2 + a1[pos, :] Qm + evec,  S[pos, c] = goa[q, c] [ksel[q, c] == pos]
 //   (Qm = W2^T diag(D2) W2, evec = E2 W2: BatchNorm-2's feedback without recomputing y2),
 //   g_u = dL/da1 [a1 > 0];  the block's row of part: {T1 = sum g_u, T2 = sum g_u yhat1}[H];
-//   A[b, n, :] += g_u of every position that gathers point n (float atomics, the ball-query
-//   fill run folded first); HA[q, :] = sum_k g_u, HB[q, :] = sum_k yhat1.
+//   GU[tile * 32 + row, :] = g_u summed over the row's positions (dense rows; the per-point sums are taken
+//   later through the index stage's inverse map, in a fixed order: no float atomics);
+//   HA[q, :] = sum_k g_u, HB[q, :] = sum_k yhat1.
 //   img: B image of Z = [W2 ; Qm] ((O + H) x H), CT = min(4, H/32) column tiles per block.
 //   pack1 = {scale1, shift1, mean1, invstd1}[H].
 // ------------------------------------------------------------------------------------------
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
                                                             const float *__restrict__ evec,
                                                             const float *__restrict__ goa,
                                                             const unsigned char *__restrict__ ksel,
-                                                            float *__restrict__ A, float *__restrict__ HA,
+                                                            float *__restrict__ GU, float *__restrict__ HA,
                                                             float *__restrict__ HB, float *__restrict__ part) {
     constexpr int NKS = O / 32, NKC = (O + H) / 32, NCB = H / (32 * CT), NCH = NKC * NCB;
     constexpr int SLOTS = RES ? NCH : 2;
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
                     const float gu = __builtin_fmaf(y1, sc, sh) > 0.0f ? __builtin_fmaf(ev, wgt, acc[j][i]) : 0.0f;
                     t1 += gu;
                     t2 = __builtin_fmaf(gu, yh, t2);
-                    if (valid && wgt != 0.0f) atomicAdd(A + ((size_t)cloud * a.n + nrow[i]) * H + mid, gu);
+                    if (valid && wgt != 0.0f) GU[((size_t)tile * 32 + acc_row(i, h)) * H + mid] = gu;
                     u[i] = gu;                       // kept for the per-query sums
                     vv[i] = wgt * yh;
                 }
@@ -504,14 +505,13 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
 // (H/32 accumulator tiles); the workgroup's range of query tiles is blockIdx.x of gridDim.x
 // (split-K).  Per tile the a1 operand (k = position, column = mid channel) is built ONCE by the
 // workgroup into LDS in fragment order; its a1^T rows are the same fragments.
-// Outputs: Rpart[split][(O+H)][H], sumapart[split][H] (summed by the caller in float64).
+// Output: Rpart[split][(O+H) H + H] = {R, suma} (one row per split, summed by the caller in float64).
 // ------------------------------------------------------------------------------------------
 template <int H, int O, int NW>
 __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const float *__restrict__ pack1,
                                                              const float *__restrict__ goa,
                                                              const unsigned char *__restrict__ ksel,
-                                                             float *__restrict__ Rpart,
-                                                             float *__restrict__ sumapart) {
+                                                             float *__restrict__ Rpart) {
     constexpr int NJ = H / 32, NT = NW * 64, NFRAG = NJ * 2 * 64;      // fragment-lanes per tile
     __shared__ uint4 bl[NJ * 2 * 2 * 64];                              // a1            [j][s][part][lane]
     __shared__ uint4 blw[NJ * 2 * 2 * 64];                             // mult * a1 (the Gram product's other side)
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const f
             }
     }
     if (rb_ok) {
-        float *__restrict__ out = Rpart + ((size_t)blockIdx.x * (O + H) + rb * 32) * H;
+        float *__restrict__ out = Rpart + (size_t)blockIdx.x * ((O + H) * H + H) + (size_t)rb * 32 * H;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const f
             const int j = mid >> 5, rr = mid & 31;
             const float v = (sred[(j * 2 + 0) * 64 + rr] + sred[(j * 2 + 0) * 64 + 32 + rr]) +
                             (sred[(j * 2 + 1) * 64 + rr] + sred[(j * 2 + 1) * 64 + 32 + rr]);
-            sumapart[(size_t)blockIdx.x * H + mid] = v;
+            Rpart[(size_t)blockIdx.x * ((O + H) * H + H) + (size_t)(O + H) * H + mid] = v;
         }
     }
 }
@@ -764,10 +764,10 @@ extern "C" int apn_sa_wide_fwd_main(int b, int n, int m, int c_mid, int c_out, c
 
 extern "C" int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
                                     const int *idx, const int *tmap, const void *z_image, const float *pack1,
-                                    const float *evec, const float *goa, const void *ksel, float *A,
+                                    const float *evec, const float *goa, const void *ksel, float *GU,
                                     float *HA, float *HB, float *part, void *stream) {
     if (!wide_args_ok(b, n, m, U, V, idx, tmap) || !wide_shape_ok(c_mid, c_out)) return APN_EINVAL;
-    if (!z_image || !pack1 || !evec || !goa || !ksel || !A || !HA || !HB || !part) return APN_EINVAL;
+    if (!z_image || !pack1 || !evec || !goa || !ksel || !GU || !HA || !HB || !part) return APN_EINVAL;
     WideArgs a{b * m, n, m, U, V, idx, tmap};
     const int grid = wide_grid(a.ntiles);
     APN_WIDE_DISPATCH(c_mid, {
@@ -777,7 +777,7 @@ extern "C" int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, c
         const size_t lds = (size_t)(RES ? NCH : 2) * Chunk<CT>::WORDS * 16 + (size_t)WIDE_WAVES * 2 * H * 4;
         hipLaunchKernelGGL((wide_bwd_main_kernel<H, O, CT, RES>), dim3(grid), dim3(256), lds,
                            (hipStream_t)stream, a, (const uint4 *)z_image, pack1, evec, goa,
-                           (const unsigned char *)ksel, A, HA, HB, part);
+                           (const unsigned char *)ksel, GU, HA, HB, part);
     });
     APN_LAUNCH_CHECK();
     return APN_OK;
@@ -794,15 +794,15 @@ extern "C" int apn_sa_wide_wgrad_splits(int b, int m, int c_mid) {
 
 extern "C" int apn_sa_wide_wgrad(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
                                  const int *idx, const int *tmap, const float *pack1, const float *goa,
-                                 const void *ksel, int splits, float *r_part, float *suma_part, void *stream) {
+                                 const void *ksel, int splits, float *r_part, void *stream) {
     if (!wide_args_ok(b, n, m, U, V, idx, tmap) || !wide_shape_ok(c_mid, c_out)) return APN_EINVAL;
-    if (!pack1 || !goa || !ksel || !r_part || !suma_part || splits < 1) return APN_EINVAL;
+    if (!pack1 || !goa || !ksel || !r_part || splits < 1) return APN_EINVAL;
     WideArgs a{b * m, n, m, U, V, idx, tmap};
     APN_WIDE_DISPATCH(c_mid, {
         constexpr int O = 2 * H, NRB = (O + H) / 32, NW = NRB < 8 ? NRB : 8;
         const dim3 grid(splits, (NRB + NW - 1) / NW);
         hipLaunchKernelGGL((wide_wgrad_kernel<H, O, NW>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a,
-                           pack1, goa, (const unsigned char *)ksel, r_part, suma_part);
+                           pack1, goa, (const unsigned char *)ksel, r_part);
     });
     APN_LAUNCH_CHECK();
     return APN_OK;

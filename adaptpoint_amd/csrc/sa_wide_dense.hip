@@ -1,0 +1,606 @@
+// sa_wide_dense.hip -- the kernels of the width-generic fused path (csrc/sa_wide.hip) whose work runs over
+// POINTS, QUERIES or CHANNELS rather than over the B*M*K positions:
+//
+//   wide_fwd_prep     conv1 hoisted to the points: U = W1f f + W1p p / r (B,N,H), V = W1p new_p / r (B,M,H),
+//                     and the MFMA image of W2^T -- one launch
+//   wide_out          out (B,O,M) = ysel (B,M,O) * scale2 + shift2 (BatchNorm-2 applied to the pooled extreme)
+//   wide_bwd_mid      BatchNorm-2 backward constants D2, E2 (+ dgamma2, dbeta2), Qm = W2^T diag(D2) W2,
+//                     evec = E2 W2 and the MFMA image of [W2 ; Qm] -- one launch
+//   wide_bwd_fin      BatchNorm-1 backward constants {ca, cb, cc} (+ dgamma1, dbeta1) and
+//                     dL/dW2 = R_S + D2 (W2 Gram) + E2 (x) suma
+//   wide_point_grads  per point: dL/dU = G (summed over the rows that gather the point, in the fixed order of the
+//                     index stage's inverse map -- no float atomics), dL/df = G W1f, dL/dp = G W1p / r; per query:
+//                     dL/dnew_p; and every workgroup's share of dL/dW1 = G^T [p / r, f] - Hq^T [new_p / r, 0]
+//
+// Reference semantics: openpoints/models/backbone/pointnext.py:157-166 (convs + BatchNorm + max) over
+// group.py:235-255 (grouping with relative positions / radius); the backward is the chain rule through them.
+// All are float32 FMA kernels (the MFMA work is in sa_wide.hip); sums that leave a workgroup leave as one
+// partial row per workgroup, added in a fixed order by wide_colsum: every result is run-to-run reproducible.
+#include "apn_common.h"
+#include "apn_mfma.h"
+
+namespace apn {
+
+// ------------------------------------------------------------------------------------------
+// forward prep.  Blocks [0, pblocks): 64 points each; [pblocks, pblocks + qblocks): V; the rest: image words.
+// Point blocks: thread (point tx, wave ty) accumulates HPW = H/4 channels h0 = ty * HPW ... of its point (the
+// weights are wave-uniform: scalar loads), the tile leaves through LDS as whole rows of U.
+// ------------------------------------------------------------------------------------------
+template <int HPW>
+__global__ __launch_bounds__(256) void wide_fwd_prep_kernel(int B, int C, int N, int M, int pblocks, int qblocks,
+                                                            const float *__restrict__ f, const float *__restrict__ p,
+                                                            const float *__restrict__ new_p,
+                                                            const float *__restrict__ w1, float inv_r,
+                                                            float *__restrict__ U, float *__restrict__ V,
+                                                            const float *__restrict__ w2, int O, int ct,
+                                                            uint4 *__restrict__ img) {
+    constexpr int H = 4 * HPW;
+    extern __shared__ float sm[];                       // [64][H + 1]
+    const int ldw = C + 3;
+    const int blk = blockIdx.x;
+    if (blk < pblocks) {
+        const int tx = threadIdx.x & 63;
+        const int h0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) * HPW);
+        const long long npts = (long long)B * N;
+        const long long pt = (long long)blk * 64 + tx;
+        const long long ptc = pt < npts ? pt : npts - 1;
+        const int b = (int)(ptc / N), n = (int)(ptc % N);
+        const float *__restrict__ fb = f + (size_t)b * C * N + n;
+        float acc[HPW];
+#pragma unroll
+        for (int hh = 0; hh < HPW; ++hh) acc[hh] = 0.0f;
+        for (int c0 = 0; c0 < C; c0 += 8) {
+            float fv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fv[j] = c0 + j < C ? fb[(size_t)(c0 + j) * N] : 0.0f;
+#pragma unroll
+            for (int hh = 0; hh < HPW; ++hh) {
+                const float *__restrict__ wr = w1 + (size_t)(h0 + hh) * ldw + 3 + c0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[hh] = __builtin_fmaf(c0 + j < C ? wr[j] : 0.0f, fv[j], acc[hh]);
+            }
+        }
+        const float px = p[ptc * 3], py = p[ptc * 3 + 1], pz = p[ptc * 3 + 2];
+#pragma unroll
+        for (int hh = 0; hh < HPW; ++hh) {
+            const float *__restrict__ wr = w1 + (size_t)(h0 + hh) * ldw;
+            const float pw = __builtin_fmaf(wr[2], pz, __builtin_fmaf(wr[1], py, wr[0] * px));
+            sm[tx * (H + 1) + h0 + hh] = __builtin_fmaf(pw, inv_r, acc[hh]);
+        }
+        __syncthreads();
+        const long long base = (long long)blk * 64;
+        for (int e = threadIdx.x; e < 64 * H; e += 256) {
+            const int pl = e / H, h = e - pl * H;
+            if (base + pl < npts) U[(base + pl) * H + h] = sm[pl * (H + 1) + h];
+        }
+    } else if (blk < pblocks + qblocks) {
+        const long long e = (long long)(blk - pblocks) * 256 + threadIdx.x;
+        if (e >= (long long)B * M * H) return;
+        const long long q = e / H;
+        const int h = (int)(e - q * H);
+        const float *__restrict__ wr = w1 + (size_t)h * ldw;
+        const float *__restrict__ qp = new_p + q * 3;
+        V[e] = __builtin_fmaf(wr[2], qp[2], __builtin_fmaf(wr[1], qp[1], wr[0] * qp[0])) * inv_r;
+    } else {
+        // image of W2^T (H x O): word [cb][kc][j][s][part][lane], see wide_image_kernel (sa_wide_glue.hip)
+        const int nkc = H / 32, ncb = O / (32 * ct);
+        const int total = ncb * nkc * ct * 2 * 2 * 64;
+        const int w = (blk - pblocks - qblocks) * 256 + threadIdx.x;
+        if (w >= total) return;
+        const int lane = w & 63, part = (w >> 6) & 1, s = (w >> 7) & 1;
+        int rest = w >> 8;
+        const int j = rest % ct; rest /= ct;
+        const int kc = rest % nkc;
+        const int cb = rest / nkc;
+        const int col = (cb * ct + j) * 32 + (lane & 31), k0 = kc * 32 + s * 16 + (lane >> 5) * 8;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = w2[(size_t)col * H + k0 + e];
+            const __bf16 hi = (__bf16)v;
+            o[e] = part == 0 ? hi : (__bf16)(v - (float)hi);
+        }
+        img[w] = __builtin_bit_cast(uint4, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// out[b][c][q] = ysel[b][q][c] * scale2[c] + shift2[c]: 64 x 64 tiles through LDS.  grid (M/64, O/64, B)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wide_out_kernel(int M, int O, const float *__restrict__ ysel,
+                                                       const float *__restrict__ pack2, float *__restrict__ out) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float sc = pack2[c0 + tx], sh = pack2[O + c0 + tx];
+    for (int qq = ty; qq < 64; qq += 4) {
+        const int q = m0 + qq;
+        tile[qq][tx] = q < M ? __builtin_fmaf(ysel[((size_t)b * M + q) * O + c0 + tx], sc, sh) : 0.0f;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int q = m0 + tx;
+        if (q < M) out[((size_t)b * O + c0 + cc) * M + q] = tile[tx][cc];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, between the prep of the upstream gradient and the pass over the positions.
+// Block (cb, kc) of the image of Z = [W2 ; Qm] ((O + H) x H); 1024 threads.
+//   every Qm block (and block 0) first forms D2, E2 [O] from partS (fixed-order float64 column sums) or from
+//   `sums` (float64 {S1[O], S2[O], global count, world}: SyncBatchNorm, already all-reduced);
+//   block 0 also writes d2e2, dgamma2, dbeta2 and evec = E2 W2.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void wide_bwd_mid_kernel(const float *__restrict__ partS, int rows,
+                                                            const double *__restrict__ sums, int H, int O, int ct,
+                                                            const float *__restrict__ pack2, double count,
+                                                            int training, const float *__restrict__ w2,
+                                                            float *__restrict__ d2e2, float *__restrict__ g_gamma2,
+                                                            float *__restrict__ g_beta2, float *__restrict__ evec,
+                                                            uint4 *__restrict__ zimg) {
+    extern __shared__ double dsm[];
+    double *red = dsm;                                            // [16][64]
+    float *de = reinterpret_cast<float *>(dsm + 16 * 64);         // D2[O], E2[O]
+    float *qt = de + 2 * O;                                       // [32][32 ct + 1]
+    const int nkc = (O + H) / 32;
+    const int cb = blockIdx.x / nkc, kc = blockIdx.x % nkc;
+    const bool qm_rows = kc >= O / 32;
+    const int t = threadIdx.x;
+    if (qm_rows || blockIdx.x == 0) {
+        double gscale = 1.0;
+        if (sums) { count = sums[2 * O]; gscale = 1.0 / sums[2 * O + 1]; }
+        const int tx = t & 63, ty = t >> 6;                       // 64 columns x 16 row groups
+        for (int c0 = 0; c0 < 2 * O; c0 += 64) {
+            const int c = c0 + tx;                                // column of partS: S1 | S2
+            double s = 0.0;
+            if (!sums) {
+                int r = ty;
+                for (; r + 48 < rows; r += 64) {
+                    const float v0 = partS[(size_t)r * 2 * O + c], v1 = partS[(size_t)(r + 16) * 2 * O + c];
+                    const float v2 = partS[(size_t)(r + 32) * 2 * O + c], v3 = partS[(size_t)(r + 48) * 2 * O + c];
+                    s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+                }
+                for (; r < rows; r += 16) s += (double)partS[(size_t)r * 2 * O + c];
+            }
+            __syncthreads();
+            red[ty * 64 + tx] = s;
+            __syncthreads();
+            if (ty == 0) {                                       // qt is free here: it holds S1 | S2 as [2 O] float64
+                double tot = 0.0;
+                if (sums) tot = sums[c];
+                else
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) tot += red[g * 64 + tx];
+                reinterpret_cast<double *>(qt)[c] = tot;
+            }
+        }
+        __syncthreads();
+        const double *S = reinterpret_cast<const double *>(qt);
+        double dv = 0.0, ev = 0.0, s1 = 0.0, s2 = 0.0;
+        if (t < O) {
+            s1 = S[t]; s2 = S[O + t];
+            const double sc = pack2[t], mu = pack2[2 * O + t], iv = pack2[3 * O + t];
+            if (training) {
+                dv = -sc * iv * s2 / count;
+                ev = -sc * s1 / count + sc * mu * iv * s2 / count;
+            }
+        }
+        __syncthreads();                                          // everyone has read S before qt is reused
+        if (t < O) {
+            de[t] = (float)dv;
+            de[O + t] = (float)ev;
+            if (blockIdx.x == 0) {
+                d2e2[t] = (float)dv;
+                d2e2[O + t] = (float)ev;
+                if (g_gamma2) g_gamma2[t] = (float)(s2 * gscale);
+                if (g_beta2) g_beta2[t] = (float)(s1 * gscale);
+            }
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && t < H) {
+            float e = 0.0f;
+            for (int c = 0; c < O; ++c) e = __builtin_fmaf(de[O + c], w2[(size_t)c * H + t], e);
+            evec[t] = e;
+        }
+    }
+    const int words = ct * 256;                                   // [j][s][part][lane] of this chunk
+    uint4 *__restrict__ dst = zimg + (size_t)blockIdx.x * words;
+    if (!qm_rows) {
+        if (t < words) {
+            const int lane = t & 63, part = (t >> 6) & 1, s = (t >> 7) & 1, j = t >> 8;
+            const int col = (cb * ct + j) * 32 + (lane & 31), k0 = kc * 32 + s * 16 + (lane >> 5) * 8;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = w2[(size_t)(k0 + e) * H + col];
+                const __bf16 hi = (__bf16)v;
+                o[e] = part == 0 ? hi : (__bf16)(v - (float)hi);
+            }
+            dst[t] = __builtin_bit_cast(uint4, o);
+        }
+        return;
+    }
+    // Qm tile: rows k' = kq0 + (t >> 5), columns mid0 + 32 j + (t & 31)
+    const int kq = (kc - O / 32) * 32 + (t >> 5), r = t & 31, mid0 = cb * ct * 32;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c = 0; c < O; ++c) {
+        const float a = w2[(size_t)c * H + kq] * de[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < ct) acc[j] = __builtin_fmaf(a, w2[(size_t)c * H + mid0 + 32 * j + r], acc[j]);
+    }
+    const int ldq = 32 * ct + 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < ct) qt[(t >> 5) * ldq + 32 * j + r] = acc[j];
+    __syncthreads();
+    if (t < words) {
+        const int lane = t & 63, part = (t >> 6) & 1, s = (t >> 7) & 1, j = t >> 8;
+        const int col = j * 32 + (lane & 31), k0 = s * 16 + (lane >> 5) * 8;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = qt[(k0 + e) * ldq + col];
+            const __bf16 hi = (__bf16)v;
+            o[e] = part == 0 ? hi : (__bf16)(v - (float)hi);
+        }
+        dst[t] = __builtin_bit_cast(uint4, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, after the passes over the positions.  R (float64): [(O + H) H] = [R_S ; Gram], then suma[H].
+//   block 0 (first): BatchNorm-1 backward constants from partT (or `sums`): cabc = {ca, cb, cc}[H], dgamma1, dbeta1
+//   every block: 256 elements of dL/dW2[c][mid] = R_S + D2[c] (W2[c] . Gram[:, mid]) + E2[c] suma[mid]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wide_bwd_fin_kernel(const float *__restrict__ partT, int rows,
+                                                           const double *__restrict__ sums, int H, int O,
+                                                           const float *__restrict__ pack1, double count, int training,
+                                                           float *__restrict__ cabc, float *__restrict__ g_gamma1,
+                                                           float *__restrict__ g_beta1, const double *__restrict__ R,
+                                                           const float *__restrict__ d2e2,
+                                                           const float *__restrict__ w2, float *__restrict__ g_w2) {
+    __shared__ double red[4][64];
+    if (blockIdx.x == 0) {
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+        double gscale = 1.0;
+        if (sums) { count = sums[2 * H]; gscale = 1.0 / sums[2 * H + 1]; }
+        for (int c0 = 0; c0 < H; c0 += 64) {
+            const int c = c0 + tx;
+            double tsum[2];
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                double s = 0.0;
+                if (!sums && c < H) {
+                    int r = ty;
+                    for (; r + 28 < rows; r += 32) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = partT[(size_t)(r + 4 * u) * 2 * H + which * H + c];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) s += (double)v[u];
+                    }
+                    for (; r < rows; r += 4) s += (double)partT[(size_t)r * 2 * H + which * H + c];
+                }
+                __syncthreads();
+                red[ty][tx] = s;
+                __syncthreads();
+                tsum[which] = sums ? (c < H ? sums[which * H + c] : 0.0)
+                                   : (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+            }
+            if (ty == 0 && c < H) {
+                const double sc = pack1[c];
+                cabc[c] = (float)sc;
+                cabc[H + c] = training ? (float)(-sc * tsum[1] / count) : 0.0f;
+                cabc[2 * H + c] = training ? (float)(-sc * tsum[0] / count) : 0.0f;
+                if (g_gamma1) g_gamma1[c] = (float)(tsum[1] * gscale);
+                if (g_beta1) g_beta1[c] = (float)(tsum[0] * gscale);
+            }
+        }
+    }
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= O * H) return;
+    const int c = e / H, mid = e - c * H;
+    const double *__restrict__ gram = R + (size_t)O * H;
+    double acc = 0.0;
+    for (int k = 0; k < H; ++k) acc += (double)w2[(size_t)c * H + k] * gram[(size_t)k * H + mid];
+    g_w2[e] = (float)(R[e] + (double)d2e2[c] * acc + (double)d2e2[O + c] * R[(size_t)(O + H) * H + mid]);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-point gradients.  Block = 64 consecutive points (+ its share of the queries), 256 threads.
+//   1. G[pt][h] = ca sum_{rows of pt} GU[row][h] + cb inv1 (occ (U - mean1) - SP . W1p[h] / r) + cc occ   -> LDS
+//      (rows: the index stage's inverse map pcnt / poff / plist, ascending: a fixed order)
+//   2. dL/df[b][c][n] = sum_h G W1f[h][c];  dL/dp[pt][d] = sum_h G W1p[h][d] / r
+//   3. this block's share of dL/dW1[h][c'] = sum_pt G[pt][h] X[c'][pt], X = [p / r ; f] (LDS), minus its
+//      queries' Hq[q][h] new_p[q][d] / r in the coordinate columns;  Hq = ca HA + cb HB + 32 cc;
+//      dL/dnew_p[q][d] = -sum_h Hq W1p[h][d] / r
+//   Wpart[block][H (C + 3)]: summed over blocks by wide_colsum (fixed order).
+// ------------------------------------------------------------------------------------------
+struct PointGradArgs {
+    int B, C, N, M, qpb;                 // qpb: queries per block
+    const float *GU;                     // (rows, H) dL/da1-side sums per row (sa_wide.hip: wide_bwd_main)
+    const int *pcnt, *poff, *plist;
+    const float *geo;                    // (B N, 4)
+    const float *U, *f, *p, *new_p;
+    const float *HA, *HB;                // (B M, H)
+    const float *cabc, *pack1, *w1;
+    float inv_r;
+    float *g_f, *g_p, *g_q, *Wpart;      // g_p / g_q may be null
+};
+
+template <int HPW>
+__global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) {
+    constexpr int H = 4 * HPW;
+    extern __shared__ float sm[];
+    const int C = a.C, ldw = C + 3;
+    float *Gs = sm;                                  // [64][H + 1]
+    float *Xs = sm + 64 * (H + 1);                   // [C + 3][65]
+    const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long npts = (long long)a.B * a.N;
+    const long long pt = (long long)blockIdx.x * 64 + tx;
+    const bool ok = pt < npts;
+    const long long ptc = ok ? pt : npts - 1;
+    const int b = (int)(ptc / a.N), n = (int)(ptc % a.N);
+    {   // 1.
+        const int h0 = ty * HPW;
+        float acc[HPW];
+#pragma unroll
+        for (int v = 0; v < HPW; ++v) acc[v] = 0.0f;
+        const int cnt = ok ? a.pcnt[ptc] : 0;
+        const int *__restrict__ l = a.plist + a.poff[ptc];
+        for (int i = 0; i < cnt; ++i) {
+            const float4 *__restrict__ g = reinterpret_cast<const float4 *>(a.GU + (size_t)l[i] * H + h0);
+#pragma unroll
+            for (int v = 0; v < HPW / 4; ++v) {
+                const float4 x = g[v];
+                acc[4 * v] += x.x; acc[4 * v + 1] += x.y; acc[4 * v + 2] += x.z; acc[4 * v + 3] += x.w;
+            }
+        }
+        const float4 ge = *reinterpret_cast<const float4 *>(a.geo + ptc * 4);
+        const float *__restrict__ ur = a.U + ptc * H + h0;
+#pragma unroll
+        for (int v = 0; v < HPW; ++v) {
+            const int h = h0 + v;
+            const float *__restrict__ wr = a.w1 + (size_t)h * ldw;
+            const float spw = __builtin_fmaf(ge.w, wr[2], __builtin_fmaf(ge.z, wr[1], ge.y * wr[0]));
+            const float yh = a.pack1[3 * H + h] * (ge.x * (ur[v] - a.pack1[2 * H + h]) - spw * a.inv_r);
+            const float G = __builtin_fmaf(a.cabc[h], acc[v], __builtin_fmaf(a.cabc[H + h], yh, a.cabc[2 * H + h] * ge.x));
+            Gs[tx * (H + 1) + h] = ok ? G : 0.0f;
+        }
+    }
+    // X tile: coordinates / r in rows 0..2, features in rows 3..; zero columns past the end
+    for (int cc = ty; cc < ldw; cc += 4) {
+        float v = 0.0f;
+        if (ok) v = cc < 3 ? a.p[ptc * 3 + cc] * a.inv_r : a.f[((size_t)b * C + (cc - 3)) * a.N + n];
+        Xs[cc * 65 + tx] = v;
+    }
+    __syncthreads();
+    // 2. wave ty: channels c = ty, ty + 4, ... in groups of 8 (weights wave-uniform)
+    {
+        const int cpw = (C + 3) / 4;                              // channels per wave (ceil)
+        const int cbeg = ty * cpw, cend = min(C, cbeg + cpw);
+        for (int c0 = cbeg; c0 < cend; c0 += 8) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < H; ++h) {
+                const float g = Gs[tx * (H + 1) + h];
+                const float *__restrict__ wr = a.w1 + (size_t)h * ldw + 3 + c0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(g, c0 + j < cend ? wr[j] : 0.0f, acc[j]);
+            }
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c0 + j < cend) a.g_f[((size_t)b * C + c0 + j) * a.N + n] = acc[j];
+            }
+        }
+        if (a.g_p && ty < 3) {
+            float acc = 0.0f;
+            for (int h = 0; h < H; ++h) acc = __builtin_fmaf(Gs[tx * (H + 1) + h], a.w1[(size_t)h * ldw + ty], acc);
+            if (ok) a.g_p[ptc * 3 + ty] = acc * a.inv_r;
+        }
+    }
+    // 3. 4 x 4 register tiles of dW[h][c'] over the 64 points
+    float *__restrict__ wrow = a.Wpart + (size_t)blockIdx.x * H * ldw;
+    const int tcols = (ldw + 3) / 4, ntile = (H / 4) * tcols;
+    for (int tile = threadIdx.x; tile < ntile; tile += 256) {
+        const int hq = tile / tcols, cq = tile - hq * tcols;        // columns cq, cq + tcols, ... (lanes: consecutive)
+        const int hb = hq * 4;
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+        for (int q = 0; q < 64; ++q) {
+            float g[4], x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = Gs[q * (H + 1) + hb + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = cq + j * tcols < ldw ? Xs[(cq + j * tcols) * 65 + q] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(g[i], x[j], acc[i][j]);
+        }
+        if (cq < 3) {
+            // coordinate column d = cq: minus this block's queries' Hq[q][h] new_p[q][d] / r
+            const long long nqry = (long long)a.B * a.M;
+            const long long q0 = (long long)blockIdx.x * a.qpb, q1 = min(nqry, q0 + a.qpb);
+            for (long long q = q0; q < q1; ++q) {
+                const float xd = a.new_p[q * 3 + cq] * a.inv_r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int h = hb + i;
+                    const float hq_ = __builtin_fmaf(a.cabc[h], a.HA[q * H + h],
+                                                     __builtin_fmaf(a.cabc[H + h], a.HB[q * H + h], 32.0f * a.cabc[2 * H + h]));
+                    acc[i][0] = __builtin_fmaf(-hq_, xd, acc[i][0]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (cq + j * tcols < ldw) wrow[(size_t)(hb + i) * ldw + cq + j * tcols] = acc[i][j];
+    }
+    if (a.g_q) {
+        const long long nqry = (long long)a.B * a.M;
+        const long long q0 = (long long)blockIdx.x * a.qpb, q1 = min(nqry, q0 + a.qpb);
+        for (long long e = q0 * 3 + threadIdx.x; e < q1 * 3; e += 256) {
+            const long long q = e / 3;
+            const int d = (int)(e - q * 3);
+            float acc = 0.0f;
+            for (int h = 0; h < H; ++h) {
+                const float hq_ = __builtin_fmaf(a.cabc[h], a.HA[q * H + h],
+                                                 __builtin_fmaf(a.cabc[H + h], a.HB[q * H + h], 32.0f * a.cabc[2 * H + h]));
+                acc = __builtin_fmaf(hq_, a.w1[(size_t)h * ldw + d], acc);
+            }
+            a.g_q[e] = -acc * a.inv_r;
+        }
+    }
+}
+
+// column sums like wide_colsum (sa_wide.hip), one level, float32 result: out[c] = sum_r part[r][c] in float64
+__global__ __launch_bounds__(256) void wide_colsum_f32_kernel(const float *__restrict__ part, int rows, int ncol,
+                                                              float *__restrict__ out) {
+    __shared__ double red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < ncol) {
+        int r = g;
+        for (; r + 12 < rows; r += 16) {
+            const float v0 = part[(size_t)r * ncol + c], v1 = part[(size_t)(r + 4) * ncol + c];
+            const float v2 = part[(size_t)(r + 8) * ncol + c], v3 = part[(size_t)(r + 12) * ncol + c];
+            s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+        }
+        for (; r < rows; r += 4) s0 += (double)part[(size_t)r * ncol + c];
+    }
+    red[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && c < ncol)
+        out[c] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+static bool dense_shape_ok(int H, int O) {
+    return (H == 32 || H == 64 || H == 128 || H == 256) && O == 2 * H;
+}
+
+}  // namespace apn
+
+using namespace apn;
+
+#define APN_DENSE_DISPATCH(H_, ...)                              \
+    switch (H_) {                                                \
+    case 32: { constexpr int HPW = 8; __VA_ARGS__; } break;      \
+    case 64: { constexpr int HPW = 16; __VA_ARGS__; } break;     \
+    case 128: { constexpr int HPW = 32; __VA_ARGS__; } break;    \
+    case 256: { constexpr int HPW = 64; __VA_ARGS__; } break;    \
+    default: return APN_EINVAL;                                  \
+    }
+
+extern "C" int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, int c_out, float radius, const float *f,
+                                    const float *p, const float *new_p, const float *w1, const float *w2, float *U,
+                                    float *V, void *w2_image, void *stream) {
+    if (b <= 0 || c_in <= 0 || n <= 0 || m <= 0 || !dense_shape_ok(c_mid, c_out) || !(radius > 0.0f) || !f || !p ||
+        !new_p || !w1 || !w2 || !U || !V || !w2_image)
+        return APN_EINVAL;
+    const long long pb = ((long long)b * n + 63) / 64, qb = ((long long)b * m * c_mid + 255) / 256;
+    const int ct = c_out / 32 >= 4 ? 4 : c_out / 32;
+    const long long ib = (c_out / 32) * (c_mid / 32);          // 256 words per (column tile, k chunk)
+    if (pb + qb + ib > 0x7fffffffLL) return APN_EINVAL;
+    APN_DENSE_DISPATCH(c_mid, {
+        const size_t lds = (size_t)64 * (4 * HPW + 1) * sizeof(float);
+        if (lds > 48 * 1024) {
+            if (hipError_t e = hipFuncSetAttribute((const void *)wide_fwd_prep_kernel<HPW>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+                return (int)e;
+        }
+        hipLaunchKernelGGL((wide_fwd_prep_kernel<HPW>), dim3((unsigned)(pb + qb + ib)), dim3(256), lds,
+                           (hipStream_t)stream, b, c_in, n, m, (int)pb, (int)qb, f, p, new_p, w1, 1.0f / radius, U, V,
+                           w2, c_out, ct, (uint4 *)w2_image);
+    });
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, float *out,
+                               void *stream) {
+    if (b <= 0 || m <= 0 || b > 65535 || c_out <= 0 || (c_out % 64) || !ysel || !pack2 || !out) return APN_EINVAL;
+    hipLaunchKernelGGL(wide_out_kernel, dim3((m + 63) / 64, c_out / 64, b), dim3(256), 0, (hipStream_t)stream, m, c_out,
+                       ysel, pack2, out);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_wide_bwd_mid(const float *part_s, int rows, const double *sums, int c_mid, int c_out,
+                                   const float *pack2, double count, int training, const float *w2, float *d2e2,
+                                   float *g_gamma2, float *g_beta2, float *evec, void *z_image, void *stream) {
+    if ((!part_s && !sums) || rows < 0 || !dense_shape_ok(c_mid, c_out) || !pack2 || !w2 || !d2e2 || !evec || !z_image)
+        return APN_EINVAL;
+    const int ct = c_mid / 32 >= 4 ? 4 : c_mid / 32;
+    const int blocks = ((c_out + c_mid) / 32) * (c_mid / (32 * ct));
+    size_t tail = (size_t)32 * (32 * ct + 1) * sizeof(float);
+    if (tail < (size_t)2 * c_out * sizeof(double)) tail = (size_t)2 * c_out * sizeof(double);   // S1|S2 staged in qt
+    const size_t lds = (size_t)16 * 64 * sizeof(double) + (size_t)2 * c_out * sizeof(float) + tail + 8;
+    hipLaunchKernelGGL(wide_bwd_mid_kernel, dim3(blocks), dim3(1024), lds, (hipStream_t)stream, part_s, rows, sums, c_mid,
+                       c_out, ct, pack2, count, training, w2, d2e2, g_gamma2, g_beta2, evec, (uint4 *)z_image);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_wide_bwd_fin(const float *part_t, int rows, const double *sums, int c_mid, int c_out,
+                                   const float *pack1, double count, int training, float *cabc, float *g_gamma1,
+                                   float *g_beta1, const double *R, const float *d2e2, const float *w2, float *g_w2,
+                                   void *stream) {
+    if ((!part_t && !sums) || rows < 0 || !dense_shape_ok(c_mid, c_out) || !pack1 || !cabc || !R || !d2e2 || !w2 || !g_w2)
+        return APN_EINVAL;
+    hipLaunchKernelGGL(wide_bwd_fin_kernel, dim3((c_out * c_mid + 255) / 256), dim3(256), 0, (hipStream_t)stream, part_t,
+                       rows, sums, c_mid, c_out, pack1, count, training, cabc, g_gamma1, g_beta1, R, d2e2, w2, g_w2);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_wide_point_grads_rows(int b, int n) {
+    if (b <= 0 || n <= 0) return 0;
+    return (int)(((long long)b * n + 63) / 64);
+}
+
+extern "C" int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid, float radius, const float *GU,
+                                       const int *pcnt_poff, const int *plist, const float *geo, const float *U,
+                                       const float *f, const float *p, const float *new_p, const float *HA,
+                                       const float *HB, const float *cabc, const float *pack1, const float *w1,
+                                       float *g_f, float *g_p, float *g_q, float *w_part, void *stream) {
+    if (b <= 0 || c_in <= 0 || n <= 0 || m <= 0 || !dense_shape_ok(c_mid, 2 * c_mid) || !(radius > 0.0f) || !GU ||
+        !pcnt_poff || !plist || !geo || !U || !f || !p || !new_p || !HA || !HB || !cabc || !pack1 || !w1 || !g_f || !w_part)
+        return APN_EINVAL;
+    const long long npts = (long long)b * n, nqry = (long long)b * m;
+    const long long blocks = (npts + 63) / 64;
+    if (blocks > 0x7fffffffLL) return APN_EINVAL;
+    PointGradArgs a;
+    a.B = b; a.C = c_in; a.N = n; a.M = m;
+    a.qpb = (int)((nqry + blocks - 1) / blocks);
+    a.GU = GU; a.pcnt = pcnt_poff; a.poff = pcnt_poff + npts; a.plist = plist; a.geo = geo;
+    a.U = U; a.f = f; a.p = p; a.new_p = new_p; a.HA = HA; a.HB = HB;
+    a.cabc = cabc; a.pack1 = pack1; a.w1 = w1; a.inv_r = 1.0f / radius;
+    a.g_f = g_f; a.g_p = g_p; a.g_q = g_q; a.Wpart = w_part;
+    APN_DENSE_DISPATCH(c_mid, {
+        const size_t lds = ((size_t)64 * (4 * HPW + 1) + (size_t)(c_in + 3) * 65) * sizeof(float);
+        if (lds > 160 * 1024) return APN_EINVAL;
+        if (lds > 48 * 1024) {
+            if (hipError_t e = hipFuncSetAttribute((const void *)wide_point_grads_kernel<HPW>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+                return (int)e;
+        }
+        hipLaunchKernelGGL((wide_point_grads_kernel<HPW>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+    });
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_wide_colsum_f32(const float *part, int rows, int ncol, float *out, void *stream) {
+    if (rows < 0 || ncol <= 0 || !part || !out) return APN_EINVAL;
+    hipLaunchKernelGGL(wide_colsum_f32_kernel, dim3((ncol + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, rows, ncol,
+                       out);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}

@@ -410,6 +410,98 @@ __global__ __launch_bounds__(256) void tilemap_fill_kernel(int nq, int m, const 
     if (starts && lane == 0) tq0[tile] = q;
 }
 
+// ------------------------------------------------------------------------------------------
+// Inverse map (index stage too): for every support point the rows that gather it, so that the backward
+// pass sums dL/dU per point in a FIXED order with plain loads instead of float atomics:
+//   pcnt[b n]  rows that gather point n;  poff[b n]  where its list starts in plist;
+//   plist      row ids (tile * 32 + row), ascending within a point's list;
+//   geo[b n]   {sum of mult, sum of mult * new_xyz[query]} over the list (what BatchNorm-1's mean term needs).
+// Counting sort: count (integer atomics: the counts do not depend on the order), scan per cloud, fill
+// (order left to the atomics), then every list is sorted -- the result is a pure function of idx.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ const int *tm_toff(const int *tmap, int nq, int b) {
+    return tmap + 4 + ((nq + 3) & ~3) + (size_t)32 * nq + b;
+}
+
+__global__ __launch_bounds__(256) void csr_zero_kernel(long long n4, int4 *__restrict__ dst) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e < n4) dst[e] = make_int4(0, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void csr_count_fill_kernel(int nq, int n, int m, int fill,
+                                                             const int *__restrict__ idx,
+                                                             const int *__restrict__ tmap, int *__restrict__ pcnt,
+                                                             int *__restrict__ poff, int *__restrict__ plist) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;       // row id
+    const int tile = (int)(e >> 5);
+    if (tile >= tmap[0]) return;
+    const unsigned info = reinterpret_cast<const unsigned *>(tmap + 4 + ((nq + 3) & ~3))[e];
+    if (((info >> 16) & 0xffu) == 0) return;
+    const int q = tmap[4 + tile] + (int)(info & 0xffu);
+    const size_t gn = (size_t)(q / m) * n + idx[(size_t)q * 32 + ((info >> 8) & 0xffu)];
+    if (!fill) atomicAdd(pcnt + gn, 1);
+    else plist[atomicAdd(poff + gn, 1)] = (int)e;
+}
+
+// one block per cloud: poff = (first row id of the cloud) + exclusive scan of pcnt
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int nq, int b, int n, const int *__restrict__ tmap,
+                                                        const int *__restrict__ pcnt, int *__restrict__ poff) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x, cloud = blockIdx.x, per = (n + 1023) / 1024;
+    const int *__restrict__ cnt = pcnt + (size_t)cloud * n;
+    int s = 0;
+    for (int i = 0; i < per; ++i) {
+        const int k = t * per + i;
+        if (k < n) s += cnt[k];
+    }
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = tm_toff(tmap, nq, b)[cloud] * 32 + part[t] - s;
+    for (int i = 0; i < per; ++i) {
+        const int k = t * per + i;
+        if (k < n) { poff[(size_t)cloud * n + k] = run; run += cnt[k]; }
+    }
+}
+
+// one thread per point: sort its list (after the fill poff is the list's END), restore poff, sum geo
+__global__ __launch_bounds__(256) void csr_sort_geo_kernel(int nq, long long npts, const int *__restrict__ tmap,
+                                                           const int *__restrict__ pcnt, int *__restrict__ poff,
+                                                           int *__restrict__ plist, const float *__restrict__ new_xyz,
+                                                           float *__restrict__ geo) {
+    const long long gn = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gn >= npts) return;
+    const int c = pcnt[gn], start = poff[gn] - c;
+    poff[gn] = start;
+    int *__restrict__ l = plist + start;
+    for (int gap = c < 14 ? 1 : (c < 41 ? 4 : (c < 122 ? 13 : (c < 365 ? 40 : 121))); gap > 0; gap = gap == 1 ? 0 : (gap - 1) / 3) {
+        for (int i = gap; i < c; ++i) {                     // Shell sort, gaps 121, 40, 13, 4, 1
+            const int v = l[i];
+            int j = i;
+            for (; j >= gap && l[j - gap] > v; j -= gap) l[j] = l[j - gap];
+            l[j] = v;
+        }
+    }
+    const unsigned *__restrict__ rows = reinterpret_cast<const unsigned *>(tmap + 4 + ((nq + 3) & ~3));
+    float occ = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    for (int i = 0; i < c; ++i) {
+        const int e = l[i];
+        const unsigned info = rows[e];
+        const float mult = (float)((info >> 16) & 0xffu);
+        const float *__restrict__ q = new_xyz + (size_t)(tmap[4 + (e >> 5)] + (int)(info & 0xffu)) * 3;
+        occ += mult;
+        sx = __builtin_fmaf(mult, q[0], sx);
+        sy = __builtin_fmaf(mult, q[1], sy);
+        sz = __builtin_fmaf(mult, q[2], sz);
+    }
+    *reinterpret_cast<float4 *>(geo + gn * 4) = make_float4(occ, sx, sy, sz);
+}
+
 }  // namespace apn
 
 // The map is ONE int32 blob (BM = b * m, BM4 = BM rounded up to 4):
@@ -439,6 +531,29 @@ extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *
     hipLaunchKernelGGL(apn::tilemap_scan_kernel, dim3(1), dim3(1024), 0, st, b, tcount, toff, tmap);
     hipLaunchKernelGGL(apn::tilemap_fill_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, nq, m, cnt8, qmeta, toff,
                        tnq_local, tq0, rowinfo);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+// pcnt_poff: int32[2 b n] (counts, then list starts); plist: int32[32 b m]; geo: float[4 b n].
+extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *new_xyz, const int *tmap,
+                               int *pcnt_poff, int *plist, float *geo, void *stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || b > 65535 || (long long)b * m > 0x7fffffffLL / 64 ||
+        (long long)b * n > 0x7fffffffLL / 8 || !idx || !new_xyz || !tmap || !pcnt_poff || !plist || !geo)
+        return APN_EINVAL;
+    const int nq = b * m;
+    const long long npts = (long long)b * n;
+    int *pcnt = pcnt_poff, *poff = pcnt_poff + npts;
+    hipStream_t st = (hipStream_t)stream;
+    // (a kernel, not hipMemsetAsync: the whole index stage must replay from a captured hipGraph)
+    const long long n4 = (npts + 3) / 4;                 // pcnt is followed by poff: rounding up stays inside
+    hipLaunchKernelGGL(apn::csr_zero_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, n4, (int4 *)pcnt);
+    const unsigned rb = (unsigned)(((long long)nq * 32 + 255) / 256);
+    hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 0, idx, tmap, pcnt, poff, plist);
+    hipLaunchKernelGGL(apn::csr_scan_kernel, dim3(b), dim3(1024), 0, st, nq, b, n, tmap, pcnt, poff);
+    hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 1, idx, tmap, pcnt, poff, plist);
+    hipLaunchKernelGGL(apn::csr_sort_geo_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, nq, npts, tmap,
+                       pcnt, poff, plist, new_xyz, geo);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

@@ -37,6 +37,7 @@ def supported(p, f, idx_or_k, conv1, conv2, bns=()):
             and H in WIDTHS and O == 2 * H and conv1.weight.shape[1] == f.shape[1] + 3
             and conv2.weight.shape[1] == H and conv1.bias is None and conv2.bias is None
             and p.shape[0] * (idx_or_k.shape[1] if torch.is_tensor(idx_or_k) else 1) < 2 ** 24
+            and (64 * (H + 1) + (f.shape[1] + 3) * 65) * 4 <= 160 * 1024        # LDS of the per-point gradient kernel
             and all(bn.momentum is not None for bn in bns))
 
 
@@ -96,16 +97,43 @@ def _image(src0, k0, trans0, src1, kd, nc, ct):
     return img
 
 
+class NeighbourIndex:
+    """What the fused passes need to know about the neighbour indices idx (B,M,32) beyond idx itself -- all of
+    it a function of the coordinates only, so it belongs to the INDEX stage and can be built once per batch,
+    off the feature stream (`neighbour_index`, `Sampling.index`, `index_pyramid`):
+      tmap       distinct-hit tile map (csrc/sa_wide_glue.hip): rows = (query, distinct slot, multiplicity)
+                 packed 32 to an MFMA tile;
+      pcnt_poff  inverse map: per support point the number of rows that gather it and where its list starts;
+      plist      the lists (row ids, ascending);   geo (B,N,4): occurrences, sum of the gathering queries' coordinates.
+    """
+    __slots__ = ("idx", "tmap", "pcnt_poff", "plist", "geo", "n_points")
+
+    def __init__(self, idx, tmap, pcnt_poff, plist, geo, n_points):
+        self.idx, self.tmap, self.pcnt_poff, self.plist, self.geo, self.n_points = idx, tmap, pcnt_poff, plist, geo, n_points
+
+
 def tile_map(idx, fold=True):
-    """The distinct-hit tile map of neighbour indices idx (B,M,32) (csrc/sa_wide_glue.hip): an int32 device
-    blob the four position kernels read.  It depends on idx alone, so it belongs to the index stage and can
-    be built once per batch, off the feature stream (`Sampling.tmap`, `index_pyramid`).  fold=False: one
-    32-row tile per query (no use made of the ball-query structure)."""
+    """The tile map alone (see NeighbourIndex).  fold=False: one 32-row tile per query (no use made of the
+    ball-query structure)."""
     B, M, K = idx.shape
     assert K == K_NS and idx.dtype == torch.int32 and idx.is_contiguous()
     tmap = torch.empty(_lib.load().apn_sa_wide_tilemap_ints(B, M), dtype=torch.int32, device=idx.device)
     _call("apn_sa_wide_tilemap", idx.device, B, M, 1 if fold else 0, idx.data_ptr(), tmap.data_ptr())
     return tmap
+
+
+def neighbour_index(idx, new_p, n_points, fold=True):
+    """Build the NeighbourIndex of idx (B,M,32) over n_points support points; new_p (B,M,3): the queries."""
+    idx, new_p = idx.contiguous(), new_p.contiguous()
+    B, M, _ = idx.shape
+    dev = idx.device
+    tmap = tile_map(idx, fold)
+    pcnt_poff = torch.empty(2 * B * n_points, dtype=torch.int32, device=dev)
+    plist = torch.empty(32 * B * M, dtype=torch.int32, device=dev)
+    geo = torch.empty(B, n_points, 4, dtype=torch.float32, device=dev)
+    _call("apn_sa_wide_csr", dev, B, n_points, M, idx.data_ptr(), new_p.data_ptr(), tmap.data_ptr(),
+          pcnt_poff.data_ptr(), plist.data_ptr(), geo.data_ptr())
+    return NeighbourIndex(idx, tmap, pcnt_poff, plist, geo, n_points)
 
 
 def _training(bn):
@@ -114,60 +142,64 @@ def _training(bn):
 
 class _WideMlpMax(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, p, new_p, f, idx, w1, g1, b1, w2, g2, b2, mods):
-        radius, bn1, bn2, sync_bn, tmap = mods
-        p, new_p, f, idx = p.contiguous(), new_p.contiguous(), f.contiguous(), idx.contiguous()
+    def forward(ctx, p, new_p, f, w1, g1, b1, w2, g2, b2, mods):
+        radius, bn1, bn2, sync_bn, nbr = mods
+        p, new_p, f = p.contiguous(), new_p.contiguous(), f.contiguous()
+        idx, tmap = nbr.idx, nbr.tmap
         dev = f.device
         B, C, N = f.shape
         M = new_p.shape[1]
         H, O = w1.shape[0], w2.shape[0]
         sync = sync_bn and (_fz._world(True) > 1 or _fz.FORCE_PHASED)
+        f32 = dict(dtype=torch.float32, device=dev)
         with torch.no_grad():
             W1 = w1.detach().reshape(H, C + 3).contiguous()
-            W1p, W1f = W1[:, :3], W1[:, 3:]
             W2 = w2.detach().reshape(O, H).contiguous()
-            # conv1 at the points: one row per support point, one per query (plain dense products)
-            U = torch.baddbmm(torch.matmul(p, W1p.t()) / radius, f.transpose(1, 2), W1f.t().expand(B, C, H))
-            V = (torch.matmul(new_p, W1p.t()) / radius).contiguous()
-            U = U.contiguous()
+            # conv1 at the points (one row per support point, one per query) and the image of W2^T: one launch
+            U = torch.empty(B, N, H, **f32)
+            V = torch.empty(B, M, H, **f32)
+            ct = min(4, O // 32)
+            w2img = torch.empty(O // (32 * ct), H // 32, ct, 2, 2, 64, 8, dtype=torch.bfloat16, device=dev)
+            _call("apn_sa_wide_fwd_prep", dev, B, C, N, M, H, O, float(radius), f.data_ptr(), p.data_ptr(),
+                  new_p.data_ptr(), W1.data_ptr(), W2.data_ptr(), U.data_ptr(), V.data_ptr(), w2img.data_ptr())
             grid = _lib.load().apn_sa_wide_grid(B, M)
             count = float(B * M * K_NS)
-            if tmap is None:
-                tmap = tile_map(idx)
             tr1, tr2 = _training(bn1), _training(bn2)
             part1 = None
             if tr1:
-                part1 = torch.empty(grid, 2 * H, dtype=torch.float32, device=dev)
+                part1 = torch.empty(grid, 2 * H, **f32)
                 _call("apn_sa_wide_stats1", dev, B, N, M, H, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
                       tmap.data_ptr(), part1.data_ptr())
             pack1, sgn2, _ = _bn_pack(part1, grid, H, count, bn1, dev, tr1, sync, sgn_from=g2, sgn_c=O)
-            w2img = _image(W2, H, True, None, H, O, min(4, O // 32))          # W2^T (H x O)
-            ysel = torch.empty(B, M, O, dtype=torch.float32, device=dev)
+            ysel = torch.empty(B, M, O, **f32)
             ksel = torch.empty(B, M, O, dtype=torch.uint8, device=dev)
-            part2 = torch.empty(grid, 2 * O, dtype=torch.float32, device=dev)
+            part2 = torch.empty(grid, 2 * O, **f32)
             _call("apn_sa_wide_fwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
                   tmap.data_ptr(), w2img.data_ptr(), pack1.data_ptr(), sgn2.data_ptr(), ysel.data_ptr(), ksel.data_ptr(),
                   part2.data_ptr())
             pack2, _, _ = _bn_pack(part2 if tr2 else None, grid, O, count, bn2, dev, tr2, sync)
-            out = torch.addcmul(pack2[O:2 * O], ysel, pack2[:O]).transpose(1, 2).contiguous()
+            out = torch.empty(B, O, M, **f32)
+            _call("apn_sa_wide_out", dev, B, M, O, ysel.data_ptr(), pack2.data_ptr(), out.data_ptr())
             if _DEBUG is not None:
                 _DEBUG.update(U=U, V=V, pack1=pack1, w2img=w2img, ysel=ysel, ksel=ksel, part2=part2, pack2=pack2,
                               sgn2=sgn2)
-        ctx.save_for_backward(p, new_p, f, idx, U, V, pack1, pack2, ysel, ksel, W1, W2, tmap)
+        ctx.save_for_backward(p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2)
+        ctx.nbr = nbr
         ctx.cfg = (radius, tr1, tr2, sync, count, g1 is not None, b1 is not None, g2 is not None, b2 is not None)
         ctx.need = (p.requires_grad, new_p.requires_grad)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        p, new_p, f, idx, U, V, pack1, pack2, ysel, ksel, W1, W2, tmap = ctx.saved_tensors
+        p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2 = ctx.saved_tensors
+        nbr = ctx.nbr
+        idx, tmap = nbr.idx, nbr.tmap
         radius, tr1, tr2, sync, count, a1, a2, a3, a4 = ctx.cfg
         need_p, need_q = ctx.need
         dev = f.device
         B, C, N = f.shape
         M = new_p.shape[1]
         H, O = W1.shape[0], W2.shape[0]
-        W1p, W1f = W1[:, :3], W1[:, 3:]
         lib = _lib.load()
         if g.dtype != torch.float32:
             g = g.float()
@@ -186,60 +218,68 @@ class _WideMlpMax(torch.autograd.Function):
         gs = g.stride()
         _call("apn_sa_wide_bwd_prep", dev, B, M, O, g.data_ptr(), gs[0], gs[1], gs[2], ysel.data_ptr(),
               pack2.data_ptr(), goa.data_ptr(), partS.data_ptr())
-        small = torch.empty(2 * O + O + O + 3 * H + 2 * H, **f32)      # d2e2 | g_gamma2 | g_beta2 | cabc | g_gamma1, g_beta1
-        d2e2, g_gamma2, g_beta2 = small[:2 * O], small[2 * O:3 * O], small[3 * O:4 * O]
-        cabc, g_gamma1, g_beta1 = small[4 * O:4 * O + 3 * H], small[4 * O + 3 * H:4 * O + 4 * H], small[4 * O + 4 * H:]
+        # BatchNorm-2 backward constants, Qm = W2^T diag(D2) W2, evec = E2 W2, image of [W2 ; Qm]: one launch
+        small = torch.empty(2 * O + O + O + H + 3 * H + 2 * H, **f32)
+        o = 0
+        d2e2 = small[o:o + 2 * O]; o += 2 * O
+        g_gamma2 = small[o:o + O]; o += O
+        g_beta2 = small[o:o + O]; o += O
+        evec = small[o:o + H]; o += H
+        cabc = small[o:o + 3 * H]; o += 3 * H
+        g_gamma1 = small[o:o + H]; o += H
+        g_beta1 = small[o:o + H]
+        ctz = min(4, H // 32)
+        zimg = torch.empty(H // (32 * ctz), (O + H) // 32, ctz, 2, 2, 64, 8, dtype=torch.bfloat16, device=dev)
         sS = reduced(partS) if sync else None
-        _call("apn_sa_wide_consts2", dev, None if sync else partS.data_ptr(), prow, _fz._ptr(sS), O, pack2.data_ptr(),
-              count, 1 if tr2 else 0, d2e2.data_ptr(), g_gamma2.data_ptr(), g_beta2.data_ptr())
-        D2, E2 = d2e2[:O], d2e2[O:]
-        Qm = torch.matmul(W2.t() * D2, W2)                                   # W2^T diag(D2) W2  (H,H)
-        evec = torch.mv(W2.t(), E2)
-        zimg = _image(W2, O, False, Qm, O + H, H, min(4, H // 32))          # [W2 ; Qm]  ((O+H) x H)
+        _call("apn_sa_wide_bwd_mid", dev, None if sync else partS.data_ptr(), prow, _fz._ptr(sS), H, O, pack2.data_ptr(),
+              count, 1 if tr2 else 0, W2.data_ptr(), d2e2.data_ptr(), g_gamma2.data_ptr(), g_beta2.data_ptr(),
+              evec.data_ptr(), zimg.data_ptr())
         grid = lib.apn_sa_wide_grid(B, M)
-        A = torch.zeros(B, N, H, **f32)
+        GU = torch.empty(B * M * K_NS, H, **f32)          # one row per tile-map row (upper bound; rows in use written)
         HA = torch.empty(B, M, H, **f32)
         HB = torch.empty(B, M, H, **f32)
         partT = torch.empty(grid, 2 * H, **f32)
         _call("apn_sa_wide_bwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
               tmap.data_ptr(), zimg.data_ptr(), pack1.data_ptr(), evec.data_ptr(), goa.data_ptr(), ksel.data_ptr(),
-              A.data_ptr(), HA.data_ptr(), HB.data_ptr(), partT.data_ptr())
-        # weight-gradient products over the positions
+              GU.data_ptr(), HA.data_ptr(), HB.data_ptr(), partT.data_ptr())
+        # weight-gradient products over the positions: {[S^T ; a1^T] a1, sum a1}, one partial row per split
         rows = O + H
         groups = (rows // 32 + 7) // 8
         splits = max(1, min(512 // groups, (B * M) // 4, (64 << 20) // (rows * H * 4)))
-        Rpart = torch.empty(splits, rows, H, **f32)
-        sumapart = torch.empty(splits, H, **f32)
+        Rpart = torch.empty(splits, rows * H + H, **f32)
         _call("apn_sa_wide_wgrad", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
-              tmap.data_ptr(), pack1.data_ptr(), goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr(),
-              sumapart.data_ptr())
-        R = _colsum(Rpart.view(splits, rows * H)).view(rows, H)
-        suma = _colsum(sumapart)
-        if _DEBUG is not None:
-            _DEBUG.update(goa=goa, zimg=zimg, A=A.clone(), HA=HA.clone(), HB=HB, partT=partT, Rpart=Rpart, R=R,
-                          suma=suma, d2e2=d2e2.clone(), evec=evec)
-        g_w2 = (R[:O] + D2.double()[:, None] * (W2.double() @ R[O:]) + E2.double()[:, None] * suma[None, :]).float()
-        # BatchNorm-1 backward constants, then dL/dU per point (in place over A) and -dL/dV per query (over HA)
+              tmap.data_ptr(), pack1.data_ptr(), goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr())
+        R = _colsum(Rpart)
+        # BatchNorm-1 backward constants and dL/dW2 = R_S + D2 (W2 Gram) + E2 (x) suma: one launch
+        g_w2 = torch.empty(O, H, **f32)
         sT = reduced(partT) if sync else None
-        _call("apn_sa_wide_consts1", dev, None if sync else partT.data_ptr(), grid, _fz._ptr(sT), H,
-              pack1.data_ptr(), count, 1 if tr1 else 0, cabc.data_ptr(), g_gamma1.data_ptr(), g_beta1.data_ptr())
-        geo = torch.zeros(B, N, 4, **f32)
-        _call("apn_sa_wide_geo", dev, B, N, M, idx.data_ptr(), new_p.data_ptr(), geo.data_ptr())
-        _call("apn_sa_wide_point_terms", dev, B, N, M, H, cabc.data_ptr(), pack1.data_ptr(), U.data_ptr(),
-              geo.data_ptr(), W1.data_ptr(), C + 3, float(radius), A.data_ptr(), HA.data_ptr(), HB.data_ptr())
-        G, Hq = A, HA
-        g_f = torch.matmul(G, W1f).transpose(1, 2).contiguous()              # (B,C,N)
-        g_p = torch.matmul(G, W1p) / radius if need_p else None
-        g_q = -torch.matmul(Hq, W1p) / radius if need_q else None
-        g_w1f = torch.einsum('bnh,bcn->hc', G, f)
-        g_w1p = (torch.einsum('bnh,bnd->hd', G, p) - torch.einsum('bmh,bmd->hd', Hq, new_p)) / radius
-        g_w1 = torch.cat([g_w1p, g_w1f], 1).view(H, C + 3, 1, 1)
-        return (g_p, g_q, g_f, None, g_w1, g_gamma1 if a1 else None, g_beta1 if a2 else None,
+        _call("apn_sa_wide_bwd_fin", dev, None if sync else partT.data_ptr(), grid, _fz._ptr(sT), H, O, pack1.data_ptr(),
+              count, 1 if tr1 else 0, cabc.data_ptr(), g_gamma1.data_ptr(), g_beta1.data_ptr(), R.data_ptr(),
+              d2e2.data_ptr(), W2.data_ptr(), g_w2.data_ptr())
+        # per point: dL/dU (rows summed through the inverse map, fixed order), dL/df, dL/dp; per query dL/dnew_p;
+        # the workgroups' shares of dL/dW1
+        wrows = lib.apn_sa_wide_point_grads_rows(B, N)
+        g_f = torch.empty(B, C, N, **f32)
+        g_p = torch.empty(B, N, 3, **f32) if need_p else None
+        g_q = torch.empty(B, M, 3, **f32) if need_q else None
+        Wpart = torch.empty(wrows, H * (C + 3), **f32)
+        _call("apn_sa_wide_point_grads", dev, B, C, N, M, H, float(radius), GU.data_ptr(), nbr.pcnt_poff.data_ptr(),
+              nbr.plist.data_ptr(), nbr.geo.data_ptr(), U.data_ptr(), f.data_ptr(), p.data_ptr(), new_p.data_ptr(),
+              HA.data_ptr(), HB.data_ptr(), cabc.data_ptr(), pack1.data_ptr(), W1.data_ptr(), g_f.data_ptr(),
+              _fz._ptr(g_p), _fz._ptr(g_q), Wpart.data_ptr())
+        g_w1 = torch.empty(H, C + 3, **f32)
+        _call("apn_sa_wide_colsum_f32", dev, Wpart.data_ptr(), wrows, H * (C + 3), g_w1.data_ptr())
+        if _DEBUG is not None:
+            _DEBUG.update(goa=goa, zimg=zimg, GU=GU, HA=HA, HB=HB, partT=partT, Rpart=Rpart, R=R, d2e2=d2e2, evec=evec,
+                          cabc=cabc, Wpart=Wpart)
+        return (g_p, g_q, g_f, g_w1.view(H, C + 3, 1, 1), g_gamma1 if a1 else None, g_beta1 if a2 else None,
                 g_w2.view(O, H, 1, 1), g_gamma2 if a3 else None, g_beta2 if a4 else None, None)
 
 
-def grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2, sync_bn=False, tmap=None):
+def grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2, sync_bn=False, index=None):
     """out (B,O,M) = max_K bn2(conv2(relu(bn1(conv1(cat[(p[idx]-new_p)/r, f[idx]]))))), any PointNeXt-S width.
-    tmap: `tile_map(idx)` built ahead of time (default: built here, on the calling stream)."""
-    return _WideMlpMax.apply(p, new_p, f, idx, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight,
-                             bn2.bias, (float(radius), bn1, bn2, sync_bn, tmap))
+    index: the `NeighbourIndex` of idx built ahead of time (default: built here, on the calling stream)."""
+    if index is None:
+        index = neighbour_index(idx, new_p, p.shape[1])
+    return _WideMlpMax.apply(p, new_p, f, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight,
+                             bn2.bias, (float(radius), bn1, bn2, sync_bn, index))

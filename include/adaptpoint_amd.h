@@ -379,11 +379,12 @@ APN_API int apn_sa_wide_fwd_main(int b, int n, int m, int c_mid, int c_out, cons
                                  const float *sgn2, float *ysel, void *ksel, float *part, void *stream);
 /* dL/da1 = S W2 + a1 Qm + evec (z_image: B image of [W2 ; Qm], (O+H) x H, min(4, H/32) column tiles
  * per block; S[pos,c] = goa[q,c] [ksel[q,c] == pos]), g_u = dL/da1 [a1 > 0]:
- * A (B,N,H) += g_u per gathered point (caller-zeroed, float atomics), HA (B,M,H) = sum_k g_u,
- * HB (B,M,H) = sum_k yhat1, part[grid][2H] = {sum g_u, sum g_u yhat1} */
+ * GU (32 b m, H): row tile * 32 + r = g_u summed over the positions the tile map's row stands for (rows in
+ * use only; no atomics -- apn_sa_wide_point_grads sums them per point through the inverse map),
+ * HA (B,M,H) = sum_k g_u, HB (B,M,H) = sum_k yhat1, part[grid][2H] = {sum g_u, sum g_u yhat1} */
 APN_API int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
                                  const int *idx, const int *tmap, const void *z_image, const float *pack1,
-                                 const float *evec, const float *goa, const void *ksel, float *A,
+                                 const float *evec, const float *goa, const void *ksel, float *GU,
                                  float *HA, float *HB, float *part, void *stream);
 /* The small kernels around those passes (csrc/sa_wide_glue.hip).
  * image: B image of Bm (kd x nc): rows < k0 from src0 (row-major kd x nc, or nc x k0 read transposed when
@@ -412,12 +413,48 @@ APN_API int apn_sa_wide_geo(int b, int n, int m, const int *idx, const float *ne
 APN_API int apn_sa_wide_point_terms(int b, int n, int m, int c_mid, const float *cabc, const float *pack1,
                                     const float *U, const float *geo, const float *w1, int ldw, float radius,
                                     float *A, float *HA, const float *HB, void *stream);
-/* r_part[splits][(O+H)][H] = partial [S^T ; a1^T] a1 (rows < O: the sparse part of dL/dW2; the rest:
- * the Gram matrix of a1), suma_part[splits][H] = partial sum of a1; the caller sums the splits */
+/* r_part[splits][(O+H) H + H] = partial {[S^T ; a1^T] a1 (rows < O: the sparse part of dL/dW2; the rest:
+ * the Gram matrix of a1), sum of a1}; the caller sums the splits (apn_sa_wide_colsum) */
 APN_API int apn_sa_wide_wgrad_splits(int b, int m, int c_mid);
 APN_API int apn_sa_wide_wgrad(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
                               const int *idx, const int *tmap, const float *pack1, const float *goa,
-                              const void *ksel, int splits, float *r_part, float *suma_part, void *stream);
+                              const void *ksel, int splits, float *r_part, void *stream);
+
+/* Inverse map of the tile map (index stage): pcnt_poff int32[2 b n] = for every support point the number of
+ * rows that gather it and where its list starts in plist int32[32 b m] (row ids tile * 32 + r, ascending);
+ * geo float[4 b n] = {occurrences, sum of the gathering queries' coordinates} per point. */
+APN_API int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *new_xyz, const int *tmap,
+                            int *pcnt_poff, int *plist, float *geo, void *stream);
+/* The dense kernels of the path (csrc/sa_wide_dense.hip), one launch each:
+ * fwd_prep: U (B,N,H) = W1f f + W1p p / r, V (B,M,H) = W1p new_p / r (w1: H x (C+3), coordinates first, as the
+ *   reference's cat([dp, fj])), and the B image of W2^T (w2: O x H).
+ * out: out (B,O,M) = ysel (B,M,O) scale2 + shift2 (pack2 = {scale, shift, mean, invstd}[O]).
+ * bwd_mid: from part_s (or `sums`, as consts2): d2e2, dgamma2, dbeta2, evec[H] = E2 W2 and the B image of
+ *   [W2 ; Qm], Qm = W2^T diag(D2) W2.
+ * bwd_fin: from part_t (or `sums`, as consts1): cabc, dgamma1, dbeta1; and g_w2 (O,H) = R_S + D2 (W2 Gram)
+ *   + E2 (x) suma, with R float64[(O+H) H + H] = {R_S ; Gram ; suma} (apn_sa_wide_wgrad's splits summed).
+ * point_grads: G = dL/dU per point (GU rows summed through the inverse map, plus BatchNorm-1's mean/variance
+ *   terms), g_f (B,C,N) = G W1f, g_p (B,N,3) = G W1p / r, g_q (B,M,3) = -Hq W1p / r (either may be NULL),
+ *   w_part[apn_sa_wide_point_grads_rows(b, n)][H (C+3)] = the workgroups' shares of dL/dW1.
+ * colsum_f32: out[ncol] (float32) = column sums (in float64, fixed order) of part[rows][ncol]. */
+APN_API int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, int c_out, float radius, const float *f,
+                                 const float *p, const float *new_p, const float *w1, const float *w2, float *U,
+                                 float *V, void *w2_image, void *stream);
+APN_API int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, float *out, void *stream);
+APN_API int apn_sa_wide_bwd_mid(const float *part_s, int rows, const double *sums, int c_mid, int c_out,
+                                const float *pack2, double count, int training, const float *w2, float *d2e2,
+                                float *g_gamma2, float *g_beta2, float *evec, void *z_image, void *stream);
+APN_API int apn_sa_wide_bwd_fin(const float *part_t, int rows, const double *sums, int c_mid, int c_out,
+                                const float *pack1, double count, int training, float *cabc, float *g_gamma1,
+                                float *g_beta1, const double *R, const float *d2e2, const float *w2, float *g_w2,
+                                void *stream);
+APN_API int apn_sa_wide_point_grads_rows(int b, int n);
+APN_API int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid, float radius, const float *GU,
+                                    const int *pcnt_poff, const int *plist, const float *geo, const float *U,
+                                    const float *f, const float *p, const float *new_p, const float *HA,
+                                    const float *HB, const float *cabc, const float *pack1, const float *w1,
+                                    float *g_f, float *g_p, float *g_q, float *w_part, void *stream);
+APN_API int apn_sa_wide_colsum_f32(const float *part, int rows, int ncol, float *out, void *stream);
 
 /* Tuning / diagnostic entry, NOT part of the reference boundary: apn_furthest_point_sampling
  * with the number of wavefronts that cooperate on one cloud (1, 2, 4, 8 or 16; 0 = the built-in

@@ -6,7 +6,7 @@ import torch
 import golden_inputs as GI
 from adaptpoint_amd import _lib
 from adaptpoint_amd.fused import _call
-from adaptpoint_amd.fused_wide import mfma_b_image, tile_map
+from adaptpoint_amd.fused_wide import mfma_b_image, neighbour_index
 from adaptpoint_amd.layers import ball_query, furthest_point_sample
 
 dev = torch.device("cuda:0")
@@ -55,7 +55,8 @@ for H, N, M, radius, kind in CASES:
     if kind == "random":
         idx = torch.randint(0, N, (B, M, 32), device=dev, dtype=torch.int32, generator=torch.Generator(dev).manual_seed(3))
         idx[:, ::3, 5:] = idx[:, ::3, :1]            # some rows with the fill structure, some with repeats that are not
-    tmap = tile_map(idx, fold=kind != "ball-nofold")
+    nbr = neighbour_index(idx, new_p, N, fold=kind != "ball-nofold")
+    tmap = nbr.tmap
     nt, used = check_map(idx, tmap, kind != "ball-nofold")
     print(f"[{kind}] tiles {nt} of {B * M}, rows {used}", end=" | ")
     g = torch.Generator(dev).manual_seed(0)
@@ -100,20 +101,33 @@ for H, N, M, radius, kind in CASES:
     A_ref = torch.zeros(B, N, H, dtype=torch.float64, device=dev)
     A_ref.scatter_add_(1, idx.long().view(B, M * 32, 1).expand(-1, -1, H), gu.view(B, M * 32, H))
     zimg = mfma_b_image(torch.cat([W2, Qm], 0).contiguous(), min(4, H // 32))
-    A = torch.zeros(B, N, H, device=dev); HA = torch.empty(B, M, H, device=dev); HB = torch.empty(B, M, H, device=dev)
+    GU = torch.full((B * M * 32, H), float("nan"), device=dev); HA = torch.empty(B, M, H, device=dev); HB = torch.empty(B, M, H, device=dev)
     partT = torch.empty(grid, 2 * H, device=dev)
     _call("apn_sa_wide_bwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(), tmap.data_ptr(), zimg.data_ptr(),
-          pack1.data_ptr(), evec.data_ptr(), goa.data_ptr(), ksel.data_ptr(), A.data_ptr(), HA.data_ptr(),
+          pack1.data_ptr(), evec.data_ptr(), goa.data_ptr(), ksel.data_ptr(), GU.data_ptr(), HA.data_ptr(),
           HB.data_ptr(), partT.data_ptr())
+    # the inverse map: every point's list is ascending, and the rows of a point sum to its scatter
+    cnt, off = nbr.pcnt_poff[:B * N].long(), nbr.pcnt_poff[B * N:].long()
+    owner = torch.repeat_interleave(torch.arange(B * N, device=dev), cnt)
+    within = torch.arange(owner.numel(), device=dev) - torch.repeat_interleave(cnt.cumsum(0) - cnt, cnt)
+    lrows = nbr.plist[torch.repeat_interleave(off, cnt) + within].long()
+    same = owner[1:] == owner[:-1]
+    assert bool((lrows[1:][same] > lrows[:-1][same]).all()), "lists not ascending"
+    A = torch.zeros(B * N, H, dtype=torch.float64, device=dev).index_add_(0, owner, GU[lrows].double()).view(B, N, H)
+    occ = torch.zeros(B, N, dtype=torch.float64, device=dev).scatter_add_(1, idx.long().view(B, -1), torch.ones(B, M * 32, dtype=torch.float64, device=dev))
+    sp = torch.zeros(B, N, 3, dtype=torch.float64, device=dev).scatter_add_(
+        1, idx.long().view(B, -1, 1).expand(-1, -1, 3), new_p.double().unsqueeze(2).expand(-1, -1, 32, -1).reshape(B, -1, 3))
+    print(f"geo occ {rel(nbr.geo[..., 0], occ):.1e} sp {rel(nbr.geo[..., 1:], sp):.1e}", end=" ")
     T = partT.double().sum(0)
     print(f"bwd A {rel(A, A_ref):.1e} HA {rel(HA, gu.sum(2)):.1e} HB {rel(HB, yh.sum(2)):.1e} T1 {rel(T[:H], gu.sum((0,1,2))):.1e} "
           f"T2 {rel(T[H:], (gu*yh).sum((0,1,2))):.1e}", end=" | ")
     rows = O + H
     groups = (rows // 32 + 7) // 8
     splits = max(1, min(512 // groups, (B * M) // 4, (16 << 20) // (rows * H * 4)))
-    Rpart = torch.empty(splits, rows, H, device=dev); sp = torch.empty(splits, H, device=dev)
+    Rpart = torch.empty(splits, rows * H + H, device=dev)
     _call("apn_sa_wide_wgrad", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(), tmap.data_ptr(), pack1.data_ptr(),
-          goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr(), sp.data_ptr())
-    R = Rpart.double().sum(0)
+          goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr())
+    R = Rpart.double().sum(0)[:rows * H].view(rows, H)
+    suma = Rpart.double().sum(0)[rows * H:]
     a1f = a1.view(-1, H)
-    print(f"wgrad sparse {rel(R[:O], S.view(-1, O).t() @ a1f):.1e} gram {rel(R[O:], a1f.t() @ a1f):.1e} suma {rel(sp.double().sum(0), a1f.sum(0)):.1e}")
+    print(f"wgrad sparse {rel(R[:O], S.view(-1, O).t() @ a1f):.1e} gram {rel(R[O:], a1f.t() @ a1f):.1e} suma {rel(suma, a1f.sum(0)):.1e}")
