@@ -76,19 +76,19 @@ SIGNATURES = {
     "apn_sa_wide_bwd_main": [_c_int] * 5 + [_c_void_p] * 14,
     "apn_sa_wide_image": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "apn_sa_wide_bwd_prep_rows": [_c_int] * 2,
-    "apn_sa_wide_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] * 5,
+    "apn_sa_wide_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] * 7,
     "apn_sa_wide_consts2": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_double, _c_int] + [_c_void_p] * 4,
     "apn_sa_wide_consts1": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_double, _c_int] + [_c_void_p] * 4,
-    "apn_sa_wide_geo": [_c_int] * 3 + [_c_void_p] * 4,
-    "apn_sa_wide_point_terms": [_c_int] * 4 + [_c_void_p] * 5 + [_c_int, _c_float] + [_c_void_p] * 4,
+    "apn_sa_wide_point_terms": [_c_int] * 4 + [_c_void_p] * 5 + [_c_int, _c_float] + [_c_void_p] * 7,
     "apn_sa_wide_wgrad_splits": [_c_int] * 3,
-    "apn_sa_wide_csr": [_c_int] * 3 + [_c_void_p] * 7,
+    "apn_sa_wide_csr": [_c_int] * 3 + [_c_void_p] * 9,
     "apn_sa_wide_fwd_prep": [_c_int] * 6 + [_c_float] + [_c_void_p] * 9,
-    "apn_sa_wide_out": [_c_int] * 3 + [_c_void_p] * 4,
+    "apn_sa_wide_out": [_c_int] * 3 + [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p] * 4 + [_c_int] + [_c_void_p] * 2,
     "apn_sa_wide_bwd_mid": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_double, _c_int] + [_c_void_p] * 7,
     "apn_sa_wide_bwd_fin": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_double, _c_int] + [_c_void_p] * 8,
     "apn_sa_wide_point_grads_rows": [_c_int] * 2,
-    "apn_sa_wide_point_grads": [_c_int] * 5 + [_c_float] + [_c_void_p] * 18,
+    "apn_sa_wide_point_grads_cols": [_c_int] * 3,
+    "apn_sa_wide_point_grads": [_c_int] * 5 + [_c_float] + [_c_void_p] * 13 + [_c_int] + [_c_void_p] * 9,
     "apn_sa_wide_colsum_f32": [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
     "apn_sa_wide_wgrad": [_c_int] * 5 + [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 2,
     "apn_sa_sample_overlap": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 7,

@@ -105,11 +105,19 @@ __global__ __launch_bounds__(256) void wide_fwd_prep_kernel(int B, int C, int N,
 }
 
 // ------------------------------------------------------------------------------------------
-// out[b][c][q] = ysel[b][q][c] * scale2[c] + shift2[c]: 64 x 64 tiles through LDS.  grid (M/64, O/64, B)
+// out[b][o][q] = act(ysel[b][q][o] * scale2[o] + shift2[o] + skip[b][o][q]): 64 x 64 tiles through LDS,
+// grid (M/64, O/64, B).  skip (optional) = Ws f[b, :, fidx[b, q]] + bs: the block's residual branch, a 1x1
+// convolution of the SAMPLED points' own features (pointnext.py:150-153, 167-168), 64 input channels at a time
+// through LDS; act = ReLU when `relu`.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wide_out_kernel(int M, int O, const float *__restrict__ ysel,
-                                                       const float *__restrict__ pack2, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void wide_out_kernel(int M, int O, int C, int N, const float *__restrict__ ysel,
+                                                       const float *__restrict__ pack2, const float *__restrict__ f,
+                                                       const int *__restrict__ fidx, const float *__restrict__ ws,
+                                                       const float *__restrict__ bs, int relu,
+                                                       float *__restrict__ out) {
     __shared__ float tile[64][65];
+    __shared__ float fg[64][65];      // [c][q]
+    __shared__ float wt[64][65];      // [o][c]
     const int b = blockIdx.z, c0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const float sc = pack2[c0 + tx], sh = pack2[O + c0 + tx];
@@ -117,10 +125,35 @@ __global__ __launch_bounds__(256) void wide_out_kernel(int M, int O, const float
         const int q = m0 + qq;
         tile[qq][tx] = q < M ? __builtin_fmaf(ysel[((size_t)b * M + q) * O + c0 + tx], sc, sh) : 0.0f;
     }
-    __syncthreads();
-    for (int cc = ty; cc < 64; cc += 4) {
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    if (ws) {
         const int q = m0 + tx;
-        if (q < M) out[((size_t)b * O + c0 + cc) * M + q] = tile[tx][cc];
+        const int src = q < M ? fidx[(size_t)b * M + q] : 0;
+        for (int k0 = 0; k0 < C; k0 += 64) {
+            __syncthreads();
+            for (int cc = ty; cc < 64; cc += 4) {
+                fg[cc][tx] = (k0 + cc < C && q < M) ? f[((size_t)b * C + k0 + cc) * N + src] : 0.0f;
+                wt[cc][tx] = k0 + tx < C ? ws[(size_t)(c0 + cc) * C + k0 + tx] : 0.0f;      // wt[o = cc][c = tx]
+            }
+            __syncthreads();
+            const int kn = C - k0 < 64 ? C - k0 : 64;
+            for (int c = 0; c < kn; ++c) {
+                const float x = fg[c][tx];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = __builtin_fmaf(wt[ty + 4 * i][c], x, acc[i]);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = ty + 4 * i, q = m0 + tx;
+        float v = tile[tx][cc] + acc[i];
+        if (bs) v += bs[c0 + cc];
+        if (relu) v = v > 0.0f ? v : 0.0f;
+        if (q < M) out[((size_t)b * O + c0 + cc) * M + q] = v;
     }
 }
 
@@ -308,23 +341,29 @@ __global__ __launch_bounds__(256) void wide_bwd_fin_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------------------------------
-// per-point gradients.  Block = 64 consecutive points (+ its share of the queries), 256 threads.
+// per-point gradients (C, H <= 64: every weight sits in LDS).  Block = 64 consecutive points + its share of
+// the queries (qpb consecutive ones), 256 threads.
 //   1. G[pt][h] = ca sum_{rows of pt} GU[row][h] + cb inv1 (occ (U - mean1) - SP . W1p[h] / r) + cc occ   -> LDS
 //      (rows: the index stage's inverse map pcnt / poff / plist, ascending: a fixed order)
-//   2. dL/df[b][c][n] = sum_h G W1f[h][c];  dL/dp[pt][d] = sum_h G W1p[h][d] / r
+//   2. dL/df[b][c][n] = sum_h G W1f[h][c]  (+ sum_o gpre[q][o] Ws[o][c] when point n is query q: the residual
+//      branch's input gradient);  dL/dp[pt][d] = sum_h G W1p[h][d] / r
 //   3. this block's share of dL/dW1[h][c'] = sum_pt G[pt][h] X[c'][pt], X = [p / r ; f] (LDS), minus its
 //      queries' Hq[q][h] new_p[q][d] / r in the coordinate columns;  Hq = ca HA + cb HB + 32 cc;
-//      dL/dnew_p[q][d] = -sum_h Hq W1p[h][d] / r
-//   Wpart[block][H (C + 3)]: summed over blocks by wide_colsum (fixed order).
+//      of dL/dWs[o][c] = sum_q gpre[q][o] f[b, c, fidx[q]] and of dL/dbs[o] = sum_q gpre[q][o]
+//   4. dL/dnew_p[q][d] = -sum_h Hq W1p[h][d] / r
+//   Wpart[block][H (C + 3) + O C + O]: summed over blocks by wide_colsum_f32 (fixed order).
 // ------------------------------------------------------------------------------------------
 struct PointGradArgs {
-    int B, C, N, M, qpb;                 // qpb: queries per block
+    int B, C, N, M, O, qpb;              // qpb: queries per block;  O: skip-branch rows (0: no skip branch)
     const float *GU;                     // (rows, H) dL/da1-side sums per row (sa_wide.hip: wide_bwd_main)
     const int *pcnt, *poff, *plist;
     const float *geo;                    // (B N, 4)
     const float *U, *f, *p, *new_p;
     const float *HA, *HB;                // (B M, H)
     const float *cabc, *pack1, *w1;
+    const float *gpre;                   // (B M, O) gradient at the block's pre-activation output
+    const int *fq, *fidx;                // (B N): the query a point is (-1: none);  (B M): the point a query is
+    const float *ws;                     // (O, C)
     float inv_r;
     float *g_f, *g_p, *g_q, *Wpart;      // g_p / g_q may be null
 };
@@ -333,15 +372,38 @@ template <int HPW>
 __global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) {
     constexpr int H = 4 * HPW;
     extern __shared__ float sm[];
-    const int C = a.C, ldw = C + 3;
+    const int C = a.C, ldw = C + 3, O = a.O, qpb = a.qpb;
     float *Gs = sm;                                  // [64][H + 1]
-    float *Xs = sm + 64 * (H + 1);                   // [C + 3][65]
+    float *Xs = Gs + 64 * (H + 1);                   // [C + 3][65]
+    float *W1s = Xs + ldw * 65;                      // [H][ldw]
+    float *Hqs = W1s + H * ldw;                      // [qpb][H + 1]
+    float *Wss = Hqs + qpb * (H + 1);                // [O][C + 1]          (skip branch)
+    float *gps = Wss + O * (C + 1);                  // [qpb][O + 1]
+    float *fgs = gps + qpb * (O + 1);                // [C][qpb + 1]
     const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long npts = (long long)a.B * a.N;
+    const long long npts = (long long)a.B * a.N, nqry = (long long)a.B * a.M;
     const long long pt = (long long)blockIdx.x * 64 + tx;
     const bool ok = pt < npts;
     const long long ptc = ok ? pt : npts - 1;
     const int b = (int)(ptc / a.N), n = (int)(ptc % a.N);
+    const long long q0 = (long long)blockIdx.x * qpb;
+    const int nq = (int)(q0 >= nqry ? 0 : (nqry - q0 < qpb ? nqry - q0 : qpb));
+    // 0. weights and this block's queries into LDS
+    for (int e = threadIdx.x; e < H * ldw; e += 256) W1s[e] = a.w1[e];
+    for (int e = threadIdx.x; e < nq * H; e += 256) {
+        const int q = e / H, h = e - q * H;
+        const size_t g = (size_t)(q0 + q) * H + h;
+        Hqs[q * (H + 1) + h] = __builtin_fmaf(a.cabc[h], a.HA[g], __builtin_fmaf(a.cabc[H + h], a.HB[g], 32.0f * a.cabc[2 * H + h]));
+    }
+    if (O) {
+        for (int e = threadIdx.x; e < O * C; e += 256) Wss[(e / C) * (C + 1) + e % C] = a.ws[e];
+        for (int e = threadIdx.x; e < nq * O; e += 256) gps[(e / O) * (O + 1) + e % O] = a.gpre[(size_t)q0 * O + e];
+        for (int e = threadIdx.x; e < nq * C; e += 256) {
+            const int c = e / nq, q = e - c * nq;
+            const long long gq = q0 + q;
+            fgs[c * (qpb + 1) + q] = a.f[((size_t)(gq / a.M) * C + c) * a.N + a.fidx[gq]];
+        }
+    }
     {   // 1.
         const int h0 = ty * HPW;
         float acc[HPW];
@@ -349,13 +411,23 @@ __global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) 
         for (int v = 0; v < HPW; ++v) acc[v] = 0.0f;
         const int cnt = ok ? a.pcnt[ptc] : 0;
         const int *__restrict__ l = a.plist + a.poff[ptc];
-        for (int i = 0; i < cnt; ++i) {
-            const float4 *__restrict__ g = reinterpret_cast<const float4 *>(a.GU + (size_t)l[i] * H + h0);
+        for (int i0 = 0; i0 < cnt; i0 += 4) {                      // four rows in flight
+            int r[4];
 #pragma unroll
-            for (int v = 0; v < HPW / 4; ++v) {
-                const float4 x = g[v];
-                acc[4 * v] += x.x; acc[4 * v + 1] += x.y; acc[4 * v + 2] += x.z; acc[4 * v + 3] += x.w;
+            for (int u = 0; u < 4; ++u) r[u] = i0 + u < cnt ? l[i0 + u] : -1;
+            float4 x[4][HPW / 4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(a.GU + (size_t)(r[u] < 0 ? 0 : r[u]) * H + h0);
+#pragma unroll
+                for (int v = 0; v < HPW / 4; ++v) x[u][v] = r[u] < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : g[v];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < HPW / 4; ++v) {
+                    acc[4 * v] += x[u][v].x; acc[4 * v + 1] += x[u][v].y; acc[4 * v + 2] += x[u][v].z; acc[4 * v + 3] += x[u][v].w;
+                }
         }
         const float4 ge = *reinterpret_cast<const float4 *>(a.geo + ptc * 4);
         const float *__restrict__ ur = a.U + ptc * H + h0;
@@ -376,86 +448,119 @@ __global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) 
         Xs[cc * 65 + tx] = v;
     }
     __syncthreads();
-    // 2. wave ty: channels c = ty, ty + 4, ... in groups of 8 (weights wave-uniform)
+    // 2. wave ty: channels [cbeg, cend), at most 16
     {
-        const int cpw = (C + 3) / 4;                              // channels per wave (ceil)
+        const int cpw = (C + 3) / 4;
         const int cbeg = ty * cpw, cend = min(C, cbeg + cpw);
-        for (int c0 = cbeg; c0 < cend; c0 += 8) {
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int h = 0; h < H; ++h) {
-                const float g = Gs[tx * (H + 1) + h];
-                const float *__restrict__ wr = a.w1 + (size_t)h * ldw + 3 + c0;
+        float acc[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(g, c0 + j < cend ? wr[j] : 0.0f, acc[j]);
-            }
-            if (ok) {
+        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+        for (int h = 0; h < H; ++h) {
+            const float g = Gs[tx * (H + 1) + h];
+            const float *wr = W1s + h * ldw + 3 + cbeg;
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (c0 + j < cend) a.g_f[((size_t)b * C + c0 + j) * a.N + n] = acc[j];
+            for (int j = 0; j < 16; ++j) acc[j] = __builtin_fmaf(g, cbeg + j < cend ? wr[j] : 0.0f, acc[j]);
+        }
+        if (O) {
+            const int q = ok ? a.fq[ptc] : -1;
+            if (q >= 0) {
+                const float4 *__restrict__ gp = reinterpret_cast<const float4 *>(a.gpre + ((size_t)b * a.M + q) * O);
+                for (int o4 = 0; o4 < O / 4; ++o4) {
+                    const float4 g4 = gp[o4];
+                    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float *wr = Wss + (o4 * 4 + u) * (C + 1) + cbeg;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc[j] = __builtin_fmaf(gv[u], cbeg + j < cend ? wr[j] : 0.0f, acc[j]);
+                    }
+                }
             }
+        }
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (cbeg + j < cend) a.g_f[((size_t)b * C + cbeg + j) * a.N + n] = acc[j];
         }
         if (a.g_p && ty < 3) {
-            float acc = 0.0f;
-            for (int h = 0; h < H; ++h) acc = __builtin_fmaf(Gs[tx * (H + 1) + h], a.w1[(size_t)h * ldw + ty], acc);
-            if (ok) a.g_p[ptc * 3 + ty] = acc * a.inv_r;
+            float s = 0.0f;
+            for (int h = 0; h < H; ++h) s = __builtin_fmaf(Gs[tx * (H + 1) + h], W1s[h * ldw + ty], s);
+            if (ok) a.g_p[ptc * 3 + ty] = s * a.inv_r;
         }
     }
-    // 3. 4 x 4 register tiles of dW[h][c'] over the 64 points
-    float *__restrict__ wrow = a.Wpart + (size_t)blockIdx.x * H * ldw;
+    // 3. 4 x 4 register tiles of dW1[h][c'] over the 64 points (columns cq, cq + tcols, ...: lanes consecutive)
+    float *__restrict__ wrow = a.Wpart + (size_t)blockIdx.x * ((size_t)H * ldw + (size_t)O * C + O);
     const int tcols = (ldw + 3) / 4, ntile = (H / 4) * tcols;
-    for (int tile = threadIdx.x; tile < ntile; tile += 256) {
-        const int hq = tile / tcols, cq = tile - hq * tcols;        // columns cq, cq + tcols, ... (lanes: consecutive)
-        const int hb = hq * 4;
+    const int stiles = O ? (O / 4) * ((C + 3) / 4) : 0;             // tiles of dWs
+    for (int tile = threadIdx.x; tile < ntile + stiles; tile += 256) {
         float acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
-        for (int q = 0; q < 64; ++q) {
-            float g[4], x[4];
+        if (tile < ntile) {
+            const int hq = tile / tcols, cq = tile - hq * tcols;
+            const int hb = hq * 4;
+            for (int q = 0; q < 64; ++q) {
+                float g[4], x[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g[i] = Gs[q * (H + 1) + hb + i];
+                for (int i = 0; i < 4; ++i) g[i] = Gs[q * (H + 1) + hb + i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = cq + j * tcols < ldw ? Xs[(cq + j * tcols) * 65 + q] : 0.0f;
+                for (int j = 0; j < 4; ++j) x[j] = cq + j * tcols < ldw ? Xs[(cq + j * tcols) * 65 + q] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(g[i], x[j], acc[i][j]);
+            }
+            if (cq < 3) {        // coordinate column d = cq: minus this block's queries' Hq[q][h] new_p[q][d] / r
+                for (int q = 0; q < nq; ++q) {
+                    const float xd = a.new_p[(q0 + q) * 3 + cq] * a.inv_r;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][0] = __builtin_fmaf(-Hqs[q * (H + 1) + hb + i], xd, acc[i][0]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(g[i], x[j], acc[i][j]);
-        }
-        if (cq < 3) {
-            // coordinate column d = cq: minus this block's queries' Hq[q][h] new_p[q][d] / r
-            const long long nqry = (long long)a.B * a.M;
-            const long long q0 = (long long)blockIdx.x * a.qpb, q1 = min(nqry, q0 + a.qpb);
-            for (long long q = q0; q < q1; ++q) {
-                const float xd = a.new_p[q * 3 + cq] * a.inv_r;
+                for (int j = 0; j < 4; ++j)
+                    if (cq + j * tcols < ldw) wrow[(size_t)(hb + i) * ldw + cq + j * tcols] = acc[i][j];
+        } else {
+            const int st = tile - ntile, scols = (C + 3) / 4;
+            const int oq = st / scols, cq = st - oq * scols;
+            const int ob = oq * 4;
+            for (int q = 0; q < nq; ++q) {
+                float g[4], x[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int h = hb + i;
-                    const float hq_ = __builtin_fmaf(a.cabc[h], a.HA[q * H + h],
-                                                     __builtin_fmaf(a.cabc[H + h], a.HB[q * H + h], 32.0f * a.cabc[2 * H + h]));
-                    acc[i][0] = __builtin_fmaf(-hq_, xd, acc[i][0]);
-                }
+                for (int i = 0; i < 4; ++i) g[i] = gps[q * (O + 1) + ob + i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = cq + j * scols < C ? fgs[(cq + j * scols) * (qpb + 1) + q] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(g[i], x[j], acc[i][j]);
             }
+            float *__restrict__ srow = wrow + (size_t)H * ldw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (cq + j * scols < C) srow[(size_t)(ob + i) * C + cq + j * scols] = acc[i][j];
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (cq + j * tcols < ldw) wrow[(size_t)(hb + i) * ldw + cq + j * tcols] = acc[i][j];
     }
+    if (O) {
+        for (int o = threadIdx.x; o < O; o += 256) {
+            float s = 0.0f;
+            for (int q = 0; q < nq; ++q) s += gps[q * (O + 1) + o];
+            wrow[(size_t)H * ldw + (size_t)O * C + o] = s;
+        }
+    }
+    // 4.
     if (a.g_q) {
-        const long long nqry = (long long)a.B * a.M;
-        const long long q0 = (long long)blockIdx.x * a.qpb, q1 = min(nqry, q0 + a.qpb);
-        for (long long e = q0 * 3 + threadIdx.x; e < q1 * 3; e += 256) {
-            const long long q = e / 3;
-            const int d = (int)(e - q * 3);
-            float acc = 0.0f;
-            for (int h = 0; h < H; ++h) {
-                const float hq_ = __builtin_fmaf(a.cabc[h], a.HA[q * H + h],
-                                                 __builtin_fmaf(a.cabc[H + h], a.HB[q * H + h], 32.0f * a.cabc[2 * H + h]));
-                acc = __builtin_fmaf(hq_, a.w1[(size_t)h * ldw + d], acc);
-            }
-            a.g_q[e] = -acc * a.inv_r;
+        for (int e = threadIdx.x; e < nq * 3; e += 256) {
+            const int q = e / 3, d = e - q * 3;
+            float s = 0.0f;
+            for (int h = 0; h < H; ++h) s = __builtin_fmaf(Hqs[q * (H + 1) + h], W1s[h * ldw + d], s);
+            a.g_q[(q0 + q) * 3 + d] = -s * a.inv_r;
         }
     }
 }
@@ -523,11 +628,13 @@ extern "C" int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, in
     return APN_OK;
 }
 
-extern "C" int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, float *out,
-                               void *stream) {
+extern "C" int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, int c_in, int n,
+                               const float *f, const int *fidx, const float *ws, const float *bs, int relu,
+                               float *out, void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || c_out <= 0 || (c_out % 64) || !ysel || !pack2 || !out) return APN_EINVAL;
+    if (ws && (!f || !fidx || c_in <= 0 || n <= 0)) return APN_EINVAL;
     hipLaunchKernelGGL(wide_out_kernel, dim3((m + 63) / 64, c_out / 64, b), dim3(256), 0, (hipStream_t)stream, m, c_out,
-                       ysel, pack2, out);
+                       c_in, n, ysel, pack2, f, fidx, ws, bs, relu, out);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -565,26 +672,36 @@ extern "C" int apn_sa_wide_point_grads_rows(int b, int n) {
     return (int)(((long long)b * n + 63) / 64);
 }
 
+extern "C" int apn_sa_wide_point_grads_cols(int c_in, int c_mid, int c_skip) {
+    return c_mid * (c_in + 3) + c_skip * c_in + c_skip;
+}
+
 extern "C" int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid, float radius, const float *GU,
                                        const int *pcnt_poff, const int *plist, const float *geo, const float *U,
                                        const float *f, const float *p, const float *new_p, const float *HA,
                                        const float *HB, const float *cabc, const float *pack1, const float *w1,
+                                       int c_skip, const float *gpre, const int *fq, const int *fidx, const float *ws,
                                        float *g_f, float *g_p, float *g_q, float *w_part, void *stream) {
-    if (b <= 0 || c_in <= 0 || n <= 0 || m <= 0 || !dense_shape_ok(c_mid, 2 * c_mid) || !(radius > 0.0f) || !GU ||
-        !pcnt_poff || !plist || !geo || !U || !f || !p || !new_p || !HA || !HB || !cabc || !pack1 || !w1 || !g_f || !w_part)
+    if (b <= 0 || c_in <= 0 || c_in > 64 || n <= 0 || m <= 0 || (c_mid != 32 && c_mid != 64) || !(radius > 0.0f) ||
+        !GU || !pcnt_poff || !plist || !geo || !U || !f || !p || !new_p || !HA || !HB || !cabc || !pack1 || !w1 || !g_f ||
+        !w_part || c_skip < 0 || (c_skip % 4) || (c_skip && (!gpre || !fq || !fidx || !ws)))
         return APN_EINVAL;
     const long long npts = (long long)b * n, nqry = (long long)b * m;
     const long long blocks = (npts + 63) / 64;
     if (blocks > 0x7fffffffLL) return APN_EINVAL;
     PointGradArgs a;
-    a.B = b; a.C = c_in; a.N = n; a.M = m;
+    a.B = b; a.C = c_in; a.N = n; a.M = m; a.O = c_skip;
     a.qpb = (int)((nqry + blocks - 1) / blocks);
     a.GU = GU; a.pcnt = pcnt_poff; a.poff = pcnt_poff + npts; a.plist = plist; a.geo = geo;
     a.U = U; a.f = f; a.p = p; a.new_p = new_p; a.HA = HA; a.HB = HB;
     a.cabc = cabc; a.pack1 = pack1; a.w1 = w1; a.inv_r = 1.0f / radius;
+    a.gpre = gpre; a.fq = fq; a.fidx = fidx; a.ws = ws;
     a.g_f = g_f; a.g_p = g_p; a.g_q = g_q; a.Wpart = w_part;
     APN_DENSE_DISPATCH(c_mid, {
-        const size_t lds = ((size_t)64 * (4 * HPW + 1) + (size_t)(c_in + 3) * 65) * sizeof(float);
+        const int H = 4 * HPW, ldw = c_in + 3;
+        const size_t lds = ((size_t)64 * (H + 1) + (size_t)ldw * 65 + (size_t)H * ldw + (size_t)a.qpb * (H + 1) +
+                            (size_t)c_skip * (c_in + 1) + (size_t)a.qpb * (c_skip + 1) + (size_t)c_in * (a.qpb + 1)) *
+                           sizeof(float);
         if (lds > 160 * 1024) return APN_EINVAL;
         if (lds > 48 * 1024) {
             if (hipError_t e = hipFuncSetAttribute((const void *)wide_point_grads_kernel<HPW>,

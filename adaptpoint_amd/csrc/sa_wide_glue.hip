@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void wide_image_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// Upstream gradient g (B,O,M; any strides, a broadcast is never materialised) ->
+// Upstream gradient g (B,O,M; any strides, a broadcast is never materialised), masked by the block's final ReLU
+// when out_act (the block's output) is given ->
 //   goa (B,M,O) = g * scale2 (the gradient that reaches y2 at the pooled slot),
 //   partS[b * mt + tile][2*O] = {sum_m g, sum_m g * yhat_sel}, yhat_sel = (ysel - mean2) * invstd2.
 // Block = 64 queries x 64 channels through an LDS tile (reads coalesced along m, writes along c).
@@ -51,6 +52,8 @@ __global__ __launch_bounds__(256) void wide_bwd_prep_kernel(int m, int O, const 
                                                             long long gs_b, long long gs_c, long long gs_m,
                                                             const float *__restrict__ ysel,
                                                             const float *__restrict__ pack2,
+                                                            const float *__restrict__ out_act,
+                                                            float *__restrict__ gpre,
                                                             float *__restrict__ goa, float *__restrict__ partS) {
     __shared__ float tile[64][65];
     __shared__ float red[2][4][64];
@@ -58,7 +61,10 @@ __global__ __launch_bounds__(256) void wide_bwd_prep_kernel(int m, int O, const 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int cc = ty; cc < 64; cc += 4) {          // tile[c][m]: coalesced along m
         const int q = m0 + tx;
-        tile[cc][tx] = q < m ? g[b * gs_b + (long long)(c0 + cc) * gs_c + q * gs_m] : 0.0f;
+        float gv = q < m ? g[b * gs_b + (long long)(c0 + cc) * gs_c + q * gs_m] : 0.0f;
+        // the block ended in a ReLU over (pooled + skip): its output (B,O,M) tells where the gradient passes
+        if (out_act && q < m && !(out_act[((size_t)b * O + c0 + cc) * m + q] > 0.0f)) gv = 0.0f;
+        tile[cc][tx] = gv;
     }
     __syncthreads();
     const int c = c0 + tx;                          // this thread's channel; queries ty, ty+4, ...
@@ -70,6 +76,7 @@ __global__ __launch_bounds__(256) void wide_bwd_prep_kernel(int m, int O, const 
             const float gv = tile[tx][qq];
             const size_t o = ((size_t)b * m + q) * O + c;
             goa[o] = gv * sc;
+            if (gpre) gpre[o] = gv;                    // the gradient before BatchNorm-2's scale: the skip branch's
             s1 += gv;
             s2 = __builtin_fmaf(gv, (ysel[o] - mu) * iv, s2);
         }
@@ -169,29 +176,10 @@ __global__ __launch_bounds__(256) void wide_consts1_kernel(const float *__restri
     if (g_beta1) g_beta1[c] = (float)(t1 * gscale);
 }
 
-// Occurrence statistics of the points (coordinates only): geo[b][n] = {how often point n is
-// gathered, sum of the gathering queries' coordinates}.  One wave per query, lane = slot; the
-// ball-query fill run (copies of slot 0) is folded into ONE atomic per component.  geo caller-zeroed.
-__global__ __launch_bounds__(256) void wide_geo_kernel(int ntiles, int n, int m, const int *__restrict__ idx,
-                                                       const float *__restrict__ new_xyz, float *__restrict__ geo) {
-    const int lane = lane_id(), tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= ntiles) return;
-    const int cloud = tile / m;
-    const int k = lane & 31, comp = lane >> 5;                 // two lanes per slot: components {0,1} / {2,3}
-    const int nn = idx[(size_t)tile * 32 + k];
-    const int first = __builtin_amdgcn_readfirstlane(nn);
-    const bool dup = k > 0 && nn == first;
-    const unsigned long long dups = __ballot(dup && comp == 0);
-    const float mult = k == 0 ? 1.0f + (float)__popcll(dups) : 1.0f;
-    if (dup) return;
-    const float *q = new_xyz + (size_t)tile * 3;
-    float *dst = geo + ((size_t)cloud * n + nn) * 4 + 2 * comp;
-    atomicAdd(dst, mult * (comp == 0 ? 1.0f : q[1]));
-    atomicAdd(dst + 1, mult * (comp == 0 ? q[0] : q[2]));
-}
-
-// dL/dU per point and (minus) dL/dV per query from dL/dy1 = ca g_u + cb yhat1 + cc:
-//   G[b,n,h]  = ca A + cb inv1 (occ (U - mean1) - (SP . W1p[h]) / r) + cc occ          (in place over A)
+// dL/dU per point and (minus) dL/dV per query from dL/dy1 = ca g_u + cb yhat1 + cc (the standalone form, for
+// the widths whose dense products are library GEMMs; csrc/sa_wide_dense.hip: wide_point_grads fuses it):
+//   G[b,n,h]  = ca sum_{rows of n} GU[row][h] + cb inv1 (occ (U - mean1) - (SP . W1p[h]) / r) + cc occ
+//               (rows through the inverse map pcnt / poff / plist, ascending: a fixed order, no atomics)
 //   Hq[b,q,h] = ca HA + cb HB + 32 cc                                                  (in place over HA)
 // W1 (H x ldw): its first three columns are W1p.  Blocks [0, pblocks) do points, the rest queries.
 __global__ __launch_bounds__(256) void wide_point_terms_kernel(long long npts, long long nqry, int H, int pblocks,
@@ -200,19 +188,27 @@ __global__ __launch_bounds__(256) void wide_point_terms_kernel(long long npts, l
                                                                const float *__restrict__ U,
                                                                const float *__restrict__ geo,
                                                                const float *__restrict__ w1, int ldw, float inv_r,
-                                                               float *__restrict__ A, float *__restrict__ HA,
+                                                               const float *__restrict__ GU,
+                                                               const int *__restrict__ pcnt,
+                                                               const int *__restrict__ poff,
+                                                               const int *__restrict__ plist,
+                                                               float *__restrict__ G, float *__restrict__ HA,
                                                                const float *__restrict__ HB) {
     if ((int)blockIdx.x < pblocks) {
         const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
         if (e >= npts * H) return;
         const int h = (int)(e % H);
         const long long pt = e / H;
+        const int cnt = pcnt[pt];
+        const int *__restrict__ l = plist + poff[pt];
+        float acc = 0.0f;
+        for (int i = 0; i < cnt; ++i) acc += GU[(size_t)l[i] * H + h];
         const float4 ge = *reinterpret_cast<const float4 *>(geo + pt * 4);
         const float occ = ge.x;
         const float spw = __builtin_fmaf(ge.w, w1[(size_t)h * ldw + 2],
                                          __builtin_fmaf(ge.z, w1[(size_t)h * ldw + 1], ge.y * w1[(size_t)h * ldw]));
         const float yh = pack1[3 * H + h] * (occ * (U[e] - pack1[2 * H + h]) - spw * inv_r);
-        A[e] = __builtin_fmaf(cabc[h], A[e], __builtin_fmaf(cabc[H + h], yh, cabc[2 * H + h] * occ));
+        G[e] = __builtin_fmaf(cabc[h], acc, __builtin_fmaf(cabc[H + h], yh, cabc[2 * H + h] * occ));
     } else {
         const long long e = (long long)(blockIdx.x - pblocks) * 256 + threadIdx.x;
         if (e >= nqry * H) return;
@@ -240,12 +236,12 @@ extern "C" int apn_sa_wide_image(const float *src0, int k0, int trans0, const fl
 extern "C" int apn_sa_wide_bwd_prep_rows(int b, int m) { return b * ((m + 63) / 64); }
 
 extern "C" int apn_sa_wide_bwd_prep(int b, int m, int c_out, const float *g, long long gs_b, long long gs_c,
-                                    long long gs_m, const float *ysel, const float *pack2, float *goa,
-                                    float *part_s, void *stream) {
+                                    long long gs_m, const float *ysel, const float *pack2, const float *out_act,
+                                    float *gpre, float *goa, float *part_s, void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || c_out <= 0 || (c_out % 64) || !g || !ysel || !pack2 || !goa || !part_s)
         return APN_EINVAL;
     hipLaunchKernelGGL(wide_bwd_prep_kernel, dim3((m + 63) / 64, c_out / 64, b), dim3(256), 0, (hipStream_t)stream,
-                       m, c_out, g, gs_b, gs_c, gs_m, ysel, pack2, goa, part_s);
+                       m, c_out, g, gs_b, gs_c, gs_m, ysel, pack2, out_act, gpre, goa, part_s);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -270,26 +266,19 @@ extern "C" int apn_sa_wide_consts1(const float *part_t, int rows, const double *
     return APN_OK;
 }
 
-extern "C" int apn_sa_wide_geo(int b, int n, int m, const int *idx, const float *new_xyz, float *geo, void *stream) {
-    if (b <= 0 || n <= 0 || m <= 0 || !idx || !new_xyz || !geo) return APN_EINVAL;
-    const int ntiles = b * m;
-    hipLaunchKernelGGL(wide_geo_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, ntiles, n, m, idx,
-                       new_xyz, geo);
-    APN_LAUNCH_CHECK();
-    return APN_OK;
-}
-
 extern "C" int apn_sa_wide_point_terms(int b, int n, int m, int c_mid, const float *cabc, const float *pack1,
                                        const float *U, const float *geo, const float *w1, int ldw, float radius,
-                                       float *A, float *HA, const float *HB, void *stream) {
-    if (b <= 0 || n <= 0 || m <= 0 || c_mid <= 0 || !cabc || !pack1 || !U || !geo || !w1 || ldw < 3 || !A || !HA ||
-        !HB || !(radius > 0.0f))
+                                       const float *GU, const int *pcnt_poff, const int *plist, float *G, float *HA,
+                                       const float *HB, void *stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || c_mid <= 0 || !cabc || !pack1 || !U || !geo || !w1 || ldw < 3 || !GU ||
+        !pcnt_poff || !plist || !G || !HA || !HB || !(radius > 0.0f))
         return APN_EINVAL;
     const long long npts = (long long)b * n, nqry = (long long)b * m;
     const long long pb = (npts * c_mid + 255) / 256, qb = (nqry * c_mid + 255) / 256;
     if (pb + qb > 0x7fffffffLL) return APN_EINVAL;
     hipLaunchKernelGGL(wide_point_terms_kernel, dim3((unsigned)(pb + qb)), dim3(256), 0, (hipStream_t)stream, npts,
-                       nqry, c_mid, (int)pb, cabc, pack1, U, geo, w1, ldw, 1.0f / radius, A, HA, HB);
+                       nqry, c_mid, (int)pb, cabc, pack1, U, geo, w1, ldw, 1.0f / radius, GU, pcnt_poff,
+                       pcnt_poff + npts, plist, G, HA, HB);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -428,6 +417,15 @@ __global__ __launch_bounds__(256) void csr_zero_kernel(long long n4, int4 *__res
     if (e < n4) dst[e] = make_int4(0, 0, 0, 0);
 }
 
+// fq[b n] = the query that point n is (fidx[b][q] == n), else -1: fill, then scatter (FPS picks are distinct)
+__global__ __launch_bounds__(256) void csr_fq_kernel(long long count, int n, int m, const int *__restrict__ fidx,
+                                                     int *__restrict__ fq) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    if (!fidx) fq[e] = -1;
+    else fq[(e / m) * n + fidx[e]] = (int)(e % m);
+}
+
 __global__ __launch_bounds__(256) void csr_count_fill_kernel(int nq, int n, int m, int fill,
                                                              const int *__restrict__ idx,
                                                              const int *__restrict__ tmap, int *__restrict__ pcnt,
@@ -535,9 +533,10 @@ extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *
     return APN_OK;
 }
 
-// pcnt_poff: int32[2 b n] (counts, then list starts); plist: int32[32 b m]; geo: float[4 b n].
+// pcnt_poff: int32[2 b n] (counts, then list starts); plist: int32[32 b m]; geo: float[4 b n];
+// optional: fidx (b,m) = the point every query is -> fq int32[b n] = the query a point is, or -1.
 extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *new_xyz, const int *tmap,
-                               int *pcnt_poff, int *plist, float *geo, void *stream) {
+                               int *pcnt_poff, int *plist, float *geo, const int *fidx, int *fq, void *stream) {
     if (b <= 0 || n <= 0 || m <= 0 || b > 65535 || (long long)b * m > 0x7fffffffLL / 64 ||
         (long long)b * n > 0x7fffffffLL / 8 || !idx || !new_xyz || !tmap || !pcnt_poff || !plist || !geo)
         return APN_EINVAL;
@@ -554,6 +553,12 @@ extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float 
     hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 1, idx, tmap, pcnt, poff, plist);
     hipLaunchKernelGGL(apn::csr_sort_geo_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, nq, npts, tmap,
                        pcnt, poff, plist, new_xyz, geo);
+    if (fidx && fq) {
+        hipLaunchKernelGGL(apn::csr_fq_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, npts, n, m,
+                           (const int *)nullptr, fq);
+        hipLaunchKernelGGL(apn::csr_fq_kernel, dim3((unsigned)(((long long)nq + 255) / 256)), dim3(256), 0, st,
+                           (long long)nq, n, m, fidx, fq);
+    }
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

@@ -413,6 +413,7 @@ class Sampling:
         self.new_p = self.buf[o:o + B * M * 3].view(torch.float32).view(B, M, 3)
         o += B * M * 3
         self.idx = self.buf[o:o + B * M * K].view(B, M, K)
+        self.index = None        # adaptpoint_amd.fused_wide.NeighbourIndex of idx, when the width-generic kernels run
 
     def clouds(self, lo, hi):
         """The index stage of clouds lo..hi-1 as a `Sampling`-like view (no copy): index stages of
@@ -421,6 +422,7 @@ class Sampling:
         v.shape = (hi - lo,) + self.shape[1:]
         v.buf = None
         v.fidx, v.new_p, v.idx = self.fidx[lo:hi], self.new_p[lo:hi], self.idx[lo:hi]
+        v.index = None
         return v
 
 

@@ -26,6 +26,7 @@ from . import fused as _fz
 from .fused import _call
 
 K_NS = 32
+LEAN_MAX = 64        # widest C_in / C_mid whose dense products run in csrc/sa_wide_dense.hip
 WIDTHS = (32, 64, 128, 256)
 _DEBUG = None        # tests may set a dict: intermediates of the last call are stashed in it
 
@@ -104,64 +105,92 @@ class NeighbourIndex:
       tmap       distinct-hit tile map (csrc/sa_wide_glue.hip): rows = (query, distinct slot, multiplicity)
                  packed 32 to an MFMA tile;
       pcnt_poff  inverse map: per support point the number of rows that gather it and where its list starts;
-      plist      the lists (row ids, ascending);   geo (B,N,4): occurrences, sum of the gathering queries' coordinates.
+      plist      the lists (row ids, ascending);   geo (B,N,4): occurrences, sum of the gathering queries' coordinates;
+      fidx / fq  (optional) the point every query is (FPS picks) and its inverse (the query a point is, or -1).
     """
-    __slots__ = ("idx", "tmap", "pcnt_poff", "plist", "geo", "n_points")
+    __slots__ = ("idx", "tmap", "pcnt_poff", "plist", "geo", "n_points", "fidx", "fq")
 
-    def __init__(self, idx, tmap, pcnt_poff, plist, geo, n_points):
+    def __init__(self, idx, tmap, pcnt_poff, plist, geo, n_points, fidx=None, fq=None):
         self.idx, self.tmap, self.pcnt_poff, self.plist, self.geo, self.n_points = idx, tmap, pcnt_poff, plist, geo, n_points
+        self.fidx, self.fq = fidx, fq
 
 
-def tile_map(idx, fold=True):
+def tile_map(idx, fold=True, out=None):
     """The tile map alone (see NeighbourIndex).  fold=False: one 32-row tile per query (no use made of the
     ball-query structure)."""
     B, M, K = idx.shape
     assert K == K_NS and idx.dtype == torch.int32 and idx.is_contiguous()
-    tmap = torch.empty(_lib.load().apn_sa_wide_tilemap_ints(B, M), dtype=torch.int32, device=idx.device)
+    tmap = out if out is not None else torch.empty(_lib.load().apn_sa_wide_tilemap_ints(B, M), dtype=torch.int32,
+                                                  device=idx.device)
     _call("apn_sa_wide_tilemap", idx.device, B, M, 1 if fold else 0, idx.data_ptr(), tmap.data_ptr())
     return tmap
 
 
-def neighbour_index(idx, new_p, n_points, fold=True):
-    """Build the NeighbourIndex of idx (B,M,32) over n_points support points; new_p (B,M,3): the queries."""
-    idx, new_p = idx.contiguous(), new_p.contiguous()
+@torch.no_grad()
+def neighbour_index(idx, new_p, n_points, fold=True, fidx=None, out=None):
+    """Build the NeighbourIndex of idx (B,M,32) over n_points support points; new_p (B,M,3): the queries;
+    fidx (B,M) int32 (optional): the FPS picks, for blocks with a residual branch.  out: a NeighbourIndex of
+    the same shapes to refill (its buffers are kept: a captured hipGraph reads the same addresses)."""
+    assert idx.is_contiguous() and new_p.is_contiguous() and (fidx is None or fidx.is_contiguous())
     B, M, _ = idx.shape
     dev = idx.device
-    tmap = tile_map(idx, fold)
-    pcnt_poff = torch.empty(2 * B * n_points, dtype=torch.int32, device=dev)
-    plist = torch.empty(32 * B * M, dtype=torch.int32, device=dev)
-    geo = torch.empty(B, n_points, 4, dtype=torch.float32, device=dev)
-    _call("apn_sa_wide_csr", dev, B, n_points, M, idx.data_ptr(), new_p.data_ptr(), tmap.data_ptr(),
-          pcnt_poff.data_ptr(), plist.data_ptr(), geo.data_ptr())
-    return NeighbourIndex(idx, tmap, pcnt_poff, plist, geo, n_points)
+    if out is None:
+        out = NeighbourIndex(idx, None, torch.empty(2 * B * n_points, dtype=torch.int32, device=dev),
+                             torch.empty(32 * B * M, dtype=torch.int32, device=dev),
+                             torch.empty(B, n_points, 4, dtype=torch.float32, device=dev), n_points, fidx,
+                             None if fidx is None else torch.empty(B, n_points, dtype=torch.int32, device=dev))
+    else:
+        assert out.n_points == n_points and out.plist.numel() == 32 * B * M and (fidx is None) == (out.fq is None)
+        out.idx, out.fidx = idx, fidx
+    out.tmap = tile_map(idx, fold, out=out.tmap)
+    _call("apn_sa_wide_csr", dev, B, n_points, M, idx.data_ptr(), new_p.data_ptr(), out.tmap.data_ptr(),
+          out.pcnt_poff.data_ptr(), out.plist.data_ptr(), out.geo.data_ptr(), _fz._ptr(fidx), _fz._ptr(out.fq))
+    return out
 
 
 def _training(bn):
     return bn.training or not bn.track_running_stats
 
 
-class _WideMlpMax(torch.autograd.Function):
+def lean(C, H):
+    """Shapes whose dense products (conv1 at the points, Qm, dL/df, dL/dW1) run in the path's own fused
+    kernels (csrc/sa_wide_dense.hip); wider ones hand them to library GEMMs."""
+    return C <= LEAN_MAX and H <= LEAN_MAX
+
+
+class _WideBlock(torch.autograd.Function):
+    """max_K bn2(conv2(relu(bn1(conv1(grouped))))) [+ ws f[fidx] + bs] [ReLU] -- forward and backward."""
+
     @staticmethod
-    def forward(ctx, p, new_p, f, w1, g1, b1, w2, g2, b2, mods):
-        radius, bn1, bn2, sync_bn, nbr = mods
+    def forward(ctx, p, new_p, f, w1, g1, b1, w2, g2, b2, ws, bs, mods):
+        radius, bn1, bn2, sync_bn, nbr, relu = mods
         p, new_p, f = p.contiguous(), new_p.contiguous(), f.contiguous()
         idx, tmap = nbr.idx, nbr.tmap
         dev = f.device
         B, C, N = f.shape
         M = new_p.shape[1]
         H, O = w1.shape[0], w2.shape[0]
+        fusedd = lean(C, H)
+        assert ws is None or (fusedd and nbr.fq is not None)
         sync = sync_bn and (_fz._world(True) > 1 or _fz.FORCE_PHASED)
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.no_grad():
             W1 = w1.detach().reshape(H, C + 3).contiguous()
             W2 = w2.detach().reshape(O, H).contiguous()
-            # conv1 at the points (one row per support point, one per query) and the image of W2^T: one launch
-            U = torch.empty(B, N, H, **f32)
-            V = torch.empty(B, M, H, **f32)
-            ct = min(4, O // 32)
-            w2img = torch.empty(O // (32 * ct), H // 32, ct, 2, 2, 64, 8, dtype=torch.bfloat16, device=dev)
-            _call("apn_sa_wide_fwd_prep", dev, B, C, N, M, H, O, float(radius), f.data_ptr(), p.data_ptr(),
-                  new_p.data_ptr(), W1.data_ptr(), W2.data_ptr(), U.data_ptr(), V.data_ptr(), w2img.data_ptr())
+            Ws = None if ws is None else ws.detach().reshape(O, C).contiguous()
+            # conv1 at the points: one row per support point, one per query; the image of W2^T
+            if fusedd:
+                U = torch.empty(B, N, H, **f32)
+                V = torch.empty(B, M, H, **f32)
+                ct = min(4, O // 32)
+                w2img = torch.empty(O // (32 * ct), H // 32, ct, 2, 2, 64, 8, dtype=torch.bfloat16, device=dev)
+                _call("apn_sa_wide_fwd_prep", dev, B, C, N, M, H, O, float(radius), f.data_ptr(), p.data_ptr(),
+                      new_p.data_ptr(), W1.data_ptr(), W2.data_ptr(), U.data_ptr(), V.data_ptr(), w2img.data_ptr())
+            else:
+                W1p, W1f = W1[:, :3], W1[:, 3:]
+                U = torch.baddbmm(torch.matmul(p, W1p.t()) / radius, f.transpose(1, 2), W1f.t().expand(B, C, H)).contiguous()
+                V = (torch.matmul(new_p, W1p.t()) / radius).contiguous()
+                w2img = _image(W2, H, True, None, H, O, min(4, O // 32))          # W2^T (H x O)
             grid = _lib.load().apn_sa_wide_grid(B, M)
             count = float(B * M * K_NS)
             tr1, tr2 = _training(bn1), _training(bn2)
@@ -179,27 +208,31 @@ class _WideMlpMax(torch.autograd.Function):
                   part2.data_ptr())
             pack2, _, _ = _bn_pack(part2 if tr2 else None, grid, O, count, bn2, dev, tr2, sync)
             out = torch.empty(B, O, M, **f32)
-            _call("apn_sa_wide_out", dev, B, M, O, ysel.data_ptr(), pack2.data_ptr(), out.data_ptr())
+            _call("apn_sa_wide_out", dev, B, M, O, ysel.data_ptr(), pack2.data_ptr(), C, N, f.data_ptr(),
+                  _fz._ptr(nbr.fidx if Ws is not None else None), _fz._ptr(Ws),
+                  _fz._ptr(None if bs is None else bs.detach()), 1 if relu else 0, out.data_ptr())
             if _DEBUG is not None:
                 _DEBUG.update(U=U, V=V, pack1=pack1, w2img=w2img, ysel=ysel, ksel=ksel, part2=part2, pack2=pack2,
                               sgn2=sgn2)
-        ctx.save_for_backward(p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2)
+        ctx.save_for_backward(p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2, Ws, out if relu else None)
         ctx.nbr = nbr
-        ctx.cfg = (radius, tr1, tr2, sync, count, g1 is not None, b1 is not None, g2 is not None, b2 is not None)
+        ctx.cfg = (radius, tr1, tr2, sync, count, relu, g1 is not None, b1 is not None, g2 is not None, b2 is not None,
+                   bs is not None)
         ctx.need = (p.requires_grad, new_p.requires_grad)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2 = ctx.saved_tensors
+        p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2, Ws, out_act = ctx.saved_tensors
         nbr = ctx.nbr
         idx, tmap = nbr.idx, nbr.tmap
-        radius, tr1, tr2, sync, count, a1, a2, a3, a4 = ctx.cfg
+        radius, tr1, tr2, sync, count, relu, a1, a2, a3, a4, a5 = ctx.cfg
         need_p, need_q = ctx.need
         dev = f.device
         B, C, N = f.shape
         M = new_p.shape[1]
         H, O = W1.shape[0], W2.shape[0]
+        fusedd = lean(C, H)
         lib = _lib.load()
         if g.dtype != torch.float32:
             g = g.float()
@@ -211,14 +244,14 @@ class _WideMlpMax(torch.autograd.Function):
                            torch.ones(1, dtype=torch.float64, device=dev)])
             _fz._allreduce_sum_(v)
             return v
-        # the upstream gradient in query-major layout, BatchNorm-2's row sums (only pooled slots carry gradient)
+        # the upstream gradient (through the block's ReLU) in query-major layout, BatchNorm-2's row sums
         prow = lib.apn_sa_wide_bwd_prep_rows(B, M)
         goa = torch.empty(B, M, O, **f32)
+        gpre = torch.empty(B, M, O, **f32) if Ws is not None else None
         partS = torch.empty(prow, 2 * O, **f32)
         gs = g.stride()
         _call("apn_sa_wide_bwd_prep", dev, B, M, O, g.data_ptr(), gs[0], gs[1], gs[2], ysel.data_ptr(),
-              pack2.data_ptr(), goa.data_ptr(), partS.data_ptr())
-        # BatchNorm-2 backward constants, Qm = W2^T diag(D2) W2, evec = E2 W2, image of [W2 ; Qm]: one launch
+              pack2.data_ptr(), _fz._ptr(out_act), _fz._ptr(gpre), goa.data_ptr(), partS.data_ptr())
         small = torch.empty(2 * O + O + O + H + 3 * H + 2 * H, **f32)
         o = 0
         d2e2 = small[o:o + 2 * O]; o += 2 * O
@@ -228,12 +261,20 @@ class _WideMlpMax(torch.autograd.Function):
         cabc = small[o:o + 3 * H]; o += 3 * H
         g_gamma1 = small[o:o + H]; o += H
         g_beta1 = small[o:o + H]
-        ctz = min(4, H // 32)
-        zimg = torch.empty(H // (32 * ctz), (O + H) // 32, ctz, 2, 2, 64, 8, dtype=torch.bfloat16, device=dev)
         sS = reduced(partS) if sync else None
-        _call("apn_sa_wide_bwd_mid", dev, None if sync else partS.data_ptr(), prow, _fz._ptr(sS), H, O, pack2.data_ptr(),
-              count, 1 if tr2 else 0, W2.data_ptr(), d2e2.data_ptr(), g_gamma2.data_ptr(), g_beta2.data_ptr(),
-              evec.data_ptr(), zimg.data_ptr())
+        if fusedd:
+            # BatchNorm-2 backward constants, Qm = W2^T diag(D2) W2, evec = E2 W2, image of [W2 ; Qm]: one launch
+            ctz = min(4, H // 32)
+            zimg = torch.empty(H // (32 * ctz), (O + H) // 32, ctz, 2, 2, 64, 8, dtype=torch.bfloat16, device=dev)
+            _call("apn_sa_wide_bwd_mid", dev, None if sync else partS.data_ptr(), prow, _fz._ptr(sS), H, O,
+                  pack2.data_ptr(), count, 1 if tr2 else 0, W2.data_ptr(), d2e2.data_ptr(), g_gamma2.data_ptr(),
+                  g_beta2.data_ptr(), evec.data_ptr(), zimg.data_ptr())
+        else:
+            _call("apn_sa_wide_consts2", dev, None if sync else partS.data_ptr(), prow, _fz._ptr(sS), O,
+                  pack2.data_ptr(), count, 1 if tr2 else 0, d2e2.data_ptr(), g_gamma2.data_ptr(), g_beta2.data_ptr())
+            Qm = torch.matmul(W2.t() * d2e2[:O], W2)                              # W2^T diag(D2) W2  (H,H)
+            torch.mv(W2.t(), d2e2[O:], out=evec)
+            zimg = _image(W2, O, False, Qm, O + H, H, min(4, H // 32))           # [W2 ; Qm]  ((O+H) x H)
         grid = lib.apn_sa_wide_grid(B, M)
         GU = torch.empty(B * M * K_NS, H, **f32)          # one row per tile-map row (upper bound; rows in use written)
         HA = torch.empty(B, M, H, **f32)
@@ -250,36 +291,77 @@ class _WideMlpMax(torch.autograd.Function):
         _call("apn_sa_wide_wgrad", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
               tmap.data_ptr(), pack1.data_ptr(), goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr())
         R = _colsum(Rpart)
-        # BatchNorm-1 backward constants and dL/dW2 = R_S + D2 (W2 Gram) + E2 (x) suma: one launch
-        g_w2 = torch.empty(O, H, **f32)
         sT = reduced(partT) if sync else None
-        _call("apn_sa_wide_bwd_fin", dev, None if sync else partT.data_ptr(), grid, _fz._ptr(sT), H, O, pack1.data_ptr(),
-              count, 1 if tr1 else 0, cabc.data_ptr(), g_gamma1.data_ptr(), g_beta1.data_ptr(), R.data_ptr(),
-              d2e2.data_ptr(), W2.data_ptr(), g_w2.data_ptr())
-        # per point: dL/dU (rows summed through the inverse map, fixed order), dL/df, dL/dp; per query dL/dnew_p;
-        # the workgroups' shares of dL/dW1
-        wrows = lib.apn_sa_wide_point_grads_rows(B, N)
-        g_f = torch.empty(B, C, N, **f32)
-        g_p = torch.empty(B, N, 3, **f32) if need_p else None
-        g_q = torch.empty(B, M, 3, **f32) if need_q else None
-        Wpart = torch.empty(wrows, H * (C + 3), **f32)
-        _call("apn_sa_wide_point_grads", dev, B, C, N, M, H, float(radius), GU.data_ptr(), nbr.pcnt_poff.data_ptr(),
-              nbr.plist.data_ptr(), nbr.geo.data_ptr(), U.data_ptr(), f.data_ptr(), p.data_ptr(), new_p.data_ptr(),
-              HA.data_ptr(), HB.data_ptr(), cabc.data_ptr(), pack1.data_ptr(), W1.data_ptr(), g_f.data_ptr(),
-              _fz._ptr(g_p), _fz._ptr(g_q), Wpart.data_ptr())
-        g_w1 = torch.empty(H, C + 3, **f32)
-        _call("apn_sa_wide_colsum_f32", dev, Wpart.data_ptr(), wrows, H * (C + 3), g_w1.data_ptr())
+        g_ws = g_bs = None
+        if fusedd:
+            # BatchNorm-1 backward constants and dL/dW2 = R_S + D2 (W2 Gram) + E2 (x) suma: one launch
+            g_w2 = torch.empty(O, H, **f32)
+            _call("apn_sa_wide_bwd_fin", dev, None if sync else partT.data_ptr(), grid, _fz._ptr(sT), H, O,
+                  pack1.data_ptr(), count, 1 if tr1 else 0, cabc.data_ptr(), g_gamma1.data_ptr(), g_beta1.data_ptr(),
+                  R.data_ptr(), d2e2.data_ptr(), W2.data_ptr(), g_w2.data_ptr())
+            # per point: dL/dU (rows summed through the inverse map, fixed order), dL/df, dL/dp; per query
+            # dL/dnew_p; the workgroups' shares of dL/dW1 (and of the residual branch's dL/dws, dL/dbs): one launch
+            Os = O if Ws is not None else 0
+            wrows, wcols = lib.apn_sa_wide_point_grads_rows(B, N), lib.apn_sa_wide_point_grads_cols(C, H, Os)
+            g_f = torch.empty(B, C, N, **f32)
+            g_p = torch.empty(B, N, 3, **f32) if need_p else None
+            g_q = torch.empty(B, M, 3, **f32) if need_q else None
+            Wpart = torch.empty(wrows, wcols, **f32)
+            _call("apn_sa_wide_point_grads", dev, B, C, N, M, H, float(radius), GU.data_ptr(), nbr.pcnt_poff.data_ptr(),
+                  nbr.plist.data_ptr(), nbr.geo.data_ptr(), U.data_ptr(), f.data_ptr(), p.data_ptr(), new_p.data_ptr(),
+                  HA.data_ptr(), HB.data_ptr(), cabc.data_ptr(), pack1.data_ptr(), W1.data_ptr(), Os, _fz._ptr(gpre),
+                  _fz._ptr(nbr.fq if Os else None), _fz._ptr(nbr.fidx if Os else None), _fz._ptr(Ws), g_f.data_ptr(),
+                  _fz._ptr(g_p), _fz._ptr(g_q), Wpart.data_ptr())
+            wsum = torch.empty(wcols, **f32)
+            _call("apn_sa_wide_colsum_f32", dev, Wpart.data_ptr(), wrows, wcols, wsum.data_ptr())
+            g_w1 = wsum[:H * (C + 3)].view(H, C + 3, 1, 1)
+            if Os:
+                g_ws = wsum[H * (C + 3):H * (C + 3) + O * C].view(O, C, 1)
+                g_bs = wsum[H * (C + 3) + O * C:] if a5 else None
+        else:
+            D2, E2 = d2e2[:O], d2e2[O:]
+            Rm, suma = R[:rows * H].view(rows, H), R[rows * H:]
+            g_w2 = (Rm[:O] + D2.double()[:, None] * (W2.double() @ Rm[O:]) + E2.double()[:, None] * suma[None, :]).float()
+            _call("apn_sa_wide_consts1", dev, None if sync else partT.data_ptr(), grid, _fz._ptr(sT), H,
+                  pack1.data_ptr(), count, 1 if tr1 else 0, cabc.data_ptr(), g_gamma1.data_ptr(), g_beta1.data_ptr())
+            G = torch.empty(B, N, H, **f32)
+            _call("apn_sa_wide_point_terms", dev, B, N, M, H, cabc.data_ptr(), pack1.data_ptr(), U.data_ptr(),
+                  nbr.geo.data_ptr(), W1.data_ptr(), C + 3, float(radius), GU.data_ptr(), nbr.pcnt_poff.data_ptr(),
+                  nbr.plist.data_ptr(), G.data_ptr(), HA.data_ptr(), HB.data_ptr())
+            Hq = HA
+            W1p, W1f = W1[:, :3], W1[:, 3:]
+            g_f = torch.matmul(G, W1f).transpose(1, 2).contiguous()              # (B,C,N)
+            g_p = torch.matmul(G, W1p) / radius if need_p else None
+            g_q = -torch.matmul(Hq, W1p) / radius if need_q else None
+            g_w1f = torch.matmul(G.reshape(B * N, H).t(), f.transpose(1, 2).reshape(B * N, C))
+            g_w1p = (torch.matmul(G.reshape(B * N, H).t(), p.reshape(B * N, 3))
+                     - torch.matmul(Hq.reshape(B * M, H).t(), new_p.reshape(B * M, 3))) / radius
+            g_w1 = torch.cat([g_w1p, g_w1f], 1).view(H, C + 3, 1, 1)
         if _DEBUG is not None:
             _DEBUG.update(goa=goa, zimg=zimg, GU=GU, HA=HA, HB=HB, partT=partT, Rpart=Rpart, R=R, d2e2=d2e2, evec=evec,
-                          cabc=cabc, Wpart=Wpart)
-        return (g_p, g_q, g_f, g_w1.view(H, C + 3, 1, 1), g_gamma1 if a1 else None, g_beta1 if a2 else None,
-                g_w2.view(O, H, 1, 1), g_gamma2 if a3 else None, g_beta2 if a4 else None, None)
+                          cabc=cabc)
+        return (g_p, g_q, g_f, g_w1, g_gamma1 if a1 else None, g_beta1 if a2 else None,
+                g_w2.view(O, H, 1, 1), g_gamma2 if a3 else None, g_beta2 if a4 else None, g_ws, g_bs, None)
 
 
 def grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2, sync_bn=False, index=None):
     """out (B,O,M) = max_K bn2(conv2(relu(bn1(conv1(cat[(p[idx]-new_p)/r, f[idx]]))))), any PointNeXt-S width.
     index: the `NeighbourIndex` of idx built ahead of time (default: built here, on the calling stream)."""
     if index is None:
-        index = neighbour_index(idx, new_p, p.shape[1])
-    return _WideMlpMax.apply(p, new_p, f, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight,
-                             bn2.bias, (float(radius), bn1, bn2, sync_bn, index))
+        index = neighbour_index(idx.contiguous(), new_p.detach().contiguous(), p.shape[1])
+    return _WideBlock.apply(p, new_p, f, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight,
+                            bn2.bias, None, None, (float(radius), bn1, bn2, sync_bn, index, False))
+
+
+def block(p, new_p, f, index, radius, conv1, bn1, conv2, bn2, skip_conv=None, relu=False, sync_bn=False):
+    """A whole set-abstraction block after its index stage (pointnext.py:150-168):
+        out (B,O,M) = act(max_K bn2(conv2(relu(bn1(conv1(grouped))))) + skip_conv(f[:, :, fidx])),
+    skip_conv: a 1x1 Conv1d on the sampled points' own features (None: no residual branch), act = ReLU when
+    `relu`.  index: the NeighbourIndex of the block's neighbours, built with `fidx` when there is a skip branch.
+    Only for shapes with `lean(C, H)`; wider blocks take `grouped_mlp_max` and apply the branch outside."""
+    ws = bs = None
+    if skip_conv is not None:
+        assert index.fq is not None, "the residual branch needs the NeighbourIndex built with fidx"
+        ws, bs = skip_conv.weight, skip_conv.bias
+    return _WideBlock.apply(p, new_p, f, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias,
+                            ws, bs, (float(radius), bn1, bn2, sync_bn, index, bool(relu)))

@@ -144,6 +144,65 @@ class SetAbstraction(nn.Module):
         return fused.sample_and_query(p, p.shape[1] // self.stride, self.grouper.radius,
                                       self.grouper.nsample, out=out)
 
+    def wide_shapes(self, c_in):
+        """(uses the width-generic kernels for c_in input channels, has a fused residual branch there)."""
+        from . import fused_wide
+        parts = self._fused_parts() if (self.fused and not self.is_head and not self.all_aggr) else None
+        if parts is None:
+            return False, False
+        H = parts[0].weight.shape[0]
+        resident = c_in == 32 and H == 32 and not fused_wide_first()
+        return (not resident) and H in fused_wide.WIDTHS, self._skip_conv1d() is not None and fused_wide.lean(c_in, H)
+
+    def index_for(self, smp, n_points, c_in, out=None):
+        """The NeighbourIndex (tile map + inverse map; adaptpoint_amd.fused_wide) of a Sampling of this block:
+        index-stage work, to be run where the Sampling is made.  Stored as smp.index and returned."""
+        from . import fused_wide
+        wide, skip = self.wide_shapes(c_in)
+        if not wide:
+            return None
+        smp.index = fused_wide.neighbour_index(smp.idx, smp.new_p, n_points, fidx=smp.fidx if skip else None, out=out)
+        return smp.index
+
+    def _skip_conv1d(self):
+        if not self.use_res:
+            return None
+        if (isinstance(self.skipconv, nn.Sequential) and len(self.skipconv) == 1
+                and isinstance(self.skipconv[0], nn.Conv1d) and isinstance(self.act, nn.ReLU)):
+            return self.skipconv[0]
+        return None
+
+    def _wide_block(self, p, f, sampling=None):
+        """The block through the width-generic kernels (adaptpoint_amd.fused_wide), residual branch and final ReLU
+        included when the shape has them fused; None when the configuration is not covered."""
+        from . import fused, fused_wide
+        parts = self._fused_parts()
+        if parts is None or self.all_aggr:
+            return None
+        conv1, bn1, conv2, bn2, relu_after = parts
+        g = self.grouper
+        if not fused_wide.supported(p, f, g.nsample, conv1, conv2, bns=(bn1, bn2)):
+            return None
+        C, H = f.shape[1], conv1.weight.shape[0]
+        skip = self._skip_conv1d()
+        if self.use_res and skip is None:
+            return None
+        smp = sampling if sampling is not None else self.sample(p.detach())
+        fuse_skip = skip is not None and fused_wide.lean(C, H)
+        nbr = smp.index
+        if nbr is None or (fuse_skip and nbr.fq is None):
+            nbr = fused_wide.neighbour_index(smp.idx, smp.new_p, p.shape[1], fidx=smp.fidx if fuse_skip else None)
+        new_p = smp.new_p
+        if p.requires_grad:            # the sampled coordinates stay differentiable (the AdaptPoint feedback path)
+            new_p = torch.gather(p, 1, smp.fidx.long().unsqueeze(-1).expand(-1, -1, 3))
+        if fuse_skip or skip is None:
+            out = fused_wide.block(p, new_p, f, nbr, g.radius, conv1, bn1, conv2, bn2, skip_conv=skip,
+                                   relu=(skip is not None) or relu_after, sync_bn=self.sync_bn)
+            return new_p, out
+        pooled = fused_wide.block(p, new_p, f, nbr, g.radius, conv1, bn1, conv2, bn2, relu=False, sync_bn=self.sync_bn)
+        identity = skip(torch.gather(f, -1, smp.fidx.long().unsqueeze(1).expand(-1, C, -1)))
+        return new_p, self.act(pooled + identity)
+
     def sample_many(self, ps, outs=None):
         """Index stages of several batches, FPS of one sharing its launch with the ball query of
         the previous one (adaptpoint_amd.fused.sample_and_query_many)."""
@@ -209,6 +268,8 @@ class SetAbstraction(nn.Module):
             return p, self.convs(f)
         if self.fused and not self.all_aggr:
             res = self._fused_block(p, f, sampling)
+            if res is None:
+                res = self._wide_block(p, f, sampling)
             if res is not None:
                 return res
         idx = None

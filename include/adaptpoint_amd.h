@@ -389,30 +389,31 @@ APN_API int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, cons
 /* The small kernels around those passes (csrc/sa_wide_glue.hip).
  * image: B image of Bm (kd x nc): rows < k0 from src0 (row-major kd x nc, or nc x k0 read transposed when
  *   trans0), the rest from src1 ((kd - k0) x nc); ct column tiles per block.
- * bwd_prep: g (B,O,M; element strides gs_*) -> goa (B,M,O) = g scale2 and
+ * bwd_prep: g (B,O,M; element strides gs_*), zeroed where out_act (B,O,M; NULL: no mask) is not positive
+ *   -> goa (B,M,O) = g scale2, gpre (B,M,O; NULL: not wanted) = g, and
  *   part_s[apn_sa_wide_bwd_prep_rows(b, m)][2*O] = {sum g, sum g yhat_sel}.
  * consts2 / consts1: the BatchNorm backward constants from those rows (or from `sums`: float64
  *   {S[2C], global count, world} all-reduced over ranks): d2e2 = {D2, E2}[O]; cabc = {ca, cb, cc}[H];
  *   dgamma, dbeta (global / world with `sums`).
- * geo: (B,N,4) += {occurrences, sum of the gathering queries' coordinates} per point (caller-zeroed).
- * point_terms: A <- dL/dU = ca A + cb inv1 (occ (U - mean1) - SP . W1p / r) + cc occ (B,N,H);
+ * point_terms: G (B,N,H) = dL/dU = ca (GU rows of the point, summed through the inverse map of apn_sa_wide_csr)
+ *   + cb inv1 (occ (U - mean1) - SP . W1p / r) + cc occ, with geo = {occ, SP} of apn_sa_wide_csr;
  *   HA <- -dL/dV = ca HA + cb HB + 32 cc (B,M,H); w1 (H x ldw) with W1p in its first three columns. */
 APN_API int apn_sa_wide_image(const float *src0, int k0, int trans0, const float *src1, int kd, int nc, int ct,
                               void *image, void *stream);
 APN_API int apn_sa_wide_bwd_prep_rows(int b, int m);
 APN_API int apn_sa_wide_bwd_prep(int b, int m, int c_out, const float *g, long long gs_b, long long gs_c,
-                                 long long gs_m, const float *ysel, const float *pack2, float *goa,
-                                 float *part_s, void *stream);
+                                 long long gs_m, const float *ysel, const float *pack2, const float *out_act,
+                                 float *gpre, float *goa, float *part_s, void *stream);
 APN_API int apn_sa_wide_consts2(const float *part_s, int rows, const double *sums, int c_out,
                                 const float *pack2, double count, int training, float *d2e2,
                                 float *g_gamma2, float *g_beta2, void *stream);
 APN_API int apn_sa_wide_consts1(const float *part_t, int rows, const double *sums, int c_mid,
                                 const float *pack1, double count, int training, float *cabc,
                                 float *g_gamma1, float *g_beta1, void *stream);
-APN_API int apn_sa_wide_geo(int b, int n, int m, const int *idx, const float *new_xyz, float *geo, void *stream);
 APN_API int apn_sa_wide_point_terms(int b, int n, int m, int c_mid, const float *cabc, const float *pack1,
                                     const float *U, const float *geo, const float *w1, int ldw, float radius,
-                                    float *A, float *HA, const float *HB, void *stream);
+                                    const float *GU, const int *pcnt_poff, const int *plist, float *G, float *HA,
+                                    const float *HB, void *stream);
 /* r_part[splits][(O+H) H + H] = partial {[S^T ; a1^T] a1 (rows < O: the sparse part of dL/dW2; the rest:
  * the Gram matrix of a1), sum of a1}; the caller sums the splits (apn_sa_wide_colsum) */
 APN_API int apn_sa_wide_wgrad_splits(int b, int m, int c_mid);
@@ -422,25 +423,33 @@ APN_API int apn_sa_wide_wgrad(int b, int n, int m, int c_mid, int c_out, const f
 
 /* Inverse map of the tile map (index stage): pcnt_poff int32[2 b n] = for every support point the number of
  * rows that gather it and where its list starts in plist int32[32 b m] (row ids tile * 32 + r, ascending);
- * geo float[4 b n] = {occurrences, sum of the gathering queries' coordinates} per point. */
+ * geo float[4 b n] = {occurrences, sum of the gathering queries' coordinates} per point; with fidx (b,m) = the
+ * point every query is (FPS picks) also fq int32[b n] = the query a point is, or -1 (both may be NULL). */
 APN_API int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *new_xyz, const int *tmap,
-                            int *pcnt_poff, int *plist, float *geo, void *stream);
+                            int *pcnt_poff, int *plist, float *geo, const int *fidx, int *fq, void *stream);
 /* The dense kernels of the path (csrc/sa_wide_dense.hip), one launch each:
  * fwd_prep: U (B,N,H) = W1f f + W1p p / r, V (B,M,H) = W1p new_p / r (w1: H x (C+3), coordinates first, as the
  *   reference's cat([dp, fj])), and the B image of W2^T (w2: O x H).
- * out: out (B,O,M) = ysel (B,M,O) scale2 + shift2 (pack2 = {scale, shift, mean, invstd}[O]).
+ * out: out (B,O,M) = act(ysel (B,M,O) scale2 + shift2 + skip) (pack2 = {scale, shift, mean, invstd}[O]);
+ *   skip = ws (O x C) f[:, :, fidx] + bs, the residual branch on the sampled points' features (ws NULL: none;
+ *   bs may be NULL); act = ReLU when relu.
  * bwd_mid: from part_s (or `sums`, as consts2): d2e2, dgamma2, dbeta2, evec[H] = E2 W2 and the B image of
  *   [W2 ; Qm], Qm = W2^T diag(D2) W2.
  * bwd_fin: from part_t (or `sums`, as consts1): cabc, dgamma1, dbeta1; and g_w2 (O,H) = R_S + D2 (W2 Gram)
  *   + E2 (x) suma, with R float64[(O+H) H + H] = {R_S ; Gram ; suma} (apn_sa_wide_wgrad's splits summed).
- * point_grads: G = dL/dU per point (GU rows summed through the inverse map, plus BatchNorm-1's mean/variance
- *   terms), g_f (B,C,N) = G W1f, g_p (B,N,3) = G W1p / r, g_q (B,M,3) = -Hq W1p / r (either may be NULL),
- *   w_part[apn_sa_wide_point_grads_rows(b, n)][H (C+3)] = the workgroups' shares of dL/dW1.
+ * point_grads (C, H <= 64): G = dL/dU per point (GU rows summed through the inverse map, plus BatchNorm-1's
+ *   mean/variance terms), g_f (B,C,N) = G W1f, g_p (B,N,3) = G W1p / r, g_q (B,M,3) = -Hq W1p / r (either may
+ *   be NULL); with a residual branch (c_skip = O > 0: gpre (B,M,O) from bwd_prep, fq (B,N) = the query a point
+ *   is or -1, fidx (B,M), ws (O x C)) g_f also receives ws^T gpre at the sampled points;
+ *   w_part[apn_sa_wide_point_grads_rows(b, n)][apn_sa_wide_point_grads_cols(C, H, O)] = the workgroups' shares
+ *   of {dL/dW1 (H x (C+3)), dL/dws (O x C), dL/dbs (O)}.
  * colsum_f32: out[ncol] (float32) = column sums (in float64, fixed order) of part[rows][ncol]. */
 APN_API int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, int c_out, float radius, const float *f,
                                  const float *p, const float *new_p, const float *w1, const float *w2, float *U,
                                  float *V, void *w2_image, void *stream);
-APN_API int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, float *out, void *stream);
+APN_API int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, int c_in, int n,
+                            const float *f, const int *fidx, const float *ws, const float *bs, int relu, float *out,
+                            void *stream);
 APN_API int apn_sa_wide_bwd_mid(const float *part_s, int rows, const double *sums, int c_mid, int c_out,
                                 const float *pack2, double count, int training, const float *w2, float *d2e2,
                                 float *g_gamma2, float *g_beta2, float *evec, void *z_image, void *stream);
@@ -453,7 +462,9 @@ APN_API int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid, fl
                                     const int *pcnt_poff, const int *plist, const float *geo, const float *U,
                                     const float *f, const float *p, const float *new_p, const float *HA,
                                     const float *HB, const float *cabc, const float *pack1, const float *w1,
+                                    int c_skip, const float *gpre, const int *fq, const int *fidx, const float *ws,
                                     float *g_f, float *g_p, float *g_q, float *w_part, void *stream);
+APN_API int apn_sa_wide_point_grads_cols(int c_in, int c_mid, int c_skip);
 APN_API int apn_sa_wide_colsum_f32(const float *part, int rows, int ncol, float *out, void *stream);
 
 /* Tuning / diagnostic entry, NOT part of the reference boundary: apn_furthest_point_sampling

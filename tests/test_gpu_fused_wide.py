@@ -112,6 +112,87 @@ def test_wide_backward_matches_autograd(dev, cin, N, M, radius, neg_gamma):
         assert v <= 1e-4, (k, v)
 
 
+@pytest.mark.parametrize("cin,N,M,radius", STAGES[:2])
+def test_wide_block_with_residual_branch(dev, cin, N, M, radius):
+    """The whole block on the width-generic kernels, residual branch and final ReLU fused (pointnext.py:150-168):
+    out = relu(max_K(...) + Ws f[:, :, fidx] + bs), against the float64 chain; pooled values with a near-tie and
+    outputs within 1e-4 of the ReLU's kink are taken out of the loss on both sides (see the test above)."""
+    from adaptpoint_amd import fused_wide
+    from adaptpoint_amd.layers import furthest_point_sample
+    p, new_p, f, idx, conv1, bn1, conv2, bn2 = _setup(dev, cin, N, M, radius, seed=7)
+    B = p.shape[0]
+    H, O = conv1.weight.shape[0], conv2.weight.shape[0]
+    fidx = furthest_point_sample(p, M)
+    skip = torch.nn.Conv1d(cin, O, 1).to(dev)
+    nbr = fused_wide.neighbour_index(idx, new_p, N, fidx=fidx)
+    assert fused_wide.lean(cin, H)
+    wts = torch.randn(B, O, M, device=dev, generator=torch.Generator(dev).manual_seed(9))
+    leaves = [t.detach().clone().requires_grad_(True) for t in _chain_args(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2)
+              if torch.is_tensor(t) and t.is_floating_point()]
+    rp, rq, rf, rw1, rg1, rb1, rw2, rg2, rb2 = leaves
+    rws = skip.weight.detach().clone().double().requires_grad_(True)
+    rbs = skip.bias.detach().clone().double().requires_grad_(True)
+    pooled, mid = chain_grad(rp, rq, rf, idx, radius, rw1, rg1, rb1, rw2, rg2, rb2)
+    fs = torch.gather(rf.double(), 2, fidx.long().unsqueeze(1).expand(-1, cin, -1))
+    pre = pooled + torch.einsum('oc,bcm->bom', rws.view(O, cin), fs) + rbs.view(1, -1, 1)
+    ref = torch.relu(pre)
+    with torch.no_grad():
+        z = ((mid["y2"] - mid["m2"]) / torch.sqrt(mid["v2"] + 1e-5) * bn2.weight.double().view(1, -1, 1, 1)
+             + bn2.bias.double().view(1, -1, 1, 1))
+        top2 = z.topk(2, dim=-1).values
+        gap = torch.where(top2[..., 0] == top2[..., 1], torch.ones_like(top2[..., 0]), top2[..., 0] - top2[..., 1])
+        keep = ((gap > 1e-4) & (pre.abs() > 1e-4)).to(wts.dtype)
+    (ref * (wts * keep).double()).sum().backward()
+    want = dict(f=rf.grad, p=rp.grad, newp=rq.grad, w1=rw1.grad, w2=rw2.grad, g1=rg1.grad, b1=rb1.grad,
+                g2=rg2.grad, b2=rb2.grad, ws=rws.grad.view(O, cin), bs=rbs.grad)
+    p.requires_grad_(True); new_p.requires_grad_(True); f.requires_grad_(True)
+    out = fused_wide.block(p, new_p, f, nbr, radius, conv1, bn1, conv2, bn2, skip_conv=skip, relu=True)
+    err = (out.double() - ref).abs()
+    assert err.max() <= 2e-3 and err.mean() <= 2e-5
+    (out * wts * keep).sum().backward()
+    got = dict(f=f.grad, p=p.grad, newp=new_p.grad, w1=conv1.weight.grad.view(H, -1),
+               w2=conv2.weight.grad.view(O, H), g1=bn1.weight.grad, b1=bn1.bias.grad,
+               g2=bn2.weight.grad, b2=bn2.bias.grad, ws=skip.weight.grad.view(O, cin), bs=skip.bias.grad)
+    l2 = {k: _rel_l2(got[k], want[k]) for k in got}
+    print("wide block C_in=%d (%.4f%% masked) rel-L2:" % (cin, 100 * (1 - keep.mean().item())),
+          {k: "%.1e" % v for k, v in l2.items()})
+    assert keep.mean().item() > 0.99
+    for k, v in l2.items():
+        assert v <= 1e-4, (k, v)
+
+
+def test_set_abstraction_module_on_the_wide_kernels_matches_unfused(dev):
+    """SetAbstraction(fused=True) with stage 1 routed to the width-generic kernels (PREFER_WIDE) against the
+    same module unfused: forward to the fused tolerance, gradients in direction (discontinuities, see above)."""
+    import copy
+    from adaptpoint_amd import set_abstraction as SA
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    torch.manual_seed(0)
+    blk = SetAbstraction(32, 64, layers=2, stride=2, fused=False, use_res=True,
+                         group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                         norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'}).to(dev)
+    fz = copy.deepcopy(blk)
+    fz.fused = True
+    p = torch.from_numpy(GI.unit_sphere_cloud(4, 1024, seed=2)).to(dev)
+    f = torch.from_numpy(GI.seeded_normal((4, 32, 1024), seed=3)).to(dev)
+    fa, fb = f.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    SA.PREFER_WIDE = True
+    try:
+        before = len(SA.FUSED_FALLBACKS)
+        qa, oa = fz([p, fa])
+        assert len(SA.FUSED_FALLBACKS) == before
+    finally:
+        SA.PREFER_WIDE = False
+    qb, ob = blk([p, fb])
+    assert torch.equal(qa, qb)
+    assert (oa - ob).abs().max() <= 2e-3 and (oa - ob).abs().mean() <= 2e-5
+    oa.square().sum().backward()
+    ob.square().sum().backward()
+    assert _rel_l2(fa.grad, fb.grad) <= 2e-2
+    for (n1, q1), (_, q2) in zip(fz.named_parameters(), blk.named_parameters()):
+        assert _rel_l2(q1.grad, q2.grad) <= 2e-2, n1
+
+
 @pytest.mark.parametrize("cin,N,M,radius", [STAGES[0], STAGES[2]])
 def test_wide_gradients_are_bit_reproducible(dev, cin, N, M, radius):
     """No float atomics anywhere in the path: the per-point sums run through the index stage's inverse map in a
