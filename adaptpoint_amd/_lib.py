@@ -73,7 +73,8 @@ SIGNATURES = {
     "apn_sa_wide_tilemap": [_c_int] * 3 + [_c_void_p] * 3,
     "apn_sa_wide_stats1": [_c_int] * 4 + [_c_void_p] * 6,
     "apn_sa_wide_fwd_main": [_c_int] * 5 + [_c_void_p] * 11,
-    "apn_sa_wide_bwd_main": [_c_int] * 5 + [_c_void_p] * 14,
+    "apn_sa_wide_bwd_main": [_c_int] * 5 + [_c_void_p] * 15,
+    "apn_sa_wide_wgrad_fused": [_c_int],
     "apn_sa_wide_image": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "apn_sa_wide_bwd_prep_rows": [_c_int] * 2,
     "apn_sa_wide_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] * 7,

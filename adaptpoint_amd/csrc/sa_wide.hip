@@ -31,6 +31,7 @@
 // by the caller (adaptpoint_amd/fused_wide.py::mfma_b_image), one contiguous block per
 // (column block, 32-deep k chunk).
 #include "apn_common.h"
+#include <stdlib.h>
 #include "apn_mfma.h"
 
 namespace apn {
@@ -50,6 +51,9 @@ __device__ __forceinline__ int tm_tiles(const WideArgs &a) { return a.tmap[0]; }
 __device__ __forceinline__ const int *tm_tq0(const WideArgs &a) { return a.tmap + 4; }
 __device__ __forceinline__ const unsigned *tm_rows(const WideArgs &a) {
     return reinterpret_cast<const unsigned *>(a.tmap + 4 + ((a.ntiles + 3) & ~3));
+}
+__device__ __forceinline__ const int *tm_nn(const WideArgs &a) {
+    return a.tmap + 4 + ((a.ntiles + 3) & ~3) + (size_t)32 * a.ntiles;
 }
 __device__ __forceinline__ int ri_q(unsigned info) { return (int)(info & 0xffu); }
 __device__ __forceinline__ int ri_slot(unsigned info) { return (int)((info >> 8) & 0xffu); }
@@ -82,13 +86,14 @@ __global__ __launch_bounds__(256) void wide_stats1_kernel(WideArgs a, float *__r
     for (int tile = blockIdx.x * WIDE_WAVES + w; tile < nt; tile += gridDim.x * WIDE_WAVES) {
         const int q0 = tq0[tile];
         const unsigned *__restrict__ ri = rows + (size_t)tile * 32;
+        const int *__restrict__ rnn = tm_nn(a) + (size_t)tile * 32;
         const float *__restrict__ ub = a.U + (size_t)(q0 / a.m) * a.n * H;
 #pragma unroll 8
         for (int p0 = 0; p0 < 32; p0 += PP) {
             const unsigned info = ri[p0 + (PP == 2 ? (lane >> 5) : 0)];
-            const int q = q0 + ri_q(info);
+            const int q = q0 + (ri_mult(info) ? ri_q(info) : 0);
             const float wgt = (float)ri_mult(info);              // 0: padding row
-            const int nn = a.idx[(size_t)q * 32 + ri_slot(info)];
+            const int nn = rnn[p0 + (PP == 2 ? (lane >> 5) : 0)];
             const float *__restrict__ row = ub + (size_t)nn * H;
             const float *__restrict__ vr = a.V + (size_t)q * H;
 #pragma unroll
@@ -122,13 +127,15 @@ __global__ __launch_bounds__(256) void wide_stats1_kernel(WideArgs a, float *__r
 // Shared pieces of the MFMA kernels
 // ------------------------------------------------------------------------------------------
 // A fragment of a1 = relu(scale1 * (U[n] - V[q]) + shift1): lane (pos r, h), 8 channels from ch0.
-__device__ __forceinline__ Frag<2> a1_frag(const float *__restrict__ row, const float *__restrict__ vq,
-                                           const float *__restrict__ pack1, int H, int ch0, float wgt = 1.0f,
-                                           bool weighted = false) {
-    const float4 u0 = *reinterpret_cast<const float4 *>(row + ch0);
-    const float4 u1 = *reinterpret_cast<const float4 *>(row + ch0 + 4);
-    const float4 v0 = *reinterpret_cast<const float4 *>(vq + ch0);
-    const float4 v1 = *reinterpret_cast<const float4 *>(vq + ch0 + 4);
+// ub / vb: wave-uniform bases (the cloud's rows of U, the tile's rows of V); uo / vo: this lane's row offsets in
+// elements -- 32-bit, so the loads take the scalar-base + vector-offset form (no 64-bit address arithmetic).
+__device__ __forceinline__ Frag<2> a1_frag(const float *__restrict__ ub, unsigned uo, const float *__restrict__ vb,
+                                           unsigned vo, const float *__restrict__ pack1, int H, int ch0,
+                                           float wgt = 1.0f, bool weighted = false) {
+    const float4 u0 = *reinterpret_cast<const float4 *>(ub + (uo + ch0));
+    const float4 u1 = *reinterpret_cast<const float4 *>(ub + (uo + ch0 + 4));
+    const float4 v0 = *reinterpret_cast<const float4 *>(vb + (vo + ch0));
+    const float4 v1 = *reinterpret_cast<const float4 *>(vb + (vo + ch0 + 4));
     const float4 c0 = *reinterpret_cast<const float4 *>(pack1 + ch0);
     const float4 c1 = *reinterpret_cast<const float4 *>(pack1 + ch0 + 4);
     const float4 d0 = *reinterpret_cast<const float4 *>(pack1 + H + ch0);
@@ -147,13 +154,31 @@ __device__ __forceinline__ Frag<2> a1_frag(const float *__restrict__ row, const 
     return make_frag<2>(t);
 }
 
-// The metadata of this lane's 16 accumulator rows acc_row(i, h): 4 runs of 4 consecutive rows.
-__device__ __forceinline__ void load_row_meta(const unsigned *__restrict__ ri, int h, unsigned (&meta)[16]) {
+// What a wave needs to start on a tile: lane (r, h) holds row r's record and neighbour, and the tile's first
+// query.  Loaded one tile AHEAD (the three loads are independent of each other; the rows of U they lead to are
+// the only dependent round trip left in the loop) and SPECULATIVELY: the first head is requested before the
+// number of tiles in use is known (the arrays hold B*M tiles, so any tile < B*M is readable); a head beyond
+// the tiles in use is replaced by `no_tile` (no query, multiplicity 0, addresses of row 0).
+struct TileHead {
+    unsigned info;
+    int nn, q0;
+};
+__device__ __forceinline__ TileHead load_head(const WideArgs &a, int tile, int r) {
+    TileHead t;
+    t.info = tm_rows(a)[(size_t)tile * 32 + r];
+    t.nn = tm_nn(a)[(size_t)tile * 32 + r];
+    t.q0 = tm_tq0(a)[tile];
+    return t;
+}
+__device__ __forceinline__ TileHead no_tile() {
+    TileHead t;
+    t.info = 0xffu; t.nn = 0; t.q0 = 0;
+    return t;
+}
+// The records of this lane's 16 accumulator rows acc_row(i, h) (row p's record sits in lane p).
+__device__ __forceinline__ void row_meta(unsigned info, int h, unsigned (&meta)[16]) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(ri + 8 * g + 4 * h);
-        meta[4 * g] = v.x; meta[4 * g + 1] = v.y; meta[4 * g + 2] = v.z; meta[4 * g + 3] = v.w;
-    }
+    for (int i = 0; i < 16; ++i) meta[i] = (unsigned)__builtin_amdgcn_ds_bpermute(acc_row(i, h) << 2, (int)info);
 }
 
 // One chunk of a B image = CT column tiles x 2 k-steps x {hi, lo} x 64 lanes x 16 bytes.
@@ -215,7 +240,11 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
     extern __shared__ uint4 dyn[];
     uint4 *wl = dyn;                                                 // SLOTS chunks
     float *st = reinterpret_cast<float *>(dyn + SLOTS * Chunk<CT>::WORDS);   // [4 waves][2*O]
-    const int lane = lane_id(), w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int lane = lane_id(), r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int step = gridDim.x * WIDE_WAVES;
+    const int first = blockIdx.x * WIDE_WAVES + w;                   // wave-uniform tile numbers
+    TileHead head = load_head(a, first < a.ntiles ? first : a.ntiles - 1, r);
     for (int e = threadIdx.x; e < WIDE_WAVES * 2 * O; e += 256) st[e] = 0.0f;
     if (RES) {
         for (int ci = 0; ci < NCH; ++ci) stage_chunk<CT>(img, ci, wl + ci * Chunk<CT>::WORDS);
@@ -223,9 +252,6 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
     __syncthreads();
     float *mine = st + w * 2 * O;
     const int nt = tm_tiles(a);
-    const int *__restrict__ tq0 = tm_tq0(a);
-    const unsigned *__restrict__ rows = tm_rows(a);
-    const int step = gridDim.x * WIDE_WAVES;
     const int rounds = (nt + step - 1) / step;
     // streaming: chunk ci of the (cyclic) sequence lives in slot ci & 1; the first one is staged here and
     // every iteration prefetches its successor (the sequence wraps from the last chunk of a tile to chunk 0)
@@ -236,19 +262,22 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
     }
     int seq = 0;                                   // running chunk counter (parity = slot)
     for (int it = 0; it < rounds; ++it) {
-        const int tile_raw = blockIdx.x * WIDE_WAVES + w + it * step;
+        const int tile_raw = first + it * step;
         const bool valid = tile_raw < nt;
-        const int tile = valid ? tile_raw : nt - 1;
-        const unsigned *__restrict__ ri = rows + (size_t)tile * 32;
-        const unsigned info = ri[r];
-        const int q0 = tq0[tile];
-        const int nq = __builtin_amdgcn_readfirstlane((int)(info >> 24));      // lane 0 holds row 0
-        const int ql = q0 + ri_q(info);
-        const int nn = a.idx[(size_t)ql * 32 + ri_slot(info)];
-        const float *__restrict__ row = a.U + ((size_t)(q0 / a.m) * a.n + nn) * H;
-        const float *__restrict__ vq = a.V + (size_t)ql * H;
+        const TileHead cur = valid ? head : no_tile();
+        {
+            const int nx = tile_raw + step;
+            head = load_head(a, nx < a.ntiles ? nx : a.ntiles - 1, r);          // consumed by the next iteration
+        }
+        const int q0 = __builtin_amdgcn_readfirstlane(cur.q0);
+        const int nq = __builtin_amdgcn_readfirstlane((int)(cur.info >> 24));      // lane 0 holds row 0
+        const float *__restrict__ ub = a.U + (size_t)(q0 / a.m) * a.n * H;         // wave-uniform bases
+        const float *__restrict__ vb = a.V + (size_t)q0 * H;
+        const unsigned uo = (unsigned)cur.nn * H, vo = (ri_mult(cur.info) ? ri_q(cur.info) : 0u) * H;
+        float *__restrict__ ysel0 = ysel + (size_t)q0 * O;
+        unsigned char *__restrict__ ksel0 = ksel + (size_t)q0 * O;
         unsigned meta[16];
-        load_row_meta(ri, h, meta);
+        row_meta(cur.info, h, meta);
 #pragma unroll 1
         for (int cb = 0; cb < NCB; ++cb) {
             f32x16 acc[CT];
@@ -268,7 +297,7 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
                 }
                 Frag<2> af[2];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) af[s] = a1_frag(row, vq, pack1, H, kc * 32 + s * 16 + h * 8);
+                for (int s = 0; s < 2; ++s) af[s] = a1_frag(ub, uo, vb, vo, pack1, H, kc * 32 + s * 16 + h * 8);
 #pragma unroll
                 for (int j = 0; j < CT; ++j)
 #pragma unroll
@@ -287,36 +316,40 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
                 const int col = (cb * CT + j) * 32 + r;
                 const float sg = sgn2[col];
                 float s1 = 0.0f, s2 = 0.0f;
+                float v[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float y = acc[j][i];
                     const float wy = (float)ri_mult(meta[i]) * y;            // the row stands for `mult` positions
                     s1 += wy;
                     s2 = __builtin_fmaf(wy, y, s2);
+                    v[i] = y * sg;
                 }
                 s1 += shfl_xor32(s1);
                 s2 += shfl_xor32(s2);
-                if (h == 0 && valid) {
+                if (h == 0) {                            // (a tile beyond the map has multiplicity 0 everywhere)
                     mine[col] += s1;                     // this wave owns its row of `st`: plain update
                     mine[O + col] += s2;
                 }
-                // the pool, query by query: rows ascend with the slot, so the first maximum is the lowest slot
+                // the pool, query by query (padding rows carry query 255: never selected); rows ascend with
+                // the slot, so the first maximum is the lowest slot
 #pragma unroll 1
                 for (int jq = 0; jq < nq; ++jq) {
                     float best = -__builtin_inff();
-                    int bslot = 0;
+                    int bi = 0;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const float v = acc[j][i] * sg;
-                        const bool in = (meta[i] & 0xff00ffu) > 0xffffu && ri_q(meta[i]) == jq;   // mult > 0, this query
-                        if (in && v > best) { best = v; bslot = ri_slot(meta[i]); }
+                        const bool up = ri_q(meta[i]) == jq && v[i] > best;
+                        best = up ? v[i] : best;
+                        bi = up ? (int)meta[i] : bi;
                     }
+                    int bslot = ri_slot((unsigned)bi);
                     const float ob = shfl_xor32(best);
                     const int op = shfl_xor32i(bslot);
                     if (ob > best || (ob == best && op < bslot)) { best = ob; bslot = op; }
-                    if (h == 0 && valid) {
-                        ysel[(size_t)(q0 + jq) * O + col] = best * sg;
-                        ksel[(size_t)(q0 + jq) * O + col] = (unsigned char)bslot;
+                    if (h == 0) {
+                        ysel0[(unsigned)(jq * O + col)] = best * sg;
+                        ksel0[(unsigned)(jq * O + col)] = (unsigned char)bslot;
                     }
                 }
             }
@@ -338,30 +371,37 @@ __global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const ui
 //   img: B image of Z = [W2 ; Qm] ((O + H) x H), CT = min(4, H/32) column tiles per block.
 //   pack1 = {scale1, shift1, mean1, invstd1}[H].
 // ------------------------------------------------------------------------------------------
-template <int H, int O, int CT, bool RES>
-__global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const uint4 *__restrict__ img,
-                                                            const float *__restrict__ pack1,
-                                                            const float *__restrict__ evec,
-                                                            const float *__restrict__ goa,
-                                                            const unsigned char *__restrict__ ksel,
-                                                            float *__restrict__ GU, float *__restrict__ HA,
-                                                            float *__restrict__ HB, float *__restrict__ part) {
+template <int H, int O, int CT, bool RES, bool WG, int OCC>
+__global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, const uint4 *__restrict__ img,
+                                                                 const float *__restrict__ pack1,
+                                                                 const float *__restrict__ evec,
+                                                                 const float *__restrict__ goa,
+                                                                 const unsigned char *__restrict__ ksel,
+                                                                 float *__restrict__ GU, float *__restrict__ HA,
+                                                                 float *__restrict__ HB, float *__restrict__ part,
+                                                                 float *__restrict__ Rpart) {
     constexpr int NKS = O / 32, NKC = (O + H) / 32, NCB = H / (32 * CT), NCH = NKC * NCB;
     constexpr int SLOTS = RES ? NCH : 2;
+    static_assert(!WG || (H == 32 && O == 64 && CT == 1), "the fused weight-gradient products are for H = 32");
+    constexpr int A1LD = 36;                                          // row stride of the a1 tile in LDS (16-byte rows, banks spread)
+    constexpr int RW = (O + H) * H + H, RWP = (O + H) * (H + 1) + H;  // the workgroup's {R_S ; Gram ; suma}: dense / padded rows
     extern __shared__ uint4 dyn[];
     uint4 *wl = dyn;
     float *st = reinterpret_cast<float *>(dyn + SLOTS * Chunk<CT>::WORDS);   // [4 waves][2*H]
-    const int lane = lane_id(), w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    float *wgl = st + WIDE_WAVES * 2 * H;                                    // WG: [4 waves] a1 tiles, later the fold
+    const int lane = lane_id(), r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int step = gridDim.x * WIDE_WAVES;
+    const int first = blockIdx.x * WIDE_WAVES + w;                   // wave-uniform tile numbers
+    TileHead head = load_head(a, first < a.ntiles ? first : a.ntiles - 1, r);
     for (int e = threadIdx.x; e < WIDE_WAVES * 2 * H; e += 256) st[e] = 0.0f;
     if (RES) {
         for (int ci = 0; ci < NCH; ++ci) stage_chunk<CT>(img, ci, wl + ci * Chunk<CT>::WORDS);
     }
     __syncthreads();
     float *mine = st + w * 2 * H;
+    float *a1s = wgl + w * 32 * A1LD;                                // this wave's a1 tile [row][mid]
     const int nt = tm_tiles(a);
-    const int *__restrict__ tq0 = tm_tq0(a);
-    const unsigned *__restrict__ rows = tm_rows(a);
-    const int step = gridDim.x * WIDE_WAVES;
     const int rounds = (nt + step - 1) / step;
     ChunkRegs<CT> pre;
     if (!RES) {
@@ -369,32 +409,65 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
         __syncthreads();
     }
     int seq = 0;
-    for (int it = 0; it < rounds; ++it) {
-        const int tile_raw = blockIdx.x * WIDE_WAVES + w + it * step;
-        const bool valid = tile_raw < nt;
-        const int tile = valid ? tile_raw : nt - 1;
-        const unsigned *__restrict__ ri = rows + (size_t)tile * 32;
-        const unsigned info = ri[r];
-        const int q0 = tq0[tile];
-        const int nq = __builtin_amdgcn_readfirstlane((int)(info >> 24));
-        const int cloud = q0 / a.m;
-        const int ql = q0 + ri_q(info), rslot = ri_slot(info);
-        const bool live = ri_mult(info) != 0;
-        const float wrow = (float)ri_mult(info);
-        const int nn = a.idx[(size_t)ql * 32 + rslot];
-        const float *__restrict__ ub = a.U + (size_t)cloud * a.n * H;
-        const float *__restrict__ row = ub + (size_t)nn * H;
-        const float *__restrict__ vq = a.V + (size_t)ql * H;
-        const float *__restrict__ gq = goa + (size_t)ql * O;
-        const unsigned char *__restrict__ kq = ksel + (size_t)ql * O;
-        // metadata and neighbour of every accumulator row of this lane (row p's neighbour sits in lane p)
-        unsigned meta[16];
-        load_row_meta(ri, h, meta);
-        int nrow[16];
+    // fused weight-gradient products (WG): Gram = a1^T diag(mult) a1 (MFMA, H x H), R_S = S^T a1 (O x H: lane =
+    // output channel c, exact fp32 sums of the pooled rows of a1), suma
+    f32x16 gram;
+    float sacc[WG ? H : 1];
+    float suma = 0.0f;
+    if (WG) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) nrow[i] = __builtin_amdgcn_ds_bpermute(acc_row(i, h) << 2, nn);
+        for (int i = 0; i < 16; ++i) gram[i] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < H; ++m) sacc[m] = 0.0f;
+    }
+    for (int it = 0; it < rounds; ++it) {
+        const int tile_raw = first + it * step;
+        const bool valid = tile_raw < nt;
+        const int tile = valid ? tile_raw : 0;
+        const TileHead cur = valid ? head : no_tile();
+        {
+            const int nx = tile_raw + step;
+            head = load_head(a, nx < a.ntiles ? nx : a.ntiles - 1, r);
+        }
+        const int q0 = __builtin_amdgcn_readfirstlane(cur.q0);
+        const int nq = __builtin_amdgcn_readfirstlane((int)(cur.info >> 24));
+        const bool live = ri_mult(cur.info) != 0;
+        const unsigned qloc = live ? ri_q(cur.info) : 0u;
+        const int rslot = ri_slot(cur.info);
+        const float wrow = (float)ri_mult(cur.info);
+        // wave-uniform bases; per-lane offsets stay 32-bit
+        const float *__restrict__ ub = a.U + (size_t)(q0 / a.m) * a.n * H;
+        const float *__restrict__ vb = a.V + (size_t)q0 * H;
+        const float *__restrict__ gb = goa + (size_t)q0 * O;
+        const unsigned char *__restrict__ kb = ksel + (size_t)q0 * O;
+        float *__restrict__ gub = GU + (size_t)tile * 32 * H;
+        float *__restrict__ hab = HA + (size_t)q0 * H;
+        float *__restrict__ hbb = HB + (size_t)q0 * H;
+        const unsigned uo = (unsigned)cur.nn * H, vo = qloc * H, go = qloc * O;
+        // record and neighbour of every accumulator row of this lane (row p's sit in lane p)
+        unsigned meta[16];
+        row_meta(cur.info, h, meta);
+        unsigned urow[16], vrow[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            urow[i] = (unsigned)__builtin_amdgcn_ds_bpermute(acc_row(i, h) << 2, (int)uo);
+            vrow[i] = (ri_mult(meta[i]) ? ri_q(meta[i]) : 0u) * H;
+        }
 #pragma unroll 1
         for (int cb = 0; cb < NCB; ++cb) {
+            // this lane's y1 operands of the epilogue (lane = mid channel): issued before the MFMA chain
+            float u[CT <= 2 ? CT : 1][16], vv[CT <= 2 ? CT : 1][16];
+            if (CT <= 2) {
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const unsigned mid = (cb * CT + j) * 32 + r;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        u[j][i] = ub[urow[i] + mid];
+                        vv[j][i] = vb[vrow[i] + mid];
+                    }
+                }
+            }
             f32x16 acc[CT];
 #pragma unroll
             for (int j = 0; j < CT; ++j)
@@ -414,10 +487,10 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
                 if (kc < NKS) {            // rows of S: the upstream gradient at the pooled slot
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const int c0 = kc * 32 + s * 16 + h * 8;
-                        const float4 g0 = *reinterpret_cast<const float4 *>(gq + c0);
-                        const float4 g1 = *reinterpret_cast<const float4 *>(gq + c0 + 4);
-                        const uint2 kk = *reinterpret_cast<const uint2 *>(kq + c0);
+                        const unsigned c0 = go + kc * 32 + s * 16 + h * 8;
+                        const float4 g0 = *reinterpret_cast<const float4 *>(gb + c0);
+                        const float4 g1 = *reinterpret_cast<const float4 *>(gb + (c0 + 4));
+                        const uint2 kk = *reinterpret_cast<const uint2 *>(kb + c0);
                         float t[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -429,7 +502,7 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
                 } else {
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
-                        af[s] = a1_frag(row, vq, pack1, H, (kc - NKS) * 32 + s * 16 + h * 8, wrow, true);
+                        af[s] = a1_frag(ub, uo, vb, vo, pack1, H, (kc - NKS) * 32 + s * 16 + h * 8, wrow, true);
                 }
 #pragma unroll
                 for (int j = 0; j < CT; ++j)
@@ -444,32 +517,36 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
             // epilogue: lane = mid channel, register = row of the tile
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
-                const int mid = (cb * CT + j) * 32 + r;
+                const unsigned mid = (cb * CT + j) * 32 + r;
                 const float sc = pack1[mid], sh = pack1[H + mid], mu = pack1[2 * H + mid], iv = pack1[3 * H + mid];
                 const float ev = evec[mid];
                 float t1 = 0.0f, t2 = 0.0f;
-                float u[16], vv[16];
+                float gu[16], yw[16];
+                float a1r[WG ? 16 : 1];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    u[i] = ub[(size_t)nrow[i] * H + mid];
-                    vv[i] = a.V[(size_t)(q0 + ri_q(meta[i])) * H + mid];
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
+                    float ui, vi;
+                    if (CT <= 2) { ui = u[j][i]; vi = vv[j][i]; }
+                    else { ui = ub[urow[i] + mid]; vi = vb[vrow[i] + mid]; }
                     const float wgt = (float)ri_mult(meta[i]);
-                    const float y1 = u[i] - vv[i];
+                    const float y1 = ui - vi;
                     const float yh = (y1 - mu) * iv;
+                    const float pre1 = __builtin_fmaf(y1, sc, sh);
                     // the row's `mult` positions share a1; only one of them can hold a pooled slot (S)
-                    const float gu = __builtin_fmaf(y1, sc, sh) > 0.0f ? __builtin_fmaf(ev, wgt, acc[j][i]) : 0.0f;
-                    t1 += gu;
-                    t2 = __builtin_fmaf(gu, yh, t2);
-                    if (valid && wgt != 0.0f) GU[((size_t)tile * 32 + acc_row(i, h)) * H + mid] = gu;
-                    u[i] = gu;                       // kept for the per-query sums
-                    vv[i] = wgt * yh;
+                    const float g = pre1 > 0.0f ? __builtin_fmaf(ev, wgt, acc[j][i]) : 0.0f;
+                    t1 += g;
+                    t2 = __builtin_fmaf(g, yh, t2);
+                    if (wgt != 0.0f) gub[(unsigned)(acc_row(i, h) * H) + mid] = g;
+                    gu[i] = g;
+                    yw[i] = wgt * yh;
+                    if (WG) {
+                        a1r[i] = pre1 > 0.0f ? pre1 : 0.0f;
+                        a1s[acc_row(i, h) * A1LD + r] = a1r[i];
+                    }
                 }
                 t1 += shfl_xor32(t1);
                 t2 += shfl_xor32(t2);
-                if (h == 0 && valid) {
+                if (h == 0) {
                     mine[mid] += t1;
                     mine[H + mid] += t2;
                 }
@@ -478,15 +555,48 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
                     float ha = 0.0f, hb = 0.0f;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const bool in = ri_q(meta[i]) == jq;     // padding rows carry zeros
-                        ha += in ? u[i] : 0.0f;
-                        hb += in ? vv[i] : 0.0f;
+                        const bool in = ri_q(meta[i]) == jq;     // padding rows carry query 255
+                        ha += in ? gu[i] : 0.0f;
+                        hb += in ? yw[i] : 0.0f;
                     }
                     ha += shfl_xor32(ha);
                     hb += shfl_xor32(hb);
-                    if (h == 0 && valid) {
-                        HA[(size_t)(q0 + jq) * H + mid] = ha;
-                        HB[(size_t)(q0 + jq) * H + mid] = hb;
+                    if (h == 0) {
+                        hab[(unsigned)(jq * H) + mid] = ha;
+                        hbb[(unsigned)(jq * H) + mid] = hb;
+                    }
+                }
+                if (WG) {
+                    // Gram += (mult a1)^T a1: a1 in the accumulator layout (lane = mid, register = row) IS an MFMA
+                    // operand whose k index runs over the tile's rows in register order, the same on both sides
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        float tb[8], ta[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            tb[e] = a1r[8 * s + e];
+                            ta[e] = tb[e] * (float)ri_mult(meta[8 * s + e]);
+                            suma += ta[e];
+                        }
+                        gram = mfma<2>(make_frag<2>(ta), make_frag<2>(tb), gram);
+                    }
+                    // R_S[c][:] += goa[q][c] a1[row of (q, ksel[q][c])][:], lane = c: the pooled row of a1 comes from
+                    // this wave's LDS tile (written above; LDS executes a wave's instructions in order)
+#pragma unroll 1
+                    for (int jq = 0; jq < nq; ++jq) {
+                        const unsigned long long mine_q = __ballot(lane < 32 && live && ri_q(cur.info) == (unsigned)jq);
+                        const int row0 = __builtin_ctzll(mine_q);                    // first row of query jq in the tile
+                        const float gv = gb[(unsigned)(jq * O) + lane];
+                        const int kr = row0 + (int)kb[(unsigned)(jq * O) + lane];
+                        const float4 *__restrict__ ar = reinterpret_cast<const float4 *>(a1s + kr * A1LD);
+#pragma unroll
+                        for (int m4 = 0; m4 < H / 4; ++m4) {
+                            const float4 x = ar[m4];
+                            sacc[4 * m4] = __builtin_fmaf(gv, x.x, sacc[4 * m4]);
+                            sacc[4 * m4 + 1] = __builtin_fmaf(gv, x.y, sacc[4 * m4 + 1]);
+                            sacc[4 * m4 + 2] = __builtin_fmaf(gv, x.z, sacc[4 * m4 + 2]);
+                            sacc[4 * m4 + 3] = __builtin_fmaf(gv, x.w, sacc[4 * m4 + 3]);
+                        }
                     }
                 }
             }
@@ -495,6 +605,23 @@ __global__ __launch_bounds__(256) void wide_bwd_main_kernel(WideArgs a, const ui
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * H; e += 256)
         part[(size_t)blockIdx.x * 2 * H + e] = (st[e] + st[2 * H + e]) + (st[4 * H + e] + st[6 * H + e]);
+    if (WG) {
+        // the workgroup's {R_S ; Gram ; suma}: the four waves fold through LDS (rows padded to H + 1: lane c writes
+        // row c), one partial row per workgroup
+        float *mywr = wgl + w * RWP;
+        suma += shfl_xor32(suma);
+#pragma unroll
+        for (int m = 0; m < H; ++m) mywr[lane * (H + 1) + m] = sacc[m];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mywr[(O + acc_row(i, h)) * (H + 1) + r] = gram[i];
+        if (h == 0) mywr[(O + H) * (H + 1) + r] = suma;
+        __syncthreads();
+        for (int e = threadIdx.x; e < RW; e += 256) {
+            const int row = e / H, col = e - row * H;
+            const int src = row < O + H ? row * (H + 1) + col : (O + H) * (H + 1) + col;
+            Rpart[(size_t)blockIdx.x * RW + e] = (wgl[src] + wgl[RWP + src]) + (wgl[2 * RWP + src] + wgl[3 * RWP + src]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -542,8 +669,8 @@ __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const f
         __syncthreads();                                               // previous tile's reads are done
         if (threadIdx.x < 32) {
             const unsigned info = rows[(size_t)tile * 32 + threadIdx.x];
-            rinfo[threadIdx.x] = info;
-            rnb[threadIdx.x] = a.idx[(size_t)(q0 + ri_q(info)) * 32 + ri_slot(info)];
+            rinfo[threadIdx.x] = ri_mult(info) ? info : (info & ~0xffu);        // padding: query 0 of the tile
+            rnb[threadIdx.x] = tm_nn(a)[(size_t)tile * 32 + threadIdx.x];
         }
         __syncthreads();
 #pragma unroll
@@ -683,8 +810,9 @@ template <int H>
 static constexpr bool bwd_res() { return (size_t)(3 * H / 32) * (H / (32 * bwd_ct<H>())) * Chunk<bwd_ct<H>()>::WORDS * 16 <= 48 * 1024; }
 
 static int wide_grid(int ntiles) {
+    static const int cap = getenv("APN_WIDE_GRID") ? atoi(getenv("APN_WIDE_GRID")) : 512;          // TUNING HOOK
     const int want = (ntiles + WIDE_WAVES - 1) / WIDE_WAVES;
-    return want < 512 ? want : 512;            // two workgroups per CU; every workgroup leaves one partial row
+    return want < cap ? want : cap;            // two workgroups per CU; every workgroup leaves one partial row
 }
 
 }  // namespace apn
@@ -765,23 +893,37 @@ extern "C" int apn_sa_wide_fwd_main(int b, int n, int m, int c_mid, int c_out, c
 extern "C" int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
                                     const int *idx, const int *tmap, const void *z_image, const float *pack1,
                                     const float *evec, const float *goa, const void *ksel, float *GU,
-                                    float *HA, float *HB, float *part, void *stream) {
+                                    float *HA, float *HB, float *part, float *r_part, void *stream) {
     if (!wide_args_ok(b, n, m, U, V, idx, tmap) || !wide_shape_ok(c_mid, c_out)) return APN_EINVAL;
     if (!z_image || !pack1 || !evec || !goa || !ksel || !GU || !HA || !HB || !part) return APN_EINVAL;
+    if (c_mid == 32 && !r_part) return APN_EINVAL;
     WideArgs a{b * m, n, m, U, V, idx, tmap};
     const int grid = wide_grid(a.ntiles);
     APN_WIDE_DISPATCH(c_mid, {
         constexpr int O = 2 * H, CT = bwd_ct<H>();
         constexpr bool RES = bwd_res<H>();
+        constexpr bool WG = H == 32;
         constexpr int NCH = ((O + H) / 32) * (H / (32 * CT));
-        const size_t lds = (size_t)(RES ? NCH : 2) * Chunk<CT>::WORDS * 16 + (size_t)WIDE_WAVES * 2 * H * 4;
-        hipLaunchKernelGGL((wide_bwd_main_kernel<H, O, CT, RES>), dim3(grid), dim3(256), lds,
+        const size_t lds = (size_t)(RES ? NCH : 2) * Chunk<CT>::WORDS * 16 + (size_t)WIDE_WAVES * 2 * H * 4 +
+                           (WG ? (size_t)WIDE_WAVES * ((O + H) * (H + 1) + H) * 4 : 0);
+        static const int occ_env = getenv("APN_WIDE_OCC") ? atoi(getenv("APN_WIDE_OCC")) : 0;     // TUNING HOOK
+        const bool occ2 = H <= 64 && occ_env != 1;
+        auto kern = occ2 ? wide_bwd_main_kernel<H, O, CT, RES, WG, (H <= 64 ? 2 : 1)> : wide_bwd_main_kernel<H, O, CT, RES, WG, 1>;
+        if (lds > 48 * 1024) {
+            if (hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+                return (int)e;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds,
                            (hipStream_t)stream, a, (const uint4 *)z_image, pack1, evec, goa,
-                           (const unsigned char *)ksel, GU, HA, HB, part);
+                           (const unsigned char *)ksel, GU, HA, HB, part, r_part);
     });
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
+
+// 1: the weight-gradient products {[S^T ; a1^T] a1, sum a1} come out of apn_sa_wide_bwd_main itself, as
+// r_part[apn_sa_wide_grid][(O+H) H + H]; 0: apn_sa_wide_wgrad computes them in its own pass.
+extern "C" int apn_sa_wide_wgrad_fused(int c_mid) { return c_mid == 32 ? 1 : 0; }
 
 extern "C" int apn_sa_wide_wgrad_splits(int b, int m, int c_mid) {
     if (b <= 0 || m <= 0 || !wide_shape_ok(c_mid, 2 * c_mid)) return 0;

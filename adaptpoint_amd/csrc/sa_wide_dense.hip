@@ -27,7 +27,7 @@ namespace apn {
 // weights are wave-uniform: scalar loads), the tile leaves through LDS as whole rows of U.
 // ------------------------------------------------------------------------------------------
 template <int HPW>
-__global__ __launch_bounds__(256) void wide_fwd_prep_kernel(int B, int C, int N, int M, int pblocks, int qblocks,
+__global__ __launch_bounds__(256, 2) void wide_fwd_prep_kernel(int B, int C, int N, int M, int pblocks, int qblocks,
                                                             const float *__restrict__ f, const float *__restrict__ p,
                                                             const float *__restrict__ new_p,
                                                             const float *__restrict__ w1, float inv_r,
@@ -49,18 +49,18 @@ __global__ __launch_bounds__(256) void wide_fwd_prep_kernel(int B, int C, int N,
         float acc[HPW];
 #pragma unroll
         for (int hh = 0; hh < HPW; ++hh) acc[hh] = 0.0f;
-        for (int c0 = 0; c0 < C; c0 += 8) {
-            float fv[8];
+        const float px = p[ptc * 3], py = p[ptc * 3 + 1], pz = p[ptc * 3 + 2];
+        for (int c0 = 0; c0 < C; c0 += 32) {
+            float fv[32];                                        // one round trip for 32 channels of this point
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fv[j] = c0 + j < C ? fb[(size_t)(c0 + j) * N] : 0.0f;
-#pragma unroll
+            for (int j = 0; j < 32; ++j) fv[j] = c0 + j < C ? fb[(size_t)(c0 + j) * N] : 0.0f;
+#pragma unroll 2
             for (int hh = 0; hh < HPW; ++hh) {
-                const float *__restrict__ wr = w1 + (size_t)(h0 + hh) * ldw + 3 + c0;
+                const float *__restrict__ wr = w1 + (size_t)(h0 + hh) * ldw + 3 + c0;       // wave-uniform: scalar loads
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[hh] = __builtin_fmaf(c0 + j < C ? wr[j] : 0.0f, fv[j], acc[hh]);
+                for (int j = 0; j < 32; ++j) acc[hh] = __builtin_fmaf(c0 + j < C ? wr[j] : 0.0f, fv[j], acc[hh]);
             }
         }
-        const float px = p[ptc * 3], py = p[ptc * 3 + 1], pz = p[ptc * 3 + 2];
 #pragma unroll
         for (int hh = 0; hh < HPW; ++hh) {
             const float *__restrict__ wr = w1 + (size_t)(h0 + hh) * ldw;
@@ -171,109 +171,92 @@ __global__ __launch_bounds__(1024) void wide_bwd_mid_kernel(const float *__restr
                                                             float *__restrict__ d2e2, float *__restrict__ g_gamma2,
                                                             float *__restrict__ g_beta2, float *__restrict__ evec,
                                                             uint4 *__restrict__ zimg) {
+    // Everything a block needs arrives in ONE round of loads (the kernel is a chain of dependent steps on a few
+    // KB: its time is the number of round trips, not the bytes): W2 (O x H <= 32 KB) and the rows of partS.
     extern __shared__ double dsm[];
-    double *red = dsm;                                            // [16][64]
-    float *de = reinterpret_cast<float *>(dsm + 16 * 64);         // D2[O], E2[O]
-    float *qt = de + 2 * O;                                       // [32][32 ct + 1]
+    double *red = dsm;                                            // [1024]
+    double *S = red + 1024;                                       // S1 | S2 [2 O]
+    float *de = reinterpret_cast<float *>(S + 2 * O);             // D2[O], E2[O]
+    float *w2s = de + 2 * O;                                      // [O][H + 1]
+    float *qt = w2s + O * (H + 1);                                // [32][32 ct + 1]
     const int nkc = (O + H) / 32;
     const int cb = blockIdx.x / nkc, kc = blockIdx.x % nkc;
     const bool qm_rows = kc >= O / 32;
     const int t = threadIdx.x;
-    if (qm_rows || blockIdx.x == 0) {
-        double gscale = 1.0;
-        if (sums) { count = sums[2 * O]; gscale = 1.0 / sums[2 * O + 1]; }
-        const int tx = t & 63, ty = t >> 6;                       // 64 columns x 16 row groups
-        for (int c0 = 0; c0 < 2 * O; c0 += 64) {
-            const int c = c0 + tx;                                // column of partS: S1 | S2
-            double s = 0.0;
-            if (!sums) {
-                int r = ty;
-                for (; r + 48 < rows; r += 64) {
-                    const float v0 = partS[(size_t)r * 2 * O + c], v1 = partS[(size_t)(r + 16) * 2 * O + c];
-                    const float v2 = partS[(size_t)(r + 32) * 2 * O + c], v3 = partS[(size_t)(r + 48) * 2 * O + c];
-                    s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
-                }
-                for (; r < rows; r += 16) s += (double)partS[(size_t)r * 2 * O + c];
-            }
-            __syncthreads();
-            red[ty * 64 + tx] = s;
-            __syncthreads();
-            if (ty == 0) {                                       // qt is free here: it holds S1 | S2 as [2 O] float64
-                double tot = 0.0;
-                if (sums) tot = sums[c];
-                else
+    const int ncol = 2 * O, groups = 1024 / ncol;                 // 2 O <= 256: >= 4 row groups
+    const int col = t % ncol, grp = t / ncol;
+    double gscale = 1.0;
+    if (sums) { count = sums[2 * O]; gscale = 1.0 / sums[2 * O + 1]; }
+    double acc = 0.0;
+    if (!sums && grp < groups) {
+        for (int r0 = grp; r0 < rows; r0 += 16 * groups) {        // 16 independent loads in flight
+            float v[16];
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) tot += red[g * 64 + tx];
-                reinterpret_cast<double *>(qt)[c] = tot;
-            }
+            for (int u = 0; u < 16; ++u) v[u] = r0 + u * groups < rows ? partS[(size_t)(r0 + u * groups) * ncol + col] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += (double)v[u];
         }
-        __syncthreads();
-        const double *S = reinterpret_cast<const double *>(qt);
-        double dv = 0.0, ev = 0.0, s1 = 0.0, s2 = 0.0;
-        if (t < O) {
-            s1 = S[t]; s2 = S[O + t];
-            const double sc = pack2[t], mu = pack2[2 * O + t], iv = pack2[3 * O + t];
-            if (training) {
-                dv = -sc * iv * s2 / count;
-                ev = -sc * s1 / count + sc * mu * iv * s2 / count;
-            }
+    }
+    for (int e = t; e < O * H; e += 1024) w2s[(e / H) * (H + 1) + e % H] = w2[e];
+    red[t] = acc;
+    __syncthreads();
+    if (t < ncol) {
+        double tot = 0.0;
+        if (sums) tot = sums[t];
+        else
+            for (int g = 0; g < groups; ++g) tot += red[g * ncol + t];
+        S[t] = tot;
+    }
+    __syncthreads();
+    if (t < O) {
+        const double s1 = S[t], s2 = S[O + t];
+        const double sc = pack2[t], mu = pack2[2 * O + t], iv = pack2[3 * O + t];
+        double dv = 0.0, ev = 0.0;
+        if (training) {
+            dv = -sc * iv * s2 / count;
+            ev = -sc * s1 / count + sc * mu * iv * s2 / count;
         }
-        __syncthreads();                                          // everyone has read S before qt is reused
-        if (t < O) {
-            de[t] = (float)dv;
-            de[O + t] = (float)ev;
-            if (blockIdx.x == 0) {
-                d2e2[t] = (float)dv;
-                d2e2[O + t] = (float)ev;
-                if (g_gamma2) g_gamma2[t] = (float)(s2 * gscale);
-                if (g_beta2) g_beta2[t] = (float)(s1 * gscale);
-            }
+        de[t] = (float)dv;
+        de[O + t] = (float)ev;
+        if (blockIdx.x == 0) {
+            d2e2[t] = (float)dv;
+            d2e2[O + t] = (float)ev;
+            if (g_gamma2) g_gamma2[t] = (float)(s2 * gscale);
+            if (g_beta2) g_beta2[t] = (float)(s1 * gscale);
         }
-        __syncthreads();
-        if (blockIdx.x == 0 && t < H) {
-            float e = 0.0f;
-            for (int c = 0; c < O; ++c) e = __builtin_fmaf(de[O + c], w2[(size_t)c * H + t], e);
-            evec[t] = e;
-        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && t < H) {
+        float e = 0.0f;
+        for (int c = 0; c < O; ++c) e = __builtin_fmaf(de[O + c], w2s[c * (H + 1) + t], e);
+        evec[t] = e;
     }
     const int words = ct * 256;                                   // [j][s][part][lane] of this chunk
     uint4 *__restrict__ dst = zimg + (size_t)blockIdx.x * words;
-    if (!qm_rows) {
-        if (t < words) {
-            const int lane = t & 63, part = (t >> 6) & 1, s = (t >> 7) & 1, j = t >> 8;
-            const int col = (cb * ct + j) * 32 + (lane & 31), k0 = kc * 32 + s * 16 + (lane >> 5) * 8;
-            bf16x8 o;
+    if (qm_rows) {
+        // Qm tile: rows k' = kq0 + (t >> 5), columns mid0 + 32 j + (t & 31);  Qm = W2^T diag(D2) W2
+        const int kq = (kc - O / 32) * 32 + (t >> 5), r = t & 31, mid0 = cb * ct * 32;
+        float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c = 0; c < O; ++c) {
+            const float a = w2s[c * (H + 1) + kq] * de[c];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = w2[(size_t)(k0 + e) * H + col];
-                const __bf16 hi = (__bf16)v;
-                o[e] = part == 0 ? hi : (__bf16)(v - (float)hi);
-            }
-            dst[t] = __builtin_bit_cast(uint4, o);
+            for (int j = 0; j < 4; ++j)
+                if (j < ct) q[j] = __builtin_fmaf(a, w2s[c * (H + 1) + mid0 + 32 * j + r], q[j]);
         }
-        return;
-    }
-    // Qm tile: rows k' = kq0 + (t >> 5), columns mid0 + 32 j + (t & 31)
-    const int kq = (kc - O / 32) * 32 + (t >> 5), r = t & 31, mid0 = cb * ct * 32;
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int c = 0; c < O; ++c) {
-        const float a = w2[(size_t)c * H + kq] * de[c];
+        const int ldq = 32 * ct + 1;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (j < ct) acc[j] = __builtin_fmaf(a, w2[(size_t)c * H + mid0 + 32 * j + r], acc[j]);
+            if (j < ct) qt[(t >> 5) * ldq + 32 * j + r] = q[j];
+        __syncthreads();
     }
-    const int ldq = 32 * ct + 1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (j < ct) qt[(t >> 5) * ldq + 32 * j + r] = acc[j];
-    __syncthreads();
     if (t < words) {
         const int lane = t & 63, part = (t >> 6) & 1, s = (t >> 7) & 1, j = t >> 8;
-        const int col = j * 32 + (lane & 31), k0 = s * 16 + (lane >> 5) * 8;
+        const int k0 = s * 16 + (lane >> 5) * 8;
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = qt[(k0 + e) * ldq + col];
+            const float v = qm_rows ? qt[(k0 + e) * (32 * ct + 1) + j * 32 + (lane & 31)]
+                                    : w2s[(kc * 32 + k0 + e) * (H + 1) + (cb * ct + j) * 32 + (lane & 31)];
             const __bf16 hi = (__bf16)v;
             o[e] = part == 0 ? hi : (__bf16)(v - (float)hi);
         }
@@ -286,58 +269,69 @@ __global__ __launch_bounds__(1024) void wide_bwd_mid_kernel(const float *__restr
 //   block 0 (first): BatchNorm-1 backward constants from partT (or `sums`): cabc = {ca, cb, cc}[H], dgamma1, dbeta1
 //   every block: 256 elements of dL/dW2[c][mid] = R_S + D2[c] (W2[c] . Gram[:, mid]) + E2[c] suma[mid]
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wide_bwd_fin_kernel(const float *__restrict__ partT, int rows,
-                                                           const double *__restrict__ sums, int H, int O,
-                                                           const float *__restrict__ pack1, double count, int training,
-                                                           float *__restrict__ cabc, float *__restrict__ g_gamma1,
-                                                           float *__restrict__ g_beta1, const double *__restrict__ R,
-                                                           const float *__restrict__ d2e2,
-                                                           const float *__restrict__ w2, float *__restrict__ g_w2) {
-    __shared__ double red[4][64];
-    if (blockIdx.x == 0) {
-        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void wide_bwd_fin_kernel(const float *__restrict__ partT, int rows,
+                                                            const double *__restrict__ sums, int H, int O,
+                                                            const float *__restrict__ pack1, double count, int training,
+                                                            float *__restrict__ cabc, float *__restrict__ g_gamma1,
+                                                            float *__restrict__ g_beta1, const double *__restrict__ R,
+                                                            const float *__restrict__ d2e2,
+                                                            const float *__restrict__ w2, float *__restrict__ g_w2) {
+    // the LAST block does the BatchNorm-1 constants (a column sum over the rows of partT: 1024 threads = 2H columns
+    // x row groups, 16 loads in flight each); the others 1024 elements of dL/dW2 each, Gram staged in LDS
+    extern __shared__ double dsm[];
+    const int t = threadIdx.x;
+    if (blockIdx.x == gridDim.x - 1) {
+        double *red = dsm;                                         // [1024]
+        const int ncol = 2 * H, groups = 1024 / ncol;
+        const int col = t % ncol, grp = t / ncol;
         double gscale = 1.0;
         if (sums) { count = sums[2 * H]; gscale = 1.0 / sums[2 * H + 1]; }
-        for (int c0 = 0; c0 < H; c0 += 64) {
-            const int c = c0 + tx;
-            double tsum[2];
+        double acc = 0.0;
+        if (!sums && grp < groups) {
+            for (int r0 = grp; r0 < rows; r0 += 16 * groups) {
+                float v[16];
 #pragma unroll
-            for (int which = 0; which < 2; ++which) {
-                double s = 0.0;
-                if (!sums && c < H) {
-                    int r = ty;
-                    for (; r + 28 < rows; r += 32) {
-                        float v[8];
+                for (int u = 0; u < 16; ++u) v[u] = r0 + u * groups < rows ? partT[(size_t)(r0 + u * groups) * ncol + col] : 0.0f;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = partT[(size_t)(r + 4 * u) * 2 * H + which * H + c];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) s += (double)v[u];
-                    }
-                    for (; r < rows; r += 4) s += (double)partT[(size_t)r * 2 * H + which * H + c];
-                }
-                __syncthreads();
-                red[ty][tx] = s;
-                __syncthreads();
-                tsum[which] = sums ? (c < H ? sums[which * H + c] : 0.0)
-                                   : (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-            }
-            if (ty == 0 && c < H) {
-                const double sc = pack1[c];
-                cabc[c] = (float)sc;
-                cabc[H + c] = training ? (float)(-sc * tsum[1] / count) : 0.0f;
-                cabc[2 * H + c] = training ? (float)(-sc * tsum[0] / count) : 0.0f;
-                if (g_gamma1) g_gamma1[c] = (float)(tsum[1] * gscale);
-                if (g_beta1) g_beta1[c] = (float)(tsum[0] * gscale);
+                for (int u = 0; u < 16; ++u) acc += (double)v[u];
             }
         }
+        red[t] = acc;
+        __syncthreads();
+        if (t < ncol) {
+            double tot = 0.0;
+            if (sums) tot = sums[t];
+            else
+                for (int g = 0; g < groups; ++g) tot += red[g * ncol + t];
+            red[t] = tot;                                           // (row 0 of red: own column only)
+        }
+        __syncthreads();
+        if (t < H) {
+            const double t1 = red[t], t2 = red[H + t], sc = pack1[t];
+            cabc[t] = (float)sc;
+            cabc[H + t] = training ? (float)(-sc * t2 / count) : 0.0f;
+            cabc[2 * H + t] = training ? (float)(-sc * t1 / count) : 0.0f;
+            if (g_gamma1) g_gamma1[t] = (float)(t2 * gscale);
+            if (g_beta1) g_beta1[t] = (float)(t1 * gscale);
+        }
+        return;
     }
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= O * H) return;
-    const int c = e / H, mid = e - c * H;
-    const double *__restrict__ gram = R + (size_t)O * H;
+    double *gram = dsm;                                            // [H][H]
+    float *w2s = reinterpret_cast<float *>(gram + (H * H > 1024 ? H * H : 1024));      // this block's 1024 elements of W2
+    const double *__restrict__ gsrc = R + (size_t)O * H;
+    for (int e = t; e < H * H; e += 1024) gram[e] = gsrc[e];
+    const int e = blockIdx.x * 1024 + t;
+    const bool ok = e < O * H;
+    w2s[t] = ok ? w2[e] : 0.0f;
+    const int c = ok ? e / H : 0, mid = ok ? e - c * H : 0;
+    const double r0 = ok ? R[e] : 0.0, sm = R[(size_t)(O + H) * H + mid];
+    const float dc = d2e2[c], ec = d2e2[O + c];
+    __syncthreads();
+    const float *wr = w2s + (t / H) * H;                           // row c of W2
     double acc = 0.0;
-    for (int k = 0; k < H; ++k) acc += (double)w2[(size_t)c * H + k] * gram[(size_t)k * H + mid];
-    g_w2[e] = (float)(R[e] + (double)d2e2[c] * acc + (double)d2e2[O + c] * R[(size_t)(O + H) * H + mid]);
+#pragma unroll 8
+    for (int k = 0; k < H; ++k) acc += (double)wr[k] * gram[k * H + mid];
+    if (ok) g_w2[e] = (float)(r0 + (double)dc * acc + (double)ec * sm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -369,7 +363,7 @@ struct PointGradArgs {
 };
 
 template <int HPW>
-__global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) {
+__global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs a) {
     constexpr int H = 4 * HPW;
     extern __shared__ float sm[];
     const int C = a.C, ldw = C + 3, O = a.O, qpb = a.qpb;
@@ -380,6 +374,8 @@ __global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) 
     float *Wss = Hqs + qpb * (H + 1);                // [O][C + 1]          (skip branch)
     float *gps = Wss + O * (C + 1);                  // [qpb][O + 1]
     float *fgs = gps + qpb * (O + 1);                // [C][qpb + 1]
+    float *nps = fgs + (O ? C * (qpb + 1) : 0);      // [qpb][3]  the block's queries' coordinates / r
+    float *gpt = nps + qpb * 3;                      // [64][O + 1]  gpre rows of the block's POINTS that are queries
     const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long npts = (long long)a.B * a.N, nqry = (long long)a.B * a.M;
     const long long pt = (long long)blockIdx.x * 64 + tx;
@@ -390,12 +386,20 @@ __global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) 
     const int nq = (int)(q0 >= nqry ? 0 : (nqry - q0 < qpb ? nqry - q0 : qpb));
     // 0. weights and this block's queries into LDS
     for (int e = threadIdx.x; e < H * ldw; e += 256) W1s[e] = a.w1[e];
+    for (int e = threadIdx.x; e < nq * 3; e += 256) nps[e] = a.new_p[q0 * 3 + e] * a.inv_r;
     for (int e = threadIdx.x; e < nq * H; e += 256) {
         const int q = e / H, h = e - q * H;
         const size_t g = (size_t)(q0 + q) * H + h;
         Hqs[q * (H + 1) + h] = __builtin_fmaf(a.cabc[h], a.HA[g], __builtin_fmaf(a.cabc[H + h], a.HB[g], 32.0f * a.cabc[2 * H + h]));
     }
     if (O) {
+        const long long pbase = (long long)blockIdx.x * 64;
+        for (int e = threadIdx.x; e < 64 * O; e += 256) {
+            const int pl = e / O, o = e - pl * O;
+            const long long g = pbase + pl;
+            const int q = g < npts ? a.fq[g] : -1;
+            gpt[pl * (O + 1) + o] = q >= 0 ? a.gpre[((size_t)(g / a.N) * a.M + q) * O + o] : 0.0f;
+        }
         for (int e = threadIdx.x; e < O * C; e += 256) Wss[(e / C) * (C + 1) + e % C] = a.ws[e];
         for (int e = threadIdx.x; e < nq * O; e += 256) gps[(e / O) * (O + 1) + e % O] = a.gpre[(size_t)q0 * O + e];
         for (int e = threadIdx.x; e < nq * C; e += 256) {
@@ -455,26 +459,20 @@ __global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) 
         float acc[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+#pragma unroll 2
         for (int h = 0; h < H; ++h) {
             const float g = Gs[tx * (H + 1) + h];
             const float *wr = W1s + h * ldw + 3 + cbeg;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = __builtin_fmaf(g, cbeg + j < cend ? wr[j] : 0.0f, acc[j]);
         }
-        if (O) {
-            const int q = ok ? a.fq[ptc] : -1;
-            if (q >= 0) {
-                const float4 *__restrict__ gp = reinterpret_cast<const float4 *>(a.gpre + ((size_t)b * a.M + q) * O);
-                for (int o4 = 0; o4 < O / 4; ++o4) {
-                    const float4 g4 = gp[o4];
-                    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        if (O) {                                   // rows of points that are no query are zero
+#pragma unroll 2
+            for (int o = 0; o < O; ++o) {
+                const float g = gpt[tx * (O + 1) + o];
+                const float *wr = Wss + o * (C + 1) + cbeg;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float *wr = Wss + (o4 * 4 + u) * (C + 1) + cbeg;
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) acc[j] = __builtin_fmaf(gv[u], cbeg + j < cend ? wr[j] : 0.0f, acc[j]);
-                    }
-                }
+                for (int j = 0; j < 16; ++j) acc[j] = __builtin_fmaf(g, cbeg + j < cend ? wr[j] : 0.0f, acc[j]);
             }
         }
         if (ok) {
@@ -501,6 +499,7 @@ __global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) 
         if (tile < ntile) {
             const int hq = tile / tcols, cq = tile - hq * tcols;
             const int hb = hq * 4;
+#pragma unroll 4
             for (int q = 0; q < 64; ++q) {
                 float g[4], x[4];
 #pragma unroll
@@ -514,7 +513,7 @@ __global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) 
             }
             if (cq < 3) {        // coordinate column d = cq: minus this block's queries' Hq[q][h] new_p[q][d] / r
                 for (int q = 0; q < nq; ++q) {
-                    const float xd = a.new_p[(q0 + q) * 3 + cq] * a.inv_r;
+                    const float xd = nps[q * 3 + cq];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i][0] = __builtin_fmaf(-Hqs[q * (H + 1) + hb + i], xd, acc[i][0]);
                 }
@@ -528,6 +527,7 @@ __global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) 
             const int st = tile - ntile, scols = (C + 3) / 4;
             const int oq = st / scols, cq = st - oq * scols;
             const int ob = oq * 4;
+#pragma unroll 4
             for (int q = 0; q < nq; ++q) {
                 float g[4], x[4];
 #pragma unroll
@@ -566,24 +566,28 @@ __global__ __launch_bounds__(256) void wide_point_grads_kernel(PointGradArgs a) 
 }
 
 // column sums like wide_colsum (sa_wide.hip), one level, float32 result: out[c] = sum_r part[r][c] in float64
-__global__ __launch_bounds__(256) void wide_colsum_f32_kernel(const float *__restrict__ part, int rows, int ncol,
-                                                              float *__restrict__ out) {
-    __shared__ double red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+__global__ __launch_bounds__(1024) void wide_colsum_f32_kernel(const float *__restrict__ part, int rows, int ncol,
+                                                               float *__restrict__ out) {
+    __shared__ double red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;     // 64 columns x 16 row groups
+    double s = 0.0;
     if (c < ncol) {
-        int r = g;
-        for (; r + 12 < rows; r += 16) {
-            const float v0 = part[(size_t)r * ncol + c], v1 = part[(size_t)(r + 4) * ncol + c];
-            const float v2 = part[(size_t)(r + 8) * ncol + c], v3 = part[(size_t)(r + 12) * ncol + c];
-            s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+        for (int r0 = g; r0 < rows; r0 += 256) {                                   // 16 independent loads in flight
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = r0 + 16 * u < rows ? part[(size_t)(r0 + 16 * u) * ncol + c] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += (double)v[u];
         }
-        for (; r < rows; r += 4) s0 += (double)part[(size_t)r * ncol + c];
     }
-    red[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    red[g][threadIdx.x & 63] = s;
     __syncthreads();
-    if (g == 0 && c < ncol)
-        out[c] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (g == 0 && c < ncol) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k][threadIdx.x];
+        out[c] = (float)tot;
+    }
 }
 
 static bool dense_shape_ok(int H, int O) {
@@ -644,11 +648,16 @@ extern "C" int apn_sa_wide_bwd_mid(const float *part_s, int rows, const double *
                                    float *g_gamma2, float *g_beta2, float *evec, void *z_image, void *stream) {
     if ((!part_s && !sums) || rows < 0 || !dense_shape_ok(c_mid, c_out) || !pack2 || !w2 || !d2e2 || !evec || !z_image)
         return APN_EINVAL;
+    if (c_mid > 64) return APN_EINVAL;                              // W2 is held in LDS
     const int ct = c_mid / 32 >= 4 ? 4 : c_mid / 32;
     const int blocks = ((c_out + c_mid) / 32) * (c_mid / (32 * ct));
-    size_t tail = (size_t)32 * (32 * ct + 1) * sizeof(float);
-    if (tail < (size_t)2 * c_out * sizeof(double)) tail = (size_t)2 * c_out * sizeof(double);   // S1|S2 staged in qt
-    const size_t lds = (size_t)16 * 64 * sizeof(double) + (size_t)2 * c_out * sizeof(float) + tail + 8;
+    const size_t lds = (size_t)(1024 + 2 * c_out) * sizeof(double) +
+                       ((size_t)2 * c_out + (size_t)c_out * (c_mid + 1) + (size_t)32 * (32 * ct + 1)) * sizeof(float);
+    if (lds > 48 * 1024) {
+        if (hipError_t e = hipFuncSetAttribute((const void *)wide_bwd_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds))
+            return (int)e;
+    }
     hipLaunchKernelGGL(wide_bwd_mid_kernel, dim3(blocks), dim3(1024), lds, (hipStream_t)stream, part_s, rows, sums, c_mid,
                        c_out, ct, pack2, count, training, w2, d2e2, g_gamma2, g_beta2, evec, (uint4 *)z_image);
     APN_LAUNCH_CHECK();
@@ -661,7 +670,9 @@ extern "C" int apn_sa_wide_bwd_fin(const float *part_t, int rows, const double *
                                    void *stream) {
     if ((!part_t && !sums) || rows < 0 || !dense_shape_ok(c_mid, c_out) || !pack1 || !cabc || !R || !d2e2 || !w2 || !g_w2)
         return APN_EINVAL;
-    hipLaunchKernelGGL(wide_bwd_fin_kernel, dim3((c_out * c_mid + 255) / 256), dim3(256), 0, (hipStream_t)stream, part_t,
+    if (c_mid > 64) return APN_EINVAL;
+    const size_t lds = (size_t)(c_mid * c_mid > 1024 ? c_mid * c_mid : 1024) * sizeof(double) + 1024 * sizeof(float);
+    hipLaunchKernelGGL(wide_bwd_fin_kernel, dim3((c_out * c_mid + 1023) / 1024 + 1), dim3(1024), lds, (hipStream_t)stream, part_t,
                        rows, sums, c_mid, c_out, pack1, count, training, cabc, g_gamma1, g_beta1, R, d2e2, w2, g_w2);
     APN_LAUNCH_CHECK();
     return APN_OK;
@@ -700,7 +711,9 @@ extern "C" int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid,
     APN_DENSE_DISPATCH(c_mid, {
         const int H = 4 * HPW, ldw = c_in + 3;
         const size_t lds = ((size_t)64 * (H + 1) + (size_t)ldw * 65 + (size_t)H * ldw + (size_t)a.qpb * (H + 1) +
-                            (size_t)c_skip * (c_in + 1) + (size_t)a.qpb * (c_skip + 1) + (size_t)c_in * (a.qpb + 1)) *
+                            (size_t)c_skip * (c_in + 1) + (size_t)a.qpb * (c_skip + 1) +
+                            (c_skip ? (size_t)c_in * (a.qpb + 1) : 0) + (size_t)a.qpb * 3 +
+                            (c_skip ? (size_t)64 * (c_skip + 1) : 0)) *
                            sizeof(float);
         if (lds > 160 * 1024) return APN_EINVAL;
         if (lds > 48 * 1024) {
@@ -716,7 +729,7 @@ extern "C" int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid,
 
 extern "C" int apn_sa_wide_colsum_f32(const float *part, int rows, int ncol, float *out, void *stream) {
     if (rows < 0 || ncol <= 0 || !part || !out) return APN_EINVAL;
-    hipLaunchKernelGGL(wide_colsum_f32_kernel, dim3((ncol + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, rows, ncol,
+    hipLaunchKernelGGL(wide_colsum_f32_kernel, dim3((ncol + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, rows, ncol,
                        out);
     APN_LAUNCH_CHECK();
     return APN_OK;

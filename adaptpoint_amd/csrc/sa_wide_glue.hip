@@ -293,7 +293,7 @@ extern "C" int apn_sa_wide_point_terms(int b, int n, int m, int c_mid, const flo
 // the max over K runs over the distinct rows.  Whole queries are packed greedily, in order, into 32-row
 // MFMA tiles (a cloud's tiles are contiguous, clouds in order): 557 tiles instead of 2048 per 4 clouds.
 //   rowinfo[tile][row] = qlocal | slot << 8 | mult << 16 | (row 0 only: queries in the tile) << 24;
-//   mult == 0 marks a padding row;  tq0[tile] = the tile's first query (global id b * M + q).
+//   mult == 0 marks a padding row (qlocal 255: no query's);  tq0[tile] = the tile's first query (global id b * M + q).
 // An index row that does not have the ball-query structure (any other grouper) is kept whole:
 // cnt = 32, every slot its own row.  mode 0 skips the analysis: one tile per query.
 // ------------------------------------------------------------------------------------------
@@ -379,7 +379,8 @@ __global__ __launch_bounds__(256) void tilemap_fill_kernel(int nq, int m, const 
                                                            const unsigned *__restrict__ qmeta,
                                                            const int *__restrict__ toff,
                                                            const unsigned short *__restrict__ tnq_local,
-                                                           int *__restrict__ tq0, unsigned *__restrict__ rowinfo) {
+                                                           int *__restrict__ tq0, unsigned *__restrict__ rowinfo,
+                                                           const int *__restrict__ idx, int *__restrict__ rownn) {
     const int lane = lane_id(), q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq || lane >= 32) return;
     const int c = q / m, cn = cnt8[q];
@@ -394,8 +395,12 @@ __global__ __launch_bounds__(256) void tilemap_fill_kernel(int nq, int m, const 
         unsigned v = qlocal | ((unsigned)lane << 8) | (mult << 16);
         if (starts && lane == 0) v |= (unsigned)tnq_local[(size_t)c * m + tl] << 24;
         rowinfo[(size_t)tile * 32 + row0 + lane] = v;
+        rownn[(size_t)tile * 32 + row0 + lane] = idx[(size_t)q * 32 + lane];
     }
-    if (ends && row0 + cn + lane < 32 && lane < 32 - (row0 + cn)) rowinfo[(size_t)tile * 32 + row0 + cn + lane] = 0u;
+    if (ends && row0 + cn + lane < 32) {                 // padding: multiplicity 0, a valid neighbour to load
+        rowinfo[(size_t)tile * 32 + row0 + cn + lane] = 0xffu;       // query 255: belongs to none
+        rownn[(size_t)tile * 32 + row0 + cn + lane] = idx[(size_t)q * 32];
+    }
     if (starts && lane == 0) tq0[tile] = q;
 }
 
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(256) void tilemap_fill_kernel(int nq, int m, const 
 // (order left to the atomics), then every list is sorted -- the result is a pure function of idx.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ const int *tm_toff(const int *tmap, int nq, int b) {
-    return tmap + 4 + ((nq + 3) & ~3) + (size_t)32 * nq + b;
+    return tmap + 4 + ((nq + 3) & ~3) + (size_t)64 * nq + b;
 }
 
 __global__ __launch_bounds__(256) void csr_zero_kernel(long long n4, int4 *__restrict__ dst) {
@@ -503,14 +508,15 @@ __global__ __launch_bounds__(256) void csr_sort_geo_kernel(int nq, long long npt
 }  // namespace apn
 
 // The map is ONE int32 blob (BM = b * m, BM4 = BM rounded up to 4):
-//   [0] tiles in use   [4, 4 + BM) tq0   [4 + BM4, 4 + BM4 + 32 BM) rowinfo   then scratch of this builder
+//   [0] tiles in use   [4, 4 + BM) tq0   [4 + BM4, + 32 BM) rowinfo   [.., + 32 BM) rownn = each row's neighbour
+//   (idx[query][slot], so that the passes need no second dependent load)   then scratch of this builder
 // (per-cloud tile counts and offsets, per-query packing records); apn_sa_wide_tilemap_ints(b, m) = its size.
 static size_t tilemap_rows_off(int bm) { return 4 + (size_t)((bm + 3) & ~3); }
 
 extern "C" int apn_sa_wide_tilemap_ints(int b, int m) {
     if (b <= 0 || m <= 0 || (long long)b * m > 0x7fffffffLL / 64) return 0;
     const size_t bm = (size_t)b * m;
-    return (int)(tilemap_rows_off((int)bm) + 32 * bm + 2 * (size_t)b + bm + (bm + 1) / 2 + (bm + 3) / 4 + 8);
+    return (int)(tilemap_rows_off((int)bm) + 64 * bm + 2 * (size_t)b + bm + (bm + 1) / 2 + (bm + 3) / 4 + 8);
 }
 
 extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *tmap, void *stream) {
@@ -518,7 +524,8 @@ extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *
     const int nq = b * m;
     int *tq0 = tmap + 4;
     unsigned *rowinfo = (unsigned *)(tmap + tilemap_rows_off(nq));
-    int *tcount = (int *)(rowinfo + (size_t)32 * nq), *toff = tcount + b;
+    int *rownn = (int *)(rowinfo + (size_t)32 * nq);
+    int *tcount = rownn + (size_t)32 * nq, *toff = tcount + b;
     unsigned *qmeta = (unsigned *)(toff + b);
     unsigned short *tnq_local = (unsigned short *)(qmeta + nq);
     unsigned char *cnt8 = (unsigned char *)(tnq_local + 2 * (((size_t)nq + 1) / 2));
@@ -528,7 +535,7 @@ extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *
                        tnq_local);
     hipLaunchKernelGGL(apn::tilemap_scan_kernel, dim3(1), dim3(1024), 0, st, b, tcount, toff, tmap);
     hipLaunchKernelGGL(apn::tilemap_fill_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, nq, m, cnt8, qmeta, toff,
-                       tnq_local, tq0, rowinfo);
+                       tnq_local, tq0, rowinfo, idx, rownn);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

@@ -280,16 +280,22 @@ class _WideBlock(torch.autograd.Function):
         HA = torch.empty(B, M, H, **f32)
         HB = torch.empty(B, M, H, **f32)
         partT = torch.empty(grid, 2 * H, **f32)
+        # weight-gradient products over the positions, {[S^T ; a1^T] a1, sum a1}: one partial row per workgroup of
+        # the backward pass itself (H = 32), or per split of their own pass
+        rows = O + H
+        wg_fused = bool(lib.apn_sa_wide_wgrad_fused(H))
+        if wg_fused:
+            splits = grid
+        else:
+            groups = (rows // 32 + 7) // 8
+            splits = max(1, min(512 // groups, (B * M) // 4, (64 << 20) // (rows * H * 4)))
+        Rpart = torch.empty(splits, rows * H + H, **f32)
         _call("apn_sa_wide_bwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
               tmap.data_ptr(), zimg.data_ptr(), pack1.data_ptr(), evec.data_ptr(), goa.data_ptr(), ksel.data_ptr(),
-              GU.data_ptr(), HA.data_ptr(), HB.data_ptr(), partT.data_ptr())
-        # weight-gradient products over the positions: {[S^T ; a1^T] a1, sum a1}, one partial row per split
-        rows = O + H
-        groups = (rows // 32 + 7) // 8
-        splits = max(1, min(512 // groups, (B * M) // 4, (64 << 20) // (rows * H * 4)))
-        Rpart = torch.empty(splits, rows * H + H, **f32)
-        _call("apn_sa_wide_wgrad", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
-              tmap.data_ptr(), pack1.data_ptr(), goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr())
+              GU.data_ptr(), HA.data_ptr(), HB.data_ptr(), partT.data_ptr(), Rpart.data_ptr())
+        if not wg_fused:
+            _call("apn_sa_wide_wgrad", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
+                  tmap.data_ptr(), pack1.data_ptr(), goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr())
         R = _colsum(Rpart)
         sT = reduced(partT) if sync else None
         g_ws = g_bs = None

@@ -272,6 +272,10 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
         sets = [[b.clouds(i * B_PER_GPU, (i + 1) * B_PER_GPU) for i in range(spg)] for b in big]
         blk.sample(p_all, out=big[0])                # prologue: index stages of the first launch
         big[1].buf.copy_(big[0].buf)
+        # the width-generic kernels also take a tile map + inverse map of the neighbourhoods (index-stage work too)
+        for st in sets:
+            for i in range(spg):
+                blk.index_for(st[i], N_PTS, C_IN)
     cur_set = [0]
     ones = torch.ones(1, 1, 1, device=dev)
     graph_grads, last_grads = {}, [None]
@@ -305,6 +309,9 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
         for g in range(0, count * B_PER_GPU, nb):
             hi = min(g + nb, count * B_PER_GPU)
             blk.sample(p_all[g:hi], out=big[dst].clouds(g, hi))
+        for i in range(count):
+            if sets[dst][i].index is not None:
+                blk.index_for(sets[dst][i], N_PTS, C_IN, out=sets[dst][i].index)
 
     # Pipelined launch of `count` steps: the MLP steps consume set `cur` on the main stream while
     # the side stream fills the other set for the NEXT launch.  mlp_done / index_done order a

@@ -357,7 +357,8 @@ APN_API int apn_sa_wide_grid(int b, int m);          /* workgroups = partial row
  * = (query, distinct slot, multiplicity), whole queries packed in order into 32-row MFMA tiles.
  * tmap: int32[apn_sa_wide_tilemap_ints(b, m)], device memory:
  *   [0] tiles in use; [4, 4 + b m) first query of each tile; [4 + roundup4(b m), ... + 32 b m) the rows,
- *   qlocal | slot << 8 | mult << 16 | (row 0: queries in the tile) << 24, mult = 0 for padding; scratch.
+ *   qlocal | slot << 8 | mult << 16 | (row 0: queries in the tile) << 24, mult = 0 for padding; then
+ *   32 b m ints: every row's neighbour idx[query][slot]; scratch.
  * mode 1: fold the copies of slot 0 of every index row that has the ball-query structure (checked row
  * by row; any other row is kept whole); mode 0: one tile per query, 32 rows of multiplicity 1. */
 APN_API int apn_sa_wide_tilemap_ints(int b, int m);
@@ -385,7 +386,11 @@ APN_API int apn_sa_wide_fwd_main(int b, int n, int m, int c_mid, int c_out, cons
 APN_API int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
                                  const int *idx, const int *tmap, const void *z_image, const float *pack1,
                                  const float *evec, const float *goa, const void *ksel, float *GU,
-                                 float *HA, float *HB, float *part, void *stream);
+                                 float *HA, float *HB, float *part, float *r_part, void *stream);
+/* 1 when apn_sa_wide_bwd_main also leaves the weight-gradient products, as r_part[apn_sa_wide_grid(b, m)]
+ * [(O+H) H + H] = the workgroups' shares of {[S^T ; a1^T] a1, sum a1} (c_mid = 32); 0: r_part is ignored and
+ * apn_sa_wide_wgrad computes them */
+APN_API int apn_sa_wide_wgrad_fused(int c_mid);
 /* The small kernels around those passes (csrc/sa_wide_glue.hip).
  * image: B image of Bm (kd x nc): rows < k0 from src0 (row-major kd x nc, or nc x k0 read transposed when
  *   trans0), the rest from src1 ((kd - k0) x nc); ct column tiles per block.

@@ -24,6 +24,7 @@ def check_map(idx, tmap, fold):
     nt, bm = int(t[0]), B * M
     tq0 = t[4:4 + bm]
     rows = (t[4 + ((bm + 3) & ~3):][:32 * bm] & 0xffffffff).reshape(bm, 32)
+    rnn = t[4 + ((bm + 3) & ~3) + 32 * bm:][:32 * bm].reshape(bm, 32)
     flat = idx.cpu().numpy().reshape(bm, 32)
     seen = [[] for _ in range(bm)]
     used = 0
@@ -36,6 +37,7 @@ def check_map(idx, tmap, fold):
                 continue
             q = int(tq0[tl]) + (info & 0xff); slot = (info >> 8) & 0xff
             qs.add(q); used += 1
+            assert rnn[tl, r] == flat[q, slot]
             seen[q] += [int(flat[q, slot])] * mult
         assert len(qs) == nq and max(qs) - min(qs) + 1 == nq, (tl, nq, qs)
         assert len({q // M for q in qs}) == 1
@@ -103,9 +105,10 @@ for H, N, M, radius, kind in CASES:
     zimg = mfma_b_image(torch.cat([W2, Qm], 0).contiguous(), min(4, H // 32))
     GU = torch.full((B * M * 32, H), float("nan"), device=dev); HA = torch.empty(B, M, H, device=dev); HB = torch.empty(B, M, H, device=dev)
     partT = torch.empty(grid, 2 * H, device=dev)
+    Rfused = torch.zeros(grid, (O + H) * H + H, device=dev)
     _call("apn_sa_wide_bwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(), tmap.data_ptr(), zimg.data_ptr(),
           pack1.data_ptr(), evec.data_ptr(), goa.data_ptr(), ksel.data_ptr(), GU.data_ptr(), HA.data_ptr(),
-          HB.data_ptr(), partT.data_ptr())
+          HB.data_ptr(), partT.data_ptr(), Rfused.data_ptr())
     # the inverse map: every point's list is ascending, and the rows of a point sum to its scatter
     cnt, off = nbr.pcnt_poff[:B * N].long(), nbr.pcnt_poff[B * N:].long()
     owner = torch.repeat_interleave(torch.arange(B * N, device=dev), cnt)
@@ -130,4 +133,8 @@ for H, N, M, radius, kind in CASES:
     R = Rpart.double().sum(0)[:rows * H].view(rows, H)
     suma = Rpart.double().sum(0)[rows * H:]
     a1f = a1.view(-1, H)
+    if lib.apn_sa_wide_wgrad_fused(H):
+        Rf = Rfused.double().sum(0)
+        print(f"fused-in-bwd sparse {rel(Rf[:O * H].view(O, H), S.view(-1, O).t() @ a1.view(-1, H)):.1e} gram "
+              f"{rel(Rf[O * H:rows * H].view(H, H), R[O:]):.1e} suma {rel(Rf[rows * H:], suma):.1e}", end=" | ")
     print(f"wgrad sparse {rel(R[:O], S.view(-1, O).t() @ a1f):.1e} gram {rel(R[O:], a1f.t() @ a1f):.1e} suma {rel(suma, a1f.sum(0)):.1e}")

@@ -15,7 +15,8 @@ from adaptpoint_amd import fused_wide
 dev = torch.device("cuda:0")
 cin, N, M, radius = T.STAGES[int(sys.argv[1]) if len(sys.argv) > 1 else 0]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-p, new_p, f, idx, conv1, bn1, conv2, bn2 = T._setup(dev, cin, N, M, radius, B=32, seed=5)
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+p, new_p, f, idx, conv1, bn1, conv2, bn2 = T._setup(dev, cin, N, M, radius, B=batch, seed=5)
 f.requires_grad_(True)
 params = [conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias]
 nbr = fused_wide.neighbour_index(idx, new_p, N)
