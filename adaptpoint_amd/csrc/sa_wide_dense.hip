@@ -50,21 +50,36 @@ __global__ __launch_bounds__(256, 2) void wide_fwd_prep_kernel(int B, int C, int
 #pragma unroll
         for (int hh = 0; hh < HPW; ++hh) acc[hh] = 0.0f;
         const float px = p[ptc * 3], py = p[ptc * 3 + 1], pz = p[ptc * 3 + 2];
+        // the weights, transposed, once per block: wt[c'][h] -- a point's FMA chain then reads its wave's HPW
+        // output channels of input channel c' as broadcast 16-byte LDS words
+        float *wt = sm + 64 * (H + 1);
+        for (int e = threadIdx.x; e < H * ldw; e += 256) {
+            const int hh = e / ldw, cc = e - hh * ldw;
+            wt[cc * H + hh] = w1[e];
+        }
         for (int c0 = 0; c0 < C; c0 += 32) {
             float fv[32];                                        // one round trip for 32 channels of this point
 #pragma unroll
             for (int j = 0; j < 32; ++j) fv[j] = c0 + j < C ? fb[(size_t)(c0 + j) * N] : 0.0f;
-#pragma unroll 2
-            for (int hh = 0; hh < HPW; ++hh) {
-                const float *__restrict__ wr = w1 + (size_t)(h0 + hh) * ldw + 3 + c0;       // wave-uniform: scalar loads
+            if (c0 == 0) __syncthreads();
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) {
+                if (c0 + j < C) {
+                    const float4 *wr = reinterpret_cast<const float4 *>(wt + (3 + c0 + j) * H + h0);
 #pragma unroll
-                for (int j = 0; j < 32; ++j) acc[hh] = __builtin_fmaf(c0 + j < C ? wr[j] : 0.0f, fv[j], acc[hh]);
+                    for (int v = 0; v < HPW / 4; ++v) {
+                        const float4 wv = wr[v];
+                        acc[4 * v] = __builtin_fmaf(wv.x, fv[j], acc[4 * v]);
+                        acc[4 * v + 1] = __builtin_fmaf(wv.y, fv[j], acc[4 * v + 1]);
+                        acc[4 * v + 2] = __builtin_fmaf(wv.z, fv[j], acc[4 * v + 2]);
+                        acc[4 * v + 3] = __builtin_fmaf(wv.w, fv[j], acc[4 * v + 3]);
+                    }
+                }
             }
         }
 #pragma unroll
         for (int hh = 0; hh < HPW; ++hh) {
-            const float *__restrict__ wr = w1 + (size_t)(h0 + hh) * ldw;
-            const float pw = __builtin_fmaf(wr[2], pz, __builtin_fmaf(wr[1], py, wr[0] * px));
+            const float pw = __builtin_fmaf(wt[2 * H + h0 + hh], pz, __builtin_fmaf(wt[H + h0 + hh], py, wt[h0 + hh] * px));
             sm[tx * (H + 1) + h0 + hh] = __builtin_fmaf(pw, inv_r, acc[hh]);
         }
         __syncthreads();
@@ -227,9 +242,13 @@ __global__ __launch_bounds__(1024) void wide_bwd_mid_kernel(const float *__restr
     }
     __syncthreads();
     if (blockIdx.x == 0 && t < H) {
-        float e = 0.0f;
-        for (int c = 0; c < O; ++c) e = __builtin_fmaf(de[O + c], w2s[c * (H + 1) + t], e);
-        evec[t] = e;
+        float e0 = 0.0f, e1 = 0.0f;
+#pragma unroll 8
+        for (int c = 0; c < O; c += 2) {
+            e0 = __builtin_fmaf(de[O + c], w2s[c * (H + 1) + t], e0);
+            e1 = __builtin_fmaf(de[O + c + 1], w2s[(c + 1) * (H + 1) + t], e1);
+        }
+        evec[t] = e0 + e1;
     }
     const int words = ct * 256;                                   // [j][s][part][lane] of this chunk
     uint4 *__restrict__ dst = zimg + (size_t)blockIdx.x * words;
@@ -237,6 +256,7 @@ __global__ __launch_bounds__(1024) void wide_bwd_mid_kernel(const float *__restr
         // Qm tile: rows k' = kq0 + (t >> 5), columns mid0 + 32 j + (t & 31);  Qm = W2^T diag(D2) W2
         const int kq = (kc - O / 32) * 32 + (t >> 5), r = t & 31, mid0 = cb * ct * 32;
         float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
         for (int c = 0; c < O; ++c) {
             const float a = w2s[c * (H + 1) + kq] * de[c];
 #pragma unroll
@@ -362,140 +382,214 @@ struct PointGradArgs {
     float *g_f, *g_p, *g_q, *Wpart;      // g_p / g_q may be null
 };
 
+__host__ __device__ inline int up4(int x) { return (x + 3) & ~3; }
+
+// LDS layout of wide_point_grads (floats; every sub-array starts 16-byte aligned)
+struct PgLds {
+    int gs, xs, w1f, w1p, hqs, nps, fqs, wss, gps, fgs, gpt, fis, total;
+    __host__ __device__ PgLds(int H, int C, int O, int qpb) {
+        int o = 0;
+        gs = o; o += up4(64 * (H + 1));
+        xs = o; o += up4((C + 3) * 65);
+        w1f = o; o += H * C;
+        w1p = o; o += H * 4;
+        hqs = o; o += up4(qpb * (H + 1));
+        nps = o; o += up4(qpb * 3);
+        fqs = o; o += 64;
+        wss = o; o += O * up4(C);
+        gps = o; o += up4(qpb * (O + 1));
+        fgs = o; o += O ? up4(C * (qpb + 1)) : 0;
+        gpt = o; o += O ? up4(64 * (O + 1)) : 0;
+        fis = o; o += O ? up4(qpb) : 0;
+        total = o;
+    }
+};
+
+// n values through registers, NB loads in flight per thread: the fills of the LDS tiles below are dependent chains
+// (index -> row) only across phases, never inside a loop
+template <int NB, typename Load, typename Store>
+__device__ __forceinline__ void fill_batched(int n, Load load, Store store) {
+    for (int e0 = threadIdx.x; e0 < n; e0 += 256 * NB) {
+        float v[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) v[u] = e0 + 256 * u < n ? load(e0 + 256 * u) : 0.0f;
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+            if (e0 + 256 * u < n) store(e0 + 256 * u, v[u]);
+    }
+}
+
 template <int HPW>
 __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs a) {
     constexpr int H = 4 * HPW;
     extern __shared__ float sm[];
-    const int C = a.C, ldw = C + 3, O = a.O, qpb = a.qpb;
-    float *Gs = sm;                                  // [64][H + 1]
-    float *Xs = Gs + 64 * (H + 1);                   // [C + 3][65]
-    float *W1s = Xs + ldw * 65;                      // [H][ldw]
-    float *Hqs = W1s + H * ldw;                      // [qpb][H + 1]
-    float *Wss = Hqs + qpb * (H + 1);                // [O][C + 1]          (skip branch)
-    float *gps = Wss + O * (C + 1);                  // [qpb][O + 1]
-    float *fgs = gps + qpb * (O + 1);                // [C][qpb + 1]
-    float *nps = fgs + (O ? C * (qpb + 1) : 0);      // [qpb][3]  the block's queries' coordinates / r
-    float *gpt = nps + qpb * 3;                      // [64][O + 1]  gpre rows of the block's POINTS that are queries
+    const int C = a.C, ldw = C + 3, O = a.O, qpb = a.qpb, C4 = up4(C);
+    const PgLds L(H, C, O, qpb);
+    float *Gs = sm + L.gs;                           // [64][H + 1]
+    float *Xs = sm + L.xs;                           // [C + 3][65]
+    float *W1f = sm + L.w1f;                         // [H][C]      feature columns of W1
+    float *W1p = sm + L.w1p;                         // [H][4]      coordinate columns
+    float *Hqs = sm + L.hqs;                         // [qpb][H + 1]
+    float *nps = sm + L.nps;                         // [qpb][3]    the block's queries' coordinates / r
+    int *fqs = reinterpret_cast<int *>(sm + L.fqs);  // [64]        the query each of the block's points is, or -1
+    float *Wss = sm + L.wss;                         // [O][C4]     (skip branch)
+    float *gps = sm + L.gps;                         // [qpb][O + 1]  gpre rows of the block's queries
+    float *fgs = sm + L.fgs;                         // [C][qpb + 1]  their source points' features
+    float *gpt = sm + L.gpt;                         // [64][O + 1]   gpre rows of the block's POINTS that are queries
+    int *fis = reinterpret_cast<int *>(sm + L.fis);  // [qpb]       the point each of the block's queries is
     const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long npts = (long long)a.B * a.N, nqry = (long long)a.B * a.M;
-    const long long pt = (long long)blockIdx.x * 64 + tx;
+    const long long pbase = (long long)blockIdx.x * 64;
+    const long long pt = pbase + tx;
     const bool ok = pt < npts;
     const long long ptc = ok ? pt : npts - 1;
     const int b = (int)(ptc / a.N), n = (int)(ptc % a.N);
     const long long q0 = (long long)blockIdx.x * qpb;
     const int nq = (int)(q0 >= nqry ? 0 : (nqry - q0 < qpb ? nqry - q0 : qpb));
-    // 0. weights and this block's queries into LDS
-    for (int e = threadIdx.x; e < H * ldw; e += 256) W1s[e] = a.w1[e];
-    for (int e = threadIdx.x; e < nq * 3; e += 256) nps[e] = a.new_p[q0 * 3 + e] * a.inv_r;
-    for (int e = threadIdx.x; e < nq * H; e += 256) {
-        const int q = e / H, h = e - q * H;
-        const size_t g = (size_t)(q0 + q) * H + h;
-        Hqs[q * (H + 1) + h] = __builtin_fmaf(a.cabc[h], a.HA[g], __builtin_fmaf(a.cabc[H + h], a.HB[g], 32.0f * a.cabc[2 * H + h]));
+    const int h0 = ty * HPW;
+    // ---- phase 0: everything that does not depend on another load
+    const int cnt = ok ? a.pcnt[ptc] : 0;
+    const int *__restrict__ l = a.plist + a.poff[ptc];
+    const float4 ge = *reinterpret_cast<const float4 *>(a.geo + ptc * 4);
+    float ur[HPW];
+#pragma unroll
+    for (int v = 0; v < HPW / 4; ++v) {
+        const float4 x = *reinterpret_cast<const float4 *>(a.U + ptc * H + h0 + 4 * v);
+        ur[4 * v] = x.x; ur[4 * v + 1] = x.y; ur[4 * v + 2] = x.z; ur[4 * v + 3] = x.w;
     }
     if (O) {
-        const long long pbase = (long long)blockIdx.x * 64;
-        for (int e = threadIdx.x; e < 64 * O; e += 256) {
-            const int pl = e / O, o = e - pl * O;
-            const long long g = pbase + pl;
-            const int q = g < npts ? a.fq[g] : -1;
-            gpt[pl * (O + 1) + o] = q >= 0 ? a.gpre[((size_t)(g / a.N) * a.M + q) * O + o] : 0.0f;
-        }
-        for (int e = threadIdx.x; e < O * C; e += 256) Wss[(e / C) * (C + 1) + e % C] = a.ws[e];
-        for (int e = threadIdx.x; e < nq * O; e += 256) gps[(e / O) * (O + 1) + e % O] = a.gpre[(size_t)q0 * O + e];
-        for (int e = threadIdx.x; e < nq * C; e += 256) {
-            const int c = e / nq, q = e - c * nq;
-            const long long gq = q0 + q;
-            fgs[c * (qpb + 1) + q] = a.f[((size_t)(gq / a.M) * C + c) * a.N + a.fidx[gq]];
-        }
+        if (ty == 0) fqs[tx] = ok ? a.fq[ptc] : -1;
+        if ((int)threadIdx.x < nq) fis[threadIdx.x] = a.fidx[q0 + threadIdx.x];
     }
-    {   // 1.
-        const int h0 = ty * HPW;
-        float acc[HPW];
-#pragma unroll
-        for (int v = 0; v < HPW; ++v) acc[v] = 0.0f;
-        const int cnt = ok ? a.pcnt[ptc] : 0;
-        const int *__restrict__ l = a.plist + a.poff[ptc];
-        for (int i0 = 0; i0 < cnt; i0 += 4) {                      // four rows in flight
-            int r[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) r[u] = i0 + u < cnt ? l[i0 + u] : -1;
-            float4 x[4][HPW / 4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(a.GU + (size_t)(r[u] < 0 ? 0 : r[u]) * H + h0);
-#pragma unroll
-                for (int v = 0; v < HPW / 4; ++v) x[u][v] = r[u] < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : g[v];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < HPW / 4; ++v) {
-                    acc[4 * v] += x[u][v].x; acc[4 * v + 1] += x[u][v].y; acc[4 * v + 2] += x[u][v].z; acc[4 * v + 3] += x[u][v].w;
-                }
-        }
-        const float4 ge = *reinterpret_cast<const float4 *>(a.geo + ptc * 4);
-        const float *__restrict__ ur = a.U + ptc * H + h0;
-#pragma unroll
-        for (int v = 0; v < HPW; ++v) {
-            const int h = h0 + v;
-            const float *__restrict__ wr = a.w1 + (size_t)h * ldw;
-            const float spw = __builtin_fmaf(ge.w, wr[2], __builtin_fmaf(ge.z, wr[1], ge.y * wr[0]));
-            const float yh = a.pack1[3 * H + h] * (ge.x * (ur[v] - a.pack1[2 * H + h]) - spw * a.inv_r);
-            const float G = __builtin_fmaf(a.cabc[h], acc[v], __builtin_fmaf(a.cabc[H + h], yh, a.cabc[2 * H + h] * ge.x));
-            Gs[tx * (H + 1) + h] = ok ? G : 0.0f;
-        }
-    }
-    // X tile: coordinates / r in rows 0..2, features in rows 3..; zero columns past the end
-    for (int cc = ty; cc < ldw; cc += 4) {
-        float v = 0.0f;
-        if (ok) v = cc < 3 ? a.p[ptc * 3 + cc] * a.inv_r : a.f[((size_t)b * C + (cc - 3)) * a.N + n];
-        Xs[cc * 65 + tx] = v;
+    fill_batched<8>(ldw * 64, [&](int e) {                       // X tile: coordinates / r, then the features
+        const int cc = e >> 6, pl = e & 63;
+        const long long g = pbase + pl;
+        if (g >= npts) return 0.0f;
+        return cc < 3 ? a.p[g * 3 + cc] * a.inv_r : a.f[((size_t)(g / a.N) * C + (cc - 3)) * a.N + (int)(g % a.N)];
+    }, [&](int e, float v) { Xs[(e >> 6) * 65 + (e & 63)] = v; });
+    fill_batched<8>(H * ldw, [&](int e) { return a.w1[e]; }, [&](int e, float v) {
+        const int hh = e / ldw, cc = e - hh * ldw;
+        if (cc < 3) W1p[hh * 4 + cc] = v; else W1f[hh * C + cc - 3] = v;
+    });
+    fill_batched<4>(nq * 3, [&](int e) { return a.new_p[q0 * 3 + e] * a.inv_r; }, [&](int e, float v) { nps[e] = v; });
+    fill_batched<4>(nq * H, [&](int e) {
+        const int hh = e % H;
+        const size_t g = (size_t)q0 * H + e;
+        return __builtin_fmaf(a.cabc[hh], a.HA[g], __builtin_fmaf(a.cabc[H + hh], a.HB[g], 32.0f * a.cabc[2 * H + hh]));
+    }, [&](int e, float v) { Hqs[(e / H) * (H + 1) + e % H] = v; });
+    if (O) {
+        fill_batched<8>(O * C, [&](int e) { return a.ws[e]; }, [&](int e, float v) { Wss[(e / C) * C4 + e % C] = v; });
+        fill_batched<8>(nq * O, [&](int e) { return a.gpre[(size_t)q0 * O + e]; },
+                        [&](int e, float v) { gps[(e / O) * (O + 1) + e % O] = v; });
     }
     __syncthreads();
-    // 2. wave ty: channels [cbeg, cend), at most 16
-    {
-        const int cpw = (C + 3) / 4;
-        const int cbeg = ty * cpw, cend = min(C, cbeg + cpw);
-        float acc[16];
+    // ---- phase 1: what needed an index first (the skip branch's rows; the rows that gather each point)
+    float acc[HPW];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-#pragma unroll 2
-        for (int h = 0; h < H; ++h) {
-            const float g = Gs[tx * (H + 1) + h];
-            const float *wr = W1s + h * ldw + 3 + cbeg;
+    for (int v = 0; v < HPW; ++v) acc[v] = 0.0f;
+    for (int i0 = 0; i0 < cnt; i0 += 4) {                      // four rows in flight
+        int rr[4];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] = __builtin_fmaf(g, cbeg + j < cend ? wr[j] : 0.0f, acc[j]);
+        for (int u = 0; u < 4; ++u) rr[u] = i0 + u < cnt ? l[i0 + u] : -1;
+        float4 x[4][HPW / 4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 *__restrict__ g = reinterpret_cast<const float4 *>(a.GU + (size_t)(rr[u] < 0 ? 0 : rr[u]) * H + h0);
+#pragma unroll
+            for (int v = 0; v < HPW / 4; ++v) x[u][v] = rr[u] < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : g[v];
         }
-        if (O) {                                   // rows of points that are no query are zero
-#pragma unroll 2
-            for (int o = 0; o < O; ++o) {
-                const float g = gpt[tx * (O + 1) + o];
-                const float *wr = Wss + o * (C + 1) + cbeg;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] = __builtin_fmaf(g, cbeg + j < cend ? wr[j] : 0.0f, acc[j]);
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < HPW / 4; ++v) {
+                acc[4 * v] += x[u][v].x; acc[4 * v + 1] += x[u][v].y; acc[4 * v + 2] += x[u][v].z; acc[4 * v + 3] += x[u][v].w;
             }
-        }
-        if (ok) {
+    }
+    if (O) {
+        fill_batched<8>(64 * O, [&](int e) {
+            const int pl = e / O, o = e - pl * O;
+            const int q = fqs[pl];
+            return q >= 0 ? a.gpre[((size_t)((pbase + pl) / a.N) * a.M + q) * O + o] : 0.0f;
+        }, [&](int e, float v) { gpt[(e / O) * (O + 1) + e % O] = v; });
+        fill_batched<8>(nq * C, [&](int e) {
+            const int c = e / nq, q = e - c * nq;
+            return a.f[((size_t)((q0 + q) / a.M) * C + c) * a.N + fis[q]];
+        }, [&](int e, float v) { fgs[(e / nq) * (qpb + 1) + e % nq] = v; });
+    }
+    // 1. G = ca sum GU + cb inv1 (occ (U - mean1) - SP . W1p / r) + cc occ
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (cbeg + j < cend) a.g_f[((size_t)b * C + cbeg + j) * a.N + n] = acc[j];
+    for (int v = 0; v < HPW; ++v) {
+        const int h = h0 + v;
+        const float spw = __builtin_fmaf(ge.w, W1p[h * 4 + 2], __builtin_fmaf(ge.z, W1p[h * 4 + 1], ge.y * W1p[h * 4]));
+        const float yh = a.pack1[3 * H + h] * (ge.x * (ur[v] - a.pack1[2 * H + h]) - spw * a.inv_r);
+        const float G = __builtin_fmaf(a.cabc[h], acc[v], __builtin_fmaf(a.cabc[H + h], yh, a.cabc[2 * H + h] * ge.x));
+        Gs[tx * (H + 1) + h] = ok ? G : 0.0f;
+    }
+    __syncthreads();
+    // 2. wave ty: channels [cbeg, cend) (at most 16, a multiple of 4): dL/df = G W1f (+ Ws^T gpre at the sampled points)
+    {
+        const int cpw = up4((C + 3) / 4);
+        const int cbeg = ty * cpw, cend = min(C, cbeg + cpw);
+        float o16[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o16[j] = 0.0f;
+        if (cbeg < cend) {
+#pragma unroll 4
+            for (int h = 0; h < H; ++h) {
+                const float g = Gs[tx * (H + 1) + h];
+                const float4 *wr = reinterpret_cast<const float4 *>(W1f + h * C + cbeg);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (cbeg + 4 * k < cend) {
+                        const float4 wv = wr[k];
+                        o16[4 * k] = __builtin_fmaf(g, wv.x, o16[4 * k]);
+                        o16[4 * k + 1] = __builtin_fmaf(g, wv.y, o16[4 * k + 1]);
+                        o16[4 * k + 2] = __builtin_fmaf(g, wv.z, o16[4 * k + 2]);
+                        o16[4 * k + 3] = __builtin_fmaf(g, wv.w, o16[4 * k + 3]);
+                    }
+                }
+            }
+            if (O) {                               // rows of points that are no query are zero
+#pragma unroll 4
+                for (int o = 0; o < O; ++o) {
+                    const float g = gpt[tx * (O + 1) + o];
+                    const float4 *wr = reinterpret_cast<const float4 *>(Wss + o * C4 + cbeg);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (cbeg + 4 * k < cend) {
+                            const float4 wv = wr[k];
+                            o16[4 * k] = __builtin_fmaf(g, wv.x, o16[4 * k]);
+                            o16[4 * k + 1] = __builtin_fmaf(g, wv.y, o16[4 * k + 1]);
+                            o16[4 * k + 2] = __builtin_fmaf(g, wv.z, o16[4 * k + 2]);
+                            o16[4 * k + 3] = __builtin_fmaf(g, wv.w, o16[4 * k + 3]);
+                        }
+                    }
+                }
+            }
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (cbeg + j < cend) a.g_f[((size_t)b * C + cbeg + j) * a.N + n] = o16[j];
+            }
         }
         if (a.g_p && ty < 3) {
             float s = 0.0f;
-            for (int h = 0; h < H; ++h) s = __builtin_fmaf(Gs[tx * (H + 1) + h], W1s[h * ldw + ty], s);
+#pragma unroll 4
+            for (int h = 0; h < H; ++h) s = __builtin_fmaf(Gs[tx * (H + 1) + h], W1p[h * 4 + ty], s);
             if (ok) a.g_p[ptc * 3 + ty] = s * a.inv_r;
         }
     }
-    // 3. 4 x 4 register tiles of dW1[h][c'] over the 64 points (columns cq, cq + tcols, ...: lanes consecutive)
+    // 3. 4 x 4 register tiles of dW1[h][c'] over the 64 points (columns cq, cq + tcols, ...: lanes consecutive),
+    //    then of dWs[o][c] over the block's queries
     float *__restrict__ wrow = a.Wpart + (size_t)blockIdx.x * ((size_t)H * ldw + (size_t)O * C + O);
     const int tcols = (ldw + 3) / 4, ntile = (H / 4) * tcols;
-    const int stiles = O ? (O / 4) * ((C + 3) / 4) : 0;             // tiles of dWs
+    const int scols = (C + 3) / 4, stiles = O ? (O / 4) * scols : 0;
     for (int tile = threadIdx.x; tile < ntile + stiles; tile += 256) {
-        float acc[4][4];
+        float t4[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+            for (int j = 0; j < 4; ++j) t4[i][j] = 0.0f;
         if (tile < ntile) {
             const int hq = tile / tcols, cq = tile - hq * tcols;
             const int hb = hq * 4;
@@ -509,22 +603,23 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(g[i], x[j], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) t4[i][j] = __builtin_fmaf(g[i], x[j], t4[i][j]);
             }
             if (cq < 3) {        // coordinate column d = cq: minus this block's queries' Hq[q][h] new_p[q][d] / r
+#pragma unroll 4
                 for (int q = 0; q < nq; ++q) {
                     const float xd = nps[q * 3 + cq];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][0] = __builtin_fmaf(-Hqs[q * (H + 1) + hb + i], xd, acc[i][0]);
+                    for (int i = 0; i < 4; ++i) t4[i][0] = __builtin_fmaf(-Hqs[q * (H + 1) + hb + i], xd, t4[i][0]);
                 }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (cq + j * tcols < ldw) wrow[(size_t)(hb + i) * ldw + cq + j * tcols] = acc[i][j];
+                    if (cq + j * tcols < ldw) wrow[(size_t)(hb + i) * ldw + cq + j * tcols] = t4[i][j];
         } else {
-            const int st = tile - ntile, scols = (C + 3) / 4;
+            const int st = tile - ntile;
             const int oq = st / scols, cq = st - oq * scols;
             const int ob = oq * 4;
 #pragma unroll 4
@@ -537,14 +632,14 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(g[i], x[j], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) t4[i][j] = __builtin_fmaf(g[i], x[j], t4[i][j]);
             }
             float *__restrict__ srow = wrow + (size_t)H * ldw;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (cq + j * scols < C) srow[(size_t)(ob + i) * C + cq + j * scols] = acc[i][j];
+                    if (cq + j * scols < C) srow[(size_t)(ob + i) * C + cq + j * scols] = t4[i][j];
         }
     }
     if (O) {
@@ -554,12 +649,13 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
             wrow[(size_t)H * ldw + (size_t)O * C + o] = s;
         }
     }
-    // 4.
+    // 4. dL/dnew_p = -Hq W1p / r
     if (a.g_q) {
         for (int e = threadIdx.x; e < nq * 3; e += 256) {
             const int q = e / 3, d = e - q * 3;
             float s = 0.0f;
-            for (int h = 0; h < H; ++h) s = __builtin_fmaf(Hqs[q * (H + 1) + h], W1s[h * ldw + d], s);
+#pragma unroll 4
+            for (int h = 0; h < H; ++h) s = __builtin_fmaf(Hqs[q * (H + 1) + h], W1p[h * 4 + d], s);
             a.g_q[(q0 + q) * 3 + d] = -s * a.inv_r;
         }
     }
@@ -568,24 +664,25 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
 // column sums like wide_colsum (sa_wide.hip), one level, float32 result: out[c] = sum_r part[r][c] in float64
 __global__ __launch_bounds__(1024) void wide_colsum_f32_kernel(const float *__restrict__ part, int rows, int ncol,
                                                                float *__restrict__ out) {
-    __shared__ double red[16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;     // 64 columns x 16 row groups
+    __shared__ double red[32][33];
+    const int tx = threadIdx.x & 31, g = threadIdx.x >> 5;                         // 32 columns x 32 row groups
+    const int c = blockIdx.x * 32 + tx;
     double s = 0.0;
     if (c < ncol) {
-        for (int r0 = g; r0 < rows; r0 += 256) {                                   // 16 independent loads in flight
+        for (int r0 = g; r0 < rows; r0 += 512) {                                   // 16 independent loads in flight
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = r0 + 16 * u < rows ? part[(size_t)(r0 + 16 * u) * ncol + c] : 0.0f;
+            for (int u = 0; u < 16; ++u) v[u] = r0 + 32 * u < rows ? part[(size_t)(r0 + 32 * u) * ncol + c] : 0.0f;
 #pragma unroll
             for (int u = 0; u < 16; ++u) s += (double)v[u];
         }
     }
-    red[g][threadIdx.x & 63] = s;
+    red[g][tx] = s;
     __syncthreads();
     if (g == 0 && c < ncol) {
         double tot = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) tot += red[k][threadIdx.x];
+        for (int k = 0; k < 32; ++k) tot += red[k][tx];
         out[c] = (float)tot;
     }
 }
@@ -618,7 +715,8 @@ extern "C" int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, in
     const long long ib = (c_out / 32) * (c_mid / 32);          // 256 words per (column tile, k chunk)
     if (pb + qb + ib > 0x7fffffffLL) return APN_EINVAL;
     APN_DENSE_DISPATCH(c_mid, {
-        const size_t lds = (size_t)64 * (4 * HPW + 1) * sizeof(float);
+        const size_t lds = ((size_t)64 * (4 * HPW + 1) + (size_t)4 * HPW * (c_in + 3)) * sizeof(float);
+        if (lds > 160 * 1024) return APN_EINVAL;
         if (lds > 48 * 1024) {
             if (hipError_t e = hipFuncSetAttribute((const void *)wide_fwd_prep_kernel<HPW>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
@@ -693,7 +791,7 @@ extern "C" int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid,
                                        const float *HB, const float *cabc, const float *pack1, const float *w1,
                                        int c_skip, const float *gpre, const int *fq, const int *fidx, const float *ws,
                                        float *g_f, float *g_p, float *g_q, float *w_part, void *stream) {
-    if (b <= 0 || c_in <= 0 || c_in > 64 || n <= 0 || m <= 0 || (c_mid != 32 && c_mid != 64) || !(radius > 0.0f) ||
+    if (b <= 0 || c_in <= 0 || c_in > 64 || (c_in % 4) || n <= 0 || m <= 0 || (c_mid != 32 && c_mid != 64) || !(radius > 0.0f) ||
         !GU || !pcnt_poff || !plist || !geo || !U || !f || !p || !new_p || !HA || !HB || !cabc || !pack1 || !w1 || !g_f ||
         !w_part || c_skip < 0 || (c_skip % 4) || (c_skip && (!gpre || !fq || !fidx || !ws)))
         return APN_EINVAL;
@@ -709,12 +807,7 @@ extern "C" int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid,
     a.gpre = gpre; a.fq = fq; a.fidx = fidx; a.ws = ws;
     a.g_f = g_f; a.g_p = g_p; a.g_q = g_q; a.Wpart = w_part;
     APN_DENSE_DISPATCH(c_mid, {
-        const int H = 4 * HPW, ldw = c_in + 3;
-        const size_t lds = ((size_t)64 * (H + 1) + (size_t)ldw * 65 + (size_t)H * ldw + (size_t)a.qpb * (H + 1) +
-                            (size_t)c_skip * (c_in + 1) + (size_t)a.qpb * (c_skip + 1) +
-                            (c_skip ? (size_t)c_in * (a.qpb + 1) : 0) + (size_t)a.qpb * 3 +
-                            (c_skip ? (size_t)64 * (c_skip + 1) : 0)) *
-                           sizeof(float);
+        const size_t lds = (size_t)PgLds(4 * HPW, c_in, c_skip, a.qpb).total * sizeof(float);
         if (lds > 160 * 1024) return APN_EINVAL;
         if (lds > 48 * 1024) {
             if (hipError_t e = hipFuncSetAttribute((const void *)wide_point_grads_kernel<HPW>,
@@ -729,7 +822,7 @@ extern "C" int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid,
 
 extern "C" int apn_sa_wide_colsum_f32(const float *part, int rows, int ncol, float *out, void *stream) {
     if (rows < 0 || ncol <= 0 || !part || !out) return APN_EINVAL;
-    hipLaunchKernelGGL(wide_colsum_f32_kernel, dim3((ncol + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, rows, ncol,
+    hipLaunchKernelGGL(wide_colsum_f32_kernel, dim3((ncol + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, rows, ncol,
                        out);
     APN_LAUNCH_CHECK();
     return APN_OK;

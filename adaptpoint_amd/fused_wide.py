@@ -155,7 +155,7 @@ def _training(bn):
 def lean(C, H):
     """Shapes whose dense products (conv1 at the points, Qm, dL/df, dL/dW1) run in the path's own fused
     kernels (csrc/sa_wide_dense.hip); wider ones hand them to library GEMMs."""
-    return C <= LEAN_MAX and H <= LEAN_MAX
+    return C <= LEAN_MAX and H <= LEAN_MAX and C % 4 == 0
 
 
 class _WideBlock(torch.autograd.Function):
