@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256, 2) void wide_fwd_prep_kernel(int B, int C, int
                                                             const float *__restrict__ w1, float inv_r,
                                                             float *__restrict__ U, float *__restrict__ V,
                                                             const float *__restrict__ w2, int O, int ct,
-                                                            uint4 *__restrict__ img) {
+                                                            uint4 *__restrict__ img, const int *__restrict__ fq,
+                                                            float *__restrict__ fs) {
     constexpr int H = 4 * HPW;
     extern __shared__ float sm[];                       // [64][H + 1]
     const int ldw = C + 3;
@@ -62,6 +63,17 @@ __global__ __launch_bounds__(256, 2) void wide_fwd_prep_kernel(int B, int C, int
 #pragma unroll
             for (int j = 0; j < 32; ++j) fv[j] = c0 + j < C ? fb[(size_t)(c0 + j) * N] : 0.0f;
             if (c0 == 0) __syncthreads();
+            if (fs && h0 == 0 && pt < npts) {
+                // the sampled points' own features as query-major rows fs[b][q][:] (what the residual branch reads,
+                // forward and backward): this thread holds its point's channels anyway
+                const int q = fq[pt];
+                if (q >= 0) {
+                    float4 *__restrict__ dst = reinterpret_cast<float4 *>(fs + ((size_t)b * M + q) * C + c0);
+#pragma unroll
+                    for (int j4 = 0; j4 < 8; ++j4)
+                        if (c0 + 4 * j4 < C) dst[j4] = make_float4(fv[4 * j4], fv[4 * j4 + 1], fv[4 * j4 + 2], fv[4 * j4 + 3]);
+                }
+            }
 #pragma unroll 8
             for (int j = 0; j < 32; ++j) {
                 if (c0 + j < C) {
@@ -121,17 +133,17 @@ __global__ __launch_bounds__(256, 2) void wide_fwd_prep_kernel(int B, int C, int
 
 // ------------------------------------------------------------------------------------------
 // out[b][o][q] = act(ysel[b][q][o] * scale2[o] + shift2[o] + skip[b][o][q]): 64 x 64 tiles through LDS,
-// grid (M/64, O/64, B).  skip (optional) = Ws f[b, :, fidx[b, q]] + bs: the block's residual branch, a 1x1
-// convolution of the SAMPLED points' own features (pointnext.py:150-153, 167-168), 64 input channels at a time
-// through LDS; act = ReLU when `relu`.
+// grid (M/64, O/64, B).  skip (optional) = Ws fs[b, q, :] + bs: the block's residual branch, a 1x1
+// convolution of the SAMPLED points' own features (pointnext.py:150-153, 167-168; fs = their rows, gathered
+// by wide_fwd_prep), 64 input channels at a time through LDS; act = ReLU when `relu`.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wide_out_kernel(int M, int O, int C, int N, const float *__restrict__ ysel,
-                                                       const float *__restrict__ pack2, const float *__restrict__ f,
-                                                       const int *__restrict__ fidx, const float *__restrict__ ws,
+__global__ __launch_bounds__(256) void wide_out_kernel(int M, int O, int C, const float *__restrict__ ysel,
+                                                       const float *__restrict__ pack2, const float *__restrict__ fs,
+                                                       const float *__restrict__ ws,
                                                        const float *__restrict__ bs, int relu,
                                                        float *__restrict__ out) {
     __shared__ float tile[64][65];
-    __shared__ float fg[64][65];      // [c][q]
+    __shared__ float fg[64][65];      // [q][c]
     __shared__ float wt[64][65];      // [o][c]
     const int b = blockIdx.z, c0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -144,18 +156,17 @@ __global__ __launch_bounds__(256) void wide_out_kernel(int M, int O, int C, int 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     if (ws) {
-        const int q = m0 + tx;
-        const int src = q < M ? fidx[(size_t)b * M + q] : 0;
         for (int k0 = 0; k0 < C; k0 += 64) {
             __syncthreads();
             for (int cc = ty; cc < 64; cc += 4) {
-                fg[cc][tx] = (k0 + cc < C && q < M) ? f[((size_t)b * C + k0 + cc) * N + src] : 0.0f;
+                const int q = m0 + cc;                                                      // fg[q = cc][c = tx]
+                fg[cc][tx] = (k0 + tx < C && q < M) ? fs[((size_t)b * M + q) * C + k0 + tx] : 0.0f;
                 wt[cc][tx] = k0 + tx < C ? ws[(size_t)(c0 + cc) * C + k0 + tx] : 0.0f;      // wt[o = cc][c = tx]
             }
             __syncthreads();
             const int kn = C - k0 < 64 ? C - k0 : 64;
             for (int c = 0; c < kn; ++c) {
-                const float x = fg[c][tx];
+                const float x = fg[tx][c];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = __builtin_fmaf(wt[ty + 4 * i][c], x, acc[i]);
             }
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(1024) void wide_bwd_fin_kernel(const float *__restr
 //      branch's input gradient);  dL/dp[pt][d] = sum_h G W1p[h][d] / r
 //   3. this block's share of dL/dW1[h][c'] = sum_pt G[pt][h] X[c'][pt], X = [p / r ; f] (LDS), minus its
 //      queries' Hq[q][h] new_p[q][d] / r in the coordinate columns;  Hq = ca HA + cb HB + 32 cc;
-//      of dL/dWs[o][c] = sum_q gpre[q][o] f[b, c, fidx[q]] and of dL/dbs[o] = sum_q gpre[q][o]
+//      of dL/dWs[o][c] = sum_q gpre[q][o] fs[q][c] and of dL/dbs[o] = sum_q gpre[q][o]
 //   4. dL/dnew_p[q][d] = -sum_h Hq W1p[h][d] / r
 //   Wpart[block][H (C + 3) + O C + O]: summed over blocks by wide_colsum_f32 (fixed order).
 // ------------------------------------------------------------------------------------------
@@ -376,7 +387,8 @@ struct PointGradArgs {
     const float *HA, *HB;                // (B M, H)
     const float *cabc, *pack1, *w1;
     const float *gpre;                   // (B M, O) gradient at the block's pre-activation output
-    const int *fq, *fidx;                // (B N): the query a point is (-1: none);  (B M): the point a query is
+    const int *fq;                       // (B N): the query a point is (-1: none)
+    const float *fs;                     // (B M, C): the sampled points' own features (wide_fwd_prep)
     const float *ws;                     // (O, C)
     float inv_r;
     float *g_f, *g_p, *g_q, *Wpart;      // g_p / g_q may be null
@@ -386,7 +398,7 @@ __host__ __device__ inline int up4(int x) { return (x + 3) & ~3; }
 
 // LDS layout of wide_point_grads (floats; every sub-array starts 16-byte aligned)
 struct PgLds {
-    int gs, xs, w1f, w1p, hqs, nps, fqs, wss, gps, fgs, gpt, fis, total;
+    int gs, xs, w1f, w1p, hqs, nps, fqs, wss, gps, fgs, gpt, total;
     __host__ __device__ PgLds(int H, int C, int O, int qpb) {
         int o = 0;
         gs = o; o += up4(64 * (H + 1));
@@ -400,7 +412,6 @@ struct PgLds {
         gps = o; o += up4(qpb * (O + 1));
         fgs = o; o += O ? up4(C * (qpb + 1)) : 0;
         gpt = o; o += O ? up4(64 * (O + 1)) : 0;
-        fis = o; o += O ? up4(qpb) : 0;
         total = o;
     }
 };
@@ -436,7 +447,6 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
     float *gps = sm + L.gps;                         // [qpb][O + 1]  gpre rows of the block's queries
     float *fgs = sm + L.fgs;                         // [C][qpb + 1]  their source points' features
     float *gpt = sm + L.gpt;                         // [64][O + 1]   gpre rows of the block's POINTS that are queries
-    int *fis = reinterpret_cast<int *>(sm + L.fis);  // [qpb]       the point each of the block's queries is
     const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long npts = (long long)a.B * a.N, nqry = (long long)a.B * a.M;
     const long long pbase = (long long)blockIdx.x * 64;
@@ -459,7 +469,6 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
     }
     if (O) {
         if (ty == 0) fqs[tx] = ok ? a.fq[ptc] : -1;
-        if ((int)threadIdx.x < nq) fis[threadIdx.x] = a.fidx[q0 + threadIdx.x];
     }
     fill_batched<8>(ldw * 64, [&](int e) {                       // X tile: coordinates / r, then the features
         const int cc = e >> 6, pl = e & 63;
@@ -511,10 +520,8 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
             const int q = fqs[pl];
             return q >= 0 ? a.gpre[((size_t)((pbase + pl) / a.N) * a.M + q) * O + o] : 0.0f;
         }, [&](int e, float v) { gpt[(e / O) * (O + 1) + e % O] = v; });
-        fill_batched<8>(nq * C, [&](int e) {
-            const int c = e / nq, q = e - c * nq;
-            return a.f[((size_t)((q0 + q) / a.M) * C + c) * a.N + fis[q]];
-        }, [&](int e, float v) { fgs[(e / nq) * (qpb + 1) + e % nq] = v; });
+        fill_batched<8>(nq * C, [&](int e) { return a.fs[(size_t)q0 * C + e]; },
+                        [&](int e, float v) { fgs[(e % C) * (qpb + 1) + e / C] = v; });
     }
     // 1. G = ca sum GU + cb inv1 (occ (U - mean1) - SP . W1p / r) + cc occ
 #pragma unroll
@@ -706,9 +713,9 @@ using namespace apn;
 
 extern "C" int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, int c_out, float radius, const float *f,
                                     const float *p, const float *new_p, const float *w1, const float *w2, float *U,
-                                    float *V, void *w2_image, void *stream) {
+                                    float *V, void *w2_image, const int *fq, float *fs, void *stream) {
     if (b <= 0 || c_in <= 0 || n <= 0 || m <= 0 || !dense_shape_ok(c_mid, c_out) || !(radius > 0.0f) || !f || !p ||
-        !new_p || !w1 || !w2 || !U || !V || !w2_image)
+        !new_p || !w1 || !w2 || !U || !V || !w2_image || (fs && (!fq || (c_in % 4))))
         return APN_EINVAL;
     const long long pb = ((long long)b * n + 63) / 64, qb = ((long long)b * m * c_mid + 255) / 256;
     const int ct = c_out / 32 >= 4 ? 4 : c_out / 32;
@@ -724,19 +731,19 @@ extern "C" int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, in
         }
         hipLaunchKernelGGL((wide_fwd_prep_kernel<HPW>), dim3((unsigned)(pb + qb + ib)), dim3(256), lds,
                            (hipStream_t)stream, b, c_in, n, m, (int)pb, (int)qb, f, p, new_p, w1, 1.0f / radius, U, V,
-                           w2, c_out, ct, (uint4 *)w2_image);
+                           w2, c_out, ct, (uint4 *)w2_image, fq, fs);
     });
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
-extern "C" int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, int c_in, int n,
-                               const float *f, const int *fidx, const float *ws, const float *bs, int relu,
-                               float *out, void *stream) {
+extern "C" int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, int c_in,
+                               const float *fs, const float *ws, const float *bs, int relu, float *out,
+                               void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || c_out <= 0 || (c_out % 64) || !ysel || !pack2 || !out) return APN_EINVAL;
-    if (ws && (!f || !fidx || c_in <= 0 || n <= 0)) return APN_EINVAL;
+    if (ws && (!fs || c_in <= 0)) return APN_EINVAL;
     hipLaunchKernelGGL(wide_out_kernel, dim3((m + 63) / 64, c_out / 64, b), dim3(256), 0, (hipStream_t)stream, m, c_out,
-                       c_in, n, ysel, pack2, f, fidx, ws, bs, relu, out);
+                       c_in, ysel, pack2, fs, ws, bs, relu, out);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -789,11 +796,11 @@ extern "C" int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid,
                                        const int *pcnt_poff, const int *plist, const float *geo, const float *U,
                                        const float *f, const float *p, const float *new_p, const float *HA,
                                        const float *HB, const float *cabc, const float *pack1, const float *w1,
-                                       int c_skip, const float *gpre, const int *fq, const int *fidx, const float *ws,
+                                       int c_skip, const float *gpre, const int *fq, const float *fs, const float *ws,
                                        float *g_f, float *g_p, float *g_q, float *w_part, void *stream) {
     if (b <= 0 || c_in <= 0 || c_in > 64 || (c_in % 4) || n <= 0 || m <= 0 || (c_mid != 32 && c_mid != 64) || !(radius > 0.0f) ||
         !GU || !pcnt_poff || !plist || !geo || !U || !f || !p || !new_p || !HA || !HB || !cabc || !pack1 || !w1 || !g_f ||
-        !w_part || c_skip < 0 || (c_skip % 4) || (c_skip && (!gpre || !fq || !fidx || !ws)))
+        !w_part || c_skip < 0 || (c_skip % 4) || (c_skip && (!gpre || !fq || !fs || !ws)))
         return APN_EINVAL;
     const long long npts = (long long)b * n, nqry = (long long)b * m;
     const long long blocks = (npts + 63) / 64;
@@ -804,7 +811,7 @@ extern "C" int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid,
     a.GU = GU; a.pcnt = pcnt_poff; a.poff = pcnt_poff + npts; a.plist = plist; a.geo = geo;
     a.U = U; a.f = f; a.p = p; a.new_p = new_p; a.HA = HA; a.HB = HB;
     a.cabc = cabc; a.pack1 = pack1; a.w1 = w1; a.inv_r = 1.0f / radius;
-    a.gpre = gpre; a.fq = fq; a.fidx = fidx; a.ws = ws;
+    a.gpre = gpre; a.fq = fq; a.fs = fs; a.ws = ws;
     a.g_f = g_f; a.g_p = g_p; a.g_q = g_q; a.Wpart = w_part;
     APN_DENSE_DISPATCH(c_mid, {
         const size_t lds = (size_t)PgLds(4 * HPW, c_in, c_skip, a.qpb).total * sizeof(float);

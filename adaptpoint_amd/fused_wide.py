@@ -184,8 +184,11 @@ class _WideBlock(torch.autograd.Function):
                 V = torch.empty(B, M, H, **f32)
                 ct = min(4, O // 32)
                 w2img = torch.empty(O // (32 * ct), H // 32, ct, 2, 2, 64, 8, dtype=torch.bfloat16, device=dev)
+                # (with a residual branch: also the sampled points' own features as rows fs (B,M,C))
+                fs = torch.empty(B, M, C, **f32) if Ws is not None else None
                 _call("apn_sa_wide_fwd_prep", dev, B, C, N, M, H, O, float(radius), f.data_ptr(), p.data_ptr(),
-                      new_p.data_ptr(), W1.data_ptr(), W2.data_ptr(), U.data_ptr(), V.data_ptr(), w2img.data_ptr())
+                      new_p.data_ptr(), W1.data_ptr(), W2.data_ptr(), U.data_ptr(), V.data_ptr(), w2img.data_ptr(),
+                      _fz._ptr(nbr.fq if Ws is not None else None), _fz._ptr(fs))
             else:
                 W1p, W1f = W1[:, :3], W1[:, 3:]
                 U = torch.baddbmm(torch.matmul(p, W1p.t()) / radius, f.transpose(1, 2), W1f.t().expand(B, C, H)).contiguous()
@@ -208,13 +211,14 @@ class _WideBlock(torch.autograd.Function):
                   part2.data_ptr())
             pack2, _, _ = _bn_pack(part2 if tr2 else None, grid, O, count, bn2, dev, tr2, sync)
             out = torch.empty(B, O, M, **f32)
-            _call("apn_sa_wide_out", dev, B, M, O, ysel.data_ptr(), pack2.data_ptr(), C, N, f.data_ptr(),
-                  _fz._ptr(nbr.fidx if Ws is not None else None), _fz._ptr(Ws),
+            _call("apn_sa_wide_out", dev, B, M, O, ysel.data_ptr(), pack2.data_ptr(), C,
+                  _fz._ptr(fs if Ws is not None else None), _fz._ptr(Ws),
                   _fz._ptr(None if bs is None else bs.detach()), 1 if relu else 0, out.data_ptr())
             if _DEBUG is not None:
                 _DEBUG.update(U=U, V=V, pack1=pack1, w2img=w2img, ysel=ysel, ksel=ksel, part2=part2, pack2=pack2,
                               sgn2=sgn2)
-        ctx.save_for_backward(p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2, Ws, out if relu else None)
+        ctx.save_for_backward(p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2, Ws, out if relu else None,
+                              fs if Ws is not None else None)
         ctx.nbr = nbr
         ctx.cfg = (radius, tr1, tr2, sync, count, relu, g1 is not None, b1 is not None, g2 is not None, b2 is not None,
                    bs is not None)
@@ -223,7 +227,7 @@ class _WideBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2, Ws, out_act = ctx.saved_tensors
+        p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2, Ws, out_act, fs = ctx.saved_tensors
         nbr = ctx.nbr
         idx, tmap = nbr.idx, nbr.tmap
         radius, tr1, tr2, sync, count, relu, a1, a2, a3, a4, a5 = ctx.cfg
@@ -316,7 +320,7 @@ class _WideBlock(torch.autograd.Function):
             _call("apn_sa_wide_point_grads", dev, B, C, N, M, H, float(radius), GU.data_ptr(), nbr.pcnt_poff.data_ptr(),
                   nbr.plist.data_ptr(), nbr.geo.data_ptr(), U.data_ptr(), f.data_ptr(), p.data_ptr(), new_p.data_ptr(),
                   HA.data_ptr(), HB.data_ptr(), cabc.data_ptr(), pack1.data_ptr(), W1.data_ptr(), Os, _fz._ptr(gpre),
-                  _fz._ptr(nbr.fq if Os else None), _fz._ptr(nbr.fidx if Os else None), _fz._ptr(Ws), g_f.data_ptr(),
+                  _fz._ptr(nbr.fq if Os else None), _fz._ptr(fs), _fz._ptr(Ws), g_f.data_ptr(),
                   _fz._ptr(g_p), _fz._ptr(g_q), Wpart.data_ptr())
             wsum = torch.empty(wcols, **f32)
             _call("apn_sa_wide_colsum_f32", dev, Wpart.data_ptr(), wrows, wcols, wsum.data_ptr())

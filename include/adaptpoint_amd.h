@@ -434,10 +434,11 @@ APN_API int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *ne
                             int *pcnt_poff, int *plist, float *geo, const int *fidx, int *fq, void *stream);
 /* The dense kernels of the path (csrc/sa_wide_dense.hip), one launch each:
  * fwd_prep: U (B,N,H) = W1f f + W1p p / r, V (B,M,H) = W1p new_p / r (w1: H x (C+3), coordinates first, as the
- *   reference's cat([dp, fj])), and the B image of W2^T (w2: O x H).
+ *   reference's cat([dp, fj])), and the B image of W2^T (w2: O x H); with fq (B,N; apn_sa_wide_csr) also
+ *   fs (B,M,C) = the sampled points' own features f[:, :, fidx] as query-major rows (fs NULL: not wanted).
  * out: out (B,O,M) = act(ysel (B,M,O) scale2 + shift2 + skip) (pack2 = {scale, shift, mean, invstd}[O]);
- *   skip = ws (O x C) f[:, :, fidx] + bs, the residual branch on the sampled points' features (ws NULL: none;
- *   bs may be NULL); act = ReLU when relu.
+ *   skip = ws (O x C) fs + bs, the residual branch on the sampled points' features fs (B,M,C) of fwd_prep
+ *   (ws NULL: none; bs may be NULL); act = ReLU when relu.
  * bwd_mid: from part_s (or `sums`, as consts2): d2e2, dgamma2, dbeta2, evec[H] = E2 W2 and the B image of
  *   [W2 ; Qm], Qm = W2^T diag(D2) W2.
  * bwd_fin: from part_t (or `sums`, as consts1): cabc, dgamma1, dbeta1; and g_w2 (O,H) = R_S + D2 (W2 Gram)
@@ -445,16 +446,15 @@ APN_API int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *ne
  * point_grads (C, H <= 64): G = dL/dU per point (GU rows summed through the inverse map, plus BatchNorm-1's
  *   mean/variance terms), g_f (B,C,N) = G W1f, g_p (B,N,3) = G W1p / r, g_q (B,M,3) = -Hq W1p / r (either may
  *   be NULL); with a residual branch (c_skip = O > 0: gpre (B,M,O) from bwd_prep, fq (B,N) = the query a point
- *   is or -1, fidx (B,M), ws (O x C)) g_f also receives ws^T gpre at the sampled points;
+ *   is or -1, fs (B,M,C) of fwd_prep, ws (O x C)) g_f also receives ws^T gpre at the sampled points;
  *   w_part[apn_sa_wide_point_grads_rows(b, n)][apn_sa_wide_point_grads_cols(C, H, O)] = the workgroups' shares
  *   of {dL/dW1 (H x (C+3)), dL/dws (O x C), dL/dbs (O)}.
  * colsum_f32: out[ncol] (float32) = column sums (in float64, fixed order) of part[rows][ncol]. */
 APN_API int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, int c_out, float radius, const float *f,
                                  const float *p, const float *new_p, const float *w1, const float *w2, float *U,
-                                 float *V, void *w2_image, void *stream);
-APN_API int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, int c_in, int n,
-                            const float *f, const int *fidx, const float *ws, const float *bs, int relu, float *out,
-                            void *stream);
+                                 float *V, void *w2_image, const int *fq, float *fs, void *stream);
+APN_API int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, int c_in,
+                            const float *fs, const float *ws, const float *bs, int relu, float *out, void *stream);
 APN_API int apn_sa_wide_bwd_mid(const float *part_s, int rows, const double *sums, int c_mid, int c_out,
                                 const float *pack2, double count, int training, const float *w2, float *d2e2,
                                 float *g_gamma2, float *g_beta2, float *evec, void *z_image, void *stream);
@@ -467,7 +467,7 @@ APN_API int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid, fl
                                     const int *pcnt_poff, const int *plist, const float *geo, const float *U,
                                     const float *f, const float *p, const float *new_p, const float *HA,
                                     const float *HB, const float *cabc, const float *pack1, const float *w1,
-                                    int c_skip, const float *gpre, const int *fq, const int *fidx, const float *ws,
+                                    int c_skip, const float *gpre, const int *fq, const float *fs, const float *ws,
                                     float *g_f, float *g_p, float *g_q, float *w_part, void *stream);
 APN_API int apn_sa_wide_point_grads_cols(int c_in, int c_mid, int c_skip);
 APN_API int apn_sa_wide_colsum_f32(const float *part, int rows, int ncol, float *out, void *stream);
