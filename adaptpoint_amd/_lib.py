@@ -83,7 +83,8 @@ SIGNATURES = {
     "apn_sa_wide_point_terms": [_c_int] * 4 + [_c_void_p] * 5 + [_c_int, _c_float] + [_c_void_p] * 7,
     "apn_sa_wide_wgrad_splits": [_c_int] * 3,
     "apn_sa_wide_csr": [_c_int] * 3 + [_c_void_p] * 9,
-    "apn_sa_wide_fwd_prep": [_c_int] * 6 + [_c_float] + [_c_void_p] * 11,
+    "apn_sa_wide_fwd_prep": [_c_int] * 6 + [_c_float] + [_c_void_p] * 13,
+    "apn_sa_wide_fwd_prep_rows": [_c_int] * 3,
     "apn_sa_wide_out": [_c_int] * 3 + [_c_void_p] * 2 + [_c_int] + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 2,
     "apn_sa_wide_bwd_mid": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_double, _c_int] + [_c_void_p] * 7,
     "apn_sa_wide_bwd_fin": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_double, _c_int] + [_c_void_p] * 8,

@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256, 2) void wide_fwd_prep_kernel(int B, int C, int
                                                             float *__restrict__ U, float *__restrict__ V,
                                                             const float *__restrict__ w2, int O, int ct,
                                                             uint4 *__restrict__ img, const int *__restrict__ fq,
-                                                            float *__restrict__ fs) {
+                                                            float *__restrict__ fs, const float *__restrict__ geo,
+                                                            float *__restrict__ part1) {
     constexpr int H = 4 * HPW;
     extern __shared__ float sm[];                       // [64][H + 1]
     const int ldw = C + 3;
@@ -89,10 +90,41 @@ __global__ __launch_bounds__(256, 2) void wide_fwd_prep_kernel(int B, int C, int
                 }
             }
         }
+        // BatchNorm-1's statistics without a pass over the positions: y1 = U[n] - V[q] over the (query, slot)
+        // pairs, and everything a point contributes is known from the index stage's geo = {occ, SP = sum of the
+        // gathering queries' coordinates}:
+        //   sum y1   = sum_n occ U            - 32 sum_q V
+        //   sum y1^2 = sum_n (occ U^2 - 2 U (W1p . SP) / r)  + 32 sum_q V^2     (V[q] = W1p . new_p[q] / r)
+        // one partial row per block {sum, sumsq}[H] (the query terms come from the V blocks below)
+        float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (part1 && pt < npts) ge = *reinterpret_cast<const float4 *>(geo + pt * 4);
+        float t1[HPW], tq[HPW];
 #pragma unroll
         for (int hh = 0; hh < HPW; ++hh) {
-            const float pw = __builtin_fmaf(wt[2 * H + h0 + hh], pz, __builtin_fmaf(wt[H + h0 + hh], py, wt[h0 + hh] * px));
-            sm[tx * (H + 1) + h0 + hh] = __builtin_fmaf(pw, inv_r, acc[hh]);
+            const float wx = wt[h0 + hh], wy = wt[H + h0 + hh], wz = wt[2 * H + h0 + hh];
+            const float pw = __builtin_fmaf(wz, pz, __builtin_fmaf(wy, py, wx * px));
+            const float u = __builtin_fmaf(pw, inv_r, acc[hh]);
+            sm[tx * (H + 1) + h0 + hh] = u;
+            const float spw = __builtin_fmaf(wz, ge.w, __builtin_fmaf(wy, ge.z, wx * ge.y)) * inv_r;
+            t1[hh] = ge.x * u;
+            tq[hh] = u * __builtin_fmaf(ge.x, u, -2.0f * spw);
+        }
+        if (part1) {
+#pragma unroll
+            for (int k = 1; k < 64; k <<= 1) {
+#pragma unroll
+                for (int hh = 0; hh < HPW; ++hh) {
+                    t1[hh] += __shfl_xor(t1[hh], k);
+                    tq[hh] += __shfl_xor(tq[hh], k);
+                }
+            }
+            if (tx == 0) {
+#pragma unroll
+                for (int hh = 0; hh < HPW; ++hh) {
+                    part1[(size_t)blk * 2 * H + h0 + hh] = t1[hh];
+                    part1[(size_t)blk * 2 * H + H + h0 + hh] = tq[hh];
+                }
+            }
         }
         __syncthreads();
         const long long base = (long long)blk * 64;
@@ -101,13 +133,34 @@ __global__ __launch_bounds__(256, 2) void wide_fwd_prep_kernel(int B, int C, int
             if (base + pl < npts) U[(base + pl) * H + h] = sm[pl * (H + 1) + h];
         }
     } else if (blk < pblocks + qblocks) {
-        const long long e = (long long)(blk - pblocks) * 256 + threadIdx.x;
-        if (e >= (long long)B * M * H) return;
-        const long long q = e / H;
-        const int h = (int)(e - q * H);
+        // 64 queries: thread (channel h, query subgroup); the block's row of part1 = {-32 sum V, 32 sum V^2}
+        const int h = threadIdx.x % H, qs = threadIdx.x / H;
+        const long long nqry = (long long)B * M, qbase = (long long)(blk - pblocks) * 64;
         const float *__restrict__ wr = w1 + (size_t)h * ldw;
-        const float *__restrict__ qp = new_p + q * 3;
-        V[e] = __builtin_fmaf(wr[2], qp[2], __builtin_fmaf(wr[1], qp[1], wr[0] * qp[0])) * inv_r;
+        const float wx = wr[0], wy = wr[1], wz = wr[2];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll 4
+        for (int ql = qs; ql < 64; ql += 256 / H) {
+            const long long q = qbase + ql;
+            if (q < nqry) {
+                const float *__restrict__ qp = new_p + q * 3;
+                const float v = __builtin_fmaf(wz, qp[2], __builtin_fmaf(wy, qp[1], wx * qp[0])) * inv_r;
+                V[q * H + h] = v;
+                s1 += v;
+                s2 = __builtin_fmaf(v, v, s2);
+            }
+        }
+        if (part1) {
+            sm[qs * H + h] = s1;
+            sm[256 + qs * H + h] = s2;
+            __syncthreads();
+            if (threadIdx.x < H) {
+                float a1 = 0.0f, a2 = 0.0f;
+                for (int g = 0; g < 256 / H; ++g) { a1 += sm[g * H + h]; a2 += sm[256 + g * H + h]; }
+                part1[(size_t)blk * 2 * H + h] = -32.0f * a1;
+                part1[(size_t)blk * 2 * H + H + h] = 32.0f * a2;
+            }
+        }
     } else {
         // image of W2^T (H x O): word [cb][kc][j][s][part][lane], see wide_image_kernel (sa_wide_glue.hip)
         const int nkc = H / 32, ncb = O / (32 * ct);
@@ -713,11 +766,12 @@ using namespace apn;
 
 extern "C" int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, int c_out, float radius, const float *f,
                                     const float *p, const float *new_p, const float *w1, const float *w2, float *U,
-                                    float *V, void *w2_image, const int *fq, float *fs, void *stream) {
+                                    float *V, void *w2_image, const int *fq, float *fs, const float *geo, float *part1,
+                                    void *stream) {
     if (b <= 0 || c_in <= 0 || n <= 0 || m <= 0 || !dense_shape_ok(c_mid, c_out) || !(radius > 0.0f) || !f || !p ||
-        !new_p || !w1 || !w2 || !U || !V || !w2_image || (fs && (!fq || (c_in % 4))))
+        !new_p || !w1 || !w2 || !U || !V || !w2_image || (fs && (!fq || (c_in % 4))) || (part1 && !geo))
         return APN_EINVAL;
-    const long long pb = ((long long)b * n + 63) / 64, qb = ((long long)b * m * c_mid + 255) / 256;
+    const long long pb = ((long long)b * n + 63) / 64, qb = ((long long)b * m + 63) / 64;
     const int ct = c_out / 32 >= 4 ? 4 : c_out / 32;
     const long long ib = (c_out / 32) * (c_mid / 32);          // 256 words per (column tile, k chunk)
     if (pb + qb + ib > 0x7fffffffLL) return APN_EINVAL;
@@ -731,10 +785,16 @@ extern "C" int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, in
         }
         hipLaunchKernelGGL((wide_fwd_prep_kernel<HPW>), dim3((unsigned)(pb + qb + ib)), dim3(256), lds,
                            (hipStream_t)stream, b, c_in, n, m, (int)pb, (int)qb, f, p, new_p, w1, 1.0f / radius, U, V,
-                           w2, c_out, ct, (uint4 *)w2_image, fq, fs);
+                           w2, c_out, ct, (uint4 *)w2_image, fq, fs, geo, part1);
     });
     APN_LAUNCH_CHECK();
     return APN_OK;
+}
+
+// rows of part1 written by apn_sa_wide_fwd_prep: one per 64 points, one per 64 queries
+extern "C" int apn_sa_wide_fwd_prep_rows(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    return (int)(((long long)b * n + 63) / 64 + ((long long)b * m + 63) / 64);
 }
 
 extern "C" int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, int c_in,

@@ -179,6 +179,7 @@ class _WideBlock(torch.autograd.Function):
             W2 = w2.detach().reshape(O, H).contiguous()
             Ws = None if ws is None else ws.detach().reshape(O, C).contiguous()
             # conv1 at the points: one row per support point, one per query; the image of W2^T
+            part1, rows1 = None, 0
             if fusedd:
                 U = torch.empty(B, N, H, **f32)
                 V = torch.empty(B, M, H, **f32)
@@ -186,9 +187,15 @@ class _WideBlock(torch.autograd.Function):
                 w2img = torch.empty(O // (32 * ct), H // 32, ct, 2, 2, 64, 8, dtype=torch.bfloat16, device=dev)
                 # (with a residual branch: also the sampled points' own features as rows fs (B,M,C))
                 fs = torch.empty(B, M, C, **f32) if Ws is not None else None
+                # BatchNorm-1's batch statistics come out of the same launch (per-point / per-query terms weighted
+                # by the index stage's occurrence counts: no pass over the positions)
+                if _training(bn1) and K_NS == 32:
+                    rows1 = _lib.load().apn_sa_wide_fwd_prep_rows(B, N, M)
+                    part1 = torch.empty(rows1, 2 * H, **f32)
                 _call("apn_sa_wide_fwd_prep", dev, B, C, N, M, H, O, float(radius), f.data_ptr(), p.data_ptr(),
                       new_p.data_ptr(), W1.data_ptr(), W2.data_ptr(), U.data_ptr(), V.data_ptr(), w2img.data_ptr(),
-                      _fz._ptr(nbr.fq if Ws is not None else None), _fz._ptr(fs))
+                      _fz._ptr(nbr.fq if Ws is not None else None), _fz._ptr(fs),
+                      _fz._ptr(nbr.geo if part1 is not None else None), _fz._ptr(part1))
             else:
                 W1p, W1f = W1[:, :3], W1[:, 3:]
                 U = torch.baddbmm(torch.matmul(p, W1p.t()) / radius, f.transpose(1, 2), W1f.t().expand(B, C, H)).contiguous()
@@ -197,12 +204,12 @@ class _WideBlock(torch.autograd.Function):
             grid = _lib.load().apn_sa_wide_grid(B, M)
             count = float(B * M * K_NS)
             tr1, tr2 = _training(bn1), _training(bn2)
-            part1 = None
-            if tr1:
+            if tr1 and part1 is None:
+                rows1 = grid
                 part1 = torch.empty(grid, 2 * H, **f32)
                 _call("apn_sa_wide_stats1", dev, B, N, M, H, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
                       tmap.data_ptr(), part1.data_ptr())
-            pack1, sgn2, _ = _bn_pack(part1, grid, H, count, bn1, dev, tr1, sync, sgn_from=g2, sgn_c=O)
+            pack1, sgn2, _ = _bn_pack(part1, rows1, H, count, bn1, dev, tr1, sync, sgn_from=g2, sgn_c=O)
             ysel = torch.empty(B, M, O, **f32)
             ksel = torch.empty(B, M, O, dtype=torch.uint8, device=dev)
             part2 = torch.empty(grid, 2 * O, **f32)

@@ -435,7 +435,10 @@ APN_API int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *ne
 /* The dense kernels of the path (csrc/sa_wide_dense.hip), one launch each:
  * fwd_prep: U (B,N,H) = W1f f + W1p p / r, V (B,M,H) = W1p new_p / r (w1: H x (C+3), coordinates first, as the
  *   reference's cat([dp, fj])), and the B image of W2^T (w2: O x H); with fq (B,N; apn_sa_wide_csr) also
- *   fs (B,M,C) = the sampled points' own features f[:, :, fidx] as query-major rows (fs NULL: not wanted).
+ *   fs (B,M,C) = the sampled points' own features f[:, :, fidx] as query-major rows (fs NULL: not wanted);
+ *   with geo (B,N,4; apn_sa_wide_csr) also part1[apn_sa_wide_fwd_prep_rows(b, n, m)][2H] = partial {sum, sumsq}
+ *   of y1 over ALL positions -- BatchNorm-1's batch statistics from per-point and per-query terms alone
+ *   (sum y1 = sum_n occ U - 32 sum_q V, ...), in place of apn_sa_wide_stats1's pass (part1 NULL: not wanted).
  * out: out (B,O,M) = act(ysel (B,M,O) scale2 + shift2 + skip) (pack2 = {scale, shift, mean, invstd}[O]);
  *   skip = ws (O x C) fs + bs, the residual branch on the sampled points' features fs (B,M,C) of fwd_prep
  *   (ws NULL: none; bs may be NULL); act = ReLU when relu.
@@ -452,7 +455,9 @@ APN_API int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *ne
  * colsum_f32: out[ncol] (float32) = column sums (in float64, fixed order) of part[rows][ncol]. */
 APN_API int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, int c_out, float radius, const float *f,
                                  const float *p, const float *new_p, const float *w1, const float *w2, float *U,
-                                 float *V, void *w2_image, const int *fq, float *fs, void *stream);
+                                 float *V, void *w2_image, const int *fq, float *fs, const float *geo, float *part1,
+                                 void *stream);
+APN_API int apn_sa_wide_fwd_prep_rows(int b, int n, int m);
 APN_API int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const float *pack2, int c_in,
                             const float *fs, const float *ws, const float *bs, int relu, float *out, void *stream);
 APN_API int apn_sa_wide_bwd_mid(const float *part_s, int rows, const double *sums, int c_mid, int c_out,
