@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void wide_fwd_prep_kernel(int B, int C, int
 }
 
 // ------------------------------------------------------------------------------------------
-// out[b][o][q] = act(ysel[b][q][o] * scale2[o] + shift2[o] + skip[b][o][q]): 64 x 64 tiles through LDS,
-// grid (M/64, O/64, B).  skip (optional) = Ws fs[b, q, :] + bs: the block's residual branch, a 1x1
+// out[b][o][q] = act(ysel[b][q][o] * scale2[o] + shift2[o] + skip[b][o][q]): 32 x 64 tiles through LDS,
+// grid (M/32, O/64, B).  skip (optional) = Ws fs[b, q, :] + bs: the block's residual branch, a 1x1
 // convolution of the SAMPLED points' own features (pointnext.py:150-153, 167-168; fs = their rows, gathered
 // by wide_fwd_prep), 64 input channels at a time through LDS; act = ReLU when `relu`.
 // ------------------------------------------------------------------------------------------
@@ -195,40 +195,54 @@ __global__ __launch_bounds__(256) void wide_out_kernel(int M, int O, int C, cons
                                                        const float *__restrict__ ws,
                                                        const float *__restrict__ bs, int relu,
                                                        float *__restrict__ out) {
-    __shared__ float tile[64][65];
-    __shared__ float fg[64][65];      // [q][c]
+    // tile = 32 queries x 64 channels (small tiles: the kernel is a load -> LDS -> store chain, it needs many
+    // blocks in flight, not big ones); thread (query tx, group ty) owns channels ty, ty + 8, ...
+    __shared__ float tile[32][65];    // [q][o]  BatchNorm-2 applied to the pooled extreme
+    __shared__ float fg[32][65];      // [q][c]
     __shared__ float wt[64][65];      // [o][c]
-    const int b = blockIdx.z, c0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const float sc = pack2[c0 + tx], sh = pack2[O + c0 + tx];
-    for (int qq = ty; qq < 64; qq += 4) {
-        const int q = m0 + qq;
-        tile[qq][tx] = q < M ? __builtin_fmaf(ysel[((size_t)b * M + q) * O + c0 + tx], sc, sh) : 0.0f;
-    }
-    float acc[16];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, m0 = blockIdx.x * 32;
+    const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int k = 0; k < 8; ++k) {
+        const int e = t + 256 * k, q = e >> 6, c = e & 63;
+        tile[q][c] = m0 + q < M ? __builtin_fmaf(ysel[((size_t)b * M + m0 + q) * O + c0 + c], pack2[c0 + c], pack2[O + c0 + c]) : 0.0f;
+    }
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
     if (ws) {
         for (int k0 = 0; k0 < C; k0 += 64) {
             __syncthreads();
-            for (int cc = ty; cc < 64; cc += 4) {
-                const int q = m0 + cc;                                                      // fg[q = cc][c = tx]
-                fg[cc][tx] = (k0 + tx < C && q < M) ? fs[((size_t)b * M + q) * C + k0 + tx] : 0.0f;
-                wt[cc][tx] = k0 + tx < C ? ws[(size_t)(c0 + cc) * C + k0 + tx] : 0.0f;      // wt[o = cc][c = tx]
+            float fv[8], wv[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = t + 256 * k, q = e >> 6, c = e & 63;
+                fv[k] = (k0 + c < C && m0 + q < M) ? fs[((size_t)b * M + m0 + q) * C + k0 + c] : 0.0f;
             }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int e = t + 256 * k, o = e >> 6, c = e & 63;
+                wv[k] = k0 + c < C ? ws[(size_t)(c0 + o) * C + k0 + c] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fg[(t + 256 * k) >> 6][(t + 256 * k) & 63] = fv[k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wt[(t + 256 * k) >> 6][(t + 256 * k) & 63] = wv[k];
             __syncthreads();
             const int kn = C - k0 < 64 ? C - k0 : 64;
+#pragma unroll 4
             for (int c = 0; c < kn; ++c) {
                 const float x = fg[tx][c];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = __builtin_fmaf(wt[ty + 4 * i][c], x, acc[i]);
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(wt[ty + 8 * i][c], x, acc[i]);
             }
         }
     }
     __syncthreads();
+    const int q = m0 + tx;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int cc = ty + 4 * i, q = m0 + tx;
+    for (int i = 0; i < 8; ++i) {
+        const int cc = ty + 8 * i;
         float v = tile[tx][cc] + acc[i];
         if (bs) v += bs[c0 + cc];
         if (relu) v = v > 0.0f ? v : 0.0f;
@@ -472,14 +486,14 @@ struct PgLds {
 // n values through registers, NB loads in flight per thread: the fills of the LDS tiles below are dependent chains
 // (index -> row) only across phases, never inside a loop
 template <int NB, typename Load, typename Store>
-__device__ __forceinline__ void fill_batched(int n, Load load, Store store) {
-    for (int e0 = threadIdx.x; e0 < n; e0 += 256 * NB) {
+__device__ __forceinline__ void fill_batched(int n, Load load, Store store, int tid = threadIdx.x, int nthreads = 256) {
+    for (int e0 = tid; e0 < n; e0 += nthreads * NB) {
         float v[NB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) v[u] = e0 + 256 * u < n ? load(e0 + 256 * u) : 0.0f;
+        for (int u = 0; u < NB; ++u) v[u] = e0 + nthreads * u < n ? load(e0 + nthreads * u) : 0.0f;
 #pragma unroll
         for (int u = 0; u < NB; ++u)
-            if (e0 + 256 * u < n) store(e0 + 256 * u, v[u]);
+            if (e0 + nthreads * u < n) store(e0 + nthreads * u, v[u]);
     }
 }
 
@@ -523,26 +537,31 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
     if (O) {
         if (ty == 0) fqs[tx] = ok ? a.fq[ptc] : -1;
     }
-    fill_batched<8>(ldw * 64, [&](int e) {                       // X tile: coordinates / r, then the features
-        const int cc = e >> 6, pl = e & 63;
-        const long long g = pbase + pl;
-        if (g >= npts) return 0.0f;
-        return cc < 3 ? a.p[g * 3 + cc] * a.inv_r : a.f[((size_t)(g / a.N) * C + (cc - 3)) * a.N + (int)(g % a.N)];
-    }, [&](int e, float v) { Xs[(e >> 6) * 65 + (e & 63)] = v; });
-    fill_batched<8>(H * ldw, [&](int e) { return a.w1[e]; }, [&](int e, float v) {
-        const int hh = e / ldw, cc = e - hh * ldw;
-        if (cc < 3) W1p[hh * 4 + cc] = v; else W1f[hh * C + cc - 3] = v;
-    });
-    fill_batched<4>(nq * 3, [&](int e) { return a.new_p[q0 * 3 + e] * a.inv_r; }, [&](int e, float v) { nps[e] = v; });
-    fill_batched<4>(nq * H, [&](int e) {
-        const int hh = e % H;
-        const size_t g = (size_t)q0 * H + e;
-        return __builtin_fmaf(a.cabc[hh], a.HA[g], __builtin_fmaf(a.cabc[H + hh], a.HB[g], 32.0f * a.cabc[2 * H + hh]));
-    }, [&](int e, float v) { Hqs[(e / H) * (H + 1) + e % H] = v; });
-    if (O) {
-        fill_batched<8>(O * C, [&](int e) { return a.ws[e]; }, [&](int e, float v) { Wss[(e / C) * C4 + e % C] = v; });
-        fill_batched<8>(nq * O, [&](int e) { return a.gpre[(size_t)q0 * O + e]; },
-                        [&](int e, float v) { gps[(e / O) * (O + 1) + e % O] = v; });
+    // the tiles of this phase, one wave each: four independent load chains in flight instead of one after the other
+    if (ty == 0) {
+        fill_batched<16>(ldw * 64, [&](int e) {                  // X tile: coordinates / r, then the features
+            const int cc = e >> 6, pl = e & 63;
+            const long long g = pbase + pl;
+            if (g >= npts) return 0.0f;
+            return cc < 3 ? a.p[g * 3 + cc] * a.inv_r : a.f[((size_t)(g / a.N) * C + (cc - 3)) * a.N + (int)(g % a.N)];
+        }, [&](int e, float v) { Xs[(e >> 6) * 65 + (e & 63)] = v; }, tx, 64);
+    } else if (ty == 1) {
+        fill_batched<16>(H * ldw, [&](int e) { return a.w1[e]; }, [&](int e, float v) {
+            const int hh = e / ldw, cc = e - hh * ldw;
+            if (cc < 3) W1p[hh * 4 + cc] = v; else W1f[hh * C + cc - 3] = v;
+        }, tx, 64);
+        fill_batched<4>(nq * 3, [&](int e) { return a.new_p[q0 * 3 + e] * a.inv_r; }, [&](int e, float v) { nps[e] = v; }, tx, 64);
+        fill_batched<16>(nq * H, [&](int e) {
+            const int hh = e % H;
+            const size_t g = (size_t)q0 * H + e;
+            return __builtin_fmaf(a.cabc[hh], a.HA[g], __builtin_fmaf(a.cabc[H + hh], a.HB[g], 32.0f * a.cabc[2 * H + hh]));
+        }, [&](int e, float v) { Hqs[(e / H) * (H + 1) + e % H] = v; }, tx, 64);
+    } else if (O) {
+        if (ty == 2)
+            fill_batched<16>(O * C, [&](int e) { return a.ws[e]; }, [&](int e, float v) { Wss[(e / C) * C4 + e % C] = v; }, tx, 64);
+        else
+            fill_batched<16>(nq * O, [&](int e) { return a.gpre[(size_t)q0 * O + e]; },
+                             [&](int e, float v) { gps[(e / O) * (O + 1) + e % O] = v; }, tx, 64);
     }
     __syncthreads();
     // ---- phase 1: what needed an index first (the skip branch's rows; the rows that gather each point)
@@ -568,13 +587,15 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
             }
     }
     if (O) {
-        fill_batched<8>(64 * O, [&](int e) {
-            const int pl = e / O, o = e - pl * O;
-            const int q = fqs[pl];
-            return q >= 0 ? a.gpre[((size_t)((pbase + pl) / a.N) * a.M + q) * O + o] : 0.0f;
-        }, [&](int e, float v) { gpt[(e / O) * (O + 1) + e % O] = v; });
-        fill_batched<8>(nq * C, [&](int e) { return a.fs[(size_t)q0 * C + e]; },
-                        [&](int e, float v) { fgs[(e % C) * (qpb + 1) + e / C] = v; });
+        if (ty < 3)
+            fill_batched<16>(64 * O, [&](int e) {
+                const int pl = e / O, o = e - pl * O;
+                const int q = fqs[pl];
+                return q >= 0 ? a.gpre[((size_t)((pbase + pl) / a.N) * a.M + q) * O + o] : 0.0f;
+            }, [&](int e, float v) { gpt[(e / O) * (O + 1) + e % O] = v; }, (int)threadIdx.x, 192);
+        else
+            fill_batched<16>(nq * C, [&](int e) { return a.fs[(size_t)q0 * C + e]; },
+                             [&](int e, float v) { fgs[(e % C) * (qpb + 1) + e / C] = v; }, tx, 64);
     }
     // 1. G = ca sum GU + cb inv1 (occ (U - mean1) - SP . W1p / r) + cc occ
 #pragma unroll
@@ -802,7 +823,7 @@ extern "C" int apn_sa_wide_out(int b, int m, int c_out, const float *ysel, const
                                void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || c_out <= 0 || (c_out % 64) || !ysel || !pack2 || !out) return APN_EINVAL;
     if (ws && (!fs || c_in <= 0)) return APN_EINVAL;
-    hipLaunchKernelGGL(wide_out_kernel, dim3((m + 63) / 64, c_out / 64, b), dim3(256), 0, (hipStream_t)stream, m, c_out,
+    hipLaunchKernelGGL(wide_out_kernel, dim3((m + 31) / 32, c_out / 64, b), dim3(256), 0, (hipStream_t)stream, m, c_out,
                        c_in, ysel, pack2, fs, ws, bs, relu, out);
     APN_LAUNCH_CHECK();
     return APN_OK;
