@@ -229,7 +229,7 @@ __device__ __forceinline__ Frag<2> chunk_frag(const uint4 *slot, int j, int s, i
 // LDS: the whole image when it fits (RES), else two streaming slots.
 // ------------------------------------------------------------------------------------------
 template <int H, int O, int CT, bool RES>
-__global__ __launch_bounds__(256) void wide_fwd_main_kernel(WideArgs a, const uint4 *__restrict__ img,
+__global__ __launch_bounds__(256, (H == 32 ? 3 : 2)) void wide_fwd_main_kernel(WideArgs a, const uint4 *__restrict__ img,
                                                             const float *__restrict__ pack1,
                                                             const float *__restrict__ sgn2,
                                                             float *__restrict__ ysel,

@@ -472,28 +472,23 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int nq, int b, int n, co
     }
 }
 
-// one thread per point: sort its list (after the fill poff is the list's END), restore poff, sum geo
-__global__ __launch_bounds__(256) void csr_sort_geo_kernel(int nq, long long npts, const int *__restrict__ tmap,
+// one thread per point: sort its list (after the fill poff is the list's END), restore poff, sum geo.
+// Lists of up to CSR_LDS entries are sorted in an LDS slice of the thread (insertion sort; the entries arrive in the
+// order the fill's atomics happened to run); longer ones in place, with Shell's gaps.
+constexpr int CSR_LDS = 48;
+__global__ __launch_bounds__(128) void csr_sort_geo_kernel(int nq, long long npts, const int *__restrict__ tmap,
                                                            const int *__restrict__ pcnt, int *__restrict__ poff,
                                                            int *__restrict__ plist, const float *__restrict__ new_xyz,
                                                            float *__restrict__ geo) {
-    const long long gn = (long long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ int slice[CSR_LDS][129];                     // [entry][thread]: conflict-free per-thread arrays
+    const long long gn = (long long)blockIdx.x * 128 + threadIdx.x;
     if (gn >= npts) return;
     const int c = pcnt[gn], start = poff[gn] - c;
     poff[gn] = start;
     int *__restrict__ l = plist + start;
-    for (int gap = c < 14 ? 1 : (c < 41 ? 4 : (c < 122 ? 13 : (c < 365 ? 40 : 121))); gap > 0; gap = gap == 1 ? 0 : (gap - 1) / 3) {
-        for (int i = gap; i < c; ++i) {                     // Shell sort, gaps 121, 40, 13, 4, 1
-            const int v = l[i];
-            int j = i;
-            for (; j >= gap && l[j - gap] > v; j -= gap) l[j] = l[j - gap];
-            l[j] = v;
-        }
-    }
     const unsigned *__restrict__ rows = reinterpret_cast<const unsigned *>(tmap + 4 + ((nq + 3) & ~3));
     float occ = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    for (int i = 0; i < c; ++i) {
-        const int e = l[i];
+    auto add = [&](int e) {
         const unsigned info = rows[e];
         const float mult = (float)((info >> 16) & 0xffu);
         const float *__restrict__ q = new_xyz + (size_t)(tmap[4 + (e >> 5)] + (int)(info & 0xffu)) * 3;
@@ -501,6 +496,30 @@ __global__ __launch_bounds__(256) void csr_sort_geo_kernel(int nq, long long npt
         sx = __builtin_fmaf(mult, q[0], sx);
         sy = __builtin_fmaf(mult, q[1], sy);
         sz = __builtin_fmaf(mult, q[2], sz);
+    };
+    if (c <= CSR_LDS) {
+        const int t = threadIdx.x;
+        for (int i = 0; i < c; ++i) {
+            const int v = l[i];
+            int j = i;
+            for (; j > 0 && slice[j - 1][t] > v; --j) slice[j][t] = slice[j - 1][t];
+            slice[j][t] = v;
+        }
+        for (int i = 0; i < c; ++i) {
+            const int e = slice[i][t];
+            l[i] = e;
+            add(e);
+        }
+    } else {
+        for (int gap = c < 122 ? 40 : (c < 365 ? 121 : 364); gap > 0; gap = gap == 1 ? 0 : (gap - 1) / 3) {
+            for (int i = gap; i < c; ++i) {                     // Shell sort, gaps 364, 121, 40, 13, 4, 1
+                const int v = l[i];
+                int j = i;
+                for (; j >= gap && l[j - gap] > v; j -= gap) l[j] = l[j - gap];
+                l[j] = v;
+            }
+        }
+        for (int i = 0; i < c; ++i) add(l[i]);
     }
     *reinterpret_cast<float4 *>(geo + gn * 4) = make_float4(occ, sx, sy, sz);
 }
@@ -558,7 +577,7 @@ extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float 
     hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 0, idx, tmap, pcnt, poff, plist);
     hipLaunchKernelGGL(apn::csr_scan_kernel, dim3(b), dim3(1024), 0, st, nq, b, n, tmap, pcnt, poff);
     hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 1, idx, tmap, pcnt, poff, plist);
-    hipLaunchKernelGGL(apn::csr_sort_geo_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, nq, npts, tmap,
+    hipLaunchKernelGGL(apn::csr_sort_geo_kernel, dim3((unsigned)((npts + 127) / 128)), dim3(128), 0, st, nq, npts, tmap,
                        pcnt, poff, plist, new_xyz, geo);
     if (fidx && fq) {
         hipLaunchKernelGGL(apn::csr_fq_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, npts, n, m,
