@@ -33,30 +33,30 @@ SIGNATURES = {
     "apn_sa_grid_blocks": [_c_int] * 2,
     "apn_sa_bwd_main_rows": [_c_int] * 2,
     "apn_sa_prep_features": [_c_int] * 3 + [_c_void_p] * 2 + [_c_int, _c_void_p],
-    "apn_sa_fwd_stats1": [_c_int] * 8 + [_c_float] + [_c_void_p] * 7,
+    "apn_sa_fwd_stats1": [_c_int] * 8 + [_c_float] + [_c_void_p] * 8,
     "apn_sa_reduce_rows": [_c_void_p, _c_int, _c_int, _c_double, _c_void_p, _c_void_p],
     "apn_sa_bn_fold": [_c_void_p, _c_int, _c_void_p, _c_int, _c_double, _c_void_p, _c_void_p,
                        _c_float, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                        _c_void_p, _c_int, _c_void_p, _c_void_p],
-    "apn_sa_fwd_main": [_c_int] * 8 + [_c_float] + [_c_void_p] * 13,
+    "apn_sa_fwd_main": [_c_int] * 8 + [_c_float] + [_c_void_p] * 14,
     "apn_sa_fwd_out": [_c_int] * 3 + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 3 + [_c_int]
                       + [_c_void_p] * 2,
     "apn_sa_bwd_prep_rows": [_c_int] * 2,
     "apn_sa_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] + [_c_int]
                        + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 7,
     "apn_sa_bwd_consts2": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_double, _c_int] + [_c_void_p] * 8,
-    "apn_sa_bwd_main": [_c_int] * 8 + [_c_float] + [_c_void_p] * 19,
+    "apn_sa_bwd_main": [_c_int] * 8 + [_c_float] + [_c_void_p] * 20,
     "apn_sa_bwd_consts1": [_c_void_p, _c_int] + [_c_void_p] * 2 + [_c_double, _c_int] + [_c_void_p] * 8,
     "apn_sa_bwd_weight_rows": [_c_int] * 2,
     "apn_sa_bwd_point_grads": [_c_int] * 3 + [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 4 + [_c_float]
                               + [_c_void_p] * 5,
     "apn_sa_bwd_finalize": [_c_void_p, _c_int, _c_float, _c_void_p, _c_void_p, _c_int, _c_void_p,
                             _c_void_p, _c_void_p, _c_void_p],
-    "apn_sa_forward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 9
+    "apn_sa_forward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 10
                            + [_c_void_p] * 5 + [_c_float, _c_float, _c_int]
                            + [_c_void_p] * 5 + [_c_float, _c_float, _c_int]
                            + [_c_double, _c_int] + [_c_void_p] * 12),
-    "apn_sa_backward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 14 + [_c_int] * 3
+    "apn_sa_backward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 15 + [_c_int] * 3
                             + [_c_double] + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p]
                             + [ctypes.c_size_t]
                             + [_c_void_p] * 29),

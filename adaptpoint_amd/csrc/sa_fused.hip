@@ -46,6 +46,7 @@
 // + out 2 x 4.2 MB ~ 13 MB (1.6 us at 8 TB/s); bf16 MFMA work 7 x 32 cycles per tile.
 // Both are far below the per-tile VALU/gather latency, which is what bounds it.
 #include "apn_common.h"
+#include <stdlib.h>
 #include "apn_mfma.h"
 
 namespace apn {
@@ -113,7 +114,29 @@ struct SaArgs {
     const int *idx;              // (B,M,32)
     const float *w1;             // (32, 35): columns [dp(3), f(32)] as the reference's cat([dp, fj])
     float radius;
+    const int *tmap;             // distinct-hit tile map (csrc/sa_wide_glue.hip: apn_sa_wide_tilemap) or null
 };
+
+// With a tile map (CP) a tile is 32 ROWS = (query, distinct neighbour, multiplicity) instead of one query's 32
+// slots: the ball query's fill copies of slot 0 are folded into one row (3.7x fewer tiles at stage 1), whole
+// queries packed in order.  Per row: rowinfo = qlocal | slot << 8 | mult << 16 (| queries of the tile << 24 in
+// row 0; padding rows: mult 0, qlocal 255), rownn = the neighbour; per tile: tq0 = its first query.
+__device__ __forceinline__ int tm_tiles(const SaArgs &a) { return a.tmap[0]; }
+__device__ __forceinline__ const int *tm_tq0(const SaArgs &a) { return a.tmap + 4; }
+__device__ __forceinline__ const unsigned *tm_rows(const SaArgs &a) {
+    return reinterpret_cast<const unsigned *>(a.tmap + 4 + ((a.b * a.m + 3) & ~3));
+}
+__device__ __forceinline__ const int *tm_nn(const SaArgs &a) {
+    return a.tmap + 4 + ((a.b * a.m + 3) & ~3) + (size_t)32 * a.b * a.m;
+}
+__device__ __forceinline__ unsigned ri_q(unsigned info) { return info & 0xffu; }
+__device__ __forceinline__ unsigned ri_slot(unsigned info) { return (info >> 8) & 0xffu; }
+__device__ __forceinline__ unsigned ri_mult(unsigned info) { return (info >> 16) & 0xffu; }
+// the records of this lane's 16 accumulator rows acc_row(i, h) (row p's record sits in lane p)
+__device__ __forceinline__ void row_meta(unsigned info, int h, unsigned (&meta)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) meta[i] = (unsigned)__builtin_amdgcn_ds_bpermute(acc_row(i, h) << 2, (int)info);
+}
 
 // Per-wave constant operand fragments of conv1: lane (r = mid channel, h), step s,
 // element j  <->  input channel k = 16 s + 8 h + j: features 0..31, then dp x,y,z.
@@ -140,13 +163,36 @@ template <int NS>
 struct TileRaw {
     uint4 f[2], fl[NS];   // feature-row slices (fl: remainder row, split mode)
     float px, py, pz;     // neighbour coordinates
-    float qx, qy, qz;     // query coordinates (wave-uniform)
+    float qx, qy, qz;     // query coordinates (wave-uniform without a tile map)
     int nb;               // neighbour index of this lane's position
+    unsigned info;        // tile map: this lane's row record
+    int q0;               // tile map: the tile's first query
 };
 
+// what is read two tiles ahead: the neighbour of this lane's position (and, with a tile map, its record)
+struct TileHead {
+    int nb, q0;
+    unsigned info;
+};
+template <bool CP>
+__device__ __forceinline__ TileHead load_head(const SaArgs &a, int tile, int r) {
+    TileHead t;
+    if (CP) {
+        t.nb = tm_nn(a)[(size_t)tile * SA_K + r];
+        t.info = tm_rows(a)[(size_t)tile * SA_K + r];
+        t.q0 = tm_tq0(a)[tile];
+    } else {
+        t.nb = a.idx[(size_t)tile * SA_K + r];
+        t.info = 0x10000u | ((unsigned)r << 8);      // one query, slot r, multiplicity 1
+        t.q0 = tile;
+    }
+    return t;
+}
+
 template <int NS>
-__device__ __forceinline__ void fetch_tile(const SaArgs &a, int tile, int nb, int h, TileRaw<NS> &t) {
-    const int cloud = tile / a.m;
+__device__ __forceinline__ void fetch_tile(const SaArgs &a, const TileHead &hd, int h, TileRaw<NS> &t) {
+    const int nb = hd.nb;
+    const int cloud = hd.q0 / a.m;
     const size_t rowoff = ((size_t)cloud * a.n + nb) * SA_C;
     const uint4 *row = reinterpret_cast<const uint4 *>(a.ft + rowoff);
     t.f[0] = row[h];
@@ -158,9 +204,11 @@ __device__ __forceinline__ void fetch_tile(const SaArgs &a, int tile, int nb, in
     }
     const float *p = a.xyz + ((size_t)cloud * a.n + nb) * 3;
     t.px = p[0]; t.py = p[1]; t.pz = p[2];
-    const float *q = a.new_xyz + (size_t)tile * 3;
+    const float *q = a.new_xyz + (size_t)(hd.q0 + (ri_mult(hd.info) ? ri_q(hd.info) : 0u)) * 3;
     t.qx = q[0]; t.qy = q[1]; t.qz = q[2];
     t.nb = nb;
+    t.info = hd.info;
+    t.q0 = hd.q0;
 }
 
 // Operand fragments of a fetched tile.  deff (optional) receives, in BOTH halves, the relative
@@ -199,29 +247,29 @@ __device__ __forceinline__ void build_frags(const SaArgs &a, const TileRaw<NS> &
 // after the last tile: the place for stores / atomics deferred from the previous tile.  The
 // memory counter is in order, so anything issued between a prefetch and the wait for it is
 // waited for too; deferred to here, the atomics of tile t have the whole of tile t+1 to retire.
-template <int NS, typename Pre, typename Body>
+template <int NS, bool CP, typename Pre, typename Body>
 __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Pre pre, Body body) {
-    const int tiles = a.b * a.m, stride = gridDim.x * SA_WAVES;
+    const int tiles = CP ? tm_tiles(a) : a.b * a.m, stride = gridDim.x * SA_WAVES;
     int tile = blockIdx.x * SA_WAVES + wave;
     if (tile >= tiles) return;
     TileRaw<NS> cur, nxt;
-    fetch_tile<NS>(a, tile, a.idx[(size_t)tile * SA_K + r], h, cur);
-    int nb_nxt = tile + stride < tiles ? a.idx[(size_t)(tile + stride) * SA_K + r] : 0;
+    fetch_tile<NS>(a, load_head<CP>(a, tile, r), h, cur);
+    TileHead hd_nxt = load_head<CP>(a, tile + stride < tiles ? tile + stride : tile, r);
     for (; tile < tiles; tile += stride) {
         const bool more = tile + stride < tiles;               // wave-uniform
         pre();
-        if (more) fetch_tile<NS>(a, tile + stride, nb_nxt, h, nxt);
-        const int nb_nxt2 = tile + 2 * stride < tiles ? a.idx[(size_t)(tile + 2 * stride) * SA_K + r] : 0;
+        if (more) fetch_tile<NS>(a, hd_nxt, h, nxt);
+        const TileHead hd_nxt2 = load_head<CP>(a, tile + 2 * stride < tiles ? tile + 2 * stride : tile, r);
         body(tile, cur);
         if (more) cur = nxt;
-        nb_nxt = nb_nxt2;
+        hd_nxt = hd_nxt2;
     }
     pre();
 }
 
-template <int NS, typename Body>
+template <int NS, bool CP, typename Body>
 __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Body body) {
-    for_each_tile<NS>(a, wave, r, h, [] {}, body);
+    for_each_tile<NS, CP>(a, wave, r, h, [] {}, body);
 }
 
 // Workgroup-level fold of per-lane statistics into ONE partial row per workgroup:
@@ -248,7 +296,7 @@ __device__ __forceinline__ void write_partials(float (&vals)[NV], float *__restr
 }
 
 // Pass 1: statistics of y1 = conv1(x).  part[gridDim.x][64] = {sum[32], sumsq[32]}.
-template <int NS>
+template <int NS, bool CP>
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
                                                                       float *__restrict__ part) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -262,7 +310,7 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
     }
     __syncthreads();
     float st[2] = {0.0f, 0.0f};
-    for_each_tile<NS>(a, wave, r, h, [&](int, const TileRaw<NS> &raw) {
+    for_each_tile<NS, CP>(a, wave, r, h, [&](int, const TileRaw<NS> &raw) {
         int lane_o = lane;                       // see sa_bwd_kernel: fragments are read per use
         asm volatile("" : "+v"(lane_o));
         Frag<NS> x[3];
@@ -270,8 +318,19 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
         f32x16 y = {0};
 #pragma unroll
         for (int s = 0; s < 3; ++s) y = mfma<NS>(x[s], get_frag<NS>(cfrag, s, lane_o), y);  // Y1: lane = mid channel
+        if (CP) {                                // a row stands for `mult` positions
+            unsigned meta[16];
+            row_meta(raw.info, h, meta);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { st[0] += y[i]; st[1] += y[i] * y[i]; }
+            for (int i = 0; i < 16; ++i) {
+                const float wy = (float)ri_mult(meta[i]) * y[i];
+                st[0] += wy;
+                st[1] += wy * y[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { st[0] += y[i]; st[1] += y[i] * y[i]; }
+        }
     });
     write_partials<2>(st, part, lane, wave);
 }
@@ -279,7 +338,7 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
 // Pass 2.  scale1/shift1: BN1 folded to y*scale+shift; sgn2[c] = +1/-1 (sign of gamma2).
 // Outputs ysel/ksel (B,M,64): the extreme of y2 over K and its position;
 // part[gridDim.x][128] = {sum[64], sumsq[64]} of y2.
-template <int NS>
+template <int NS, bool CP>
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
     SaArgs a, const float *__restrict__ w2, const float *__restrict__ scale1,
     const float *__restrict__ shift1, const float *__restrict__ sgn2, float *__restrict__ ysel,
@@ -314,11 +373,15 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
     const float sg[2] = {sgn2[r], sgn2[32 + r]};
     float st[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum t0, sum t1, sumsq t0, sumsq t1
 
-    for_each_tile<NS>(a, wave, r, h, [&](int tile, const TileRaw<NS> &raw) {
+    for_each_tile<NS, CP>(a, wave, r, h, [&](int tile, const TileRaw<NS> &raw) {
         int lane_o = lane;                       // see sa_bwd_kernel: fragments are read per use
         asm volatile("" : "+v"(lane_o));
         Frag<NS> x[3];
         build_frags<NS>(a, raw, h, x);
+        unsigned meta[16];
+        if (CP) row_meta(raw.info, h, meta);
+        const int q0 = __builtin_amdgcn_readfirstlane(raw.q0);
+        const int nq = __builtin_amdgcn_readfirstlane((int)(raw.info >> 24));       // lane 0 holds row 0
         f32x16 y1 = {0};
 #pragma unroll
         for (int s = 0; s < 3; ++s) y1 = mfma<NS>(get_frag<NS>(cfrag, F_W1 + s, lane_o), x[s], y1);  // Y1^T: lane = position
@@ -340,6 +403,40 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
             f32x16 y2 = {0};
             y2 = mfma<NS>(a0, get_frag<NS>(cfrag, F_W2 + 2 * t, lane_o), y2);  // Y2: lane = out channel 32 t + r, register = position
             y2 = mfma<NS>(a1, get_frag<NS>(cfrag, F_W2 + 2 * t + 1, lane_o), y2);
+            if (CP) {
+                float s1 = 0.0f, s2 = 0.0f, v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float wy = (float)ri_mult(meta[i]) * y2[i];
+                    s1 += wy;
+                    s2 += wy * y2[i];
+                    v[i] = sg[t] * y2[i];
+                }
+                st[t] += s1;
+                st[2 + t] += s2;
+                // the pool, query by query (padding rows carry query 255); rows ascend with the slot, so the
+                // first maximum is the lowest slot
+#pragma unroll 1
+                for (int jq = 0; jq < nq; ++jq) {
+                    float best = -__builtin_inff();
+                    int bi = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const bool up = ri_q(meta[i]) == (unsigned)jq && v[i] > best;
+                        best = up ? v[i] : best;
+                        bi = up ? (int)meta[i] : bi;
+                    }
+                    int kpos = (int)ri_slot((unsigned)bi);
+                    const float obest = __shfl_xor(best, 32);
+                    const int okpos = __shfl_xor(kpos, 32);
+                    if (obest > best || (obest == best && okpos < kpos)) { best = obest; kpos = okpos; }
+                    if (h == 0) {
+                        ysel[(size_t)(q0 + jq) * SA_C2 + 32 * t + r] = sg[t] * best;
+                        ksel[(size_t)(q0 + jq) * SA_C2 + 32 * t + r] = (unsigned char)kpos;
+                    }
+                }
+                continue;
+            }
             float best = sg[t] * y2[0];
             int bpos = 0;
             float s1 = 0.0f, s2 = 0.0f;
@@ -408,7 +505,7 @@ struct SaBwdArgs {
     const unsigned char *ksel;  // (B,M,64)
 };
 
-template <int NS>
+template <int NS, bool CP>
 __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
                                                                float *__restrict__ part,
                                                                float *__restrict__ gw2_acc,
@@ -496,7 +593,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         }
         pend_live = 0;
     };
-    for_each_tile<NS>(a, wave, r, h, scatter_pending, [&](int tile, const TileRaw<NS> &raw) {
+    for_each_tile<NS, CP>(a, wave, r, h, scatter_pending, [&](int tile, const TileRaw<NS> &raw) {
         // the constant fragments are READ PER USE: an opaque copy of the lane id keeps the
         // compiler from hoisting these loop-invariant LDS reads back into ~130 registers
         int lane_o = lane;
@@ -505,6 +602,13 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         float deff[3];
         build_frags<NS>(a, raw, h, x, deff);
         const int nb = raw.nb;
+        // tile map: the records of this lane's accumulator rows; this lane's own row (position r) is raw.info
+        unsigned meta[16];
+        if (CP) row_meta(raw.info, h, meta);
+        const int q0 = __builtin_amdgcn_readfirstlane(raw.q0);
+        const int nq = CP ? __builtin_amdgcn_readfirstlane((int)(raw.info >> 24)) : 1;
+        const bool live_row = !CP || ri_mult(raw.info) != 0;
+        const float mrow = CP ? (float)ri_mult(raw.info) : 1.0f;       // multiplicity of position r
         // conv1 in both layouts (3 + 3 k-steps on the same fragments)
         f32x16 yT = {0}, y1 = {0};
 #pragma unroll
@@ -525,35 +629,43 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 yT[4 * i4 + 3] = __builtin_fmaxf(__builtin_fmaf(yT[4 * i4 + 3], sc.w, sh.w), 0.0f);
             }
         }
-        const Frag<NS> a0 = pack8<NS>(yT, 0), a1 = pack8<NS>(yT, 8);
+        // operand of the Qm product: a1, weighted by the row's multiplicity (the dense part of dL/dy2 reaches
+        // every one of the positions the row stands for)
+        Frag<NS> a0, a1;
+        if (CP) {
+            f32x16 yw;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) yw[i] = yT[i] * mrow;
+            a0 = pack8<NS>(yw, 0);
+            a1 = pack8<NS>(yw, 8);
+        } else {
+            a0 = pack8<NS>(yT, 0);
+            a1 = pack8<NS>(yT, 8);
+        }
 
         // One-hot-weighted operand of the sparse part, S[pos][c] = goa[c] * [ksel[c] == pos]
         // (64 nonzeros in a 32 x 64 tile).  Built through a wave-private LDS image instead of
         // 2048 compare/selects: lane c drops its value into row ksel[c], every lane reads its
         // fragment rows back (ds_read_b128, conflict-free with 144-byte rows), and lane c
         // zeroes its element again.  LDS executes one wave's instructions in order, so the
-        // image needs no barrier; it starts zeroed and is left zeroed.
+        // image needs no barrier; it starts zeroed and is left zeroed.  With a tile map the tile holds
+        // several queries: each drops into ITS rows (row0 of the query + the pooled slot).
         Frag<NS> sp[4];
-        const float gv = g.goa[(size_t)tile * SA_C2 + lane];      // lane = out channel c
-        const int kc = g.ksel[(size_t)tile * SA_C2 + lane];
-        {
+#pragma unroll 1
+        for (int jq = 0; jq < nq; ++jq) {
+            const float gv = g.goa[(size_t)(q0 + jq) * SA_C2 + lane];      // lane = out channel c
+            int kc = g.ksel[(size_t)(q0 + jq) * SA_C2 + lane];
+            if (CP) {
+                const unsigned long long rows_q = __ballot(lane < 32 && live_row && ri_q(raw.info) == (unsigned)jq);
+                kc += __builtin_ctzll(rows_q);                              // first row of query jq in the tile
+            }
             const __bf16 ghi = (__bf16)gv;
             const __bf16 glo = (__bf16)(gv - (float)ghi);
             __bf16 *cell = sp_img + kc * SP_ROW + lane;
             cell[0] = ghi;
             if (NS == 2) cell[SP_TILE] = glo;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const __bf16 *src = sp_img + r * SP_ROW + 16 * s + 8 * h;
-                sp[s].p[0] = *reinterpret_cast<const bf16x8 *>(src);
-                if (NS == 2) sp[s].p[NS - 1] = *reinterpret_cast<const bf16x8 *>(src + SP_TILE);
-            }
-            cell[0] = (__bf16)0.0f;
-            if (NS == 2) cell[SP_TILE] = (__bf16)0.0f;
-        }
-        // sparse part of dL/dW2: lane c adds goa[c] * a1[pos = ksel[c]][:]; that row of a1 sits in
-        // lanes ksel[c] (mids acc_row(i, 0)) and ksel[c] + 32 (mids acc_row(i, 1)), register i
-        {
+            // sparse part of dL/dW2: lane c adds goa[c] * a1[pos = ksel[c]][:]; that row of a1 sits in
+            // lanes kc (mids acc_row(i, 0)) and kc + 32 (mids acc_row(i, 1)), register i
             const int src0 = kc << 2, src1 = (kc + 32) << 2;      // ds_bpermute takes byte addresses
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -562,65 +674,120 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 sacc[16 + i] = __builtin_fmaf(gv, __int_as_float(__builtin_amdgcn_ds_bpermute(src1, bits)), sacc[16 + i]);
             }
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const __bf16 *src = sp_img + r * SP_ROW + 16 * s + 8 * h;
+            sp[s].p[0] = *reinterpret_cast<const bf16x8 *>(src);
+            if (NS == 2) sp[s].p[NS - 1] = *reinterpret_cast<const bf16x8 *>(src + SP_TILE);
+        }
+#pragma unroll 1
+        for (int jq = 0; jq < nq; ++jq) {
+            int kc = g.ksel[(size_t)(q0 + jq) * SA_C2 + lane];
+            if (CP) {
+                const unsigned long long rows_q = __ballot(lane < 32 && live_row && ri_q(raw.info) == (unsigned)jq);
+                kc += __builtin_ctzll(rows_q);
+            }
+            __bf16 *cell = sp_img + kc * SP_ROW + lane;
+            cell[0] = (__bf16)0.0f;
+            if (NS == 2) cell[SP_TILE] = (__bf16)0.0f;
+        }
         // dL/da1 [lane = mid, register = position]
         f32x16 ga;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ga[i] = ev;
+        for (int i = 0; i < 16; ++i) ga[i] = CP ? ev * (float)ri_mult(meta[i]) : ev;
         ga = mfma<NS>(a0, get_frag<NS>(cfrag, F_QM, lane_o), ga);
         ga = mfma<NS>(a1, get_frag<NS>(cfrag, F_QM + 1, lane_o), ga);
 #pragma unroll
         for (int s = 0; s < 4; ++s) ga = mfma<NS>(sp[s], get_frag<NS>(cfrag, F_W2T + s, lane_o), ga);
 
         f32x16 an;   // a1 in the [lane = mid] layout: both operands of the Gram product
+        f32x16 yhw;  // (tile map) multiplicity * yhat1, for the per-query sums
         float s1 = 0.0f, s2 = 0.0f, hb = 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float u = __builtin_fmaf(y1[i], sc1, sh1);
             const float yhat = (y1[i] - mu1) * iv1;
             an[i] = __builtin_fmaxf(u, 0.0f);
-            suma += an[i];
+            if (CP) suma = __builtin_fmaf((float)ri_mult(meta[i]), an[i], suma);
+            else suma += an[i];
             ga[i] = u > 0.0f ? ga[i] : 0.0f;   // g_u
             s1 += ga[i];
             s2 += ga[i] * yhat;
-            hb += yhat;
+            if (CP) yhw[i] = (float)ri_mult(meta[i]) * yhat;
+            else hb += yhat;
         }
         st[0] += s1;
         st[1] += s2;
 
         {   // sums per query and per source point
-            const float ha = s1 + __shfl_xor(s1, 32);
-            hb += __shfl_xor(hb, 32);
-            if (h == 0) {
-                HA[(size_t)tile * SA_C1 + r] = ha;
-                HB[(size_t)tile * SA_C1 + r] = hb;
+            int live;
+            float gmult;
+            if (CP) {
+#pragma unroll 1
+                for (int jq = 0; jq < nq; ++jq) {
+                    float ha = 0.0f, hq = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const bool in = ri_q(meta[i]) == (unsigned)jq;         // padding rows carry query 255
+                        ha += in ? ga[i] : 0.0f;
+                        hq += in ? yhw[i] : 0.0f;
+                    }
+                    ha += __shfl_xor(ha, 32);
+                    hq += __shfl_xor(hq, 32);
+                    if (h == 0) {
+                        HA[(size_t)(q0 + jq) * SA_C1 + r] = ha;
+                        HB[(size_t)(q0 + jq) * SA_C1 + r] = hq;
+                    }
+                }
+                // rows in use are a prefix of the tile, every one a distinct point of its query: no folding
+                live = __popcll(__ballot(lane < 32 && live_row));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pend_g[i] = ga[i];
+                gmult = mrow;
+            } else {
+                const float ha = s1 + __shfl_xor(s1, 32);
+                hb += __shfl_xor(hb, 32);
+                if (h == 0) {
+                    HA[(size_t)tile * SA_C1 + r] = ha;
+                    HB[(size_t)tile * SA_C1 + r] = hb;
+                }
+                // Rows produced by ball query end in a run of slots that repeat slot 0
+                // (ball_query_gpu.cu:41-45): fold that run into slot 0 before the atomics.
+                const int nb0 = __builtin_amdgcn_readfirstlane(nb);
+                const unsigned eq = (unsigned)__ballot(nb == nb0);          // lanes 0..31 = positions
+                const int tail = (~eq == 0u) ? 32 : __builtin_clz(~eq);      // leading ones of eq
+                live = SA_K - tail;
+                if (live < 1) live = 1;
+                float extra = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) extra += acc_row(i, h) >= live ? ga[i] : 0.0f;
+                extra += __shfl_xor(extra, 32);
+                // hand the tile's sums to the deferred scatter
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pend_g[i] = (i == 0 && h == 0) ? ga[0] + extra : ga[i];
+                gmult = r == 0 ? (float)(SA_K - live + 1) : 1.0f;
             }
-            // Rows produced by ball query end in a run of slots that repeat slot 0
-            // (ball_query_gpu.cu:41-45): fold that run into slot 0 before the atomics.
-            const int nb0 = __builtin_amdgcn_readfirstlane(nb);
-            const unsigned eq = (unsigned)__ballot(nb == nb0);          // lanes 0..31 = positions
-            const int tail = (~eq == 0u) ? 32 : __builtin_clz(~eq);      // leading ones of eq
-            int live = SA_K - tail;
-            if (live < 1) live = 1;
-            float extra = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) extra += acc_row(i, h) >= live ? ga[i] : 0.0f;
-            extra += __shfl_xor(extra, 32);
-            // hand the tile's sums to the deferred scatter
-#pragma unroll
-            for (int i = 0; i < 16; ++i) pend_g[i] = (i == 0 && h == 0) ? ga[0] + extra : ga[i];
-            const float mult = r == 0 ? (float)(SA_K - live + 1) : 1.0f;
-            pend_geo[0] = (h ? deff[1] : 1.0f) * mult;
-            pend_geo[1] = (h ? deff[2] : deff[0]) * mult;
+            pend_geo[0] = (h ? deff[1] : 1.0f) * gmult;
+            pend_geo[1] = (h ? deff[2] : deff[0]) * gmult;
             pend_nb = nb;
             pend_live = live;
-            pend_cloud = tile / a.m;
+            pend_cloud = q0 / a.m;
         }
 
-        // Gram += a1^T a1: the k index (positions, accumulator-row order) pairs the same registers
+        // Gram += a1^T a1 (one side weighted by the multiplicity): the k index (positions, accumulator-row
+        // order) pairs the same registers
         {
             const Frag<NS> b0 = pack8<NS>(an, 0), b1 = pack8<NS>(an, 8);
-            gram = mfma<NS>(b0, b0, gram);
-            gram = mfma<NS>(b1, b1, gram);
+            if (CP) {
+                f32x16 aw;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) aw[i] = an[i] * (float)ri_mult(meta[i]);
+                gram = mfma<NS>(pack8<NS>(aw, 0), b0, gram);
+                gram = mfma<NS>(pack8<NS>(aw, 8), b1, gram);
+            } else {
+                gram = mfma<NS>(b0, b0, gram);
+                gram = mfma<NS>(b1, b1, gram);
+            }
         }
     });
     write_partials<2>(st, part, lane, wave);
@@ -657,8 +824,9 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
 
 static int sa_grid(int tiles) {
     // two workgroups of 4 waves per CU when there is enough work: 2 waves per SIMD
+    static const int cap = getenv("APN_SA_GRID") ? atoi(getenv("APN_SA_GRID")) : 512;        // TUNING HOOK
     int g = (tiles + SA_WAVES - 1) / SA_WAVES;
-    return g < 512 ? (g < 1 ? 1 : g) : 512;
+    return g < cap ? (g < 1 ? 1 : g) : cap;
 }
 
 // The backward pass fits two workgroups per CU (241 registers, 57 KB of LDS) and, alone, is
@@ -692,10 +860,10 @@ extern "C" int apn_sa_prep_features(int b, int c, int n, const float *f, void *f
 }
 
 static apn::SaArgs sa_args(int b, int n, int m, const float *xyz, const float *new_xyz, const void *ft,
-                           int precision, const int *idx, const float *w1, float radius) {
+                           int precision, const int *idx, const float *w1, float radius, const int *tmap) {
     const __bf16 *hi = (const __bf16 *)ft;
     return apn::SaArgs{b, n, m, xyz, new_xyz, hi,
-                       precision == 2 ? hi + (size_t)b * n * apn::SA_C : nullptr, idx, w1, radius};
+                       precision == 2 ? hi + (size_t)b * n * apn::SA_C : nullptr, idx, w1, radius, tmap};
 }
 
 static int sa_check(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample, int precision) {
@@ -709,37 +877,30 @@ static int sa_check(int b, int n, int m, int c_in, int c_mid, int c_out, int nsa
 
 extern "C" int apn_sa_fwd_stats1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                                  int precision, float radius, const float *xyz, const float *new_xyz,
-                                 const void *ft, const int *idx, const float *w1, float *part,
+                                 const void *ft, const int *idx, const int *tmap, const float *w1, float *part,
                                  void *stream) {
     using namespace apn;
     if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
-    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius);
-    if (precision == 2)
-        hipLaunchKernelGGL(sa_fwd_stats1_kernel<2>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, part);
-    else
-        hipLaunchKernelGGL(sa_fwd_stats1_kernel<1>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, part);
+    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius, tmap);
+    auto kern = precision == 2 ? (tmap ? sa_fwd_stats1_kernel<2, true> : sa_fwd_stats1_kernel<2, false>)
+                               : (tmap ? sa_fwd_stats1_kernel<1, true> : sa_fwd_stats1_kernel<1, false>);
+    hipLaunchKernelGGL(kern, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, part);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
 extern "C" int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                                int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                               const int *idx, const float *w1, const float *w2,
+                               const int *idx, const int *tmap, const float *w1, const float *w2,
                                const float *scale1, const float *shift1, const float *sgn2,
                                float *ysel, void *ksel, float *part, void *stream) {
     using namespace apn;
     if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
-    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius);
-    if (precision == 2)
-        hipLaunchKernelGGL(sa_fwd_main_kernel<2>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, w2, scale1, shift1, sgn2, ysel,
-                           (unsigned char *)ksel, part);
-    else
-        hipLaunchKernelGGL(sa_fwd_main_kernel<1>, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, w2, scale1, shift1, sgn2, ysel,
-                           (unsigned char *)ksel, part);
+    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius, tmap);
+    auto kern = precision == 2 ? (tmap ? sa_fwd_main_kernel<2, true> : sa_fwd_main_kernel<2, false>)
+                               : (tmap ? sa_fwd_main_kernel<1, true> : sa_fwd_main_kernel<1, false>);
+    hipLaunchKernelGGL(kern, dim3(sa_grid(b * m)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, w2, scale1, shift1,
+                       sgn2, ysel, (unsigned char *)ksel, part);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -757,7 +918,7 @@ static apn::SaBwdArgs sa_bwd_args(const float *w2, const float *bn1 /* [4][32]: 
 
 extern "C" int apn_sa_bwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                                int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                               const int *idx, const float *w1, const float *w2, const float *bn1,
+                               const int *idx, const int *tmap, const float *w1, const float *w2, const float *bn1,
                                const float *qm, const float *evec, const float *goa,
                                const void *ksel, float *part, float *gw2_acc, float *gram_acc,
                                float *A, float *geo, float *HA, float *HB, void *stream) {
@@ -766,14 +927,12 @@ extern "C" int apn_sa_bwd_main(int b, int n, int m, int c_in, int c_mid, int c_o
     if (!w2 || !bn1 || !qm || !evec || !goa || !ksel || !part || !gw2_acc || !gram_acc || !A || !geo ||
         !HA || !HB)
         return APN_EINVAL;
-    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius);
+    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius, tmap);
     SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, goa, ksel);
-    if (precision == 2)
-        hipLaunchKernelGGL((sa_bwd_kernel<2>), dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, g, part, gw2_acc, gram_acc, A, geo, HA, HB);
-    else
-        hipLaunchKernelGGL((sa_bwd_kernel<1>), dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0,
-                           (hipStream_t)stream, a, g, part, gw2_acc, gram_acc, A, geo, HA, HB);
+    auto kern = precision == 2 ? (tmap ? sa_bwd_kernel<2, true> : sa_bwd_kernel<2, false>)
+                               : (tmap ? sa_bwd_kernel<1, true> : sa_bwd_kernel<1, false>);
+    hipLaunchKernelGGL(kern, dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, g, part, gw2_acc,
+                       gram_acc, A, geo, HA, HB);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

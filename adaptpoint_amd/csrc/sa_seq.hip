@@ -23,7 +23,7 @@
 
 extern "C" int apn_sa_forward_seq(
     int phases, int precision, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
-    const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
+    const float *f, const int *idx, const int *tmap, const int *fidx, const float *w1, const float *w2,
     const float *ws, const float *bs,
     const float *g1, const float *b1, float *rm1, float *rv1, void *nbt1, float eps1, float mom1,
     int train1,
@@ -37,12 +37,12 @@ extern "C" int apn_sa_forward_seq(
         APN_TRY(apn_sa_prep_features(b, 32, n, f, ft, precision, stream));
         if (train1)
             APN_TRY(apn_sa_fwd_stats1(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx,
-                                      w1, part1, stream));
+                                      tmap, w1, part1, stream));
     }
     if (phases & 2) {
         APN_TRY(apn_sa_bn_fold(sums1 ? nullptr : part1, rows, sums1, 32, count, g1, b1, eps1, mom1,
                                rm1, rv1, nbt1, train1, pack1, g2, 64, sgn2, stream));
-        APN_TRY(apn_sa_fwd_main(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, w1,
+        APN_TRY(apn_sa_fwd_main(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, tmap, w1,
                                 w2, pack1, pack1 + 32, sgn2, ysel, ksel, part2, stream));
     }
     if (phases & 4) {
@@ -56,7 +56,7 @@ extern "C" int apn_sa_forward_seq(
 
 extern "C" int apn_sa_backward_seq(
     int phases, int precision, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
-    const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
+    const float *f, const int *idx, const int *tmap, const int *fidx, const float *w1, const float *w2,
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
@@ -80,7 +80,7 @@ extern "C" int apn_sa_backward_seq(
     if (phases & 2) {
         APN_TRY(apn_sa_bwd_consts2(sumsS ? nullptr : partS, prow, sumsS, pack2, w2, count, train2,
                                    d2e2, qm, evec, g_g2, g_b2, g_w2, gram, stream));
-        APN_TRY(apn_sa_bwd_main(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, w1,
+        APN_TRY(apn_sa_bwd_main(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, tmap, w1,
                                 w2, pack1, qm, evec, goa, ksel, partT, g_w2, gram, A, geo, HA, HB,
                                 stream));
     }

@@ -456,15 +456,21 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
 #pragma unroll 1
         for (int cb = 0; cb < NCB; ++cb) {
             // this lane's y1 operands of the epilogue (lane = mid channel): issued before the MFMA chain
+            // (a tile of ONE query -- dense neighbourhoods pack that way -- has one row of V: one load, not 16)
             float u[CT <= 2 ? CT : 1][16], vv[CT <= 2 ? CT : 1][16];
             if (CT <= 2) {
 #pragma unroll
                 for (int j = 0; j < CT; ++j) {
                     const unsigned mid = (cb * CT + j) * 32 + r;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        u[j][i] = ub[urow[i] + mid];
-                        vv[j][i] = vb[vrow[i] + mid];
+                    for (int i = 0; i < 16; ++i) u[j][i] = ub[urow[i] + mid];
+                    if (nq == 1) {
+                        const float v1 = vb[mid];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) vv[j][i] = v1;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) vv[j][i] = vb[vrow[i] + mid];
                     }
                 }
             }
@@ -523,11 +529,24 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
                 float t1 = 0.0f, t2 = 0.0f;
                 float gu[16], yw[16];
                 float a1r[WG ? 16 : 1];
+                float uw[CT > 2 ? 16 : 1], vw[CT > 2 ? 16 : 1];
+                if (CT > 2) {                     // wide blocks: this column tile's operands, all loads in flight
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) uw[i] = ub[urow[i] + mid];
+                    if (nq == 1) {
+                        const float v1 = vb[mid];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) vw[i] = v1;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) vw[i] = vb[vrow[i] + mid];
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     float ui, vi;
                     if (CT <= 2) { ui = u[j][i]; vi = vv[j][i]; }
-                    else { ui = ub[urow[i] + mid]; vi = vb[vrow[i] + mid]; }
+                    else { ui = uw[i]; vi = vw[i]; }
                     const float wgt = (float)ri_mult(meta[i]);
                     const float y1 = ui - vi;
                     const float yh = (y1 - mu) * iv;

@@ -24,6 +24,8 @@ all on the current stream with no host reads, so a step can be captured in a HIP
 With sync_bn=True the per-channel float64 sums are all-reduced across ranks
 (SyncBatchNorm semantics) at the four points where statistics leave the kernels.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -31,6 +33,7 @@ import torch.nn as nn
 from . import _lib
 
 C_IN, C_MID, C_OUT, K_NS = 32, 32, 64, 32
+TILE_MAP_IN_BACKWARD = os.environ.get('APN_TMAP_BWD', '1') == '1'     # TUNING HOOK
 
 # Operand precision of the MFMA contractions:
 #   "bf16x3" (default) every f32 operand is split into hi + lo bf16 parts and each product is
@@ -169,7 +172,9 @@ class _Forward:
     """Runs the forward launches and keeps what the backward needs."""
 
     def __init__(self, p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
-                 sync_bn):
+                 sync_bn, tmap=None):
+        """tmap: the distinct-hit tile map of idx (adaptpoint_amd.fused_wide.tile_map; index-stage work) -- the
+        three passes over the positions then run over ~1/4 of the tiles at stage 1; None: one tile per query."""
         dev = f.device
         call = _Launcher(dev)
         lib = _lib.load()
@@ -199,9 +204,9 @@ class _Forward:
             if PER_KERNEL_LAUNCH:
                 return _forward_per_kernel(call, phases, prec, B, N, M, self.radius, p, new_p, f, idx, fidx,
                                            w1, w2, ws, bs, bn1a, bn2a, count, self.relu, v, sums1,
-                                           sums2, out, rows)
+                                           sums2, out, rows, tmap)
             call("apn_sa_forward_seq", phases, prec, B, N, M, self.radius, p.data_ptr(), new_p.data_ptr(),
-                 f.data_ptr(), idx.data_ptr(), _ptr(fidx), w1.data_ptr(), w2.data_ptr(), _ptr(ws),
+                 f.data_ptr(), idx.data_ptr(), _ptr(tmap), _ptr(fidx), w1.data_ptr(), w2.data_ptr(), _ptr(ws),
                  _ptr(bs), *bn1a, *bn2a, count, self.relu, v["ft"].data_ptr(),
                  v["part1"].data_ptr(), v["part2"].data_ptr(), _ptr(sums1), _ptr(sums2),
                  v["pack1"].data_ptr(), v["pack2"].data_ptr(), v["sgn2"].data_ptr(),
@@ -216,7 +221,7 @@ class _Forward:
             s2 = _all_reduce_rows(call, v["part2"], rows, 128, count, dev) if self.train2 else None
             run(4, sums2=s2)
         self.out = out
-        self.saved = dict(p=p, f=f, new_p=new_p, idx=idx, fidx=fidx, ft=v["ft"], w1=w1, w2=w2, ws=ws,
+        self.saved = dict(p=p, f=f, new_p=new_p, idx=idx, tmap=tmap if TILE_MAP_IN_BACKWARD else None, fidx=fidx, ft=v["ft"], w1=w1, w2=w2, ws=ws,
                           has_bs=bs is not None, pack1=v["pack1"], pack2=v["pack2"], ysel=v["ysel"],
                           ksel=v["ksel"], count=count)
 
@@ -267,7 +272,7 @@ def _backward(fw, g_out, need_p, need_newp):
             return _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, sumsS,
                                         sumsT, g_f, g_p, g_newp, rows, prow, wrows, has_skip)
         call("apn_sa_backward_seq", phases, fw.prec, B, N, M, fw.radius, sv["p"].data_ptr(),
-             sv["new_p"].data_ptr(), sv["f"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["fidx"]),
+             sv["new_p"].data_ptr(), sv["f"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["tmap"]), _ptr(sv["fidx"]),
              w1.data_ptr(), w2.data_ptr(), _ptr(ws), sv["ft"].data_ptr(), sv["pack1"].data_ptr(),
              sv["pack2"].data_ptr(), sv["ysel"].data_ptr(), sv["ksel"].data_ptr(),
              fw.out.data_ptr(), fw.relu, 1 if fw.train1 else 0, 1 if fw.train2 else 0, float(P),
@@ -302,10 +307,10 @@ def _backward(fw, g_out, need_p, need_newp):
 
 
 def _forward_per_kernel(call, phases, prec, B, N, M, radius, p, new_p, f, idx, fidx, w1, w2, ws, bs,
-                        bn1a, bn2a, count, relu, v, sums1, sums2, out, rows):
+                        bn1a, bn2a, count, relu, v, sums1, sums2, out, rows, tmap=None):
     """Python mirror of apn_sa_forward_seq (csrc/sa_seq.hip), one foreign call per kernel."""
     hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, prec, radius, p.data_ptr(), new_p.data_ptr(),
-           v["ft"].data_ptr(), idx.data_ptr(), w1.data_ptr())
+           v["ft"].data_ptr(), idx.data_ptr(), _ptr(tmap), w1.data_ptr())
     if phases & 1:
         call("apn_sa_prep_features", B, C_IN, N, f.data_ptr(), v["ft"].data_ptr(), prec)
         if bn1a[7]:
@@ -333,7 +338,7 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
     w1, w2, ws, P = sv["w1"], sv["w2"], sv["ws"], float(sv["count"])
     gip = v["gip"].data_ptr() if has_skip else None
     hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, fw.prec, fw.radius, sv["p"].data_ptr(),
-           sv["new_p"].data_ptr(), sv["ft"].data_ptr(), sv["idx"].data_ptr(), w1.data_ptr(),
+           sv["new_p"].data_ptr(), sv["ft"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["tmap"]), w1.data_ptr(),
            w2.data_ptr(), sv["pack1"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr())
     if phases & 1:
         buf[:zero_floats].zero_()
@@ -414,6 +419,7 @@ class Sampling:
         o += B * M * 3
         self.idx = self.buf[o:o + B * M * K].view(B, M, K)
         self.index = None        # adaptpoint_amd.fused_wide.NeighbourIndex of idx, when the width-generic kernels run
+        self.tmap = None         # adaptpoint_amd.fused_wide.tile_map of idx, for the register-resident kernels
 
     def clouds(self, lo, hi):
         """The index stage of clouds lo..hi-1 as a `Sampling`-like view (no copy): index stages of
@@ -423,6 +429,7 @@ class Sampling:
         v.buf = None
         v.fidx, v.new_p, v.idx = self.fidx[lo:hi], self.new_p[lo:hi], self.idx[lo:hi]
         v.index = None
+        v.tmap = None
         return v
 
 
@@ -485,7 +492,7 @@ class _SetAbstraction(torch.autograd.Function):
         if p.requires_grad:
             new_p = new_p.clone()          # returned as a differentiable output
         fw = _Forward(p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
-                      sync_bn)
+                      sync_bn, tmap=getattr(smp, "tmap", None))
         ctx.fw = fw
         ctx.save_for_backward(p, f)        # autograd's in-place version checks cover the inputs
         ctx.set_materialize_grads(False)   # an unused output's gradient arrives as None, not as zeros

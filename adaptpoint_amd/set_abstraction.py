@@ -26,6 +26,7 @@ FUSED_FALLBACKS = {}
 # True: the width-generic kernels (csrc/sa_wide.hip) also take the 32 -> 32 -> 64 shape that the
 # register-resident kernels of csrc/sa_fused.hip specialise in (A/B switch for benchmarks and tests).
 PREFER_WIDE = False
+COMPACT_RESIDENT = True      # the register-resident kernels run over the distinct-hit tile map when a Sampling carries one
 
 
 def fused_wide_first():
@@ -160,6 +161,9 @@ class SetAbstraction(nn.Module):
         from . import fused_wide
         wide, skip = self.wide_shapes(c_in)
         if not wide:
+            # the register-resident kernels take the tile map alone
+            if self.fused and not self.is_head and not self.all_aggr and self._fused_parts() is not None and COMPACT_RESIDENT:
+                smp.tmap = fused_wide.tile_map(smp.idx, out=smp.tmap)
             return None
         smp.index = fused_wide.neighbour_index(smp.idx, smp.new_p, n_points, fidx=smp.fidx if skip else None, out=out)
         return smp.index

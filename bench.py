@@ -312,7 +312,7 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
             hi = min(g + nb, count * B_PER_GPU)
             blk.sample(p_all[g:hi], out=big[dst].clouds(g, hi))
         for i in range(count):
-            if sets[dst][i].index is not None:
+            if sets[dst][i].index is not None or sets[dst][i].tmap is not None:
                 blk.index_for(sets[dst][i], N_PTS, C_IN, out=sets[dst][i].index)
 
     # Pipelined launch of `count` steps: the MLP steps consume set `cur` on the main stream while

@@ -161,7 +161,7 @@ APN_API int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, 
 /* Forward pass 1: part[rows][64] = {sum, sumsq}[32] of y1 = conv1(cat(dp, f[idx])). */
 APN_API int apn_sa_fwd_stats1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                               int precision, float radius, const float *xyz, const float *new_xyz,
-                              const void *ft, const int *idx, const float *w1, float *part,
+                              const void *ft, const int *idx, const int *tmap, const float *w1, float *part,
                               void *stream);
 
 /* out[0..ncol) = float64 column sums of part[rows][ncol] (ncol <= 128, a power of two);
@@ -189,7 +189,7 @@ APN_API int apn_sa_bn_fold(const float *part, int rows, const double *sums, int 
  * part[rows][128] = {sum[64], sumsq[64]} of y2. */
 APN_API int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                             int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                            const int *idx, const float *w1, const float *w2,
+                            const int *idx, const int *tmap, const float *w1, const float *w2,
                             const float *scale1, const float *shift1, const float *sgn2,
                             float *ysel, void *ksel, float *part, void *stream);
 
@@ -230,7 +230,7 @@ APN_API int apn_sa_bwd_consts2(const float *partS, int rows, const double *S, co
  *   HA, HB (B,M,32) = g_u and yhat1 summed per query.  bn1 = pack1 [4][32]. */
 APN_API int apn_sa_bwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
                             int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                            const int *idx, const float *w1, const float *w2, const float *bn1,
+                            const int *idx, const int *tmap, const float *w1, const float *w2, const float *bn1,
                             const float *qm, const float *evec, const float *goa,
                             const void *ksel, float *part, float *gw2_acc, float *gram_acc,
                             float *A, float *geo, float *HA, float *HB, void *stream);
@@ -270,7 +270,7 @@ APN_API int apn_sa_bwd_finalize(const float *partW, int rows_w, float radius, fl
  * sums* (float64, reduced over ranks) replace the partial rows when non-NULL. */
 APN_API int apn_sa_forward_seq(
     int phases, int precision, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
-    const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
+    const float *f, const int *idx, const int *tmap, const int *fidx, const float *w1, const float *w2,
     const float *ws, const float *bs,
     const float *g1, const float *b1, float *rm1, float *rv1, void *nbt1, float eps1, float mom1,
     int train1,
@@ -281,7 +281,7 @@ APN_API int apn_sa_forward_seq(
     float *out, void *stream);
 APN_API int apn_sa_backward_seq(
     int phases, int precision, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
-    const float *f, const int *idx, const int *fidx, const float *w1, const float *w2,
+    const float *f, const int *idx, const int *tmap, const int *fidx, const float *w1, const float *w2,
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,

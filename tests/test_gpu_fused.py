@@ -548,3 +548,40 @@ def test_syncbn_two_ranks_equal_one_double_batch(dev):
                                         halves[1].named_buffers()):
         assert torch.allclose(b.float(), b0.float(), rtol=1e-5, atol=1e-6), k   # running stats: global
         assert torch.equal(b0, b1), k
+
+
+@pytest.mark.gpu
+def test_register_resident_kernels_over_the_tile_map_equal_one_tile_per_query():
+    """The distinct-hit tile map (index-stage work, fused_wide.tile_map) only regroups the positions: folded fill
+    copies are weighted by their multiplicity, the pool runs per query over the distinct rows.  Same block, same
+    inputs, with and without the map: forward equal to summation-order rounding, gradients likewise."""
+    import copy
+    from adaptpoint_amd import fused, fused_wide
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    blk = SetAbstraction(32, 64, layers=2, stride=2, fused=True, use_res=True,
+                         group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                         norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'}).to(dev)
+    blk2 = copy.deepcopy(blk)
+    p = torch.from_numpy(GI.unit_sphere_cloud(8, 1024, seed=4)).to(dev)
+    f = torch.from_numpy(GI.seeded_normal((8, 32, 1024), seed=5)).to(dev)
+    fa, fb = f.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    smp_a = blk.sample(p)
+    smp_b = blk2.sample(p)
+    smp_b.tmap = fused_wide.tile_map(smp_b.idx)
+    assert int(smp_b.tmap[0]) < smp_b.idx.shape[0] * smp_b.idx.shape[1] // 2          # the map does fold
+    qa, oa = blk([p, fa], sampling=smp_a)
+    qb, ob = blk2([p, fb], sampling=smp_b)
+    assert torch.equal(qa, qb)
+    err = (oa - ob).abs()
+    assert err.max() <= 1e-4 and err.mean() <= 2e-6, (float(err.max()), float(err.mean()))
+    w = torch.randn_like(oa)
+    (oa * w).sum().backward()
+    (ob * w).sum().backward()
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert rel(fb.grad, fa.grad) <= 2e-3, rel(fb.grad, fa.grad)          # a pooled near-tie may flip (see test_gpu_fused_wide)
+    for (n1, q1), (_, q2) in zip(blk2.named_parameters(), blk.named_parameters()):
+        assert rel(q1.grad, q2.grad) <= 2e-3, (n1, rel(q1.grad, q2.grad))
+    for b1, b2 in zip(blk2.buffers(), blk.buffers()):
+        assert torch.allclose(b1.float(), b2.float(), rtol=1e-5, atol=1e-6)
