@@ -31,6 +31,7 @@ SIGNATURES = {
     "apn_furthest_point_sampling_xyz": [_c_int] * 3 + [_c_void_p] * 5,
     "apn_ball_query_zero": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 4,
     "apn_sa_grid_blocks": [_c_int] * 2,
+    "apn_sa_grid_rows": [_c_int] * 3,
     "apn_sa_bwd_main_rows": [_c_int] * 2,
     "apn_sa_prep_features": [_c_int] * 3 + [_c_void_p] * 2 + [_c_int, _c_void_p],
     "apn_sa_fwd_stats1": [_c_int] * 8 + [_c_float] + [_c_void_p] * 8,

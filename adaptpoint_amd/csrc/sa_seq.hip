@@ -32,7 +32,7 @@ extern "C" int apn_sa_forward_seq(
     double count, int relu, void *ft, float *part1, float *part2, const double *sums1,
     const double *sums2, float *pack1, float *pack2, float *sgn2, float *ysel, void *ksel,
     float *out, void *stream) {
-    const int rows = apn_sa_grid_blocks(b, m);
+    const int rows = apn_sa_grid_rows(b, m, tmap != nullptr);
     if (phases & 1) {
         APN_TRY(apn_sa_prep_features(b, 32, n, f, ft, precision, stream));
         if (train1)

@@ -31,7 +31,6 @@
 // by the caller (adaptpoint_amd/fused_wide.py::mfma_b_image), one contiguous block per
 // (column block, 32-deep k chunk).
 #include "apn_common.h"
-#include <stdlib.h>
 #include "apn_mfma.h"
 
 namespace apn {
@@ -829,9 +828,8 @@ template <int H>
 static constexpr bool bwd_res() { return (size_t)(3 * H / 32) * (H / (32 * bwd_ct<H>())) * Chunk<bwd_ct<H>()>::WORDS * 16 <= 48 * 1024; }
 
 static int wide_grid(int ntiles) {
-    static const int cap = getenv("APN_WIDE_GRID") ? atoi(getenv("APN_WIDE_GRID")) : 512;          // TUNING HOOK
     const int want = (ntiles + WIDE_WAVES - 1) / WIDE_WAVES;
-    return want < cap ? want : cap;            // two workgroups per CU; every workgroup leaves one partial row
+    return want < 512 ? want : 512;            // two workgroups per CU; every workgroup leaves one partial row
 }
 
 }  // namespace apn
@@ -925,9 +923,7 @@ extern "C" int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, c
         constexpr int NCH = ((O + H) / 32) * (H / (32 * CT));
         const size_t lds = (size_t)(RES ? NCH : 2) * Chunk<CT>::WORDS * 16 + (size_t)WIDE_WAVES * 2 * H * 4 +
                            (WG ? (size_t)WIDE_WAVES * ((O + H) * (H + 1) + H) * 4 : 0);
-        static const int occ_env = getenv("APN_WIDE_OCC") ? atoi(getenv("APN_WIDE_OCC")) : 0;     // TUNING HOOK
-        const bool occ2 = H <= 64 && occ_env != 1;
-        auto kern = occ2 ? wide_bwd_main_kernel<H, O, CT, RES, WG, (H <= 64 ? 2 : 1)> : wide_bwd_main_kernel<H, O, CT, RES, WG, 1>;
+        auto kern = wide_bwd_main_kernel<H, O, CT, RES, WG, (H <= 64 ? 2 : 1)>;       // two waves per SIMD where 256 registers do
         if (lds > 48 * 1024) {
             if (hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
                 return (int)e;

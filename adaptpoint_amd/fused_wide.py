@@ -28,7 +28,6 @@ from .fused import _call
 K_NS = 32
 LEAN_MAX = 64        # widest C_in / C_mid whose dense products run in csrc/sa_wide_dense.hip
 WIDTHS = (32, 64, 128, 256)
-_DEBUG = None        # tests may set a dict: intermediates of the last call are stashed in it
 
 
 def supported(p, f, idx_or_k, conv1, conv2, bns=()):
@@ -221,9 +220,6 @@ class _WideBlock(torch.autograd.Function):
             _call("apn_sa_wide_out", dev, B, M, O, ysel.data_ptr(), pack2.data_ptr(), C,
                   _fz._ptr(fs if Ws is not None else None), _fz._ptr(Ws),
                   _fz._ptr(None if bs is None else bs.detach()), 1 if relu else 0, out.data_ptr())
-            if _DEBUG is not None:
-                _DEBUG.update(U=U, V=V, pack1=pack1, w2img=w2img, ysel=ysel, ksel=ksel, part2=part2, pack2=pack2,
-                              sgn2=sgn2)
         ctx.save_for_backward(p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2, Ws, out if relu else None,
                               fs if Ws is not None else None)
         ctx.nbr = nbr
@@ -354,9 +350,6 @@ class _WideBlock(torch.autograd.Function):
             g_w1p = (torch.matmul(G.reshape(B * N, H).t(), p.reshape(B * N, 3))
                      - torch.matmul(Hq.reshape(B * M, H).t(), new_p.reshape(B * M, 3))) / radius
             g_w1 = torch.cat([g_w1p, g_w1f], 1).view(H, C + 3, 1, 1)
-        if _DEBUG is not None:
-            _DEBUG.update(goa=goa, zimg=zimg, GU=GU, HA=HA, HB=HB, partT=partT, Rpart=Rpart, R=R, d2e2=d2e2, evec=evec,
-                          cabc=cabc)
         return (g_p, g_q, g_f, g_w1, g_gamma1 if a1 else None, g_beta1 if a2 else None,
                 g_w2.view(O, H, 1, 1), g_gamma2 if a3 else None, g_beta2 if a4 else None, g_ws, g_bs, None)
 

@@ -301,8 +301,6 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
                 out.sum().backward()
 
     def index_steps(count, dst):
-        if os.environ.get("APN_BENCH_INDEX_ONCE"):          # DIAGNOSTIC ONLY (not a valid measurement): no index work
-            return
         if args.index_overlap == "on":
             # FPS of batch i and ball query of batch i-1 in one launch, batch by batch
             blk.sample_many(ps[:count], outs=sets[dst][:count])
@@ -508,9 +506,6 @@ def main():
     # The timed step issues whole launch sequences (one C call per direction, or one hipGraph),
     # which cannot carry per-kernel events.  The dominant kernel is therefore timed right after
     # the timed region: the same launch, same inputs, same stream, HIP events around it.
-    if os.environ.get("APN_BENCH_INDEX_ONCE"):
-        print(json.dumps({"DIAGNOSTIC": "index stage not run inside the timed region", "ms_per_step": 1e3 * elapsed / args.steps}))
-        return
     t2 = KernelTimer()
     r2 = instrument(t2, only={"fps"})
     for _ in range(max(2, 20 // spg)):

@@ -146,6 +146,8 @@ APN_API int apn_ball_query_zero(int b, int n, int m, float radius, int nsample,
 
 /* Workgroups (= partial rows) the fused passes launch for B clouds x M queries. */
 APN_API int apn_sa_grid_blocks(int b, int m);
+/* ... and with a tile map (apn_sa_wide_tilemap) behind the two forward passes: their partial rows then */
+APN_API int apn_sa_grid_rows(int b, int m, int with_tile_map);
 /* rows of the backward pass's partial sums (partT) */
 APN_API int apn_sa_bwd_main_rows(int b, int m);
 

@@ -551,7 +551,8 @@ def test_syncbn_two_ranks_equal_one_double_batch(dev):
 
 
 @pytest.mark.gpu
-def test_register_resident_kernels_over_the_tile_map_equal_one_tile_per_query():
+@pytest.mark.parametrize("map_in_backward", [False, True])
+def test_register_resident_kernels_over_the_tile_map_equal_one_tile_per_query(map_in_backward, monkeypatch):
     """The distinct-hit tile map (index-stage work, fused_wide.tile_map) only regroups the positions: folded fill
     copies are weighted by their multiplicity, the pool runs per query over the distinct rows.  Same block, same
     inputs, with and without the map: forward equal to summation-order rounding, gradients likewise."""
@@ -559,6 +560,7 @@ def test_register_resident_kernels_over_the_tile_map_equal_one_tile_per_query():
     from adaptpoint_amd import fused, fused_wide
     from adaptpoint_amd.set_abstraction import SetAbstraction
     dev = torch.device("cuda:0")
+    monkeypatch.setattr(fused, "TILE_MAP_IN_BACKWARD", map_in_backward)
     torch.manual_seed(0)
     blk = SetAbstraction(32, 64, layers=2, stride=2, fused=True, use_res=True,
                          group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
