@@ -299,33 +299,135 @@ extern "C" int apn_sa_wide_point_terms(int b, int n, int m, int c_mid, const flo
 // ------------------------------------------------------------------------------------------
 namespace apn {
 
-__global__ __launch_bounds__(256) void tilemap_count_kernel(int nq, int mode, const int *__restrict__ idx,
-                                                            unsigned char *__restrict__ cnt8) {
-    const int lane = lane_id(), q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= nq) return;
-    int cnt = 32;
-    if (mode) {
-        const int nn = idx[(size_t)q * 32 + (lane & 31)];
-        const int first = __builtin_amdgcn_readfirstlane(nn);
-        const unsigned differ = (unsigned)(__ballot(lane < 32 && lane > 0 && nn != first));   // bit k: slot k != slot 0
-        const int c = __popc(differ) + 1;
-        // ball-query structure: the differing slots are exactly 1..c-1 (and, being hits in index order, distinct)
-        if (differ == ((c >= 32 ? 0xffffffffu : ((1u << c) - 1u)) & ~1u)) cnt = c;
+// Rows of query q of cloud c (mode 1: the ball-query structure folded; any other row, or mode 0, kept whole).
+__device__ __forceinline__ int query_rows(const int *__restrict__ row, int mode) {
+    if (!mode) return 32;
+    const int4 *__restrict__ r4 = reinterpret_cast<const int4 *>(row);
+    unsigned differ = 0;
+    int first = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int4 v = r4[k];
+        if (k == 0) first = v.x;
+        differ |= (unsigned)(v.x != first) << (4 * k) | (unsigned)(v.y != first) << (4 * k + 1) |
+                  (unsigned)(v.z != first) << (4 * k + 2) | (unsigned)(v.w != first) << (4 * k + 3);
     }
-    if (lane == 0) cnt8[q] = (unsigned char)cnt;
+    const int c = __popc(differ) + 1;
+    // ball-query structure: the differing slots are exactly 1..c-1 (and, being hits in index order, distinct)
+    return differ == ((c >= 32 ? 0xffffffffu : ((1u << c) - 1u)) & ~1u) ? c : 32;
 }
 
-// one WAVE per cloud: greedy packing, 64 queries per round -- the counts arrive coalesced, the sequential
-// part runs on the scalar unit over v_readlane.  qmeta[q] = tile_local | row0 << 16 | starts_tile << 24 | number in its tile << 25
-__global__ __launch_bounds__(256) void tilemap_pack_kernel(int b, int m, const unsigned char *__restrict__ cnt8,
+// One block per cloud: next-fit packing of its M queries into 32-row tiles WITHOUT a serial pass over the
+// queries.  With P the prefix sums of the row counts, the tile that starts at query s ends before
+// next(s) = the first j with P[j+1] - P[s] > 32 (a binary search per query, all in parallel); the tile starts
+// are the orbit 0, next(0), next(next(0)), ...: the t-th start is reached through the binary digits of t over the
+// doubled maps next^(2^k) (log M rounds), every tile independently.
+//   qmeta[q] = tile_local | row0 << 16 | starts_tile << 24 | number in its tile << 25;  cnt8[q] = its row count
+//   tcount[c] = tiles of the cloud;  tnq_local[c m + t] = queries in tile t.   M <= 2048.
+__global__ __launch_bounds__(256) void tilemap_pack_kernel(int m, int mode, int levels, const int *__restrict__ idx,
+                                                           unsigned char *__restrict__ cnt8,
                                                            unsigned *__restrict__ qmeta, int *__restrict__ tcount,
                                                            unsigned short *__restrict__ tnq_local) {
+    extern __shared__ int sh[];
+    int *P = sh;                              // [m + 1]  exclusive prefix of the counts
+    int *start = P + (m + 1);                 // [m + 1]  tile starts
+    int *jump = start + (m + 1);              // [levels][m + 1]
+    __shared__ int wsum[256];
+    __shared__ int ntile_s;
+    const int t = threadIdx.x, c = blockIdx.x;
+    const int per = (m + 255) / 256;          // consecutive queries per thread (<= 8)
+    int cn[8], loc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = t * per + i;
+        cn[i] = (i < per && q < m) ? query_rows(idx + ((size_t)c * m + q) * 32, mode) : 0;
+        loc += cn[i];
+    }
+    wsum[t] = loc;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = t >= d ? wsum[t - d] : 0;
+        __syncthreads();
+        wsum[t] += v;
+        __syncthreads();
+    }
+    int run = wsum[t] - loc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = t * per + i;
+        if (i < per && q < m) {
+            P[q] = run;
+            cnt8[(size_t)c * m + q] = (unsigned char)cn[i];
+            run += cn[i];
+        }
+    }
+    if (t == 255) P[m] = wsum[255];
+    if (t == 0) ntile_s = 0;
+    __syncthreads();
+    // next(q): first j in (q, m] with P[j + 1] > P[q] + 32, i.e. the first query that no longer fits; next(m) = m
+    for (int q = t; q <= m; q += 256) {
+        int nx = m;
+        if (q < m) {
+            const int lim = P[q] + 32;
+            int lo = q + 1, hi = m;           // answer in [lo, hi]: smallest j >= q + 1 with P[j + 1] > lim, or m
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (P[mid + 1] > lim) hi = mid; else lo = mid + 1;
+            }
+            nx = lo;
+        }
+        jump[q] = nx;
+    }
+    __syncthreads();
+    for (int k = 1; k < levels; ++k) {
+        int *prev = jump + (k - 1) * (m + 1), *cur = jump + k * (m + 1);
+        for (int q = t; q <= m; q += 256) cur[q] = prev[prev[q]];
+        __syncthreads();
+    }
+    // tile t starts at next^t(0)
+    for (int tl = t; tl <= m; tl += 256) {
+        int s0 = 0;
+        for (int k = 0; k < levels; ++k)
+            if ((tl >> k) & 1) s0 = jump[k * (m + 1) + s0];
+        start[tl] = tl < m ? s0 : m;
+    }
+    __syncthreads();
+    for (int tl = t; tl < m; tl += 256) {
+        if (start[tl] < m) {
+            const int nxt = start[tl + 1];
+            tnq_local[(size_t)c * m + tl] = (unsigned short)(nxt - start[tl]);
+            if (nxt >= m) ntile_s = tl + 1;                       // the last tile: exactly one thread
+        }
+    }
+    __syncthreads();
+    const int T = ntile_s;
+    if (t == 0) tcount[c] = T;
+    for (int q = t; q < m; q += 256) {
+        int lo = 0, hi = T - 1;               // largest tile with start <= q
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (start[mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        const int s0 = start[lo];
+        qmeta[(size_t)c * m + q] = (unsigned)lo | ((unsigned)(P[q] - P[s0]) << 16) | (q == s0 ? 1u << 24 : 0u) |
+                                   ((unsigned)(q - s0) << 25);
+    }
+}
+
+// The serial form of the same packing, for clouds of more than 2048 queries: one WAVE per cloud, 64 queries per
+// round, the sequential part on the scalar unit over v_readlane.
+__global__ __launch_bounds__(256) void tilemap_pack_serial_kernel(int b, int m, int mode, const int *__restrict__ idx,
+                                                                  unsigned char *__restrict__ cnt8,
+                                                                  unsigned *__restrict__ qmeta,
+                                                                  int *__restrict__ tcount,
+                                                                  unsigned short *__restrict__ tnq_local) {
     const int lane = lane_id();
     const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (c >= b) return;
     int tile = 0, fill = 0, nq = 0;                       // wave-uniform
     for (int base = 0; base < m; base += 64) {
-        const int mine = base + lane < m ? cnt8[(size_t)c * m + base + lane] : 0;
+        const int mine = base + lane < m ? query_rows(idx + ((size_t)c * m + base + lane) * 32, mode) : 0;
+        if (base + lane < m) cnt8[(size_t)c * m + base + lane] = (unsigned char)mine;
         const int lim = m - base < 64 ? m - base : 64;
         unsigned meta = 0;
         for (int i = 0; i < lim; ++i) {
@@ -348,60 +450,57 @@ __global__ __launch_bounds__(256) void tilemap_pack_kernel(int b, int m, const u
     }
 }
 
-// exclusive scan of the per-cloud tile counts (one block): toff[c], ntiles[0] = total
-__global__ __launch_bounds__(1024) void tilemap_scan_kernel(int b, const int *__restrict__ tcount,
-                                                            int *__restrict__ toff, int *__restrict__ ntiles) {
-    __shared__ int part[1024];
-    const int t = threadIdx.x, per = (b + 1023) / 1024;
-    int s = 0;
-    for (int i = 0; i < per; ++i) {
-        const int c = t * per + i;
-        if (c < b) s += tcount[c];
-    }
-    part[t] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int v = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    int run = part[t] - s;
-    for (int i = 0; i < per; ++i) {
-        const int c = t * per + i;
-        if (c < b) { toff[c] = run; run += tcount[c]; }
-    }
-    if (t == 1023) ntiles[0] = part[1023];
-}
-
-// one wave per query: write its rows (and the padding behind a tile's last query)
-__global__ __launch_bounds__(256) void tilemap_fill_kernel(int nq, int m, const unsigned char *__restrict__ cnt8,
+// Block = (cloud, 64 of its queries), a wave per 16 queries: write the rows (and the padding behind a tile's last
+// query).  The cloud's first tile = the tile counts of the clouds before it, summed here (toff[c] kept for the
+// inverse map); the last cloud's first block also leaves the number of tiles in use.
+__global__ __launch_bounds__(256) void tilemap_fill_kernel(int b, int m, const unsigned char *__restrict__ cnt8,
                                                            const unsigned *__restrict__ qmeta,
-                                                           const int *__restrict__ toff,
+                                                           const int *__restrict__ tcount, int *__restrict__ toff,
                                                            const unsigned short *__restrict__ tnq_local,
-                                                           int *__restrict__ tq0, unsigned *__restrict__ rowinfo,
+                                                           int *__restrict__ ntiles, int *__restrict__ tq0,
+                                                           unsigned *__restrict__ rowinfo,
                                                            const int *__restrict__ idx, int *__restrict__ rownn) {
-    const int lane = lane_id(), q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= nq || lane >= 32) return;
-    const int c = q / m, cn = cnt8[q];
-    const unsigned meta = qmeta[q];
-    const int tl = meta & 0xffff, row0 = (meta >> 16) & 0xff;
-    const bool starts = (meta >> 24) & 1;
-    const bool ends = (q % m) == m - 1 || ((qmeta[q + 1] >> 24) & 1);       // the next query opens a tile
-    const int tile = toff[c] + tl;
-    const unsigned qlocal = (meta >> 25) & 0x3fu;
-    if (lane < cn) {
-        const unsigned mult = lane == 0 ? (unsigned)(33 - cn) : 1u;
-        unsigned v = qlocal | ((unsigned)lane << 8) | (mult << 16);
-        if (starts && lane == 0) v |= (unsigned)tnq_local[(size_t)c * m + tl] << 24;
-        rowinfo[(size_t)tile * 32 + row0 + lane] = v;
-        rownn[(size_t)tile * 32 + row0 + lane] = idx[(size_t)q * 32 + lane];
+    __shared__ int red[256];
+    const int c = blockIdx.y, t = threadIdx.x;
+    int s = 0;
+    for (int j = t; j < c; j += 256) s += tcount[j];
+    red[t] = s;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (t < d) red[t] += red[t + d];
+        __syncthreads();
     }
-    if (ends && row0 + cn + lane < 32) {                 // padding: multiplicity 0, a valid neighbour to load
-        rowinfo[(size_t)tile * 32 + row0 + cn + lane] = 0xffu;       // query 255: belongs to none
-        rownn[(size_t)tile * 32 + row0 + cn + lane] = idx[(size_t)q * 32];
+    const int base_tile = red[0];
+    if (blockIdx.x == 0 && t == 0) {
+        toff[c] = base_tile;
+        if (c == b - 1) ntiles[0] = base_tile + tcount[c];
     }
-    if (starts && lane == 0) tq0[tile] = q;
+    const int lane = t & 63, w = t >> 6;
+    if (lane >= 32) return;
+    for (int k = 0; k < 16; ++k) {
+        const int ql = blockIdx.x * 64 + w * 16 + k;
+        if (ql >= m) return;
+        const size_t q = (size_t)c * m + ql;
+        const int cn = cnt8[q];
+        const unsigned meta = qmeta[q];
+        const int tl = meta & 0xffff, row0 = (meta >> 16) & 0xff;
+        const bool starts = (meta >> 24) & 1;
+        const bool ends = ql == m - 1 || ((qmeta[q + 1] >> 24) & 1);        // the next query opens a tile
+        const size_t tile = (size_t)base_tile + tl;
+        const unsigned qlocal = (meta >> 25) & 0x3fu;
+        if (lane < cn) {
+            const unsigned mult = lane == 0 ? (unsigned)(33 - cn) : 1u;
+            unsigned v = qlocal | ((unsigned)lane << 8) | (mult << 16);
+            if (starts && lane == 0) v |= (unsigned)tnq_local[(size_t)c * m + tl] << 24;
+            rowinfo[tile * 32 + row0 + lane] = v;
+            rownn[tile * 32 + row0 + lane] = idx[q * 32 + lane];
+        }
+        if (ends && row0 + cn + lane < 32) {                 // padding: multiplicity 0, a valid neighbour to load
+            rowinfo[tile * 32 + row0 + cn + lane] = 0xffu;               // query 255: belongs to none
+            rownn[tile * 32 + row0 + cn + lane] = idx[q * 32];
+        }
+        if (starts && lane == 0) tq0[tile] = (int)q;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -417,33 +516,36 @@ __device__ __forceinline__ const int *tm_toff(const int *tmap, int nq, int b) {
     return tmap + 4 + ((nq + 3) & ~3) + (size_t)64 * nq + b;
 }
 
-__global__ __launch_bounds__(256) void csr_zero_kernel(long long n4, int4 *__restrict__ dst) {
+// pcnt = 0 and (optional) fq = -1, one launch (a kernel, not hipMemsetAsync: the whole index stage must
+// replay from a captured hipGraph, and a captured memset node aborted the replay here)
+__global__ __launch_bounds__(256) void csr_init_kernel(long long npts, int *__restrict__ pcnt, int *__restrict__ fq) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e < n4) dst[e] = make_int4(0, 0, 0, 0);
+    if (e >= npts) return;
+    pcnt[e] = 0;
+    if (fq) fq[e] = -1;
 }
 
-// fq[b n] = the query that point n is (fidx[b][q] == n), else -1: fill, then scatter (FPS picks are distinct)
-__global__ __launch_bounds__(256) void csr_fq_kernel(long long count, int n, int m, const int *__restrict__ fidx,
-                                                     int *__restrict__ fq) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= count) return;
-    if (!fidx) fq[e] = -1;
-    else fq[(e / m) * n + fidx[e]] = (int)(e % m);
-}
-
+// one thread per row of the tile map.  fill = 0: count the rows of every point (and, with fidx, record which query
+// each sampled point is: fq[b n] -- FPS picks are distinct); fill = 1: write the row ids behind the cursors.
 __global__ __launch_bounds__(256) void csr_count_fill_kernel(int nq, int n, int m, int fill,
                                                              const int *__restrict__ idx,
                                                              const int *__restrict__ tmap, int *__restrict__ pcnt,
-                                                             int *__restrict__ poff, int *__restrict__ plist) {
+                                                             int *__restrict__ poff, int *__restrict__ plist,
+                                                             const int *__restrict__ fidx, int *__restrict__ fq) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;       // row id
     const int tile = (int)(e >> 5);
     if (tile >= tmap[0]) return;
     const unsigned info = reinterpret_cast<const unsigned *>(tmap + 4 + ((nq + 3) & ~3))[e];
     if (((info >> 16) & 0xffu) == 0) return;
     const int q = tmap[4 + tile] + (int)(info & 0xffu);
-    const size_t gn = (size_t)(q / m) * n + idx[(size_t)q * 32 + ((info >> 8) & 0xffu)];
-    if (!fill) atomicAdd(pcnt + gn, 1);
-    else plist[atomicAdd(poff + gn, 1)] = (int)e;
+    const size_t cbase = (size_t)(q / m) * n;
+    const size_t gn = cbase + tmap[4 + ((nq + 3) & ~3) + (size_t)32 * nq + e];           // rownn[e]
+    if (!fill) {
+        atomicAdd(pcnt + gn, 1);
+        if (fq && ((info >> 8) & 0xffu) == 0) fq[cbase + fidx[q]] = q % m;                 // one row per query has slot 0
+    } else {
+        plist[atomicAdd(poff + gn, 1)] = (int)e;
+    }
 }
 
 // one block per cloud: poff = (first row id of the cloud) + exclusive scan of pcnt
@@ -539,7 +641,8 @@ extern "C" int apn_sa_wide_tilemap_ints(int b, int m) {
 }
 
 extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *tmap, void *stream) {
-    if (b <= 0 || m <= 0 || m > 65535 || (long long)b * m > 0x7fffffffLL / 64 || !idx || !tmap) return APN_EINVAL;
+    if (b <= 0 || m <= 0 || m > 65535 || b > 65535 || (long long)b * m > 0x7fffffffLL / 64 || !idx || !tmap)
+        return APN_EINVAL;
     const int nq = b * m;
     int *tq0 = tmap + 4;
     unsigned *rowinfo = (unsigned *)(tmap + tilemap_rows_off(nq));
@@ -549,12 +652,23 @@ extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *
     unsigned short *tnq_local = (unsigned short *)(qmeta + nq);
     unsigned char *cnt8 = (unsigned char *)(tnq_local + 2 * (((size_t)nq + 1) / 2));
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(apn::tilemap_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, nq, mode, idx, cnt8);
-    hipLaunchKernelGGL(apn::tilemap_pack_kernel, dim3((b + 3) / 4), dim3(256), 0, st, b, m, cnt8, qmeta, tcount,
-                       tnq_local);
-    hipLaunchKernelGGL(apn::tilemap_scan_kernel, dim3(1), dim3(1024), 0, st, b, tcount, toff, tmap);
-    hipLaunchKernelGGL(apn::tilemap_fill_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, nq, m, cnt8, qmeta, toff,
-                       tnq_local, tq0, rowinfo, idx, rownn);
+    if (m <= 2048) {
+        int levels = 1;
+        while ((1 << levels) <= m) ++levels;                     // tile numbers < m need `levels` binary digits
+        const size_t lds = (size_t)(levels + 2) * (m + 1) * sizeof(int);
+        if (lds > 48 * 1024) {
+            if (hipError_t e = hipFuncSetAttribute((const void *)apn::tilemap_pack_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+                return (int)e;
+        }
+        hipLaunchKernelGGL(apn::tilemap_pack_kernel, dim3(b), dim3(256), lds, st, m, mode, levels, idx, cnt8, qmeta,
+                           tcount, tnq_local);
+    } else {
+        hipLaunchKernelGGL(apn::tilemap_pack_serial_kernel, dim3((b + 3) / 4), dim3(256), 0, st, b, m, mode, idx, cnt8,
+                           qmeta, tcount, tnq_local);
+    }
+    hipLaunchKernelGGL(apn::tilemap_fill_kernel, dim3((m + 63) / 64, b), dim3(256), 0, st, b, m, cnt8, qmeta, tcount,
+                       toff, tnq_local, tmap, tq0, rowinfo, idx, rownn);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -564,27 +678,22 @@ extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *
 extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *new_xyz, const int *tmap,
                                int *pcnt_poff, int *plist, float *geo, const int *fidx, int *fq, void *stream) {
     if (b <= 0 || n <= 0 || m <= 0 || b > 65535 || (long long)b * m > 0x7fffffffLL / 64 ||
-        (long long)b * n > 0x7fffffffLL / 8 || !idx || !new_xyz || !tmap || !pcnt_poff || !plist || !geo)
+        (long long)b * n > 0x7fffffffLL / 8 || !idx || !new_xyz || !tmap || !pcnt_poff || !plist || !geo ||
+        ((fidx != nullptr) != (fq != nullptr)))
         return APN_EINVAL;
     const int nq = b * m;
     const long long npts = (long long)b * n;
     int *pcnt = pcnt_poff, *poff = pcnt_poff + npts;
     hipStream_t st = (hipStream_t)stream;
-    // (a kernel, not hipMemsetAsync: the whole index stage must replay from a captured hipGraph)
-    const long long n4 = (npts + 3) / 4;                 // pcnt is followed by poff: rounding up stays inside
-    hipLaunchKernelGGL(apn::csr_zero_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, n4, (int4 *)pcnt);
+    hipLaunchKernelGGL(apn::csr_init_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, npts, pcnt, fq);
     const unsigned rb = (unsigned)(((long long)nq * 32 + 255) / 256);
-    hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 0, idx, tmap, pcnt, poff, plist);
+    hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 0, idx, tmap, pcnt, poff, plist,
+                       fidx, fq);
     hipLaunchKernelGGL(apn::csr_scan_kernel, dim3(b), dim3(1024), 0, st, nq, b, n, tmap, pcnt, poff);
-    hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 1, idx, tmap, pcnt, poff, plist);
+    hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 1, idx, tmap, pcnt, poff, plist,
+                       fidx, fq);
     hipLaunchKernelGGL(apn::csr_sort_geo_kernel, dim3((unsigned)((npts + 127) / 128)), dim3(128), 0, st, nq, npts, tmap,
                        pcnt, poff, plist, new_xyz, geo);
-    if (fidx && fq) {
-        hipLaunchKernelGGL(apn::csr_fq_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, npts, n, m,
-                           (const int *)nullptr, fq);
-        hipLaunchKernelGGL(apn::csr_fq_kernel, dim3((unsigned)(((long long)nq + 255) / 256)), dim3(256), 0, st,
-                           (long long)nq, n, m, fidx, fq);
-    }
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
