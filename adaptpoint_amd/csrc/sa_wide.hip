@@ -446,11 +446,15 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
         // record and neighbour of every accumulator row of this lane (row p's sit in lane p)
         unsigned meta[16];
         row_meta(cur.info, h, meta);
-        unsigned urow[16], vrow[16];
+        // (row offsets into U and V of the accumulator rows: kept in registers across the MFMA chain only where the
+        // epilogue's loads are issued ahead of it, CT <= 2; the wide blocks recompute them in the epilogue)
+        unsigned urow[CT <= 2 ? 16 : 1], vrow[CT <= 2 ? 16 : 1];
+        if (CT <= 2) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            urow[i] = (unsigned)__builtin_amdgcn_ds_bpermute(acc_row(i, h) << 2, (int)uo);
-            vrow[i] = (ri_mult(meta[i]) ? ri_q(meta[i]) : 0u) * H;
+            for (int i = 0; i < 16; ++i) {
+                urow[i] = (unsigned)__builtin_amdgcn_ds_bpermute(acc_row(i, h) << 2, (int)uo);
+                vrow[i] = (ri_mult(meta[i]) ? ri_q(meta[i]) : 0u) * H;
+            }
         }
 #pragma unroll 1
         for (int cb = 0; cb < NCB; ++cb) {
@@ -531,14 +535,15 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
                 float uw[CT > 2 ? 16 : 1], vw[CT > 2 ? 16 : 1];
                 if (CT > 2) {                     // wide blocks: this column tile's operands, all loads in flight
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) uw[i] = ub[urow[i] + mid];
+                    for (int i = 0; i < 16; ++i)
+                        uw[i] = ub[(unsigned)__builtin_amdgcn_ds_bpermute(acc_row(i, h) << 2, (int)uo) + mid];
                     if (nq == 1) {
                         const float v1 = vb[mid];
 #pragma unroll
                         for (int i = 0; i < 16; ++i) vw[i] = v1;
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) vw[i] = vb[vrow[i] + mid];
+                        for (int i = 0; i < 16; ++i) vw[i] = vb[(ri_mult(meta[i]) ? ri_q(meta[i]) : 0u) * H + mid];
                     }
                 }
 #pragma unroll
