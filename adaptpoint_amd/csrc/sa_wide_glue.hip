@@ -574,56 +574,113 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int nq, int b, int n, co
     }
 }
 
-// one thread per point: sort its list (after the fill poff is the list's END), restore poff, sum geo.
-// Lists of up to CSR_LDS entries are sorted in an LDS slice of the thread (insertion sort; the entries arrive in the
-// order the fill's atomics happened to run); longer ones in place, with Shell's gaps.
-constexpr int CSR_LDS = 48;
-__global__ __launch_bounds__(128) void csr_sort_geo_kernel(int nq, long long npts, const int *__restrict__ tmap,
-                                                           const int *__restrict__ pcnt, int *__restrict__ poff,
-                                                           int *__restrict__ plist, const float *__restrict__ new_xyz,
-                                                           float *__restrict__ geo) {
-    __shared__ int slice[CSR_LDS][129];                     // [entry][thread]: conflict-free per-thread arrays
+// Sort every point's list (after the fill poff is the list's END; the entries arrive in the order the fill's atomics
+// happened to run), restore poff to the list's start, sum geo over the sorted list.  Two kernels share the points:
+//   csr_sort_short  one THREAD per point, lists of up to CSR_SHORT entries: insertion sort in an LDS slice;
+//   csr_sort_long   one WAVE per point, longer lists (dense neighbourhoods: a point gathered by 30-1000 rows):
+//                   bitonic network over an LDS buffer of up to CSR_LONG entries (beyond that -- a point in more than
+//                   CSR_LONG neighbourhoods -- lane 0 falls back to Shell's sort in place).
+// Both leave the same ascending list; geo's sum order is fixed per kernel (so per list length): reproducible.
+constexpr int CSR_SHORT = 16, CSR_LONG = 2048;
+
+__device__ __forceinline__ void geo_add(const int *__restrict__ tmap, const unsigned *__restrict__ rows,
+                                        const float *__restrict__ new_xyz, int e, float &occ, float &sx, float &sy,
+                                        float &sz) {
+    const unsigned info = rows[e];
+    const float mult = (float)((info >> 16) & 0xffu);
+    const float *__restrict__ q = new_xyz + (size_t)(tmap[4 + (e >> 5)] + (int)(info & 0xffu)) * 3;
+    occ += mult;
+    sx = __builtin_fmaf(mult, q[0], sx);
+    sy = __builtin_fmaf(mult, q[1], sy);
+    sz = __builtin_fmaf(mult, q[2], sz);
+}
+
+__global__ __launch_bounds__(128) void csr_sort_short_kernel(int nq, long long npts, const int *__restrict__ tmap,
+                                                             const int *__restrict__ pcnt, int *__restrict__ poff,
+                                                             int *__restrict__ plist,
+                                                             const float *__restrict__ new_xyz,
+                                                             float *__restrict__ geo) {
+    __shared__ int slice[CSR_SHORT][129];                   // [entry][thread]: conflict-free per-thread arrays
     const long long gn = (long long)blockIdx.x * 128 + threadIdx.x;
     if (gn >= npts) return;
-    const int c = pcnt[gn], start = poff[gn] - c;
+    const int c = pcnt[gn];
+    if (c > CSR_SHORT) return;                              // csr_sort_long's
+    const int start = poff[gn] - c;
     poff[gn] = start;
     int *__restrict__ l = plist + start;
     const unsigned *__restrict__ rows = reinterpret_cast<const unsigned *>(tmap + 4 + ((nq + 3) & ~3));
+    const int t = threadIdx.x;
+    for (int i = 0; i < c; ++i) {
+        const int v = l[i];
+        int j = i;
+        for (; j > 0 && slice[j - 1][t] > v; --j) slice[j][t] = slice[j - 1][t];
+        slice[j][t] = v;
+    }
     float occ = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    auto add = [&](int e) {
-        const unsigned info = rows[e];
-        const float mult = (float)((info >> 16) & 0xffu);
-        const float *__restrict__ q = new_xyz + (size_t)(tmap[4 + (e >> 5)] + (int)(info & 0xffu)) * 3;
-        occ += mult;
-        sx = __builtin_fmaf(mult, q[0], sx);
-        sy = __builtin_fmaf(mult, q[1], sy);
-        sz = __builtin_fmaf(mult, q[2], sz);
-    };
-    if (c <= CSR_LDS) {
-        const int t = threadIdx.x;
-        for (int i = 0; i < c; ++i) {
-            const int v = l[i];
-            int j = i;
-            for (; j > 0 && slice[j - 1][t] > v; --j) slice[j][t] = slice[j - 1][t];
-            slice[j][t] = v;
+    for (int i = 0; i < c; ++i) {
+        const int e = slice[i][t];
+        l[i] = e;
+        geo_add(tmap, rows, new_xyz, e, occ, sx, sy, sz);
+    }
+    *reinterpret_cast<float4 *>(geo + gn * 4) = make_float4(occ, sx, sy, sz);
+}
+
+__global__ __launch_bounds__(256) void csr_sort_long_kernel(int nq, long long npts, const int *__restrict__ tmap,
+                                                            const int *__restrict__ pcnt, int *__restrict__ poff,
+                                                            int *__restrict__ plist,
+                                                            const float *__restrict__ new_xyz,
+                                                            float *__restrict__ geo) {
+    __shared__ int buf[4][CSR_LONG];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const long long gn = (long long)blockIdx.x * 4 + w;
+    if (gn >= npts) return;
+    const int c = pcnt[gn];
+    if (c <= CSR_SHORT) return;                             // csr_sort_short's
+    const int start = poff[gn] - c;
+    int *__restrict__ l = plist + start;
+    const unsigned *__restrict__ rows = reinterpret_cast<const unsigned *>(tmap + 4 + ((nq + 3) & ~3));
+    float occ = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    if (c <= CSR_LONG) {
+        int n = 32;
+        while (n < c) n <<= 1;
+        int *b = buf[w];
+        // (one wave owns b: its LDS operations execute in program order, no barrier between the stages)
+        for (int i = lane; i < n; i += 64) b[i] = i < c ? l[i] : 0x7fffffff;
+        for (int k = 2; k <= n; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < n / 2; t += 64) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));     // the lower index of pair t at distance j
+                    const int p = i | j;
+                    const bool up = (i & k) == 0;
+                    const int x = b[i], y = b[p];
+                    if ((x > y) == up) { b[i] = y; b[p] = x; }
+                }
+            }
         }
-        for (int i = 0; i < c; ++i) {
-            const int e = slice[i][t];
+        for (int i = lane; i < c; i += 64) {
+            const int e = b[i];
             l[i] = e;
-            add(e);
+            geo_add(tmap, rows, new_xyz, e, occ, sx, sy, sz);
         }
-    } else {
-        for (int gap = c < 122 ? 40 : (c < 365 ? 121 : 364); gap > 0; gap = gap == 1 ? 0 : (gap - 1) / 3) {
-            for (int i = gap; i < c; ++i) {                     // Shell sort, gaps 364, 121, 40, 13, 4, 1
+    } else if (lane == 0) {
+        for (int gap = 1093; gap > 0; gap = gap == 1 ? 0 : (gap - 1) / 3) {
+            for (int i = gap; i < c; ++i) {                     // Shell sort, gaps 1093, 364, 121, 40, 13, 4, 1
                 const int v = l[i];
                 int j = i;
                 for (; j >= gap && l[j - gap] > v; j -= gap) l[j] = l[j - gap];
                 l[j] = v;
             }
         }
-        for (int i = 0; i < c; ++i) add(l[i]);
+        for (int i = 0; i < c; ++i) geo_add(tmap, rows, new_xyz, l[i], occ, sx, sy, sz);
     }
-    *reinterpret_cast<float4 *>(geo + gn * 4) = make_float4(occ, sx, sy, sz);
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+        occ += __shfl_xor(occ, k); sx += __shfl_xor(sx, k); sy += __shfl_xor(sy, k); sz += __shfl_xor(sz, k);
+    }
+    if (lane == 0) {
+        poff[gn] = start;
+        *reinterpret_cast<float4 *>(geo + gn * 4) = make_float4(occ, sx, sy, sz);
+    }
 }
 
 }  // namespace apn
@@ -692,7 +749,9 @@ extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float 
     hipLaunchKernelGGL(apn::csr_scan_kernel, dim3(b), dim3(1024), 0, st, nq, b, n, tmap, pcnt, poff);
     hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 1, idx, tmap, pcnt, poff, plist,
                        fidx, fq);
-    hipLaunchKernelGGL(apn::csr_sort_geo_kernel, dim3((unsigned)((npts + 127) / 128)), dim3(128), 0, st, nq, npts, tmap,
+    hipLaunchKernelGGL(apn::csr_sort_short_kernel, dim3((unsigned)((npts + 127) / 128)), dim3(128), 0, st, nq, npts, tmap,
+                       pcnt, poff, plist, new_xyz, geo);
+    hipLaunchKernelGGL(apn::csr_sort_long_kernel, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, st, nq, npts, tmap,
                        pcnt, poff, plist, new_xyz, geo);
     APN_LAUNCH_CHECK();
     return APN_OK;

@@ -15,7 +15,14 @@ if [ "$what" = bench ]; then
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o b -- python $R/bench.py --steps 200 --warmup 20 $B > $O/prof_bench.log 2>&1
     cp $O/prof_bench/b_kernel_stats.csv $O/r02_bench_default_kernel_stats.csv
     python $R/scripts/steady_stats.py $O/prof_bench/b_kernel_trace.csv sa_prep_features 20 3 --csv $O/r02_bench_default_steady_per_replay.csv > $O/r02_bench_default_steady.txt
+    python $R/scripts/chain_gaps.py $O/prof_bench/b_kernel_trace.csv sa_prep_features 40 > $O/r02_bench_default_chain.txt
     rm -rf $O/prof_bench
+    # the same step on the width-generic kernels (deterministic: no float atomics), for comparison
+    python $R/bench.py --steps 200 --warmup 20 --kernels wide $B 2>/dev/null | grep '^{' > $O/r02_bench_wide.json
+    rocprofv3 --kernel-trace --output-format csv -d $O/prof_wide -o b -- python $R/bench.py --steps 200 --warmup 20 --kernels wide $B > $O/prof_wide.log 2>&1
+    python $R/scripts/steady_stats.py $O/prof_wide/b_kernel_trace.csv wide_fwd_prep 20 3 > $O/r02_bench_wide_steady.txt
+    python $R/scripts/chain_gaps.py $O/prof_wide/b_kernel_trace.csv wide_fwd_prep 40 > $O/r02_bench_wide_chain.txt
+    rm -rf $O/prof_wide
     : > $O/r02_bench_distributions.jsonl
     for d in D1 D2; do for s in 0 1 2 3 4; do
         python $R/bench.py --steps 100 --warmup 20 $B --distribution $d --seed $s 2>/dev/null | grep '^{' >> $O/r02_bench_distributions.jsonl

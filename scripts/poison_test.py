@@ -1,0 +1,12 @@
+"""Diagnostic: run GPU tests with the allocator pool pre-filled with NaN, so that a kernel reading memory it (or a
+predecessor) never wrote shows up as NaN instead of depending on what the box last held.
+    python scripts/poison_test.py [pytest -k expression]"""
+import sys, torch, pytest
+# poison the caching allocator's pool: every later torch.empty() sees NaN / huge ints instead of stale data
+import os
+pat = int(os.environ.get("POISON", "0x7fc00000"), 0)                     # default: quiet NaN; as an int, a huge index
+pat = pat - (1 << 32) if pat >= (1 << 31) else pat
+blocks = [torch.full((64 << 20,), pat, dtype=torch.int32, device="cuda:0") for _ in range(24)]     # 24 x 256 MB
+small = [torch.full((1 << 16,), pat, dtype=torch.int32, device="cuda:0") for _ in range(512)]
+del blocks, small
+sys.exit(pytest.main(["tests/test_gpu_adaptpoint.py", "tests/test_gpu_fused_wide.py", "-q", "-m", "gpu", "-x", "-s", "-k", sys.argv[1] if len(sys.argv) > 1 else "gan_step or block or reproducible"]))
