@@ -11,7 +11,7 @@ what=${1:-bench}
 B="--no-cpu-baseline --no-secondary"
 
 if [ "$what" = bench ]; then
-    python $R/bench.py --steps 200 --warmup 20 > $O/r02_bench_default.json 2> $O/bench_default.err
+    python $R/bench.py > $O/r02_bench_default.json 2> $O/bench_default.err
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o b -- python $R/bench.py --steps 200 --warmup 20 $B > $O/prof_bench.log 2>&1
     cp $O/prof_bench/b_kernel_stats.csv $O/r02_bench_default_kernel_stats.csv
     python $R/scripts/steady_stats.py $O/prof_bench/b_kernel_trace.csv sa_prep_features 20 3 --csv $O/r02_bench_default_steady_per_replay.csv > $O/r02_bench_default_steady.txt
@@ -35,6 +35,11 @@ if [ "$what" = pmc ]; then
         rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${c}_pn -o p -- python $R/scripts/bench_pointnext.py --fused --steps 5 --warmup 2 >> $O/pmc_$c.log 2>&1
     done
     python $R/scripts/pmc_summary.py $O/r02_pmc_fetch_write_summary_block.csv $O/pmc_FETCH_SIZE_sa $O/pmc_WRITE_SIZE_sa > /dev/null
+    for c in FETCH_SIZE WRITE_SIZE; do
+        rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${c}_wide -o p -- python $R/bench.py --steps 20 --warmup 5 --graph off --pipeline off --kernels wide $B >> $O/pmc_$c.log 2>&1
+    done
+    python $R/scripts/pmc_summary.py $O/r02_pmc_fetch_write_summary_block_wide.csv $O/pmc_FETCH_SIZE_wide $O/pmc_WRITE_SIZE_wide > /dev/null
+    rm -rf $O/pmc_*_wide
     python $R/scripts/pmc_summary.py $O/r02_pmc_fetch_write_summary_classifier.csv $O/pmc_FETCH_SIZE_pn $O/pmc_WRITE_SIZE_pn > /dev/null
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/pmc_sq_pn -o p -- python $R/scripts/bench_pointnext.py --fused --steps 5 --warmup 2 > $O/pmc_sq.log 2>&1
     python $R/scripts/pmc_summary.py $O/r02_pmc_sq_summary_classifier.csv $O/pmc_sq_pn > /dev/null
