@@ -41,7 +41,7 @@ SIGNATURES = {
                        _c_void_p, _c_int, _c_void_p, _c_void_p],
     "apn_sa_fwd_main": [_c_int] * 8 + [_c_float] + [_c_void_p] * 14,
     "apn_sa_fwd_out": [_c_int] * 3 + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 3 + [_c_int]
-                      + [_c_void_p] * 2,
+                      + [_c_void_p] * 2 + [_c_longlong, _c_void_p],
     "apn_sa_bwd_prep_rows": [_c_int] * 2,
     "apn_sa_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] + [_c_int]
                        + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 7,
@@ -56,7 +56,7 @@ SIGNATURES = {
     "apn_sa_forward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 10
                            + [_c_void_p] * 5 + [_c_float, _c_float, _c_int]
                            + [_c_void_p] * 5 + [_c_float, _c_float, _c_int]
-                           + [_c_double, _c_int] + [_c_void_p] * 12),
+                           + [_c_double, _c_int] + [_c_void_p] * 12 + [_c_longlong, _c_void_p]),
     "apn_sa_backward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 15 + [_c_int] * 3
                             + [_c_double] + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p]
                             + [ctypes.c_size_t]

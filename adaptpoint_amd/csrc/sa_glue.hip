@@ -227,9 +227,16 @@ __global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float
                                                        const int *__restrict__ fidx,
                                                        const float *__restrict__ ws,
                                                        const float *__restrict__ bs, int relu,
-                                                       float *__restrict__ out) {
+                                                       float *__restrict__ out, float4 *__restrict__ zero,
+                                                       long long zero_n4) {
     __shared__ float tile[64][65];
     __shared__ float sfi[64][33];
+    // The backward pass accumulates into A / geo / gip with atomics; they are zeroed HERE, by the last forward
+    // launch (race-free: their writers run after it), so that the backward needs no fill launch of its own.
+    if (zero) {
+        const long long nb = (long long)gridDim.x * gridDim.y, bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        for (long long i = bid * 1024 + threadIdx.x; i < zero_n4; i += nb * 1024) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __shared__ __attribute__((aligned(16))) float sws[64][36];
     const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..15
@@ -718,13 +725,15 @@ extern "C" int apn_sa_bn_fold(const float *part, int rows, const double *sums, i
 
 extern "C" int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const float *pack2,
                               const void *ft, int precision, const int *fidx, const float *ws,
-                              const float *bs, int relu, float *out, void *stream) {
+                              const float *bs, int relu, float *out, float *zero_base, long long zero_floats,
+                              void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || !ysel || !pack2 || !out) return APN_EINVAL;
     if (ws && (!ft || !fidx || n <= 0 || (precision != 1 && precision != 2))) return APN_EINVAL;
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = (ws && precision == 2) ? hi + (size_t)b * n * 32 : nullptr;
+    if (zero_base && (zero_floats < 0 || (zero_floats & 3) || ((uintptr_t)zero_base & 15))) return APN_EINVAL;
     hipLaunchKernelGGL(apn::fwd_out_kernel, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, ysel,
-                       pack2, hi, lo, fidx, ws, bs, relu, out);
+                       pack2, hi, lo, fidx, ws, bs, relu, out, (float4 *)zero_base, zero_base ? zero_floats / 4 : 0);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

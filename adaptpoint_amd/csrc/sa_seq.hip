@@ -31,7 +31,7 @@ extern "C" int apn_sa_forward_seq(
     int train2,
     double count, int relu, void *ft, float *part1, float *part2, const double *sums1,
     const double *sums2, float *pack1, float *pack2, float *sgn2, float *ysel, void *ksel,
-    float *out, void *stream) {
+    float *out, float *zero_base, long long zero_floats, void *stream) {
     const int rows = apn_sa_grid_rows(b, m, tmap != nullptr);
     if (phases & 1) {
         APN_TRY(apn_sa_prep_features(b, 32, n, f, ft, precision, stream));
@@ -49,7 +49,7 @@ extern "C" int apn_sa_forward_seq(
         APN_TRY(apn_sa_bn_fold(sums2 ? nullptr : part2, rows, sums2, 64, count, g2, b2, eps2, mom2,
                                rm2, rv2, nbt2, train2, pack2, nullptr, 0, nullptr, stream));
         APN_TRY(apn_sa_fwd_out(b, n, m, ysel, pack2, ws ? ft : nullptr, precision,
-                               ws ? fidx : nullptr, ws, bs, relu, out, stream));
+                               ws ? fidx : nullptr, ws, bs, relu, out, zero_base, zero_floats, stream));
     }
     return APN_OK;
 }
@@ -60,8 +60,8 @@ extern "C" int apn_sa_backward_seq(
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
-    // zero-filled here: A (B*N*32) | geo (B*N*4) | gip (B*N*32, only with ws) by one memset
-    // (phase 1); g_w2 (64*32) and gram (32*32 + 32) by the consts2 launch (phase 2)
+    // zero-filled here unless zero_bytes == 0 (then apn_sa_fwd_out cleared them): A (B*N*32) | geo (B*N*4) |
+    // gip (B*N*32, only with ws) by one memset (phase 1); g_w2 (64*32) and gram (32*32 + 32) by the consts2 launch (phase 2)
     float *zero_base, size_t zero_bytes, float *g_w2, float *gram, float *A, float *geo, float *gip,
     // scratch
     float *goa, float *partS, float *partWs, float *partT, float *partW, const double *sumsS,
@@ -72,8 +72,10 @@ extern "C" int apn_sa_backward_seq(
     const int rows_t = apn_sa_bwd_main_rows(b, m);
     const int prow = apn_sa_bwd_prep_rows(b, m);
     if (phases & 1) {
-        hipError_t me = hipMemsetAsync(zero_base, 0, zero_bytes, (hipStream_t)stream);
-        if (me != hipSuccess) return (int)me;
+        if (zero_bytes) {                 // 0: the forward's last launch already cleared the region
+            hipError_t me = hipMemsetAsync(zero_base, 0, zero_bytes, (hipStream_t)stream);
+            if (me != hipSuccess) return (int)me;
+        }
         APN_TRY(apn_sa_bwd_prep(b, n, m, g_out, gs_b, gs_c, gs_m, out, relu, ysel, pack2, ws ? ft : nullptr, precision,
                                 ws ? fidx : nullptr, ws, goa, partS, partWs, gip, stream));
     }

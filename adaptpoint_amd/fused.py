@@ -176,8 +176,10 @@ class _Forward:
     """Runs the forward launches and keeps what the backward needs."""
 
     def __init__(self, p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
-                 sync_bn, tmap=None):
-        """tmap: the distinct-hit tile map of idx (adaptpoint_amd.fused_wide.tile_map; index-stage work) -- the
+                 sync_bn, tmap=None, want_backward=False):
+        """want_backward: the backward's atomically accumulated region (A | geo | gip) is allocated now and cleared
+        by the forward's last launch, so that the backward runs without a fill launch of its own.
+        tmap: the distinct-hit tile map of idx (adaptpoint_amd.fused_wide.tile_map; index-stage work) -- the
         three passes over the positions then run over ~1/4 of the tiles at stage 1; None: one tile per query."""
         dev = f.device
         call = _Launcher(dev)
@@ -201,6 +203,11 @@ class _Forward:
                                ("sgn2", C_OUT), ("ysel", B * M * C_OUT), ("ksel", B * M * C_OUT // 4),
                                ("part1", rows * 64), ("part2", rows * 128)])
         out = torch.empty(B, C_OUT, M, dtype=torch.float32, device=dev)
+        self.zsizes = [("A", B * N * C_MID), ("geo", B * N * 4)] + ([("gip", B * N * C_MID)] if ws is not None else [])
+        self.zviews = self.zbuf = None
+        if want_backward:
+            self.zviews, self.zbuf = _carve(dev, self.zsizes)
+        zptr, zfl = _ptr(self.zbuf), (self.zbuf.numel() if self.zbuf is not None else 0)
         bn1a, bn2a = _bn_args(bn1), _bn_args(bn2)
         self.train1, self.train2 = bool(bn1a[7]), bool(bn2a[7])
 
@@ -208,13 +215,13 @@ class _Forward:
             if PER_KERNEL_LAUNCH:
                 return _forward_per_kernel(call, phases, prec, B, N, M, self.radius, p, new_p, f, idx, fidx,
                                            w1, w2, ws, bs, bn1a, bn2a, count, self.relu, v, sums1,
-                                           sums2, out, rows, tmap)
+                                           sums2, out, rows, tmap, zptr, zfl)
             call("apn_sa_forward_seq", phases, prec, B, N, M, self.radius, p.data_ptr(), new_p.data_ptr(),
                  f.data_ptr(), idx.data_ptr(), _ptr(tmap), _ptr(fidx), w1.data_ptr(), w2.data_ptr(), _ptr(ws),
                  _ptr(bs), *bn1a, *bn2a, count, self.relu, v["ft"].data_ptr(),
                  v["part1"].data_ptr(), v["part2"].data_ptr(), _ptr(sums1), _ptr(sums2),
                  v["pack1"].data_ptr(), v["pack2"].data_ptr(), v["sgn2"].data_ptr(),
-                 v["ysel"].data_ptr(), v["ksel"].data_ptr(), out.data_ptr())
+                 v["ysel"].data_ptr(), v["ksel"].data_ptr(), out.data_ptr(), zptr, zfl)
 
         if not _phased(sync_bn):
             run(7)
@@ -253,8 +260,10 @@ def _backward(fw, g_out, need_p, need_newp):
     prow = lib.apn_sa_bwd_prep_rows(B, M)
     wrows = lib.apn_sa_bwd_weight_rows(B, N)
 
-    # scratch: the zero-filled (atomically accumulated) region first, contiguous
-    zsizes = [("A", B * N * C_MID), ("geo", B * N * 4)] + ([("gip", B * N * C_MID)] if has_skip else [])
+    # scratch: the zero-filled (atomically accumulated) region first, contiguous -- unless the forward's last
+    # launch already allocated and cleared it (fw.zbuf)
+    prezeroed = fw.zbuf is not None
+    zsizes = [] if prezeroed else fw.zsizes
     sizes = zsizes + [("goa", B * M * C_OUT), ("partS", prow * 128),
                       ("partWs", prow * C_OUT * C_IN if has_skip else 0), ("partT", rows * 64),
                       ("partW", wrows * 32 * 38), ("d2e2", 2 * C_OUT), ("qm", C_MID * C_MID),
@@ -262,6 +271,9 @@ def _backward(fw, g_out, need_p, need_newp):
                       ("HB", B * M * C_MID)]
     v, buf = _carve(dev, sizes)
     zero_floats = sum((nfl + 63) // 64 * 64 for _, nfl in zsizes)
+    if prezeroed:
+        v.update(fw.zviews)
+        fw.zbuf = fw.zviews = None                        # consumed: a second backward must not trust it
     # small gradients in one buffer (kept alive by the parameters' .grad), g_w2 zero-filled
     gsz = [("w2", C_OUT * C_MID), ("w1", C_MID * (C_IN + 3)), ("g1", C_MID), ("b1", C_MID),
            ("g2", C_OUT), ("b2", C_OUT), ("ws", C_OUT * C_IN if has_skip else 0),
@@ -311,7 +323,7 @@ def _backward(fw, g_out, need_p, need_newp):
 
 
 def _forward_per_kernel(call, phases, prec, B, N, M, radius, p, new_p, f, idx, fidx, w1, w2, ws, bs,
-                        bn1a, bn2a, count, relu, v, sums1, sums2, out, rows, tmap=None):
+                        bn1a, bn2a, count, relu, v, sums1, sums2, out, rows, tmap=None, zptr=None, zfl=0):
     """Python mirror of apn_sa_forward_seq (csrc/sa_seq.hip), one foreign call per kernel."""
     hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, prec, radius, p.data_ptr(), new_p.data_ptr(),
            v["ft"].data_ptr(), idx.data_ptr(), _ptr(tmap), w1.data_ptr())
@@ -332,7 +344,7 @@ def _forward_per_kernel(call, phases, prec, B, N, M, radius, p, new_p, f, idx, f
              v["pack2"].data_ptr(), None, 0, None)
         call("apn_sa_fwd_out", B, N, M, v["ysel"].data_ptr(), v["pack2"].data_ptr(),
              v["ft"].data_ptr() if ws is not None else None, prec,
-             _ptr(fidx) if ws is not None else None, _ptr(ws), _ptr(bs), relu, out.data_ptr())
+             _ptr(fidx) if ws is not None else None, _ptr(ws), _ptr(bs), relu, out.data_ptr(), zptr, zfl)
 
 
 def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, sumsS, sumsT, g_f, g_p,
@@ -379,7 +391,7 @@ class _GroupedMlpMax(torch.autograd.Function):
     def forward(ctx, p, new_p, f, idx, w1, g1, b1, w2, g2, b2, mods):
         radius, conv1, bn1, conv2, bn2, sync_bn = mods
         fw = _Forward(p.contiguous(), f.contiguous(), new_p.contiguous(), idx.contiguous(), None,
-                      radius, conv1, bn1, conv2, bn2, None, False, sync_bn)
+                      radius, conv1, bn1, conv2, bn2, None, False, sync_bn, want_backward=any(ctx.needs_input_grad))
         ctx.fw = fw
         ctx.save_for_backward(p, new_p, f, idx)     # autograd's in-place version checks cover the inputs
         ctx.set_materialize_grads(False)
@@ -496,7 +508,7 @@ class _SetAbstraction(torch.autograd.Function):
         if p.requires_grad:
             new_p = new_p.clone()          # returned as a differentiable output
         fw = _Forward(p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
-                      sync_bn, tmap=getattr(smp, "tmap", None))
+                      sync_bn, tmap=getattr(smp, "tmap", None), want_backward=any(ctx.needs_input_grad))
         ctx.fw = fw
         ctx.save_for_backward(p, f)        # autograd's in-place version checks cover the inputs
         ctx.set_materialize_grads(False)   # an unused output's gradient arrives as None, not as zeros

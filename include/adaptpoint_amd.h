@@ -195,12 +195,15 @@ APN_API int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out,
                             const float *scale1, const float *shift1, const float *sgn2,
                             float *ysel, void *ksel, float *part, void *stream);
 
-/* out (B,64,M) = act(ysel*scale2 + shift2 + Ws f[:, fidx] + bs); ws/bs/ft/fidx may be null
+/* (zero_base, zero_floats: optional region -- the backward's atomically accumulated A | geo | gip -- cleared by
+ * this launch, the forward's last, so that apn_sa_backward_seq(zero_bytes = 0) needs no fill launch)
+ * out (B,64,M) = act(ysel*scale2 + shift2 + Ws f[:, fidx] + bs); ws/bs/ft/fidx may be null
  * (no skip branch), relu = 0/1.  f is read from the point-major table(s) ft; fidx (B,M),
  * ws (64,32), bs (64). */
 APN_API int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const float *pack2,
                            const void *ft, int precision, const int *fidx, const float *ws,
-                           const float *bs, int relu, float *out, void *stream);
+                           const float *bs, int relu, float *out, float *zero_base, long long zero_floats,
+                           void *stream);
 
 /* Backward entry: g = g_out * [out > 0] (relu) ; goa (B,M,64) = g * scale2;
  * g_out (B,64,M) is read with element strides (gs_b, gs_c, gs_m) -- a broadcast upstream
@@ -280,7 +283,7 @@ APN_API int apn_sa_forward_seq(
     int train2,
     double count, int relu, void *ft, float *part1, float *part2, const double *sums1,
     const double *sums2, float *pack1, float *pack2, float *sgn2, float *ysel, void *ksel,
-    float *out, void *stream);
+    float *out, float *zero_base, long long zero_floats, void *stream);
 APN_API int apn_sa_backward_seq(
     int phases, int precision, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
     const float *f, const int *idx, const int *tmap, const int *fidx, const float *w1, const float *w2,
