@@ -650,10 +650,18 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         // image needs no barrier; it starts zeroed and is left zeroed.  With a tile map the tile holds
         // several queries: each drops into ITS rows (row0 of the query + the pooled slot).
         Frag<NS> sp[4];
+        // (the next query's pooled slot and gradient are requested while this one is processed: the loop would
+        // otherwise pay one memory round trip per query of the tile)
+        float gv_nx = g.goa[(size_t)q0 * SA_C2 + lane];
+        int kc_nx = g.ksel[(size_t)q0 * SA_C2 + lane];
 #pragma unroll 1
         for (int jq = 0; jq < nq; ++jq) {
-            const float gv = g.goa[(size_t)(q0 + jq) * SA_C2 + lane];      // lane = out channel c
-            int kc = g.ksel[(size_t)(q0 + jq) * SA_C2 + lane];
+            const float gv = gv_nx;                                         // lane = out channel c
+            int kc = kc_nx;
+            if (jq + 1 < nq) {
+                gv_nx = g.goa[(size_t)(q0 + jq + 1) * SA_C2 + lane];
+                kc_nx = g.ksel[(size_t)(q0 + jq + 1) * SA_C2 + lane];
+            }
             if (CP) {
                 const unsigned long long rows_q = __ballot(lane < 32 && live_row && ri_q(raw.info) == (unsigned)jq);
                 kc += __builtin_ctzll(rows_q);                              // first row of query jq in the tile
@@ -679,9 +687,11 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             sp[s].p[0] = *reinterpret_cast<const bf16x8 *>(src);
             if (NS == 2) sp[s].p[NS - 1] = *reinterpret_cast<const bf16x8 *>(src + SP_TILE);
         }
+        kc_nx = g.ksel[(size_t)q0 * SA_C2 + lane];
 #pragma unroll 1
         for (int jq = 0; jq < nq; ++jq) {
-            int kc = g.ksel[(size_t)(q0 + jq) * SA_C2 + lane];
+            int kc = kc_nx;
+            if (jq + 1 < nq) kc_nx = g.ksel[(size_t)(q0 + jq + 1) * SA_C2 + lane];
             if (CP) {
                 const unsigned long long rows_q = __ballot(lane < 32 && live_row && ri_q(raw.info) == (unsigned)jq);
                 kc += __builtin_ctzll(rows_q);

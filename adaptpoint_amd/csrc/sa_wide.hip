@@ -605,12 +605,18 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
                     }
                     // R_S[c][:] += goa[q][c] a1[row of (q, ksel[q][c])][:], lane = c: the pooled row of a1 comes from
                     // this wave's LDS tile (written above; LDS executes a wave's instructions in order)
+                    float gv_nx = gb[lane];                      // (one query ahead: no round trip per query)
+                    int ks_nx = (int)kb[lane];
 #pragma unroll 1
                     for (int jq = 0; jq < nq; ++jq) {
                         const unsigned long long mine_q = __ballot(lane < 32 && live && ri_q(cur.info) == (unsigned)jq);
                         const int row0 = __builtin_ctzll(mine_q);                    // first row of query jq in the tile
-                        const float gv = gb[(unsigned)(jq * O) + lane];
-                        const int kr = row0 + (int)kb[(unsigned)(jq * O) + lane];
+                        const float gv = gv_nx;
+                        const int kr = row0 + ks_nx;
+                        if (jq + 1 < nq) {
+                            gv_nx = gb[(unsigned)((jq + 1) * O) + lane];
+                            ks_nx = (int)kb[(unsigned)((jq + 1) * O) + lane];
+                        }
                         const float4 *__restrict__ ar = reinterpret_cast<const float4 *>(a1s + kr * A1LD);
 #pragma unroll
                         for (int m4 = 0; m4 < H / 4; ++m4) {
