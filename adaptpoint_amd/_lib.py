@@ -33,6 +33,7 @@ SIGNATURES = {
     "apn_sa_grid_blocks": [_c_int] * 2,
     "apn_sa_grid_rows": [_c_int] * 3,
     "apn_sa_bwd_main_rows": [_c_int] * 2,
+    "apn_sa_bwd_acc_copies": [],
     "apn_sa_prep_features": [_c_int] * 3 + [_c_void_p] * 2 + [_c_int, _c_void_p],
     "apn_sa_fwd_stats1": [_c_int] * 8 + [_c_float] + [_c_void_p] * 8,
     "apn_sa_reduce_rows": [_c_void_p, _c_int, _c_int, _c_double, _c_void_p, _c_void_p],
@@ -47,7 +48,7 @@ SIGNATURES = {
                        + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 7,
     "apn_sa_bwd_consts2": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_double, _c_int] + [_c_void_p] * 8,
     "apn_sa_bwd_main": [_c_int] * 8 + [_c_float] + [_c_void_p] * 20,
-    "apn_sa_bwd_consts1": [_c_void_p, _c_int] + [_c_void_p] * 2 + [_c_double, _c_int] + [_c_void_p] * 8,
+    "apn_sa_bwd_consts1": [_c_void_p, _c_int] + [_c_void_p] * 2 + [_c_double, _c_int] + [_c_void_p] * 9,
     "apn_sa_bwd_weight_rows": [_c_int] * 2,
     "apn_sa_bwd_point_grads": [_c_int] * 3 + [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 4 + [_c_float]
                               + [_c_void_p] * 5,
@@ -60,7 +61,7 @@ SIGNATURES = {
     "apn_sa_backward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 15 + [_c_int] * 3
                             + [_c_double] + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p]
                             + [ctypes.c_size_t]
-                            + [_c_void_p] * 29),
+                            + [_c_void_p] * 30),
     "apn_attention_prep": [_c_int] * 3 + [_c_void_p] * 4 + [_c_int, _c_void_p],
     "apn_attention_fwd": [_c_int] * 3 + [_c_void_p] * 4,
     "apn_attention_bwd": [_c_int] * 3 + [_c_void_p] * 9,

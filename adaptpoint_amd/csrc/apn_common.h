@@ -54,6 +54,10 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// copies of the register-resident backward pass's dL/dW2 accumulators (sa_fused.hip: sa_bwd_kernel's tail;
+// cleared by bwd_consts2, added up by bwd_consts1 in sa_glue.hip)
+constexpr int SA_ACC_COPIES = 8;
+
 __device__ __forceinline__ int lane_id() {
     return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }

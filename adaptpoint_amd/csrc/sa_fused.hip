@@ -802,7 +802,9 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     write_partials<2>(st, part, lane, wave);
     // The workgroup's three ingredients of dL/dW2: fold the four waves in LDS, then one float atomic
     // per element into the zeroed accumulators: gw2_acc (64,32) sparse part; gram_acc[0..1023]
-    // Gram[mid'][mid], gram_acc[1024..1055] suma[mid].
+    // Gram[mid'][mid], gram_acc[1024..1055] suma[mid] -- SA_ACC_COPIES copies of each, workgroup b adds into copy
+    // b % SA_ACC_COPIES (448 workgroups on ONE set of 3104 addresses cost the pass 9 us of same-address atomics;
+    // bwd_consts1 adds the copies up).
     float (*wred)[SA_C2 * SA_C1] = reinterpret_cast<float (*)[SA_C2 * SA_C1]>(sp_raw);   // images are dead
     __syncthreads();
 #pragma unroll
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         float sum = 0.0f;
 #pragma unroll
         for (int w = 0; w < SA_WAVES; ++w) sum += wred[w][e];
-        atomicAdd(gw2_acc + e, sum);
+        atomicAdd(gw2_acc + (blockIdx.x % SA_ACC_COPIES) * (SA_C2 * SA_C1) + e, sum);
     }
     __syncthreads();
     suma += __shfl_xor(suma, 32);
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         float sum = 0.0f;
 #pragma unroll
         for (int w = 0; w < SA_WAVES; ++w) sum += wred[w][e];
-        atomicAdd(gram_acc + e, sum);
+        atomicAdd(gram_acc + (blockIdx.x % SA_ACC_COPIES) * (SA_C1 * SA_C1 + SA_C1) + e, sum);
     }
 }
 
@@ -854,6 +856,7 @@ static int sa_grid_bwd(int tiles) {
 extern "C" int apn_sa_grid_blocks(int b, int m) { return apn::sa_grid(b * m); }
 extern "C" int apn_sa_grid_rows(int b, int m, int with_tile_map) { return apn::sa_grid(b * m, with_tile_map != 0); }
 extern "C" int apn_sa_bwd_main_rows(int b, int m) { return apn::sa_grid_bwd(b * m); }
+extern "C" int apn_sa_bwd_acc_copies(void) { return apn::SA_ACC_COPIES; }
 
 // ft holds `precision` tables of (B,N,32) bf16 back to back: [hi] or [hi][lo].
 extern "C" int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, int precision,

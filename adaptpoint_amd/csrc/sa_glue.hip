@@ -389,14 +389,12 @@ __global__ __launch_bounds__(1024) void bwd_consts2_kernel(const float *__restri
     __shared__ double D[64], E[64], S[128];
     __shared__ float sw2[64][33];
     const int t = threadIdx.x;
-    if (zero_w2) {   // dL/dW2 (64x32) is accumulated atomically by the backward pass, the next launch
-        zero_w2[t] = 0.0f;
-        zero_w2[1024 + t] = 0.0f;
-    }
-    if (zero_gram) {   // Gram (32x32) + suma (32), same launch
-        zero_gram[t] = 0.0f;
-        if (t < 32) zero_gram[1024 + t] = 0.0f;
-    }
+    // dL/dW2's sparse part (64x32) and Gram (32x32) + suma (32) are accumulated atomically by the backward pass,
+    // the next launch, into SA_ACC_COPIES copies each (see sa_bwd_kernel's tail): cleared here
+    if (zero_w2)
+        for (int e = t; e < SA_ACC_COPIES * 2048; e += 1024) zero_w2[e] = 0.0f;
+    if (zero_gram)
+        for (int e = t; e < SA_ACC_COPIES * 1056; e += 1024) zero_gram[e] = 0.0f;
     // operands requested before the row sums: their latency hides behind them
     const float wa = w2[t], wb = w2[1024 + t];
     float p_sc = 0.0f, p_mu = 0.0f, p_iv = 0.0f;
@@ -442,17 +440,36 @@ __global__ __launch_bounds__(256) void bwd_consts1_kernel(
     const float *__restrict__ partT, int rows, const double *__restrict__ T_in,
     const float *__restrict__ pack1, double count, int training, float *__restrict__ cabc,
     float *__restrict__ g_gamma1, float *__restrict__ g_beta1, const float *__restrict__ w2,
-    const float *__restrict__ d2e2, const float *__restrict__ gram, float *__restrict__ g_w2) {
+    const float *__restrict__ d2e2, const float *__restrict__ gram, const float *__restrict__ gw2_acc,
+    float *__restrict__ g_w2) {
     // grid: 8 workgroups, workgroup b owns mid channels 4b..4b+3 (columns 4b.. and 32+4b..)
     __shared__ double red[256][4];
+    __shared__ float gsum[1056];
     if (g_w2) {
-        // dL/dW2[c][mid] = sparse part (already in g_w2) + D2[c] (W2 Gram)[c][mid] + E2[c] suma[mid]
-        // (sa_fused.hip); 8 x 256 threads = the 64 x 32 elements
+        // dL/dW2[c][mid] = sparse part + D2[c] (W2 Gram)[c][mid] + E2[c] suma[mid] (sa_fused.hip); the backward
+        // pass left SA_ACC_COPIES partial copies of the sparse part and of {Gram, suma}: added up here in a fixed
+        // order.  8 x 256 threads = the 64 x 32 elements
+        for (int e = threadIdx.x; e < 1056; e += 256) {
+            float v[SA_ACC_COPIES];
+#pragma unroll
+            for (int k = 0; k < SA_ACC_COPIES; ++k) v[k] = gram[k * 1056 + e];
+            float sgm = 0.0f;
+#pragma unroll
+            for (int k = 0; k < SA_ACC_COPIES; ++k) sgm += v[k];
+            gsum[e] = sgm;
+        }
         const int e = blockIdx.x * 256 + threadIdx.x, c = e >> 5, mid = e & 31;
+        float sp[SA_ACC_COPIES];
+#pragma unroll
+        for (int k = 0; k < SA_ACC_COPIES; ++k) sp[k] = gw2_acc[k * 2048 + e];
+        double sparse = 0.0;
+#pragma unroll
+        for (int k = 0; k < SA_ACC_COPIES; ++k) sparse += (double)sp[k];
+        __syncthreads();
         double acc = 0.0;
 #pragma unroll 8
-        for (int k = 0; k < 32; ++k) acc += (double)w2[c * 32 + k] * (double)gram[k * 32 + mid];
-        g_w2[e] = (float)((double)g_w2[e] + (double)d2e2[c] * acc + (double)d2e2[64 + c] * (double)gram[1024 + mid]);
+        for (int k = 0; k < 32; ++k) acc += (double)w2[c * 32 + k] * (double)gsum[k * 32 + mid];
+        g_w2[e] = (float)(sparse + (double)d2e2[c] * acc + (double)d2e2[64 + c] * (double)gsum[1024 + mid]);
     }
     const int t = threadIdx.x, i = blockIdx.x * 4 + t;
     const float sc32 = t < 4 ? pack1[i] : 0.0f;      // requested before the row sums
@@ -771,12 +788,12 @@ extern "C" int apn_sa_bwd_consts2(const float *partS, int rows, const double *S,
 extern "C" int apn_sa_bwd_consts1(const float *partT, int rows, const double *T, const float *pack1,
                                   double count, int training, float *cabc, float *g_gamma1,
                                   float *g_beta1, const float *w2, const float *d2e2,
-                                  const float *gram, float *g_w2, void *stream) {
+                                  const float *gram, const float *gw2_acc, float *g_w2, void *stream) {
     if ((!partT && !T) || !pack1 || !cabc) return APN_EINVAL;
-    if (g_w2 && (!w2 || !d2e2 || !gram)) return APN_EINVAL;
+    if (g_w2 && (!w2 || !d2e2 || !gram || !gw2_acc)) return APN_EINVAL;
     if (partT && ((uintptr_t)partT & 15)) return APN_EINVAL;
     hipLaunchKernelGGL(apn::bwd_consts1_kernel, dim3(8), dim3(256), 0, APN_ST, partT, rows, T, pack1,
-                       count, training, cabc, g_gamma1, g_beta1, w2, d2e2, gram, g_w2);
+                       count, training, cabc, g_gamma1, g_beta1, w2, d2e2, gram, gw2_acc, g_w2);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

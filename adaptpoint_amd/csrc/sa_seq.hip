@@ -61,8 +61,9 @@ extern "C" int apn_sa_backward_seq(
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
     // zero-filled here unless zero_bytes == 0 (then apn_sa_fwd_out cleared them): A (B*N*32) | geo (B*N*4) |
-    // gip (B*N*32, only with ws) by one memset (phase 1); g_w2 (64*32) and gram (32*32 + 32) by the consts2 launch (phase 2)
-    float *zero_base, size_t zero_bytes, float *g_w2, float *gram, float *A, float *geo, float *gip,
+    // gip (B*N*32, only with ws) by one memset (phase 1); the accumulators gw2_acc (copies x 64*32) and gram (copies x (32*32 + 32)), copies =
+    // apn_sa_bwd_acc_copies(), by the consts2 launch (phase 2); g_w2 (64*32) is written by consts1
+    float *zero_base, size_t zero_bytes, float *g_w2, float *gw2_acc, float *gram, float *A, float *geo, float *gip,
     // scratch
     float *goa, float *partS, float *partWs, float *partT, float *partW, const double *sumsS,
     const double *sumsT, float *d2e2, float *qm, float *evec, float *cabc, float *HA, float *HB,
@@ -81,14 +82,14 @@ extern "C" int apn_sa_backward_seq(
     }
     if (phases & 2) {
         APN_TRY(apn_sa_bwd_consts2(sumsS ? nullptr : partS, prow, sumsS, pack2, w2, count, train2,
-                                   d2e2, qm, evec, g_g2, g_b2, g_w2, gram, stream));
+                                   d2e2, qm, evec, g_g2, g_b2, gw2_acc, gram, stream));
         APN_TRY(apn_sa_bwd_main(b, n, m, 32, 32, 64, 32, precision, radius, xyz, new_xyz, ft, idx, tmap, w1,
-                                w2, pack1, qm, evec, goa, ksel, partT, g_w2, gram, A, geo, HA, HB,
+                                w2, pack1, qm, evec, goa, ksel, partT, gw2_acc, gram, A, geo, HA, HB,
                                 stream));
     }
     if (phases & 4) {
         APN_TRY(apn_sa_bwd_consts1(sumsT ? nullptr : partT, rows_t, sumsT, pack1, count, train1, cabc,
-                                   g_g1, g_b1, w2, d2e2, gram, g_w2, stream));
+                                   g_g1, g_b1, w2, d2e2, gram, gw2_acc, g_w2, stream));
         APN_TRY(apn_sa_bwd_point_grads(b, n, m, A, geo, HA, HB, cabc, pack1, ft, precision, xyz,
                                        new_xyz, w1, gip, radius, partW, g_f, g_p, g_newp, stream));
         APN_TRY(apn_sa_bwd_finalize(partW, apn_sa_bwd_weight_rows(b, n), radius, g_w1, partWs, prow,

@@ -259,6 +259,7 @@ def _backward(fw, g_out, need_p, need_newp):
     rows = lib.apn_sa_bwd_main_rows(B, M)
     prow = lib.apn_sa_bwd_prep_rows(B, M)
     wrows = lib.apn_sa_bwd_weight_rows(B, N)
+    ncopy = lib.apn_sa_bwd_acc_copies()           # copies of the dL/dW2 accumulators (spread same-address atomics)
 
     # scratch: the zero-filled (atomically accumulated) region first, contiguous -- unless the forward's last
     # launch already allocated and cleared it (fw.zbuf)
@@ -267,7 +268,8 @@ def _backward(fw, g_out, need_p, need_newp):
     sizes = zsizes + [("goa", B * M * C_OUT), ("partS", prow * 128),
                       ("partWs", prow * C_OUT * C_IN if has_skip else 0), ("partT", rows * 64),
                       ("partW", wrows * 32 * 38), ("d2e2", 2 * C_OUT), ("qm", C_MID * C_MID),
-                      ("evec", C_MID), ("cabc", 3 * C_MID), ("gram", C_MID * C_MID + C_MID), ("HA", B * M * C_MID),
+                      ("evec", C_MID), ("cabc", 3 * C_MID), ("gram", ncopy * (C_MID * C_MID + C_MID)),
+                      ("gw2c", ncopy * C_OUT * C_MID), ("HA", B * M * C_MID),
                       ("HB", B * M * C_MID)]
     v, buf = _carve(dev, sizes)
     zero_floats = sum((nfl + 63) // 64 * 64 for _, nfl in zsizes)
@@ -278,7 +280,7 @@ def _backward(fw, g_out, need_p, need_newp):
     gsz = [("w2", C_OUT * C_MID), ("w1", C_MID * (C_IN + 3)), ("g1", C_MID), ("b1", C_MID),
            ("g2", C_OUT), ("b2", C_OUT), ("ws", C_OUT * C_IN if has_skip else 0),
            ("bs", C_OUT if (has_skip and sv["has_bs"]) else 0)]
-    g, _gbuf = _carve(dev, gsz)           # every view is fully written (w2: cleared by consts2)
+    g, _gbuf = _carve(dev, gsz)           # every view is fully written
     g_f = torch.empty(B, C_IN, N, **f32)
     g_p = torch.zeros(B, N, 3, **f32) if need_p else None
     g_newp = torch.empty(B, M, 3, **f32) if need_newp else None
@@ -293,7 +295,7 @@ def _backward(fw, g_out, need_p, need_newp):
              sv["pack2"].data_ptr(), sv["ysel"].data_ptr(), sv["ksel"].data_ptr(),
              fw.out.data_ptr(), fw.relu, 1 if fw.train1 else 0, 1 if fw.train2 else 0, float(P),
              g_out.data_ptr(), gs[0], gs[1], gs[2], buf.data_ptr(), zero_floats * 4,
-             g["w2"].data_ptr(), v["gram"].data_ptr(),
+             g["w2"].data_ptr(), v["gw2c"].data_ptr(), v["gram"].data_ptr(),
              v["A"].data_ptr(), v["geo"].data_ptr(), v["gip"].data_ptr() if has_skip else None,
              v["goa"].data_ptr(),
              v["partS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None,
@@ -366,16 +368,16 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
         call("apn_sa_bwd_consts2", None if sumsS is not None else v["partS"].data_ptr(), prow,
              _ptr(sumsS), sv["pack2"].data_ptr(), w2.data_ptr(), P, 1 if fw.train2 else 0,
              v["d2e2"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr(), g["g2"].data_ptr(),
-             g["b2"].data_ptr(), g["w2"].data_ptr(), v["gram"].data_ptr())
+             g["b2"].data_ptr(), v["gw2c"].data_ptr(), v["gram"].data_ptr())
         call("apn_sa_bwd_main", *hdr, v["goa"].data_ptr(),
-             sv["ksel"].data_ptr(), v["partT"].data_ptr(), g["w2"].data_ptr(), v["gram"].data_ptr(),
+             sv["ksel"].data_ptr(), v["partT"].data_ptr(), v["gw2c"].data_ptr(), v["gram"].data_ptr(),
              v["A"].data_ptr(),
              v["geo"].data_ptr(), v["HA"].data_ptr(), v["HB"].data_ptr())
     if phases & 4:
         call("apn_sa_bwd_consts1", None if sumsT is not None else v["partT"].data_ptr(), rows,
              _ptr(sumsT), sv["pack1"].data_ptr(), P, 1 if fw.train1 else 0, v["cabc"].data_ptr(),
              g["g1"].data_ptr(), g["b1"].data_ptr(), w2.data_ptr(), v["d2e2"].data_ptr(),
-             v["gram"].data_ptr(), g["w2"].data_ptr())
+             v["gram"].data_ptr(), v["gw2c"].data_ptr(), g["w2"].data_ptr())
         call("apn_sa_bwd_point_grads", B, N, M, v["A"].data_ptr(), v["geo"].data_ptr(),
              v["HA"].data_ptr(), v["HB"].data_ptr(), v["cabc"].data_ptr(), sv["pack1"].data_ptr(),
              sv["ft"].data_ptr(), fw.prec, sv["p"].data_ptr(), sv["new_p"].data_ptr(), w1.data_ptr(),

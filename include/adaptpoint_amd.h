@@ -148,6 +148,10 @@ APN_API int apn_ball_query_zero(int b, int n, int m, float radius, int nsample,
 APN_API int apn_sa_grid_blocks(int b, int m);
 /* ... and with a tile map (apn_sa_wide_tilemap) behind the two forward passes: their partial rows then */
 APN_API int apn_sa_grid_rows(int b, int m, int with_tile_map);
+/* copies of the backward pass's dL/dW2 accumulators: gw2_acc is copies x 64*32 floats, gram_acc copies x
+ * (32*32 + 32); workgroup b adds into copy b % copies (same-address float atomics of 448 workgroups on one set
+ * cost the pass 9 us), apn_sa_bwd_consts2 clears them, apn_sa_bwd_consts1 adds them up into g_w2 */
+APN_API int apn_sa_bwd_acc_copies(void);
 /* rows of the backward pass's partial sums (partT) */
 APN_API int apn_sa_bwd_main_rows(int b, int m);
 
@@ -246,7 +250,7 @@ APN_API int apn_sa_bwd_main(int b, int n, int m, int c_in, int c_mid, int c_out,
 APN_API int apn_sa_bwd_consts1(const float *partT, int rows, const double *T, const float *pack1,
                                double count, int training, float *cabc, float *g_gamma1,
                                float *g_beta1, const float *w2, const float *d2e2,
-                               const float *gram, float *g_w2, void *stream);
+                               const float *gram, const float *gw2_acc, float *g_w2, void *stream);
 
 /* dL/dy1 = g_u*ca + yhat1*cb + cc summed per source point (G) and per query (H), formed from
  * A, geo, HA, HB and the batch constants, and everything linear in them, one workgroup per
@@ -290,7 +294,7 @@ APN_API int apn_sa_backward_seq(
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
-    float *zero_base, size_t zero_bytes, float *g_w2, float *gram, float *A, float *geo, float *gip,
+    float *zero_base, size_t zero_bytes, float *g_w2, float *gw2_acc, float *gram, float *A, float *geo, float *gip,
     float *goa, float *partS, float *partWs, float *partT, float *partW, const double *sumsS,
     const double *sumsT, float *d2e2, float *qm, float *evec, float *cabc, float *HA, float *HB,
     float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_g1, float *g_b1, float *g_g2,
