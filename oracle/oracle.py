@@ -252,3 +252,74 @@ def attention_grad(q, k, v, heads, grad_out):
     dk = ds.transpose(0, 1, 3, 2) @ qh
     back = lambda t: t.transpose(0, 2, 1, 3).reshape(B, M, C)
     return back(dq), back(dk), back(dv)
+
+
+# ------------------------------------------------------------------------------------------
+# Index-stage structures of the fused passes (include/adaptpoint_amd.h: apn_sa_wide_tilemap,
+# apn_sa_wide_csr).  They have no counterpart in the reference: these are plain-Python
+# statements of their DEFINITION (written independently of the kernels: a serial next-fit
+# loop, a dictionary of lists), against which the GPU builders are compared bit for bit.
+# ------------------------------------------------------------------------------------------
+def tile_map(idx, fold=True):
+    """idx (B,M,32) int32 -> dict(nt, tq0 (nt,), rowinfo (nt,32) uint32, rownn (nt,32) int32).
+    A query's rows: with the ball-query structure (slots 1..c-1 differ from slot 0, slots c..31 repeat it)
+    its c leading slots, slot 0 with multiplicity 33 - c; otherwise all 32 slots with multiplicity 1.
+    Whole queries are packed in order into 32-row tiles (next fit), a cloud's tiles first to last;
+    rowinfo = qlocal | slot << 8 | mult << 16 (| queries of the tile << 24 in row 0); padding rows:
+    rowinfo 0xff, rownn = slot 0 of the tile's LAST query."""
+    idx = np.asarray(idx)
+    B, M, K = idx.shape
+    assert K == 32
+    tq0, info, nn = [], [], []
+    for b in range(B):
+        rows_i, rows_n, first_q, nq = [], [], None, 0
+
+        def close(last_q):
+            pad = 32 - len(rows_i)
+            ri = rows_i + [0xff] * pad
+            ri[0] |= nq << 24
+            info.append(ri)
+            nn.append(rows_n + [int(idx[b, last_q, 0])] * pad)
+            tq0.append(b * M + first_q)
+        for q in range(M):
+            row = idx[b, q]
+            c = 32
+            if fold:
+                differ = row != row[0]
+                c0 = int(differ.sum()) + 1
+                if differ[1:c0].all() and not differ[c0:].any():
+                    c = c0
+            if first_q is not None and len(rows_i) + c > 32:
+                close(q - 1)
+                rows_i, rows_n, first_q, nq = [], [], None, 0
+            if first_q is None:
+                first_q = q
+            ql = q - first_q
+            for s in range(c):
+                mult = (33 - c) if s == 0 else 1
+                rows_i.append(ql | (s << 8) | (mult << 16))
+                rows_n.append(int(row[s]))
+            nq += 1
+        close(M - 1)
+    return dict(nt=len(tq0), tq0=np.array(tq0, np.int32), rowinfo=np.array(info, np.uint32),
+                rownn=np.array(nn, np.int32))
+
+
+def inverse_map(tm, new_xyz, n_points, m):
+    """Tile map `tm` (of `tile_map`), new_xyz (B,M,3) -> dict(pcnt (B*N,), lists: per point the ascending row ids
+    tile * 32 + row of the rows that gather it, occ (B*N,) = sum of their multiplicities, sp (B*N,3) float64 =
+    sum of multiplicity * the gathering query's coordinates)."""
+    new_xyz = np.asarray(new_xyz, np.float64).reshape(-1, 3)
+    lists, occ, sp = {}, {}, {}
+    for t in range(tm["nt"]):
+        for r in range(32):
+            info = int(tm["rowinfo"][t, r])
+            mult = (info >> 16) & 0xff
+            if mult == 0:
+                continue
+            q = int(tm["tq0"][t]) + (info & 0xff)
+            gn = (q // m) * n_points + int(tm["rownn"][t, r])
+            lists.setdefault(gn, []).append(t * 32 + r)
+            occ[gn] = occ.get(gn, 0) + mult
+            sp[gn] = sp.get(gn, 0.0) + mult * new_xyz[q]
+    return dict(lists=lists, occ=occ, sp=sp)

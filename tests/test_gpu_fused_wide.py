@@ -112,6 +112,57 @@ def test_wide_backward_matches_autograd(dev, cin, N, M, radius, neg_gamma):
         assert v <= 1e-4, (k, v)
 
 
+@pytest.mark.parametrize("kind,B,N,M,radius", [("ball", 3, 1024, 512, 0.15), ("ball", 2, 300, 97, 0.3),
+                                               ("dense", 2, 128, 64, 0.6), ("random", 2, 256, 130, 0.0),
+                                               ("nofold", 2, 512, 256, 0.2)])
+def test_tile_map_and_inverse_map_equal_the_oracle_statement(dev, kind, B, N, M, radius):
+    """The index-stage structures are integer work: the GPU builders (parallel next-fit packer, counting sort +
+    per-list sort) must reproduce the serial Python statement of their definition (oracle.tile_map /
+    inverse_map) bit for bit -- tile count, first queries, row records, row neighbours, per-point counts and
+    ascending lists; geo (float sums) to rounding."""
+    from adaptpoint_amd.fused_wide import neighbour_index
+    from adaptpoint_amd.layers import ball_query, furthest_point_sample
+    from oracle import oracle as O
+    p = torch.from_numpy(GI.unit_sphere_cloud(B, N, seed=21)).to(dev)
+    fidx = furthest_point_sample(p, M)
+    new_p = torch.gather(p, 1, fidx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    if kind == "random":
+        idx = torch.randint(0, N, (B, M, 32), device=dev, dtype=torch.int32, generator=torch.Generator(dev).manual_seed(3))
+        idx[:, ::3, 5:] = idx[:, ::3, :1]            # some rows with the fill structure, some with repeats that are not
+        idx[:, 1::7, 1:] = idx[:, 1::7, :1]          # and single-hit rows
+    else:
+        idx = ball_query(radius, 32, p, new_p)
+    fold = kind != "nofold"
+    nbr = neighbour_index(idx, new_p, N, fold=fold, fidx=fidx)
+    want = O.tile_map(idx.cpu().numpy(), fold=fold)
+    t = nbr.tmap.cpu().numpy()
+    bm = B * M
+    nt = int(t[0])
+    assert nt == want["nt"]
+    assert np.array_equal(t[4:4 + nt], want["tq0"])
+    off = 4 + ((bm + 3) & ~3)
+    assert np.array_equal(t[off:off + 32 * nt].view(np.uint32).reshape(nt, 32), want["rowinfo"])
+    assert np.array_equal(t[off + 32 * bm:off + 32 * bm + 32 * nt].reshape(nt, 32), want["rownn"])
+    inv = O.inverse_map(want, new_p.cpu().numpy(), N, M)
+    pcnt = nbr.pcnt_poff[:B * N].cpu().numpy()
+    poff = nbr.pcnt_poff[B * N:].cpu().numpy()
+    plist = nbr.plist.cpu().numpy()
+    geo = nbr.geo.cpu().numpy().reshape(B * N, 4)
+    for gn in range(B * N):
+        rows = inv["lists"].get(gn, [])
+        assert pcnt[gn] == len(rows)
+        assert plist[poff[gn]:poff[gn] + pcnt[gn]].tolist() == rows, gn
+        assert geo[gn, 0] == inv["occ"].get(gn, 0)
+        np.testing.assert_allclose(geo[gn, 1:], inv["sp"].get(gn, np.zeros(3)), rtol=1e-5, atol=1e-5)
+    fq = nbr.fq.cpu().numpy().reshape(B, N)
+    ref_fq = -np.ones((B, N), np.int32)
+    for b in range(B):
+        ref_fq[b, fidx[b].cpu().numpy()] = np.arange(M)
+    assert np.array_equal(fq, ref_fq)
+    if kind == "dense":
+        assert max(len(v) for v in inv["lists"].values()) > 16       # the wave-wide sort of long lists ran
+
+
 @pytest.mark.parametrize("cin,N,M,radius", STAGES[:2])
 def test_wide_block_with_residual_branch(dev, cin, N, M, radius):
     """The whole block on the width-generic kernels, residual branch and final ReLU fused (pointnext.py:150-168):
