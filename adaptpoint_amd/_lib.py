@@ -95,6 +95,15 @@ SIGNATURES = {
     "apn_sa_wide_point_grads": [_c_int] * 5 + [_c_float] + [_c_void_p] * 13 + [_c_int] + [_c_void_p] * 9,
     "apn_sa_wide_colsum_f32": [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
     "apn_sa_wide_wgrad": [_c_int] * 5 + [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 2,
+    "apn_pw_conv_tiles": [_c_int] * 2,
+    "apn_pw_conv_forward": [_c_int] * 5 + [_c_void_p] * 5,
+    "apn_pw_bn_act": [_c_int] * 3 + [_c_void_p] * 2 + [_c_int] + [_c_void_p] * 2 + [_c_float] * 2 + [_c_int] * 2
+                     + [_c_void_p] * 6,
+    "apn_pw_bn_act_grad_splits": [_c_int] * 2,
+    "apn_pw_bn_act_grad": [_c_int] * 3 + [_c_void_p] * 3 + [_c_int] * 2 + [_c_void_p] * 5,
+    "apn_pw_conv_grad_input": [_c_int] * 5 + [_c_void_p] * 4,
+    "apn_pw_conv_grad_weight_splits": [_c_int] * 4,
+    "apn_pw_conv_grad_weight": [_c_int] * 5 + [_c_void_p] * 5,
     "apn_sa_sample_overlap": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 7,
     "apn_sa_sample_seq": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 6,
 }

@@ -1,0 +1,590 @@
+// pointwise.hip -- the imitator's per-point MLP layer, Conv1d(k = 1, no bias) + BatchNorm1d (+ ReLU)
+// (`ConvBNReLU1D`, openpoints/models_adaptpoint/generator_component4_15.py:92-104; the embedding, the four
+// `extract_feat_list` layers and the `fuse` layer of the four feature-propagation decoders, :330-366, 588-657),
+// forward and backward, on channels-first (B, C, N) float32 tensors as torch.nn.Conv1d takes them.
+//
+// One MFMA contraction kernel serves the three products of a layer,
+//     y_b  (O x N) = W   (O x C) x_b  (C x N)          forward
+//     gx_b (C x N) = W^T (C x O) gy_b (O x N)          gradient w.r.t. the input
+//     gW   (O x C) = sum_b gy_b (O x N) x_b^T (N x C)   gradient w.r.t. the weight (split over (b, position) ranges,
+//                                                       the shares added in a fixed order: reproducible)
+// by describing each operand as "k-contiguous" (element (i, k) at i * ld + k) or "row-contiguous" (k * ld + i):
+// the float32 operands are read exactly as they lie in HBM (no transposed copies, no NHWC detour), split into
+// bf16 hi + lo on the way into LDS (three MFMAs per product, apn_mfma.h: the contraction agrees with an fp32 one to
+// ~1e-5), and every one of the 128 x 128 workgroup tile's fragment reads is a conflict-free 16-byte LDS read.
+// BatchNorm's batch statistics are column sums of the forward product and leave the contraction's epilogue as one
+// partial row per workgroup; the normalise + ReLU pass folds them itself.  The backward pass forms
+// gy = dL/dy once (two passes over (g, y): the sums BatchNorm's gradient needs, then the apply) and both
+// gradient contractions read it.
+#include <hip/hip_runtime.h>
+
+#include "../../include/adaptpoint_amd.h"
+#include "apn_mfma.h"
+
+namespace apn {
+
+constexpr int PW_T = 128;     // workgroup tile: 128 x 128 outputs, four waves of 64 x 64
+constexpr int PW_KC = 32;     // contraction indices per chunk (two MFMA k-steps)
+constexpr int PW_ROW = 40;    // bf16 per LDS row: 32 + 8 pad (80-byte rows: 16 lanes' 16-byte reads cover all banks)
+
+struct PwOperand {
+    const float *p;
+    long long batch;          // elements between consecutive batch entries (0: shared)
+    int ld;
+};
+
+struct PwGemm {
+    PwOperand A, B;           // A (R x K), B (K x Q)
+    float *D;                 // D (R x Q) per grid.z slice
+    long long d_batch;
+    int ldd;
+    int R, Q, K;
+    int cpb;                  // chunks per batch entry = ceil(K / 32)
+    int cps;                  // chunks per grid.z slice
+    int total;                // chunks in all
+    int a_vec, b_vec;         // k-contiguous operand readable as float4
+    float *part;              // optional [(z * gridDim.x + x)][2][R]: row sums and sums of squares of this tile
+};
+
+// Loader roles of the 256 threads for one 128 x 32 operand chunk (16 values per thread), chosen so that every
+// wave-instruction reads whole 128-byte lines:
+//   k-contiguous operand (element (i, k) at i * ld + k): 8 lanes x float4 cover the 32 k of a row, a wave-instruction
+//     covers 8 rows; thread (seg = t & 7, rg = t >> 3) holds k = 4 seg .. 4 seg + 3 of rows rg, 32 + rg, 64 + rg, 96 + rg
+//     (16 k per thread of ONE row -- two threads per row -- measured 3x slower: 32 lines per instruction, 16 bytes each);
+//   row-contiguous operand (k * ld + i): the lane runs along i (64 consecutive floats per instruction), thread
+//     (i = t & 127, half = t >> 7) holds k = 16 half .. 16 half + 15 of row i.
+// Addresses are clamped into the operand (every load legal and unpredicated); staging zeroes what lies outside.
+template <bool KCONT>
+struct PwLoader {
+    int i0, kofs;            // KCONT: rg, 4 seg; else: i, 16 half
+    unsigned rows;           // bit j: row j of this thread lies inside the operand
+
+    __device__ __forceinline__ void init(int t, int origin, int lim) {
+        if (KCONT) {
+            i0 = t >> 3; kofs = 4 * (t & 7);
+            rows = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rows |= (origin + 32 * j + i0 < lim ? 1u : 0u) << j;
+        } else {
+            i0 = t & 127; kofs = 16 * (t >> 7);
+            rows = origin + i0 < lim ? 1u : 0u;
+        }
+    }
+    // -> the number of leading k of this thread's values that lie inside the operand
+    __device__ __forceinline__ int load(const PwOperand &op, const float *__restrict__ base, int origin, int lim,
+                                        int k0, int K, int vec, float (&v)[16]) const {
+        const int kk = k0 + kofs, left = K - kk;
+        if (KCONT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = origin + 32 * j + i0;
+                const float *src = base + (size_t)(i < lim ? i : lim - 1) * op.ld;
+                if (vec) {
+                    const float4 q = *reinterpret_cast<const float4 *>(src + (kk < K - 4 ? kk : K - 4));
+                    v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * j + e] = src[kk + e < K ? kk + e : K - 1];
+                }
+            }
+            return left < 0 ? 0 : (left > 4 ? 4 : left);
+        } else {
+            const int i = origin + i0;
+            const float *src = base + (i < lim ? i : lim - 1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(kk + j < K ? kk + j : K - 1) * op.ld];
+            return left < 0 ? 0 : (left > 16 ? 16 : left);
+        }
+    }
+    // NS bf16 planes of every value (hi, the rounded remainder, (NS = 3) the remainder of that: 16 or 24 significant
+    // bits) into the LDS tile [plane][row][k]
+    template <int NS>
+    __device__ __forceinline__ void stage(__bf16 *tile, const float (&v)[16], int nk) const {
+        if (KCONT) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x4 pl[NS];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float f = (((rows >> j) & 1u) && e < nk) ? v[4 * j + e] : 0.0f;
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) {
+                        const __bf16 x = (__bf16)f;
+                        pl[p][e] = x;
+                        f -= (float)x;
+                    }
+                }
+                __bf16 *dst = tile + (32 * j + i0) * PW_ROW + kofs;
+#pragma unroll
+                for (int p = 0; p < NS; ++p) *reinterpret_cast<bf16x4 *>(dst + p * PW_T * PW_ROW) = pl[p];
+            }
+        } else {
+            bf16x8 pl[NS][2];
+            const int n = rows ? nk : 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float f = j < n ? v[j] : 0.0f;
+#pragma unroll
+                for (int p = 0; p < NS; ++p) {
+                    const __bf16 x = (__bf16)f;
+                    pl[p][j >> 3][j & 7] = x;
+                    f -= (float)x;
+                }
+            }
+            __bf16 *dst = tile + i0 * PW_ROW + kofs;
+#pragma unroll
+            for (int p = 0; p < NS; ++p) {
+                *reinterpret_cast<bf16x8 *>(dst + p * PW_T * PW_ROW) = pl[p][0];
+                *reinterpret_cast<bf16x8 *>(dst + p * PW_T * PW_ROW + 8) = pl[p][1];
+            }
+        }
+    }
+};
+
+// sums over the 32 lanes of a half-wave of 32 values per lane by recursive halving (31 exchanges instead of 160):
+// afterwards lane r holds the total of value r in v[0]
+template <int M>
+__device__ __forceinline__ void pw_halve_step(float (&v)[32], int r) {
+    const bool up = (r & M) != 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const float keep = up ? v[j + M] : v[j];
+        const float send = up ? v[j] : v[j + M];
+        v[j] = keep + __shfl_xor(send, M);
+    }
+}
+
+__device__ __forceinline__ void pw_halving(float (&v)[32], int r) {
+    pw_halve_step<16>(v, r);
+    pw_halve_step<8>(v, r);
+    pw_halve_step<4>(v, r);
+    pw_halve_step<2>(v, r);
+    pw_halve_step<1>(v, r);
+}
+
+// NS = 2: products as hi*hi + hi*lo + lo*hi (three MFMAs, ~4e-6 of an fp32 contraction: the operands keep 16 bits);
+// NS = 3: six MFMAs over three planes, every term down to 2^-24 of the product -- fp32-class results.
+template <bool A_KC, bool B_KC, int NS>
+__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwGemm g) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[NS * PW_T * PW_ROW];   // [plane][row][k]
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[NS * PW_T * PW_ROW];
+    __shared__ float red[2][2][PW_T];
+    const int t = threadIdx.x, lane = t & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), wr = wave >> 1, wq = wave & 1;
+    const int R0 = blockIdx.y * PW_T, Q0 = blockIdx.x * PW_T, z = blockIdx.z;
+    PwLoader<A_KC> la;
+    PwLoader<B_KC> lb;
+    la.init(t, R0, g.R);
+    lb.init(t, Q0, g.Q);
+    int c0 = z * g.cps, c1 = c0 + g.cps;
+    if (c1 > g.total) c1 = g.total;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
+
+    // Two chunks of operands in flight in registers beside the one in LDS: a chunk's loads are issued two compute
+    // phases before its values are needed (one phase ahead left every wave waiting on memory at the staging step).
+    float va0[16], vb0[16], va1[16], vb1[16];
+    int ka0 = 0, kb0 = 0, ka1 = 0, kb1 = 0;
+    auto fetch = [&](int c, float (&xa)[16], float (&xb)[16], int &ka, int &kb) {
+        const int bz = c / g.cpb, k0 = (c - bz * g.cpb) * PW_KC;
+        ka = la.load(g.A, g.A.p + g.A.batch * bz, R0, g.R, k0, g.K, g.a_vec, xa);
+        kb = lb.load(g.B, g.B.p + g.B.batch * bz, Q0, g.Q, k0, g.K, g.b_vec, xb);
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[2][NS], b[2][NS];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const __bf16 *pa = As + (wr * 64 + j * 32 + r) * PW_ROW + s * 16 + h * 8;
+                const __bf16 *pb = Bs + (wq * 64 + j * 32 + r) * PW_ROW + s * 16 + h * 8;
+#pragma unroll
+                for (int p = 0; p < NS; ++p) {
+                    a[j][p] = *reinterpret_cast<const bf16x8 *>(pa + p * PW_T * PW_ROW);
+                    b[j][p] = *reinterpret_cast<const bf16x8 *>(pb + p * PW_T * PW_ROW);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 d = acc[i][j];                      // small terms first
+                    if (NS == 3) {
+                        d = mfma(a[i][1], b[j][1], d);
+                        d = mfma(a[i][0], b[j][NS - 1], d);
+                        d = mfma(a[i][NS - 1], b[j][0], d);
+                    }
+                    d = mfma(a[i][0], b[j][1], d);
+                    d = mfma(a[i][1], b[j][0], d);
+                    acc[i][j] = mfma(a[i][0], b[j][0], d);
+                }
+            }
+        }
+    };
+    // LDS holds chunk c, (xa, xb) chunk c + 1; (fa, fb) are free and take chunk c + 2
+    auto step = [&](int c, float (&fa)[16], float (&fb)[16], int &fka, int &fkb, float (&xa)[16], float (&xb)[16],
+                    int xka, int xkb) {
+        if (c + 2 < c1) fetch(c + 2, fa, fb, fka, fkb);
+        compute();
+        __syncthreads();
+        if (c + 1 < c1) {
+            la.template stage<NS>(As, xa, xka);
+            lb.template stage<NS>(Bs, xb, xkb);
+        }
+        __syncthreads();
+    };
+    if (c0 < c1) {
+        fetch(c0, va0, vb0, ka0, kb0);
+        if (c0 + 1 < c1) fetch(c0 + 1, va1, vb1, ka1, kb1);
+        la.template stage<NS>(As, va0, ka0);
+        lb.template stage<NS>(Bs, vb0, kb0);
+    }
+    __syncthreads();
+    for (int c = c0; c < c1; c += 2) {
+        step(c, va0, vb0, ka0, kb0, va1, vb1, ka1, kb1);
+        if (c + 1 < c1) step(c + 1, va1, vb1, ka1, kb1, va0, vb0, ka0, kb0);
+    }
+
+    // D: lane = column, register i <-> row acc_row(i, h): 32 consecutive columns per store
+    float *D = g.D + g.d_batch * z;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = R0 + wr * 64 + i * 32 + acc_row(e, h);
+            if (row < g.R) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = Q0 + wq * 64 + j * 32 + r;
+                    if (q < g.Q) D[(size_t)row * g.ldd + q] = acc[i][j][e];
+                }
+            }
+        }
+    }
+    if (g.part) {
+        // row sums over this tile's columns (columns past Q hold zeros): value 16 i + e of a lane <-> row
+        // 32 i + acc_row(e, h) of the wave; after the halving lane r holds row 32 (r >> 4) + acc_row(r & 15, h)
+        float s1[32], s2[32];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float u = acc[i][0][e], w = acc[i][1][e];
+                s1[16 * i + e] = u + w;
+                s2[16 * i + e] = u * u + w * w;
+            }
+        }
+        pw_halving(s1, r);
+        pw_halving(s2, r);
+        const int row = wr * 64 + (r >> 4) * 32 + acc_row(r & 15, h);
+        red[wq][0][row] = s1[0];
+        red[wq][1][row] = s2[0];
+        __syncthreads();
+        if (t < PW_T && R0 + t < g.R) {
+            float *dst = g.part + ((size_t)z * gridDim.x + blockIdx.x) * 2 * g.R + R0 + t;
+            dst[0] = red[0][0][t] + red[1][0][t];
+            dst[g.R] = red[0][1][t] + red[1][1][t];
+        }
+    }
+}
+
+// sum of one double per thread over the workgroup, returned to every thread
+__device__ __forceinline__ double pw_block_sum(double v, double *scratch) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+template <typename F>
+__device__ __forceinline__ void pw_for_rows(int B, int N, int C, int ch, F fn) {
+    for (int b = blockIdx.y; b < B; b += gridDim.y) fn(((size_t)b * C + ch) * N);
+}
+
+// BatchNorm (batch statistics folded here from the contraction's partial rows, or the running ones) + ReLU.
+// grid (C, S): workgroup (c, s) serves channel c of the clouds b = s mod S; stat [4][C] = {mean, invstd, scale, shift}.
+__global__ __launch_bounds__(256) void pw_bn_act_kernel(int B, int C, int N, const float *__restrict__ y,
+                                                        const float *__restrict__ part, int tiles,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        float eps, float momentum, int training, int relu,
+                                                        float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                        long long *__restrict__ batches, float *__restrict__ stat,
+                                                        float *__restrict__ out) {
+    __shared__ double scratch[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    float mean, inv;
+    if (training) {
+        double a = 0.0, q = 0.0;
+        for (int i = t; i < tiles; i += 256) {
+            a += (double)part[(size_t)i * 2 * C + c];
+            q += (double)part[(size_t)i * 2 * C + C + c];
+        }
+        a = pw_block_sum(a, scratch);
+        q = pw_block_sum(q, scratch);
+        const double cnt = (double)B * N, mu = a / cnt;
+        double var = q / cnt - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean = (float)mu;
+        inv = (float)(1.0 / sqrt(var + (double)eps));
+        if (blockIdx.y == 0 && t == 0) {
+            if (run_mean) {
+                run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
+                run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)(var * (cnt > 1.0 ? cnt / (cnt - 1.0) : 1.0));
+            }
+            if (batches && c == 0) batches[0] += 1;
+        }
+    } else {
+        mean = run_mean[c];
+        inv = 1.0f / sqrtf(run_var[c] + eps);
+    }
+    const float sc = (gamma ? gamma[c] : 1.0f) * inv, sh = (beta ? beta[c] : 0.0f) - mean * sc;
+    if (blockIdx.y == 0 && t == 0) {
+        stat[c] = mean;
+        stat[C + c] = inv;
+        stat[2 * C + c] = sc;
+        stat[3 * C + c] = sh;
+    }
+    const bool vec = (N & 3) == 0;
+    pw_for_rows(B, N, C, c, [&](size_t off) {
+        if (vec) {
+            const float4 *src = reinterpret_cast<const float4 *>(y + off);
+            float4 *dst = reinterpret_cast<float4 *>(out + off);
+            for (int i = t; i < N / 4; i += 256) {
+                float4 v = src[i];
+                v.x = __builtin_fmaf(v.x, sc, sh); v.y = __builtin_fmaf(v.y, sc, sh);
+                v.z = __builtin_fmaf(v.z, sc, sh); v.w = __builtin_fmaf(v.w, sc, sh);
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                dst[i] = v;
+            }
+        } else {
+            for (int i = t; i < N; i += 256) {
+                const float v = __builtin_fmaf(y[off + i], sc, sh);
+                out[off + i] = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    });
+}
+
+// pass 1 of the backward: partb[s][2][C] = {sum g m, sum g m yhat} over workgroup (c, s)'s clouds, m = the ReLU mask
+__global__ __launch_bounds__(256) void pw_bwd_sums_kernel(int B, int C, int N, const float *__restrict__ g,
+                                                          const float *__restrict__ y, const float *__restrict__ stat,
+                                                          int relu, float *__restrict__ partb) {
+    __shared__ double scratch[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const float mean = stat[c], inv = stat[C + c], sc = stat[2 * C + c], sh = stat[3 * C + c];
+    float s1 = 0.0f, s2 = 0.0f;
+    double d1 = 0.0, d2 = 0.0;
+    pw_for_rows(B, N, C, c, [&](size_t off) {
+        for (int i = t; i < N; i += 256) {
+            const float yv = y[off + i];
+            const float gm = (!relu || __builtin_fmaf(yv, sc, sh) > 0.0f) ? g[off + i] : 0.0f;
+            s1 += gm;
+            s2 = __builtin_fmaf(gm, (yv - mean) * inv, s2);
+        }
+        d1 += (double)s1; d2 += (double)s2;     // one cloud's share at a time into the wide accumulator
+        s1 = 0.0f; s2 = 0.0f;
+    });
+    d1 = pw_block_sum(d1, scratch);
+    d2 = pw_block_sum(d2, scratch);
+    if (t == 0) {
+        partb[(size_t)blockIdx.y * 2 * C + c] = (float)d1;
+        partb[(size_t)blockIdx.y * 2 * C + C + c] = (float)d2;
+    }
+}
+
+// pass 2: gy = scale (g m - mean(g m) - yhat mean(g m yhat)) (training) or scale g m (running statistics);
+// dL/dgamma = sum g m yhat, dL/dbeta = sum g m
+__global__ __launch_bounds__(256) void pw_bwd_apply_kernel(int B, int C, int N, const float *__restrict__ g,
+                                                           const float *__restrict__ y, const float *__restrict__ stat,
+                                                           int relu, int training, const float *__restrict__ partb,
+                                                           int splits, float *__restrict__ gy,
+                                                           float *__restrict__ g_gamma, float *__restrict__ g_beta) {
+    const int c = blockIdx.x, t = threadIdx.x;
+    const float mean = stat[c], inv = stat[C + c], sc = stat[2 * C + c], sh = stat[3 * C + c];
+    double d1 = 0.0, d2 = 0.0;
+    for (int s = 0; s < splits; ++s) {          // every thread the same fixed order
+        d1 += (double)partb[(size_t)s * 2 * C + c];
+        d2 += (double)partb[(size_t)s * 2 * C + C + c];
+    }
+    if (blockIdx.y == 0 && t == 0) {
+        if (g_gamma) g_gamma[c] = (float)d2;
+        if (g_beta) g_beta[c] = (float)d1;
+    }
+    // gy = sc gm + k0 + k1 y
+    float k0 = 0.0f, k1 = 0.0f;
+    if (training) {
+        const double cnt = (double)B * N;
+        const double m1 = d1 / cnt, m2 = d2 / cnt;
+        k1 = (float)(-(double)sc * (double)inv * m2);
+        k0 = (float)(-(double)sc * m1 + (double)sc * (double)inv * m2 * (double)mean);
+    }
+    const bool vec = (N & 3) == 0;
+    pw_for_rows(B, N, C, c, [&](size_t off) {
+        if (vec) {
+            const float4 *gs = reinterpret_cast<const float4 *>(g + off), *ys = reinterpret_cast<const float4 *>(y + off);
+            float4 *dst = reinterpret_cast<float4 *>(gy + off);
+            for (int i = t; i < N / 4; i += 256) {
+                const float4 gv = gs[i], yv = ys[i];
+                float4 o;
+                o.x = __builtin_fmaf((!relu || __builtin_fmaf(yv.x, sc, sh) > 0.0f) ? gv.x : 0.0f, sc, __builtin_fmaf(k1, yv.x, k0));
+                o.y = __builtin_fmaf((!relu || __builtin_fmaf(yv.y, sc, sh) > 0.0f) ? gv.y : 0.0f, sc, __builtin_fmaf(k1, yv.y, k0));
+                o.z = __builtin_fmaf((!relu || __builtin_fmaf(yv.z, sc, sh) > 0.0f) ? gv.z : 0.0f, sc, __builtin_fmaf(k1, yv.z, k0));
+                o.w = __builtin_fmaf((!relu || __builtin_fmaf(yv.w, sc, sh) > 0.0f) ? gv.w : 0.0f, sc, __builtin_fmaf(k1, yv.w, k0));
+                dst[i] = o;
+            }
+        } else {
+            for (int i = t; i < N; i += 256) {
+                const float yv = y[off + i];
+                const float gm = (!relu || __builtin_fmaf(yv, sc, sh) > 0.0f) ? g[off + i] : 0.0f;
+                gy[off + i] = __builtin_fmaf(gm, sc, __builtin_fmaf(k1, yv, k0));
+            }
+        }
+    });
+}
+
+// out[e] = sum_s part[s][e] in a fixed order: 64 elements x 4 interleaved split lanes per workgroup
+__global__ __launch_bounds__(256) void pw_fold_kernel(const float *__restrict__ part, int splits, size_t n,
+                                                      float *__restrict__ out) {
+    __shared__ double red[4][64];
+    const size_t e = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int q = threadIdx.x >> 6;
+    double s = 0.0;
+    if (e < n)
+        for (int k = q; k < splits; k += 4) s += (double)part[(size_t)k * n + e];
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && e < n) out[e] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+static int pw_channel_splits(int b, int c) {
+    // (c, s) workgroups: enough of them to fill the chip, never more than clouds
+    int s = (2048 + c - 1) / c;
+    if (s > b) s = b;
+    return s < 1 ? 1 : s;
+}
+
+static int pw_weight_splits(int b, int c_in, int c_out, int n) {
+    const long long tiles = (long long)((c_out + PW_T - 1) / PW_T) * ((c_in + PW_T - 1) / PW_T);
+    const long long total = (long long)b * ((n + PW_KC - 1) / PW_KC);
+    // tiles * s workgroups, two of which a CU holds at a time: never just over a multiple of 512
+    long long s = 512 / tiles;
+    if (s > total / 8) s = total / 8;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+static bool pw_vec(const float *p, long long batch, int ld, int K) {
+    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (batch % 4 == 0) && (ld % 4 == 0) && (K % 4 == 0);
+}
+
+}  // namespace apn
+
+extern "C" int apn_pw_conv_tiles(int b, int n) { return b * ((n + apn::PW_T - 1) / apn::PW_T); }
+
+#define PW_LAUNCH(AK, BK, grid, g)                                                                         \
+    do {                                                                                                   \
+        if (precision == 3)                                                                                \
+            hipLaunchKernelGGL((pw_gemm_kernel<AK, BK, 3>), grid, dim3(256), 0, (hipStream_t)stream, g);   \
+        else                                                                                               \
+            hipLaunchKernelGGL((pw_gemm_kernel<AK, BK, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);   \
+    } while (0)
+
+extern "C" int apn_pw_conv_forward(int b, int c_in, int c_out, int n, int precision, const float *x, const float *w,
+                                   float *y, float *part, void *stream) {
+    using namespace apn;
+    if (b < 0 || c_in <= 0 || c_out <= 0 || n < 0 || b > 65535 || (precision != 2 && precision != 3)) return APN_EINVAL;
+    if (b == 0 || n == 0) return APN_OK;
+    if (!x || !w || !y) return APN_EINVAL;
+    PwGemm g{};
+    g.A = PwOperand{w, 0, c_in};
+    g.B = PwOperand{x, (long long)c_in * n, n};
+    g.D = y; g.d_batch = (long long)c_out * n; g.ldd = n;
+    g.R = c_out; g.Q = n; g.K = c_in;
+    g.cpb = (c_in + PW_KC - 1) / PW_KC; g.cps = g.cpb; g.total = b * g.cpb;
+    g.a_vec = pw_vec(w, 0, c_in, c_in); g.b_vec = 0;
+    g.part = part;
+    PW_LAUNCH(true, false, dim3((n + PW_T - 1) / PW_T, (c_out + PW_T - 1) / PW_T, b), g);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_pw_bn_act(int b, int c, int n, const float *y, const float *part, int tiles, const float *gamma,
+                             const float *beta, float eps, float momentum, int training, int relu, float *run_mean,
+                             float *run_var, long long *batches, float *stat, float *out, void *stream) {
+    using namespace apn;
+    if (b < 0 || c <= 0 || n < 0) return APN_EINVAL;
+    if (b == 0 || n == 0) return APN_OK;
+    if (!y || !stat || !out || (training && (!part || tiles <= 0)) || (!training && (!run_mean || !run_var)))
+        return APN_EINVAL;
+    hipLaunchKernelGGL(pw_bn_act_kernel, dim3(c, pw_channel_splits(b, c)), dim3(256), 0, (hipStream_t)stream, b, c, n,
+                       y, part, tiles, gamma, beta, eps, momentum, training, relu, run_mean, run_var, batches, stat, out);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_pw_bn_act_grad_splits(int b, int c) { return apn::pw_channel_splits(b, c); }
+
+extern "C" int apn_pw_bn_act_grad(int b, int c, int n, const float *g, const float *y, const float *stat, int training,
+                                  int relu, float *part_b, float *gy, float *g_gamma, float *g_beta, void *stream) {
+    using namespace apn;
+    if (b < 0 || c <= 0 || n < 0) return APN_EINVAL;
+    if (b == 0 || n == 0) return APN_OK;
+    if (!g || !y || !stat || !part_b || !gy) return APN_EINVAL;
+    const int s = pw_channel_splits(b, c);
+    hipLaunchKernelGGL(pw_bwd_sums_kernel, dim3(c, s), dim3(256), 0, (hipStream_t)stream, b, c, n, g, y, stat, relu,
+                       part_b);
+    APN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pw_bwd_apply_kernel, dim3(c, s), dim3(256), 0, (hipStream_t)stream, b, c, n, g, y, stat, relu,
+                       training, part_b, s, gy, g_gamma, g_beta);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_pw_conv_grad_input(int b, int c_in, int c_out, int n, int precision, const float *gy, const float *w,
+                                      float *gx, void *stream) {
+    using namespace apn;
+    if (b < 0 || c_in <= 0 || c_out <= 0 || n < 0 || b > 65535 || (precision != 2 && precision != 3)) return APN_EINVAL;
+    if (b == 0 || n == 0) return APN_OK;
+    if (!gy || !w || !gx) return APN_EINVAL;
+    PwGemm g{};
+    g.A = PwOperand{w, 0, c_in};                      // W^T: element (c, k = o) at w[k * c_in + c]
+    g.B = PwOperand{gy, (long long)c_out * n, n};
+    g.D = gx; g.d_batch = (long long)c_in * n; g.ldd = n;
+    g.R = c_in; g.Q = n; g.K = c_out;
+    g.cpb = (c_out + PW_KC - 1) / PW_KC; g.cps = g.cpb; g.total = b * g.cpb;
+    PW_LAUNCH(false, false, dim3((n + PW_T - 1) / PW_T, (c_in + PW_T - 1) / PW_T, b), g);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_pw_conv_grad_weight_splits(int b, int c_in, int c_out, int n) {
+    return apn::pw_weight_splits(b, c_in, c_out, n);
+}
+
+extern "C" int apn_pw_conv_grad_weight(int b, int c_in, int c_out, int n, int precision, const float *gy,
+                                       const float *x, float *scratch, float *gw, void *stream) {
+    using namespace apn;
+    if (b <= 0 || c_in <= 0 || c_out <= 0 || n <= 0 || !gy || !x || !scratch || !gw || (precision != 2 && precision != 3))
+        return APN_EINVAL;
+    const int s = pw_weight_splits(b, c_in, c_out, n);
+    PwGemm g{};
+    g.A = PwOperand{gy, (long long)c_out * n, n};     // (o, k = position)
+    g.B = PwOperand{x, (long long)c_in * n, n};       // (k = position, c) at x[c * n + k]
+    g.D = scratch; g.d_batch = (long long)c_out * c_in; g.ldd = c_in;
+    g.R = c_out; g.Q = c_in; g.K = n;
+    g.cpb = (n + PW_KC - 1) / PW_KC; g.total = b * g.cpb; g.cps = (g.total + s - 1) / s;
+    g.a_vec = pw_vec(gy, g.A.batch, n, n); g.b_vec = pw_vec(x, g.B.batch, n, n);
+    PW_LAUNCH(true, true, dim3((c_in + PW_T - 1) / PW_T, (c_out + PW_T - 1) / PW_T, s), g);
+    APN_LAUNCH_CHECK();
+    const size_t ne = (size_t)c_out * c_in;
+    hipLaunchKernelGGL(pw_fold_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(256), 0, (hipStream_t)stream, scratch, s,
+                       ne, gw);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .attention import AnchorSelfAttention
+from . import pointwise
 from .layers import three_interpolation
 from .pointset import PointsetGrouper
 
@@ -35,17 +36,21 @@ def knn_point(nsample, xyz, new_xyz):
 
 
 class ConvBNReLU1D(nn.Module):
-    """(:92-104)"""
+    """(:92-104).  `fused`: the layer on csrc/pointwise.hip (adaptpoint_amd.pointwise) where its shape and mode
+    are served -- kernel 1, no bias, float32 on the GPU -- and as the reference's three modules otherwise."""
 
-    def __init__(self, in_channels, out_channels, kernel_size=1, bias=True, activation='relu'):
+    def __init__(self, in_channels, out_channels, kernel_size=1, bias=True, activation='relu', fused=True):
         super().__init__()
         if activation.lower() != 'relu':
             raise NotImplementedError("only the ReLU activation is instantiated by the imitator")
         self.act = nn.ReLU(inplace=True)
         self.net = nn.Sequential(nn.Conv1d(in_channels, out_channels, kernel_size, bias=bias),
                                  nn.BatchNorm1d(out_channels), self.act)
+        self.fused = fused
 
     def forward(self, x):
+        if self.fused and pointwise.supported(x, self.net[0], self.net[1]):
+            return pointwise.conv_bn_act(x, self.net[0], self.net[1], relu=True)
         return self.net(x)
 
 
@@ -53,9 +58,9 @@ class PointNetFeaturePropagation(nn.Module):
     """(:330-366)"""
 
     def __init__(self, in_channel, out_channel, blocks=1, groups=1, res_expansion=1.0, bias=False,
-                 activation='relu'):
+                 activation='relu', fused=True):
         super().__init__()
-        self.fuse = ConvBNReLU1D(in_channel, out_channel, 1, bias=bias)
+        self.fuse = ConvBNReLU1D(in_channel, out_channel, 1, bias=bias, fused=fused)
 
     def forward(self, xyz1, xyz2, points1, points2):
         interpolated = three_interpolation(xyz1, xyz2, points2)
@@ -93,14 +98,15 @@ class SAComponent(nn.Module):
                  k_neighbors=(24, 24, 24, 24), reducers=(2, 2, 2, 2), fused=True, **kwargs):
         super().__init__()
         self.stages = len(dim_expansion)
-        self.embedding = ConvBNReLU1D(in_channel, embed_dim, bias=bias, activation=activation)
+        self.embedding = ConvBNReLU1D(in_channel, embed_dim, bias=bias, activation=activation, fused=fused)
         self.extract_feat_list = nn.ModuleList()
         self.pointset_grouper_list = nn.ModuleList()
         last = embed_dim
         channels = [embed_dim]
         for i in range(self.stages):
             out = last * dim_expansion[i]
-            self.extract_feat_list.append(ConvBNReLU1D(last, out, kernel_size=1, bias=bias, activation=activation))
+            self.extract_feat_list.append(ConvBNReLU1D(last, out, kernel_size=1, bias=bias, activation=activation,
+                                                       fused=fused))
             self.pointset_grouper_list.append(PointsetGrouper(channel=out, reduce=reducers[i],
                                                               kneighbors=k_neighbors[i], radi=radii[i],
                                                               normalize=normalize, fused=fused))
@@ -110,7 +116,7 @@ class SAComponent(nn.Module):
         self.decode_list = nn.ModuleList(
             PointNetFeaturePropagation(channels[-(i + 1)] + channels[-(i + 2)], channels[-(i + 2)],
                                        blocks=1, groups=1, res_expansion=res_expansion, bias=bias,
-                                       activation=activation) for i in range(self.stages))
+                                       activation=activation, fused=fused) for i in range(self.stages))
         self.localfeat_mask_selfattention = AnchorSelfAttention(dim=embed_dim, head_num=4, fused=fused)
         self.extract_local_feat_masking = nn.Sequential(nn.Conv1d(embed_dim, 3, 1, bias=False), nn.BatchNorm1d(3))
         self.extract_global_feat_masking = nn.Sequential(nn.Conv1d(last, 3, 1, bias=False), nn.BatchNorm1d(3))

@@ -1,0 +1,100 @@
+"""The imitator's per-point MLP layer on the gfx950 kernels of csrc/pointwise.hip.
+
+`ConvBNReLU1D` (openpoints/models_adaptpoint/generator_component4_15.py:92-104) is
+Conv1d(kernel 1) + BatchNorm1d + ReLU on channels-first (B, C, N) tensors; the reference runs it as
+three cuDNN / elementwise calls forward and five or more backward.  Here a layer is
+
+    forward   y = W x            one MFMA contraction (bf16 hi+lo operands, f32 accumulate) whose epilogue
+                                  leaves BatchNorm's batch statistics as partial rows,
+              out = relu(bn(y))   one pass that folds those rows (float64) and updates the running statistics;
+    backward  gy = dL/dy          two passes over (g, y) (BatchNorm's two sums, then the apply),
+              gx = W^T gy         the same contraction kernel, W read transposed in place,
+              gW = sum gy x^T     the same kernel with both operands position-contiguous, split over
+                                  (cloud, position) ranges whose shares are added in a fixed order
+
+-- 2 launches forward, 5 backward, bit-reproducible gradients, no transposed copies.  `conv_bn_act` takes the
+torch modules (their parameters and buffers are used and updated in place), so `state_dict`s stay the
+reference's.
+"""
+import torch
+
+from . import _lib
+from .fused import _call
+
+# bf16 planes per operand of the contractions: 3 = six MFMAs per product, fp32-class (~2e-7: what a stack of ~40
+# training-mode BatchNorm layers over few points needs to stay within a few 1e-3 of the reference's gradients);
+# 2 = three MFMAs, ~4e-6 per contraction, as the fused set-abstraction kernels use
+PRECISION = 3
+
+
+def supported(x, conv, bn):
+    """Shapes / modes the kernels serve: float32 CUDA, contiguous (B, C, N), kernel 1, no bias, a BatchNorm1d with a
+    numeric momentum (the cumulative-average mode of momentum=None stays on PyTorch)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[0] <= 65535
+            and x.shape[0] > 0 and x.shape[2] > 0
+            and conv.kernel_size == (1,) and conv.stride == (1,) and conv.padding == (0,) and conv.groups == 1
+            and conv.dilation == (1,) and conv.bias is None and conv.weight.dtype == torch.float32
+            and (bn.momentum is not None or not bn.training)
+            and (bn.training or bn.track_running_stats))
+
+
+class _ConvBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bn, relu):
+        dev = x.device
+        x = x.contiguous()
+        B, C, N = x.shape
+        O = weight.shape[0]
+        w = weight.detach().reshape(O, C).contiguous()
+        training = bn.training or not bn.track_running_stats
+        lib = _lib.load()
+        y = torch.empty(B, O, N, device=dev)
+        tiles = lib.apn_pw_conv_tiles(B, N)
+        part = torch.empty(tiles, 2, O, device=dev) if training else None
+        _call("apn_pw_conv_forward", dev, B, C, O, N, PRECISION, x.data_ptr(), w.data_ptr(), y.data_ptr(),
+              part.data_ptr() if training else None)
+        out = torch.empty_like(y)
+        stat = torch.empty(4, O, device=dev)
+        track = bn.track_running_stats and bn.running_mean is not None
+        _call("apn_pw_bn_act", dev, B, O, N, y.data_ptr(), part.data_ptr() if training else None, tiles,
+              gamma.data_ptr() if gamma is not None else None, beta.data_ptr() if beta is not None else None,
+              float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.0), int(training), int(relu),
+              bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+              bn.num_batches_tracked.data_ptr() if (track and training and bn.num_batches_tracked is not None) else None,
+              stat.data_ptr(), out.data_ptr())
+        ctx.save_for_backward(x, w, y, stat)
+        ctx.cfg = (training, relu, gamma is not None, beta is not None, weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y, stat = ctx.saved_tensors
+        training, relu, has_gamma, has_beta, wshape = ctx.cfg
+        dev = x.device
+        B, C, N = x.shape
+        O = w.shape[0]
+        lib = _lib.load()
+        g = g.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        part_b = torch.empty(lib.apn_pw_bn_act_grad_splits(B, O), 2, O, device=dev)
+        gy = torch.empty_like(y)
+        ggb = torch.empty(2, O, device=dev)
+        _call("apn_pw_bn_act_grad", dev, B, O, N, g.data_ptr(), y.data_ptr(), stat.data_ptr(), int(training), int(relu),
+              part_b.data_ptr(), gy.data_ptr(), ggb[0].data_ptr(), ggb[1].data_ptr())
+        gx = gw = None
+        if need_x:
+            gx = torch.empty_like(x)
+            _call("apn_pw_conv_grad_input", dev, B, C, O, N, PRECISION, gy.data_ptr(), w.data_ptr(), gx.data_ptr())
+        if need_w:
+            splits = lib.apn_pw_conv_grad_weight_splits(B, C, O, N)
+            scratch = torch.empty(splits, O, C, device=dev)
+            gw = torch.empty(O, C, device=dev)
+            _call("apn_pw_conv_grad_weight", dev, B, C, O, N, PRECISION, gy.data_ptr(), x.data_ptr(), scratch.data_ptr(),
+                  gw.data_ptr())
+            gw = gw.view(wshape)
+        return gx, gw, (ggb[0] if has_gamma else None), (ggb[1] if has_beta else None), None, None
+
+
+def conv_bn_act(x, conv, bn, relu=True):
+    """relu(bn(conv(x))) for a kernel-1 bias-free `conv` (nn.Conv1d) and `bn` (nn.BatchNorm1d) on x (B, C, N)."""
+    return _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, bn, relu)

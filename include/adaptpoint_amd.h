@@ -486,6 +486,40 @@ APN_API int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid, fl
 APN_API int apn_sa_wide_point_grads_cols(int c_in, int c_mid, int c_skip);
 APN_API int apn_sa_wide_colsum_f32(const float *part, int rows, int ncol, float *out, void *stream);
 
+/* ------------------------------------------------------------------------
+ * the imitator's per-point MLP layer `ConvBNReLU1D` =
+ * Conv1d(kernel 1, no bias) + BatchNorm1d (+ ReLU)
+ * (openpoints/models_adaptpoint/generator_component4_15.py:92-104; instantiated as the embedding, the four
+ * extract_feat_list layers :588-657 and the `fuse` layer of PointNetFeaturePropagation :330-366), which the
+ * reference runs as cuDNN convolution / batch-norm calls.  Tensors are channels-first contiguous float32 as
+ * torch.nn.Conv1d takes them: x (B,c_in,N), w (c_out,c_in), y / out / g / gy (B,c_out,N).  Any sizes.
+ * precision = 2: operands split into two bf16 planes (three MFMAs per product, ~4e-6 of an fp32 contraction);
+ *   3: three planes, six MFMAs, fp32-class (~2e-7).  f32 accumulation either way.
+ * conv_forward: y = w x per cloud; part (may be NULL)
+ *   [apn_pw_conv_tiles(b, n)][2][c_out] = each 128-position tile's {sum, sum of squares} of y per channel.
+ * bn_act: out = [relu](gamma (y - mean) invstd + beta); training: batch statistics folded (float64) from `part`
+ *   (tiles rows), running_mean / running_var updated with `momentum` (unbiased variance) and batches[0] += 1
+ *   (each may be NULL); otherwise the running statistics are used.  stat [4][c] = {mean, invstd, scale, shift}.
+ * bn_act_grad: gy = dL/dy from g = dL/dout (BatchNorm's batch-statistics gradient when training), g_gamma,
+ *   g_beta [c] (may be NULL); part_b = scratch [apn_pw_bn_act_grad_splits(b, c)][2][c].  Two launches.
+ * conv_grad_input: gx (B,c_in,N) = w^T gy.   conv_grad_weight: gw (c_out,c_in) = sum_b gy_b x_b^T, split over
+ *   apn_pw_conv_grad_weight_splits(...) ranges of (cloud, position) whose shares (scratch [splits][c_out][c_in])
+ *   are added in a fixed order: bit-reproducible. */
+APN_API int apn_pw_conv_tiles(int b, int n);
+APN_API int apn_pw_conv_forward(int b, int c_in, int c_out, int n, int precision, const float *x, const float *w,
+                                float *y, float *part, void *stream);
+APN_API int apn_pw_bn_act(int b, int c, int n, const float *y, const float *part, int tiles, const float *gamma,
+                          const float *beta, float eps, float momentum, int training, int relu, float *run_mean,
+                          float *run_var, long long *batches, float *stat, float *out, void *stream);
+APN_API int apn_pw_bn_act_grad_splits(int b, int c);
+APN_API int apn_pw_bn_act_grad(int b, int c, int n, const float *g, const float *y, const float *stat, int training,
+                               int relu, float *part_b, float *gy, float *g_gamma, float *g_beta, void *stream);
+APN_API int apn_pw_conv_grad_input(int b, int c_in, int c_out, int n, int precision, const float *gy, const float *w,
+                                   float *gx, void *stream);
+APN_API int apn_pw_conv_grad_weight_splits(int b, int c_in, int c_out, int n);
+APN_API int apn_pw_conv_grad_weight(int b, int c_in, int c_out, int n, int precision, const float *gy, const float *x,
+                                    float *scratch, float *gw, void *stream);
+
 /* Tuning / diagnostic entry, NOT part of the reference boundary: apn_furthest_point_sampling
  * with the number of wavefronts that cooperate on one cloud (1, 2, 4, 8 or 16; 0 = the built-in
  * heuristic) and the step algorithm (0 = default: one LDS 64-bit atomic max per step for
