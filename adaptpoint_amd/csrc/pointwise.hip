@@ -23,7 +23,7 @@
 
 namespace apn {
 
-constexpr int PW_T = 128;     // workgroup tile: 128 x 128 outputs, four waves of 64 x 64
+constexpr int PW_T = 128;     // workgroup tile: 128 x 128 outputs, eight waves of 64 x 32
 constexpr int PW_KC = 32;     // contraction indices per chunk (two MFMA k-steps)
 constexpr int PW_ROW = 40;    // bf16 per LDS row: 32 + 8 pad (80-byte rows: 16 lanes' 16-byte reads cover all banks)
 
@@ -46,38 +46,36 @@ struct PwGemm {
     float *part;              // optional [(z * gridDim.x + x)][2][R]: row sums and sums of squares of this tile
 };
 
-// Loader roles of the 256 threads for one 128 x 32 operand chunk (16 values per thread), chosen so that every
+// Loader roles of the 512 threads for one 128 x 32 operand chunk (8 values per thread), chosen so that every
 // wave-instruction reads whole 128-byte lines:
 //   k-contiguous operand (element (i, k) at i * ld + k): 8 lanes x float4 cover the 32 k of a row, a wave-instruction
-//     covers 8 rows; thread (seg = t & 7, rg = t >> 3) holds k = 4 seg .. 4 seg + 3 of rows rg, 32 + rg, 64 + rg, 96 + rg
-//     (16 k per thread of ONE row -- two threads per row -- measured 3x slower: 32 lines per instruction, 16 bytes each);
+//     covers 8 rows; thread (seg = t & 7, rg = t >> 3) holds k = 4 seg .. 4 seg + 3 of rows rg and 64 + rg
+//     (a first version gave a thread 16 k of ONE row, 32 lines of 16 bytes per instruction: 3x slower end to end);
 //   row-contiguous operand (k * ld + i): the lane runs along i (64 consecutive floats per instruction), thread
-//     (i = t & 127, half = t >> 7) holds k = 16 half .. 16 half + 15 of row i.
+//     (i = t & 127, q = t >> 7) holds k = 8 q .. 8 q + 7 of row i.
 // Addresses are clamped into the operand (every load legal and unpredicated); staging zeroes what lies outside.
 template <bool KCONT>
 struct PwLoader {
-    int i0, kofs;            // KCONT: rg, 4 seg; else: i, 16 half
+    int i0, kofs;            // KCONT: rg, 4 seg; else: i, 8 q
     unsigned rows;           // bit j: row j of this thread lies inside the operand
 
     __device__ __forceinline__ void init(int t, int origin, int lim) {
         if (KCONT) {
             i0 = t >> 3; kofs = 4 * (t & 7);
-            rows = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rows |= (origin + 32 * j + i0 < lim ? 1u : 0u) << j;
+            rows = (origin + i0 < lim ? 1u : 0u) | (origin + 64 + i0 < lim ? 2u : 0u);
         } else {
-            i0 = t & 127; kofs = 16 * (t >> 7);
+            i0 = t & 127; kofs = 8 * (t >> 7);
             rows = origin + i0 < lim ? 1u : 0u;
         }
     }
     // -> the number of leading k of this thread's values that lie inside the operand
     __device__ __forceinline__ int load(const PwOperand &op, const float *__restrict__ base, int origin, int lim,
-                                        int k0, int K, int vec, float (&v)[16]) const {
+                                        int k0, int K, int vec, float (&v)[8]) const {
         const int kk = k0 + kofs, left = K - kk;
         if (KCONT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = origin + 32 * j + i0;
+            for (int j = 0; j < 2; ++j) {
+                const int i = origin + 64 * j + i0;
                 const float *src = base + (size_t)(i < lim ? i : lim - 1) * op.ld;
                 if (vec) {
                     const float4 q = *reinterpret_cast<const float4 *>(src + (kk < K - 4 ? kk : K - 4));
@@ -92,18 +90,18 @@ struct PwLoader {
             const int i = origin + i0;
             const float *src = base + (i < lim ? i : lim - 1);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(kk + j < K ? kk + j : K - 1) * op.ld];
-            return left < 0 ? 0 : (left > 16 ? 16 : left);
+            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(kk + j < K ? kk + j : K - 1) * op.ld];
+            return left < 0 ? 0 : (left > 8 ? 8 : left);
         }
     }
     // NS bf16 planes of every value (hi, the rounded remainder, (NS = 3) the remainder of that: 16 or 24 significant
     // bits) into the LDS tile [plane][row][k]
     template <int NS>
-    __device__ __forceinline__ void stage(__bf16 *tile, const float (&v)[16], int nk) const {
+    __device__ __forceinline__ void stage(__bf16 *tile, const float (&v)[8], int nk) const {
         if (KCONT) {
             typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 bf16x4 pl[NS];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -115,29 +113,26 @@ struct PwLoader {
                         f -= (float)x;
                     }
                 }
-                __bf16 *dst = tile + (32 * j + i0) * PW_ROW + kofs;
+                __bf16 *dst = tile + (64 * j + i0) * PW_ROW + kofs;
 #pragma unroll
                 for (int p = 0; p < NS; ++p) *reinterpret_cast<bf16x4 *>(dst + p * PW_T * PW_ROW) = pl[p];
             }
         } else {
-            bf16x8 pl[NS][2];
+            bf16x8 pl[NS];
             const int n = rows ? nk : 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 float f = j < n ? v[j] : 0.0f;
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
                     const __bf16 x = (__bf16)f;
-                    pl[p][j >> 3][j & 7] = x;
+                    pl[p][j] = x;
                     f -= (float)x;
                 }
             }
             __bf16 *dst = tile + i0 * PW_ROW + kofs;
 #pragma unroll
-            for (int p = 0; p < NS; ++p) {
-                *reinterpret_cast<bf16x8 *>(dst + p * PW_T * PW_ROW) = pl[p][0];
-                *reinterpret_cast<bf16x8 *>(dst + p * PW_T * PW_ROW + 8) = pl[p][1];
-            }
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<bf16x8 *>(dst + p * PW_T * PW_ROW) = pl[p];
         }
     }
 };
@@ -165,13 +160,21 @@ __device__ __forceinline__ void pw_halving(float (&v)[32], int r) {
 
 // NS = 2: products as hi*hi + hi*lo + lo*hi (three MFMAs, ~4e-6 of an fp32 contraction: the operands keep 16 bits);
 // NS = 3: six MFMAs over three planes, every term down to 2^-24 of the product -- fp32-class results.
+//
+// Eight waves (2 x 4, each 64 rows x 32 columns of the 128 x 128 tile), LDS tiles double-buffered: while the MFMAs
+// of chunk c read one buffer, chunk c + 1 (loaded one step earlier) is split into the other and the loads of chunk
+// c + 2 are in flight -- ONE barrier per chunk.
+template <int NS>
+constexpr int pw_lds_bytes() { return 2 * 2 * NS * PW_T * PW_ROW * 2 + 4 * 2 * PW_T * 4; }
+
 template <bool A_KC, bool B_KC, int NS>
-__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwGemm g) {
-    __shared__ __attribute__((aligned(16))) __bf16 As[NS * PW_T * PW_ROW];   // [plane][row][k]
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[NS * PW_T * PW_ROW];
-    __shared__ float red[2][2][PW_T];
+__global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_lds[];
+    constexpr int TILE = NS * PW_T * PW_ROW;                       // bf16 per operand tile
+    __bf16 *lds = reinterpret_cast<__bf16 *>(pw_lds);              // [buffer][A | B][plane][row][k]
+    float (*red)[2][PW_T] = reinterpret_cast<float (*)[2][PW_T]>(pw_lds + 2 * 2 * TILE * 2);
     const int t = threadIdx.x, lane = t & 63, r = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), wr = wave >> 1, wq = wave & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), wr = wave >> 2, wq = wave & 3;
     const int R0 = blockIdx.y * PW_T, Q0 = blockIdx.x * PW_T, z = blockIdx.z;
     PwLoader<A_KC> la;
     PwLoader<B_KC> lb;
@@ -180,69 +183,59 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwGemm g) {
     int c0 = z * g.cps, c1 = c0 + g.cps;
     if (c1 > g.total) c1 = g.total;
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
-
-    // Two chunks of operands in flight in registers beside the one in LDS: a chunk's loads are issued two compute
-    // phases before its values are needed (one phase ahead left every wave waiting on memory at the staging step).
-    float va0[16], vb0[16], va1[16], vb1[16];
+    f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+    float va0[8], vb0[8], va1[8], vb1[8];
     int ka0 = 0, kb0 = 0, ka1 = 0, kb1 = 0;
-    auto fetch = [&](int c, float (&xa)[16], float (&xb)[16], int &ka, int &kb) {
+    auto fetch = [&](int c, float (&xa)[8], float (&xb)[8], int &ka, int &kb) {
         const int bz = c / g.cpb, k0 = (c - bz * g.cpb) * PW_KC;
         ka = la.load(g.A, g.A.p + g.A.batch * bz, R0, g.R, k0, g.K, g.a_vec, xa);
         kb = lb.load(g.B, g.B.p + g.B.batch * bz, Q0, g.Q, k0, g.K, g.b_vec, xb);
     };
-    auto compute = [&]() {
+    auto compute = [&](const __bf16 *As, const __bf16 *Bs) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 a[2][NS], b[2][NS];
+            bf16x8 a[2][NS], b[NS];
+            const __bf16 *pb = Bs + (wq * 32 + r) * PW_ROW + s * 16 + h * 8;
+#pragma unroll
+            for (int p = 0; p < NS; ++p) b[p] = *reinterpret_cast<const bf16x8 *>(pb + p * PW_T * PW_ROW);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const __bf16 *pa = As + (wr * 64 + j * 32 + r) * PW_ROW + s * 16 + h * 8;
-                const __bf16 *pb = Bs + (wq * 64 + j * 32 + r) * PW_ROW + s * 16 + h * 8;
 #pragma unroll
-                for (int p = 0; p < NS; ++p) {
-                    a[j][p] = *reinterpret_cast<const bf16x8 *>(pa + p * PW_T * PW_ROW);
-                    b[j][p] = *reinterpret_cast<const bf16x8 *>(pb + p * PW_T * PW_ROW);
-                }
+                for (int p = 0; p < NS; ++p) a[j][p] = *reinterpret_cast<const bf16x8 *>(pa + p * PW_T * PW_ROW);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x16 d = acc[i][j];                      // small terms first
-                    if (NS == 3) {
-                        d = mfma(a[i][1], b[j][1], d);
-                        d = mfma(a[i][0], b[j][NS - 1], d);
-                        d = mfma(a[i][NS - 1], b[j][0], d);
-                    }
-                    d = mfma(a[i][0], b[j][1], d);
-                    d = mfma(a[i][1], b[j][0], d);
-                    acc[i][j] = mfma(a[i][0], b[j][0], d);
+                f32x16 d = acc[i];                             // small terms first
+                if (NS == 3) {
+                    d = mfma(a[i][1], b[1], d);
+                    d = mfma(a[i][0], b[NS - 1], d);
+                    d = mfma(a[i][NS - 1], b[0], d);
                 }
+                d = mfma(a[i][0], b[1], d);
+                d = mfma(a[i][1], b[0], d);
+                acc[i] = mfma(a[i][0], b[0], d);
             }
         }
     };
-    // LDS holds chunk c, (xa, xb) chunk c + 1; (fa, fb) are free and take chunk c + 2
-    auto step = [&](int c, float (&fa)[16], float (&fb)[16], int &fka, int &fkb, float (&xa)[16], float (&xb)[16],
+    // buffer (c & 1) holds chunk c, (xa, xb) chunk c + 1; (fa, fb) are free and take chunk c + 2
+    auto step = [&](int c, float (&fa)[8], float (&fb)[8], int &fka, int &fkb, float (&xa)[8], float (&xb)[8],
                     int xka, int xkb) {
+        __bf16 *cur = lds + (c & 1) * 2 * TILE, *nxt = lds + ((c + 1) & 1) * 2 * TILE;
         if (c + 2 < c1) fetch(c + 2, fa, fb, fka, fkb);
-        compute();
-        __syncthreads();
+        compute(cur, cur + TILE);
         if (c + 1 < c1) {
-            la.template stage<NS>(As, xa, xka);
-            lb.template stage<NS>(Bs, xb, xkb);
+            la.template stage<NS>(nxt, xa, xka);
+            lb.template stage<NS>(nxt + TILE, xb, xkb);
         }
         __syncthreads();
     };
     if (c0 < c1) {
         fetch(c0, va0, vb0, ka0, kb0);
         if (c0 + 1 < c1) fetch(c0 + 1, va1, vb1, ka1, kb1);
-        la.template stage<NS>(As, va0, ka0);
-        lb.template stage<NS>(Bs, vb0, kb0);
+        __bf16 *first = lds + (c0 & 1) * 2 * TILE;
+        la.template stage<NS>(first, va0, ka0);
+        lb.template stage<NS>(first + TILE, vb0, kb0);
     }
     __syncthreads();
     for (int c = c0; c < c1; c += 2) {
@@ -250,20 +243,15 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwGemm g) {
         if (c + 1 < c1) step(c + 1, va1, vb1, ka1, kb1, va0, vb0, ka0, kb0);
     }
 
-    // D: lane = column, register i <-> row acc_row(i, h): 32 consecutive columns per store
+    // D: lane = column, register e <-> row acc_row(e, h): 32 consecutive columns per store
     float *D = g.D + g.d_batch * z;
+    const int q = Q0 + wq * 32 + r;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = R0 + wr * 64 + i * 32 + acc_row(e, h);
-            if (row < g.R) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int q = Q0 + wq * 64 + j * 32 + r;
-                    if (q < g.Q) D[(size_t)row * g.ldd + q] = acc[i][j][e];
-                }
-            }
+            if (row < g.R && q < g.Q) D[(size_t)row * g.ldd + q] = acc[i][e];
         }
     }
     if (g.part) {
@@ -274,9 +262,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwGemm g) {
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float u = acc[i][0][e], w = acc[i][1][e];
-                s1[16 * i + e] = u + w;
-                s2[16 * i + e] = u * u + w * w;
+                s1[16 * i + e] = acc[i][e];
+                s2[16 * i + e] = acc[i][e] * acc[i][e];
             }
         }
         pw_halving(s1, r);
@@ -287,8 +274,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(PwGemm g) {
         __syncthreads();
         if (t < PW_T && R0 + t < g.R) {
             float *dst = g.part + ((size_t)z * gridDim.x + blockIdx.x) * 2 * g.R + R0 + t;
-            dst[0] = red[0][0][t] + red[1][0][t];
-            dst[g.R] = red[0][1][t] + red[1][1][t];
+            dst[0] = (red[0][0][t] + red[1][0][t]) + (red[2][0][t] + red[3][0][t]);
+            dst[g.R] = (red[0][1][t] + red[1][1][t]) + (red[2][1][t] + red[3][1][t]);
         }
     }
 }
@@ -487,12 +474,26 @@ static bool pw_vec(const float *p, long long batch, int ld, int K) {
 
 extern "C" int apn_pw_conv_tiles(int b, int n) { return b * ((n + apn::PW_T - 1) / apn::PW_T); }
 
-#define PW_LAUNCH(AK, BK, grid, g)                                                                         \
-    do {                                                                                                   \
-        if (precision == 3)                                                                                \
-            hipLaunchKernelGGL((pw_gemm_kernel<AK, BK, 3>), grid, dim3(256), 0, (hipStream_t)stream, g);   \
-        else                                                                                               \
-            hipLaunchKernelGGL((pw_gemm_kernel<AK, BK, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);   \
+template <bool AK, bool BK, int NS>
+static int pw_launch(dim3 grid, const apn::PwGemm &g, hipStream_t stream) {
+    using namespace apn;
+    static bool configured = false;      // per instantiation; setting it twice is harmless
+    if (!configured) {
+        if (hipError_t e = hipFuncSetAttribute((const void *)pw_gemm_kernel<AK, BK, NS>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, pw_lds_bytes<NS>()))
+            return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((pw_gemm_kernel<AK, BK, NS>), grid, dim3(512), pw_lds_bytes<NS>(), stream, g);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+#define PW_LAUNCH(AK, BK, grid, g)                                                                              \
+    do {                                                                                                        \
+        const int rc__ = precision == 3 ? pw_launch<AK, BK, 3>(grid, g, (hipStream_t)stream)                   \
+                                        : pw_launch<AK, BK, 2>(grid, g, (hipStream_t)stream);                  \
+        if (rc__) return rc__;                                                                                  \
     } while (0)
 
 extern "C" int apn_pw_conv_forward(int b, int c_in, int c_out, int n, int precision, const float *x, const float *w,
