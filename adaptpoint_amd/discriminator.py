@@ -6,7 +6,8 @@ cfgs/scanobjectnn/pointnext-s_adaptpoint_1.yaml:58-61): per-point 1x1 convolutio
 3 -> 64 -> 128 -> 1024 with ReLU, max over the N points, then 1024 -> 512 -> 256 -> num_classes -> 1
 with ReLU / dropout 0.4 and a final sigmoid.  No BatchNorm; every weight carries
 `torch.nn.utils.parametrizations.spectral_norm` (one power iteration per training-mode forward,
-state in the `_u` / `_v` buffers).  It uses none of the extension operators: the "group all"
+state in the `_u` / `_v` buffers) -- registered through `adaptpoint_amd.spectral`, which evaluates it in three
+launches instead of ~13 on the GPU.  It uses none of the extension operators: the "group all"
 stage is the identity grouping, so the per-point MLP runs directly on (B,3,N).
 
 Module names and the convolution type (Conv2d with 1x1 kernels) are the reference's, so its
@@ -16,7 +17,8 @@ state_dict -- `sa1.mlp_convs.<i>.parametrizations.weight.original`, `..._u`, `..
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.nn.utils.parametrizations import spectral_norm
+
+from .spectral import spectral_norm        # torch's parametrisation, evaluated by csrc/spectral.hip on the GPU
 
 
 class _GroupAllStage(nn.Module):

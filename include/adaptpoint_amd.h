@@ -520,6 +520,23 @@ APN_API int apn_pw_conv_grad_weight_splits(int b, int c_in, int c_out, int n);
 APN_API int apn_pw_conv_grad_weight(int b, int c_in, int c_out, int n, int precision, const float *gy, const float *x,
                                     float *scratch, float *gw, void *stream);
 
+/* ------------------------------------------------------------------------
+ * spectral normalisation, the parametrisation of every layer of PointDiscriminator1
+ * (openpoints/models_adaptpoint/point_discriminator.py:17-73, 149-191: torch.nn.utils.spectral_norm, which the
+ * reference evaluates as ~13 small PyTorch launches per training-mode forward and ~7 per backward).
+ *   w (rows x cols) the weight as a matrix; u [rows], v [cols] the module's power-iteration buffers.
+ * spectral_norm (3 launches; 2 when !training): training: one power iteration u = normalize(w v),
+ *   v = normalize(w^T u) written INTO u, v; sigma[0] = u^T w v; w_normalized = w / sigma; u_used / v_used = the
+ *   vectors sigma was formed with (kept for the backward, as PyTorch clones them); scratch [rows + cols] floats.
+ * spectral_norm_grad (2 launches): g_w = g / sigma - (sum(g o w_normalized) / sigma) u_used v_used^T;
+ *   part = scratch of apn_spectral_norm_blocks(rows, cols) doubles.  Fixed summation orders: reproducible. */
+APN_API int apn_spectral_norm_blocks(int rows, int cols);
+APN_API int apn_spectral_norm(int rows, int cols, const float *w, int training, float eps, float *u, float *v,
+                              float *scratch, float *u_used, float *v_used, float *sigma, float *w_normalized,
+                              void *stream);
+APN_API int apn_spectral_norm_grad(int rows, int cols, const float *g, const float *w_normalized, const float *sigma,
+                                   const float *u_used, const float *v_used, double *part, float *g_w, void *stream);
+
 /* Tuning / diagnostic entry, NOT part of the reference boundary: apn_furthest_point_sampling
  * with the number of wavefronts that cooperate on one cloud (1, 2, 4, 8 or 16; 0 = the built-in
  * heuristic) and the step algorithm (0 = default: one LDS 64-bit atomic max per step for
