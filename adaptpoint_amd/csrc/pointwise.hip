@@ -44,6 +44,8 @@ struct PwGemm {
     int total;                // chunks in all
     int a_vec, b_vec;         // k-contiguous operand readable as float4
     float *part;              // optional [(z * gridDim.x + x)][2][R]: row sums and sums of squares of this tile
+    float *pool_val;          // optional [(z * gridDim.x + x)][R]: the tile's row maxima (D is then not written) ...
+    int *pool_idx;            // ... and the column each was found at (the lowest one among equals)
 };
 
 // Loader roles of the 512 threads for one 128 x 32 operand chunk (8 values per thread), chosen so that every
@@ -167,6 +169,22 @@ __device__ __forceinline__ void pw_halving(float (&v)[32], int r) {
 template <int NS>
 constexpr int pw_lds_bytes() { return 2 * 2 * NS * PW_T * PW_ROW * 2 + 4 * 2 * PW_T * 4; }
 
+// the same halving for (maximum, column) pairs: the larger value wins, among equal values the lower column
+template <int M>
+__device__ __forceinline__ void pw_halve_max_step(float (&v)[32], int (&ix)[32], int r) {
+    const bool up = (r & M) != 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const float keep = up ? v[j + M] : v[j], send = up ? v[j] : v[j + M];
+        const int keepi = up ? ix[j + M] : ix[j], sendi = up ? ix[j] : ix[j + M];
+        const float rv = __shfl_xor(send, M);
+        const int ri = __shfl_xor(sendi, M);
+        const bool take = rv > keep || (rv == keep && ri < keepi);
+        v[j] = take ? rv : keep;
+        ix[j] = take ? ri : keepi;
+    }
+}
+
 template <bool A_KC, bool B_KC, int NS>
 __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_lds[];
@@ -243,9 +261,45 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         if (c + 1 < c1) step(c + 1, va1, vb1, ka1, kb1, va0, vb0, ka0, kb0);
     }
 
+    const int q = Q0 + wq * 32 + r;
+    if (g.pool_val) {
+        // row maxima over the tile's columns instead of the tile: value 16 i + e of a lane <-> row
+        // 32 i + acc_row(e, h) of the wave, as in the statistics epilogue below
+        float mv[32];
+        int mi[32];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                mv[16 * i + e] = q < g.Q ? acc[i][e] : -__builtin_inff();
+                mi[16 * i + e] = q;
+            }
+        }
+        pw_halve_max_step<16>(mv, mi, r);
+        pw_halve_max_step<8>(mv, mi, r);
+        pw_halve_max_step<4>(mv, mi, r);
+        pw_halve_max_step<2>(mv, mi, r);
+        pw_halve_max_step<1>(mv, mi, r);
+        const int row = wr * 64 + (r >> 4) * 32 + acc_row(r & 15, h);
+        red[wq][0][row] = mv[0];
+        reinterpret_cast<int *>(&red[wq][1][0])[row] = mi[0];
+        __syncthreads();
+        if (t < PW_T && R0 + t < g.R) {
+            float best = red[0][0][t];
+            int bi = reinterpret_cast<int *>(&red[0][1][0])[t];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {                    // ascending columns: a later wave wins only if larger
+                const float cand = red[w][0][t];
+                if (cand > best) { best = cand; bi = reinterpret_cast<int *>(&red[w][1][0])[t]; }
+            }
+            const size_t o = ((size_t)z * gridDim.x + blockIdx.x) * g.R + R0 + t;
+            g.pool_val[o] = best;
+            g.pool_idx[o] = bi;
+        }
+        return;
+    }
     // D: lane = column, register e <-> row acc_row(e, h): 32 consecutive columns per store
     float *D = g.D + g.d_batch * z;
-    const int q = Q0 + wq * 32 + r;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -449,6 +503,82 @@ __global__ __launch_bounds__(256) void pw_fold_kernel(const float *__restrict__ 
     if (q == 0 && e < n) out[e] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
+// ---- convolution + bias + ReLU + max over the points of a cloud (the last layer of the discriminator's group-all
+// stage, point_discriminator.py:183-189: the (B, 1024, N) activation it pools is never written) ------------------
+// out[b][o] = [relu](max_n y[b][o][n] + bias[o]) from the tiles' maxima (ascending tiles: the lowest position wins ties)
+__global__ __launch_bounds__(256) void pw_pool_finish_kernel(int total, int O, int tiles, const float *__restrict__ pv,
+                                                             const int *__restrict__ pi, const float *__restrict__ bias,
+                                                             int relu, float *__restrict__ out, int *__restrict__ idx) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int b = e / O, o = e - b * O;
+    const size_t base = (size_t)b * tiles * O + o;
+    float best = pv[base];
+    int bi = pi[base];
+    for (int t = 1; t < tiles; ++t) {
+        const float c = pv[base + (size_t)t * O];
+        if (c > best) { best = c; bi = pi[base + (size_t)t * O]; }
+    }
+    best += bias ? bias[o] : 0.0f;
+    out[e] = relu ? fmaxf(best, 0.0f) : best;
+    idx[e] = bi;
+}
+
+// Backward, part 1, workgroup (chunk of 64 positions, cloud b): the pooled output (b, o) passes its gradient to ONE
+// position idx[b][o]; the workgroup walks the channels o in a fixed order (even o: threads 0-127, odd o: 128-255, one
+// LDS accumulator tile each, added at the end) and, where idx falls into its chunk, adds w[o][:] * gp to that
+// position's column of g_x and copies the position's input column to xsel[b][o][:] for part 2 -- no atomics.
+// LDS: xt [64][C + 1] | acc [2][64][C + 1]
+__global__ __launch_bounds__(256) void pw_pool_grad_points_kernel(int C, int O, int N, const float *__restrict__ x,
+                                                                  const float *__restrict__ w,
+                                                                  const float *__restrict__ g_out,
+                                                                  const float *__restrict__ out,
+                                                                  const int *__restrict__ idx, int relu,
+                                                                  float *__restrict__ xsel, float *__restrict__ g_x) {
+    extern __shared__ float pool_sm[];
+    const int ld = C + 1, n0 = blockIdx.x * 64, b = blockIdx.y, tid = threadIdx.x;
+    float *xt = pool_sm, *acc = pool_sm + 64 * ld;
+    const int p = tid & 63, cg = tid >> 6;
+    const float *xb = x + (size_t)b * C * N;
+    for (int c = cg; c < C; c += 4) xt[p * ld + c] = n0 + p < N ? xb[(size_t)c * N + n0 + p] : 0.0f;
+    for (int e = tid; e < 2 * 64 * ld; e += 256) acc[e] = 0.0f;
+    __syncthreads();
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7), c = tid & 127;
+    float *mine = acc + half * 64 * ld;
+    for (int o = half; o < O; o += 2) {
+        const int at = idx[(size_t)b * O + o] - n0;
+        if (at < 0 || at >= 64) continue;                       // wave-uniform
+        const float gv = g_out[(size_t)b * O + o];
+        const float gp = (!relu || out[(size_t)b * O + o] > 0.0f) ? gv : 0.0f;
+        if (c < C) {
+            xsel[((size_t)b * O + o) * C + c] = xt[at * ld + c];
+            if (g_x) mine[at * ld + c] = __builtin_fmaf(w[(size_t)o * C + c], gp, mine[at * ld + c]);
+        }
+    }
+    if (!g_x) return;
+    __syncthreads();
+    float *gb = g_x + (size_t)b * C * N;
+    if (n0 + p < N)
+        for (int cc = cg; cc < C; cc += 4) gb[(size_t)cc * N + n0 + p] = acc[p * ld + cc] + acc[64 * ld + p * ld + cc];
+}
+
+// part 2: g_w[o][c] = sum_b gp[b][o] xsel[b][o][c], g_bias[o] = sum_b gp[b][o]: workgroup o, thread c, clouds in order
+__global__ __launch_bounds__(128) void pw_pool_grad_weight_kernel(int B, int C, int O, const float *__restrict__ xsel,
+                                                                  const float *__restrict__ g_out,
+                                                                  const float *__restrict__ out, int relu,
+                                                                  float *__restrict__ g_w, float *__restrict__ g_bias) {
+    const int o = blockIdx.x, c = threadIdx.x;
+    float a = 0.0f, sb = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float gv = g_out[(size_t)b * O + o];
+        const float gp = (!relu || out[(size_t)b * O + o] > 0.0f) ? gv : 0.0f;
+        sb += gp;
+        if (c < C) a = __builtin_fmaf(gp, xsel[((size_t)b * O + o) * C + c], a);
+    }
+    if (c < C) g_w[(size_t)o * C + c] = a;
+    if (c == 0 && g_bias) g_bias[o] = sb;
+}
+
 static int pw_channel_splits(int b, int c) {
     // (c, s) workgroups: enough of them to fill the chip, never more than clouds
     int s = (2048 + c - 1) / c;
@@ -586,6 +716,51 @@ extern "C" int apn_pw_conv_grad_weight(int b, int c_in, int c_out, int n, int pr
     const size_t ne = (size_t)c_out * c_in;
     hipLaunchKernelGGL(pw_fold_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(256), 0, (hipStream_t)stream, scratch, s,
                        ne, gw);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_pw_conv_max_tiles(int n) { return (n + apn::PW_T - 1) / apn::PW_T; }
+
+extern "C" int apn_pw_conv_max_forward(int b, int c_in, int c_out, int n, int precision, const float *x, const float *w,
+                                       const float *bias, int relu, float *tile_val, int *tile_idx, float *out, int *idx,
+                                       void *stream) {
+    using namespace apn;
+    if (b <= 0 || c_in <= 0 || c_out <= 0 || n <= 0 || b > 65535 || (precision != 2 && precision != 3) || !x || !w ||
+        !tile_val || !tile_idx || !out || !idx)
+        return APN_EINVAL;
+    const int tiles = (n + PW_T - 1) / PW_T;
+    PwGemm g{};
+    g.A = PwOperand{w, 0, c_in};
+    g.B = PwOperand{x, (long long)c_in * n, n};
+    g.R = c_out; g.Q = n; g.K = c_in;
+    g.cpb = (c_in + PW_KC - 1) / PW_KC; g.cps = g.cpb; g.total = b * g.cpb;
+    g.a_vec = pw_vec(w, 0, c_in, c_in);
+    g.pool_val = tile_val; g.pool_idx = tile_idx;
+    PW_LAUNCH(true, false, dim3(tiles, (c_out + PW_T - 1) / PW_T, b), g);
+    const int total = b * c_out;
+    hipLaunchKernelGGL(pw_pool_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, total, c_out,
+                       tiles, tile_val, tile_idx, bias, relu, out, idx);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_pw_conv_max_backward(int b, int c_in, int c_out, int n, const float *g_out, const float *out,
+                                        const int *idx, const float *x, const float *w, int relu, float *xsel, float *g_x,
+                                        float *g_w, float *g_bias, void *stream) {
+    using namespace apn;
+    if (b <= 0 || c_in <= 0 || c_in > 128 || c_out <= 0 || n <= 0 || b > 65535 || !g_out || !out || !idx || !x || !w ||
+        !xsel || !g_w)
+        return APN_EINVAL;
+    const size_t lds = (size_t)3 * 64 * (c_in + 1) * sizeof(float);
+    if (hipError_t e = hipFuncSetAttribute((const void *)pw_pool_grad_points_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+        return (int)e;
+    hipLaunchKernelGGL(pw_pool_grad_points_kernel, dim3((n + 63) / 64, b), dim3(256), lds, (hipStream_t)stream, c_in,
+                       c_out, n, x, w, g_out, out, idx, relu, xsel, g_x);
+    APN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pw_pool_grad_weight_kernel, dim3(c_out), dim3(128), 0, (hipStream_t)stream, b, c_in, c_out, xsel,
+                       g_out, out, relu, g_w, g_bias);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

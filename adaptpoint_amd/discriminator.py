@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import pointwise
 from .spectral import spectral_norm        # torch's parametrisation, evaluated by csrc/spectral.hip on the GPU
 
 
@@ -25,8 +26,9 @@ class _GroupAllStage(nn.Module):
     """point_discriminator.py:149-191 with group_all=True: the shared MLP over every point of
     the cloud and a max over them.  `mlp_bns` exists (empty) because the reference registers it."""
 
-    def __init__(self, in_channel, mlp):
+    def __init__(self, in_channel, mlp, fused=True):
         super().__init__()
+        self.fused = fused
         self.mlp_convs = nn.ModuleList()
         self.mlp_bns = nn.ModuleList()
         for out_channel in mlp:
@@ -37,20 +39,26 @@ class _GroupAllStage(nn.Module):
         """xyz (B,3,N) -> (B,C_last): the reference's (B,3,N,1) layout is (B,3,N) with a unit
         trailing axis; the max over the "nsample" axis (:189) is the max over the points."""
         x = xyz.unsqueeze(-1)
-        for conv in self.mlp_convs:
+        for conv in self.mlp_convs[:-1]:
             x = F.relu(conv(x))
-        return x.amax(dim=2).squeeze(-1)
+        last = self.mlp_convs[-1]
+        if self.fused and pointwise.conv_max_supported(x.squeeze(-1), last.in_channels):
+            # convolution + ReLU + max in one pass: the (B, 1024, N) activation is never written, the backward
+            # touches one position per (cloud, channel).  (`last.weight` is read ONCE: every read of a
+            # spectral-normalised weight in training mode is a power iteration.)
+            return pointwise.conv_max(x.squeeze(-1), last.weight, last.bias, relu=True)
+        return F.relu(last(x)).amax(dim=2).squeeze(-1)
 
 
 class PointDiscriminator1(nn.Module):
     """point_discriminator.py:17-73."""
 
-    def __init__(self, num_classes=40, normal_channel=False, **kwargs):
+    def __init__(self, num_classes=40, normal_channel=False, fused=True, **kwargs):
         super().__init__()
         if normal_channel:
             raise NotImplementedError("normal channels are not used by the AdaptPoint configs")
         self.normal_channel = False
-        self.sa1 = _GroupAllStage(3, [64, 128, 1024])
+        self.sa1 = _GroupAllStage(3, [64, 128, 1024], fused=fused)
         self.fc1 = spectral_norm(nn.Linear(1024, 512))
         self.drop1 = nn.Dropout(0.4)
         self.fc2 = spectral_norm(nn.Linear(512, 256))

@@ -98,3 +98,54 @@ class _ConvBNAct(torch.autograd.Function):
 def conv_bn_act(x, conv, bn, relu=True):
     """relu(bn(conv(x))) for a kernel-1 bias-free `conv` (nn.Conv1d) and `bn` (nn.BatchNorm1d) on x (B, C, N)."""
     return _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, bn, relu)
+
+
+class _ConvMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        dev = x.device
+        x = x.contiguous()
+        B, C, N = x.shape
+        O = weight.shape[0]
+        w = weight.detach().reshape(O, C).contiguous()
+        tiles = _lib.load().apn_pw_conv_max_tiles(N)
+        tile_val = torch.empty(B, tiles, O, device=dev)
+        tile_idx = torch.empty(B, tiles, O, dtype=torch.int32, device=dev)
+        out = torch.empty(B, O, device=dev)
+        idx = torch.empty(B, O, dtype=torch.int32, device=dev)
+        _call("apn_pw_conv_max_forward", dev, B, C, O, N, PRECISION, x.data_ptr(), w.data_ptr(),
+              bias.data_ptr() if bias is not None else None, int(relu), tile_val.data_ptr(), tile_idx.data_ptr(),
+              out.data_ptr(), idx.data_ptr())
+        ctx.save_for_backward(x, w, out, idx)
+        ctx.cfg = (relu, bias is not None, weight.shape)
+        ctx.mark_non_differentiable(idx)
+        return out, idx
+
+    @staticmethod
+    def backward(ctx, g, _):
+        x, w, out, idx = ctx.saved_tensors
+        relu, has_bias, wshape = ctx.cfg
+        dev = x.device
+        B, C, N = x.shape
+        O = w.shape[0]
+        g = g.contiguous()
+        xsel = torch.empty(B, O, C, device=dev)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty(O, C, device=dev)
+        gb = torch.empty(O, device=dev) if has_bias else None
+        _call("apn_pw_conv_max_backward", dev, B, C, O, N, g.data_ptr(), out.data_ptr(), idx.data_ptr(), x.data_ptr(),
+              w.data_ptr(), int(relu), xsel.data_ptr(), gx.data_ptr() if gx is not None else None, gw.data_ptr(),
+              gb.data_ptr() if gb is not None else None)
+        return gx, gw.view(wshape), gb, None
+
+
+def conv_max_supported(x, c_in):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and 0 < x.shape[0] <= 65535 and x.shape[2] > 0
+            and c_in == x.shape[1] and c_in <= 128)
+
+
+def conv_max(x, weight, bias=None, relu=True):
+    """(B, O) = [relu](max over the N points of (weight x + bias)) for x (B, C, N), weight (O, C[, 1, 1]): the last
+    layer of the discriminator's group-all stage with its pooling (point_discriminator.py:183-189), without the
+    (B, O, N) activation.  Also returns nothing else: the arg-max positions stay inside the autograd node."""
+    return _ConvMax.apply(x, weight, bias, relu)[0]

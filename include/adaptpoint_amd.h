@@ -520,6 +520,22 @@ APN_API int apn_pw_conv_grad_weight_splits(int b, int c_in, int c_out, int n);
 APN_API int apn_pw_conv_grad_weight(int b, int c_in, int c_out, int n, int precision, const float *gy, const float *x,
                                     float *scratch, float *gw, void *stream);
 
+/* The last layer of the discriminator's group-all stage with its pooling
+ * (openpoints/models_adaptpoint/point_discriminator.py:183-189: conv -> ReLU -> max over the cloud's points), fused:
+ *   out (B,c_out) = [relu](max_n (w x_b)[o][n] + bias[o]),  idx (B,c_out) int32 = the position of that maximum (the
+ *   lowest one among equals); the (B,c_out,N) activation is never written.  bias may be NULL.  Scratch: tile_val /
+ *   tile_idx [b][apn_pw_conv_max_tiles(n)][c_out].
+ * Backward (c_in <= 128): every (b, o) passes its gradient to position idx[b][o] alone -- g_x (B,c_in,N) (fully
+ *   written; may be NULL), g_w (c_out,c_in), g_bias [c_out] (may be NULL); xsel = scratch (B,c_out,c_in).  No
+ *   atomics: fixed orders, bit-reproducible. */
+APN_API int apn_pw_conv_max_tiles(int n);
+APN_API int apn_pw_conv_max_forward(int b, int c_in, int c_out, int n, int precision, const float *x, const float *w,
+                                    const float *bias, int relu, float *tile_val, int *tile_idx, float *out, int *idx,
+                                    void *stream);
+APN_API int apn_pw_conv_max_backward(int b, int c_in, int c_out, int n, const float *g_out, const float *out,
+                                     const int *idx, const float *x, const float *w, int relu, float *xsel, float *g_x,
+                                     float *g_w, float *g_bias, void *stream);
+
 /* ------------------------------------------------------------------------
  * spectral normalisation, the parametrisation of every layer of PointDiscriminator1
  * (openpoints/models_adaptpoint/point_discriminator.py:17-73, 149-191: torch.nn.utils.spectral_norm, which the

@@ -130,3 +130,32 @@ def test_module_falls_back_where_the_kernels_do_not_apply(dev):
     a, b = fused(x), plain(x)
     assert _rel(a, b.double()) < 1e-5
     assert _rel(fused.net[1].running_var, plain.net[1].running_var.double()) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 1024, 1024), (3, 128, 1024, 2048), (2, 37, 70, 333), (4, 5, 130, 64)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("relu", [True, False], ids=["relu", "linear"])
+def test_conv_max_matches_float64_composition(dev, shape, relu):
+    """convolution + bias (+ ReLU) + max over the points, fused (the discriminator's last group-all layer,
+    point_discriminator.py:183-189), against the composed float64 evaluation: output, arg-max consistency, and the
+    three gradients (the pooled gradient reaches one position per (cloud, channel))."""
+    from adaptpoint_amd import pointwise
+    B, C, O, N = shape
+    g = torch.Generator(dev).manual_seed(B + C + O + N)
+    x = torch.randn(B, C, N, device=dev, generator=g).requires_grad_(True)
+    w = (torch.randn(O, C, 1, 1, device=dev, generator=g) / C ** 0.5).requires_grad_(True)
+    bias = (0.3 * torch.randn(O, device=dev, generator=g)).requires_grad_(True)
+    gout = torch.randn(B, O, device=dev, generator=g)
+    x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, w, bias))
+    y = torch.einsum("oc,bcn->bon", w64.view(O, C), x64) + b64.view(1, O, 1)
+    ref = (torch.relu(y) if relu else y).amax(dim=2)
+    # near-ties of the maximum (and of the ReLU kink) decide where the gradient goes: keep them out of the comparison
+    top2 = y.detach().topk(2, dim=2)[0]
+    clear = ((top2[..., 0] - top2[..., 1]) > 1e-4) & ((top2[..., 0].abs() > 1e-4) | (not relu))
+    gout = gout * clear
+    ref.backward(gout.double())
+    assert pointwise.conv_max_supported(x, C)
+    out = pointwise.conv_max(x, w, bias, relu=relu)
+    out.backward(gout)
+    assert _rel(out, ref.detach()) < 1e-6
+    assert _rel(x.grad, x64.grad) < 5e-6 and _rel(w.grad, w64.grad) < 5e-6 and _rel(bias.grad, b64.grad) < 5e-6
