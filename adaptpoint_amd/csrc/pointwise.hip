@@ -525,10 +525,12 @@ __global__ __launch_bounds__(256) void pw_pool_finish_kernel(int total, int O, i
 }
 
 // Backward, part 1, workgroup (chunk of 64 positions, cloud b): the pooled output (b, o) passes its gradient to ONE
-// position idx[b][o]; the workgroup walks the channels o in a fixed order (even o: threads 0-127, odd o: 128-255, one
-// LDS accumulator tile each, added at the end) and, where idx falls into its chunk, adds w[o][:] * gp to that
-// position's column of g_x and copies the position's input column to xsel[b][o][:] for part 2 -- no atomics.
-// LDS: xt [64][C + 1] | acc [2][64][C + 1]
+// position idx[b][o].  The workgroup first lists the channels o whose position falls into its chunk, in ascending o
+// (a ballot / prefix compaction over the cloud's idx row: walking all O channels with a dependent scalar load each
+// took 147 us), then walks the list -- entries alternately by threads 0-127 and 128-255, one LDS accumulator tile each,
+// added at the end: fixed orders, no atomics -- adding w[o][:] * gp to that position's column of g_x and copying the
+// position's input column to xsel[b][o][:] for part 2.
+// LDS: xt [64][C + 1] | acc [2][64][C + 1] | hits [O] ints
 __global__ __launch_bounds__(256) void pw_pool_grad_points_kernel(int C, int O, int N, const float *__restrict__ x,
                                                                   const float *__restrict__ w,
                                                                   const float *__restrict__ g_out,
@@ -536,18 +538,34 @@ __global__ __launch_bounds__(256) void pw_pool_grad_points_kernel(int C, int O, 
                                                                   const int *__restrict__ idx, int relu,
                                                                   float *__restrict__ xsel, float *__restrict__ g_x) {
     extern __shared__ float pool_sm[];
+    __shared__ int wave_count[4], nhits;
     const int ld = C + 1, n0 = blockIdx.x * 64, b = blockIdx.y, tid = threadIdx.x;
     float *xt = pool_sm, *acc = pool_sm + 64 * ld;
+    int *hits = reinterpret_cast<int *>(pool_sm + 3 * 64 * ld);
     const int p = tid & 63, cg = tid >> 6;
     const float *xb = x + (size_t)b * C * N;
     for (int c = cg; c < C; c += 4) xt[p * ld + c] = n0 + p < N ? xb[(size_t)c * N + n0 + p] : 0.0f;
     for (int e = tid; e < 2 * 64 * ld; e += 256) acc[e] = 0.0f;
+    if (tid == 0) nhits = 0;
     __syncthreads();
-    const int half = __builtin_amdgcn_readfirstlane(tid >> 7), c = tid & 127;
+    for (int base = 0; base < O; base += 256) {
+        const int o = base + tid;
+        const int at = o < O ? idx[(size_t)b * O + o] - n0 : -1;
+        const bool hit = at >= 0 && at < 64;
+        const unsigned long long m = __ballot(hit);
+        if (p == 0) wave_count[cg] = __popcll(m);
+        __syncthreads();
+        int before = nhits;
+        for (int k = 0; k < cg; ++k) before += wave_count[k];
+        if (hit) hits[before + __popcll(m & ((1ull << p) - 1ull))] = o | (at << 24);
+        __syncthreads();
+        if (tid == 0) nhits += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        __syncthreads();
+    }
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7), c = tid & 127, total = nhits;
     float *mine = acc + half * 64 * ld;
-    for (int o = half; o < O; o += 2) {
-        const int at = idx[(size_t)b * O + o] - n0;
-        if (at < 0 || at >= 64) continue;                       // wave-uniform
+    for (int k = half; k < total; k += 2) {
+        const int o = hits[k] & 0xffffff, at = hits[k] >> 24;
         const float gv = g_out[(size_t)b * O + o];
         const float gp = (!relu || out[(size_t)b * O + o] > 0.0f) ? gv : 0.0f;
         if (c < C) {
@@ -752,7 +770,8 @@ extern "C" int apn_pw_conv_max_backward(int b, int c_in, int c_out, int n, const
     if (b <= 0 || c_in <= 0 || c_in > 128 || c_out <= 0 || n <= 0 || b > 65535 || !g_out || !out || !idx || !x || !w ||
         !xsel || !g_w)
         return APN_EINVAL;
-    const size_t lds = (size_t)3 * 64 * (c_in + 1) * sizeof(float);
+    if (c_out >= (1 << 24)) return APN_EINVAL;
+    const size_t lds = ((size_t)3 * 64 * (c_in + 1) + c_out) * sizeof(float);
     if (hipError_t e = hipFuncSetAttribute((const void *)pw_pool_grad_points_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
         return (int)e;

@@ -37,17 +37,23 @@ __global__ __launch_bounds__(256) void sn_mv_kernel(int R, int C, const float *_
     if (lane == 0) t[row] = acc;
 }
 
-// s[c] = sum_r W[r][c] t[r]: 64 columns per workgroup, four interleaved row groups added in a fixed order
-__global__ __launch_bounds__(256) void sn_mtv_kernel(int R, int C, const float *__restrict__ W,
-                                                     const float *__restrict__ t, float *__restrict__ s) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+// s[c] = sum_r W[r][c] t[r]: 64 columns per workgroup, sixteen interleaved row groups added in a fixed order
+// (four groups of 256 threads left the 1024 x 512 layer's sixteen workgroups at 19 us)
+__global__ __launch_bounds__(1024) void sn_mtv_kernel(int R, int C, const float *__restrict__ W,
+                                                      const float *__restrict__ t, float *__restrict__ s) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, col = blockIdx.x * 64 + lane, g = threadIdx.x >> 6;
     float acc = 0.0f;
     if (col < C)
-        for (int r = g; r < R; r += 4) acc = __builtin_fmaf(W[(size_t)r * C + col], t[r], acc);
-    red[g][threadIdx.x & 63] = acc;
+        for (int r = g; r < R; r += 16) acc = __builtin_fmaf(W[(size_t)r * C + col], t[r], acc);
+    red[g][lane] = acc;
     __syncthreads();
-    if (g == 0 && col < C) s[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (g == 0 && col < C) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += red[k][lane];
+        s[col] = sum;
+    }
 }
 
 // training: (t, s) -> u', v' (into the buffers and into the copies kept for the backward), sigma, Wn = W / sigma;
@@ -113,8 +119,10 @@ __global__ __launch_bounds__(256) void sn_grad_apply_kernel(int R, int C, const 
                                                             const float *__restrict__ sigma_p,
                                                             const float *__restrict__ uc, const float *__restrict__ vc,
                                                             float *__restrict__ gW) {
+    __shared__ double scratch[4];
     double d = 0.0;
-    for (int i = 0; i < nparts; ++i) d += part[i];          // every thread the same fixed order
+    for (int i = threadIdx.x; i < nparts; i += 256) d += part[i];
+    d = sn_block_sum(d, scratch);                             // the same fixed tree in every workgroup
     const float sigma = sigma_p[0], k = (float)(d / (double)sigma);
     const size_t n = (size_t)R * C;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
@@ -143,7 +151,7 @@ extern "C" int apn_spectral_norm(int rows, int cols, const float *w, int trainin
     if (training) {
         hipLaunchKernelGGL(sn_mv_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, cols, w, v, t);
         APN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sn_mtv_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, rows, cols, w, t, s);
+        hipLaunchKernelGGL(sn_mtv_kernel, dim3((cols + 63) / 64), dim3(1024), 0, st, rows, cols, w, t, s);
         APN_LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL(sn_mv_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, cols, w, v, t);
