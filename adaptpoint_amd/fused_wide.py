@@ -235,6 +235,7 @@ class _WideBlock(torch.autograd.Function):
         idx, tmap = nbr.idx, nbr.tmap
         radius, tr1, tr2, sync, count, relu, a1, a2, a3, a4, a5 = ctx.cfg
         need_p, need_q = ctx.need
+        need_w = any(ctx.needs_input_grad[3:11])       # any weight of the block (frozen in the GAN feedback pass)
         dev = f.device
         B, C, N = f.shape
         M = new_p.shape[1]
@@ -300,10 +301,11 @@ class _WideBlock(torch.autograd.Function):
         _call("apn_sa_wide_bwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
               tmap.data_ptr(), zimg.data_ptr(), pack1.data_ptr(), evec.data_ptr(), goa.data_ptr(), ksel.data_ptr(),
               GU.data_ptr(), HA.data_ptr(), HB.data_ptr(), partT.data_ptr(), Rpart.data_ptr())
-        if not wg_fused:
+        if not wg_fused and need_w:
             _call("apn_sa_wide_wgrad", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
                   tmap.data_ptr(), pack1.data_ptr(), goa.data_ptr(), ksel.data_ptr(), splits, Rpart.data_ptr())
-        R = _colsum(Rpart)
+        # (no weight needs a gradient: the weight-gradient pass and its fold are skipped, dL/dW2 below is unused)
+        R = _colsum(Rpart) if need_w else torch.zeros(rows * H + H, dtype=torch.float64, device=dev)
         sT = reduced(partT) if sync else None
         g_ws = g_bs = None
         if fusedd:
@@ -334,7 +336,8 @@ class _WideBlock(torch.autograd.Function):
         else:
             D2, E2 = d2e2[:O], d2e2[O:]
             Rm, suma = R[:rows * H].view(rows, H), R[rows * H:]
-            g_w2 = (Rm[:O] + D2.double()[:, None] * (W2.double() @ Rm[O:]) + E2.double()[:, None] * suma[None, :]).float()
+            g_w2 = ((Rm[:O] + D2.double()[:, None] * (W2.double() @ Rm[O:]) + E2.double()[:, None] * suma[None, :]).float()
+                    if need_w else None)
             _call("apn_sa_wide_consts1", dev, None if sync else partT.data_ptr(), grid, _fz._ptr(sT), H,
                   pack1.data_ptr(), count, 1 if tr1 else 0, cabc.data_ptr(), g_gamma1.data_ptr(), g_beta1.data_ptr())
             G = torch.empty(B, N, H, **f32)
@@ -346,10 +349,14 @@ class _WideBlock(torch.autograd.Function):
             g_f = torch.matmul(G, W1f).transpose(1, 2).contiguous()              # (B,C,N)
             g_p = torch.matmul(G, W1p) / radius if need_p else None
             g_q = -torch.matmul(Hq, W1p) / radius if need_q else None
-            g_w1f = torch.matmul(G.reshape(B * N, H).t(), f.transpose(1, 2).reshape(B * N, C))
-            g_w1p = (torch.matmul(G.reshape(B * N, H).t(), p.reshape(B * N, 3))
-                     - torch.matmul(Hq.reshape(B * M, H).t(), new_p.reshape(B * M, 3))) / radius
-            g_w1 = torch.cat([g_w1p, g_w1f], 1).view(H, C + 3, 1, 1)
+            g_w1 = None
+            if need_w:
+                g_w1f = torch.matmul(G.reshape(B * N, H).t(), f.transpose(1, 2).reshape(B * N, C))
+                g_w1p = (torch.matmul(G.reshape(B * N, H).t(), p.reshape(B * N, 3))
+                         - torch.matmul(Hq.reshape(B * M, H).t(), new_p.reshape(B * M, 3))) / radius
+                g_w1 = torch.cat([g_w1p, g_w1f], 1).view(H, C + 3, 1, 1)
+        if not need_w:
+            return (g_p, g_q, g_f) + (None,) * 9
         return (g_p, g_q, g_f, g_w1, g_gamma1 if a1 else None, g_beta1 if a2 else None,
                 g_w2.view(O, H, 1, 1), g_gamma2 if a3 else None, g_beta2 if a4 else None, g_ws, g_bs, None)
 

@@ -14,6 +14,8 @@ loading, logging, checkpointing or epoch control:
 Hyper-parameters default to cfgs/scanobjectnn/pointnext-s_adaptpoint_1.yaml:63-71 and
 cfgs/scanobjectnn/default.yaml:36-56.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -70,21 +72,40 @@ class ClassifierStep:
         return logits, loss
 
 
-def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=True):
+class _frozen:
+    """Parameters of `module` without requires_grad inside the block: a graph recorded there holds no gradient
+    path to them, so the backward passes of the fused blocks skip their weight-gradient kernels (the reference's
+    `g_loss.backward()` computes the classifier's weight gradients and discards them, train_autoaug.py:165-170)."""
+
+    def __init__(self, module):
+        self.params = [q for q in module.parameters() if q.requires_grad]
+
+    def __enter__(self):
+        for q in self.params:
+            q.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for q in self.params:
+            q.requires_grad_(True)
+
+
+def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=True, frozen=False):
     """ganloss_cls.py:31-65: how much harder the augmented clouds are than the real ones for the
     CURRENT classifier, pulled towards `hard_ratio`: |1 - exp(L(fake) - hard_ratio * L(real))|.
     The classifier runs in eval mode (running BatchNorm statistics, no dropout), so every cloud
     is processed independently of its batch: `batched` stacks fake and real into ONE 2B pass
     (their FPS chains then run side by side) with the same result per cloud.
-    `real` / `fake`: dicts with 'pos' (B,N,3) and 'x' (B,C,N)."""
+    `real` / `fake`: dicts with 'pos' (B,N,3) and 'x' (B,C,N).  frozen: only the inputs receive gradients (what
+    the generator step needs)."""
     classifier.eval()
-    if batched:
-        both = classifier({'pos': torch.cat([fake['pos'], real['pos']], 0),
-                           'x': torch.cat([fake['x'], real['x']], 0)})
-        pred_fake, pred_real = both.chunk(2, 0)
-    else:
-        pred_fake = classifier(fake)
-        pred_real = classifier(real)
+    with (_frozen(classifier) if frozen else contextlib.nullcontext()):
+        if batched:
+            both = classifier({'pos': torch.cat([fake['pos'], real['pos']], 0),
+                               'x': torch.cat([fake['x'], real['x']], 0)})
+            pred_fake, pred_real = both.chunk(2, 0)
+        else:
+            pred_fake = classifier(fake)
+            pred_real = classifier(real)
     loss_fake = criterion(pred_fake, label.long())
     loss_real = criterion(pred_real, label.long())
     return torch.abs(1 - torch.exp(loss_fake - hard_ratio * loss_real)), loss_fake, loss_real
@@ -145,7 +166,7 @@ class GanStep:
             fake = {'pos': gen, 'x': torch.cat([gen, tail], -1).transpose(1, 2).contiguous()}
             real = {'pos': xyz, 'x': points[:, :, :self.in_channels].transpose(1, 2).contiguous()}
             fb, _, _ = feedback_loss(self.C, self.criterion, real, fake, label, self.hard_ratio,
-                                     self.batched_feedback)
+                                     self.batched_feedback, frozen=True)
             g_loss = g_raw + fb * self.feedback_ratio
         self.opt_g.zero_grad()
         torch.autograd.backward(g_loss, inputs=[q for q in G.parameters() if q.requires_grad])

@@ -22,21 +22,18 @@ step = GanStep(G, D, C, SmoothCrossEntropy(0.3), batched_feedback=True, capturab
 for _ in range(3):
     step(points, label, device_noise=True)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=False) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(points, label, device_noise=True)
     torch.cuda.synchronize()
-evs = prof.key_averages(group_by_stack_n=6)
 rows = []
-for e in evs:
+for e in prof.key_averages(group_by_input_shape=True):
     dt = getattr(e, "self_device_time_total", None)
     if dt is None:
         dt = getattr(e, "self_cuda_time_total", 0)
-    if dt <= 0:
+    if dt <= 0 or not e.key.startswith("aten::"):
         continue
-    frames = [f for f in e.stack if "adaptpoint_amd" in f or "scripts/" in f]
-    rows.append((dt, e.count, e.key, frames[0] if frames else (e.stack[0] if e.stack else "")))
+    rows.append((dt, e.count, e.key, str(e.input_shapes)[:110]))
 rows.sort(reverse=True)
-tot = sum(r[0] for r in rows)
-print(f"total self device time {tot / 1e3:.2f} ms over {sum(r[1] for r in rows)} op calls")
-for dt, cnt, key, fr in rows[:70]:
-    print(f"{dt / 1e3:8.3f} ms {cnt:4d}x  {key[:38]:38s} {fr[-90:]}")
+print(f"aten ops with device time: {sum(r[0] for r in rows) / 1e3:.2f} ms over {sum(r[1] for r in rows)} calls")
+for dt, cnt, key, shp in rows[:90]:
+    print(f"{dt / 1e3:8.3f} ms {cnt:4d}x  {key[:30]:30s} {shp}")
