@@ -104,6 +104,8 @@ SIGNATURES = {
     "apn_pw_conv_grad_input": [_c_int] * 5 + [_c_void_p] * 4,
     "apn_pw_conv_grad_weight_splits": [_c_int] * 4,
     "apn_pw_conv_grad_weight": [_c_int] * 5 + [_c_void_p] * 5,
+    "apn_anchor_transforms": [_c_int] + [_c_void_p] * 3 + [_c_float] * 3 + [_c_void_p] * 3,
+    "apn_anchor_transforms_grad": [_c_int] + [_c_void_p] * 3 + [_c_float] * 3 + [_c_void_p] * 4,
     "apn_pw_conv_max_tiles": [_c_int],
     "apn_pw_conv_max_forward": [_c_int] * 5 + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 5,
     "apn_pw_conv_max_backward": [_c_int] * 4 + [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 5,

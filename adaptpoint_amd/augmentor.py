@@ -28,6 +28,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from .fused import _call
 from .imitator import SAComponent, index_points
 from .layers import furthest_point_sample
 
@@ -76,7 +77,42 @@ def draw_noise_on(device, batch, n_points, n_anchor):
     return Noise(keep, axes, kernel_axes, expo)
 
 
+class _AnchorTransforms(torch.autograd.Function):
+    """csrc/augment.hip: one launch forward, one backward, for what the composed form below spends ~40 + ~40 on."""
+
+    @staticmethod
+    def forward(ctx, prob, keep, axes, ranges):
+        prob = prob.contiguous()
+        n = prob.numel() // 9
+        lin = torch.empty(*prob.shape[:-1], 3, 3, device=prob.device)
+        off = torch.empty(*prob.shape[:-1], 3, device=prob.device)
+        _call("apn_anchor_transforms", prob.device, n, prob.data_ptr(), keep.data_ptr(), axes.data_ptr(), *ranges,
+              lin.data_ptr(), off.data_ptr())
+        ctx.save_for_backward(prob, keep, axes)
+        ctx.ranges = ranges
+        return lin, off
+
+    @staticmethod
+    def backward(ctx, g_lin, g_off):
+        prob, keep, axes = ctx.saved_tensors
+        g = torch.empty_like(prob)
+        _call("apn_anchor_transforms_grad", prob.device, prob.numel() // 9, prob.data_ptr(), keep.data_ptr(),
+              axes.data_ptr(), *ctx.ranges, g_lin.contiguous().data_ptr() if g_lin is not None else None,
+              g_off.contiguous().data_ptr() if g_off is not None else None, g.data_ptr())
+        return g, None, None, None
+
+
 def anchor_transforms(prob, noise, r_range, s_range, t_range):
+    """prob (B,M,9) -> A (B,M,3,3) = R diag(s) and t (B,M,3)   (:236-297): the extension's kernel on the GPU, the
+    composed PyTorch form elsewhere."""
+    if prob.is_cuda and prob.dtype == torch.float32:
+        keep = noise.keep.to(prob.dtype).contiguous()
+        axes = noise.axes.to(prob.dtype).contiguous()
+        return _AnchorTransforms.apply(prob, keep, axes, (float(r_range), float(s_range), float(t_range)))
+    return anchor_transforms_composed(prob, noise, r_range, s_range, t_range)
+
+
+def anchor_transforms_composed(prob, noise, r_range, s_range, t_range):
     """prob (B,M,9) -> A (B,M,3,3) = R diag(s) and t (B,M,3)   (:236-297).
     Rotation angles tanh(.) * r_range degrees, scales 1 + sigmoid(.) * (s_range - 1), offsets
     tanh(.) * t_range; each of the three switched per anchor by `keep`, scale and offset confined

@@ -520,6 +520,16 @@ APN_API int apn_pw_conv_grad_weight_splits(int b, int c_in, int c_out, int n);
 APN_API int apn_pw_conv_grad_weight(int b, int c_in, int c_out, int n, int precision, const float *gy, const float *x,
                                     float *scratch, float *gw, void *stream);
 
+/* the per-anchor transforms of AdaptPoint_Augmentor.local_transformaton
+ * (openpoints/models_adaptpoint/generator_component4_15.py:236-297): prob (n,9) the imitator's numbers per anchor,
+ * keep (n,3) / axes (n,3) the call's random switches as floats -> lin (n,3,3) = R diag(s), off (n,3); formulas in
+ * csrc/augment.hip.  _grad: g_prob (n,9) from g_lin (n,3,3) and g_off (n,3) (either may be NULL = zero). */
+APN_API int apn_anchor_transforms(int n, const float *prob, const float *keep, const float *axes, float r_range,
+                                  float s_range, float t_range, float *lin, float *off, void *stream);
+APN_API int apn_anchor_transforms_grad(int n, const float *prob, const float *keep, const float *axes, float r_range,
+                                       float s_range, float t_range, const float *g_lin, const float *g_off,
+                                       float *g_prob, void *stream);
+
 /* The last layer of the discriminator's group-all stage with its pooling
  * (openpoints/models_adaptpoint/point_discriminator.py:183-189: conv -> ReLU -> max over the cloud's points), fused:
  *   out (B,c_out) = [relu](max_n (w x_b)[o][n] + bias[o]),  idx (B,c_out) int32 = the position of that maximum (the

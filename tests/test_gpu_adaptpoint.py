@@ -268,3 +268,25 @@ def test_feature_propagation_and_decoder_match_reference(dev, golden_ap, oracle)
     seg = PointNextDecoder([q.shape[1] for q in f[1:]], in_channels=4).to(dev).train()
     o = seg(p[1:], f[1:])
     assert o.shape == (2, 32, 4096) and torch.isfinite(o).all()
+
+
+def test_anchor_transforms_kernel_matches_composed_form(dev):
+    """csrc/augment.hip (one launch each way) against the composed PyTorch form in float64
+    (generator_component4_15.py:236-297): matrices, offsets and the gradient w.r.t. the imitator's numbers, with
+    every switch combination of `keep` and `axes` present (a scale switched off is exactly 1, gradient 0)."""
+    from adaptpoint_amd.augmentor import Noise, anchor_transforms, anchor_transforms_composed
+    B, M = 64, 4
+    g = torch.Generator().manual_seed(7)
+    prob = (2.0 * torch.randn(B, M, 9, generator=g)).to(dev).requires_grad_(True)
+    noise = Noise(keep=torch.bernoulli(torch.full((B, M, 3), 0.5), generator=g),
+                  axes=torch.randint(0, 2, (B, M, 3), generator=g).int(), kernel_axes=torch.ones(B, 1, 3).int()).to(dev)
+    g_lin = torch.randn(B, M, 3, 3, generator=g).to(dev)
+    g_off = torch.randn(B, M, 3, generator=g).to(dev)
+    p64 = prob.detach().double().requires_grad_(True)
+    lin64, off64 = anchor_transforms_composed(p64, noise, 10, 3, 0.25)
+    ((lin64 * g_lin.double()).sum() + (off64 * g_off.double()).sum()).backward()
+    lin, off = anchor_transforms(prob, noise, 10, 3, 0.25)
+    ((lin * g_lin).sum() + (off * g_off).sum()).backward()
+    host = lambda t: t.detach().cpu().numpy()
+    assert rel(lin, host(lin64)) < 1e-6 and rel(off, host(off64)) < 1e-6
+    assert rel(prob.grad, host(p64.grad)) < 1e-5
