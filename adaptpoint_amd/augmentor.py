@@ -102,10 +102,10 @@ class _AnchorTransforms(torch.autograd.Function):
         return g, None, None, None
 
 
-def anchor_transforms(prob, noise, r_range, s_range, t_range):
+def anchor_transforms(prob, noise, r_range, s_range, t_range, fused=True):
     """prob (B,M,9) -> A (B,M,3,3) = R diag(s) and t (B,M,3)   (:236-297): the extension's kernel on the GPU, the
     composed PyTorch form elsewhere."""
-    if prob.is_cuda and prob.dtype == torch.float32:
+    if fused and prob.is_cuda and prob.dtype == torch.float32:
         keep = noise.keep.to(prob.dtype).contiguous()
         axes = noise.axes.to(prob.dtype).contiguous()
         return _AnchorTransforms.apply(prob, keep, axes, (float(r_range), float(s_range), float(t_range)))
@@ -163,6 +163,7 @@ class AdaptPointAugmentor(nn.Module):
         self.num_anchor = w_num_anchor
         self.sigma = w_sigma
         self.w_R_range, self.w_S_range, self.w_T_range = w_R_range, w_S_range, w_T_range
+        self.fused = fused
         self.predict_prob_layer = SAComponent(fused=fused)
 
     def forward(self, xyz, noise: Optional[Noise] = None):
@@ -180,7 +181,7 @@ class AdaptPointAugmentor(nn.Module):
             noise.gumbel_expo = expo
         noise = noise.to(xyz.device)
         mask = self.predict_prob_layer.hard_mask(logits, noise.gumbel_expo)
-        lin, off = anchor_transforms(prob, noise, self.w_R_range, self.w_S_range, self.w_T_range)
+        lin, off = anchor_transforms(prob, noise, self.w_R_range, self.w_S_range, self.w_T_range, self.fused)
         w = kernel_weights(xyz, anchors, noise.kernel_axes, self.sigma)
         out = unit_sphere(deform(xyz, anchors, lin, off, w))
         return xyz, out * mask[:, :, 0:1]

@@ -564,13 +564,33 @@ __global__ __launch_bounds__(256) void pw_pool_grad_points_kernel(int C, int O, 
     }
     const int half = __builtin_amdgcn_readfirstlane(tid >> 7), c = tid & 127, total = nhits;
     float *mine = acc + half * 64 * ld;
-    for (int k = half; k < total; k += 2) {
-        const int o = hits[k] & 0xffffff, at = hits[k] >> 24;
-        const float gv = g_out[(size_t)b * O + o];
-        const float gp = (!relu || out[(size_t)b * O + o] > 0.0f) ? gv : 0.0f;
-        if (c < C) {
-            xsel[((size_t)b * O + o) * C + c] = xt[at * ld + c];
-            if (g_x) mine[at * ld + c] = __builtin_fmaf(w[(size_t)o * C + c], gp, mine[at * ld + c]);
+    // four list entries per round: their loads (gradient, weight row) are independent and issued together, the LDS
+    // updates follow in list order (one entry at a time paid a global round trip each: 110 us)
+    for (int k0 = half; k0 < total; k0 += 8) {
+        int o[4], at[4];
+        float gp[4], wv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + 2 * j;
+            const int h = k < total ? hits[k] : -1;
+            o[j] = h < 0 ? -1 : (h & 0xffffff);
+            at[j] = h < 0 ? 0 : (h >> 24);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            gp[j] = 0.0f; wv[j] = 0.0f;
+            if (o[j] >= 0) {
+                const float gv = g_out[(size_t)b * O + o[j]];
+                gp[j] = (!relu || out[(size_t)b * O + o[j]] > 0.0f) ? gv : 0.0f;
+                if (c < C && g_x) wv[j] = w[(size_t)o[j] * C + c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (o[j] >= 0 && c < C) {
+                xsel[((size_t)b * O + o[j]) * C + c] = xt[at[j] * ld + c];
+                if (g_x) mine[at[j] * ld + c] = __builtin_fmaf(wv[j], gp[j], mine[at[j] * ld + c]);
+            }
         }
     }
     if (!g_x) return;

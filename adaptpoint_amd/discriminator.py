@@ -18,8 +18,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from torch.nn.utils.parametrizations import spectral_norm as _torch_spectral_norm
+
 from . import pointwise
-from .spectral import spectral_norm        # torch's parametrisation, evaluated by csrc/spectral.hip on the GPU
+from .spectral import spectral_norm as _fused_spectral_norm    # torch's parametrisation on csrc/spectral.hip
 
 
 class _GroupAllStage(nn.Module):
@@ -29,6 +31,7 @@ class _GroupAllStage(nn.Module):
     def __init__(self, in_channel, mlp, fused=True):
         super().__init__()
         self.fused = fused
+        spectral_norm = _fused_spectral_norm if fused else _torch_spectral_norm
         self.mlp_convs = nn.ModuleList()
         self.mlp_bns = nn.ModuleList()
         for out_channel in mlp:
@@ -38,10 +41,19 @@ class _GroupAllStage(nn.Module):
     def forward(self, xyz):
         """xyz (B,3,N) -> (B,C_last): the reference's (B,3,N,1) layout is (B,3,N) with a unit
         trailing axis; the max over the "nsample" axis (:189) is the max over the points."""
+        last = self.mlp_convs[-1]
+        if self.fused and pointwise.conv_max_supported(xyz, xyz.shape[1]):
+            # every layer on the contraction kernels of csrc/pointwise.hip (each spectral-normalised `weight` is
+            # read ONCE: a read in training mode is a power iteration); the last one fused with the pooling
+            x = xyz
+            for conv in self.mlp_convs[:-1]:
+                x = pointwise.conv_bias_act(x, conv.weight, conv.bias, relu=True)
+            if pointwise.conv_max_supported(x, last.in_channels):
+                return pointwise.conv_max(x, last.weight, last.bias, relu=True)
+            return F.relu(last(x.unsqueeze(-1))).amax(dim=2).squeeze(-1)
         x = xyz.unsqueeze(-1)
         for conv in self.mlp_convs[:-1]:
             x = F.relu(conv(x))
-        last = self.mlp_convs[-1]
         if self.fused and pointwise.conv_max_supported(x.squeeze(-1), last.in_channels):
             # convolution + ReLU + max in one pass: the (B, 1024, N) activation is never written, the backward
             # touches one position per (cloud, channel).  (`last.weight` is read ONCE: every read of a
@@ -59,6 +71,7 @@ class PointDiscriminator1(nn.Module):
             raise NotImplementedError("normal channels are not used by the AdaptPoint configs")
         self.normal_channel = False
         self.sa1 = _GroupAllStage(3, [64, 128, 1024], fused=fused)
+        spectral_norm = _fused_spectral_norm if fused else _torch_spectral_norm
         self.fc1 = spectral_norm(nn.Linear(1024, 512))
         self.drop1 = nn.Dropout(0.4)
         self.fc2 = spectral_norm(nn.Linear(512, 256))

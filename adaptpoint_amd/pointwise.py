@@ -95,6 +95,29 @@ class _ConvBNAct(torch.autograd.Function):
         return gx, gw, (ggb[0] if has_gamma else None), (ggb[1] if has_beta else None), None, None
 
 
+class _NoNorm:
+    """What `_ConvBNAct` reads of a BatchNorm module, set so that the normalisation is the identity in eval mode
+    (mean 0, variance 1, eps 0, no scale): the layer is then convolution + bias (+ ReLU)."""
+    training = False
+    track_running_stats = True
+    momentum = 0.0
+    eps = 0.0
+    num_batches_tracked = None
+    _cache = {}
+
+    def __init__(self, channels, device):
+        key = (channels, str(device))
+        if key not in _NoNorm._cache:
+            _NoNorm._cache[key] = (torch.zeros(channels, device=device), torch.ones(channels, device=device))
+        self.running_mean, self.running_var = _NoNorm._cache[key]
+
+
+def conv_bias_act(x, weight, bias=None, relu=True):
+    """[relu](weight x + bias) for x (B, C, N) and a kernel-1 weight (O, C[, 1[, 1]]) on the contraction kernels
+    (the discriminator's per-point layers, point_discriminator.py:183-187, which carry no BatchNorm)."""
+    return _ConvBNAct.apply(x, weight, None, bias, _NoNorm(weight.shape[0], x.device), relu)
+
+
 def conv_bn_act(x, conv, bn, relu=True):
     """relu(bn(conv(x))) for a kernel-1 bias-free `conv` (nn.Conv1d) and `bn` (nn.BatchNorm1d) on x (B, C, N)."""
     return _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, bn, relu)

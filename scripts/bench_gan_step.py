@@ -59,7 +59,7 @@ def main():
         fused = mode == "fused"
         torch.manual_seed(0)
         G = AdaptPointAugmentor(fused=fused).to(dev)
-        D = PointDiscriminator1(num_classes=15).to(dev)
+        D = PointDiscriminator1(num_classes=15, fused=fused).to(dev)
         C = PointNextSClassifier(fused=fused).to(dev)
         step = GanStep(G, D, C, SmoothCrossEntropy(0.3), batched_feedback=fused, capturable=a.graph)
         run = lambda: step(points, label)

@@ -165,7 +165,7 @@ def test_gan_step_matches_reference_trainer(dev, golden_ap, fused):
     from adaptpoint_amd.gan import GanStep
     from adaptpoint_amd.pointnext import PointNextSClassifier, SmoothCrossEntropy, fill_parameters_by_name
     G = fill_parameters_by_name(AdaptPointAugmentor(fused=fused)).to(dev)
-    D = no_dropout(fill_parameters_by_name(PointDiscriminator1(num_classes=15))).to(dev)
+    D = no_dropout(fill_parameters_by_name(PointDiscriminator1(num_classes=15, fused=fused))).to(dev)
     C = fill_parameters_by_name(PointNextSClassifier(fused=fused)).to(dev)
     pos = torch.from_numpy(GI.unit_sphere_cloud(2, 512, seed=111))
     points = torch.cat([pos, height_channel(pos)], -1).to(dev)
