@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void pw_pool_finish_kernel(int total, int O, i
 // took 147 us), then walks the list -- entries alternately by threads 0-127 and 128-255, one LDS accumulator tile each,
 // added at the end: fixed orders, no atomics -- adding w[o][:] * gp to that position's column of g_x and copying the
 // position's input column to xsel[b][o][:] for part 2.
-// LDS: xt [64][C + 1] | acc [2][64][C + 1] | hits [O] ints
+// LDS: xt [64][C + 1] | acc [2][64][C + 1] | hits [O] ints | the hits' gradients [O]
 __global__ __launch_bounds__(256) void pw_pool_grad_points_kernel(int C, int O, int N, const float *__restrict__ x,
                                                                   const float *__restrict__ w,
                                                                   const float *__restrict__ g_out,
@@ -542,6 +542,7 @@ __global__ __launch_bounds__(256) void pw_pool_grad_points_kernel(int C, int O, 
     const int ld = C + 1, n0 = blockIdx.x * 64, b = blockIdx.y, tid = threadIdx.x;
     float *xt = pool_sm, *acc = pool_sm + 64 * ld;
     int *hits = reinterpret_cast<int *>(pool_sm + 3 * 64 * ld);
+    float *hitg = pool_sm + 3 * 64 * ld + O;
     const int p = tid & 63, cg = tid >> 6;
     const float *xb = x + (size_t)b * C * N;
     for (int c = cg; c < C; c += 4) xt[p * ld + c] = n0 + p < N ? xb[(size_t)c * N + n0 + p] : 0.0f;
@@ -557,7 +558,13 @@ __global__ __launch_bounds__(256) void pw_pool_grad_points_kernel(int C, int O, 
         __syncthreads();
         int before = nhits;
         for (int k = 0; k < cg; ++k) before += wave_count[k];
-        if (hit) hits[before + __popcll(m & ((1ull << p) - 1ull))] = o | (at << 24);
+        if (hit) {
+            // the entry's gradient through the ReLU, fetched here by the thread that found it (all entries at once)
+            const int slot = before + __popcll(m & ((1ull << p) - 1ull));
+            const float gv = g_out[(size_t)b * O + o];
+            hits[slot] = o | (at << 24);
+            hitg[slot] = (!relu || out[(size_t)b * O + o] > 0.0f) ? gv : 0.0f;
+        }
         __syncthreads();
         if (tid == 0) nhits += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
         __syncthreads();
@@ -580,8 +587,7 @@ __global__ __launch_bounds__(256) void pw_pool_grad_points_kernel(int C, int O, 
         for (int j = 0; j < 4; ++j) {
             gp[j] = 0.0f; wv[j] = 0.0f;
             if (o[j] >= 0) {
-                const float gv = g_out[(size_t)b * O + o[j]];
-                gp[j] = (!relu || out[(size_t)b * O + o[j]] > 0.0f) ? gv : 0.0f;
+                gp[j] = hitg[k0 + 2 * j];
                 if (c < C && g_x) wv[j] = w[(size_t)o[j] * C + c];
             }
         }
@@ -791,7 +797,7 @@ extern "C" int apn_pw_conv_max_backward(int b, int c_in, int c_out, int n, const
         !xsel || !g_w)
         return APN_EINVAL;
     if (c_out >= (1 << 24)) return APN_EINVAL;
-    const size_t lds = ((size_t)3 * 64 * (c_in + 1) + c_out) * sizeof(float);
+    const size_t lds = ((size_t)3 * 64 * (c_in + 1) + 2 * (size_t)c_out) * sizeof(float);
     if (hipError_t e = hipFuncSetAttribute((const void *)pw_pool_grad_points_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
         return (int)e;
