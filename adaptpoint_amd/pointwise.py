@@ -30,12 +30,36 @@ PRECISION = 3
 def supported(x, conv, bn):
     """Shapes / modes the kernels serve: float32 CUDA, contiguous (B, C, N), kernel 1, no bias, a BatchNorm1d with a
     numeric momentum (the cumulative-average mode of momentum=None stays on PyTorch)."""
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[0] <= 65535
-            and x.shape[0] > 0 and x.shape[2] > 0
-            and conv.kernel_size == (1,) and conv.stride == (1,) and conv.padding == (0,) and conv.groups == 1
-            and conv.dilation == (1,) and conv.bias is None and conv.weight.dtype == torch.float32
+    return (_pointwise_conv(x, conv) and conv.bias is None
             and (bn.momentum is not None or not bn.training)
             and (bn.training or bn.track_running_stats))
+
+
+def _pointwise_conv(x, conv):
+    """x (B, C, N) float32 on the GPU and `conv` a plain 1x1 convolution (Conv1d, or Conv2d as the reference's
+    grouped stages hold them: a (B, C, 1, N) tensor is the same memory)."""
+    one = lambda t, v: all(k == v for k in t)
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and 0 < x.shape[0] <= 65535 and x.shape[2] > 0
+            and one(conv.kernel_size, 1) and one(conv.stride, 1) and one(conv.padding, 0) and one(conv.dilation, 1)
+            and conv.groups == 1 and conv.weight.dtype == torch.float32 and conv.in_channels == x.shape[1])
+
+
+def run_block(x, block, allow=True):
+    """One `convblock` of the PointNeXt mirror -- Sequential(conv[, BatchNorm][, ReLU]) with a 1x1 convolution -- on
+    x (B, C, N): through the contraction kernels where they apply, else through the modules themselves."""
+    mods = list(block)
+    conv = mods[0]
+    bn = mods[1] if len(mods) > 1 and isinstance(mods[1], (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)) else None
+    relu = isinstance(mods[-1], torch.nn.ReLU)
+    known = len(mods) == 1 + (bn is not None) + relu
+    if allow and known and _pointwise_conv(x, conv):
+        if bn is not None and supported(x, conv, bn):
+            return _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, bn, relu)
+        if bn is None:
+            return conv_bias_act(x, conv.weight, conv.bias, relu)
+    if isinstance(conv, torch.nn.Conv2d):
+        return block(x.unsqueeze(2)).squeeze(2)
+    return block(x)
 
 
 class _ConvBNAct(torch.autograd.Function):

@@ -13,7 +13,7 @@ import logging
 import torch
 import torch.nn as nn
 
-from . import layers
+from . import layers, pointwise
 from .layers import BallGrouper, make_grouper
 
 _log = logging.getLogger("adaptpoint_amd")
@@ -204,7 +204,8 @@ class SetAbstraction(nn.Module):
                                    relu=(skip is not None) or relu_after, sync_bn=self.sync_bn)
             return new_p, out
         pooled = fused_wide.block(p, new_p, f, nbr, g.radius, conv1, bn1, conv2, bn2, relu=False, sync_bn=self.sync_bn)
-        identity = skip(torch.gather(f, -1, smp.fidx.long().unsqueeze(1).expand(-1, C, -1)))
+        identity = pointwise.run_block(torch.gather(f, -1, smp.fidx.long().unsqueeze(1).expand(-1, C, -1)),
+                                       self.skipconv)
         return new_p, self.act(pooled + identity)
 
     def sample_many(self, ps, outs=None):
@@ -269,7 +270,9 @@ class SetAbstraction(nn.Module):
     def forward(self, pf, sampling=None):
         p, f = pf
         if self.is_head:
-            return p, self.convs(f)
+            for blk in self.convs:                      # the stem: a 1x1 convolution (csrc/pointwise.hip when fused)
+                f = pointwise.run_block(f, blk, self.fused)
+            return p, f
         if self.fused and not self.all_aggr:
             res = self._fused_block(p, f, sampling)
             if res is None:
@@ -295,7 +298,16 @@ class SetAbstraction(nn.Module):
                 _note_fallback(f"C_in={f.shape[1]} -> {[c[0].out_channels for c in self.convs]}, "
                                f"K={getattr(self.grouper, 'nsample', None)}: no fused kernel for this shape")
             dp, fj = self.grouper(new_p, p, f, idx) if idx is not None else self.grouper(new_p, p, f)
-            pooled = self.pool(self.convs(torch.cat([dp, fj], 1)))       # 'dp_fj' (group.py:325-326)
+            x = torch.cat([dp, fj], 1)                                   # 'dp_fj' (group.py:325-326)
+            if self.fused and self.all_aggr and x.shape[2] == 1:
+                # group-all: the "grouped" tensor is (B, C, 1, N) = the points themselves; its 1x1 layers run on
+                # the per-point contraction kernels
+                x = x.squeeze(2)
+                for blk in self.convs:
+                    x = pointwise.run_block(x, blk)
+                pooled = self.pool(x).unsqueeze(-1)
+            else:
+                pooled = self.pool(self.convs(x))
         if identity is not None:
             pooled = self.act(pooled + identity)
         return new_p, pooled
