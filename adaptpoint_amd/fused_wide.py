@@ -21,7 +21,7 @@ gradients of gamma/beta reported as global / world -- see adaptpoint_amd.fused).
 """
 import torch
 
-from . import _lib
+from . import _lib, pointwise
 from . import fused as _fz
 from .fused import _call
 
@@ -280,7 +280,8 @@ class _WideBlock(torch.autograd.Function):
         else:
             _call("apn_sa_wide_consts2", dev, None if sync else partS.data_ptr(), prow, _fz._ptr(sS), O,
                   pack2.data_ptr(), count, 1 if tr2 else 0, d2e2.data_ptr(), g_gamma2.data_ptr(), g_beta2.data_ptr())
-            Qm = torch.matmul(W2.t() * d2e2[:O], W2)                              # W2^T diag(D2) W2  (H,H)
+            W2t = W2.t().contiguous()
+            Qm = pointwise.matmul_nt(W2t * d2e2[:O], W2t)                         # W2^T diag(D2) W2  (H,H)
             torch.mv(W2.t(), d2e2[O:], out=evec)
             zimg = _image(W2, O, False, Qm, O + H, H, min(4, H // 32))           # [W2 ; Qm]  ((O+H) x H)
         grid = lib.apn_sa_wide_grid(B, M)

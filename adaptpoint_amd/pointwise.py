@@ -196,3 +196,19 @@ def conv_max(x, weight, bias=None, relu=True):
     layer of the discriminator's group-all stage with its pooling (point_discriminator.py:183-189), without the
     (B, O, N) activation.  Also returns nothing else: the arg-max positions stay inside the autograd node."""
     return _ConvMax.apply(x, weight, bias, relu)[0]
+
+
+def matmul_nt(a, b):
+    """a (R, K) @ b (Q, K)^T -> (R, Q) on the contraction kernel in its split-K form (both operands contiguous along
+    the contracted index; fixed-order fold).  For the small products of the fused blocks' backward passes whose
+    shapes PyTorch's GEMM library serves badly (a 256 x 512 x 256 product ran as ONE workgroup, 122 us)."""
+    a, b = a.contiguous(), b.contiguous()
+    R, K = a.shape
+    Q = b.shape[0]
+    lib = _lib.load()
+    splits = lib.apn_pw_conv_grad_weight_splits(1, Q, R, K)
+    scratch = torch.empty(splits, R, Q, device=a.device)
+    out = torch.empty(R, Q, device=a.device)
+    _call("apn_pw_conv_grad_weight", a.device, 1, Q, R, K, PRECISION, a.data_ptr(), b.data_ptr(), scratch.data_ptr(),
+          out.data_ptr())
+    return out
