@@ -127,8 +127,12 @@ class GanStep:
 
     def __init__(self, generator, discriminator, classifier, criterion, lr_generator=1e-4,
                  lr_discriminator=4e-4, betas=(0.5, 0.999), hard_ratio=3.0, feedback_ratio=1.0,
-                 in_channels=4, batched_feedback=True, capturable=False):
+                 in_channels=4, batched_feedback=True, capturable=False, grad_sync=None):
         self.G, self.D, self.C = generator, discriminator, classifier
+        # grad_sync(list of .grad tensors): called before each optimizer step -- under data parallelism
+        # `adaptpoint_amd.dp.allreduce_mean_`, what the reference's DistributedDataParallel wrappers of the
+        # generator and the discriminator do (train_autoaug.py:98-102; their BatchNorm stays per rank)
+        self.grad_sync = grad_sync
         self.criterion = criterion
         # capturable: optimizer state on the device, so that the whole step can be a hipGraph -- and PyTorch's
         # fused multi-tensor Adam (one launch per ~parameter group instead of ~15 foreach launches: 1.4 -> 0.2 ms
@@ -170,6 +174,8 @@ class GanStep:
             g_loss = g_raw + fb * self.feedback_ratio
         self.opt_g.zero_grad()
         torch.autograd.backward(g_loss, inputs=[q for q in G.parameters() if q.requires_grad])
+        if self.grad_sync is not None:
+            self.grad_sync([q.grad for q in G.parameters() if q.grad is not None])
         self.opt_g.step()
 
         # ---- discriminator (two forwards, as the reference: each is one spectral-norm power iteration)
@@ -178,6 +184,8 @@ class GanStep:
         d_loss = (real_loss + fake_loss) / 2
         self.opt_d.zero_grad()
         d_loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync([q.grad for q in D.parameters() if q.grad is not None])
         self.opt_d.step()
         return {'g_loss_raw': g_raw.detach(), 'feedback_loss': None if fb is None else fb.detach(),
                 'g_loss': g_loss.detach(), 'd_loss': d_loss.detach(), 'gen': gen.detach()}
