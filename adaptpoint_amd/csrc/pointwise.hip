@@ -809,3 +809,50 @@ extern "C" int apn_pw_conv_max_backward(int b, int c_in, int c_out, int n, const
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
+
+// The contraction kernel itself, for the small dense products around the fused set-abstraction blocks (their
+// PyTorch forms are skinny or oddly shaped GEMMs the vendor library serves at 40-120 us apiece):
+//   splits == 0:  D[z] (R x Q) = A[z] (R x K) B[z] (K x Q) for z < nbatch  (a batch stride of 0 shares an operand)
+//   splits  > 0:  D (R x Q) = sum_z A[z] B[z], the (z, k) range cut into `splits` shares (scratch [splits][R][Q]) that
+//                 are added in a fixed order.
+// An operand is k-contiguous (element (i, k) at i * ld + k) or row-contiguous (k * ld + i).
+extern "C" int apn_pw_contract_splits(int nbatch, int r, int q, int k) { return apn::pw_weight_splits(nbatch, q, r, k); }
+
+extern "C" int apn_pw_contract(int nbatch, int r, int q, int k, const float *a, long long a_batch, int lda, int a_kcont,
+                               const float *b, long long b_batch, int ldb, int b_kcont, float *d, long long d_batch,
+                               int ldd, int splits, float *scratch, int precision, void *stream) {
+    using namespace apn;
+    if (nbatch <= 0 || r <= 0 || q <= 0 || k <= 0 || nbatch > 65535 || !a || !b || !d || (precision != 2 && precision != 3) ||
+        splits < 0 || (splits > 0 && !scratch))
+        return APN_EINVAL;
+    PwGemm g{};
+    g.A = PwOperand{a, a_batch, lda};
+    g.B = PwOperand{b, b_batch, ldb};
+    g.R = r; g.Q = q; g.K = k;
+    g.cpb = (k + PW_KC - 1) / PW_KC;
+    g.total = nbatch * g.cpb;
+    g.a_vec = a_kcont && pw_vec(a, a_batch, lda, k);
+    g.b_vec = b_kcont && pw_vec(b, b_batch, ldb, k);
+    int nz = nbatch;
+    if (splits > 0) {
+        g.D = scratch; g.d_batch = (long long)r * q; g.ldd = q;
+        g.cps = (g.total + splits - 1) / splits;
+        nz = splits;
+    } else {
+        g.D = d; g.d_batch = d_batch; g.ldd = ldd;
+        g.cps = g.cpb;
+    }
+    const dim3 grid((q + PW_T - 1) / PW_T, (r + PW_T - 1) / PW_T, nz);
+    if (a_kcont && b_kcont) PW_LAUNCH(true, true, grid, g);
+    else if (a_kcont) PW_LAUNCH(true, false, grid, g);
+    else if (b_kcont) PW_LAUNCH(false, true, grid, g);
+    else PW_LAUNCH(false, false, grid, g);
+    if (splits > 0) {
+        const size_t ne = (size_t)r * q;
+        if (ldd != q) return APN_EINVAL;
+        hipLaunchKernelGGL(pw_fold_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(256), 0, (hipStream_t)stream, scratch,
+                           splits, ne, d);
+        APN_LAUNCH_CHECK();
+    }
+    return APN_OK;
+}

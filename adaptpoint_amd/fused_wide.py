@@ -196,9 +196,13 @@ class _WideBlock(torch.autograd.Function):
                       _fz._ptr(nbr.fq if Ws is not None else None), _fz._ptr(fs),
                       _fz._ptr(nbr.geo if part1 is not None else None), _fz._ptr(part1))
             else:
-                W1p, W1f = W1[:, :3], W1[:, 3:]
-                U = torch.baddbmm(torch.matmul(p, W1p.t()) / radius, f.transpose(1, 2), W1f.t().expand(B, C, H)).contiguous()
-                V = (torch.matmul(new_p, W1p.t()) / radius).contiguous()
+                # conv1's input per point, channels-first as W1's columns order it: [p / r ; f]  (B, C + 3, N); then
+                # U[b] (N x H) = X[b]^T W1^T on the per-point contraction kernel, operands read where they lie
+                # (as PyTorch ops: a skinny matmul, a division and a baddbmm of 40 us)
+                X = torch.cat([p.transpose(1, 2) / radius, f], 1)
+                U = torch.empty(B, N, H, **f32)
+                pointwise.contract(B, N, H, C + 3, X, (C + 3) * N, N, False, W1, 0, C + 3, True, U, d_batch=N * H, ldd=H)
+                V = (torch.matmul(new_p, W1[:, :3].t()) / radius).contiguous()
                 w2img = _image(W2, H, True, None, H, O, min(4, O // 32))          # W2^T (H x O)
             grid = _lib.load().apn_sa_wide_grid(B, M)
             count = float(B * M * K_NS)
@@ -221,7 +225,7 @@ class _WideBlock(torch.autograd.Function):
                   _fz._ptr(fs if Ws is not None else None), _fz._ptr(Ws),
                   _fz._ptr(None if bs is None else bs.detach()), 1 if relu else 0, out.data_ptr())
         ctx.save_for_backward(p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2, Ws, out if relu else None,
-                              fs if Ws is not None else None)
+                              fs if Ws is not None else None, None if fusedd else X)
         ctx.nbr = nbr
         ctx.cfg = (radius, tr1, tr2, sync, count, relu, g1 is not None, b1 is not None, g2 is not None, b2 is not None,
                    bs is not None)
@@ -230,7 +234,7 @@ class _WideBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2, Ws, out_act, fs = ctx.saved_tensors
+        p, new_p, f, U, V, pack1, pack2, ysel, ksel, W1, W2, Ws, out_act, fs, X = ctx.saved_tensors
         nbr = ctx.nbr
         idx, tmap = nbr.idx, nbr.tmap
         radius, tr1, tr2, sync, count, relu, a1, a2, a3, a4, a5 = ctx.cfg
@@ -346,16 +350,21 @@ class _WideBlock(torch.autograd.Function):
                   nbr.geo.data_ptr(), W1.data_ptr(), C + 3, float(radius), GU.data_ptr(), nbr.pcnt_poff.data_ptr(),
                   nbr.plist.data_ptr(), G.data_ptr(), HA.data_ptr(), HB.data_ptr())
             Hq = HA
-            W1p, W1f = W1[:, :3], W1[:, 3:]
-            g_f = torch.matmul(G, W1f).transpose(1, 2).contiguous()              # (B,C,N)
+            W1p = W1[:, :3]
+            # dL/df[b] (C x N) = W1f^T G[b]^T and dL/dW1 = sum_b G[b]^T X[b]^T on the contraction kernel (channels-first
+            # results without a transposed copy; the PyTorch forms were five GEMMs of 25-50 us, three of them 3 wide)
+            g_f = torch.empty(B, C, N, **f32)
+            pointwise.contract(B, C, N, H, W1[:, 3:], 0, C + 3, False, G, N * H, H, True, g_f, d_batch=C * N, ldd=N)
             g_p = torch.matmul(G, W1p) / radius if need_p else None
             g_q = -torch.matmul(Hq, W1p) / radius if need_q else None
             g_w1 = None
             if need_w:
-                g_w1f = torch.matmul(G.reshape(B * N, H).t(), f.transpose(1, 2).reshape(B * N, C))
-                g_w1p = (torch.matmul(G.reshape(B * N, H).t(), p.reshape(B * N, 3))
-                         - torch.matmul(Hq.reshape(B * M, H).t(), new_p.reshape(B * M, 3))) / radius
-                g_w1 = torch.cat([g_w1p, g_w1f], 1).view(H, C + 3, 1, 1)
+                g_w1 = torch.empty(H, C + 3, **f32)
+                pointwise.contract(B, H, C + 3, N, G, N * H, H, False, X, (C + 3) * N, N, True, g_w1, reduce=True)
+                gq = torch.empty(H, 3, **f32)          # the queries' share of the coordinate columns
+                pointwise.contract(B, H, 3, M, Hq, M * H, H, False, new_p, M * 3, 3, False, gq, reduce=True)
+                g_w1[:, :3].sub_(gq, alpha=1.0 / radius)
+                g_w1 = g_w1.view(H, C + 3, 1, 1)
         if not need_w:
             return (g_p, g_q, g_f) + (None,) * 9
         return (g_p, g_q, g_f, g_w1, g_gamma1 if a1 else None, g_beta1 if a2 else None,

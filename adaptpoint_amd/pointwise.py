@@ -212,3 +212,18 @@ def matmul_nt(a, b):
     _call("apn_pw_conv_grad_weight", a.device, 1, Q, R, K, PRECISION, a.data_ptr(), b.data_ptr(), scratch.data_ptr(),
           out.data_ptr())
     return out
+
+
+def contract(nbatch, R, Q, K, a, a_batch, lda, a_kcont, b, b_batch, ldb, b_kcont, out, d_batch=0, ldd=None, reduce=False):
+    """csrc/pointwise.hip's contraction kernel on raw operand descriptions (include/adaptpoint_amd.h,
+    apn_pw_contract): out[z] = a[z] b[z] per batch entry, or (reduce) out = sum_z a[z] b[z] in fixed-order shares.
+    a / b: tensors whose data_ptr() is the operand's first element (a storage offset is a column offset)."""
+    lib = _lib.load()
+    splits, scratch = 0, None
+    if reduce:
+        splits = lib.apn_pw_contract_splits(nbatch, R, Q, K)
+        scratch = torch.empty(splits, R, Q, device=out.device)
+    _call("apn_pw_contract", out.device, nbatch, R, Q, K, a.data_ptr(), a_batch, lda, int(a_kcont), b.data_ptr(), b_batch,
+          ldb, int(b_kcont), out.data_ptr(), d_batch, Q if ldd is None else ldd, splits,
+          scratch.data_ptr() if scratch is not None else None, PRECISION)
+    return out

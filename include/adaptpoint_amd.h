@@ -520,6 +520,17 @@ APN_API int apn_pw_conv_grad_weight_splits(int b, int c_in, int c_out, int n);
 APN_API int apn_pw_conv_grad_weight(int b, int c_in, int c_out, int n, int precision, const float *gy, const float *x,
                                     float *scratch, float *gw, void *stream);
 
+/* The contraction kernel of the per-point layers as such (csrc/pointwise.hip), for the small dense products around
+ * the fused set-abstraction blocks (conv1 at the points, dL/df, dL/dW1 of the wide blocks):
+ *   splits == 0: d[z] (r x q) = a[z] (r x k) b[z] (k x q), z < nbatch (a batch stride of 0 shares the operand);
+ *   splits  > 0: d (r x q, ldd == q) = sum_z a[z] b[z] in `splits` shares (apn_pw_contract_splits; scratch
+ *                [splits][r][q]) added in a fixed order.
+ * a_kcont / b_kcont: the operand's element (i, k) lies at i * ld + k (1) or at k * ld + i (0). */
+APN_API int apn_pw_contract_splits(int nbatch, int r, int q, int k);
+APN_API int apn_pw_contract(int nbatch, int r, int q, int k, const float *a, long long a_batch, int lda, int a_kcont,
+                            const float *b, long long b_batch, int ldb, int b_kcont, float *d, long long d_batch, int ldd,
+                            int splits, float *scratch, int precision, void *stream);
+
 /* the per-anchor transforms of AdaptPoint_Augmentor.local_transformaton
  * (openpoints/models_adaptpoint/generator_component4_15.py:236-297): prob (n,9) the imitator's numbers per anchor,
  * keep (n,3) / axes (n,3) the call's random switches as floats -> lin (n,3,3) = R diag(s), off (n,3); formulas in
