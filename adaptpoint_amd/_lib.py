@@ -104,6 +104,8 @@ SIGNATURES = {
     "apn_pw_conv_grad_input": [_c_int] * 5 + [_c_void_p] * 4,
     "apn_pw_conv_grad_weight_splits": [_c_int] * 4,
     "apn_pw_conv_grad_weight": [_c_int] * 5 + [_c_void_p] * 5,
+    "apn_deform_forward": [_c_int] * 3 + [_c_void_p] * 6 + [_c_float] + [_c_void_p] * 4,
+    "apn_deform_backward": [_c_int] * 3 + [_c_void_p] * 4 + [_c_float] + [_c_void_p] * 7,
     "apn_pw_contract_splits": [_c_int] * 4,
     "apn_pw_contract": [_c_int] * 4 + [_c_void_p, _c_longlong, _c_int, _c_int] * 2 + [_c_void_p, _c_longlong, _c_int, _c_int,
                                                                                          _c_void_p, _c_int, _c_void_p],

@@ -147,6 +147,52 @@ def deform(x, anchors, lin, off, w):
     return (w.unsqueeze(-1) * moved).sum(1) / w.sum(1).unsqueeze(-1)
 
 
+class _DeformNormaliseMask(torch.autograd.Function):
+    """csrc/augment.hip: kernel regression + blend + unit sphere + mask, one workgroup per cloud, one launch each way
+    (the composed form below -- kernel_weights, deform, unit_sphere and the mask product -- is ~30 launches forward and
+    ~50 backward).  Gradients reach the per-anchor transforms and the mask; the cloud and its anchors are data."""
+
+    @staticmethod
+    def forward(ctx, x, anchors, lin, off, axes, mask0, sigma):
+        B, N, _ = x.shape
+        M = anchors.shape[1]
+        x, anchors, lin, off = x.contiguous(), anchors.contiguous(), lin.contiguous(), off.contiguous()
+        z = torch.empty_like(x)
+        stat = torch.empty(B, 8, device=x.device)
+        out = torch.empty_like(x)
+        _call("apn_deform_forward", x.device, B, N, M, x.data_ptr(), anchors.data_ptr(), lin.data_ptr(), off.data_ptr(),
+              axes.data_ptr(), mask0.data_ptr(), float(sigma), z.data_ptr(), stat.data_ptr(), out.data_ptr())
+        ctx.save_for_backward(x, anchors, axes, mask0, z, stat)
+        ctx.sigma = float(sigma)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, anchors, axes, mask0, z, stat = ctx.saved_tensors
+        B, N, _ = x.shape
+        M = anchors.shape[1]
+        g = g.contiguous()
+        g_lin = torch.empty(B, M, 3, 3, device=x.device)
+        g_off = torch.empty(B, M, 3, device=x.device)
+        g_mask = torch.empty(B, N, device=x.device) if ctx.needs_input_grad[5] else None
+        _call("apn_deform_backward", x.device, B, N, M, x.data_ptr(), anchors.data_ptr(), axes.data_ptr(),
+              mask0.data_ptr(), ctx.sigma, z.data_ptr(), stat.data_ptr(), g.data_ptr(), g_lin.data_ptr(),
+              g_off.data_ptr(), g_mask.data_ptr() if g_mask is not None else None)
+        return None, None, g_lin, g_off, None, g_mask, None
+
+
+def deform_normalise_mask(x, anchors, lin, off, kernel_axes, mask0, sigma, fused=True):
+    """x (B,N,3), per-anchor (lin, off), kernel_axes (B,1,3), mask0 (B,N) -> the augmented cloud (B,N,3)
+    (:156-232, 313-327, 180).  The extension's kernel where it applies (GPU, float32, <= 8 anchors, N <= 4096, no
+    gradient asked for the cloud itself), the composed form otherwise."""
+    if (fused and x.is_cuda and x.dtype == torch.float32 and anchors.shape[1] <= 8 and x.shape[1] <= 4096
+            and not x.requires_grad and not anchors.requires_grad):
+        axes = kernel_axes.to(x.dtype).reshape(x.shape[0], 3).contiguous()
+        return _DeformNormaliseMask.apply(x, anchors, lin, off, axes, mask0.contiguous(), sigma)
+    w = kernel_weights(x, anchors, kernel_axes, sigma)
+    return unit_sphere(deform(x, anchors, lin, off, w)) * mask0.unsqueeze(-1)
+
+
 def unit_sphere(z):
     """Centre each cloud and scale it just inside the unit sphere (:313-327)."""
     z = z - z.mean(dim=-2, keepdim=True)
@@ -182,9 +228,8 @@ class AdaptPointAugmentor(nn.Module):
         noise = noise.to(xyz.device)
         mask = self.predict_prob_layer.hard_mask(logits, noise.gumbel_expo)
         lin, off = anchor_transforms(prob, noise, self.w_R_range, self.w_S_range, self.w_T_range, self.fused)
-        w = kernel_weights(xyz, anchors, noise.kernel_axes, self.sigma)
-        out = unit_sphere(deform(xyz, anchors, lin, off, w))
-        return xyz, out * mask[:, :, 0:1]
+        out = deform_normalise_mask(xyz, anchors, lin, off, noise.kernel_axes, mask[:, :, 0], self.sigma, self.fused)
+        return xyz, out
 
 
 AdaptPoint_Augmentor = AdaptPointAugmentor          # the reference's registry name

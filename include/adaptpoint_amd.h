@@ -541,6 +541,18 @@ APN_API int apn_anchor_transforms_grad(int n, const float *prob, const float *ke
                                        float s_range, float t_range, const float *g_lin, const float *g_off,
                                        float *g_prob, void *stream);
 
+/* The deformation that consumes them (generator_component4_15.py:156-232, 313-327 and the mask at :180): kernel
+ * regression weights towards the m <= 8 anchors, blend of the anchors' affine maps, unit-sphere normalisation, mask:
+ *   xyz (B,n,3), anchors (B,m,3), lin (B,m,3,3), off (B,m,3), axes (B,3) floats, mask (B,n) or NULL ->
+ *   out (B,n,3); z (B,n,3) and stat (B,8) are kept for the backward.  n <= 4096.  One workgroup per cloud.
+ * _backward: g_lin (B,m,3,3), g_off (B,m,3), g_mask (B,n) (may be NULL) from g_out (B,n,3). */
+APN_API int apn_deform_forward(int b, int n, int m, const float *xyz, const float *anchors, const float *lin,
+                               const float *off, const float *axes, const float *mask, float sigma, float *z, float *stat,
+                               float *out, void *stream);
+APN_API int apn_deform_backward(int b, int n, int m, const float *xyz, const float *anchors, const float *axes,
+                                const float *mask, float sigma, const float *z, const float *stat, const float *g_out,
+                                float *g_lin, float *g_off, float *g_mask, void *stream);
+
 /* The last layer of the discriminator's group-all stage with its pooling
  * (openpoints/models_adaptpoint/point_discriminator.py:183-189: conv -> ReLU -> max over the cloud's points), fused:
  *   out (B,c_out) = [relu](max_n (w x_b)[o][n] + bias[o]),  idx (B,c_out) int32 = the position of that maximum (the

@@ -290,3 +290,31 @@ def test_anchor_transforms_kernel_matches_composed_form(dev):
     host = lambda t: t.detach().cpu().numpy()
     assert rel(lin, host(lin64)) < 1e-6 and rel(off, host(off64)) < 1e-6
     assert rel(prob.grad, host(p64.grad)) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(4, 1024, 4), (3, 777, 3), (2, 2048, 8)], ids=lambda s: "x".join(map(str, s)))
+def test_deformation_kernel_matches_composed_form(dev, shape):
+    """csrc/augment.hip's kernel regression + blend + unit sphere + mask (one launch each way) against the composed
+    PyTorch form in float64 (generator_component4_15.py:156-232, 313-327, 180): the augmented cloud and the gradients
+    w.r.t. the per-anchor matrices, offsets and the mask."""
+    from adaptpoint_amd.augmentor import deform_normalise_mask
+    B, N, M = shape
+    g = torch.Generator().manual_seed(N + M)
+    x = torch.from_numpy(GI.unit_sphere_cloud(B, N, seed=5)).to(dev)
+    anchors = x[:, torch.randperm(N, generator=g)[:M]].contiguous()
+    lin = (torch.eye(3) + 0.3 * torch.randn(B, M, 3, 3, generator=g)).to(dev).requires_grad_(True)
+    off = (0.2 * torch.randn(B, M, 3, generator=g)).to(dev).requires_grad_(True)
+    axes = torch.randint(0, 2, (B, 1, 3), generator=g).int()
+    axes[:, :, 0] |= (axes.sum(-1) == 0).int()                       # at least one axis (codes 1..7)
+    axes = axes.to(dev)
+    mask0 = (torch.rand(B, N, generator=g) < 0.8).float().to(dev).requires_grad_(True)
+    gout = torch.randn(B, N, 3, generator=g).to(dev)
+    lin64, off64, m64 = (t.detach().double().requires_grad_(True) for t in (lin, off, mask0))
+    ref = deform_normalise_mask(x.double(), anchors.double(), lin64, off64, axes, m64, 0.5, fused=False)
+    (ref * gout.double()).sum().backward()
+    out = deform_normalise_mask(x, anchors, lin, off, axes, mask0, 0.5)
+    (out * gout).sum().backward()
+    host = lambda t: t.detach().cpu().numpy()
+    assert rel(out, host(ref)) < 2e-6
+    assert rel(lin.grad, host(lin64.grad)) < 2e-5 and rel(off.grad, host(off64.grad)) < 2e-5
+    assert rel(mask0.grad, host(m64.grad)) < 2e-5
