@@ -9,13 +9,16 @@
 //     gW   (O x C) = sum_b gy_b (O x N) x_b^T (N x C)   gradient w.r.t. the weight (split over (b, position) ranges,
 //                                                       the shares added in a fixed order: reproducible)
 // by describing each operand as "k-contiguous" (element (i, k) at i * ld + k) or "row-contiguous" (k * ld + i):
-// the float32 operands are read exactly as they lie in HBM (no transposed copies, no NHWC detour), split into
-// bf16 hi + lo on the way into LDS (three MFMAs per product, apn_mfma.h: the contraction agrees with an fp32 one to
-// ~1e-5), and every one of the 128 x 128 workgroup tile's fragment reads is a conflict-free 16-byte LDS read.
+// the float32 operands are read exactly as they lie in HBM (no transposed copies, no NHWC detour), split into two
+// or three bf16 planes on the way into LDS (three or six MFMAs per product: ~4e-6 of an fp32 contraction, or
+// fp32-class -- see pw_gemm_kernel), and every one of the 128 x 128 workgroup tile's fragment reads is a
+// conflict-free 16-byte LDS read.
 // BatchNorm's batch statistics are column sums of the forward product and leave the contraction's epilogue as one
 // partial row per workgroup; the normalise + ReLU pass folds them itself.  The backward pass forms
 // gy = dL/dy once (two passes over (g, y): the sums BatchNorm's gradient needs, then the apply) and both
-// gradient contractions read it.
+// gradient contractions read it.  The same kernel, with other epilogues or as a raw-operand entry, also serves the
+// discriminator's per-point layers (convolution + bias + ReLU; convolution + ReLU + max over the points) and the
+// small dense products around the fused set-abstraction blocks (apn_pw_contract).
 #include <hip/hip_runtime.h>
 
 #include "../../include/adaptpoint_amd.h"

@@ -4,7 +4,7 @@
 Conv1d(kernel 1) + BatchNorm1d + ReLU on channels-first (B, C, N) tensors; the reference runs it as
 three cuDNN / elementwise calls forward and five or more backward.  Here a layer is
 
-    forward   y = W x            one MFMA contraction (bf16 hi+lo operands, f32 accumulate) whose epilogue
+    forward   y = W x            one MFMA contraction (operands in bf16 planes, f32 accumulate) whose epilogue
                                   leaves BatchNorm's batch statistics as partial rows,
               out = relu(bn(y))   one pass that folds those rows (float64) and updates the running statistics;
     backward  gy = dL/dy          two passes over (g, y) (BatchNorm's two sums, then the apply),
@@ -12,9 +12,11 @@ three cuDNN / elementwise calls forward and five or more backward.  Here a layer
               gW = sum gy x^T     the same kernel with both operands position-contiguous, split over
                                   (cloud, position) ranges whose shares are added in a fixed order
 
--- 2 launches forward, 5 backward, bit-reproducible gradients, no transposed copies.  `conv_bn_act` takes the
-torch modules (their parameters and buffers are used and updated in place), so `state_dict`s stay the
-reference's.
+-- 2 launches forward, 6 backward (the weight gradient's shares are folded by one more), bit-reproducible
+gradients, no transposed copies.  `conv_bn_act` takes the torch modules (their parameters and buffers are used and
+updated in place), so `state_dict`s stay the reference's.  Also here: `conv_bias_act` and `conv_max` (the
+discriminator's per-point layers, the last one fused with its max-pool), `run_block` (a 1x1 `convblock` of the
+PointNeXt mirror), `matmul_nt` / `contract` (the contraction kernel on raw operands).
 """
 import torch
 
