@@ -73,9 +73,11 @@ struct PwLoader {
             rows = origin + i0 < lim ? 1u : 0u;
         }
     }
-    // -> the number of leading k of this thread's values that lie inside the operand
+    // -> the number of leading k of this thread's values that lie inside the operand.  `full`: the chunk lies
+    // wholly inside K (wave-uniform): no clamping of the k indices (the common case; the address arithmetic is most
+    // of this function's instructions, and the kernel's VALU time is as large as its MFMA time)
     __device__ __forceinline__ int load(const PwOperand &op, const float *__restrict__ base, int origin, int lim,
-                                        int k0, int K, int vec, float (&v)[8]) const {
+                                        int k0, int K, int vec, bool full, float (&v)[8]) const {
         const int kk = k0 + kofs, left = K - kk;
         if (KCONT) {
 #pragma unroll
@@ -83,17 +85,23 @@ struct PwLoader {
                 const int i = origin + 64 * j + i0;
                 const float *src = base + (size_t)(i < lim ? i : lim - 1) * op.ld;
                 if (vec) {
-                    const float4 q = *reinterpret_cast<const float4 *>(src + (kk < K - 4 ? kk : K - 4));
+                    const float4 q = *reinterpret_cast<const float4 *>(src + (full || kk < K - 4 ? kk : K - 4));
                     v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * j + e] = src[kk + e < K ? kk + e : K - 1];
+                    for (int e = 0; e < 4; ++e) v[4 * j + e] = src[full || kk + e < K ? kk + e : K - 1];
                 }
             }
-            return left < 0 ? 0 : (left > 4 ? 4 : left);
+            return full ? 4 : (left < 0 ? 0 : (left > 4 ? 4 : left));
         } else {
             const int i = origin + i0;
             const float *src = base + (i < lim ? i : lim - 1);
+            if (full) {
+                const float *row = src + (size_t)kk * op.ld;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = row[(size_t)j * op.ld];
+                return 8;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(kk + j < K ? kk + j : K - 1) * op.ld];
             return left < 0 ? 0 : (left > 8 ? 8 : left);
@@ -207,10 +215,14 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
     f32x16 acc[2] = {f32x16{0}, f32x16{0}};
     float va0[8], vb0[8], va1[8], vb1[8];
     int ka0 = 0, kb0 = 0, ka1 = 0, kb1 = 0;
-    auto fetch = [&](int c, float (&xa)[8], float (&xb)[8], int &ka, int &kb) {
-        const int bz = c / g.cpb, k0 = (c - bz * g.cpb) * PW_KC;
-        ka = la.load(g.A, g.A.p + g.A.batch * bz, R0, g.R, k0, g.K, g.a_vec, xa);
-        kb = lb.load(g.B, g.B.p + g.B.batch * bz, Q0, g.Q, k0, g.K, g.b_vec, xb);
+    // chunks are fetched in order: (batch entry, chunk inside it) advance by counting, not by a division per fetch
+    int fz = c0 / g.cpb, fk = c0 - fz * g.cpb;
+    auto fetch = [&](float (&xa)[8], float (&xb)[8], int &ka, int &kb) {
+        const int k0 = fk * PW_KC;
+        const bool full = k0 + PW_KC <= g.K;
+        ka = la.load(g.A, g.A.p + g.A.batch * fz, R0, g.R, k0, g.K, g.a_vec, full, xa);
+        kb = lb.load(g.B, g.B.p + g.B.batch * fz, Q0, g.Q, k0, g.K, g.b_vec, full, xb);
+        if (++fk == g.cpb) { fk = 0; ++fz; }
     };
     auto compute = [&](const __bf16 *As, const __bf16 *Bs) {
 #pragma unroll
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
     auto step = [&](int c, float (&fa)[8], float (&fb)[8], int &fka, int &fkb, float (&xa)[8], float (&xb)[8],
                     int xka, int xkb) {
         __bf16 *cur = lds + (c & 1) * 2 * TILE, *nxt = lds + ((c + 1) & 1) * 2 * TILE;
-        if (c + 2 < c1) fetch(c + 2, fa, fb, fka, fkb);
+        if (c + 2 < c1) fetch(fa, fb, fka, fkb);
         compute(cur, cur + TILE);
         if (c + 1 < c1) {
             la.template stage<NS>(nxt, xa, xka);
@@ -252,8 +264,8 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         __syncthreads();
     };
     if (c0 < c1) {
-        fetch(c0, va0, vb0, ka0, kb0);
-        if (c0 + 1 < c1) fetch(c0 + 1, va1, vb1, ka1, kb1);
+        fetch(va0, vb0, ka0, kb0);
+        if (c0 + 1 < c1) fetch(va1, vb1, ka1, kb1);
         __bf16 *first = lds + (c0 & 1) * 2 * TILE;
         la.template stage<NS>(first, va0, ka0);
         lb.template stage<NS>(first + TILE, vb0, kb0);
