@@ -14,10 +14,8 @@ Module names and the convolution type (Conv2d with 1x1 kernels) are the referenc
 state_dict -- `sa1.mlp_convs.<i>.parametrizations.weight.original`, `..._u`, `..._v`, `fc1...`,
 `prob_head.0...` -- loads unchanged (800,671 parameters at num_classes = 15).
 """
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
-
 from torch.nn.utils.parametrizations import spectral_norm as _torch_spectral_norm
 
 from . import pointwise
