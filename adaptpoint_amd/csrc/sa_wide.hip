@@ -482,15 +482,19 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
             for (int j = 0; j < CT; ++j)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+            // evec == NULL: BatchNorm-2 normalises with its running statistics (eval mode, e.g. the classifier in the
+            // AdaptPoint feedback pass): D2 = E2 = 0, so Qm = 0 and the a1 Qm third of the chain is skipped
+            const int kend = evec ? NKC : NKS;
 #pragma unroll 1
-            for (int kc = 0; kc < NKC; ++kc) {
+            for (int kc = 0; kc < kend; ++kc) {
                 const int ci = cb * NKC + kc;
                 const uint4 *slot;
                 if (RES) {
                     slot = wl + ci * Chunk<CT>::WORDS;
                 } else {
                     slot = wl + (seq & 1) * Chunk<CT>::WORDS;
-                    fetch_chunk<CT>(img, ci + 1 == NCH ? 0 : ci + 1, pre);
+                    const int nxt = kc + 1 < kend ? ci + 1 : (cb + 1 < NCB ? (cb + 1) * NKC : 0);
+                    fetch_chunk<CT>(img, nxt, pre);
                 }
                 Frag<2> af[2];
                 if (kc < NKS) {            // rows of S: the upstream gradient at the pooled slot
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
             for (int j = 0; j < CT; ++j) {
                 const unsigned mid = (cb * CT + j) * 32 + r;
                 const float sc = pack1[mid], sh = pack1[H + mid], mu = pack1[2 * H + mid], iv = pack1[3 * H + mid];
-                const float ev = evec[mid];
+                const float ev = evec ? evec[mid] : 0.0f;
                 float t1 = 0.0f, t2 = 0.0f;
                 float gu[16], yw[16];
                 float a1r[WG ? 16 : 1];
@@ -923,7 +927,7 @@ extern "C" int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, c
                                     const float *evec, const float *goa, const void *ksel, float *GU,
                                     float *HA, float *HB, float *part, float *r_part, void *stream) {
     if (!wide_args_ok(b, n, m, U, V, idx, tmap) || !wide_shape_ok(c_mid, c_out)) return APN_EINVAL;
-    if (!z_image || !pack1 || !evec || !goa || !ksel || !GU || !HA || !HB || !part) return APN_EINVAL;
+    if (!z_image || !pack1 || !goa || !ksel || !GU || !HA || !HB || !part) return APN_EINVAL;
     if (c_mid == 32 && !r_part) return APN_EINVAL;
     WideArgs a{b * m, n, m, U, V, idx, tmap};
     const int grid = wide_grid(a.ntiles);

@@ -303,8 +303,10 @@ class _WideBlock(torch.autograd.Function):
             groups = (rows // 32 + 7) // 8
             splits = max(1, min(512 // groups, (B * M) // 4, (64 << 20) // (rows * H * 4)))
         Rpart = torch.empty(splits, rows * H + H, **f32)
+        # (eval-mode BatchNorm-2: Qm = 0 and evec = 0 -- the kernel skips that third of its chain on a NULL evec)
         _call("apn_sa_wide_bwd_main", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),
-              tmap.data_ptr(), zimg.data_ptr(), pack1.data_ptr(), evec.data_ptr(), goa.data_ptr(), ksel.data_ptr(),
+              tmap.data_ptr(), zimg.data_ptr(), pack1.data_ptr(), evec.data_ptr() if tr2 else None, goa.data_ptr(),
+              ksel.data_ptr(),
               GU.data_ptr(), HA.data_ptr(), HB.data_ptr(), partT.data_ptr(), Rpart.data_ptr())
         if not wg_fused and need_w:
             _call("apn_sa_wide_wgrad", dev, B, N, M, H, O, U.data_ptr(), V.data_ptr(), idx.data_ptr(),

@@ -391,7 +391,8 @@ APN_API int apn_sa_wide_fwd_main(int b, int n, int m, int c_mid, int c_out, cons
  * per block; S[pos,c] = goa[q,c] [ksel[q,c] == pos]), g_u = dL/da1 [a1 > 0]:
  * GU (32 b m, H): row tile * 32 + r = g_u summed over the positions the tile map's row stands for (rows in
  * use only; no atomics -- apn_sa_wide_point_grads sums them per point through the inverse map),
- * HA (B,M,H) = sum_k g_u, HB (B,M,H) = sum_k yhat1, part[grid][2H] = {sum g_u, sum g_u yhat1} */
+ * HA (B,M,H) = sum_k g_u, HB (B,M,H) = sum_k yhat1, part[grid][2H] = {sum g_u, sum g_u yhat1}.
+ * evec == NULL: BatchNorm-2 on running statistics (D2 = E2 = 0): the a1 Qm part of the chain is skipped. */
 APN_API int apn_sa_wide_bwd_main(int b, int n, int m, int c_mid, int c_out, const float *U, const float *V,
                                  const int *idx, const int *tmap, const void *z_image, const float *pack1,
                                  const float *evec, const float *goa, const void *ksel, float *GU,
