@@ -15,8 +15,9 @@ SHAPES = [(2, 3, 64, 1024), (2, 64, 128, 1024), (2, 512, 1024, 128), (2, 1536, 5
           (3, 130, 70, 77), (1, 5, 33, 257), (5, 36, 200, 130)]
 
 # planes per operand -> (bar on out, bar on gradients), relative L2 against float64: two bf16 planes keep 16 bits
-# of each operand (~4e-6 measured), three keep all 24 (~1e-7 measured: fp32-class, the default)
-TOL = {2: (3e-5, 2e-4), 3: (1e-6, 5e-6)}
+# of each operand (~4e-6 measured), three keep all 24 (5e-8 .. 6e-7 measured, growing with the contraction length up to
+# 1536: f32 accumulation -- fp32-class, the default)
+TOL = {2: (3e-5, 2e-4), 3: (2e-6, 1e-5)}
 
 
 def _rel(a, ref):
