@@ -57,10 +57,16 @@ if [ "$what" = models ]; then
         python $R/scripts/bench_gan_step.py --points $n --graph 2>/dev/null | grep '^{' >> $O/r02_gan_step_bench.jsonl
     done
     python $R/scripts/bench_wide.py 2>/dev/null | grep '^{' > $O/r02_wide_kernels.jsonl
+    python $R/scripts/bench_pointwise.py 2>/dev/null | grep '^{' > $O/r02_pointwise_layers.jsonl
     rocprofv3 --kernel-trace --output-format csv -d $O/prof_pn -o pn -- python $R/scripts/bench_pointnext.py --fused --graph --steps 12 --warmup 6 > $O/prof_pn.log 2>&1
     python $R/scripts/steady_stats.py $O/prof_pn/pn_kernel_trace.csv fps_ 4 3 --csv $O/r02_pointnext_fused_graph_steady.csv > $O/r02_pointnext_fused_graph_steady.txt
     rocprofv3 --kernel-trace --output-format csv -d $O/prof_gan -o gan -- python $R/scripts/bench_gan_step.py --mode fused --graph --iters 10 --warmup 4 > $O/prof_gan.log 2>&1
     python $R/scripts/steady_stats.py $O/prof_gan/gan_kernel_trace.csv pointset_group_max_kernel 4 3 --csv $O/r02_gan_step_fused_graph_steady.csv > $O/r02_gan_step_fused_graph_steady.txt
     rm -rf $O/prof_pn $O/prof_gan
+    rocprofv3 --kernel-trace --output-format csv -d $O/prof_gan -o gan -- python $R/scripts/bench_gan_step.py --mode fused --graph --points 2048 --iters 8 --warmup 3 > $O/prof_gan.log 2>&1
+    python $R/scripts/steady_stats.py $O/prof_gan/gan_kernel_trace.csv pointset_group_max_kernel 4 3 > $O/r02_gan_step_2048_steady.txt
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc_pw -o p -- python $R/scripts/bench_pointwise.py --layers decode1 --only planes3 --iters 2 > $O/pmc_pw.log 2>&1
+    python $R/scripts/pmc_summary.py $O/r02_pmc_sq_summary_pointwise.csv $O/pmc_pw > /dev/null
+    rm -rf $O/prof_gan $O/pmc_pw
 fi
 ls -la $O | tail -30
