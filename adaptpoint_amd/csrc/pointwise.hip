@@ -650,7 +650,10 @@ static int pw_weight_splits(int b, int c_in, int c_out, int n) {
     const long long total = (long long)b * ((n + PW_KC - 1) / PW_KC);
     // tiles * s workgroups, two of which a CU holds at a time: never just over a multiple of 512
     long long s = 512 / tiles;
-    if (s > total / 8) s = total / 8;
+    // (a lone workgroup walks its chunks at ~2 us each: the short contractions are spread down to two chunks per
+    // share, the long ones keep at least eight and a light fold)
+    const long long cap = total >= 64 ? total / 8 : total / 2;
+    if (s > cap) s = cap;
     if (s < 1) s = 1;
     return (int)s;
 }
