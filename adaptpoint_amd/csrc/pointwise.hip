@@ -841,7 +841,7 @@ extern "C" int apn_pw_contract(int nbatch, int r, int q, int k, const float *a, 
                                int ldd, int splits, float *scratch, int precision, void *stream) {
     using namespace apn;
     if (nbatch <= 0 || r <= 0 || q <= 0 || k <= 0 || nbatch > 65535 || !a || !b || !d || (precision != 2 && precision != 3) ||
-        splits < 0 || (splits > 0 && !scratch))
+        splits < 0 || (splits > 0 && (!scratch || ldd != q)))
         return APN_EINVAL;
     PwGemm g{};
     g.A = PwOperand{a, a_batch, lda};
@@ -867,7 +867,6 @@ extern "C" int apn_pw_contract(int nbatch, int r, int q, int k, const float *a, 
     else PW_LAUNCH(false, false, grid, g);
     if (splits > 0) {
         const size_t ne = (size_t)r * q;
-        if (ldd != q) return APN_EINVAL;
         hipLaunchKernelGGL(pw_fold_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(256), 0, (hipStream_t)stream, scratch,
                            splits, ne, d);
         APN_LAUNCH_CHECK();
