@@ -142,6 +142,65 @@ __global__ __launch_bounds__(256) void pointset_group_max_grad_kernel(
     }
 }
 
+// The same gradient with the cloud's slice of g_points held in LDS: workgroup (channel block of CB, cloud) owns
+// g_points[cloud][:, block] as a tile [n][CB], every (query, channel) adds its two terms there with LDS atomics
+// (ds_add_f32) and the tile leaves with plain coalesced stores -- no global float atomics (the scatter above issues
+// 2 b m c of them: 116 us per stage at b = 32, the atomic units' rate).  Rows of `part`: the cloud's first row holds
+// the block's {dalpha, dbeta} shares, its other rows are zeroed for these channels.
+__global__ __launch_bounds__(256) void pointset_group_max_grad_tile_kernel(
+    int n, int m, int c, int k, int cb_size, int rows_per_cloud, const float *__restrict__ points,
+    const int *__restrict__ idx, const int *__restrict__ fidx, const float *__restrict__ alpha,
+    const unsigned char *__restrict__ ksel, const float *__restrict__ g_out, float *__restrict__ g_points,
+    float *__restrict__ part) {
+    extern __shared__ float s_tile[];                      // [n][CB] | g tile [CB][65] | reduction [256][2]
+    const int CB = cb_size, G = 256 / CB;
+    float *s_g = s_tile + (size_t)n * CB;
+    float *s_red = s_g + CB * 65;
+    const int cloud = blockIdx.y, ch0 = blockIdx.x * CB, tid = threadIdx.x;
+    const int cc = tid % CB, grp = tid / CB, ch = ch0 + cc;
+    for (int e = tid; e < n * CB; e += 256) s_tile[e] = 0.0f;
+    const float *P = points + (size_t)cloud * n * c;
+    const float al = alpha[ch];
+    float da = 0.0f, db = 0.0f;
+    for (int q0 = 0; q0 < m; q0 += 64) {
+        __syncthreads();
+        // g_out (B, C, M) is query-contiguous: stage 64 queries of the block's channels (coalesced along the queries)
+        for (int e = tid; e < CB * 64; e += 256) {
+            const int j = e >> 6, q = e & 63;
+            s_g[j * 65 + q] = q0 + q < m ? g_out[((size_t)cloud * c + ch0 + j) * m + q0 + q] : 0.0f;
+        }
+        __syncthreads();
+        const int qe = m - q0 < 64 ? m - q0 : 64;
+        for (int q = grp; q < qe; q += G) {
+            const size_t qa = (size_t)cloud * m + q0 + q;
+            const float g = s_g[cc * 65 + q];
+            const int sel = idx[qa * k + ksel[qa * c + ch]], anc = fidx[qa];
+            const float ag = al * g;
+            atomicAdd(&s_tile[sel * CB + cc], ag);
+            atomicAdd(&s_tile[anc * CB + cc], -ag);
+            da = __builtin_fmaf(g, P[(size_t)sel * c + ch] - P[(size_t)anc * c + ch], da);
+            db += g;
+        }
+    }
+    __syncthreads();
+    float *GP = g_points + (size_t)cloud * n * c + ch0;
+    for (int e = tid; e < n * CB; e += 256) GP[(size_t)(e / CB) * c + (e % CB)] = s_tile[e];
+    s_red[tid * 2] = da;
+    s_red[tid * 2 + 1] = db;
+    __syncthreads();
+    if (tid < CB) {
+        float sa = 0.0f, sb = 0.0f;
+        for (int t = tid; t < 256; t += CB) { sa += s_red[t * 2]; sb += s_red[t * 2 + 1]; }
+        float *row = part + (size_t)cloud * rows_per_cloud * 2 * c;
+        row[ch0 + tid] = sa;
+        row[c + ch0 + tid] = sb;
+        for (int r = 1; r < rows_per_cloud; ++r) {
+            row[(size_t)r * 2 * c + ch0 + tid] = 0.0f;
+            row[(size_t)r * 2 * c + c + ch0 + tid] = 0.0f;
+        }
+    }
+}
+
 static int pg_check(int b, int n, int m, int c, int k) {
     if (b <= 0 || n <= 0 || m <= 0 || c <= 0 || k <= 0 || k > 255 || b > 65535) return APN_EINVAL;
     const int c4n = c >> 2;
@@ -185,6 +244,21 @@ extern "C" int apn_pointset_group_max_grad(int b, int n, int m, int c, int k, co
     if (int e = pg_check(b, n, m, c, k)) return e;
     if (!points || !idx || !fidx || !alpha || !ksel || !g_out || !g_points || !part) return APN_EINVAL;
     const int PG_QT = pg_qt(c);
+    // the LDS-tile form where a cloud's slice [n][CB] fits (CB channels per workgroup, a divisor of 256 and of c)
+    int cbs = 0;
+    for (int t = 32; t >= 8; t >>= 1)
+        if (c % t == 0 && (size_t)n * t * sizeof(float) <= 128 * 1024) { cbs = t; break; }
+    if (cbs) {
+        const size_t dyn = sizeof(float) * ((size_t)n * cbs + (size_t)cbs * 65 + 512);
+        hipError_t ae = hipFuncSetAttribute((const void *)pointset_group_max_grad_tile_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (ae != hipSuccess) return (int)ae;
+        hipLaunchKernelGGL(pointset_group_max_grad_tile_kernel, dim3(c / cbs, b), dim3(256), dyn, (hipStream_t)stream, n, m,
+                           c, k, cbs, (m + PG_QT - 1) / PG_QT, points, idx, fidx, alpha, (const unsigned char *)ksel, g_out,
+                           g_points, part);
+        APN_LAUNCH_CHECK();
+        return APN_OK;
+    }
     const size_t dyn = sizeof(int) * (PG_QT * k + PG_QT) + sizeof(float) * ((size_t)c * (PG_QT + 1) + 256 * 8);
     if (dyn > 48 * 1024) {
         hipError_t ae = hipFuncSetAttribute((const void *)pointset_group_max_grad_kernel,

@@ -320,9 +320,11 @@ APN_API int apn_sa_sample_seq(int b, int n, int m, float radius, int nsample, co
  * idx (B,M,K) from apn_ball_query, fidx (B,M) from apn_furthest_point_sampling, alpha/beta [C];
  * out (B,C,M); ksel (B,M,C) uint8 = position of the (first) maximum, kept for the backward.
  * C a power of two in 4..1024, K <= 255.
- * Backward: g_points (B,N,C) += alpha*g at the selected neighbour, -= alpha*g at the anchor
- * (caller-zeroed, float atomics); part[apn_pointset_group_rows(b, m, c)][2C] = per-workgroup
- * {sum g*(x_sel - anchor), sum g} = dL/dalpha, dL/dbeta partial rows.
+ * Backward: g_points (B,N,C) = alpha*g at the selected neighbour - alpha*g at the anchor, summed over the
+ * queries: caller-zeroed; where a cloud's slice [N][8..32 channels] fits in LDS (N <= 4096) it is accumulated
+ * there (LDS atomics) and stored whole, otherwise added with global float atomics;
+ * part[apn_pointset_group_rows(b, m, c)][2C] = partial rows of {sum g*(x_sel - anchor), sum g} = dL/dalpha,
+ * dL/dbeta (summed by the caller).
  * ------------------------------------------------------------------------ */
 APN_API int apn_pointset_group_rows(int b, int m, int c);
 APN_API int apn_pointset_group_max(int b, int n, int m, int c, int k, const float *points,
