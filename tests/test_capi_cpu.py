@@ -91,3 +91,29 @@ def test_argument_validation_needs_no_gpu(lib):
     assert t(2, 8, 0, None, None, None, 3, 0, None) == 0      # m <= 0 returns before anything is read
     assert t(2, 8, 4, None, None, None, 0, 0, None) == -1
     assert not hasattr(lib, "apn_fps_set_waves") and not hasattr(lib, "apn_fps_set_algo")   # no process-wide state
+
+
+def test_argument_validation_of_the_adaptpoint_entries_needs_no_gpu():
+    """The per-point layer, spectral-norm, anchor-transform and deformation entries reject bad arguments (and accept
+    empty work) before any HIP call, like the reference-boundary entries above."""
+    from adaptpoint_amd import _lib
+    lib = _lib.load()
+    EINVAL = -1
+    assert lib.apn_pw_conv_tiles(4, 1000) == 4 * 8
+    assert lib.apn_pw_conv_forward(2, 8, 8, 16, 5, None, None, None, None, None) == EINVAL        # precision 2 or 3
+    assert lib.apn_pw_conv_forward(0, 8, 8, 16, 3, None, None, None, None, None) == 0             # no clouds
+    assert lib.apn_pw_conv_forward(2, 8, 8, 16, 3, None, None, None, None, None) == EINVAL        # null tensors
+    assert lib.apn_pw_bn_act(2, 0, 16, None, None, 0, None, None, 1e-5, 0.1, 1, 1, None, None, None, None, None, None) == EINVAL
+    assert lib.apn_pw_bn_act(0, 8, 16, None, None, 0, None, None, 1e-5, 0.1, 1, 1, None, None, None, None, None, None) == 0
+    assert lib.apn_pw_conv_grad_weight(2, 8, 8, 16, 3, None, None, None, None, None) == EINVAL
+    assert lib.apn_pw_conv_max_backward(2, 129, 8, 16, None, None, None, None, None, 1, None, None, None, None, None) == EINVAL
+    assert lib.apn_pw_contract(1, 4, 4, 4, None, 0, 4, 1, None, 0, 4, 1, None, 0, 4, 0, None, 3, None) == EINVAL
+    # split-K shares: short contractions down to two chunks per share, long ones at least eight, <= 512 workgroups
+    assert lib.apn_pw_contract_splits(1, 256, 256, 512) == 8 and lib.apn_pw_contract_splits(32, 512, 1536, 256) == 10
+    assert lib.apn_spectral_norm(0, 4, None, 1, 1e-12, None, None, None, None, None, None, None, None) == EINVAL
+    assert lib.apn_spectral_norm_blocks(1024, 512) == 512 and lib.apn_spectral_norm_blocks(15, 1) == 1
+    assert lib.apn_anchor_transforms(0, None, None, None, 10.0, 3.0, 0.25, None, None, None) == 0
+    assert lib.apn_anchor_transforms(4, None, None, None, 10.0, 3.0, 0.25, None, None, None) == EINVAL
+    assert lib.apn_deform_forward(2, 5000, 4, None, None, None, None, None, None, 0.5, None, None, None, None) == EINVAL   # n <= 4096
+    assert lib.apn_deform_forward(2, 1024, 9, None, None, None, None, None, None, 0.5, None, None, None, None) == EINVAL   # m <= 8
+    assert lib.apn_deform_forward(0, 1024, 4, None, None, None, None, None, None, 0.5, None, None, None, None) == 0
