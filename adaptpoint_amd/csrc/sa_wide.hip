@@ -125,6 +125,38 @@ __global__ __launch_bounds__(256) void wide_stats1_kernel(WideArgs a, float *__r
 // ------------------------------------------------------------------------------------------
 // Shared pieces of the MFMA kernels
 // ------------------------------------------------------------------------------------------
+// The raw words of one chunk's A operand (two k-steps), requested a chunk ahead of their use by the backward pass:
+// rows of S (f[s][0..1] = the gradient's 8 channels, kk = their pooled slots) or of a1 (f[s][0..7] = U, V and
+// BatchNorm-1's scale / shift for 8 channels).
+struct RawA {
+    float4 f[2][8];
+    uint2 kk[2];
+};
+
+__device__ __forceinline__ void a1_raw(const float *__restrict__ ub, unsigned uo, const float *__restrict__ vb,
+                                       unsigned vo, const float *__restrict__ pack1, int H, int ch0, float4 (&f)[8]) {
+    f[0] = *reinterpret_cast<const float4 *>(ub + (uo + ch0));
+    f[1] = *reinterpret_cast<const float4 *>(ub + (uo + ch0 + 4));
+    f[2] = *reinterpret_cast<const float4 *>(vb + (vo + ch0));
+    f[3] = *reinterpret_cast<const float4 *>(vb + (vo + ch0 + 4));
+    f[4] = *reinterpret_cast<const float4 *>(pack1 + ch0);
+    f[5] = *reinterpret_cast<const float4 *>(pack1 + ch0 + 4);
+    f[6] = *reinterpret_cast<const float4 *>(pack1 + H + ch0);
+    f[7] = *reinterpret_cast<const float4 *>(pack1 + H + ch0 + 4);
+}
+
+// the multiplicity-weighted a1 fragment from those words (the arithmetic of a1_frag below)
+__device__ __forceinline__ Frag<2> a1_from_raw(const float4 (&f)[8], float wgt) {
+    float t[8];
+    t[0] = __builtin_fmaf(f[0].x - f[2].x, f[4].x, f[6].x); t[1] = __builtin_fmaf(f[0].y - f[2].y, f[4].y, f[6].y);
+    t[2] = __builtin_fmaf(f[0].z - f[2].z, f[4].z, f[6].z); t[3] = __builtin_fmaf(f[0].w - f[2].w, f[4].w, f[6].w);
+    t[4] = __builtin_fmaf(f[1].x - f[3].x, f[5].x, f[7].x); t[5] = __builtin_fmaf(f[1].y - f[3].y, f[5].y, f[7].y);
+    t[6] = __builtin_fmaf(f[1].z - f[3].z, f[5].z, f[7].z); t[7] = __builtin_fmaf(f[1].w - f[3].w, f[5].w, f[7].w);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (t[e] > 0.0f ? t[e] : 0.0f) * wgt;
+    return make_frag<2>(t);
+}
+
 // A fragment of a1 = relu(scale1 * (U[n] - V[q]) + shift1): lane (pos r, h), 8 channels from ch0.
 // ub / vb: wave-uniform bases (the cloud's rows of U, the tile's rows of V); uo / vo: this lane's row offsets in
 // elements -- 32-bit, so the loads take the scalar-base + vector-offset form (no 64-bit address arithmetic).
@@ -485,6 +517,25 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
             // evec == NULL: BatchNorm-2 normalises with its running statistics (eval mode, e.g. the classifier in the
             // AdaptPoint feedback pass): D2 = E2 = 0, so Qm = 0 and the a1 Qm third of the chain is skipped
             const int kend = evec ? NKC : NKS;
+            auto load_raw = [&](int kc, RawA &rw) {
+                if (kc < NKS) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const unsigned c0 = go + kc * 32 + s * 16 + h * 8;
+                        rw.f[s][0] = *reinterpret_cast<const float4 *>(gb + c0);
+                        rw.f[s][1] = *reinterpret_cast<const float4 *>(gb + (c0 + 4));
+                        rw.kk[s] = *reinterpret_cast<const uint2 *>(kb + c0);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) a1_raw(ub, uo, vb, vo, pack1, H, (kc - NKS) * 32 + s * 16 + h * 8, rw.f[s]);
+                }
+            };
+            // (one wave per SIMD has the registers for two chunks of words; the two-waves-per-SIMD variants request
+            // and consume in the same step, as before: their tiles hold fewer chunks and a partner wave covers the wait)
+            constexpr bool AHEAD = OCC == 1;
+            RawA cur_raw;
+            if (AHEAD) load_raw(0, cur_raw);
 #pragma unroll 1
             for (int kc = 0; kc < kend; ++kc) {
                 const int ci = cb * NKC + kc;
@@ -496,8 +547,31 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
                     const int nxt = kc + 1 < kend ? ci + 1 : (cb + 1 < NCB ? (cb + 1) * NKC : 0);
                     fetch_chunk<CT>(img, nxt, pre);
                 }
+                // this chunk's A operand from the words requested one chunk ago; the next chunk's are requested now and
+                // arrive behind the MFMAs (requested and consumed in the same step they put an L2 round trip on the
+                // critical path of every chunk: 48 steps of ~2.5 us on the 256-wide block)
+                RawA nxt;
                 Frag<2> af[2];
-                if (kc < NKS) {            // rows of S: the upstream gradient at the pooled slot
+                if (AHEAD) {
+                    if (kc + 1 < kend) load_raw(kc + 1, nxt);
+                    if (kc < NKS) {            // rows of S: the upstream gradient at the pooled slot
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const float4 g0 = cur_raw.f[s][0], g1 = cur_raw.f[s][1];
+                            const uint2 kk = cur_raw.kk[s];
+                            float t[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const unsigned sel = ((e < 4 ? kk.x : kk.y) >> (8 * (e & 3))) & 0xffu;
+                                t[e] = (live && sel == (unsigned)rslot) ? t[e] : 0.0f;
+                            }
+                            af[s] = make_frag<2>(t);
+                        }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) af[s] = a1_from_raw(cur_raw.f[s], wrow);
+                    }
+                } else if (kc < NKS) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const unsigned c0 = go + kc * 32 + s * 16 + h * 8;
@@ -526,6 +600,7 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
                     __syncthreads();
                     ++seq;
                 }
+                if (AHEAD) cur_raw = nxt;
             }
             // epilogue: lane = mid channel, register = row of the tile
 #pragma unroll
