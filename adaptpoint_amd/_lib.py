@@ -73,6 +73,7 @@ SIGNATURES = {
     "apn_sa_wide_colsum": [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "apn_sa_wide_tilemap_ints": [_c_int] * 2,
     "apn_sa_wide_tilemap": [_c_int] * 3 + [_c_void_p] * 3,
+    "apn_sa_wide_tilemap_many": [_c_int] * 4 + [_c_void_p] * 3,
     "apn_sa_wide_stats1": [_c_int] * 4 + [_c_void_p] * 6,
     "apn_sa_wide_fwd_main": [_c_int] * 5 + [_c_void_p] * 11,
     "apn_sa_wide_bwd_main": [_c_int] * 5 + [_c_void_p] * 15,

@@ -324,10 +324,21 @@ __device__ __forceinline__ int query_rows(const int *__restrict__ row, int mode)
 // doubled maps next^(2^k) (log M rounds), every tile independently.
 //   qmeta[q] = tile_local | row0 << 16 | starts_tile << 24 | number in its tile << 25;  cnt8[q] = its row count
 //   tcount[c] = tiles of the cloud;  tnq_local[c m + t] = queries in tile t.   M <= 2048.
+// (blockIdx.y = which of several independent maps: the batches of a stacked index stage; their neighbour arrays lie
+// idx_stride ints apart, their blobs blob_bytes apart)
 __global__ __launch_bounds__(256) void tilemap_pack_kernel(int m, int mode, int levels, const int *__restrict__ idx,
                                                            unsigned char *__restrict__ cnt8,
                                                            unsigned *__restrict__ qmeta, int *__restrict__ tcount,
-                                                           unsigned short *__restrict__ tnq_local) {
+                                                           unsigned short *__restrict__ tnq_local, long long idx_stride,
+                                                           long long blob_bytes) {
+    {
+        const long long z = blockIdx.y, off = z * blob_bytes;
+        idx += z * idx_stride;
+        cnt8 += off;
+        qmeta = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(qmeta) + off);
+        tcount = reinterpret_cast<int *>(reinterpret_cast<char *>(tcount) + off);
+        tnq_local = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(tnq_local) + off);
+    }
     extern __shared__ int sh[];
     int *P = sh;                              // [m + 1]  exclusive prefix of the counts
     int *start = P + (m + 1);                 // [m + 1]  tile starts
@@ -459,7 +470,21 @@ __global__ __launch_bounds__(256) void tilemap_fill_kernel(int b, int m, const u
                                                            const unsigned short *__restrict__ tnq_local,
                                                            int *__restrict__ ntiles, int *__restrict__ tq0,
                                                            unsigned *__restrict__ rowinfo,
-                                                           const int *__restrict__ idx, int *__restrict__ rownn) {
+                                                           const int *__restrict__ idx, int *__restrict__ rownn,
+                                                           long long idx_stride, long long blob_bytes) {
+    {
+        const long long z = blockIdx.z, off = z * blob_bytes;
+        idx += z * idx_stride;
+        cnt8 += off;
+        qmeta = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(qmeta) + off);
+        tcount = reinterpret_cast<const int *>(reinterpret_cast<const char *>(tcount) + off);
+        toff = reinterpret_cast<int *>(reinterpret_cast<char *>(toff) + off);
+        tnq_local = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(tnq_local) + off);
+        ntiles = reinterpret_cast<int *>(reinterpret_cast<char *>(ntiles) + off);
+        tq0 = reinterpret_cast<int *>(reinterpret_cast<char *>(tq0) + off);
+        rowinfo = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(rowinfo) + off);
+        rownn = reinterpret_cast<int *>(reinterpret_cast<char *>(rownn) + off);
+    }
     __shared__ int red[256];
     const int c = blockIdx.y, t = threadIdx.x;
     int s = 0;
@@ -694,13 +719,18 @@ static size_t tilemap_rows_off(int bm) { return 4 + (size_t)((bm + 3) & ~3); }
 extern "C" int apn_sa_wide_tilemap_ints(int b, int m) {
     if (b <= 0 || m <= 0 || (long long)b * m > 0x7fffffffLL / 64) return 0;
     const size_t bm = (size_t)b * m;
-    return (int)(tilemap_rows_off((int)bm) + 64 * bm + 2 * (size_t)b + bm + (bm + 1) / 2 + (bm + 3) / 4 + 8);
+    // (a multiple of four ints: maps stacked back to back by apn_sa_wide_tilemap_many stay 16-byte aligned)
+    return (int)((tilemap_rows_off((int)bm) + 64 * bm + 2 * (size_t)b + bm + (bm + 1) / 2 + (bm + 3) / 4 + 8 + 3) & ~(size_t)3);
 }
 
-extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *tmap, void *stream) {
-    if (b <= 0 || m <= 0 || m > 65535 || b > 65535 || (long long)b * m > 0x7fffffffLL / 64 || !idx || !tmap)
+// count maps in one pair of launches: map z reads idx + z * b * m * 32 and fills tmap + z * tilemap_ints(b, m)
+// (the index stage of a whole hipGraph replay: twenty batches' maps were forty launches of 12-15 us on the index stream)
+extern "C" int apn_sa_wide_tilemap_many(int count, int b, int m, int mode, const int *idx, int *tmap, void *stream) {
+    if (count <= 0 || count > 65535 || b <= 0 || m <= 0 || m > 65535 || b > 65535 ||
+        (long long)b * m > 0x7fffffffLL / 64 || !idx || !tmap)
         return APN_EINVAL;
     const int nq = b * m;
+    const long long idx_stride = (long long)nq * 32, blob_bytes = (long long)apn_sa_wide_tilemap_ints(b, m) * 4;
     int *tq0 = tmap + 4;
     unsigned *rowinfo = (unsigned *)(tmap + tilemap_rows_off(nq));
     int *rownn = (int *)(rowinfo + (size_t)32 * nq);
@@ -718,16 +748,23 @@ extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
                 return (int)e;
         }
-        hipLaunchKernelGGL(apn::tilemap_pack_kernel, dim3(b), dim3(256), lds, st, m, mode, levels, idx, cnt8, qmeta,
-                           tcount, tnq_local);
+        hipLaunchKernelGGL(apn::tilemap_pack_kernel, dim3(b, count), dim3(256), lds, st, m, mode, levels, idx, cnt8, qmeta,
+                           tcount, tnq_local, idx_stride, blob_bytes);
     } else {
-        hipLaunchKernelGGL(apn::tilemap_pack_serial_kernel, dim3((b + 3) / 4), dim3(256), 0, st, b, m, mode, idx, cnt8,
-                           qmeta, tcount, tnq_local);
+        for (int z = 0; z < count; ++z)
+            hipLaunchKernelGGL(apn::tilemap_pack_serial_kernel, dim3((b + 3) / 4), dim3(256), 0, st, b, m, mode,
+                               idx + z * idx_stride, cnt8 + z * blob_bytes,
+                               (unsigned *)((char *)qmeta + z * blob_bytes), (int *)((char *)tcount + z * blob_bytes),
+                               (unsigned short *)((char *)tnq_local + z * blob_bytes));
     }
-    hipLaunchKernelGGL(apn::tilemap_fill_kernel, dim3((m + 63) / 64, b), dim3(256), 0, st, b, m, cnt8, qmeta, tcount,
-                       toff, tnq_local, tmap, tq0, rowinfo, idx, rownn);
+    hipLaunchKernelGGL(apn::tilemap_fill_kernel, dim3((m + 63) / 64, b, count), dim3(256), 0, st, b, m, cnt8, qmeta, tcount,
+                       toff, tnq_local, tmap, tq0, rowinfo, idx, rownn, idx_stride, blob_bytes);
     APN_LAUNCH_CHECK();
     return APN_OK;
+}
+
+extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *tmap, void *stream) {
+    return apn_sa_wide_tilemap_many(1, b, m, mode, idx, tmap, stream);
 }
 
 // pcnt_poff: int32[2 b n] (counts, then list starts); plist: int32[32 b m]; geo: float[4 b n];

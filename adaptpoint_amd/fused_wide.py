@@ -125,6 +125,18 @@ def tile_map(idx, fold=True, out=None):
     return tmap
 
 
+def tile_maps(idx_all, count, fold=True, out=None):
+    """The tile maps of `count` consecutive batches of one stacked index stage -- idx_all (count * B, M, 32) -- in ONE
+    pair of launches: a tensor (count, ints), row z the map of batch z (what `tile_map` gives for idx_all[z*B:(z+1)*B])."""
+    SB, M, K = idx_all.shape
+    assert K == K_NS and idx_all.dtype == torch.int32 and idx_all.is_contiguous() and SB % count == 0
+    B = SB // count
+    ints = _lib.load().apn_sa_wide_tilemap_ints(B, M)
+    maps = out if out is not None else torch.empty(count, ints, dtype=torch.int32, device=idx_all.device)
+    _call("apn_sa_wide_tilemap_many", idx_all.device, count, B, M, 1 if fold else 0, idx_all.data_ptr(), maps.data_ptr())
+    return maps
+
+
 @torch.no_grad()
 def neighbour_index(idx, new_p, n_points, fold=True, fidx=None, out=None):
     """Build the NeighbourIndex of idx (B,M,32) over n_points support points; new_p (B,M,3): the queries;

@@ -276,6 +276,15 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
         for st in sets:
             for i in range(spg):
                 blk.index_for(st[i], N_PTS, C_IN)
+        # register-resident kernels: the tile maps of a launch's spg batches live in ONE buffer per set and are built by
+        # one pair of launches over the stacked neighbour array (forty launches of 12-15 us per replay before)
+        big_maps = None
+        if all(x.tmap is not None and x.index is None for st in sets for x in st):
+            from adaptpoint_amd import fused_wide
+            big_maps = [fused_wide.tile_maps(b.idx, spg) for b in big]
+            for st, maps in zip(sets, big_maps):
+                for i in range(spg):
+                    st[i].tmap = maps[i]
     cur_set = [0]
     ones = torch.ones(1, 1, 1, device=dev)
     graph_grads, last_grads = {}, [None]
@@ -309,6 +318,9 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
         for g in range(0, count * B_PER_GPU, nb):
             hi = min(g + nb, count * B_PER_GPU)
             blk.sample(p_all[g:hi], out=big[dst].clouds(g, hi))
+        if big_maps is not None and count == spg:
+            fused_wide.tile_maps(big[dst].idx, spg, out=big_maps[dst])
+            return
         for i in range(count):
             if sets[dst][i].index is not None or sets[dst][i].tmap is not None:
                 blk.index_for(sets[dst][i], N_PTS, C_IN, out=sets[dst][i].index)

@@ -374,6 +374,9 @@ APN_API int apn_sa_wide_grid(int b, int m);          /* workgroups = partial row
  * by row; any other row is kept whole); mode 0: one tile per query, 32 rows of multiplicity 1. */
 APN_API int apn_sa_wide_tilemap_ints(int b, int m);
 APN_API int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *tmap, void *stream);
+/* count tile maps in one pair of launches (the batches of a stacked index stage): map z reads idx + z * b * m * 32
+ * and fills tmap + z * apn_sa_wide_tilemap_ints(b, m). */
+APN_API int apn_sa_wide_tilemap_many(int count, int b, int m, int mode, const int *idx, int *tmap, void *stream);
 /* out[ncol] (float64) = column sums of part[rows][ncol] (float32) in a fixed order; two passes
  * through scratch[apn_sa_wide_colsum_chunks(rows, ncol)][ncol] (float64) when there is more than one chunk */
 APN_API int apn_sa_wide_colsum_chunks(int rows, int ncol);
