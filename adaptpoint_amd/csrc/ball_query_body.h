@@ -6,6 +6,7 @@
 namespace apn {
 
 constexpr int BQ_CHUNK = 4096;             // support points staged per LDS pass (48 KiB)
+constexpr int BQ_QPW = 4;                  // queries a wave tests each staged point against
 
 // One workgroup of WAVES waves: tile `bx` of cloud `cloud`; each wave owns queries
 // q0 + wave, q0 + wave + WAVES, ... of the tile.  s_dyn: three coordinate planes of
@@ -46,35 +47,57 @@ __device__ __forceinline__ void ball_query_body(
         }
         __syncthreads();
 
-        for (int q = q_begin + wave; q < q_end; q += WAVES) {
-            const int ql = q - q_begin;
-            int cnt = __builtin_amdgcn_readfirstlane(cnt_of[ql]);  // wave-uniform
-            if (cnt >= nsample) continue;
-            int first = __builtin_amdgcn_readfirstlane(first_of[ql]);
-            const float qx = new_xyz[q * 3 + 0];
-            const float qy = new_xyz[q * 3 + 1];
-            const float qz = new_xyz[q * 3 + 2];
-            int *row = idx + (size_t)q * nsample;
-            for (int k0 = 0; k0 < len && cnt < nsample; k0 += 64) {
-                const int k = k0 + lane;
-                bool hit = false;
-                if (k < len) {
-                    const float d2 = dist2(qx - sx[k], qy - sy[k], qz - sz[k]);
-                    hit = d2 < radius2;
-                }
-                const unsigned long long mask = __ballot(hit);
-                if (mask == 0ull) continue;
-                if (cnt == 0) first = base + k0 + (int)__builtin_ctzll(mask);
-                const int slot = cnt + (int)__builtin_amdgcn_mbcnt_hi(
-                                           (unsigned)(mask >> 32),
-                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (hit && slot < nsample) row[slot] = base + k;
-                cnt += (int)__builtin_popcountll(mask);
+        // A wave takes BQ_QPW consecutive queries per pass over the chunk: a point's coordinates are read from LDS
+        // once for all of them (one query per pass spent most of its instructions on the three LDS reads and the
+        // loop; the per-query part -- distance, ballot, slot arithmetic -- and the order of the hits are unchanged)
+        for (int qb = q_begin + wave * BQ_QPW; qb < q_end; qb += WAVES * BQ_QPW) {
+            int cnt[BQ_QPW], first[BQ_QPW];
+            float qx[BQ_QPW], qy[BQ_QPW], qz[BQ_QPW];
+            bool open = false;
+#pragma unroll
+            for (int j = 0; j < BQ_QPW; ++j) {
+                const int q = qb + j;
+                const bool in = q < q_end;
+                cnt[j] = in ? __builtin_amdgcn_readfirstlane(cnt_of[q - q_begin]) : nsample;   // wave-uniform
+                first[j] = in ? __builtin_amdgcn_readfirstlane(first_of[q - q_begin]) : 0;
+                const int qc = in ? q : q_begin;
+                qx[j] = new_xyz[qc * 3 + 0];
+                qy[j] = new_xyz[qc * 3 + 1];
+                qz[j] = new_xyz[qc * 3 + 2];
+                open = open || cnt[j] < nsample;
             }
-            if (lane == 0) { cnt_of[ql] = cnt; first_of[ql] = first; }
+            if (!open) continue;
+            for (int k0 = 0; k0 < len; k0 += 64) {
+                const int k = k0 + lane;
+                const bool inside = k < len;
+                const float px = inside ? sx[k] : 0.0f, py = inside ? sy[k] : 0.0f, pz = inside ? sz[k] : 0.0f;
+                bool any_open = false;
+#pragma unroll
+                for (int j = 0; j < BQ_QPW; ++j) {
+                    if (cnt[j] >= nsample) continue;              // wave-uniform
+                    const bool hit = inside && dist2(qx[j] - px, qy[j] - py, qz[j] - pz) < radius2;
+                    const unsigned long long mask = __ballot(hit);
+                    if (mask != 0ull) {
+                        if (cnt[j] == 0) first[j] = base + k0 + (int)__builtin_ctzll(mask);
+                        const int slot = cnt[j] + (int)__builtin_amdgcn_mbcnt_hi(
+                                                      (unsigned)(mask >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if (hit && slot < nsample) idx[(size_t)(qb + j) * nsample + slot] = base + k;
+                        cnt[j] += (int)__builtin_popcountll(mask);
+                    }
+                    any_open = any_open || cnt[j] < nsample;
+                }
+                if (!any_open) break;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < BQ_QPW; ++j)
+                    if (qb + j < q_end) { cnt_of[qb + j - q_begin] = cnt[j]; first_of[qb + j - q_begin] = first[j]; }
+            }
         }
     }
 
+    __syncthreads();   // the counts were left by the wave that scanned the query's group of BQ_QPW, read below per query
     // Tail of each row: slots the scan never reached repeat the first hit
     // (ball_query_gpu.cu:41-45).  Rows of empty balls stay untouched.
     for (int q = q_begin + wave; q < q_end; q += WAVES) {
