@@ -33,35 +33,38 @@ SIGNATURES = {
     "apn_sa_grid_blocks": [_c_int] * 2,
     "apn_sa_grid_rows": [_c_int] * 3,
     "apn_sa_bwd_main_rows": [_c_int] * 2,
-    "apn_sa_bwd_acc_copies": [],
-    "apn_sa_prep_features": [_c_int] * 3 + [_c_void_p] * 2 + [_c_int, _c_void_p],
-    "apn_sa_fwd_stats1": [_c_int] * 8 + [_c_float] + [_c_void_p] * 8,
+    "apn_sa_acc_words": [_c_int],
+    "apn_zero_fill": [_c_void_p, _c_longlong, _c_void_p],
+    "apn_sa_geo_dd_doubles": [_c_int],
+    "apn_sa_point_geo": [_c_int] * 4 + [_c_float] + [_c_void_p] * 6,
+    "apn_sa_prep_rows": [_c_int] * 2,
+    "apn_sa_prep_stats": [_c_int] * 2 + [_c_void_p] * 4 + [_c_int] * 2 + [_c_void_p] * 3 + [_c_longlong, _c_void_p],
     "apn_sa_reduce_rows": [_c_void_p, _c_int, _c_int, _c_double, _c_void_p, _c_void_p],
+    "apn_sa_reduce_acc": [_c_void_p, _c_int, _c_double, _c_void_p, _c_void_p],
     "apn_sa_bn_fold": [_c_void_p, _c_int, _c_void_p, _c_int, _c_double, _c_void_p, _c_void_p,
                        _c_float, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                        _c_void_p, _c_int, _c_void_p, _c_void_p],
-    "apn_sa_fwd_main": [_c_int] * 8 + [_c_float] + [_c_void_p] * 14,
-    "apn_sa_fwd_out": [_c_int] * 3 + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 3 + [_c_int]
-                      + [_c_void_p] * 2 + [_c_longlong, _c_void_p],
+    "apn_sa_fwd_main": [_c_int] * 4 + [_c_float] + [_c_void_p] * 12 + [_c_float, _c_float, _c_int, _c_double,
+                                                                        _c_void_p, _c_int] + [_c_void_p] * 7,
+    "apn_sa_fwd_out": [_c_int] * 3 + [_c_void_p] * 8 + [_c_float, _c_float, _c_int, _c_double] + [_c_void_p] * 2
+                      + [_c_int] + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 2 + [_c_longlong, _c_void_p],
     "apn_sa_bwd_prep_rows": [_c_int] * 2,
     "apn_sa_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] + [_c_int]
                        + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 7,
-    "apn_sa_bwd_consts2": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_double, _c_int] + [_c_void_p] * 8,
-    "apn_sa_bwd_main": [_c_int] * 8 + [_c_float] + [_c_void_p] * 20,
-    "apn_sa_bwd_consts1": [_c_void_p, _c_int] + [_c_void_p] * 2 + [_c_double, _c_int] + [_c_void_p] * 9,
+    "apn_sa_bwd_main": [_c_int] * 4 + [_c_float] + [_c_void_p] * 11 + [_c_double, _c_int] + [_c_void_p] * 8,
     "apn_sa_bwd_weight_rows": [_c_int] * 2,
-    "apn_sa_bwd_point_grads": [_c_int] * 3 + [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 4 + [_c_float]
-                              + [_c_void_p] * 5,
-    "apn_sa_bwd_finalize": [_c_void_p, _c_int, _c_float, _c_void_p, _c_void_p, _c_int, _c_void_p,
-                            _c_void_p, _c_void_p, _c_void_p],
-    "apn_sa_forward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 10
+    "apn_sa_bwd_point_grads": [_c_int] * 3 + [_c_void_p] * 6 + [_c_double, _c_int] + [_c_void_p] * 2 + [_c_int]
+                              + [_c_void_p] * 4 + [_c_float] + [_c_void_p] * 5,
+    "apn_sa_bwd_finalize": [_c_void_p, _c_int, _c_float, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int]
+                           + [_c_void_p] * 11,
+    "apn_sa_forward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 12
                            + [_c_void_p] * 5 + [_c_float, _c_float, _c_int]
                            + [_c_void_p] * 5 + [_c_float, _c_float, _c_int]
-                           + [_c_double, _c_int] + [_c_void_p] * 12 + [_c_longlong, _c_void_p]),
+                           + [_c_double, _c_int] + [_c_void_p] * 11 + [_c_longlong, _c_void_p]),
     "apn_sa_backward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 15 + [_c_int] * 3
                             + [_c_double] + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p]
-                            + [ctypes.c_size_t]
-                            + [_c_void_p] * 30),
+                            + [_c_longlong]
+                            + [_c_void_p] * 24),
     "apn_attention_prep": [_c_int] * 3 + [_c_void_p] * 4 + [_c_int, _c_void_p],
     "apn_attention_fwd": [_c_int] * 3 + [_c_void_p] * 4,
     "apn_attention_bwd": [_c_int] * 3 + [_c_void_p] * 9,
@@ -119,7 +122,7 @@ SIGNATURES = {
     "apn_spectral_norm": [_c_int] * 2 + [_c_void_p, _c_int, _c_float] + [_c_void_p] * 8,
     "apn_spectral_norm_grad": [_c_int] * 2 + [_c_void_p] * 8,
     "apn_sa_sample_overlap": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 7,
-    "apn_sa_sample_seq": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 6,
+    "apn_sa_sample_seq": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 8,
 }
 
 _lib = None

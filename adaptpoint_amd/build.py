@@ -16,8 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libadaptpoint_amd.so")
 ARCH = "gfx950"
-SOURCES = ["capi.hip", "fps.hip", "ball_query.hip", "group_points.hip", "interpolate.hip", "sa_fused.hip", "sa_glue.hip", "sa_seq.hip", "sa_wide.hip", "sa_wide_glue.hip", "sa_wide_dense.hip", "pointwise.hip", "spectral.hip", "augment.hip", "pointset_group.hip", "attention.hip"]
-HEADERS = ["apn_common.h", "apn_mfma.h", "ball_query_body.h",
+SOURCES = ["capi.hip", "fps.hip", "ball_query.hip", "group_points.hip", "interpolate.hip", "sa_fused.hip", "sa_glue.hip", "sa_seq.hip", "sa_geo.hip", "sa_wide.hip", "sa_wide_glue.hip", "sa_wide_dense.hip", "pointwise.hip", "spectral.hip", "augment.hip", "pointset_group.hip", "attention.hip"]
+HEADERS = ["apn_common.h", "apn_mfma.h", "sa_chain.h", "ball_query_body.h",
            os.path.join("..", "..", "include", "adaptpoint_amd.h")]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
             "-fvisibility=hidden", "-Wall", "-Wno-unused-command-line-argument"]

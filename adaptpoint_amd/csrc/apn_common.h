@@ -56,7 +56,49 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 
 // copies of the register-resident backward pass's dL/dW2 accumulators (sa_fused.hip: sa_bwd_kernel's tail;
 // cleared by bwd_consts2, added up by bwd_consts1 in sa_glue.hip)
-constexpr int SA_ACC_COPIES = 8;
+
+
+// ---------------------------------------------------------------------------------------------
+// Order-independent accumulators ("acc sets") for the per-channel sums that cross workgroups
+// inside the fused set-abstraction chain (BatchNorm statistics and their backward terms).
+// A producer workgroup adds its float partial sum v with TWO 64-bit integer atomics,
+//     hi += floor(v)            lo += (v - floor(v)) * 2^52            (value = hi + lo * 2^-52),
+// so the total is exact for every addend (|v| < 2^62, resolution 2^-52 absolute) and does not
+// depend on the order the atomics retire in: the consumer kernels read the SAME bits run after run
+// without a fold launch between producer and consumer.  ACC_COPIES copies per set spread the
+// same-address traffic (workgroup w adds into copy w % ACC_COPIES; 500-800 workgroups on one set of
+// addresses serialise for microseconds); the consumer adds the copies.  Cell ncol of a copy is a
+// flag: a non-finite or out-of-range addend bumps it and the consumer returns NaN (loud, not silent).
+// Layout: set[copy][ncol + 1][2] unsigned 64-bit words, caller- (i.e. earlier-kernel-) zeroed.
+constexpr int ACC_COPIES = 8;
+__host__ __device__ constexpr int acc_words(int ncol) { return ACC_COPIES * (ncol + 1) * 2; }
+
+__device__ __forceinline__ void acc_add(unsigned long long *set, int ncol, int copy, int col, float v) {
+    unsigned long long *cell = set + ((size_t)copy * (ncol + 1) + col) * 2;
+    const double dv = (double)v;
+    if (!(__builtin_fabs(dv) < 4611686018427387904.0)) {      // NaN, inf or >= 2^62
+        atomicAdd(set + ((size_t)copy * (ncol + 1) + ncol) * 2, 1ull);
+        return;
+    }
+    const double dh = __builtin_floor(dv);
+    atomicAdd(cell, (unsigned long long)(long long)dh);
+    atomicAdd(cell + 1, (unsigned long long)((dv - dh) * 4503599627370496.0));
+}
+
+// the total of column `col` over the copies (NaN if any copy's flag is set)
+__device__ __forceinline__ double acc_read(const unsigned long long *set, int ncol, int col) {
+    long long hi = 0;
+    unsigned long long lo = 0, bad = 0;
+#pragma unroll
+    for (int k = 0; k < ACC_COPIES; ++k) {
+        const unsigned long long *cp = set + (size_t)k * (ncol + 1) * 2;
+        hi += (long long)cp[2 * col];
+        lo += cp[2 * col + 1];
+        bad |= cp[2 * ncol];
+    }
+    if (bad) return __builtin_nan("");
+    return (double)hi + (double)lo * (1.0 / 4503599627370496.0);
+}
 
 __device__ __forceinline__ int lane_id() {
     return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));

@@ -47,6 +47,7 @@
 // Both are far below the per-tile VALU/gather latency, which is what bounds it.
 #include "apn_common.h"
 #include "apn_mfma.h"
+#include "sa_chain.h"
 
 namespace apn {
 
@@ -76,32 +77,13 @@ __device__ __forceinline__ Frag<NS> get_frag(const uint4 *base, int f, int lane)
     return v;
 }
 
-// (B,C,N) f32 channel-major  ->  (B,N,C) bf16 point-major, C = 32: one 64-byte row per point.
-// ft_lo (optional): the bf16 remainder f - float(ft), for the split-operand mode.
-__global__ __launch_bounds__(256) void sa_prep_features_kernel(int n, const float *__restrict__ f,
-                                                               __bf16 *__restrict__ ft,
-                                                               __bf16 *__restrict__ ft_lo) {
-    __shared__ float tile[SA_C][65];
-    const int cloud = blockIdx.y;
-    const int n0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
-    for (int c = ty; c < SA_C; c += 4) {
-        const int p = n0 + tx;
-        tile[c][tx] = p < n ? f[((size_t)cloud * SA_C + c) * n + p] : 0.0f;
-    }
-    __syncthreads();
-    // 64 points x 32 channels: thread -> (point = tid>>2, 8 channels = (tid&3)*8)
-    const int pt = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 8;
-    if (n0 + pt < n) {
-        bf16x8 o, ol;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            o[j] = (__bf16)tile[c0 + j][pt];
-            ol[j] = (__bf16)(tile[c0 + j][pt] - (float)o[j]);
-        }
-        *reinterpret_cast<bf16x8 *>(ft + ((size_t)cloud * n + n0 + pt) * SA_C + c0) = o;
-        if (ft_lo) *reinterpret_cast<bf16x8 *>(ft_lo + ((size_t)cloud * n + n0 + pt) * SA_C + c0) = ol;
-    }
+// The operand value the MFMA sees: rounded to bf16, or to hi + lo bf16 parts (split mode).
+template <int NS>
+__device__ __forceinline__ float eff(float v) {
+    const __bf16 hi = (__bf16)v;
+    float r = (float)hi;
+    if (NS == 2) r += (float)(__bf16)(v - r);
+    return r;
 }
 
 struct SaArgs {
@@ -150,6 +132,114 @@ __device__ __forceinline__ void load_w1_frags(const float *__restrict__ w1, int 
             t[j] = s < 2 ? w1[r * 35 + 3 + 16 * s + 8 * h + j]
                          : ((h == 0 && j < 3) ? w1[r * 35 + j] : 0.0f);
         wf[s] = make_frag<NS>(t);
+    }
+}
+
+// Forward launch 1 of 3: the point-major operand table AND BatchNorm-1's batch statistics, per POINT.
+//   ft[b][n][0..31] = bf16(f[b][:, n])  (+ the remainder table in split mode): one 64-byte row per point, so that
+//   a neighbour gather is two 16-byte loads per lane instead of 32 strided 4-byte loads;
+//   part[workgroup][64] = {sum y1, sum y1^2}[32] over the positions that gather the workgroup's points, from the
+//   index stage's occurrence statistics (sa_geo.hip): with F = W1f f_n (operands as the MFMA sees them),
+//   sum y1 = occ F + W1p D,  sum y1^2 = occ F^2 + 2 F W1p D  (+ W1p DD W1p^T once, added by workgroup 0).
+// No pass over the positions: this replaced sa_prep_features + sa_fwd_stats1 (6.7 + 8.8 us at B = 32).
+// A wave owns 32 points: their operand fragments (the hi / lo split of 16 channels per lane) ARE the table rows it
+// writes, and F = X W1f^T is two MFMA k-steps (accumulator: lane = mid channel, register = point), so the
+// statistics are 16 fused multiply-adds per lane.  At most PS_MAX_ROWS workgroups of 16 waves, each walking
+// tiles of 512 points: few enough partial rows that every workgroup of the next launch folds them itself
+// (no fold launch, fixed order: deterministic).
+constexpr int PS_PTS = 512, PS_MAX_ROWS = 64;
+constexpr double GEO_INV_UNIT = 1.0 / 68719476736.0;       // sa_geo.hip: D in units of 2^-36
+
+template <int NS>
+__global__ __launch_bounds__(1024) void sa_prep_stats_kernel(
+    int n, int tiles_per_cloud, int total_tiles, const float *__restrict__ f, const long long *__restrict__ geo,
+    const double *__restrict__ dd, int dd_rows, const float *__restrict__ w1, int stats, __bf16 *__restrict__ ft,
+    __bf16 *__restrict__ ft_lo, float *__restrict__ part, unsigned long long *__restrict__ zero, long long zero_words) {
+    extern __shared__ float sf_raw[];                            // [32][PS_PTS + 1] the tile, channel-major
+    float (*sf)[PS_PTS + 1] = reinterpret_cast<float (*)[PS_PTS + 1]>(sf_raw);
+    __shared__ float4 sgeo[PS_PTS];                              // {occ, Dx, Dy, Dz} of the tile's points
+    __shared__ float red[16][64];
+    __shared__ double sdd[6];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // accumulators of LATER launches (BatchNorm-2's sums) are cleared here
+    for (long long e = (long long)blockIdx.x * 1024 + tid; e < zero_words; e += (long long)gridDim.x * 1024) zero[e] = 0ull;
+    Frag<NS> wf[3];                                              // W1f^T as B operand: lane = mid channel r (step 2 unused)
+    load_w1_frags<NS>(w1, r, h, wf);
+    const float wp0 = eff<NS>(w1[r * 35]), wp1 = eff<NS>(w1[r * 35 + 1]), wp2 = eff<NS>(w1[r * 35 + 2]);
+    float s1 = 0.0f, s2 = 0.0f;                                  // this lane's mid channel r, its half's points
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int cloud = tile / tiles_per_cloud, n0 = (tile % tiles_per_cloud) * PS_PTS;
+        {
+            const int pt = tid & (PS_PTS - 1), cg = tid >> 9;
+            const bool in = n0 + pt < n;
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = in ? f[((size_t)cloud * SA_C + cg + 2 * k) * n + n0 + pt] : 0.0f;
+            float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (stats && in && cg == 0) {
+                const longlong2 *gp = reinterpret_cast<const longlong2 *>(geo + ((size_t)cloud * n + n0 + pt) * 4);
+                const longlong2 g0 = gp[0], g1 = gp[1];
+                gv = make_float4((float)g0.x, (float)((double)g0.y * GEO_INV_UNIT), (float)((double)g1.x * GEO_INV_UNIT),
+                                 (float)((double)g1.y * GEO_INV_UNIT));
+            }
+            __syncthreads();                                        // the previous tile's readers
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sf[cg + 2 * k][pt] = v[k];
+            if (cg == 0) sgeo[pt] = gv;
+        }
+        __syncthreads();
+        const int pt = 32 * wave + r;                               // this lane's point: channels 8h.., 16 + 8h..
+        float x0[8], x1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x0[j] = sf[8 * h + j][pt]; x1[j] = sf[16 + 8 * h + j][pt]; }
+        const Frag<NS> a0 = make_frag<NS>(x0), a1 = make_frag<NS>(x1);
+        if (n0 + pt < n) {
+            uint4 *row = reinterpret_cast<uint4 *>(ft + ((size_t)cloud * n + n0 + pt) * SA_C);
+            row[h] = __builtin_bit_cast(uint4, a0.p[0]);
+            row[2 + h] = __builtin_bit_cast(uint4, a1.p[0]);
+            if (NS == 2) {
+                uint4 *rl = reinterpret_cast<uint4 *>(ft_lo + ((size_t)cloud * n + n0 + pt) * SA_C);
+                rl[h] = __builtin_bit_cast(uint4, a0.p[NS - 1]);
+                rl[2 + h] = __builtin_bit_cast(uint4, a1.p[NS - 1]);
+            }
+        }
+        if (stats) {
+            f32x16 y = {0};
+            y = mfma<NS>(a0, wf[0], y);                             // F: lane = mid channel r, register = point
+            y = mfma<NS>(a1, wf[1], y);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float4 g = sgeo[32 * wave + acc_row(i, h)];
+                const float PD = __builtin_fmaf(wp2, g.w, __builtin_fmaf(wp1, g.z, wp0 * g.y));
+                const float oF = g.x * y[i];
+                s1 += oF + PD;
+                s2 += __builtin_fmaf(oF, y[i], 2.0f * y[i] * PD);
+            }
+        }
+    }
+    if (!stats) return;
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (lane < 32) { red[wave][r] = s1; red[wave][32 + r] = s2; }
+    if (blockIdx.x == 0 && tid >= 64 && tid < 70) {          // the batch's second moments: its clouds' shares, in order
+        double s = 0.0;
+        for (int e = 0; e < dd_rows; ++e) s += dd[(size_t)e * 6 + (tid - 64)];
+        sdd[tid - 64] = s;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float val = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) val += red[w][tid];
+        if (tid >= 32 && blockIdx.x == 0) {
+            // the per-position term of sum y1^2: (W1p d)^2 summed over all positions = W1p DD W1p^T
+            const double wx = wp0, wy = wp1, wz = wp2;           // tid & 31 == r
+            const double t = wx * wx * sdd[0] + 2.0 * wx * wy * sdd[1] + 2.0 * wx * wz * sdd[2] + wy * wy * sdd[3] +
+                             2.0 * wy * wz * sdd[4] + wz * wz * sdd[5];
+            val += (float)t;
+        }
+        part[(size_t)blockIdx.x * 64 + tid] = val;
     }
 }
 
@@ -242,17 +332,26 @@ __device__ __forceinline__ void build_frags(const SaArgs &a, const TileRaw<NS> &
 
 // The tile loop of a wave, software-pipelined as described above.  BODY(tile, raw) consumes one
 // fetched tile.
+// PROLOGUE() is the kernel's workgroup-wide start-up (constant fragments into LDS, the BatchNorm fold: barriers
+// inside, so EVERY wave runs it, also one without tiles).  It runs AFTER the wave's first tile has been
+// requested: the head of that tile is read speculatively, before the tile count is known (any tile number below
+// the map's capacity B*M addresses allocated rows), so the start-up's own round trips (partial rows, weights)
+// overlap the dependent head -> rows chain instead of preceding it.
 // PRE() runs at the top of every iteration BEFORE the next tile's loads are issued, and once more
 // after the last tile: the place for stores / atomics deferred from the previous tile.  The
 // memory counter is in order, so anything issued between a prefetch and the wait for it is
 // waited for too; deferred to here, the atomics of tile t have the whole of tile t+1 to retire.
-template <int NS, bool CP, typename Pre, typename Body>
-__device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Pre pre, Body body) {
-    const int tiles = CP ? tm_tiles(a) : a.b * a.m, stride = gridDim.x * SA_WAVES;
+template <int NS, bool CP, typename Pro, typename Pre, typename Body>
+__device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Pro prologue, Pre pre, Body body) {
+    const int cap = a.b * a.m, stride = gridDim.x * SA_WAVES;
     int tile = blockIdx.x * SA_WAVES + wave;
-    if (tile >= tiles) return;
+    const TileHead hd0 = load_head<CP>(a, tile < cap ? tile : 0, r);
+    const int tiles = CP ? tm_tiles(a) : cap;
     TileRaw<NS> cur, nxt;
-    fetch_tile<NS>(a, load_head<CP>(a, tile, r), h, cur);
+    const bool any = tile < tiles;                                 // wave-uniform
+    if (any) fetch_tile<NS>(a, hd0, h, cur);
+    prologue();
+    if (!any) return;
     TileHead hd_nxt = load_head<CP>(a, tile + stride < tiles ? tile + stride : tile, r);
     for (; tile < tiles; tile += stride) {
         const bool more = tile + stride < tiles;               // wave-uniform
@@ -266,18 +365,11 @@ __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, 
     pre();
 }
 
-template <int NS, bool CP, typename Body>
-__device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Body body) {
-    for_each_tile<NS, CP>(a, wave, r, h, [] {}, body);
-}
-
-// Workgroup-level fold of per-lane statistics into ONE partial row per workgroup:
-// part[blockIdx.x][NV*32].  vals[i] belongs to channel (i*32 + r) of this lane's half;
-// halves and waves add.  The consumer kernel (sa_glue.hip) sums the rows in float64 --
-// deterministic, and cheaper than 512 workgroups contending on 64 atomic addresses.
+// Workgroup-level fold of per-lane statistics: vals[i] belongs to channel (i*32 + r) of this lane's half;
+// halves and waves add.  Thread e < NV*32 returns the workgroup's sum of column e (the others 0), which it then
+// adds into the launch's accumulator set (apn_common.h: acc_add -- integer atomics, order-independent).
 template <int NV>
-__device__ __forceinline__ void write_partials(float (&vals)[NV], float *__restrict__ part,
-                                               int lane, int wave) {
+__device__ __forceinline__ float fold_partials(float (&vals)[NV], int lane, int wave) {
     __shared__ float red[SA_WAVES][NV][32];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -285,94 +377,112 @@ __device__ __forceinline__ void write_partials(float (&vals)[NV], float *__restr
         if (lane < 32) red[wave][i][lane] = vals[i] + other;
     }
     __syncthreads();
-    float *row = part + (size_t)blockIdx.x * NV * 32;
-    for (int e = threadIdx.x; e < NV * 32; e += SA_WAVES * 64) {
-        float s = 0.0f;
+    float s = 0.0f;
+    const int e = threadIdx.x;
+    if (e < NV * 32) {
 #pragma unroll
         for (int w = 0; w < SA_WAVES; ++w) s += red[w][e >> 5][e & 31];
-        row[e] = s;
     }
+    return s;
 }
 
-// Pass 1: statistics of y1 = conv1(x).  part[gridDim.x][64] = {sum[32], sumsq[32]}.
-template <int NS, bool CP>
-__global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_stats1_kernel(SaArgs a,
-                                                                      float *__restrict__ part) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __shared__ uint4 cfrag[3 * NS * 64];
-    if (wave == 0) {
-        Frag<NS> w1f[3];
-        load_w1_frags<NS>(a.w1, r, h, w1f);
+// The BatchNorm fold inside its consumer: float64 column sums of part[rows][2 C] (C = 32: rows of 64 floats; a few
+// dozen rows from sa_prep_stats_kernel), or already reduced sums[2 C + 2] = {sums, global count, world} (the
+// SyncBatchNorm path), then the C channel constants by threads 0..C-1.  For a workgroup of 256 threads; fixed
+// summation order: every workgroup computes the same bits.  Workgroup 0 also leaves pack[4][C] and updates the
+// running buffers.  scale/shift are valid in threads 0..C-1 on return (no trailing barrier).
+__device__ __forceinline__ void fold_rows32(const float *__restrict__ part, int rows, const double *__restrict__ sums,
+                                            const BnArgs &bn, float *__restrict__ pack, float &scale, float &shift) {
+    __shared__ double fred[16][64];
+    __shared__ double ftot[64];
+    const int tid = threadIdx.x;
+    double count = bn.count;
+    if (bn.training) {
+        if (part) {
+            const int quad = tid & 15, rg = tid >> 4;
+            const float4 *__restrict__ p4 = reinterpret_cast<const float4 *>(part) + quad;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int rr = rg;
+            for (; rr + 7 * 16 < rows; rr += 8 * 16) {
+                float4 v[8];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) put_frag<NS>(cfrag, s, lane, w1f[s]);
-    }
-    __syncthreads();
-    float st[2] = {0.0f, 0.0f};
-    for_each_tile<NS, CP>(a, wave, r, h, [&](int, const TileRaw<NS> &raw) {
-        int lane_o = lane;                       // see sa_bwd_kernel: fragments are read per use
-        asm volatile("" : "+v"(lane_o));
-        Frag<NS> x[3];
-        build_frags<NS>(a, raw, h, x);
-        f32x16 y = {0};
+                for (int u = 0; u < 8; ++u) v[u] = p4[(size_t)(rr + 16 * u) * 16];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) y = mfma<NS>(x[s], get_frag<NS>(cfrag, s, lane_o), y);  // Y1: lane = mid channel
-        if (CP) {                                // a row stands for `mult` positions
-            unsigned meta[16];
-            row_meta(raw.info, h, meta);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float wy = (float)ri_mult(meta[i]) * y[i];
-                st[0] += wy;
-                st[1] += wy * y[i];
+                for (int u = 0; u < 8; ++u) {
+                    s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w;
+                }
             }
-        } else {
+            for (; rr < rows; rr += 16) {
+                const float4 v = p4[(size_t)rr * 16];
+                s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+            }
+            fred[rg][4 * quad] = s0; fred[rg][4 * quad + 1] = s1; fred[rg][4 * quad + 2] = s2; fred[rg][4 * quad + 3] = s3;
+            __syncthreads();
+            if (tid < 64) {
+                double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { st[0] += y[i]; st[1] += y[i] * y[i]; }
+                for (int k = 0; k < 16; ++k) s += fred[k][tid];
+                ftot[tid] = s;
+            }
+        } else if (tid < 64) {
+            ftot[tid] = sums[tid];
         }
-    });
-    write_partials<2>(st, part, lane, wave);
+        if (!part) count = sums[64];
+        __syncthreads();
+    }
+    if (tid < 32) {
+        if (tid == 0 && blockIdx.x == 0 && bn.training && bn.nbt) *bn.nbt += 1;
+        bn_channel(bn, 32, tid, bn.training ? ftot[tid] : 0.0, bn.training ? ftot[32 + tid] : 0.0, count,
+                   blockIdx.x == 0, pack, scale, shift);
+    }
 }
 
-// Pass 2.  scale1/shift1: BN1 folded to y*scale+shift; sgn2[c] = +1/-1 (sign of gamma2).
-// Outputs ysel/ksel (B,M,64): the extreme of y2 over K and its position;
-// part[gridDim.x][128] = {sum[64], sumsq[64]} of y2.
+// Forward launch 2 of 3.  Prologue: BatchNorm-1 folded from the partial rows of sa_prep_stats_kernel (or from reduced
+// sums); then per tile a1 = relu(bn1(conv1)), y2 = conv2(a1).  Outputs ysel/ksel (B,M,64): the extreme of y2 over K
+// (max where gamma2 >= 0, else min) and its position; {sum[64], sumsq[64]} of y2 into the accumulator set acc2
+// (cleared by the launch before); pack1 (workgroup 0) for the backward.
 template <int NS, bool CP>
-__global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
-    SaArgs a, const float *__restrict__ w2, const float *__restrict__ scale1,
-    const float *__restrict__ shift1, const float *__restrict__ sgn2, float *__restrict__ ysel,
-    unsigned char *__restrict__ ksel, float *__restrict__ part) {
+__global__ __launch_bounds__(SA_WAVES * 64, 3) void sa_fwd_main_kernel(
+    SaArgs a, const float *__restrict__ w2, BnArgs bn1, const float *__restrict__ part1, int rows1,
+    const double *__restrict__ sums1, float *__restrict__ pack1, const float *__restrict__ gamma2,
+    float *__restrict__ ysel, unsigned char *__restrict__ ksel, unsigned long long *__restrict__ acc2) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     enum { F_W1 = 0, F_W2 = 3, F_COUNT = 7 };
     __shared__ uint4 cfrag[F_COUNT * NS * 64];
     __shared__ __attribute__((aligned(16))) float bn1v[2][2][16];   // {scale, shift}[h][register]
-    if (wave == 0) {
-        Frag<NS> w1f[3];
-        load_w1_frags<NS>(a.w1, r, h, w1f);
-#pragma unroll
-        for (int s = 0; s < 3; ++s) put_frag<NS>(cfrag, F_W1 + s, lane, w1f[s]);
-        if (lane < 32) {
-            bn1v[0][lane >> 4][lane & 15] = scale1[acc_row(lane & 15, lane >> 4)];
-            bn1v[1][lane >> 4][lane & 15] = shift1[acc_row(lane & 15, lane >> 4)];
-        }
-    }
-    if (wave == 1 || wave == 2) {
-        // conv2 B fragments: lane (out channel 32 t + r, h), step s, element j <-> mid channel row(8s+j, h)
-        const int t = wave - 1;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float tmp[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) tmp[j] = w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
-            put_frag<NS>(cfrag, F_W2 + 2 * t + s, lane, make_frag<NS>(tmp));
-        }
-    }
-    __syncthreads();
-    const float sg[2] = {sgn2[r], sgn2[32 + r]};
+    const float sg[2] = {(!gamma2 || gamma2[r] >= 0.0f) ? 1.0f : -1.0f, (!gamma2 || gamma2[32 + r] >= 0.0f) ? 1.0f : -1.0f};
     float st[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum t0, sum t1, sumsq t0, sumsq t1
 
-    for_each_tile<NS, CP>(a, wave, r, h, [&](int tile, const TileRaw<NS> &raw) {
+    auto prologue = [&]() {
+        if (wave == 0) {
+            Frag<NS> w1f[3];
+            load_w1_frags<NS>(a.w1, r, h, w1f);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) put_frag<NS>(cfrag, F_W1 + s, lane, w1f[s]);
+        }
+        if (wave == 1 || wave == 2) {
+            // conv2 B fragments: lane (out channel 32 t + r, h), step s, element j <-> mid channel row(8s+j, h)
+            const int t = wave - 1;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float tmp[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tmp[j] = w2[(32 * t + r) * SA_C1 + acc_row(8 * s + j, h)];
+                put_frag<NS>(cfrag, F_W2 + 2 * t + s, lane, make_frag<NS>(tmp));
+            }
+        }
+        float sc, sh;
+        fold_rows32(part1, rows1, sums1, bn1, pack1, sc, sh);
+        if (threadIdx.x < 32) {          // channel i sits in half (i >> 2) & 1, register (i & 3) + 4 (i >> 3)
+            const int i = threadIdx.x;
+            bn1v[0][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = sc;
+            bn1v[1][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = sh;
+        }
+        __syncthreads();
+    };
+
+    for_each_tile<NS, CP>(a, wave, r, h, prologue, [] {}, [&](int tile, const TileRaw<NS> &raw) {
         int lane_o = lane;                       // see sa_bwd_kernel: fragments are read per use
         asm volatile("" : "+v"(lane_o));
         Frag<NS> x[3];
@@ -458,7 +568,8 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
             }
         }
     });
-    write_partials<4>(st, part, lane, wave);
+    const float tot = fold_partials<4>(st, lane, wave);
+    if (threadIdx.x < 128) acc_add(acc2, 128, blockIdx.x % ACC_COPIES, threadIdx.x, tot);
 }
 
 // ---------------------------------------------------------------------------
@@ -497,20 +608,26 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_fwd_main_kernel(
 // layout that the ReLU mask and BN1 terms already use.
 struct SaBwdArgs {
     const float *w2;        // (64,32)
-    const float *scale1, *shift1, *mean1, *inv1;   // BN1 fold and statistics [32]
-    const float *qm;        // (32,32)  W2^T diag(D2) W2, qm[k][mid]
-    const float *evec;      // [32]     sum_c E2[c] W2[c][mid]
+    const float *scale1, *shift1, *mean1, *inv1;   // BN1 fold and statistics [32] (pack1 of the forward)
+    const float *pack2;     // BN2 {scale, shift, mean, invstd}[64] (the forward's)
+    const unsigned long long *accS;   // accumulator set {S1 = sum g, S2 = sum g*yhat_sel}[64] of the backward entry, or
+    const double *sumsS;              // ... the reduced sums {S[128], global count, world} (SyncBatchNorm)
+    double count;           // positions on this rank
+    int train2;
     const float *goa;       // (B,M,64)
     const unsigned char *ksel;  // (B,M,64)
 };
 
+// Backward launch 2 of 4.  Prologue (every workgroup, same bits): the per-channel constants of
+//   dL/dy2 = goa*[pos==ksel] + y2*D2 + E2,  D2 = -scale2 inv2 S2 / P,  E2 = -scale2 S1 / P + scale2 mean2 inv2 S2 / P
+// and their images through W2: Qm = W2^T diag(D2) W2 (32x32), evec = E2 W2 -- formerly a launch of its own.
+// Epilogue: the workgroup's share of dL/dW2 = sparse part + D2 (W2 Gram) + E2 (x) suma as ONE partial row
+// partW2[workgroup][64*32] (summed in float64, in a fixed order, by the last launch): no float atomics on dL/dW2.
 template <int NS, bool CP>
 __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
-                                                               float *__restrict__ part,
-                                                               float *__restrict__ gw2_acc,
-                                                               float *__restrict__ gram_acc,
+                                                               unsigned long long *__restrict__ accT,
+                                                               float *__restrict__ partW2,
                                                                float *__restrict__ A,
-                                                               float *__restrict__ geo,
                                                                float *__restrict__ HA,
                                                                float *__restrict__ HB) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -519,40 +636,11 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     enum { F_W1 = 0, F_QM = 3, F_W2T = 5, F_COUNT = 9 };
     __shared__ uint4 cfrag[F_COUNT * NS * 64];
     __shared__ __attribute__((aligned(16))) float bn1v[2][2][16];   // {scale, shift}[h][register]
-    {
-        Frag<NS> w1f[3];
-        load_w1_frags<NS>(a.w1, r, h, w1f);
-        if (wave == 0) {
-#pragma unroll
-            for (int s = 0; s < 3; ++s) put_frag<NS>(cfrag, F_W1 + s, lane, w1f[s]);
-        }
-        if (wave == 1) {
-            // term 1 of dL/da1: B fragments of Qm, k slot (h,j) of step s <-> mid' = row(8s+j,h)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float tmp[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) tmp[j] = g.qm[acc_row(8 * s + j, h) * SA_C1 + r];
-                put_frag<NS>(cfrag, F_QM + s, lane, make_frag<NS>(tmp));
-            }
-            if (lane < 32) {
-                bn1v[0][lane >> 4][lane & 15] = g.scale1[acc_row(lane & 15, lane >> 4)];
-                bn1v[1][lane >> 4][lane & 15] = g.shift1[acc_row(lane & 15, lane >> 4)];
-            }
-        }
-        if (wave == 2) {
-            // term 3: B fragments of W2 with k = output channel in natural order 16 s + 8 h + j
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float tmp[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) tmp[j] = g.w2[(16 * s + 8 * h + j) * SA_C1 + r];
-                put_frag<NS>(cfrag, F_W2T + s, lane, make_frag<NS>(tmp));
-            }
-        }
-    }
+    __shared__ __attribute__((aligned(16))) float sw2[SA_C2][SA_C1 + 4];   // W2 (prologue products, epilogue row)
+    __shared__ float sD[SA_C2], sE[SA_C2];
+    __shared__ __attribute__((aligned(16))) float sqm[SA_C1 + 1][SA_C1 + 4];   // Qm[k][mid]; row 32 = evec; later Gram | suma
     const float sc1 = g.scale1[r], sh1 = g.shift1[r], mu1 = g.mean1[r], iv1 = g.inv1[r];
-    const float ev = g.evec[r];
+    float ev = 0.0f;
     float sacc[32];           // lane c: sparse part of dL/dW2[c][mid], mid = acc_row(i, 0) | acc_row(i, 1)
 #pragma unroll
     for (int i = 0; i < 32; ++i) sacc[i] = 0.0f;
@@ -566,11 +654,96 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     constexpr int SP_BYTES = SA_WAVES * NS * SP_TILE * 2, WRED_BYTES = SA_WAVES * SA_C2 * SA_C1 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char sp_raw[SP_BYTES > WRED_BYTES ? SP_BYTES : WRED_BYTES];
     __bf16 *sp_img = reinterpret_cast<__bf16 *>(sp_raw) + wave * NS * SP_TILE;
-    for (int e = lane; e < NS * SP_TILE; e += 64) sp_img[e] = (__bf16)0.0f;
-    __syncthreads();
+
+    auto prologue = [&]() {
+        const int tid = threadIdx.x;
+        {   // requested first: everything the constants need
+            Frag<NS> w1f[3];
+            if (wave == 0) load_w1_frags<NS>(a.w1, r, h, w1f);
+            float wv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wv[k] = g.w2[tid + 256 * k];
+            double sv = 0.0, count = g.count;                // S[tid] (threads 0..127: one column each)
+            float p_sc = 0.0f, p_mu = 0.0f, p_iv = 0.0f;
+            if (tid < 128) sv = g.sumsS ? g.sumsS[tid] : acc_read(g.accS, 128, tid);
+            if (g.sumsS) count = g.sumsS[128];
+            if (tid < 64) { p_sc = g.pack2[tid]; p_mu = g.pack2[128 + tid]; p_iv = g.pack2[192 + tid]; }
+            if (wave == 0) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) put_frag<NS>(cfrag, F_W1 + s, lane, w1f[s]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sw2[(tid + 256 * k) >> 5][tid & 31] = wv[k];
+            // S2 (threads 64..127) meets S1 (threads 0..63) in the same wave's other half: lanes l and l + 64 are
+            // different waves, so it goes through LDS (sqm is free until the barrier below)
+            double *sS2 = reinterpret_cast<double *>(&sqm[0][0]);
+            if (tid >= 64 && tid < 128) sS2[tid - 64] = sv;
+            __syncthreads();
+            if (tid < 64) {
+                const double sc = p_sc, mu = p_mu, iv = p_iv, s1 = sv, s2 = sS2[tid];
+                double d = 0.0, e = 0.0;
+                if (g.train2) {
+                    d = -sc * iv * s2 / count;
+                    e = -sc * s1 / count + sc * mu * iv * s2 / count;
+                }
+                sD[tid] = (float)d;
+                sE[tid] = (float)e;
+            }
+            if (tid >= 64 && tid < 96) {
+                const int i = tid - 64;          // channel i sits in half (i >> 2) & 1, register (i & 3) + 4 (i >> 3)
+                bn1v[0][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = g.scale1[i];
+                bn1v[1][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = g.shift1[i];
+            }
+            for (int e = lane; e < NS * SP_TILE; e += 64) sp_img[e] = (__bf16)0.0f;
+        }
+        __syncthreads();
+        {   // Qm[k][mid] = sum_c W2[c][k] D[c] W2[c][mid]: thread (k = tid >> 3, four mids); evec by threads 0..31
+            const int k = tid >> 3, m0 = (tid & 7) * 4;
+            float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+#pragma unroll 8
+            for (int c = 0; c < SA_C2; ++c) {
+                const float wd = sw2[c][k] * sD[c];
+                const float4 w4 = *reinterpret_cast<const float4 *>(&sw2[c][m0]);
+                q0 = __builtin_fmaf(wd, w4.x, q0);
+                q1 = __builtin_fmaf(wd, w4.y, q1);
+                q2 = __builtin_fmaf(wd, w4.z, q2);
+                q3 = __builtin_fmaf(wd, w4.w, q3);
+            }
+            *reinterpret_cast<float4 *>(&sqm[k][m0]) = make_float4(q0, q1, q2, q3);   // (S2's readers are behind the barrier above)
+            if (tid < 32) {
+                float e = 0.0f;
+#pragma unroll 8
+                for (int c = 0; c < SA_C2; ++c) e = __builtin_fmaf(sE[c], sw2[c][tid], e);
+                sqm[32][tid] = e;
+            }
+        }
+        __syncthreads();
+        if (wave == 1) {
+            // term 1 of dL/da1: B fragments of Qm, k slot (h,j) of step s <-> mid' = row(8s+j,h)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float tmp[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tmp[j] = sqm[acc_row(8 * s + j, h)][r];
+                put_frag<NS>(cfrag, F_QM + s, lane, make_frag<NS>(tmp));
+            }
+        }
+        if (wave == 2) {
+            // term 3: B fragments of W2 with k = output channel in natural order 16 s + 8 h + j
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float tmp[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tmp[j] = sw2[16 * s + 8 * h + j][r];
+                put_frag<NS>(cfrag, F_W2T + s, lane, make_frag<NS>(tmp));
+            }
+        }
+        ev = sqm[32][r];
+        __syncthreads();
+    };
 
     // the previous tile's per-point sums, scattered at the top of the next iteration (see for_each_tile)
-    float pend_g[16], pend_geo[2];
+    float pend_g[16];
     int pend_nb = 0, pend_live = 0, pend_cloud = 0;      // pend_live == 0: nothing pending
     auto scatter_pending = [&]() {
         if (pend_live == 0) return;                       // wave-uniform
@@ -584,22 +757,15 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 if (acc_row(i, h) < pend_live) atomicAdd(Ac + (size_t)nn * SA_C1, pend_g[i]);
             }
         }
-        // occurrences and relative positions: lane (pos = r, h) adds {count, dx} or {dy, dz}
-        if (r < pend_live) {
-            float *gp = geo + ((size_t)pend_cloud * a.n + pend_nb) * 4 + 2 * h;
-            atomicAdd(gp, pend_geo[0]);
-            atomicAdd(gp + 1, pend_geo[1]);
-        }
         pend_live = 0;
     };
-    for_each_tile<NS, CP>(a, wave, r, h, scatter_pending, [&](int tile, const TileRaw<NS> &raw) {
+    for_each_tile<NS, CP>(a, wave, r, h, prologue, scatter_pending, [&](int tile, const TileRaw<NS> &raw) {
         // the constant fragments are READ PER USE: an opaque copy of the lane id keeps the
         // compiler from hoisting these loop-invariant LDS reads back into ~130 registers
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
         Frag<NS> x[3];
-        float deff[3];
-        build_frags<NS>(a, raw, h, x, deff);
+        build_frags<NS>(a, raw, h, x);
         const int nb = raw.nb;
         // tile map: the records of this lane's accumulator rows; this lane's own row (position r) is raw.info
         unsigned meta[16];
@@ -730,7 +896,6 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
 
         {   // sums per query and per source point
             int live;
-            float gmult;
             if (CP) {
 #pragma unroll 1
                 for (int jq = 0; jq < nq; ++jq) {
@@ -752,7 +917,6 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 live = __popcll(__ballot(lane < 32 && live_row));
 #pragma unroll
                 for (int i = 0; i < 16; ++i) pend_g[i] = ga[i];
-                gmult = mrow;
             } else {
                 const float ha = s1 + __shfl_xor(s1, 32);
                 hb += __shfl_xor(hb, 32);
@@ -774,10 +938,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 // hand the tile's sums to the deferred scatter
 #pragma unroll
                 for (int i = 0; i < 16; ++i) pend_g[i] = (i == 0 && h == 0) ? ga[0] + extra : ga[i];
-                gmult = r == 0 ? (float)(SA_K - live + 1) : 1.0f;
             }
-            pend_geo[0] = (h ? deff[1] : 1.0f) * gmult;
-            pend_geo[1] = (h ? deff[2] : deff[0]) * gmult;
             pend_nb = nb;
             pend_live = live;
             pend_cloud = q0 / a.m;
@@ -799,12 +960,12 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             }
         }
     });
-    write_partials<2>(st, part, lane, wave);
-    // The workgroup's three ingredients of dL/dW2: fold the four waves in LDS, then one float atomic
-    // per element into the zeroed accumulators: gw2_acc (64,32) sparse part; gram_acc[0..1023]
-    // Gram[mid'][mid], gram_acc[1024..1055] suma[mid] -- SA_ACC_COPIES copies of each, workgroup b adds into copy
-    // b % SA_ACC_COPIES (448 workgroups on ONE set of 3104 addresses cost the pass 9 us of same-address atomics;
-    // bwd_consts1 adds the copies up).
+    {   // BatchNorm-1's reduction terms {T1, T2}[32] into their accumulator set
+        const float tot = fold_partials<2>(st, lane, wave);
+        if (threadIdx.x < 64) acc_add(accT, 64, blockIdx.x % ACC_COPIES, threadIdx.x, tot);
+    }
+    // The workgroup's share of dL/dW2: fold the four waves' sparse parts in LDS (kept in registers: thread t owns
+    // elements t + 256 j), then Gram and suma, then  row[c][mid] = sparse + D2[c] (W2 Gram)[c][mid] + E2[c] suma[mid].
     float (*wred)[SA_C2 * SA_C1] = reinterpret_cast<float (*)[SA_C2 * SA_C1]>(sp_raw);   // images are dead
     __syncthreads();
 #pragma unroll
@@ -813,11 +974,20 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         wred[wave][lane * SA_C1 + acc_row(i, 1)] = sacc[16 + i];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < SA_C2 * SA_C1; e += SA_WAVES * 64) {
-        float sum = 0.0f;
+    // thread (c = tid >> 2, eight mids from mid0 = 8 (tid & 3)): its eight elements of the workgroup's row
+    const int ec = threadIdx.x >> 2, emid = (threadIdx.x & 3) * 8;
+    float sp8[8];
+    {
+        float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), hi4 = lo4;
 #pragma unroll
-        for (int w = 0; w < SA_WAVES; ++w) sum += wred[w][e];
-        atomicAdd(gw2_acc + (blockIdx.x % SA_ACC_COPIES) * (SA_C2 * SA_C1) + e, sum);
+        for (int w = 0; w < SA_WAVES; ++w) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(&wred[w][ec * SA_C1 + emid]);
+            const float4 b4 = *reinterpret_cast<const float4 *>(&wred[w][ec * SA_C1 + emid + 4]);
+            lo4.x += a4.x; lo4.y += a4.y; lo4.z += a4.z; lo4.w += a4.w;
+            hi4.x += b4.x; hi4.y += b4.y; hi4.z += b4.z; hi4.w += b4.w;
+        }
+        sp8[0] = lo4.x; sp8[1] = lo4.y; sp8[2] = lo4.z; sp8[3] = lo4.w;
+        sp8[4] = hi4.x; sp8[5] = hi4.y; sp8[6] = hi4.z; sp8[7] = hi4.w;
     }
     __syncthreads();
     suma += __shfl_xor(suma, 32);
@@ -825,11 +995,31 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     for (int i = 0; i < 16; ++i) wred[wave][acc_row(i, h) * SA_C1 + r] = gram[i];
     if (h == 0) wred[wave][SA_C1 * SA_C1 + r] = suma;
     __syncthreads();
-    for (int e = threadIdx.x; e < SA_C1 * SA_C1 + SA_C1; e += SA_WAVES * 64) {
-        float sum = 0.0f;
+    for (int e = threadIdx.x; e < SA_C1 * SA_C1 + SA_C1; e += SA_WAVES * 64)       // Gram[mid'][mid] | suma: sqm is free
+        sqm[e >> 5][e & 31] = (wred[0][e] + wred[1][e]) + (wred[2][e] + wred[3][e]);
+    __syncthreads();
+    {
+        float acc[8];
 #pragma unroll
-        for (int w = 0; w < SA_WAVES; ++w) sum += wred[w][e];
-        atomicAdd(gram_acc + (blockIdx.x % SA_ACC_COPIES) * (SA_C1 * SA_C1 + SA_C1) + e, sum);
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < SA_C1; ++k) {
+            const float w = sw2[ec][k];
+            const float4 g0 = *reinterpret_cast<const float4 *>(&sqm[k][emid]);
+            const float4 g1 = *reinterpret_cast<const float4 *>(&sqm[k][emid + 4]);
+            acc[0] = __builtin_fmaf(w, g0.x, acc[0]); acc[1] = __builtin_fmaf(w, g0.y, acc[1]);
+            acc[2] = __builtin_fmaf(w, g0.z, acc[2]); acc[3] = __builtin_fmaf(w, g0.w, acc[3]);
+            acc[4] = __builtin_fmaf(w, g1.x, acc[4]); acc[5] = __builtin_fmaf(w, g1.y, acc[5]);
+            acc[6] = __builtin_fmaf(w, g1.z, acc[6]); acc[7] = __builtin_fmaf(w, g1.w, acc[7]);
+        }
+        const float d = sD[ec], e = sE[ec];
+        const float4 s0 = *reinterpret_cast<const float4 *>(&sqm[32][emid]);
+        const float4 s1 = *reinterpret_cast<const float4 *>(&sqm[32][emid + 4]);
+        float4 *row = reinterpret_cast<float4 *>(partW2 + (size_t)blockIdx.x * (SA_C2 * SA_C1) + ec * SA_C1 + emid);
+        row[0] = make_float4(sp8[0] + d * acc[0] + e * s0.x, sp8[1] + d * acc[1] + e * s0.y,
+                             sp8[2] + d * acc[2] + e * s0.z, sp8[3] + d * acc[3] + e * s0.w);
+        row[1] = make_float4(sp8[4] + d * acc[4] + e * s1.x, sp8[5] + d * acc[5] + e * s1.y,
+                             sp8[6] + d * acc[6] + e * s1.z, sp8[7] + d * acc[7] + e * s1.w);
     }
 }
 
@@ -856,19 +1046,35 @@ static int sa_grid_bwd(int tiles) {
 extern "C" int apn_sa_grid_blocks(int b, int m) { return apn::sa_grid(b * m); }
 extern "C" int apn_sa_grid_rows(int b, int m, int with_tile_map) { return apn::sa_grid(b * m, with_tile_map != 0); }
 extern "C" int apn_sa_bwd_main_rows(int b, int m) { return apn::sa_grid_bwd(b * m); }
-extern "C" int apn_sa_bwd_acc_copies(void) { return apn::SA_ACC_COPIES; }
+extern "C" int apn_sa_acc_words(int ncol) { return ncol > 0 ? apn::acc_words(ncol) : 0; }
+
+extern "C" int apn_sa_prep_rows(int b, int n) {
+    const long long tiles = (long long)b * ((n + apn::PS_PTS - 1) / apn::PS_PTS);
+    return (int)(tiles < apn::PS_MAX_ROWS ? (tiles < 1 ? 1 : tiles) : apn::PS_MAX_ROWS);
+}
 
 // ft holds `precision` tables of (B,N,32) bf16 back to back: [hi] or [hi][lo].
-extern "C" int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, int precision,
-                                    void *stream) {
+extern "C" int apn_sa_prep_stats(int b, int n, const float *f, const void *geo, const void *dd, const float *w1,
+                                 int precision, int stats, void *ft, float *part1, void *zero, long long zero_words,
+                                 void *stream) {
     using namespace apn;
-    if (b < 0 || n < 0 || c != SA_C || (precision != 1 && precision != 2)) return APN_EINVAL;
-    if (b == 0 || n == 0) return APN_OK;
-    if (!f || !ft || b > 65535) return APN_EINVAL;
+    if (b <= 0 || n <= 0 || b > 65535 || (precision != 1 && precision != 2) || !f || !ft || !w1) return APN_EINVAL;
+    if (stats && (!geo || !dd || !part1 || ((uintptr_t)geo & 15) || ((uintptr_t)part1 & 15))) return APN_EINVAL;
+    if (zero_words < 0 || (zero_words && !zero)) return APN_EINVAL;
     __bf16 *hi = (__bf16 *)ft;
     __bf16 *lo = precision == 2 ? hi + (size_t)b * n * SA_C : nullptr;
-    hipLaunchKernelGGL(sa_prep_features_kernel, dim3((n + 63) / 64, b), dim3(256), 0,
-                       (hipStream_t)stream, n, f, hi, lo);
+    const int tpc = (n + PS_PTS - 1) / PS_PTS;
+    auto kern = precision == 2 ? sa_prep_stats_kernel<2> : sa_prep_stats_kernel<1>;
+    const int lds = SA_C * (PS_PTS + 1) * (int)sizeof(float);
+    static bool lds_set[2] = {false, false};                  // (idempotent: a racing second call sets the same value)
+    if (!lds_set[precision - 1]) {
+        if (hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+            return (int)e;
+        lds_set[precision - 1] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(apn_sa_prep_rows(b, n)), dim3(1024), lds, (hipStream_t)stream, n, tpc, b * tpc, f,
+                       (const long long *)geo, (const double *)dd, b * (apn_sa_geo_dd_doubles(n) / 6), w1, stats, hi, lo, part1,
+                       (unsigned long long *)zero, zero_words);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -880,73 +1086,57 @@ static apn::SaArgs sa_args(int b, int n, int m, const float *xyz, const float *n
                        precision == 2 ? hi + (size_t)b * n * apn::SA_C : nullptr, idx, w1, radius, tmap};
 }
 
-static int sa_check(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample, int precision) {
-    using namespace apn;
+static int sa_check(int b, int n, int m, int precision) {
     if (precision != 1 && precision != 2) return APN_EINVAL;
     if (b <= 0 || n <= 0 || m <= 0) return APN_EINVAL;
-    if (c_in != SA_C || c_mid != SA_C1 || c_out != SA_C2 || nsample != SA_K) return APN_EINVAL;
     if ((long long)b * m > 0x7fffffffLL / 64) return APN_EINVAL;
     return APN_OK;
 }
 
-extern "C" int apn_sa_fwd_stats1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                                 int precision, float radius, const float *xyz, const float *new_xyz,
-                                 const void *ft, const int *idx, const int *tmap, const float *w1, float *part,
-                                 void *stream) {
+extern "C" int apn_sa_fwd_main(int b, int n, int m, int precision, float radius, const float *xyz,
+                               const float *new_xyz, const void *ft, const int *idx, const int *tmap, const float *w1,
+                               const float *w2, const float *g1, const float *b1, float *rm1, float *rv1, void *nbt1,
+                               float eps1, float mom1, int train1, double count, const float *part1, int rows1,
+                               const double *sums1, float *pack1, const float *gamma2, float *ysel, void *ksel,
+                               void *acc2, void *stream) {
     using namespace apn;
-    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
+    if (int e = sa_check(b, n, m, precision)) return e;
+    if (!xyz || !new_xyz || !ft || !idx || !w1 || !w2 || !pack1 || !ysel || !ksel || !acc2) return APN_EINVAL;
+    if (train1 && !part1 && !sums1) return APN_EINVAL;
+    if (!train1 && (!rm1 || !rv1)) return APN_EINVAL;
+    if (part1 && (((uintptr_t)part1 & 15) || rows1 <= 0)) return APN_EINVAL;
     SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius, tmap);
-    auto kern = precision == 2 ? (tmap ? sa_fwd_stats1_kernel<2, true> : sa_fwd_stats1_kernel<2, false>)
-                               : (tmap ? sa_fwd_stats1_kernel<1, true> : sa_fwd_stats1_kernel<1, false>);
-    hipLaunchKernelGGL(kern, dim3(sa_grid(b * m, tmap != nullptr)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, part);
-    APN_LAUNCH_CHECK();
-    return APN_OK;
-}
-
-extern "C" int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                               int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                               const int *idx, const int *tmap, const float *w1, const float *w2,
-                               const float *scale1, const float *shift1, const float *sgn2,
-                               float *ysel, void *ksel, float *part, void *stream) {
-    using namespace apn;
-    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
-    SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius, tmap);
+    BnArgs bn{g1, b1, rm1, rv1, (long long *)nbt1, eps1, mom1, train1, count};
     auto kern = precision == 2 ? (tmap ? sa_fwd_main_kernel<2, true> : sa_fwd_main_kernel<2, false>)
                                : (tmap ? sa_fwd_main_kernel<1, true> : sa_fwd_main_kernel<1, false>);
-    hipLaunchKernelGGL(kern, dim3(sa_grid(b * m, tmap != nullptr)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, w2, scale1, shift1,
-                       sgn2, ysel, (unsigned char *)ksel, part);
+    hipLaunchKernelGGL(kern, dim3(sa_grid(b * m, tmap != nullptr)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, w2, bn,
+                       sums1 ? nullptr : part1, rows1, sums1, pack1, gamma2, ysel, (unsigned char *)ksel,
+                       (unsigned long long *)acc2);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
-static apn::SaBwdArgs sa_bwd_args(const float *w2, const float *bn1 /* [4][32]: scale, shift, mean, inv */,
-                                  const float *qm, const float *evec, const float *goa,
-                                  const void *ksel) {
-    apn::SaBwdArgs g;
-    g.w2 = w2;
-    g.scale1 = bn1; g.shift1 = bn1 + 32; g.mean1 = bn1 + 64; g.inv1 = bn1 + 96;
-    g.qm = qm; g.evec = evec;
-    g.goa = goa; g.ksel = (const unsigned char *)ksel;
-    return g;
-}
-
-extern "C" int apn_sa_bwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                               int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                               const int *idx, const int *tmap, const float *w1, const float *w2, const float *bn1,
-                               const float *qm, const float *evec, const float *goa,
-                               const void *ksel, float *part, float *gw2_acc, float *gram_acc,
-                               float *A, float *geo, float *HA, float *HB, void *stream) {
+extern "C" int apn_sa_bwd_main(int b, int n, int m, int precision, float radius, const float *xyz,
+                               const float *new_xyz, const void *ft, const int *idx, const int *tmap, const float *w1,
+                               const float *w2, const float *pack1, const float *pack2, const void *accS,
+                               const double *sumsS, double count, int train2, const float *goa, const void *ksel,
+                               void *accT, float *partW2, float *A, float *HA, float *HB, void *stream) {
     using namespace apn;
-    if (int e = sa_check(b, n, m, c_in, c_mid, c_out, nsample, precision)) return e;
-    if (!w2 || !bn1 || !qm || !evec || !goa || !ksel || !part || !gw2_acc || !gram_acc || !A || !geo ||
-        !HA || !HB)
+    if (int e = sa_check(b, n, m, precision)) return e;
+    if (!w2 || !pack1 || !pack2 || (!accS && !sumsS) || !goa || !ksel || !accT || !partW2 || !A || !HA || !HB)
         return APN_EINVAL;
     SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius, tmap);
-    SaBwdArgs g = sa_bwd_args(w2, bn1, qm, evec, goa, ksel);
+    SaBwdArgs g;
+    g.w2 = w2;
+    g.scale1 = pack1; g.shift1 = pack1 + 32; g.mean1 = pack1 + 64; g.inv1 = pack1 + 96;
+    g.pack2 = pack2;
+    g.accS = (const unsigned long long *)accS; g.sumsS = sumsS;
+    g.count = count; g.train2 = train2;
+    g.goa = goa; g.ksel = (const unsigned char *)ksel;
     auto kern = precision == 2 ? (tmap ? sa_bwd_kernel<2, true> : sa_bwd_kernel<2, false>)
                                : (tmap ? sa_bwd_kernel<1, true> : sa_bwd_kernel<1, false>);
-    hipLaunchKernelGGL(kern, dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, g, part, gw2_acc,
-                       gram_acc, A, geo, HA, HB);
+    hipLaunchKernelGGL(kern, dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, g,
+                       (unsigned long long *)accT, partW2, A, HA, HB);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

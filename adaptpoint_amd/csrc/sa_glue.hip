@@ -4,11 +4,15 @@
 // sampled points, add, ReLU) and its backward folded in, the per-channel constants of
 // the backward, and the "everything downstream of dL/dy1 is linear" products.  They
 // replace ~150 tiny PyTorch launches per step (and two pathological long-K rocBLAS
-// GEMMs) with a fixed sequence of 9, all graph-capturable: no host reads, no
-// allocation.  Cross-workgroup sums leave the producers as one partial row per workgroup and
-// are summed in float64, in a fixed order, by the consumer (deterministic; float atomics are
-// used only for the scatters into per-point buffers).
+// GEMMs), all graph-capturable: no host reads, no allocation.  Round 3: the BatchNorm folds and
+// per-channel constants that used to be launches of their own (bn_fold x2, bwd_consts2, bwd_consts1) are
+// PROLOGUES of their consumer kernels: per-channel sums cross workgroups through the integer accumulator sets
+// of apn_common.h (order-independent: the same bits every run) or through a few dozen partial rows, and every
+// consumer workgroup folds them itself.  Weight gradients leave their producers as one partial row per
+// workgroup and are summed in float64, in a fixed order, by the last launch (float atomics are used only
+// for the scatters into per-point buffers).  bn_fold / reduce_rows remain for the width-generic family.
 #include "apn_common.h"
+#include "sa_chain.h"
 
 namespace apn {
 
@@ -221,7 +225,9 @@ __device__ __forceinline__ void stage_skip_operands(int cloud, int n, int m, int
 // thread = (query tx, 4 channels of wave ty): the query's 32 inputs sit in registers, the
 // weight rows are wave-uniform 16-byte LDS broadcasts.
 __global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float *__restrict__ ysel,
-                                                       const float *__restrict__ pack2,
+                                                       const unsigned long long *__restrict__ acc2,
+                                                       const double *__restrict__ sums2, BnArgs bn2,
+                                                       float *__restrict__ pack2,
                                                        const __bf16 *__restrict__ ft,
                                                        const __bf16 *__restrict__ ft_lo,
                                                        const int *__restrict__ fidx,
@@ -231,7 +237,17 @@ __global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float
                                                        long long zero_n4) {
     __shared__ float tile[64][65];
     __shared__ float sfi[64][33];
-    // The backward pass accumulates into A / geo / gip with atomics; they are zeroed HERE, by the last forward
+    __shared__ double ftot[128];
+    __shared__ float s_sc[64], s_sh[64];
+    // BatchNorm-2 folded here (formerly a launch of its own): {sum, sumsq}[64] of y2 from the forward pass's
+    // accumulator set (integer atomics: the same bits in every workgroup and every run) or from reduced sums
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+    double count2 = bn2.count;
+    if (bn2.training) {
+        if (threadIdx.x < 128) ftot[threadIdx.x] = sums2 ? sums2[threadIdx.x] : acc_read(acc2, 128, threadIdx.x);
+        if (sums2) count2 = sums2[128];
+    }
+    // The backward pass accumulates into A / gip / its accumulator sets with atomics; they are zeroed HERE, by the last forward
     // launch (race-free: their writers run after it), so that the backward needs no fill launch of its own.
     if (zero) {
         const long long nb = (long long)gridDim.x * gridDim.y, bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
@@ -240,13 +256,29 @@ __global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float
     __shared__ __attribute__((aligned(16))) float sws[64][36];
     const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..15
-    if (ws) stage_skip_operands<1024, 36, 33>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, nullptr);
-    {
-        const float sc = pack2[tx], sh = pack2[64 + tx];
+    float ys4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {   // j = query within tile, tx = channel
-            const int j = ty + 16 * k, q = m0 + j;
-            tile[j][tx] = q < m ? ysel[((size_t)cloud * m + q) * 64 + tx] * sc + sh : 0.f;
+    for (int k = 0; k < 4; ++k) {   // j = query within tile, tx = channel (requested before the fold's barrier)
+        const int q = m0 + ty + 16 * k;
+        ys4[k] = q < m ? ysel[((size_t)cloud * m + q) * 64 + tx] : 0.f;
+    }
+    if (ws) stage_skip_operands<1024, 36, 33>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, nullptr);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        if (first && threadIdx.x == 0 && bn2.training && bn2.nbt) *bn2.nbt += 1;
+        float sc, sh;
+        bn_channel(bn2, 64, threadIdx.x, bn2.training ? ftot[threadIdx.x] : 0.0, bn2.training ? ftot[64 + threadIdx.x] : 0.0,
+                   count2, first, pack2, sc, sh);
+        s_sc[threadIdx.x] = sc;
+        s_sh[threadIdx.x] = sh;
+    }
+    __syncthreads();
+    {
+        const float sc = s_sc[tx], sh = s_sh[tx];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = ty + 16 * k;
+            tile[j][tx] = m0 + j < m ? ys4[k] * sc + sh : 0.f;
         }
     }
     __syncthreads();
@@ -295,7 +327,7 @@ __global__ __launch_bounds__(1024) void bwd_prep_kernel(int n, int m, const floa
                                                         const int *__restrict__ fidx,
                                                         const float *__restrict__ ws,
                                                         float *__restrict__ goa,
-                                                        float *__restrict__ partS,
+                                                        unsigned long long *__restrict__ accS,
                                                         float *__restrict__ partWs,
                                                         float *__restrict__ gip) {
     // 1024 threads per 64-query tile (about one tile per CU), as in fwd_out_kernel
@@ -345,7 +377,7 @@ __global__ __launch_bounds__(1024) void bwd_prep_kernel(int n, int m, const floa
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc += red[k][ty][tx];
-        partS[blk * 128 + ty * 64 + tx] = acc;
+        acc_add(accS, 128, (int)(blk % ACC_COPIES), ty * 64 + tx, acc);
     }
     if (ws) {
         // dL/dWs[c][i]: thread (c = tx, inputs i = 2 ty, 2 ty + 1)
@@ -372,126 +404,6 @@ __global__ __launch_bounds__(1024) void bwd_prep_kernel(int n, int m, const floa
     }
 }
 
-// Per-channel constants of dL/dy2 = goa*[pos==ksel] + y2*D2 + E2 and their images
-// through W2:  qm = W2^T diag(D2) W2 (32x32), evec = E2 W2.  Also dL/dgamma2, dL/dbeta2.
-// One workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void bwd_consts2_kernel(const float *__restrict__ partS, int rows,
-                                                           const double *__restrict__ S_in,
-                                                           const float *__restrict__ pack2,
-                                                           const float *__restrict__ w2, double count,
-                                                           int training, float *__restrict__ d2e2,
-                                                           float *__restrict__ qm,
-                                                           float *__restrict__ evec,
-                                                           float *__restrict__ g_gamma2,
-                                                           float *__restrict__ g_beta2,
-                                                           float *__restrict__ zero_w2,
-                                                           float *__restrict__ zero_gram) {
-    __shared__ double D[64], E[64], S[128];
-    __shared__ float sw2[64][33];
-    const int t = threadIdx.x;
-    // dL/dW2's sparse part (64x32) and Gram (32x32) + suma (32) are accumulated atomically by the backward pass,
-    // the next launch, into SA_ACC_COPIES copies each (see sa_bwd_kernel's tail): cleared here
-    if (zero_w2)
-        for (int e = t; e < SA_ACC_COPIES * 2048; e += 1024) zero_w2[e] = 0.0f;
-    if (zero_gram)
-        for (int e = t; e < SA_ACC_COPIES * 1056; e += 1024) zero_gram[e] = 0.0f;
-    // operands requested before the row sums: their latency hides behind them
-    const float wa = w2[t], wb = w2[1024 + t];
-    float p_sc = 0.0f, p_mu = 0.0f, p_iv = 0.0f;
-    if (t < 64) { p_sc = pack2[t]; p_mu = pack2[128 + t]; p_iv = pack2[192 + t]; }
-    block_sum_rows(partS, rows, 128, S_in, S);
-    // SyncBatchNorm (reduced sums): the statistics use the GLOBAL sums and count; dL/dgamma and
-    // dL/dbeta are reported as global / world = the mean over ranks of the rank-local sums, which
-    // is what torch.nn.SyncBatchNorm + DistributedDataParallel leave in .grad (the later
-    // gradient averaging over ranks then is the identity on them).
-    double gscale = 1.0;
-    if (!partS) { count = S_in[128]; gscale = 1.0 / S_in[129]; }
-    sw2[t >> 5][t & 31] = wa;
-    sw2[32 + (t >> 5)][t & 31] = wb;
-    if (t < 64) {
-        const double sc = p_sc, mu = p_mu, iv = p_iv;
-        const double s1 = S[t], s2 = S[64 + t];
-        double d = 0.0, e = 0.0;
-        if (training) {
-            d = -sc * iv * s2 / count;
-            e = -sc * s1 / count + sc * mu * iv * s2 / count;
-        }
-        D[t] = d; E[t] = e;
-        d2e2[t] = (float)d;
-        d2e2[64 + t] = (float)e;
-        if (g_gamma2) g_gamma2[t] = (float)(s2 * gscale);
-        if (g_beta2) g_beta2[t] = (float)(s1 * gscale);
-    }
-    __syncthreads();
-    const int k = t >> 5, mid = t & 31;   // 32 x 32
-    double q = 0.0;
-#pragma unroll 8
-    for (int c = 0; c < 64; ++c) q += (double)sw2[c][k] * D[c] * (double)sw2[c][mid];
-    qm[k * 32 + mid] = (float)q;
-    if (t < 32) {
-        double e = 0.0;
-        for (int c = 0; c < 64; ++c) e += E[c] * (double)sw2[c][t];
-        evec[t] = (float)e;
-    }
-}
-
-// dL/dy1 = g_u*ca + yhat1*cb + cc ; dL/dgamma1 = T2, dL/dbeta1 = T1.
-__global__ __launch_bounds__(256) void bwd_consts1_kernel(
-    const float *__restrict__ partT, int rows, const double *__restrict__ T_in,
-    const float *__restrict__ pack1, double count, int training, float *__restrict__ cabc,
-    float *__restrict__ g_gamma1, float *__restrict__ g_beta1, const float *__restrict__ w2,
-    const float *__restrict__ d2e2, const float *__restrict__ gram, const float *__restrict__ gw2_acc,
-    float *__restrict__ g_w2) {
-    // grid: 8 workgroups, workgroup b owns mid channels 4b..4b+3 (columns 4b.. and 32+4b..)
-    __shared__ double red[256][4];
-    __shared__ float gsum[1056];
-    if (g_w2) {
-        // dL/dW2[c][mid] = sparse part + D2[c] (W2 Gram)[c][mid] + E2[c] suma[mid] (sa_fused.hip); the backward
-        // pass left SA_ACC_COPIES partial copies of the sparse part and of {Gram, suma}: added up here in a fixed
-        // order.  8 x 256 threads = the 64 x 32 elements
-        for (int e = threadIdx.x; e < 1056; e += 256) {
-            float v[SA_ACC_COPIES];
-#pragma unroll
-            for (int k = 0; k < SA_ACC_COPIES; ++k) v[k] = gram[k * 1056 + e];
-            float sgm = 0.0f;
-#pragma unroll
-            for (int k = 0; k < SA_ACC_COPIES; ++k) sgm += v[k];
-            gsum[e] = sgm;
-        }
-        const int e = blockIdx.x * 256 + threadIdx.x, c = e >> 5, mid = e & 31;
-        float sp[SA_ACC_COPIES];
-#pragma unroll
-        for (int k = 0; k < SA_ACC_COPIES; ++k) sp[k] = gw2_acc[k * 2048 + e];
-        double sparse = 0.0;
-#pragma unroll
-        for (int k = 0; k < SA_ACC_COPIES; ++k) sparse += (double)sp[k];
-        __syncthreads();
-        double acc = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) acc += (double)w2[c * 32 + k] * (double)gsum[k * 32 + mid];
-        g_w2[e] = (float)(sparse + (double)d2e2[c] * acc + (double)d2e2[64 + c] * (double)gsum[1024 + mid]);
-    }
-    const int t = threadIdx.x, i = blockIdx.x * 4 + t;
-    const float sc32 = t < 4 ? pack1[i] : 0.0f;      // requested before the row sums
-    double t1 = 0.0, t2 = 0.0, gscale = 1.0;
-    if (partT) {
-        slice_sum_rows(partT, rows, 16, blockIdx.x, 8 + blockIdx.x, red);
-        if (t < 4) { t1 = red[0][t]; t2 = red[1][t]; }
-    } else if (t < 4) {
-        t1 = T_in[i];
-        t2 = T_in[32 + i];
-        count = T_in[64];                    // global count, world size (reduce_rows_kernel)
-        gscale = 1.0 / T_in[65];
-    }
-    if (t >= 4) return;
-    const double sc = sc32;
-    cabc[i] = (float)sc;
-    cabc[32 + i] = training ? (float)(-sc * t2 / count) : 0.0f;
-    cabc[64 + i] = training ? (float)(-sc * t1 / count) : 0.0f;
-    if (g_gamma1) g_gamma1[i] = (float)(t2 * gscale);
-    if (g_beta1) g_beta1[i] = (float)(t1 * gscale);
-}
-
 // Everything downstream of dL/dy1 = g_u*ca + yhat1*cb + cc, which is only ever needed summed
 // per source point (G) and per query (H).  The backward pass (sa_fused.hip) left the sums of
 // g_u (A per point, HA per query), of yhat1 per query (HB) and the occurrence statistics of
@@ -513,8 +425,9 @@ __global__ __launch_bounds__(256) void bwd_consts1_kernel(
 constexpr int WG_PTS = 64;
 
 __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
-    int n, int total_q, int split, const float *__restrict__ A, const float *__restrict__ geo,
-    const float *__restrict__ HA, const float *__restrict__ HB, const float *__restrict__ cabc,
+    int n, int total_q, int split, const float *__restrict__ A, const long long *__restrict__ geo,
+    const float *__restrict__ HA, const float *__restrict__ HB, const unsigned long long *__restrict__ accT,
+    const double *__restrict__ sumsT, double count, int train1,
     const float *__restrict__ pack1, const __bf16 *__restrict__ ft,
     const __bf16 *__restrict__ ft_lo, const float *__restrict__ xyz,
     const float *__restrict__ new_xyz, const float *__restrict__ w1, const float *__restrict__ gip,
@@ -543,11 +456,26 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
         swt[col][mid] = w;
         swr[mid][col < 3 ? 32 + col : col - 3] = wr;
     }
-    if (tid < 96) sc[tid >> 5][tid & 31] = cabc[tid];
-    else if (tid < 160) sc[3 + ((tid - 96) >> 5)][tid & 31] = pack1[64 + tid - 96];   // mean1, inv1
+    // The batch constants of dL/dy1 = g_u*ca + yhat1*cb + cc (formerly a launch of its own): BatchNorm-1's reduction
+    // terms T1 = sum g_u, T2 = sum g_u*yhat1 from the backward pass's accumulator set (or reduced sums), every
+    // thread for its own mid channel c = tid & 31 (same bits in every workgroup).
+    // (threads 0..63 read one column of the set each; the 96 constants reach the other threads through LDS)
+    if (tid < 64) {
+        const int c = tid & 31;
+        const float sca = pack1[c];
+        float val = 0.0f;
+        if (train1) {
+            const double t = sumsT ? sumsT[tid] : acc_read(accT, 64, tid);      // tid < 32: T1, else T2
+            const double cnt = sumsT ? sumsT[64] : count;
+            val = (float)(-(double)sca * t / cnt);
+        }
+        sc[tid < 32 ? 2 : 1][c] = val;                    // cc from T1, cb from T2
+        if (tid < 32) sc[0][c] = sca;
+    } else if (tid >= 96 && tid < 160) sc[3 + ((tid - 96) >> 5)][tid & 31] = pack1[64 + tid - 96];   // mean1, inv1
+    __syncthreads();
     {
         const int c = tid & 31;                           // fixed per thread: e = tid + 1024 k
-        const float ca = cabc[c], cb = cabc[32 + c], cc = cabc[64 + c];
+        const float ca = sc[0][c], cb = sc[1][c], cc = sc[2][c];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int pt = (tid >> 5) + 32 * k;
@@ -574,7 +502,9 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
         sB[e / 3][38 + e % 3] = 0.0f;                     // pad columns
     } else if (tid < WG_PTS * 6 + WG_PTS * 4) {
         const int e = tid - WG_PTS * 6, pt = e >> 2, j = e & 3;
-        sGeo[pt][j] = pt < n_here ? geo[(p0 + pt) * 4 + j] : 0.0f;
+        // the index stage's occurrence statistics (sa_geo.hip): {count, sum of relative positions in units of 2^-36}
+        const long long gv = pt < n_here ? geo[(p0 + pt) * 4 + j] : 0ll;
+        sGeo[pt][j] = j == 0 ? (float)gv : (float)((double)gv * (1.0 / 68719476736.0));
     }
     __syncthreads();
 
@@ -655,10 +585,14 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
     }
 }
 
-// Parameter gradients out of the partial rows (column sums in float64):
-//   g_w1[mid][0..2] = (W[mid][0..2] - W[mid][3..5]) / r ; g_w1[mid][3+i] = W[mid][6+i],
-//        W = sum_rows partW[row][32*38]
-//   g_ws[c][i] = sum_rows partWs[row][64*32] ;  g_bs[c] = sum_rows partS[row][c]
+// Backward launch 4 of 4: every parameter gradient out of the partial rows (column sums in float64, fixed order)
+// and the accumulator sets:
+//   g_w1[mid][0..2] = (W[mid][0..2] - W[mid][3..5]) / r ; g_w1[mid][3+i] = W[mid][6+i],  W = sum_rows partW[row][32*38]
+//   g_ws[c][i] = sum_rows partWs[row][64*32] ;  g_w2[c][mid] = sum_rows partW2[row][64*32]
+//   g_bs[c] = S1[c], g_beta2 = S1 * gscale, g_gamma2 = S2 * gscale ; g_beta1 = T1 * gscale, g_gamma1 = T2 * gscale
+// gscale = 1, or 1 / world with reduced sums (SyncBatchNorm: global sum / world = the mean over ranks of the
+// rank-local sums -- what torch.nn.SyncBatchNorm + DistributedDataParallel leave in .grad; g_bs is a conv bias
+// gradient and stays this rank's own sum).
 // A workgroup owns 16 output elements x 16 row groups; loads are issued 8 deep.
 __device__ __forceinline__ double col_sum(const float *__restrict__ base, int rows, int stride,
                                           int col, int g) {
@@ -675,39 +609,74 @@ __device__ __forceinline__ double col_sum(const float *__restrict__ base, int ro
     return s;
 }
 
+constexpr int FIN_W1 = 32 * 35, FIN_WS = 2048, FIN_W2 = 2048, FIN_SMALL = 64 * 3 + 32 * 2;
+constexpr int FIN_TOTAL = FIN_W1 + FIN_WS + FIN_W2 + FIN_SMALL;
+
 __global__ __launch_bounds__(256) void bwd_finalize_kernel(
     const float *__restrict__ partW, int rowsW, double inv_r, float *__restrict__ g_w1,
     const float *__restrict__ partWs, int rowsS, float *__restrict__ g_ws,
-    const float *__restrict__ partS, float *__restrict__ g_bs) {
+    const float *__restrict__ partW2, int rows2, float *__restrict__ g_w2,
+    const unsigned long long *__restrict__ accS, const double *__restrict__ sumsS,
+    const unsigned long long *__restrict__ accT, const double *__restrict__ sumsT,
+    float *__restrict__ g_bs, float *__restrict__ g_g2, float *__restrict__ g_b2, float *__restrict__ g_g1,
+    float *__restrict__ g_b1) {
     __shared__ double red[16][16];
     const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + o;
     double v = 0.0;
-    int kind = 0;   // 1: g_w1, 2: g_ws, 3: g_bs
-    if (e < 32 * 35) {
-        kind = 1;
+    float *dst = nullptr;
+    if (e < FIN_W1) {
         const int mid = e / 35, col = e % 35;
+        dst = g_w1 + e;
         if (col < 3)
             v = (col_sum(partW, rowsW, 1216, mid * 38 + col, g) -
                  col_sum(partW, rowsW, 1216, mid * 38 + 3 + col, g)) * inv_r;
         else
             v = col_sum(partW, rowsW, 1216, mid * 38 + 3 + col, g);
-    } else if (e < 32 * 35 + 2048) {
-        if (g_ws) { kind = 2; v = col_sum(partWs, rowsS, 2048, e - 32 * 35, g); }
-    } else if (e < 32 * 35 + 2048 + 64) {
-        if (g_bs) { kind = 3; v = col_sum(partS, rowsS, 128, e - 32 * 35 - 2048, g); }
+    } else if (e < FIN_W1 + FIN_WS) {
+        if (g_ws) { dst = g_ws + (e - FIN_W1); v = col_sum(partWs, rowsS, 2048, e - FIN_W1, g); }
+    } else if (e < FIN_W1 + FIN_WS + FIN_W2) {
+        if (g_w2) { dst = g_w2 + (e - FIN_W1 - FIN_WS); v = col_sum(partW2, rows2, 2048, e - FIN_W1 - FIN_WS, g); }
+    } else if (e < FIN_TOTAL) {
+        if (g == 0) {
+            const int k = e - FIN_W1 - FIN_WS - FIN_W2;
+            if (k < 192) {                 // 0..63 g_bs, 64..127 g_beta2 (S1), 128..191 g_gamma2 (S2)
+                const int c = k & 63, which = k >> 6;
+                const double scale = (sumsS && which) ? 1.0 / sumsS[129] : 1.0;
+                if (which == 0) {
+                    // the skip bias: this rank's own sum of g (accS is this rank's set also when reduced sums are given)
+                    if (g_bs) { dst = g_bs + c; v = acc_read(accS, 128, c); }
+                } else {
+                    const int col = which == 1 ? c : 64 + c;
+                    dst = which == 1 ? (g_b2 ? g_b2 + c : nullptr) : (g_g2 ? g_g2 + c : nullptr);
+                    if (dst) v = (sumsS ? sumsS[col] : acc_read(accS, 128, col)) * scale;
+                }
+            } else {                       // 192..223 g_beta1 (T1), 224..255 g_gamma1 (T2)
+                const int c = (k - 192) & 31, which = (k - 192) >> 5;
+                const double scale = sumsT ? 1.0 / sumsT[65] : 1.0;
+                dst = which == 0 ? (g_b1 ? g_b1 + c : nullptr) : (g_g1 ? g_g1 + c : nullptr);
+                if (dst) v = (sumsT ? sumsT[32 * which + c] : acc_read(accT, 64, 32 * which + c)) * scale;
+            }
+        }
     }
     red[g][o] = v;
     __syncthreads();
-    if (g == 0 && kind) {
+    if (g == 0 && dst) {
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc += red[k][o];
-        const float r = (float)acc;
-        if (kind == 1) g_w1[e] = r;
-        else if (kind == 2) g_ws[e - 32 * 35] = r;
-        else g_bs[e - 32 * 35 - 2048] = r;
+        *dst = (float)acc;
     }
+}
+
+// Accumulator set -> float64 sums (the SyncBatchNorm path: reduce -> all_reduce -> consumer with sums):
+// out[0..ncol) = the totals, out[ncol] = this rank's position count, out[ncol + 1] = 1 (summed over ranks:
+// the GLOBAL count and the world size, which the consumers read from the reduced vector).
+__global__ __launch_bounds__(128) void reduce_acc_kernel(const unsigned long long *__restrict__ acc, int ncol,
+                                                         double count, double *__restrict__ out) {
+    const int t = threadIdx.x;
+    if (t < ncol) out[t] = acc_read(acc, ncol, t);
+    if (t == 0) { out[ncol] = count; out[ncol + 1] = 1.0; }
 }
 
 }  // namespace apn
@@ -720,6 +689,14 @@ extern "C" int apn_sa_reduce_rows(const float *part, int rows, int ncol, double 
     if ((uintptr_t)part & 15) return APN_EINVAL;
     hipLaunchKernelGGL(apn::reduce_rows_kernel, dim3(1), dim3(1024), 0, APN_ST, part, rows, ncol, count,
                        out);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_sa_reduce_acc(const void *acc, int ncol, double count, double *out, void *stream) {
+    if (ncol < 1 || ncol > 128 || !acc || !out) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::reduce_acc_kernel, dim3(1), dim3(128), 0, APN_ST, (const unsigned long long *)acc, ncol,
+                       count, out);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -740,17 +717,22 @@ extern "C" int apn_sa_bn_fold(const float *part, int rows, const double *sums, i
     return APN_OK;
 }
 
-extern "C" int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const float *pack2,
-                              const void *ft, int precision, const int *fidx, const float *ws,
-                              const float *bs, int relu, float *out, float *zero_base, long long zero_floats,
-                              void *stream) {
+extern "C" int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const void *acc2, const double *sums2,
+                              const float *g2, const float *b2, float *rm2, float *rv2, void *nbt2, float eps2,
+                              float mom2, int train2, double count, float *pack2, const void *ft, int precision,
+                              const int *fidx, const float *ws, const float *bs, int relu, float *out,
+                              float *zero_base, long long zero_floats, void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || !ysel || !pack2 || !out) return APN_EINVAL;
+    if (train2 && !acc2 && !sums2) return APN_EINVAL;
+    if (!train2 && (!rm2 || !rv2)) return APN_EINVAL;
     if (ws && (!ft || !fidx || n <= 0 || (precision != 1 && precision != 2))) return APN_EINVAL;
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = (ws && precision == 2) ? hi + (size_t)b * n * 32 : nullptr;
     if (zero_base && (zero_floats < 0 || (zero_floats & 3) || ((uintptr_t)zero_base & 15))) return APN_EINVAL;
+    apn::BnArgs bn{g2, b2, rm2, rv2, (long long *)nbt2, eps2, mom2, train2, count};
     hipLaunchKernelGGL(apn::fwd_out_kernel, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, ysel,
-                       pack2, hi, lo, fidx, ws, bs, relu, out, (float4 *)zero_base, zero_base ? zero_floats / 4 : 0);
+                       (const unsigned long long *)(sums2 ? nullptr : acc2), sums2, bn, pack2, hi, lo, fidx, ws, bs, relu,
+                       out, (float4 *)zero_base, zero_base ? zero_floats / 4 : 0);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -760,73 +742,55 @@ extern "C" int apn_sa_bwd_prep_rows(int b, int m) { return b * ((m + 63) / 64); 
 extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long long gs_b,
                                long long gs_c, long long gs_m, const float *out, int relu,
                                const float *ysel, const float *pack2, const void *ft, int precision,
-                               const int *fidx, const float *ws, float *goa, float *partS,
+                               const int *fidx, const float *ws, float *goa, void *accS,
                                float *partWs, float *gip, void *stream) {
-    if (b <= 0 || m <= 0 || b > 65535 || !g_out || !ysel || !pack2 || !goa || !partS) return APN_EINVAL;
+    if (b <= 0 || m <= 0 || b > 65535 || !g_out || !ysel || !pack2 || !goa || !accS) return APN_EINVAL;
     if (relu && !out) return APN_EINVAL;
     if (ws && (!ft || !fidx || !partWs || !gip || n <= 0 || (precision != 1 && precision != 2)))
         return APN_EINVAL;
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = (ws && precision == 2) ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::bwd_prep_kernel, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, g_out,
-                       gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, partS, partWs, gip);
-    APN_LAUNCH_CHECK();
-    return APN_OK;
-}
-
-extern "C" int apn_sa_bwd_consts2(const float *partS, int rows, const double *S, const float *pack2,
-                                  const float *w2, double count, int training, float *d2e2,
-                                  float *qm, float *evec, float *g_gamma2, float *g_beta2,
-                                  float *zero_w2, float *zero_gram, void *stream) {
-    if ((!partS && !S) || !pack2 || !w2 || !d2e2 || !qm || !evec) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::bwd_consts2_kernel, dim3(1), dim3(1024), 0, APN_ST, partS, rows, S, pack2,
-                       w2, count, training, d2e2, qm, evec, g_gamma2, g_beta2, zero_w2, zero_gram);
-    APN_LAUNCH_CHECK();
-    return APN_OK;
-}
-
-extern "C" int apn_sa_bwd_consts1(const float *partT, int rows, const double *T, const float *pack1,
-                                  double count, int training, float *cabc, float *g_gamma1,
-                                  float *g_beta1, const float *w2, const float *d2e2,
-                                  const float *gram, const float *gw2_acc, float *g_w2, void *stream) {
-    if ((!partT && !T) || !pack1 || !cabc) return APN_EINVAL;
-    if (g_w2 && (!w2 || !d2e2 || !gram || !gw2_acc)) return APN_EINVAL;
-    if (partT && ((uintptr_t)partT & 15)) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::bwd_consts1_kernel, dim3(8), dim3(256), 0, APN_ST, partT, rows, T, pack1,
-                       count, training, cabc, g_gamma1, g_beta1, w2, d2e2, gram, gw2_acc, g_w2);
+                       gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, (unsigned long long *)accS,
+                       partWs, gip);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
 extern "C" int apn_sa_bwd_weight_rows(int b, int n) { return b * ((n + apn::WG_PTS - 1) / apn::WG_PTS); }
 
-extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const float *A, const float *geo,
-                                      const float *HA, const float *HB, const float *cabc,
-                                      const float *pack1, const void *ft, int precision,
+extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const float *A, const void *geo,
+                                      const float *HA, const float *HB, const void *accT, const double *sumsT,
+                                      double count, int train1, const float *pack1, const void *ft, int precision,
                                       const float *xyz, const float *new_xyz, const float *w1,
                                       const float *gip, float radius, float *partW, float *g_f,
                                       float *g_p, float *g_newp, void *stream) {
     if (b <= 0 || n <= 0 || m <= 0 || b > 65535) return APN_EINVAL;
-    if (!A || !geo || !HA || !HB || !cabc || !pack1 || !ft || !xyz || !new_xyz || !w1 || !partW || !g_f)
+    if (!A || !geo || !HA || !HB || (!accT && !sumsT) || !pack1 || !ft || !xyz || !new_xyz || !w1 || !partW || !g_f)
         return APN_EINVAL;
     if (precision != 1 && precision != 2) return APN_EINVAL;
     if (m > n) return APN_EINVAL;                    // query tiles are walked with the point tiles
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = precision == 2 ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::bwd_point_grads_kernel, dim3((n + apn::WG_PTS - 1) / apn::WG_PTS, b),
-                       dim3(1024), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, A, geo, HA, HB, cabc,
+                       dim3(1024), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, A, (const long long *)geo, HA, HB,
+                       (const unsigned long long *)accT, sumsT, count, train1,
                        pack1, hi, lo, xyz, new_xyz, w1, gip, 1.0f / radius, partW, g_f, g_p, g_newp);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
 extern "C" int apn_sa_bwd_finalize(const float *partW, int rows_w, float radius, float *g_w1,
-                                   const float *partWs, int rows_s, float *g_ws,
-                                   const float *partS, float *g_bs, void *stream) {
-    if (!partW || !g_w1 || (g_ws && !partWs) || (g_bs && !partS)) return APN_EINVAL;
-    const int total = 32 * 35 + 2048 + 64;
-    hipLaunchKernelGGL(apn::bwd_finalize_kernel, dim3((total + 15) / 16), dim3(256), 0, APN_ST, partW,
-                       rows_w, 1.0 / (double)radius, g_w1, partWs, rows_s, g_ws, partS, g_bs);
+                                   const float *partWs, int rows_s, float *g_ws, const float *partW2, int rows_2,
+                                   float *g_w2, const void *accS, const double *sumsS,
+                                   const void *accT, const double *sumsT, float *g_bs, float *g_g2, float *g_b2,
+                                   float *g_g1, float *g_b1, void *stream) {
+    if (!partW || !g_w1 || (g_ws && !partWs) || (g_w2 && !partW2) || !accS || (!accT && !sumsT))
+        return APN_EINVAL;
+    hipLaunchKernelGGL(apn::bwd_finalize_kernel, dim3((apn::FIN_TOTAL + 15) / 16), dim3(256), 0, APN_ST, partW,
+                       rows_w, 1.0 / (double)radius, g_w1, partWs, rows_s, g_ws, partW2, rows_2, g_w2,
+                       (const unsigned long long *)accS, sumsS, (const unsigned long long *)accT, sumsT, g_bs,
+                       g_g2, g_b2, g_g1, g_b1);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

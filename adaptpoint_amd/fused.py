@@ -19,8 +19,10 @@ Two entry points over the same kernels:
 No (B, C, M, K) tensor is materialised, forward or backward.  BatchNorm follows the
 modules' training flag (batch statistics + running-buffer update, or the running
 buffers); the MFMA contractions are bf16 x bf16 -> f32 accumulate on split (hi + lo) operands
-by default (`PRECISION`), every statistic is an f32 partial summed in f64.  Forward is 8 kernel launches, backward 9 (+ one memset),
-all on the current stream with no host reads, so a step can be captured in a HIP graph.
+by default (`PRECISION`), every statistic is an f32 partial summed exactly (integer accumulator sets) or in f64.
+Forward is 3 kernel launches, backward 4 (round 2: 6 + 6: every BatchNorm fold / constants kernel is now a
+prologue of its consumer, and BatchNorm-1's statistics come per POINT from the index stage's occurrence
+statistics `Sampling.geo`), all on the current stream with no host reads, so a step can be captured in a HIP graph.
 With sync_bn=True the per-channel float64 sums are all-reduced across ranks
 (SyncBatchNorm semantics) at the four points where statistics leave the kernels.
 """
@@ -153,6 +155,14 @@ def _all_reduce_rows(call, part, rows, ncol, count, dev):
     return sums
 
 
+def _all_reduce_acc(call, acc, ncol, count, dev):
+    """The same exchange for an accumulator set (csrc/apn_common.h) instead of partial rows."""
+    sums = torch.empty(ncol + 2, dtype=torch.float64, device=dev)
+    call("apn_sa_reduce_acc", acc.data_ptr(), ncol, float(count), sums.data_ptr())
+    _allreduce_sum_(sums)
+    return sums
+
+
 def _bn_args(bn):
     """(gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, training)."""
     training = bn.training or not bn.track_running_stats
@@ -172,15 +182,22 @@ def _mat(w, rows, cols):
     return w if w.is_contiguous() else w.contiguous()
 
 
+def _acc_floats(ncol):
+    """float32 slots of an accumulator set of ncol columns (it holds 64-bit words)."""
+    return 2 * _lib.load().apn_sa_acc_words(ncol)
+
+
 class _Forward:
     """Runs the forward launches and keeps what the backward needs."""
 
     def __init__(self, p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
-                 sync_bn, tmap=None, want_backward=False):
-        """want_backward: the backward's atomically accumulated region (A | geo | gip) is allocated now and cleared
-        by the forward's last launch, so that the backward runs without a fill launch of its own.
+                 sync_bn, tmap=None, geo=None, dd=None, want_backward=False):
+        """want_backward: the backward's atomically accumulated region (A | gip | accS | accT) is allocated now and
+        cleared by the forward's last launch, so that the backward runs without a fill launch of its own.
         tmap: the distinct-hit tile map of idx (adaptpoint_amd.fused_wide.tile_map; index-stage work) -- the
-        three passes over the positions then run over ~1/4 of the tiles at stage 1; None: one tile per query."""
+        passes over the positions then run over ~1/4 of the tiles at stage 1; None: one tile per query.
+        geo, dd: the neighbourhoods' occurrence statistics (index-stage work too: `point_geo`; computed here when
+        the caller has none)."""
         dev = f.device
         call = _Launcher(dev)
         lib = _lib.load()
@@ -198,12 +215,15 @@ class _Forward:
             ws = _mat(skip_conv.weight, C_OUT, C_IN)
             bs = skip_conv.bias.detach() if skip_conv.bias is not None else None
         count = float(B * M * K_NS)       # this rank's positions; SyncBatchNorm all-reduces it with the sums
-        rows = lib.apn_sa_grid_rows(B, M, 1 if tmap is not None else 0)
+        if geo is None:
+            geo, dd = point_geo(p, new_p, idx, radius)
+        rows1 = lib.apn_sa_prep_rows(B, N)
         v, _buf = _carve(dev, [("ft", prec * B * N * C // 2), ("pack1", 4 * C_MID), ("pack2", 4 * C_OUT),
-                               ("sgn2", C_OUT), ("ysel", B * M * C_OUT), ("ksel", B * M * C_OUT // 4),
-                               ("part1", rows * 64), ("part2", rows * 128)])
+                               ("ysel", B * M * C_OUT), ("ksel", B * M * C_OUT // 4),
+                               ("part1", rows1 * 64), ("acc2", _acc_floats(128))])
         out = torch.empty(B, C_OUT, M, dtype=torch.float32, device=dev)
-        self.zsizes = [("A", B * N * C_MID), ("geo", B * N * 4)] + ([("gip", B * N * C_MID)] if ws is not None else [])
+        self.zsizes = ([("A", B * N * C_MID)] + ([("gip", B * N * C_MID)] if ws is not None else [])
+                       + [("accS", _acc_floats(128)), ("accT", _acc_floats(64))])
         self.zviews = self.zbuf = None
         if want_backward:
             self.zviews, self.zbuf = _carve(dev, self.zsizes)
@@ -213,26 +233,27 @@ class _Forward:
 
         def run(phases, sums1=None, sums2=None):
             if PER_KERNEL_LAUNCH:
-                return _forward_per_kernel(call, phases, prec, B, N, M, self.radius, p, new_p, f, idx, fidx,
+                return _forward_per_kernel(call, phases, prec, B, N, M, self.radius, p, new_p, f, idx, fidx, geo, dd,
                                            w1, w2, ws, bs, bn1a, bn2a, count, self.relu, v, sums1,
-                                           sums2, out, rows, tmap, zptr, zfl)
+                                           sums2, out, rows1, tmap, zptr, zfl)
             call("apn_sa_forward_seq", phases, prec, B, N, M, self.radius, p.data_ptr(), new_p.data_ptr(),
-                 f.data_ptr(), idx.data_ptr(), _ptr(tmap), _ptr(fidx), w1.data_ptr(), w2.data_ptr(), _ptr(ws),
-                 _ptr(bs), *bn1a, *bn2a, count, self.relu, v["ft"].data_ptr(),
-                 v["part1"].data_ptr(), v["part2"].data_ptr(), _ptr(sums1), _ptr(sums2),
-                 v["pack1"].data_ptr(), v["pack2"].data_ptr(), v["sgn2"].data_ptr(),
+                 f.data_ptr(), idx.data_ptr(), _ptr(tmap), _ptr(fidx), geo.data_ptr(), dd.data_ptr(),
+                 w1.data_ptr(), w2.data_ptr(), _ptr(ws), _ptr(bs), *bn1a, *bn2a, count, self.relu,
+                 v["ft"].data_ptr(), v["part1"].data_ptr(), _ptr(sums1), _ptr(sums2),
+                 v["pack1"].data_ptr(), v["pack2"].data_ptr(), v["acc2"].data_ptr(),
                  v["ysel"].data_ptr(), v["ksel"].data_ptr(), out.data_ptr(), zptr, zfl)
 
         if not _phased(sync_bn):
             run(7)
         else:                                   # SyncBatchNorm: all-reduce between the phases
             run(1)
-            s1 = _all_reduce_rows(call, v["part1"], rows, 64, count, dev) if self.train1 else None
+            s1 = _all_reduce_rows(call, v["part1"], rows1, 64, count, dev) if self.train1 else None
             run(2, sums1=s1)
-            s2 = _all_reduce_rows(call, v["part2"], rows, 128, count, dev) if self.train2 else None
+            s2 = _all_reduce_acc(call, v["acc2"], 128, count, dev) if self.train2 else None
             run(4, sums2=s2)
         self.out = out
-        self.saved = dict(p=p, f=f, new_p=new_p, idx=idx, tmap=tmap if TILE_MAP_IN_BACKWARD else None, fidx=fidx, ft=v["ft"], w1=w1, w2=w2, ws=ws,
+        self.saved = dict(p=p, f=f, new_p=new_p, idx=idx, tmap=tmap if TILE_MAP_IN_BACKWARD else None, fidx=fidx,
+                          geo=geo, ft=v["ft"], w1=w1, w2=w2, ws=ws,
                           has_bs=bs is not None, pack1=v["pack1"], pack2=v["pack2"], ysel=v["ysel"],
                           ksel=v["ksel"], count=count)
 
@@ -259,24 +280,20 @@ def _backward(fw, g_out, need_p, need_newp):
     rows = lib.apn_sa_bwd_main_rows(B, M)
     prow = lib.apn_sa_bwd_prep_rows(B, M)
     wrows = lib.apn_sa_bwd_weight_rows(B, N)
-    ncopy = lib.apn_sa_bwd_acc_copies()           # copies of the dL/dW2 accumulators (spread same-address atomics)
 
     # scratch: the zero-filled (atomically accumulated) region first, contiguous -- unless the forward's last
     # launch already allocated and cleared it (fw.zbuf)
     prezeroed = fw.zbuf is not None
     zsizes = [] if prezeroed else fw.zsizes
-    sizes = zsizes + [("goa", B * M * C_OUT), ("partS", prow * 128),
-                      ("partWs", prow * C_OUT * C_IN if has_skip else 0), ("partT", rows * 64),
-                      ("partW", wrows * 32 * 38), ("d2e2", 2 * C_OUT), ("qm", C_MID * C_MID),
-                      ("evec", C_MID), ("cabc", 3 * C_MID), ("gram", ncopy * (C_MID * C_MID + C_MID)),
-                      ("gw2c", ncopy * C_OUT * C_MID), ("HA", B * M * C_MID),
-                      ("HB", B * M * C_MID)]
+    sizes = zsizes + [("goa", B * M * C_OUT), ("partWs", prow * C_OUT * C_IN if has_skip else 0),
+                      ("partW2", rows * C_OUT * C_MID), ("partW", wrows * 32 * 38),
+                      ("HA", B * M * C_MID), ("HB", B * M * C_MID)]
     v, buf = _carve(dev, sizes)
     zero_floats = sum((nfl + 63) // 64 * 64 for _, nfl in zsizes)
     if prezeroed:
         v.update(fw.zviews)
         fw.zbuf = fw.zviews = None                        # consumed: a second backward must not trust it
-    # small gradients in one buffer (kept alive by the parameters' .grad), g_w2 zero-filled
+    # small gradients in one buffer (kept alive by the parameters' .grad)
     gsz = [("w2", C_OUT * C_MID), ("w1", C_MID * (C_IN + 3)), ("g1", C_MID), ("b1", C_MID),
            ("g2", C_OUT), ("b2", C_OUT), ("ws", C_OUT * C_IN if has_skip else 0),
            ("bs", C_OUT if (has_skip and sv["has_bs"]) else 0)]
@@ -284,68 +301,58 @@ def _backward(fw, g_out, need_p, need_newp):
     g_f = torch.empty(B, C_IN, N, **f32)
     g_p = torch.zeros(B, N, 3, **f32) if need_p else None
     g_newp = torch.empty(B, M, 3, **f32) if need_newp else None
+    gws = g["ws"].data_ptr() if has_skip else None
+    gbs = g["bs"].data_ptr() if (has_skip and sv["has_bs"]) else None
 
     def run(phases, sumsS=None, sumsT=None):
         if PER_KERNEL_LAUNCH:
             return _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, sumsS,
                                         sumsT, g_f, g_p, g_newp, rows, prow, wrows, has_skip)
         call("apn_sa_backward_seq", phases, fw.prec, B, N, M, fw.radius, sv["p"].data_ptr(),
-             sv["new_p"].data_ptr(), sv["f"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["tmap"]), _ptr(sv["fidx"]),
+             sv["new_p"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["tmap"]), _ptr(sv["fidx"]), sv["geo"].data_ptr(),
              w1.data_ptr(), w2.data_ptr(), _ptr(ws), sv["ft"].data_ptr(), sv["pack1"].data_ptr(),
              sv["pack2"].data_ptr(), sv["ysel"].data_ptr(), sv["ksel"].data_ptr(),
              fw.out.data_ptr(), fw.relu, 1 if fw.train1 else 0, 1 if fw.train2 else 0, float(P),
              g_out.data_ptr(), gs[0], gs[1], gs[2], buf.data_ptr(), zero_floats * 4,
-             g["w2"].data_ptr(), v["gw2c"].data_ptr(), v["gram"].data_ptr(),
-             v["A"].data_ptr(), v["geo"].data_ptr(), v["gip"].data_ptr() if has_skip else None,
-             v["goa"].data_ptr(),
-             v["partS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None,
-             v["partT"].data_ptr(), v["partW"].data_ptr(), _ptr(sumsS), _ptr(sumsT),
-             v["d2e2"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr(), v["cabc"].data_ptr(),
-             v["HA"].data_ptr(), v["HB"].data_ptr(), g_f.data_ptr(), _ptr(g_p), _ptr(g_newp),
-             g["w1"].data_ptr(),
-             g["g1"].data_ptr(), g["b1"].data_ptr(), g["g2"].data_ptr(), g["b2"].data_ptr(),
-             g["ws"].data_ptr() if has_skip else None,
-             g["bs"].data_ptr() if (has_skip and sv["has_bs"]) else None)
+             v["A"].data_ptr(), v["gip"].data_ptr() if has_skip else None, v["accS"].data_ptr(),
+             v["accT"].data_ptr(), v["goa"].data_ptr(),
+             v["partWs"].data_ptr() if has_skip else None, v["partW2"].data_ptr(), v["partW"].data_ptr(),
+             _ptr(sumsS), _ptr(sumsT), v["HA"].data_ptr(), v["HB"].data_ptr(),
+             g_f.data_ptr(), _ptr(g_p), _ptr(g_newp), g["w1"].data_ptr(), g["w2"].data_ptr(),
+             g["g1"].data_ptr(), g["b1"].data_ptr(), g["g2"].data_ptr(), g["b2"].data_ptr(), gws, gbs)
 
     if not _phased(sync):
         run(7)
     else:
         run(1)
-        sS = _all_reduce_rows(call, v["partS"], prow, 128, P, dev)
+        sS = _all_reduce_acc(call, v["accS"], 128, P, dev)
         run(2, sumsS=sS)
-        sT = _all_reduce_rows(call, v["partT"], rows, 64, P, dev)
-        run(4, sumsT=sT)
+        sT = _all_reduce_acc(call, v["accT"], 64, P, dev)
+        run(4, sumsS=sS, sumsT=sT)
     # conv-weight gradients are per-rank sums here and DistributedDataParallel (or
     # dp.allreduce_mean_) averages them; under SyncBatchNorm dL/dgamma, dL/dbeta already are
-    # global / world on every rank (sa_glue.hip, bwd_consts*), which that averaging leaves as is
+    # global / world on every rank (sa_glue.hip: bwd_finalize), which that averaging leaves as is
     return dict(f=g_f, p=g_p, new_p=g_newp, w1=g["w1"].view(C_MID, C_IN + 3, 1, 1),
                 w2=g["w2"].view(C_OUT, C_MID, 1, 1), g1=g["g1"], b1=g["b1"], g2=g["g2"], b2=g["b2"],
                 ws=g["ws"].view(C_OUT, C_IN, 1) if has_skip else None,
                 bs=g["bs"] if (has_skip and sv["has_bs"]) else None)
 
 
-def _forward_per_kernel(call, phases, prec, B, N, M, radius, p, new_p, f, idx, fidx, w1, w2, ws, bs,
-                        bn1a, bn2a, count, relu, v, sums1, sums2, out, rows, tmap=None, zptr=None, zfl=0):
+def _forward_per_kernel(call, phases, prec, B, N, M, radius, p, new_p, f, idx, fidx, geo, dd, w1, w2, ws, bs,
+                        bn1a, bn2a, count, relu, v, sums1, sums2, out, rows1, tmap=None, zptr=None, zfl=0):
     """Python mirror of apn_sa_forward_seq (csrc/sa_seq.hip), one foreign call per kernel."""
-    hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, prec, radius, p.data_ptr(), new_p.data_ptr(),
-           v["ft"].data_ptr(), idx.data_ptr(), _ptr(tmap), w1.data_ptr())
+    lib = _lib.load()
     if phases & 1:
-        call("apn_sa_prep_features", B, C_IN, N, f.data_ptr(), v["ft"].data_ptr(), prec)
-        if bn1a[7]:
-            call("apn_sa_fwd_stats1", *hdr, v["part1"].data_ptr())
+        call("apn_sa_prep_stats", B, N, f.data_ptr(), geo.data_ptr(), dd.data_ptr(), w1.data_ptr(), prec,
+             bn1a[7], v["ft"].data_ptr(), v["part1"].data_ptr(), v["acc2"].data_ptr(), lib.apn_sa_acc_words(128))
     if phases & 2:
-        call("apn_sa_bn_fold", None if sums1 is not None else v["part1"].data_ptr(), rows, _ptr(sums1),
-             C_MID, count, bn1a[0], bn1a[1], bn1a[5], bn1a[6], bn1a[2], bn1a[3], bn1a[4], bn1a[7],
-             v["pack1"].data_ptr(), bn2a[0], C_OUT, v["sgn2"].data_ptr())
-        call("apn_sa_fwd_main", *hdr, w2.data_ptr(), v["pack1"].data_ptr(),
-             v["pack1"].data_ptr() + 4 * C_MID, v["sgn2"].data_ptr(), v["ysel"].data_ptr(),
-             v["ksel"].data_ptr(), v["part2"].data_ptr())
+        call("apn_sa_fwd_main", B, N, M, prec, radius, p.data_ptr(), new_p.data_ptr(), v["ft"].data_ptr(),
+             idx.data_ptr(), _ptr(tmap), w1.data_ptr(), w2.data_ptr(), *bn1a, count, v["part1"].data_ptr(), rows1,
+             _ptr(sums1), v["pack1"].data_ptr(), bn2a[0], v["ysel"].data_ptr(), v["ksel"].data_ptr(),
+             v["acc2"].data_ptr())
     if phases & 4:
-        call("apn_sa_bn_fold", None if sums2 is not None else v["part2"].data_ptr(), rows, _ptr(sums2),
-             C_OUT, count, bn2a[0], bn2a[1], bn2a[5], bn2a[6], bn2a[2], bn2a[3], bn2a[4], bn2a[7],
-             v["pack2"].data_ptr(), None, 0, None)
-        call("apn_sa_fwd_out", B, N, M, v["ysel"].data_ptr(), v["pack2"].data_ptr(),
-             v["ft"].data_ptr() if ws is not None else None, prec,
+        call("apn_sa_fwd_out", B, N, M, v["ysel"].data_ptr(), v["acc2"].data_ptr(), _ptr(sums2), *bn2a, count,
+             v["pack2"].data_ptr(), v["ft"].data_ptr() if ws is not None else None, prec,
              _ptr(fidx) if ws is not None else None, _ptr(ws), _ptr(bs), relu, out.data_ptr(), zptr, zfl)
 
 
@@ -355,37 +362,29 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
     B, N, M = fw.dims
     w1, w2, ws, P = sv["w1"], sv["w2"], sv["ws"], float(sv["count"])
     gip = v["gip"].data_ptr() if has_skip else None
-    hdr = (B, N, M, C_IN, C_MID, C_OUT, K_NS, fw.prec, fw.radius, sv["p"].data_ptr(),
-           sv["new_p"].data_ptr(), sv["ft"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["tmap"]), w1.data_ptr(),
-           w2.data_ptr(), sv["pack1"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr())
     if phases & 1:
-        buf[:zero_floats].zero_()
+        if zero_floats:
+            call("apn_zero_fill", buf.data_ptr(), zero_floats * 4)
         call("apn_sa_bwd_prep", B, N, M, g_out.data_ptr(), *g_out.stride(), fw.out.data_ptr(), fw.relu,
              sv["ysel"].data_ptr(), sv["pack2"].data_ptr(), sv["ft"].data_ptr() if has_skip else None,
              fw.prec, _ptr(sv["fidx"]) if has_skip else None, _ptr(ws), v["goa"].data_ptr(),
-             v["partS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None, gip)
+             v["accS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None, gip)
     if phases & 2:
-        call("apn_sa_bwd_consts2", None if sumsS is not None else v["partS"].data_ptr(), prow,
-             _ptr(sumsS), sv["pack2"].data_ptr(), w2.data_ptr(), P, 1 if fw.train2 else 0,
-             v["d2e2"].data_ptr(), v["qm"].data_ptr(), v["evec"].data_ptr(), g["g2"].data_ptr(),
-             g["b2"].data_ptr(), v["gw2c"].data_ptr(), v["gram"].data_ptr())
-        call("apn_sa_bwd_main", *hdr, v["goa"].data_ptr(),
-             sv["ksel"].data_ptr(), v["partT"].data_ptr(), v["gw2c"].data_ptr(), v["gram"].data_ptr(),
-             v["A"].data_ptr(),
-             v["geo"].data_ptr(), v["HA"].data_ptr(), v["HB"].data_ptr())
+        call("apn_sa_bwd_main", B, N, M, fw.prec, fw.radius, sv["p"].data_ptr(), sv["new_p"].data_ptr(),
+             sv["ft"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["tmap"]), w1.data_ptr(), w2.data_ptr(),
+             sv["pack1"].data_ptr(), sv["pack2"].data_ptr(), v["accS"].data_ptr(), _ptr(sumsS), P,
+             1 if fw.train2 else 0, v["goa"].data_ptr(), sv["ksel"].data_ptr(), v["accT"].data_ptr(),
+             v["partW2"].data_ptr(), v["A"].data_ptr(), v["HA"].data_ptr(), v["HB"].data_ptr())
     if phases & 4:
-        call("apn_sa_bwd_consts1", None if sumsT is not None else v["partT"].data_ptr(), rows,
-             _ptr(sumsT), sv["pack1"].data_ptr(), P, 1 if fw.train1 else 0, v["cabc"].data_ptr(),
-             g["g1"].data_ptr(), g["b1"].data_ptr(), w2.data_ptr(), v["d2e2"].data_ptr(),
-             v["gram"].data_ptr(), v["gw2c"].data_ptr(), g["w2"].data_ptr())
-        call("apn_sa_bwd_point_grads", B, N, M, v["A"].data_ptr(), v["geo"].data_ptr(),
-             v["HA"].data_ptr(), v["HB"].data_ptr(), v["cabc"].data_ptr(), sv["pack1"].data_ptr(),
-             sv["ft"].data_ptr(), fw.prec, sv["p"].data_ptr(), sv["new_p"].data_ptr(), w1.data_ptr(),
-             gip, fw.radius, v["partW"].data_ptr(), g_f.data_ptr(), _ptr(g_p), _ptr(g_newp))
+        call("apn_sa_bwd_point_grads", B, N, M, v["A"].data_ptr(), sv["geo"].data_ptr(),
+             v["HA"].data_ptr(), v["HB"].data_ptr(), v["accT"].data_ptr(), _ptr(sumsT), P, 1 if fw.train1 else 0,
+             sv["pack1"].data_ptr(), sv["ft"].data_ptr(), fw.prec, sv["p"].data_ptr(), sv["new_p"].data_ptr(),
+             w1.data_ptr(), gip, fw.radius, v["partW"].data_ptr(), g_f.data_ptr(), _ptr(g_p), _ptr(g_newp))
         call("apn_sa_bwd_finalize", v["partW"].data_ptr(), wrows, fw.radius, g["w1"].data_ptr(),
-             v["partWs"].data_ptr() if has_skip else None, prow,
-             g["ws"].data_ptr() if has_skip else None, v["partS"].data_ptr(),
-             g["bs"].data_ptr() if (has_skip and sv["has_bs"]) else None)
+             v["partWs"].data_ptr() if has_skip else None, prow, g["ws"].data_ptr() if has_skip else None,
+             v["partW2"].data_ptr(), rows, g["w2"].data_ptr(), v["accS"].data_ptr(), _ptr(sumsS),
+             v["accT"].data_ptr(), _ptr(sumsT), g["bs"].data_ptr() if (has_skip and sv["has_bs"]) else None,
+             g["g2"].data_ptr(), g["b2"].data_ptr(), g["g1"].data_ptr(), g["b1"].data_ptr())
 
 
 class _GroupedMlpMax(torch.autograd.Function):
@@ -425,7 +424,8 @@ class Sampling:
     features or weights -- so it can be computed ahead of the feature path (another stream,
     the next batch) and handed to `fused_set_abstraction(..., sampling=...)`.
     The three tensors are views of ONE buffer, so a double-buffered pipeline rotates them
-    with a single copy."""
+    with a single copy.  A buffer may stack several batches (their index stages then run as single
+    launches); `clouds(lo, hi)` hands out one batch."""
 
     def __init__(self, B, M, K, device):
         self.shape = (B, M, K)
@@ -438,6 +438,16 @@ class Sampling:
         self.idx = self.buf[o:o + B * M * K].view(B, M, K)
         self.index = None        # adaptpoint_amd.fused_wide.NeighbourIndex of idx, when the width-generic kernels run
         self.tmap = None         # adaptpoint_amd.fused_wide.tile_map of idx, for the register-resident kernels
+        self.geo = None          # (B,N,4) int64 occurrence statistics of the neighbourhoods (csrc/sa_geo.hip) and
+        self.dd = None           # (B, 6 * slabs) float64 their second moments, for the register-resident kernels
+
+    def alloc_geo(self, n_points):
+        if self.geo is None or self.geo.shape[1] != n_points:
+            B = self.shape[0]
+            dev = self.buf.device
+            self.geo = torch.empty(B, n_points, 4, dtype=torch.int64, device=dev)
+            self.dd = torch.empty(B, _lib.load().apn_sa_geo_dd_doubles(n_points), dtype=torch.float64, device=dev)
+        return self.geo, self.dd
 
     def clouds(self, lo, hi):
         """The index stage of clouds lo..hi-1 as a `Sampling`-like view (no copy): index stages of
@@ -448,28 +458,59 @@ class Sampling:
         v.fidx, v.new_p, v.idx = self.fidx[lo:hi], self.new_p[lo:hi], self.idx[lo:hi]
         v.index = None
         v.tmap = None
+        v.geo = v.dd = None
+        if self.geo is not None:
+            v.geo, v.dd = self.geo[lo:hi], self.dd[lo:hi]
         return v
 
 
 @torch.no_grad()
-def sample_and_query(p, npoint, radius, nsample=K_NS, out=None):
+def point_geo(p, new_p, idx, radius, out=None):
+    """The neighbourhoods' occurrence statistics (csrc/sa_geo.hip; index-stage work: coordinates and indices
+    only): geo (B,N,4) int64 = per support point {occurrences, sum of (p - query)/radius in units of 2^-36},
+    dd (B, 6 * slabs) float64 = each cloud's shares of sum d d^T over its positions."""
+    B, N, _ = p.shape
+    M, K = idx.shape[1], idx.shape[2]
+    dev = p.device
+    if out is None:
+        geo = torch.empty(B, N, 4, dtype=torch.int64, device=dev)
+        dd = torch.empty(B, _lib.load().apn_sa_geo_dd_doubles(N), dtype=torch.float64, device=dev)
+    else:
+        geo, dd = out
+    _Launcher(dev)("apn_sa_point_geo", B, N, M, K, float(radius), p.contiguous().data_ptr(),
+                   new_p.contiguous().data_ptr(), idx.contiguous().data_ptr(), geo.data_ptr(), dd.data_ptr())
+    return geo, dd
+
+
+@torch.no_grad()
+def sample_and_query(p, npoint, radius, nsample=K_NS, out=None, geo=False):
     """FPS (+ gather of the sampled coordinates, one launch; pointnext.py:146-147) and ball
-    query (group.py:245) on the current stream."""
+    query (group.py:245) on the current stream; geo=True: also the occurrence statistics the
+    register-resident fused block takes (`point_geo`)."""
     p = p.contiguous()
     dev = p.device
     B, N, _ = p.shape
     smp = out if out is not None else Sampling(B, npoint, nsample, dev)
     assert smp.shape == (B, npoint, nsample)
+    gptr = dptr = None
+    if geo and nsample == K_NS and smp.buf is not None:
+        g_, d_ = smp.alloc_geo(N)
+        gptr, dptr = g_.data_ptr(), d_.data_ptr()
+    elif geo and nsample == K_NS and smp.geo is not None:
+        gptr, dptr = smp.geo.data_ptr(), smp.dd.data_ptr()
     call = _Launcher(dev)
     if PER_KERNEL_LAUNCH:
         call("apn_furthest_point_sampling_xyz", B, N, npoint, p.data_ptr(), None,
              smp.fidx.data_ptr(), smp.new_p.data_ptr())
         call("apn_ball_query_zero", B, N, npoint, float(radius), nsample, smp.new_p.data_ptr(),
              p.data_ptr(), smp.idx.data_ptr())
+        if gptr is not None:
+            call("apn_sa_point_geo", B, N, npoint, nsample, float(radius), p.data_ptr(),
+                 smp.new_p.data_ptr(), smp.idx.data_ptr(), gptr, dptr)
         return smp
     # temp = None: the sampler starts from 1e10 in registers (no fill launch, no min-distances kept)
     call("apn_sa_sample_seq", B, N, npoint, float(radius), nsample, p.data_ptr(), None,
-         smp.fidx.data_ptr(), smp.new_p.data_ptr(), smp.idx.data_ptr())
+         smp.fidx.data_ptr(), smp.new_p.data_ptr(), smp.idx.data_ptr(), gptr, dptr)
     return smp
 
 
@@ -496,6 +537,8 @@ def sample_and_query_many(ps, npoint, radius, nsample=K_NS, outs=None):
              ps[b].data_ptr() if b is not None else None,
              outs[b].new_p.data_ptr() if b is not None else None,
              outs[b].idx.data_ptr() if b is not None else None)
+        if b is not None and outs[b].geo is not None:           # buffers that carry occurrence statistics get them
+            point_geo(ps[b], outs[b].new_p, outs[b].idx, radius, out=(outs[b].geo, outs[b].dd))
     return outs
 
 
@@ -505,12 +548,13 @@ class _SetAbstraction(torch.autograd.Function):
         npoint, radius, conv1, bn1, conv2, bn2, skip_conv, relu, sync_bn, sampling = mods
         p = p.contiguous()
         f = f.contiguous()
-        smp = sampling if sampling is not None else sample_and_query(p, npoint, radius)
+        smp = sampling if sampling is not None else sample_and_query(p, npoint, radius, geo=True)
         fidx, new_p, idx = smp.fidx, smp.new_p, smp.idx
         if p.requires_grad:
             new_p = new_p.clone()          # returned as a differentiable output
         fw = _Forward(p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
-                      sync_bn, tmap=getattr(smp, "tmap", None), want_backward=any(ctx.needs_input_grad))
+                      sync_bn, tmap=getattr(smp, "tmap", None), geo=getattr(smp, "geo", None),
+                      dd=getattr(smp, "dd", None), want_backward=any(ctx.needs_input_grad))
         ctx.fw = fw
         ctx.save_for_backward(p, f)        # autograd's in-place version checks cover the inputs
         ctx.set_materialize_grads(False)   # an unused output's gradient arrives as None, not as zeros

@@ -63,7 +63,7 @@ class PointNextEncoderS(nn.Module):
                 res.append(None)
                 continue
             smp = fused.sample_and_query(p, p.shape[1] // sa.stride, sa.grouper.radius, sa.grouper.nsample,
-                                         out=None if out is None else out[i])
+                                         out=None if out is None else out[i], geo=sa._resident())
             # tile map + inverse map of the neighbourhoods, for the blocks on the width-generic kernels
             sa.index_for(smp, p.shape[1], sa.convs[0][0].in_channels - 3, out=smp.index)
             res.append(smp)

@@ -139,11 +139,22 @@ class SetAbstraction(nn.Module):
             return None
         return blk1[0], blk1[1], blk2[0], blk2[1], len(blk2) == 3
 
+    def _resident(self):
+        """Whether this block runs on the register-resident fused kernels (32 -> 32 -> 64, K = 32)."""
+        if not self.fused or self.is_head or self.all_aggr or fused_wide_first():
+            return False
+        parts = self._fused_parts()
+        if parts is None:
+            return False
+        w = parts[0].weight
+        return w.shape[0] == 32 and w.shape[1] == 35 and parts[2].weight.shape[0] == 64 and self.grouper.nsample == 32
+
     def sample(self, p, out=None):
-        """The block's index stage alone (FPS + ball query) -> adaptpoint_amd.fused.Sampling."""
+        """The block's index stage alone (FPS + ball query; for the register-resident kernels also the
+        neighbourhoods' occurrence statistics) -> adaptpoint_amd.fused.Sampling."""
         from . import fused
         return fused.sample_and_query(p, p.shape[1] // self.stride, self.grouper.radius,
-                                      self.grouper.nsample, out=out)
+                                      self.grouper.nsample, out=out, geo=self._resident())
 
     def wide_shapes(self, c_in):
         """(uses the width-generic kernels for c_in input channels, has a fused residual branch there)."""

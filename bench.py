@@ -30,7 +30,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -54,7 +53,7 @@ def make_block(fused=False, sync_bn=False):
 def make_inputs(batch, seed, distribution="D1"):
     """SURVEY 8d: D1 = uniform cube, centred, scaled to the unit sphere (~9 neighbours in r=0.15);
     D2 = unit-sphere surface + N(0, 0.01) jitter (scan-like, ~6)."""
-    import golden_inputs as GI
+    from adaptpoint_amd import synthetic as GI
     cloud = GI.unit_sphere_cloud if distribution == "D1" else GI.sphere_surface_cloud
     p = torch.from_numpy(cloud(batch, N_PTS, seed=seed))
     f = torch.from_numpy(GI.seeded_normal((batch, C_IN, N_PTS), seed=seed + 7))
@@ -78,12 +77,15 @@ def algorithmic_bytes(batch, fused=True):
         "group_xyz": batch * (3 * N_PTS * 4 + mk * 4 + 3 * mk * 4),        # rows, idx, out
         "group_feat": batch * (C_IN * N_PTS * 4 + mk * 4 + C_IN * mk * 4),
         "group_feat_grad": batch * (C_IN * mk * 4 + mk * 4 + 2 * C_IN * N_PTS * 4),
+        # index stage's occurrence statistics: idx + coordinates in, int64 geo (B,N,4) out
+        "sa_point_geo": batch * (mk * 4 + N_PTS * 12 + NPOINT * 12 + N_PTS * 32),
+        # per-point pass: f + geo in, the bf16 operand table(s) out
+        "sa_prep_stats": batch * (C_IN * N_PTS * 4 + N_PTS * 32 + (2 if fused else 1) * N_PTS * 64),
         # fused passes: xyz + queries + idx + bf16 feature table in; pooled outputs / G, H out
-        "sa_fwd_stats1": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64),
         "sa_fwd_main": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64 + NPOINT * 64 * 5),
-        # + goa, ksel in; per-point sums A (128 B) + geo (16 B), per-query sums HA, HB out
+        # + goa, ksel in; per-point sums A (128 B), per-query sums HA, HB out
         "sa_bwd_main": batch * (N_PTS * 12 + NPOINT * 12 + mk * 4 + N_PTS * 64 + NPOINT * 64 * 5
-                                + N_PTS * 144 + NPOINT * 256),
+                                + N_PTS * 128 + NPOINT * 256),
     }
 
 
@@ -207,7 +209,7 @@ class Measured:
     pass
 
 
-def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps, warmup):
+def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps, warmup, repeats=1):
     """Build the block for one configuration, time `steps` steps per the contract, and return the
     elapsed seconds plus the eager single-step closure (for the per-kernel passes)."""
     from adaptpoint_amd import dp
@@ -269,9 +271,13 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
         # workgroup: the serial chains of different batches are independent and a batch of 32
         # keeps only 32 of 256 CUs busy).
         big = [Sampling(spg * B_PER_GPU, NPOINT, NSAMPLE, dev) for _ in range(2)]
+        for b in big:
+            b.alloc_geo(N_PTS)                       # the index stage also leaves the neighbourhoods' occurrence statistics
         sets = [[b.clouds(i * B_PER_GPU, (i + 1) * B_PER_GPU) for i in range(spg)] for b in big]
         blk.sample(p_all, out=big[0])                # prologue: index stages of the first launch
         big[1].buf.copy_(big[0].buf)
+        big[1].geo.copy_(big[0].geo)
+        big[1].dd.copy_(big[0].dd)
         # the width-generic kernels also take a tile map + inverse map of the neighbourhoods (index-stage work too)
         for st in sets:
             for i in range(spg):
@@ -424,6 +430,13 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
     # (a replay of an spg-step graph counts as spg steps: exactly `steps` steps are timed)
     # (warm-up is rounded UP to whole replays: at least `warmup` untimed steps)
     r.elapsed = dp.timed_steps(step, steps // spg, -(-warmup // spg), dev)
+    # A short timed region (the driver's --steps 20 is ONE graph replay of 3 ms) is repeated: the same K-step block,
+    # fenced on both sides every time, `repeats` times; the MEDIAN block is reported, min / max beside it.
+    r.blocks = [r.elapsed]
+    if repeats > 1:
+        for _ in range(repeats - 1):
+            r.blocks.append(dp.timed_steps(step, steps // spg, 0, dev))
+        r.elapsed = sorted(r.blocks)[len(r.blocks) // 2]
     r.steps, r.spg, r.use_graph, r.pipelined, r.fused_mlp = steps, spg, use_graph, pipelined, fused_mlp
     r.index_batch = index_batch if pipelined and args.index_overlap != "on" else 1
 
@@ -444,6 +457,8 @@ def main():
     # moved by 5 % from run to run
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed blocks of --steps steps each (median reported; 0 = auto: 25 when --steps < 400, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary figures (value_f32_dropin at 1 GPU, value_no_syncbn at N>1)")
@@ -514,7 +529,9 @@ def main():
         from adaptpoint_amd import set_abstraction as _sa_mod
         _sa_mod.PREFER_WIDE = True
     sync_bn = distributed and args.sync_bn != "off"          # auto = on, as the reference (main.py:27)
-    m = measure(args, dev, world, rank, local_rank, distributed, args.mlp, sync_bn, args.steps, args.warmup)
+    # fewer than ~400 steps are less than 0.1 s of work: repeat the K-step block and report the median (keeps `steps` = K)
+    repeats = args.repeats if args.repeats > 0 else (25 if args.steps < 400 else 1)
+    m = measure(args, dev, world, rank, local_rank, distributed, args.mlp, sync_bn, args.steps, args.warmup, repeats)
     elapsed, spg, use_graph, pipelined, fused_mlp, eager_step = (m.elapsed, m.spg, m.use_graph, m.pipelined,
                                                                  m.fused_mlp, m.eager_step)
     # The timed step issues whole launch sequences (one C call per direction, or one hipGraph),
@@ -539,7 +556,7 @@ def main():
     total_clouds = B_PER_GPU * world * args.steps
     value = total_clouds / elapsed
     ab = algorithmic_bytes(B_PER_GPU, fused=fused_mlp)
-    for k in ("fps", "ball_query"):                   # index launches cover index_batch batches
+    for k in ("fps", "ball_query", "sa_point_geo"):   # index launches cover index_batch batches
         ab[k] *= m.index_batch
     kernels = {}
     for k, us in sorted(per_kernel_us.items()):
@@ -549,54 +566,67 @@ def main():
             ent["achieved_GBps"] = round(ab[k] / us * 1e-3, 2)
             ent["frac_hbm"] = round(ab[k] / us * 1e-3 / HBM_PEAK_GBS, 5)
         kernels[k] = ent
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):       # PMC-measured HBM bytes per launch (rocprofv3 --pmc, committed)
-        traffic = json.load(open(tpath)).get("bytes_per_launch", {})
+    # PMC-measured HBM bytes per launch (rocprofv3 --pmc passes over THIS command's default launch structure,
+    # corrected as MI355X_MICROARCH.md prescribes; scripts/collect_profiles.sh pmc -> scripts/make_traffic_json.py).
+    # A committed constant, labelled as such: bench.py cannot run the profiler on itself.
+    traffic, traffic_src = {}, None
+    for name in ("r03_traffic.json",):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("structure", "default") == "default":
+                traffic, traffic_src = tj.get("bytes_per_launch", {}), "profiles/" + name
+            break
     for k, ent in kernels.items():
         if k in traffic:
             ent["traffic_bytes_pmc"] = traffic[k]
-    dominant = max(per_kernel_us, key=per_kernel_us.get)
-    dom_us = fps_us if dominant == "fps" else per_kernel_us[dominant]
-    achieved = ab.get(dominant, 0) / dom_us * 1e-3
     step_s = elapsed / args.steps
     step_flops, step_bytes = STEP_FLOPS_PER_CLOUD * B_PER_GPU, STEP_BYTES_PER_CLOUD * B_PER_GPU
-    roofline = {
-        "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-        "traffic": traffic.get(dominant) if m.index_batch == 1 else None,
+    # The dominant kernel = the largest TOTAL time per step on the stream that bounds `value`.  With the index
+    # stage on its own stream (one sampler launch per `index_batch` steps) that is the MLP stream; its kernels
+    # launch once per step, so total = average launch duration.  Without the pipeline everything is one stream and
+    # the index kernels count with their per-step share.
+    index_names = {"fps", "ball_query", "fps+ball_query", "sa_point_geo"}
+    per_step_us = {k: (us / m.index_batch if k in index_names else us) for k, us in per_kernel_us.items()}
+    cand = {k: v for k, v in per_step_us.items() if not (pipelined and k in index_names)}
+    dominant = max(cand, key=cand.get)
+    dom_us = per_kernel_us[dominant]
+    split = 3 if args.mlp.endswith("x3") else 1
+    # SURVEY 8d per-cloud MLP flops, by pass: conv1 2*35*32 and conv2 2*32*64 per position forward; the backward pass
+    # re-runs conv1 in both orientations 2*(2*35*32), dL/da1 = a1*Qm (2*32*32) + sparse*W2^T (2*64*32) and the Gram
+    # product a1^T a1 (2*32*32) per position (after the Gram reformulation of dL/dW2: DESIGN.md section 4).
+    pos = B_PER_GPU * NPOINT * NSAMPLE
+    mfma_flops = {"sa_fwd_main": pos * (2 * 35 * 32 + 2 * 32 * 64),
+                  "sa_bwd_main": pos * (2 * 2 * 35 * 32 + 2 * 2 * 32 * 32 + 2 * 64 * 32)}
+    if dominant in mfma_flops:
+        tf = mfma_flops[dominant] / dom_us * 1e-6
+        roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 5),
+                    "algorithmic_flops_per_launch": mfma_flops[dominant],
+                    "algorithmic_bytes_per_launch": ab.get(dominant),
+                    "note": (f"algorithmic flops of the 32 clouds of one launch (every product is issued as {split} bf16 "
+                             f"MFMA(s): MFMA issue = {split} x this fraction) over the kernel's average launch duration, "
+                             "HIP events on its launch stream in an eager pass of the same launches right after the "
+                             "timed region; the kernel is bound by per-tile latency (one wave per SIMD at ~250 VGPRs), "
+                             "not by MFMA issue or HBM (DESIGN.md section 5)")}
+    else:
+        gb = ab.get(dominant, 0) / dom_us * 1e-3
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(gb, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gb / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": ab.get(dominant)}
+    roofline.update({
         "avg_launch_us": round(dom_us, 2),
-        "note": ("FPS is a serial chain of npoint-1 dependent arg-max steps, one workgroup per cloud; its "
-                 "bound is per-step latency, not HBM or MFMA (DESIGN.md): fps_step_ns = avg launch / "
-                 "(npoint-1) is the figure of merit, `step` below the whole step against both peaks."),
-        "fps_step_ns": round(fps_us * 1e3 / (NPOINT - 1), 1),
-        "fps_clouds_per_launch": fps_clouds,
-        "fps_us_per_batch": round(fps_us / m.index_batch, 2),
+        "traffic": traffic.get(dominant), "traffic_source": traffic_src if dominant in traffic else None,
         # the whole step (one batch of 32 clouds through FPS, ball query, fused forward and backward)
         # against the two peaks: SURVEY 8d's per-cloud figures x 32 over the measured step time
         "step": {"flops": step_flops, "bytes": step_bytes,
                  "frac_mfma": round(step_flops / step_s / (MFMA_BF16_PEAK_TFLOPS * 1e12), 5),
                  "frac_hbm": round(step_bytes / step_s / (HBM_PEAK_GBS * 1e9), 5)},
+        # FPS is a serial chain of npoint-1 dependent arg-max steps, one workgroup per cloud: bound by per-step
+        # latency, neither HBM nor MFMA; it runs on the index stream
+        "index_stream": {"fps_step_ns": round(fps_us * 1e3 / (NPOINT - 1), 1), "fps_clouds_per_launch": fps_clouds,
+                         "fps_us_per_batch": round(fps_us / m.index_batch, 2)},
         "kernels": kernels,
-    }
-    if fused_mlp and "sa_bwd_main" in per_kernel_us:
-        # The sampler is the longest launch but runs beside the MLP stream, which is the stream
-        # that bounds `value`; that stream's longest kernel is the backward pass (MFMA chain).
-        # Algorithmic flops per position: conv1 in both orientations 2*(2*35*32), dL/da1 =
-        # a1*Qm (2*32*32) + sparse*W2^T (2*64*32), the Gram product a1^T a1 (2*32*32).
-        flops = B_PER_GPU * NPOINT * NSAMPLE * (2 * 2 * 35 * 32 + 2 * 2 * 32 * 32 + 2 * 64 * 32)
-        us = per_kernel_us["sa_bwd_main"]
-        tf = flops / us * 1e-6
-        split = 3 if args.mlp.endswith("x3") else 1
-        roofline["critical_stream_kernel"] = {
-            "kernel": "sa_bwd_main", "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "avg_launch_us": round(us, 2),
-            "algorithmic_flops": flops,
-            "note": (f"every product issued as {split} bf16 MFMA(s): MFMA issue = {split} x this fraction; "
-                     "the kernel is VALU-issue bound (operand splitting, BN/ReLU, scatter), "
-                     "profiles/r01_pmc_sq_summary.csv")}
+    })
 
     from adaptpoint_amd import set_abstraction as _sa
     result = {
@@ -604,6 +634,9 @@ def main():
         "value": round(value, 2), "unit": "point-clouds/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+        "timed_blocks": len(m.blocks),       # blocks of `steps` steps, each fenced on both sides; median reported
+        "ms_per_step_min": round(1e3 * min(m.blocks) / args.steps, 4),
+        "ms_per_step_max": round(1e3 * max(m.blocks) / args.steps, 4),
         "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if fused_mlp else "f32", "data": "synthetic",
         "config": {"workload": "PointNeXt-S stage-1 SetAbstraction fwd+bwd, B=32/GPU N=1024 "
@@ -613,9 +646,9 @@ def main():
                    "seed": args.seed,
                    "mlp": ({"fused-bf16x3": "fused bf16 MFMA on split hi+lo operands (3 MFMAs per product, "
                                             "f32 accumulate; forward within 7e-5 of an fp32 chain), "
-                                            "f32 BatchNorm statistics summed in f64",
+                                            "f32 BatchNorm partial sums added exactly (integer accumulators) or in f64",
                             "fused-bf16": "fused bf16 MFMA (operands rounded to bf16, f32 accumulate), "
-                                          "f32 BatchNorm statistics summed in f64",
+                                          "f32 BatchNorm partial sums added exactly (integer accumulators) or in f64",
                             "torch-f32": "unfused: extension ops + PyTorch fp32 conv/BN"}[args.mlp]),
                    "kernels": args.kernels,
                    "tile_map": ("forward passes over the index stage's distinct-hit tile map (ball-query fill copies "
@@ -624,7 +657,9 @@ def main():
                                 ("all passes over the distinct-hit tile map; per-point sums through its inverse map "
                                  "(no float atomics: gradients bit-reproducible)" if fused_mlp else "none")),
                    "launch": (f"hipGraph replay, {spg} step(s) per graph" if use_graph else "eager"),
-                   "pipeline": (f"index stages (FPS + ball query + tile map) of the NEXT launch's batches on a second stream, "
+                   "launches_per_step": ("3 forward + 4 backward on the MLP stream (BatchNorm folds and per-channel "
+                                         "constants are prologues of their consumer kernels)" if fused_mlp and args.kernels == "resident" else None),
+                   "pipeline": (f"index stages (FPS + ball query + occurrence statistics + tile map) of the NEXT launch's batches on a second stream, "
                                 f"{m.index_batch} batch(es) per sampler launch, beside the MLP fwd+bwd of the "
                                 "current batch(es); the two streams meet once per launch" if pipelined else "none"),
                    "global_batch": B_PER_GPU * world,

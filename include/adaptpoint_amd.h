@@ -125,11 +125,14 @@ APN_API int apn_three_interpolate_grad(int b, int c, int n, int m, const float *
  * nsample = 32; anything else returns APN_EINVAL and callers use the unfused ops.
  *   xyz (B,N,3) f32, new_xyz (B,M,3) f32, ft (B,N,32) bf16 point-major copy of the
  *   features, idx (B,M,32) i32, w1 (32,35) f32 with columns [dp(3), f(32)],
- *   w2 (64,32) f32.  Per-channel statistics leave the pass kernels as one partial
- *   row per workgroup ("part", rows = apn_sa_grid_blocks(b, m)); the small consumer
- *   kernels sum the rows in float64, or take already reduced (e.g. all-reduced)
- *   float64 sums instead when part == NULL.  dL/dW2, G and gip are float atomic adds
- *   into caller-zeroed buffers.
+ *   w2 (64,32) f32.  Per-channel sums cross workgroups WITHOUT fold launches: BatchNorm-1's statistics
+ *   leave apn_sa_prep_stats as a few dozen partial rows that every workgroup of the next launch sums itself;
+ *   every other per-channel sum goes through an ACCUMULATOR SET -- apn_sa_acc_words(ncol) unsigned 64-bit
+ *   words, zeroed by an earlier launch, added to with integer atomics on a two-limb fixed-point value
+ *   (csrc/apn_common.h: order-independent, the same bits every run) -- which the consumer kernel reads in
+ *   its prologue; with reduced (e.g. all-reduced) float64 sums `sums*` the consumers take those instead.
+ *   Weight gradients leave their producers as partial rows summed in float64 by apn_sa_bwd_finalize; G and
+ *   gip are float atomic adds into zeroed buffers.
  *   "pack" = {scale, shift, mean, invstd}[C] of a BatchNorm folded to y*scale+shift.
  * Everything below only enqueues kernels (graph-capturable).
  * ------------------------------------------------------------------------ */
@@ -144,160 +147,159 @@ APN_API int apn_furthest_point_sampling_xyz(int b, int n, int m, const float *xy
 APN_API int apn_ball_query_zero(int b, int n, int m, float radius, int nsample,
                                 const float *new_xyz, const float *xyz, int *idx, void *stream);
 
-/* Workgroups (= partial rows) the fused passes launch for B clouds x M queries. */
+/* Workgroups the fused passes launch for B clouds x M queries (without / with a tile map). */
 APN_API int apn_sa_grid_blocks(int b, int m);
-/* ... and with a tile map (apn_sa_wide_tilemap) behind the two forward passes: their partial rows then */
 APN_API int apn_sa_grid_rows(int b, int m, int with_tile_map);
-/* copies of the backward pass's dL/dW2 accumulators: gw2_acc is copies x 64*32 floats, gram_acc copies x
- * (32*32 + 32); workgroup b adds into copy b % copies (same-address float atomics of 448 workgroups on one set
- * cost the pass 9 us), apn_sa_bwd_consts2 clears them, apn_sa_bwd_consts1 adds them up into g_w2 */
-APN_API int apn_sa_bwd_acc_copies(void);
-/* rows of the backward pass's partial sums (partT) */
+/* workgroups (= partial rows partW2) of the backward pass */
 APN_API int apn_sa_bwd_main_rows(int b, int m);
+/* unsigned 64-bit words of an accumulator set of ncol columns */
+APN_API int apn_sa_acc_words(int ncol);
+/* 16-byte granular zero fill by a kernel (graph-capturable) */
+APN_API int apn_zero_fill(void *base, long long bytes, void *stream);
 
 /* `precision` (every function that takes ft): 1 = operands rounded to bf16; 2 = operands split
  * into hi + lo bf16 parts, each product three MFMAs (hi*hi + hi*lo + lo*hi, "bf16x3"): fp32-grade
  * results (~1e-5) at 3x the (small) MFMA cost.  ft then holds `precision` tables of (B,N,32)
  * bf16 back to back: [hi] or [hi][lo]. */
 
-/* f (B,C,N) f32 -> ft (C must be 32). */
-APN_API int apn_sa_prep_features(int b, int c, int n, const float *f, void *ft, int precision,
-                                 void *stream);
+/* Index stage, last piece (csrc/sa_geo.hip): occurrence statistics of the neighbourhoods.  For every support
+ * point n: geo[b][n] = {occ, Dx, Dy, Dz} as four int64 -- the number of positions (query, slot) with
+ * idx == n and the sum over them of d = (xyz[n] - new_xyz[query]) / radius (group.py:250-253) in units of
+ * 2^-36 (integer sums: reproducible); dd[b][apn_sa_geo_dd_doubles(n)] (float64) = the cloud's shares of
+ * sum d d^T over its positions, six values {xx, xy, xz, yy, yz, zz} per slab of 2048 points.  One launch, LDS
+ * accumulation, nothing to clear; nsample must be 32. */
+APN_API int apn_sa_geo_dd_doubles(int n);
+APN_API int apn_sa_point_geo(int b, int n, int m, int nsample, float radius, const float *xyz,
+                             const float *new_xyz, const int *idx, void *geo, void *dd, void *stream);
 
-/* Forward pass 1: part[rows][64] = {sum, sumsq}[32] of y1 = conv1(cat(dp, f[idx])). */
-APN_API int apn_sa_fwd_stats1(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                              int precision, float radius, const float *xyz, const float *new_xyz,
-                              const void *ft, const int *idx, const int *tmap, const float *w1, float *part,
+/* Forward launch 1 of 3: f (B,32,N) f32 -> ft, and (stats != 0) BatchNorm-1's batch statistics WITHOUT a pass
+ * over the positions: part1[apn_sa_prep_rows(b, n)][64] = {sum, sumsq}[32] of y1 = conv1(cat(dp, f[idx])) from geo / dd
+ * (y1 is affine in per-point and per-position terms; operands as the MFMA sees them).  Also clears `zero_words`
+ * 64-bit words at `zero` (the accumulator set of the next launch). */
+APN_API int apn_sa_prep_rows(int b, int n);
+APN_API int apn_sa_prep_stats(int b, int n, const float *f, const void *geo, const void *dd, const float *w1,
+                              int precision, int stats, void *ft, float *part1, void *zero, long long zero_words,
                               void *stream);
 
-/* out[0..ncol) = float64 column sums of part[rows][ncol] (ncol <= 128, a power of two);
- * out[ncol] = count (this rank's positions), out[ncol + 1] = 1.  The SyncBatchNorm path reduces,
- * all-reduces the ncol + 2 values over ranks (sums, GLOBAL count, world size), then calls the
- * consumer with part == NULL: apn_sa_bn_fold / apn_sa_bwd_consts2 / apn_sa_bwd_consts1 then take
- * the count from the reduced vector (their `count` argument is ignored) and report dL/dgamma,
- * dL/dbeta as global sum / world (what SyncBatchNorm + DistributedDataParallel leave in .grad). */
+/* out[0..ncol) = float64 column sums of part[rows][ncol] (ncol <= 128, a power of two) /
+ * the totals of an accumulator set; out[ncol] = count (this rank's positions), out[ncol + 1] = 1.
+ * The SyncBatchNorm path reduces, all-reduces the ncol + 2 values over ranks (sums, GLOBAL count, world size),
+ * then calls the consumer with `sums`: it takes the count from the reduced vector (its `count` argument is
+ * ignored) and dL/dgamma, dL/dbeta are reported as global sum / world (what SyncBatchNorm +
+ * DistributedDataParallel leave in .grad). */
 APN_API int apn_sa_reduce_rows(const float *part, int rows, int ncol, double count, double *out,
                                void *stream);
+APN_API int apn_sa_reduce_acc(const void *acc, int ncol, double count, double *out, void *stream);
 
-/* BatchNorm fold: {sum, sumsq}[C] over `count` positions (part[rows][2C], or sums[2C] when
- * part == NULL) -> pack[4][C]; updates the running buffers / num_batches_tracked when
- * training (torch.nn.BatchNorm semantics); uses the running buffers when not training.
- * Rider: sgn_out[i] = sign(sgn_gamma[i]), i < sgn_c.  C a multiple of 4, <= 1024. */
+/* BatchNorm fold as a launch of its own (the width-generic family, csrc/sa_wide*.hip): {sum, sumsq}[C] over
+ * `count` positions (part[rows][2C], or sums[2C] when part == NULL) -> pack[4][C]; updates the running
+ * buffers / num_batches_tracked when training (torch.nn.BatchNorm semantics); uses the running buffers when
+ * not training.  Rider: sgn_out[i] = sign(sgn_gamma[i]), i < sgn_c.  C a multiple of 4, <= 1024. */
 APN_API int apn_sa_bn_fold(const float *part, int rows, const double *sums, int c, double count,
                            const float *gamma, const float *beta, float eps, float momentum,
                            float *running_mean, float *running_var, void *num_batches_tracked,
                            int training, float *pack, const float *sgn_gamma, int sgn_c,
                            float *sgn_out, void *stream);
 
-/* Forward pass 2: a1 = relu(y1*scale1+shift1); y2 = conv2(a1);
- * ysel/ksel (B,M,64): per (query, channel) the extreme of y2 over the K neighbours
- * (max where sgn2 = +1, min where sgn2 = -1) and the neighbour slot holding it;
- * part[rows][128] = {sum[64], sumsq[64]} of y2. */
-APN_API int apn_sa_fwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                            int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                            const int *idx, const int *tmap, const float *w1, const float *w2,
-                            const float *scale1, const float *shift1, const float *sgn2,
-                            float *ysel, void *ksel, float *part, void *stream);
+/* Forward launch 2 of 3.  Prologue: BatchNorm-1 (g1, b1, running buffers, eps, momentum, training flag; `count`
+ * positions) folded from part1[rows1][64] -- or from sums1 -- by every workgroup (workgroup 0 writes pack1
+ * [4][32] and updates the running buffers).  Then a1 = relu(bn1(y1)); y2 = conv2(a1);
+ * ysel/ksel (B,M,64): per (query, channel) the extreme of y2 over the K neighbours (max where gamma2 >= 0,
+ * min otherwise) and the neighbour slot holding it; acc2 (accumulator set, 128 columns, zeroed by
+ * apn_sa_prep_stats) += {sum[64], sumsq[64]} of y2. */
+APN_API int apn_sa_fwd_main(int b, int n, int m, int precision, float radius, const float *xyz,
+                            const float *new_xyz, const void *ft, const int *idx, const int *tmap, const float *w1,
+                            const float *w2, const float *g1, const float *b1, float *rm1, float *rv1, void *nbt1,
+                            float eps1, float mom1, int train1, double count, const float *part1, int rows1,
+                            const double *sums1, float *pack1, const float *gamma2, float *ysel, void *ksel,
+                            void *acc2, void *stream);
 
-/* (zero_base, zero_floats: optional region -- the backward's atomically accumulated A | geo | gip -- cleared by
- * this launch, the forward's last, so that apn_sa_backward_seq(zero_bytes = 0) needs no fill launch)
+/* Forward launch 3 of 3.  Prologue: BatchNorm-2 folded from acc2 (or sums2) by every workgroup (the first
+ * writes pack2 [4][64] and updates the running buffers).
  * out (B,64,M) = act(ysel*scale2 + shift2 + Ws f[:, fidx] + bs); ws/bs/ft/fidx may be null
- * (no skip branch), relu = 0/1.  f is read from the point-major table(s) ft; fidx (B,M),
- * ws (64,32), bs (64). */
-APN_API int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const float *pack2,
-                           const void *ft, int precision, const int *fidx, const float *ws,
-                           const float *bs, int relu, float *out, float *zero_base, long long zero_floats,
-                           void *stream);
+ * (no skip branch), relu = 0/1.  f is read from the point-major table(s) ft; fidx (B,M), ws (64,32), bs (64).
+ * (zero_base, zero_floats: optional region -- the backward's atomically accumulated A | gip | accS | accT --
+ * cleared by this launch, the forward's last, so that apn_sa_backward_seq(zero_bytes = 0) needs no fill launch) */
+APN_API int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const void *acc2, const double *sums2,
+                           const float *g2, const float *b2, float *rm2, float *rv2, void *nbt2, float eps2,
+                           float mom2, int train2, double count, float *pack2, const void *ft, int precision,
+                           const int *fidx, const float *ws, const float *bs, int relu, float *out,
+                           float *zero_base, long long zero_floats, void *stream);
 
-/* Backward entry: g = g_out * [out > 0] (relu) ; goa (B,M,64) = g * scale2;
+/* Backward launch 1 of 4: g = g_out * [out > 0] (relu) ; goa (B,M,64) = g * scale2;
  * g_out (B,64,M) is read with element strides (gs_b, gs_c, gs_m) -- a broadcast upstream
  * gradient (stride 0, e.g. from loss = out.sum()) needs no materialised copy;
- * partS[rows][128] = {sum g, sum g*yhat_sel} per block of 64 queries
- * (rows = apn_sa_bwd_prep_rows(b, m)); with the skip branch partWs[rows][64*32] = dL/dWs
- * per block and gip (B,N,32) += Ws^T g at the sampled points (caller-zeroed). */
+ * accS (accumulator set, 128 columns, zeroed) += {S1 = sum g, S2 = sum g*yhat_sel}[64]; with the skip branch
+ * partWs[apn_sa_bwd_prep_rows(b, m)][64*32] = dL/dWs per block of 64 queries and gip (B,N,32) += Ws^T g at the
+ * sampled points (zeroed). */
 APN_API int apn_sa_bwd_prep_rows(int b, int m);
 APN_API int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long long gs_b,
                             long long gs_c, long long gs_m, const float *out, int relu,
                             const float *ysel, const float *pack2, const void *ft, int precision,
-                            const int *fidx, const float *ws, float *goa, float *partS,
+                            const int *fidx, const float *ws, float *goa, void *accS,
                             float *partWs, float *gip, void *stream);
 
-/* Constants of dL/dy2 = goa*[pos==ksel] + y2*D2 + E2: d2e2 [2][64], qm (32,32) =
- * W2^T diag(D2) W2, evec [32] = E2 W2; g_gamma2 = S2, g_beta2 = S1.  Optional zero_w2
- * [64*32] and zero_gram [32*32 + 32] are cleared (accumulators of the backward pass that follows). */
-APN_API int apn_sa_bwd_consts2(const float *partS, int rows, const double *S, const float *pack2,
-                               const float *w2, double count, int training, float *d2e2,
-                               float *qm, float *evec, float *g_gamma2, float *g_beta2,
-                               float *zero_w2, float *zero_gram, void *stream);
+/* Backward launch 2 of 4: the pass over the positions.  Prologue (every workgroup): the constants of
+ * dL/dy2 = goa*[pos==ksel] + y2*D2 + E2 from accS (or sumsS) and pack2, Qm = W2^T diag(D2) W2, evec = E2 W2.
+ * accT (accumulator set, 64 columns, zeroed) += {sum g_u, sum g_u*yhat1}[32] (g_u = dL/da1 * [a1 > 0]);
+ * partW2[apn_sa_bwd_main_rows(b, m)][64*32] = the workgroup's share of dL/dW2 (sparse arg-max part +
+ * D2 (W2 Gram) + E2 (x) sum a1);  A (B,N,32) += g_u summed per source point (zeroed, float atomics);
+ * HA, HB (B,M,32) = g_u and yhat1 summed per query.  pack1 = BN1's [4][32] of the forward. */
+APN_API int apn_sa_bwd_main(int b, int n, int m, int precision, float radius, const float *xyz,
+                            const float *new_xyz, const void *ft, const int *idx, const int *tmap, const float *w1,
+                            const float *w2, const float *pack1, const float *pack2, const void *accS,
+                            const double *sumsS, double count, int train2, const float *goa, const void *ksel,
+                            void *accT, float *partW2, float *A, float *HA, float *HB, void *stream);
 
-/* The backward pass over the positions -> part[apn_sa_bwd_main_rows(b, m)][64] =
- *   {sum g_u, sum g_u*yhat1}[32] (g_u = dL/da1 * [a1 > 0]); the ingredients of dL/dW2:
- *   gw2_acc[64*32] += its sparse (arg-max) part, gram_acc[0..1023] += sum a1^T a1,
- *   gram_acc[1024..1055] += sum a1 (apn_sa_bwd_consts1 assembles dL/dW2 from them);
- *   A (B,N,32) += g_u summed per source point, geo (B,N,4) += {count, sum of relative
- *   positions} of each point's occurrences (both caller-zeroed, float atomics);
- *   HA, HB (B,M,32) = g_u and yhat1 summed per query.  bn1 = pack1 [4][32]. */
-APN_API int apn_sa_bwd_main(int b, int n, int m, int c_in, int c_mid, int c_out, int nsample,
-                            int precision, float radius, const float *xyz, const float *new_xyz, const void *ft,
-                            const int *idx, const int *tmap, const float *w1, const float *w2, const float *bn1,
-                            const float *qm, const float *evec, const float *goa,
-                            const void *ksel, float *part, float *gw2_acc, float *gram_acc,
-                            float *A, float *geo, float *HA, float *HB, void *stream);
-
-/* cabc [3][32]: dL/dy1 = g_u*ca + yhat1*cb + cc ; g_gamma1 = T2, g_beta1 = T1.  With g_w2:
- * g_w2 (64,32) += D2 (W2 Gram) + E2 suma, i.e. dL/dW2 completed from the backward pass's
- * accumulators (d2e2 from apn_sa_bwd_consts2). */
-APN_API int apn_sa_bwd_consts1(const float *partT, int rows, const double *T, const float *pack1,
-                               double count, int training, float *cabc, float *g_gamma1,
-                               float *g_beta1, const float *w2, const float *d2e2,
-                               const float *gram, const float *gw2_acc, float *g_w2, void *stream);
-
-/* dL/dy1 = g_u*ca + yhat1*cb + cc summed per source point (G) and per query (H), formed from
- * A, geo, HA, HB and the batch constants, and everything linear in them, one workgroup per
- * 64-point tile: g_f (B,32,N) = G W1[:,3:] (+ gip); optional g_p (B,N,3) += G W1[:,:3]/r and
- * g_newp (B,M,3) = -H W1[:,:3]/r; partW[apn_sa_bwd_weight_rows(b, n)][32*38] = per-block
- * products for dL/dW1 (sa_glue.hip).  pack1 = BN1's {scale, shift, mean, invstd}[32]. */
+/* Backward launch 3 of 4.  Prologue: the batch constants of dL/dy1 = g_u*ca + yhat1*cb + cc from accT (or sumsT).
+ * dL/dy1 summed per source point (G) and per query (H), formed from A, geo (apn_sa_point_geo), HA, HB, and
+ * everything linear in them, one workgroup per 64-point tile: g_f (B,32,N) = G W1[:,3:] (+ gip); optional
+ * g_p (B,N,3) += G W1[:,:3]/r and g_newp (B,M,3) = -H W1[:,:3]/r; partW[apn_sa_bwd_weight_rows(b, n)][32*38] =
+ * per-block products for dL/dW1 (sa_glue.hip). */
 APN_API int apn_sa_bwd_weight_rows(int b, int n);
-APN_API int apn_sa_bwd_point_grads(int b, int n, int m, const float *A, const float *geo,
-                                   const float *HA, const float *HB, const float *cabc,
-                                   const float *pack1, const void *ft, int precision,
+APN_API int apn_sa_bwd_point_grads(int b, int n, int m, const float *A, const void *geo,
+                                   const float *HA, const float *HB, const void *accT, const double *sumsT,
+                                   double count, int train1, const float *pack1, const void *ft, int precision,
                                    const float *xyz, const float *new_xyz, const float *w1,
                                    const float *gip, float radius, float *partW, float *g_f,
                                    float *g_p, float *g_newp, void *stream);
 
-/* Column sums in float64 -> g_w1 (32,35) from partW; optional g_ws (64,32) from partWs and
- * g_bs [64] from partS (rows_s rows each). */
+/* Backward launch 4 of 4: column sums in float64 -> g_w1 (32,35) from partW, g_w2 (64,32) from partW2, optional
+ * g_ws (64,32) from partWs; g_bs [64] = S1 of this rank (accS); g_b2 / g_g2 = S1 / S2 and g_b1 / g_g1 = T1 / T2
+ * from the accumulator sets or, with reduced sums, global / world.  Any gradient pointer may be null. */
 APN_API int apn_sa_bwd_finalize(const float *partW, int rows_w, float radius, float *g_w1,
-                                const float *partWs, int rows_s, float *g_ws,
-                                const float *partS, float *g_bs, void *stream);
+                                const float *partWs, int rows_s, float *g_ws, const float *partW2, int rows_2,
+                                float *g_w2, const void *accS, const double *sumsS,
+                                const void *accT, const double *sumsT, float *g_bs, float *g_g2, float *g_b2,
+                                float *g_g1, float *g_b1, void *stream);
 
 /* Whole-direction launch sequences (csrc/sa_seq.hip): the same kernels as above, enqueued
  * back-to-back by ONE call so that an eager step stays GPU-bound.  `phases` (bit mask
  * 1|2|4) selects the part to enqueue, so a caller can all-reduce the BatchNorm sums between
- * phases (SyncBatchNorm): forward 1 = prep+stats1, 2 = fold1+main, 4 = fold2+out; backward
- * 1 = zero+prep, 2 = consts2+pass1, 4 = consts1+pass2+input/weight grads+finalize.
- * sums* (float64, reduced over ranks) replace the partial rows when non-NULL. */
+ * phases (SyncBatchNorm): forward 1 = prep + BatchNorm-1 sums, 2 = main pass, 4 = output; backward
+ * 1 = (zero +) entry, 2 = main pass, 4 = point gradients + finalize.
+ * sums* (float64, reduced over ranks) replace the partial rows / accumulator sets when non-NULL. */
 APN_API int apn_sa_forward_seq(
     int phases, int precision, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
-    const float *f, const int *idx, const int *tmap, const int *fidx, const float *w1, const float *w2,
-    const float *ws, const float *bs,
+    const float *f, const int *idx, const int *tmap, const int *fidx, const void *geo, const void *dd,
+    const float *w1, const float *w2, const float *ws, const float *bs,
     const float *g1, const float *b1, float *rm1, float *rv1, void *nbt1, float eps1, float mom1,
     int train1,
     const float *g2, const float *b2, float *rm2, float *rv2, void *nbt2, float eps2, float mom2,
     int train2,
-    double count, int relu, void *ft, float *part1, float *part2, const double *sums1,
-    const double *sums2, float *pack1, float *pack2, float *sgn2, float *ysel, void *ksel,
+    double count, int relu, void *ft, float *part1, const double *sums1, const double *sums2,
+    float *pack1, float *pack2, void *acc2, float *ysel, void *ksel,
     float *out, float *zero_base, long long zero_floats, void *stream);
 APN_API int apn_sa_backward_seq(
     int phases, int precision, int b, int n, int m, float radius, const float *xyz, const float *new_xyz,
-    const float *f, const int *idx, const int *tmap, const int *fidx, const float *w1, const float *w2,
+    const int *idx, const int *tmap, const int *fidx, const void *geo, const float *w1, const float *w2,
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
-    float *zero_base, size_t zero_bytes, float *g_w2, float *gw2_acc, float *gram, float *A, float *geo, float *gip,
-    float *goa, float *partS, float *partWs, float *partT, float *partW, const double *sumsS,
-    const double *sumsT, float *d2e2, float *qm, float *evec, float *cabc, float *HA, float *HB,
-    float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_g1, float *g_b1, float *g_g2,
+    void *zero_base, long long zero_bytes, float *A, float *gip, void *accS, void *accT,
+    float *goa, float *partWs, float *partW2, float *partW, const double *sumsS, const double *sumsT,
+    float *HA, float *HB,
+    float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_w2, float *g_g1, float *g_b1, float *g_g2,
     float *g_b2, float *g_ws, float *g_bs, void *stream);
 /* Index stages of consecutive batches, overlapped: FPS (+ sampled coordinates) of batch A and,
  * in the SAME launch, the zero-filling ball query of batch B, whose new_xyz_b an earlier call
@@ -307,10 +309,11 @@ APN_API int apn_sa_sample_overlap(int b, int n, int m, float radius, int nsample
                                   const float *xyz_a, int *fidx_a, float *new_xyz_a,
                                   const float *xyz_b, const float *new_xyz_b, int *idx_b,
                                   void *stream);
-/* Index stage: temp := 1e10, FPS (+ sampled coordinates), ball query (zero-filling).
- * temp may be NULL (no min-distances kept). */
+/* Index stage: temp := 1e10, FPS (+ sampled coordinates), ball query (zero-filling) and, with geo != NULL,
+ * apn_sa_point_geo.  temp may be NULL (no min-distances kept). */
 APN_API int apn_sa_sample_seq(int b, int n, int m, float radius, int nsample, const float *xyz,
-                              float *temp, int *fidx, float *new_xyz, int *idx, void *stream);
+                              float *temp, int *fidx, float *new_xyz, int *idx, void *geo, void *dd,
+                              void *stream);
 
 /* ------------------------------------------------------------------------
  * the grouping stage of the imitator's PointsetGrouper

@@ -323,3 +323,31 @@ def inverse_map(tm, new_xyz, n_points, m):
             occ[gn] = occ.get(gn, 0) + mult
             sp[gn] = sp.get(gn, 0.0) + mult * new_xyz[q]
     return dict(lists=lists, occ=occ, sp=sp)
+
+
+def point_geo(xyz, new_xyz, idx, radius):
+    """Statement of the index stage's occurrence statistics (adaptpoint_amd/csrc/sa_geo.hip): for every support
+    point n, over the positions (query q, slot k) with idx[q][k] == n,
+        geo[b][n] = {count, sum of rint(d * 2^36)} with d = (xyz[n] - new_xyz[q]) / radius in float32
+    (the relative position of openpoints/models/layers/group.py:250-253) as four int64, and the second moments
+    dd[6] = sum over all positions of the batch of {dx dx, dx dy, dx dz, dy dy, dy dz, dz dz} in float64.
+    Integer sums: exact, independent of the order the positions are visited in."""
+    xyz = np.asarray(xyz, np.float32)
+    new_xyz = np.asarray(new_xyz, np.float32)
+    idx = np.asarray(idx, np.int64)
+    B, N, _ = xyz.shape
+    r = np.float32(radius)
+    geo = np.zeros((B, N, 4), np.int64)
+    dd = np.zeros(6, np.float64)
+    for b in range(B):
+        pts = xyz[b][idx[b]]                                  # (M, K, 3)
+        d = ((pts - new_xyz[b][:, None, :]) / r).astype(np.float32)
+        fixed = np.rint(d.astype(np.float64) * 68719476736.0).astype(np.int64)
+        flat = idx[b].reshape(-1)
+        np.add.at(geo[b, :, 0], flat, 1)
+        for j in range(3):
+            np.add.at(geo[b, :, 1 + j], flat, fixed[..., j].reshape(-1))
+        d64 = d.astype(np.float64).reshape(-1, 3)
+        dd += np.array([(d64[:, 0] * d64[:, 0]).sum(), (d64[:, 0] * d64[:, 1]).sum(), (d64[:, 0] * d64[:, 2]).sum(),
+                        (d64[:, 1] * d64[:, 1]).sum(), (d64[:, 1] * d64[:, 2]).sum(), (d64[:, 2] * d64[:, 2]).sum()])
+    return geo, dd

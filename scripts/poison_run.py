@@ -1,6 +1,6 @@
 """Diagnostic: run GPU tests with the allocator pool pre-filled with NaN, so that a kernel reading memory it (or a
 predecessor) never wrote shows up as NaN instead of depending on what the box last held.
-    python scripts/poison_test.py [pytest -k expression]"""
+    python scripts/poison_run.py [pytest -k expression]"""
 import sys, torch, pytest
 # poison the caching allocator's pool: every later torch.empty() sees NaN / huge ints instead of stale data
 import os

@@ -8,6 +8,11 @@ def _bf(x):
     return x.to(torch.bfloat16).to(torch.float64)
 
 
+def bf16_round(x):
+    """x rounded to bfloat16, returned in float32 (exactly representable)."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
 def group(t, idx):
     """t (B,C,N), idx (B,M,K) -> (B,C,M,K)  (== group_points)."""
     B, C, N = t.shape
@@ -25,8 +30,16 @@ def chain_grad(p, new_p, f, idx, radius, w1, g1, b1, w2, g2, b2, eps=1e-5, emula
     y1 = torch.einsum('oc,bcmk->bomk', rnd(w1), x)
     if y1_noise is not None:
         y1 = y1 + y1_noise
-    m1 = y1.mean((0, 2, 3), keepdim=True)
-    v1 = y1.var((0, 2, 3), unbiased=False, keepdim=True)
+    # BatchNorm-1's batch statistics as the kernels form them (round 3): per point from the index stage's
+    # occurrence statistics, i.e. over y1 with the relative positions NOT rounded to the operand precision
+    # (features and weights rounded as the MFMA sees them) -- identical to y1's own statistics in fp32 mode
+    ys = y1
+    if emulate_bf16:
+        ys = torch.einsum('oc,bcmk->bomk', rnd(w1), torch.cat([dp.double(), x[:, 3:]], 1))
+        if y1_noise is not None:
+            ys = ys + y1_noise
+    m1 = ys.mean((0, 2, 3), keepdim=True)
+    v1 = ys.var((0, 2, 3), unbiased=False, keepdim=True)
     a1 = torch.relu((y1 - m1) / torch.sqrt(v1 + eps) * g1.double().view(1, -1, 1, 1) + b1.double().view(1, -1, 1, 1))
     if emulate_bf16:
         a1 = _bf(a1.float())

@@ -3,6 +3,9 @@ Fixtures store outputs only; these functions regenerate the matching inputs."""
 import numpy as np
 import torch
 
+from adaptpoint_amd.synthetic import (seeded_normal, seeded_uniform, sphere_surface_cloud,  # noqa: F401
+                                      unit_sphere_cloud)
+
 
 def config1_xyz():
     """BASELINE.json configs[0]: torch.manual_seed(0); rand(2,1024,3)*2-1."""
@@ -10,35 +13,9 @@ def config1_xyz():
     return (torch.rand(2, 1024, 3, generator=g) * 2 - 1).numpy()
 
 
-def seeded_normal(shape, seed):
-    g = torch.Generator().manual_seed(seed)
-    return torch.randn(*shape, generator=g).numpy()
-
-
-def seeded_uniform(shape, seed):
-    g = torch.Generator().manual_seed(seed)
-    return (torch.rand(*shape, generator=g) * 2 - 1).numpy()
-
-
 def take_points(xyz, idx):
     """(B,N,3), (B,M) -> (B,M,3)"""
     return np.take_along_axis(xyz, idx[..., None].astype(np.int64).repeat(3, -1), 1).copy()
-
-
-def unit_sphere_cloud(b, n, seed):
-    """D1 of SURVEY.md section 8d: uniform cube, centred, scaled into the unit sphere
-    (the arithmetic of PointCloudCenterAndNormalize)."""
-    x = seeded_uniform((b, n, 3), seed).astype(np.float32)
-    x = x - x.mean(axis=1, keepdims=True)
-    m = np.sqrt((x ** 2).sum(-1, keepdims=True)).max(axis=1, keepdims=True)
-    return (x / m).astype(np.float32)
-
-
-def sphere_surface_cloud(b, n, seed):
-    """D2: unit-sphere surface + N(0, 0.01) jitter (scan-like)."""
-    x = seeded_normal((b, n, 3), seed).astype(np.float32)
-    x = x / np.sqrt((x ** 2).sum(-1, keepdims=True))
-    return (x + 0.01 * seeded_normal((b, n, 3), seed + 1000)).astype(np.float32)
 
 
 def three_nn_weights(dist2):

@@ -587,3 +587,77 @@ def test_register_resident_kernels_over_the_tile_map_equal_one_tile_per_query(ma
         assert rel(q1.grad, q2.grad) <= 2e-3, (n1, rel(q1.grad, q2.grad))
     for b1, b2 in zip(blk2.buffers(), blk.buffers()):
         assert torch.allclose(b1.float(), b2.float(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["ball", "random", "partial_fill"])
+def test_point_geo_equals_its_statement(dev, oracle, kind):
+    """The index stage's occurrence statistics (csrc/sa_geo.hip): counts and fixed-point sums of the relative
+    positions are INTEGERS -- bit-exact against the numpy statement for ball-query rows (fill run folded), random
+    rows and rows with a partial fill structure; the second moments to float64 rounding."""
+    from adaptpoint_amd import _lib, fused
+    B, N, M = 3, 1024, 500
+    p, new_p, f, idx, *_ = _setup(dev, B=B, seed=11)
+    new_p, idx = new_p[:, :M].contiguous(), idx[:, :M].contiguous()
+    g = torch.Generator().manual_seed(5)
+    if kind == "random":
+        idx = torch.randint(0, N, (B, M, 32), generator=g, dtype=torch.int32).to(dev)
+    elif kind == "partial_fill":
+        idx = idx.clone()
+        rnd = torch.randint(0, N, (B, M, 32), generator=g, dtype=torch.int32).to(dev)
+        idx[:, ::3, 5:9] = rnd[:, ::3, 5:9]            # breaks the fill structure of every third row
+        idx[:, 1::3, 3] = idx[:, 1::3, 0]              # slot 0 repeated in the middle of a row
+    geo, dd = fused.point_geo(p, new_p, idx, 0.15)
+    torch.cuda.synchronize()
+    sums = dd.view(B, -1, 6).sum((0, 1))
+    o_geo, o_dd = oracle.point_geo(p.cpu().numpy(), new_p.cpu().numpy(), idx.cpu().numpy(), 0.15)
+    assert np.array_equal(geo.cpu().numpy(), o_geo)
+    # (float32 partial sums per workgroup: the off-diagonal moments cancel to ~1e-3 of the diagonal ones)
+    np.testing.assert_allclose(sums[:6].cpu().numpy(), o_dd, rtol=1e-6, atol=1e-8 * float(np.abs(o_dd).max()))
+    # a second run gives the same bits (integer accumulation)
+    geo2, dd2 = fused.point_geo(p, new_p, idx, 0.15)
+    assert torch.equal(geo, geo2) and torch.equal(dd, dd2)
+    assert _lib.load().apn_sa_geo_dd_doubles(N) == dd.shape[1] == 6
+
+
+@pytest.mark.parametrize("prec", [2, 1])
+def test_per_point_statistics_equal_the_pass_over_the_positions(dev, prec):
+    """apn_sa_prep_stats: BatchNorm-1's batch sums from the occurrence statistics (no pass over the positions)
+    against sum / sum of squares of the materialised y1 = conv1(cat[dp, f[idx]]) in float64, operands rounded as
+    the MFMA sees them; and the operand table(s) it writes."""
+    from adaptpoint_amd import _lib, fused
+    from fused_reference import bf16_round
+    B, N, M = 4, 1024, 512
+    p, new_p, f, idx, conv1, *_ = _setup(dev, B=B, seed=2)
+    lib = _lib.load()
+    geo, dd = fused.point_geo(p, new_p, idx, 0.15)
+    rows = lib.apn_sa_prep_rows(B, N)
+    ft = torch.empty(prec * B * N * 32, dtype=torch.bfloat16, device=dev)
+    part = torch.zeros(rows, 64, device=dev)
+    acc = torch.ones(lib.apn_sa_acc_words(128), dtype=torch.int64, device=dev)
+    w1 = conv1.weight.detach().view(32, 35).contiguous()
+    fused._call("apn_sa_prep_stats", dev, B, N, f.data_ptr(), geo.data_ptr(), dd.data_ptr(), w1.data_ptr(), prec, 1,
+                ft.data_ptr(), part.data_ptr(), acc.data_ptr(), acc.numel())
+    torch.cuda.synchronize()
+    assert int(acc.abs().sum()) == 0                                   # the next launch's accumulator set is cleared
+
+    def eff(t):
+        hi = bf16_round(t)
+        return hi if prec == 1 else hi + bf16_round(t - hi)
+    ft_hi = ft[:B * N * 32].view(B, N, 32).float()
+    assert torch.equal(ft_hi, bf16_round(f.transpose(1, 2)))
+    if prec == 2:
+        assert torch.equal(ft[B * N * 32:].view(B, N, 32).float(), bf16_round(f.transpose(1, 2) - ft_hi))
+    li = idx.long()
+    fj = torch.gather(eff(f).double().unsqueeze(2).expand(-1, -1, M, -1), 3, li.unsqueeze(1).expand(-1, 32, -1, -1))
+    pj = torch.gather(p.unsqueeze(1).expand(-1, M, -1, -1), 2, li.unsqueeze(-1).expand(-1, -1, -1, 3))
+    d = ((pj - new_p.unsqueeze(2)) / 0.15).permute(0, 3, 1, 2).double()                  # (B,3,M,K), unrounded: see below
+    y1 = torch.einsum("oc,bcmk->bomk", eff(w1).double(), torch.cat([d, fj], 1))
+    got = part.double().sum(0)
+    s1, s2 = y1.sum((0, 2, 3)), (y1 * y1).sum((0, 2, 3))
+    # the kernel sums the exact relative positions (2^-36 fixed point) where the MFMA rounds each to the operand
+    # precision: a 2^-17 (split) / 2^-9 (bf16) relative perturbation of three of the 35 inputs, random in sign
+    tol = 2e-6 if prec == 2 else 2e-4
+    e1 = float(((got[:32] - s1).abs() / s2.sqrt().clamp_min(1e-9) / (B * M * 32) ** 0.5).max())
+    e2 = float(((got[32:] - s2).abs() / s2).max())
+    print("per-point statistics: sum %.2e (of sigma sqrt(P)), sumsq %.2e relative" % (e1, e2))
+    assert e1 <= tol and e2 <= tol
