@@ -45,6 +45,7 @@
 // Roofline: compulsory HBM traffic of pass 2 at B=32 is xyz 0.4 + idx 2.1 + ft 2.1
 // + out 2 x 4.2 MB ~ 13 MB (1.6 us at 8 TB/s); bf16 MFMA work 7 x 32 cycles per tile.
 // Both are far below the per-tile VALU/gather latency, which is what bounds it.
+#include <stdlib.h>
 #include "apn_common.h"
 #include "apn_mfma.h"
 #include "sa_chain.h"
@@ -616,6 +617,7 @@ struct SaBwdArgs {
     int train2;
     const float *goa;       // (B,M,64)
     const unsigned char *ksel;  // (B,M,64)
+    int knock;              // EXPERIMENT
 };
 
 // Backward launch 2 of 4.  Prologue (every workgroup, same bits): the per-channel constants of
@@ -651,9 +653,12 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     // wave-private LDS image of the sparse operand: [hi | lo] tiles of 32 rows x 72 bf16
     // (64 channels + 8 pad: 144-byte rows keep the 16-byte fragment reads conflict-free)
     constexpr int SP_ROW = 72, SP_TILE = 32 * SP_ROW;
-    constexpr int SP_BYTES = SA_WAVES * NS * SP_TILE * 2, WRED_BYTES = SA_WAVES * SA_C2 * SA_C1 * 4;
+    // (tile map: the region also holds two [32][33] float tiles between the image's uses)
+    constexpr int SP_WAVE = (CP && NS * SP_TILE * 2 < 2 * 32 * 33 * 4) ? 2 * 32 * 33 * 4 : NS * SP_TILE * 2;   // bytes
+    constexpr int SP_BYTES = SA_WAVES * SP_WAVE, WRED_BYTES = SA_WAVES * SA_C2 * SA_C1 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char sp_raw[SP_BYTES > WRED_BYTES ? SP_BYTES : WRED_BYTES];
-    __bf16 *sp_img = reinterpret_cast<__bf16 *>(sp_raw) + wave * NS * SP_TILE;
+    __shared__ __attribute__((aligned(16))) unsigned sinfo[SA_WAVES][32];
+    __bf16 *sp_img = reinterpret_cast<__bf16 *>(sp_raw + wave * SP_WAVE);
 
     auto prologue = [&]() {
         const int tid = threadIdx.x;
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             for (int k = 0; k < 8; ++k) wv[k] = g.w2[tid + 256 * k];
             double sv = 0.0, count = g.count;                // S[tid] (threads 0..127: one column each)
             float p_sc = 0.0f, p_mu = 0.0f, p_iv = 0.0f;
-            if (tid < 128) sv = g.sumsS ? g.sumsS[tid] : acc_read(g.accS, 128, tid);
+            if (tid < 128 && !(g.knock & 1)) sv = g.sumsS ? g.sumsS[tid] : acc_read(g.accS, 128, tid);
             if (g.sumsS) count = g.sumsS[128];
             if (tid < 64) { p_sc = g.pack2[tid]; p_mu = g.pack2[128 + tid]; p_iv = g.pack2[192 + tid]; }
             if (wave == 0) {
@@ -701,7 +706,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             const int k = tid >> 3, m0 = (tid & 7) * 4;
             float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
 #pragma unroll 8
-            for (int c = 0; c < SA_C2; ++c) {
+            for (int c = 0; c < ((g.knock & 1) ? 0 : SA_C2); ++c) {
                 const float wd = sw2[c][k] * sD[c];
                 const float4 w4 = *reinterpret_cast<const float4 *>(&sw2[c][m0]);
                 q0 = __builtin_fmaf(wd, w4.x, q0);
@@ -746,7 +751,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     float pend_g[16];
     int pend_nb = 0, pend_live = 0, pend_cloud = 0;      // pend_live == 0: nothing pending
     auto scatter_pending = [&]() {
-        if (pend_live == 0) return;                       // wave-uniform
+        if (CP || pend_live == 0) return;                 // wave-uniform (tile map: scattered at the end of the tile)
         float *Ac = A + (size_t)pend_cloud * a.n * SA_C1 + r;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 const int n0 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 0));
                 const int n1 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 1));
                 const int nn = h ? n1 : n0;
-                if (acc_row(i, h) < pend_live) atomicAdd(Ac + (size_t)nn * SA_C1, pend_g[i]);
+                if (acc_row(i, h) < pend_live && !(g.knock & 4)) atomicAdd(Ac + (size_t)nn * SA_C1, pend_g[i]);
             }
         }
         pend_live = 0;
@@ -767,13 +772,38 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         Frag<NS> x[3];
         build_frags<NS>(a, raw, h, x);
         const int nb = raw.nb;
-        // tile map: the records of this lane's accumulator rows; this lane's own row (position r) is raw.info
-        unsigned meta[16];
-        if (CP) row_meta(raw.info, h, meta);
         const int q0 = __builtin_amdgcn_readfirstlane(raw.q0);
         const int nq = CP ? __builtin_amdgcn_readfirstlane((int)(raw.info >> 24)) : 1;
         const bool live_row = !CP || ri_mult(raw.info) != 0;
         const float mrow = CP ? (float)ri_mult(raw.info) : 1.0f;       // multiplicity of position r
+        // (tile map) the gradients and pooled slots of the tile's first four queries are requested NOW, one batch
+        // of loads: a query-by-query chain paid one memory round trip per query (~4 per tile)
+        float gv4[4];
+        int kc4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            gv4[u] = 0.0f;
+            kc4[u] = 0;
+            if (u == 0 || (CP && u < nq)) {
+                gv4[u] = g.goa[(size_t)(q0 + u) * SA_C2 + lane];
+                kc4[u] = g.ksel[(size_t)(q0 + u) * SA_C2 + lane];
+            }
+        }
+        // tile map: multiplicities of this lane's sixteen accumulator rows acc_row(i, h) (the row records go through
+        // a wave-private LDS line: one write, four 16-byte broadcast reads), and where the queries' rows start
+        float multf[16];
+        unsigned starts = 1u;                                          // bit = a query's first row (wave-uniform)
+        if (CP) {
+            if (lane < 32) sinfo[wave][lane] = raw.info;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&sinfo[wave][8 * gq + 4 * (lane_o >> 5)]);
+                multf[4 * gq] = (float)ri_mult(v.x); multf[4 * gq + 1] = (float)ri_mult(v.y);
+                multf[4 * gq + 2] = (float)ri_mult(v.z); multf[4 * gq + 3] = (float)ri_mult(v.w);
+            }
+            const unsigned prev = (unsigned)__shfl_up((int)raw.info, 1);
+            starts = (unsigned)__ballot(lane < 32 && (lane == 0 || ri_q(raw.info) != ri_q(prev)));
+        }
         // conv1 in both layouts (3 + 3 k-steps on the same fragments)
         f32x16 yT = {0}, y1 = {0};
 #pragma unroll
@@ -811,40 +841,49 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         // One-hot-weighted operand of the sparse part, S[pos][c] = goa[c] * [ksel[c] == pos]
         // (64 nonzeros in a 32 x 64 tile).  Built through a wave-private LDS image instead of
         // 2048 compare/selects: lane c drops its value into row ksel[c], every lane reads its
-        // fragment rows back (ds_read_b128, conflict-free with 144-byte rows), and lane c
-        // zeroes its element again.  LDS executes one wave's instructions in order, so the
-        // image needs no barrier; it starts zeroed and is left zeroed.  With a tile map the tile holds
-        // several queries: each drops into ITS rows (row0 of the query + the pooled slot).
+        // fragment rows back (ds_read_b128, conflict-free with 144-byte rows).  LDS executes one wave's
+        // instructions in order, so the image needs no barrier; it starts zeroed and is left zeroed (one tile per
+        // query: lane c zeroes its element again; tile map: the region is reused below and cleared whole).  With a
+        // tile map the tile holds several queries: each drops into ITS rows (row0 of the query + the pooled slot).
         Frag<NS> sp[4];
-        // (the next query's pooled slot and gradient are requested while this one is processed: the loop would
-        // otherwise pay one memory round trip per query of the tile)
-        float gv_nx = g.goa[(size_t)q0 * SA_C2 + lane];
-        int kc_nx = g.ksel[(size_t)q0 * SA_C2 + lane];
+        {
+            unsigned todo = starts;                                     // consumed query by query
 #pragma unroll 1
-        for (int jq = 0; jq < nq; ++jq) {
-            const float gv = gv_nx;                                         // lane = out channel c
-            int kc = kc_nx;
-            if (jq + 1 < nq) {
-                gv_nx = g.goa[(size_t)(q0 + jq + 1) * SA_C2 + lane];
-                kc_nx = g.ksel[(size_t)(q0 + jq + 1) * SA_C2 + lane];
-            }
-            if (CP) {
-                const unsigned long long rows_q = __ballot(lane < 32 && live_row && ri_q(raw.info) == (unsigned)jq);
-                kc += __builtin_ctzll(rows_q);                              // first row of query jq in the tile
-            }
-            const __bf16 ghi = (__bf16)gv;
-            const __bf16 glo = (__bf16)(gv - (float)ghi);
-            __bf16 *cell = sp_img + kc * SP_ROW + lane;
-            cell[0] = ghi;
-            if (NS == 2) cell[SP_TILE] = glo;
-            // sparse part of dL/dW2: lane c adds goa[c] * a1[pos = ksel[c]][:]; that row of a1 sits in
-            // lanes kc (mids acc_row(i, 0)) and kc + 32 (mids acc_row(i, 1)), register i
-            const int src0 = kc << 2, src1 = (kc + 32) << 2;      // ds_bpermute takes byte addresses
+            for (int jb = 0; jb < nq; jb += 4) {
+                if (jb) {                                               // (rare) the tile's queries beyond the first four
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int bits = __float_as_int(yT[i]);
-                sacc[i] = __builtin_fmaf(gv, __int_as_float(__builtin_amdgcn_ds_bpermute(src0, bits)), sacc[i]);
-                sacc[16 + i] = __builtin_fmaf(gv, __int_as_float(__builtin_amdgcn_ds_bpermute(src1, bits)), sacc[16 + i]);
+                    for (int u = 0; u < 4; ++u)
+                        if (jb + u < nq) {
+                            gv4[u] = g.goa[(size_t)(q0 + jb + u) * SA_C2 + lane];
+                            kc4[u] = g.ksel[(size_t)(q0 + jb + u) * SA_C2 + lane];
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (jb + u < nq) {                                  // wave-uniform
+                        const float gv = gv4[u];                        // lane = out channel c
+                        int kc = kc4[u];
+                        if (CP) {
+                            kc += __builtin_ctz(todo);                  // first row of this query in the tile
+                            todo &= todo - 1u;
+                        }
+                        const __bf16 ghi = (__bf16)gv;
+                        const __bf16 glo = (__bf16)(gv - (float)ghi);
+                        __bf16 *cell = sp_img + kc * SP_ROW + lane;
+                        cell[0] = ghi;
+                        if (NS == 2) cell[SP_TILE] = glo;
+                        if (!CP) kc4[u] = kc;
+                        // sparse part of dL/dW2: lane c adds goa[c] * a1[pos = ksel[c]][:]; that row of a1 sits in
+                        // lanes kc (mids acc_row(i, 0)) and kc + 32 (mids acc_row(i, 1)), register i
+                        const int src0 = kc << 2, src1 = (kc + 32) << 2;      // ds_bpermute takes byte addresses
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int bits = __float_as_int(yT[i]);
+                            sacc[i] = __builtin_fmaf(gv, __int_as_float(__builtin_amdgcn_ds_bpermute(src0, bits)), sacc[i]);
+                            sacc[16 + i] = __builtin_fmaf(gv, __int_as_float(__builtin_amdgcn_ds_bpermute(src1, bits)), sacc[16 + i]);
+                        }
+                    }
+                }
             }
         }
 #pragma unroll
@@ -853,43 +892,43 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             sp[s].p[0] = *reinterpret_cast<const bf16x8 *>(src);
             if (NS == 2) sp[s].p[NS - 1] = *reinterpret_cast<const bf16x8 *>(src + SP_TILE);
         }
-        kc_nx = g.ksel[(size_t)q0 * SA_C2 + lane];
-#pragma unroll 1
-        for (int jq = 0; jq < nq; ++jq) {
-            int kc = kc_nx;
-            if (jq + 1 < nq) kc_nx = g.ksel[(size_t)(q0 + jq + 1) * SA_C2 + lane];
-            if (CP) {
-                const unsigned long long rows_q = __ballot(lane < 32 && live_row && ri_q(raw.info) == (unsigned)jq);
-                kc += __builtin_ctzll(rows_q);
-            }
-            __bf16 *cell = sp_img + kc * SP_ROW + lane;
+        asm volatile("" ::: "memory");      // (the region is accessed through several types: keep the phases in program order)
+        if (!CP) {                                                      // one query per tile: its 64 cells again
+            __bf16 *cell = sp_img + kc4[0] * SP_ROW + lane;
             cell[0] = (__bf16)0.0f;
             if (NS == 2) cell[SP_TILE] = (__bf16)0.0f;
         }
         // dL/da1 [lane = mid, register = position]
         f32x16 ga;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ga[i] = CP ? ev * (float)ri_mult(meta[i]) : ev;
+        for (int i = 0; i < 16; ++i) ga[i] = CP ? ev * multf[i] : ev;
         ga = mfma<NS>(a0, get_frag<NS>(cfrag, F_QM, lane_o), ga);
         ga = mfma<NS>(a1, get_frag<NS>(cfrag, F_QM + 1, lane_o), ga);
 #pragma unroll
         for (int s = 0; s < 4; ++s) ga = mfma<NS>(sp[s], get_frag<NS>(cfrag, F_W2T + s, lane_o), ga);
 
         f32x16 an;   // a1 in the [lane = mid] layout: both operands of the Gram product
-        f32x16 yhw;  // (tile map) multiplicity * yhat1, for the per-query sums
+        // (tile map) g_u and multiplicity * yhat1 of every row also go to two wave-private LDS tiles [row][mid] (the
+        // image's region: the image is dead until the next tile), for the sums per query below
+        float *gt = reinterpret_cast<float *>(sp_img);
+        asm volatile("" ::: "memory");
         float s1 = 0.0f, s2 = 0.0f, hb = 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float u = __builtin_fmaf(y1[i], sc1, sh1);
             const float yhat = (y1[i] - mu1) * iv1;
             an[i] = __builtin_fmaxf(u, 0.0f);
-            if (CP) suma = __builtin_fmaf((float)ri_mult(meta[i]), an[i], suma);
+            if (CP) suma = __builtin_fmaf(multf[i], an[i], suma);
             else suma += an[i];
             ga[i] = u > 0.0f ? ga[i] : 0.0f;   // g_u
             s1 += ga[i];
             s2 += ga[i] * yhat;
-            if (CP) yhw[i] = (float)ri_mult(meta[i]) * yhat;
-            else hb += yhat;
+            if (CP) {
+                gt[acc_row(i, h) * 33 + r] = ga[i];
+                gt[32 * 33 + acc_row(i, h) * 33 + r] = multf[i] * yhat;
+            } else {
+                hb += yhat;
+            }
         }
         st[0] += s1;
         st[1] += s2;
@@ -897,26 +936,33 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         {   // sums per query and per source point
             int live;
             if (CP) {
+                // a query's rows are consecutive: half 0 adds g_u (HA), half 1 multiplicity * yhat1 (HB), row by row
+                // in ascending order (fixed: reproducible), each lane its mid channel
+                asm volatile("" ::: "memory");
+                const float *mine = gt + h * (32 * 33) + r;
+                float *dst = (h ? HB : HA) + (size_t)q0 * SA_C1 + r;
+                unsigned todo = starts;
 #pragma unroll 1
                 for (int jq = 0; jq < nq; ++jq) {
-                    float ha = 0.0f, hq = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const bool in = ri_q(meta[i]) == (unsigned)jq;         // padding rows carry query 255
-                        ha += in ? ga[i] : 0.0f;
-                        hq += in ? yhw[i] : 0.0f;
-                    }
-                    ha += __shfl_xor(ha, 32);
-                    hq += __shfl_xor(hq, 32);
-                    if (h == 0) {
-                        HA[(size_t)(q0 + jq) * SA_C1 + r] = ha;
-                        HB[(size_t)(q0 + jq) * SA_C1 + r] = hq;
-                    }
+                    const int ra = __builtin_ctz(todo);
+                    todo &= todo - 1u;
+                    const int rb = todo ? __builtin_ctz(todo) : 32;
+                    float sum = 0.0f;
+#pragma unroll 1
+                    for (int rho = ra; rho < rb; ++rho) sum += mine[rho * 33];
+                    dst[(size_t)jq * SA_C1] = sum;
                 }
+                // the image's region: cleared for the next tile
+                asm volatile("" ::: "memory");
+                {
+                    uint4 *z = reinterpret_cast<uint4 *>(sp_img);
+#pragma unroll
+                    for (int e = 0; e < (NS * SP_TILE * 2 / 16 + 63) / 64; ++e)
+                        if (e * 64 + lane < NS * SP_TILE * 2 / 16) z[e * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                asm volatile("" ::: "memory");
                 // rows in use are a prefix of the tile, every one a distinct point of its query: no folding
                 live = __popcll(__ballot(lane < 32 && live_row));
-#pragma unroll
-                for (int i = 0; i < 16; ++i) pend_g[i] = ga[i];
             } else {
                 const float ha = s1 + __shfl_xor(s1, 32);
                 hb += __shfl_xor(hb, 32);
@@ -938,25 +984,40 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 // hand the tile's sums to the deferred scatter
 #pragma unroll
                 for (int i = 0; i < 16; ++i) pend_g[i] = (i == 0 && h == 0) ? ga[0] + extra : ga[i];
+                pend_nb = nb;
+                pend_live = live;
+                pend_cloud = q0 / a.m;
             }
-            pend_nb = nb;
-            pend_live = live;
-            pend_cloud = q0 / a.m;
-        }
 
-        // Gram += a1^T a1 (one side weighted by the multiplicity): the k index (positions, accumulator-row
-        // order) pairs the same registers
-        {
-            const Frag<NS> b0 = pack8<NS>(an, 0), b1 = pack8<NS>(an, 8);
-            if (CP) {
-                f32x16 aw;
+            // Gram += a1^T a1 (one side weighted by the multiplicity): the k index (positions, accumulator-row
+            // order) pairs the same registers
+            {
+                const Frag<NS> b0 = pack8<NS>(an, 0), b1 = pack8<NS>(an, 8);
+                if (CP) {
+                    f32x16 aw;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) aw[i] = an[i] * (float)ri_mult(meta[i]);
-                gram = mfma<NS>(pack8<NS>(aw, 0), b0, gram);
-                gram = mfma<NS>(pack8<NS>(aw, 8), b1, gram);
-            } else {
-                gram = mfma<NS>(b0, b0, gram);
-                gram = mfma<NS>(b1, b1, gram);
+                    for (int i = 0; i < 16; ++i) aw[i] = an[i] * multf[i];
+                    gram = mfma<NS>(pack8<NS>(aw, 0), b0, gram);
+                    gram = mfma<NS>(pack8<NS>(aw, 8), b1, gram);
+                } else {
+                    gram = mfma<NS>(b0, b0, gram);
+                    gram = mfma<NS>(b1, b1, gram);
+                }
+            }
+            if (CP) {
+                // the tile's per-point sums, scattered at the END of the tile: behind every load of this iteration and
+                // ahead of the next iteration's prefetch (the memory counter is in order: they retire behind a whole
+                // tile of arithmetic; the one-tile-per-query path reaches the same order through scatter_pending)
+                float *Ac = A + (size_t)(q0 / a.m) * a.n * SA_C1 + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (acc_row(i, 0) < live) {                   // wave-uniform: is any lane's position live?
+                        const int n0 = __builtin_amdgcn_readlane(nb, acc_row(i, 0));
+                        const int n1 = __builtin_amdgcn_readlane(nb, acc_row(i, 1));
+                        const int nn = h ? n1 : n0;
+                        if (acc_row(i, h) < live && !(g.knock & 4)) atomicAdd(Ac + (size_t)nn * SA_C1, ga[i]);
+                    }
+                }
             }
         }
     });
@@ -964,6 +1025,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         const float tot = fold_partials<2>(st, lane, wave);
         if (threadIdx.x < 64) acc_add(accT, 64, blockIdx.x % ACC_COPIES, threadIdx.x, tot);
     }
+    if (g.knock & 2) return;
     // The workgroup's share of dL/dW2: fold the four waves' sparse parts in LDS (kept in registers: thread t owns
     // elements t + 256 j), then Gram and suma, then  row[c][mid] = sparse + D2[c] (W2 Gram)[c][mid] + E2[c] suma[mid].
     float (*wred)[SA_C2 * SA_C1] = reinterpret_cast<float (*)[SA_C2 * SA_C1]>(sp_raw);   // images are dead
@@ -1133,6 +1195,7 @@ extern "C" int apn_sa_bwd_main(int b, int n, int m, int precision, float radius,
     g.accS = (const unsigned long long *)accS; g.sumsS = sumsS;
     g.count = count; g.train2 = train2;
     g.goa = goa; g.ksel = (const unsigned char *)ksel;
+    { static int kn = -1; if (kn < 0) { const char *e = getenv("APN_KNOCK"); kn = e ? atoi(e) : 0; } g.knock = kn; }
     auto kern = precision == 2 ? (tmap ? sa_bwd_kernel<2, true> : sa_bwd_kernel<2, false>)
                                : (tmap ? sa_bwd_kernel<1, true> : sa_bwd_kernel<1, false>);
     hipLaunchKernelGGL(kern, dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, g,

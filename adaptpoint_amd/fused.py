@@ -35,11 +35,12 @@ import torch.nn as nn
 from . import _lib
 
 C_IN, C_MID, C_OUT, K_NS = 32, 32, 64, 32
-# The register-resident passes can run over the distinct-hit tile map of the index stage (fused_wide.tile_map):
-# 3.7x fewer tiles at stage 1.  Measured on the headline step (B=32): the two forward passes gain (12.1 -> 9.1 us,
-# 26.3 -> 23.2 us); the backward pass does not (its per-QUERY work -- the pooled-slot scatter into dL/dW2, the
-# per-query sums -- does not shrink with the rows: 52.9 -> 60.2 us), so by default it keeps one tile per query.
-TILE_MAP_IN_BACKWARD = False
+# The register-resident passes run over the distinct-hit tile map of the index stage (fused_wide.tile_map): 3.7x fewer
+# tiles at stage 1.  Round 2 measured a LOSS for the backward pass (52.9 -> 60.2 us: one memory round trip and ~90
+# compare/select instructions per QUERY of a tile, 50 spilled registers); round 3 rebuilt its per-query work (the
+# queries' gradients / pooled slots in one batch of loads, per-query sums through two wave-private LDS tiles, the
+# scatter at the end of the tile): 58 -> 44 us, so the map is now used in both directions (APN_TMAP_BWD=0: forward only).
+TILE_MAP_IN_BACKWARD = os.environ.get("APN_TMAP_BWD", "1") == "1"
 
 # Operand precision of the MFMA contractions:
 #   "bf16x3" (default) every f32 operand is split into hi + lo bf16 parts and each product is

@@ -41,7 +41,13 @@ def test_bench_variants_emit_the_contract_line(dev, extra, launch):
     assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["frac"] >= 0
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["scaling"] == "weak"
     st = d["roofline"]["step"]
-    assert 0 < st["frac_mfma"] < 1 and 0 < st["frac_hbm"] < 1 and d["roofline"]["fps_step_ns"] > 0
+    assert 0 < st["frac_mfma"] < 1 and 0 < st["frac_hbm"] < 1 and d["roofline"]["index_stream"]["fps_step_ns"] > 0
+    # a short timed region is repeated: the median block is reported, min / max beside it
+    assert d["timed_blocks"] == 25 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    if d["dtype"] == "bf16" and "--pipeline" not in extra:
+        # the dominant kernel is the one with the largest total time per step on the stream that bounds `value`
+        assert d["roofline"]["kernel"] == "sa_bwd_main" and d["roofline"]["bound"] == "mfma"
+        assert d["roofline"]["avg_launch_us"] == d["roofline"]["kernels"]["sa_bwd_main"]["avg_us"]
     if launch is not None:
         assert d["config"]["launch"] == launch
 
