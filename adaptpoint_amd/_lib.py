@@ -34,6 +34,7 @@ SIGNATURES = {
     "apn_sa_grid_rows": [_c_int] * 3,
     "apn_sa_bwd_main_rows": [_c_int] * 2,
     "apn_sa_acc_words": [_c_int],
+    "apn_sa_debug_stamps": [_c_void_p],
     "apn_zero_fill": [_c_void_p, _c_longlong, _c_void_p],
     "apn_sa_geo_dd_doubles": [_c_int],
     "apn_sa_point_geo": [_c_int] * 4 + [_c_float] + [_c_void_p] * 6,

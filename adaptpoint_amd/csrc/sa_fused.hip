@@ -97,7 +97,14 @@ struct SaArgs {
     const float *w1;             // (32, 35): columns [dp(3), f(32)] as the reference's cat([dp, fj])
     float radius;
     const int *tmap;             // distinct-hit tile map (csrc/sa_wide_glue.hip: apn_sa_wide_tilemap) or null
+    unsigned long long *stamps;  // diagnostics (apn_sa_debug_stamps): per wave 8 wall-clock stamps, else null
 };
+
+// wall-clock stamp k of this wave (100 MHz counter, chip-wide), when a stamp buffer is attached
+__device__ __forceinline__ void stamp(const SaArgs &a, int wave, int k) {
+    if (a.stamps && (threadIdx.x & 63) == 0)
+        a.stamps[((size_t)blockIdx.x * SA_WAVES + wave) * 8 + k] = wall_clock64();
+}
 
 // With a tile map (CP) a tile is 32 ROWS = (query, distinct neighbour, multiplicity) instead of one query's 32
 // slots: the ball query's fill copies of slot 0 are folded into one row (3.7x fewer tiles at stage 1), whole
@@ -346,24 +353,32 @@ template <int NS, bool CP, typename Pro, typename Pre, typename Body>
 __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Pro prologue, Pre pre, Body body) {
     const int cap = a.b * a.m, stride = gridDim.x * SA_WAVES;
     int tile = blockIdx.x * SA_WAVES + wave;
+    // the heads of the wave's first TWO tiles, both before anything else (the second was requested after the
+    // prologue: the first iteration then stalled a full memory round trip on it before its own tile's arithmetic)
     const TileHead hd0 = load_head<CP>(a, tile < cap ? tile : 0, r);
+    TileHead hd_nxt = load_head<CP>(a, tile + stride < cap ? tile + stride : 0, r);
     const int tiles = CP ? tm_tiles(a) : cap;
     TileRaw<NS> cur, nxt;
     const bool any = tile < tiles;                                 // wave-uniform
+    stamp(a, wave, 1);
     if (any) fetch_tile<NS>(a, hd0, h, cur);
     prologue();
+    stamp(a, wave, 2);
     if (!any) return;
-    TileHead hd_nxt = load_head<CP>(a, tile + stride < tiles ? tile + stride : tile, r);
+    int nst = 3;
     for (; tile < tiles; tile += stride) {
         const bool more = tile + stride < tiles;               // wave-uniform
         pre();
         if (more) fetch_tile<NS>(a, hd_nxt, h, nxt);
         const TileHead hd_nxt2 = load_head<CP>(a, tile + 2 * stride < tiles ? tile + 2 * stride : tile, r);
         body(tile, cur);
+        stamp(a, wave, nst < 5 ? nst : 5);
+        ++nst;
         if (more) cur = nxt;
         hd_nxt = hd_nxt2;
     }
     pre();
+    stamp(a, wave, 6);
 }
 
 // Workgroup-level fold of per-lane statistics: vals[i] belongs to channel (i*32 + r) of this lane's half;
@@ -393,9 +408,10 @@ __device__ __forceinline__ float fold_partials(float (&vals)[NV], int lane, int 
 // summation order: every workgroup computes the same bits.  Workgroup 0 also leaves pack[4][C] and updates the
 // running buffers.  scale/shift are valid in threads 0..C-1 on return (no trailing barrier).
 __device__ __forceinline__ void fold_rows32(const float *__restrict__ part, int rows, const double *__restrict__ sums,
-                                            const BnArgs &bn, float *__restrict__ pack, float &scale, float &shift) {
-    __shared__ double fred[16][64];
-    __shared__ double ftot[64];
+                                            const BnArgs &bn, float *__restrict__ pack, float &scale, float &shift,
+                                            double *scratch /* LDS, 17 x 64 doubles */) {
+    double (*fred)[64] = reinterpret_cast<double (*)[64]>(scratch);
+    double *ftot = scratch + 16 * 64;
     const int tid = threadIdx.x;
     double count = bn.count;
     if (bn.training) {
@@ -410,6 +426,15 @@ __device__ __forceinline__ void fold_rows32(const float *__restrict__ part, int 
                 for (int u = 0; u < 8; ++u) v[u] = p4[(size_t)(rr + 16 * u) * 16];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
+                    s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w;
+                }
+            }
+            for (; rr + 3 * 16 < rows; rr += 4 * 16) {       // (64 rows: exactly one batch of four loads per thread)
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = p4[(size_t)(rr + 16 * u) * 16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
                     s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w;
                 }
             }
@@ -452,6 +477,13 @@ __global__ __launch_bounds__(SA_WAVES * 64, 3) void sa_fwd_main_kernel(
     enum { F_W1 = 0, F_W2 = 3, F_COUNT = 7 };
     __shared__ uint4 cfrag[F_COUNT * NS * 64];
     __shared__ __attribute__((aligned(16))) float bn1v[2][2][16];   // {scale, shift}[h][register]
+    // wave-private tiles [out-channel half][row][32 + 1] of the signed y2, for the pool per query over a tile map
+    // (one tile per query: only the prologue's fold scratch lives here)
+    constexpr int PT_WAVE = CP ? 2 * 32 * 33 : 17 * 64 * 2 / SA_WAVES;        // floats per wave
+    __shared__ __attribute__((aligned(16))) float ptile[SA_WAVES * PT_WAVE];
+    __shared__ __attribute__((aligned(16))) unsigned sinfo[SA_WAVES][32];
+    static_assert(SA_WAVES * PT_WAVE * 4 >= 17 * 64 * 8, "fold scratch");
+    stamp(a, wave, 0);
     const float sg[2] = {(!gamma2 || gamma2[r] >= 0.0f) ? 1.0f : -1.0f, (!gamma2 || gamma2[32 + r] >= 0.0f) ? 1.0f : -1.0f};
     float st[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum t0, sum t1, sumsq t0, sumsq t1
 
@@ -474,7 +506,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 3) void sa_fwd_main_kernel(
             }
         }
         float sc, sh;
-        fold_rows32(part1, rows1, sums1, bn1, pack1, sc, sh);
+        fold_rows32(part1, rows1, sums1, bn1, pack1, sc, sh, reinterpret_cast<double *>(ptile));
         if (threadIdx.x < 32) {          // channel i sits in half (i >> 2) & 1, register (i & 3) + 4 (i >> 3)
             const int i = threadIdx.x;
             bn1v[0][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = sc;
@@ -488,10 +520,24 @@ __global__ __launch_bounds__(SA_WAVES * 64, 3) void sa_fwd_main_kernel(
         asm volatile("" : "+v"(lane_o));
         Frag<NS> x[3];
         build_frags<NS>(a, raw, h, x);
-        unsigned meta[16];
-        if (CP) row_meta(raw.info, h, meta);
         const int q0 = __builtin_amdgcn_readfirstlane(raw.q0);
         const int nq = __builtin_amdgcn_readfirstlane((int)(raw.info >> 24));       // lane 0 holds row 0
+        // tile map: multiplicities of this lane's sixteen accumulator rows (the row records go through a wave-private
+        // LDS line: one write, four 16-byte broadcast reads) and where the queries' rows start
+        float multf[16];
+        unsigned starts = 1u;
+        float *pt = ptile + wave * PT_WAVE;
+        if (CP) {
+            if (lane < 32) sinfo[wave][lane] = raw.info;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&sinfo[wave][8 * gq + 4 * (lane_o >> 5)]);
+                multf[4 * gq] = (float)ri_mult(v.x); multf[4 * gq + 1] = (float)ri_mult(v.y);
+                multf[4 * gq + 2] = (float)ri_mult(v.z); multf[4 * gq + 3] = (float)ri_mult(v.w);
+            }
+            const unsigned prev = (unsigned)__shfl_up((int)raw.info, 1);
+            starts = (unsigned)__ballot(lane < 32 && (lane == 0 || ri_q(raw.info) != ri_q(prev)));
+        }
         f32x16 y1 = {0};
 #pragma unroll
         for (int s = 0; s < 3; ++s) y1 = mfma<NS>(get_frag<NS>(cfrag, F_W1 + s, lane_o), x[s], y1);  // Y1^T: lane = position
@@ -514,37 +560,16 @@ __global__ __launch_bounds__(SA_WAVES * 64, 3) void sa_fwd_main_kernel(
             y2 = mfma<NS>(a0, get_frag<NS>(cfrag, F_W2 + 2 * t, lane_o), y2);  // Y2: lane = out channel 32 t + r, register = position
             y2 = mfma<NS>(a1, get_frag<NS>(cfrag, F_W2 + 2 * t + 1, lane_o), y2);
             if (CP) {
-                float s1 = 0.0f, s2 = 0.0f, v[16];
+                float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float wy = (float)ri_mult(meta[i]) * y2[i];
+                    const float wy = multf[i] * y2[i];
                     s1 += wy;
                     s2 += wy * y2[i];
-                    v[i] = sg[t] * y2[i];
+                    pt[(t * 32 + acc_row(i, h)) * 33 + r] = sg[t] * y2[i];
                 }
                 st[t] += s1;
                 st[2 + t] += s2;
-                // the pool, query by query (padding rows carry query 255); rows ascend with the slot, so the
-                // first maximum is the lowest slot
-#pragma unroll 1
-                for (int jq = 0; jq < nq; ++jq) {
-                    float best = -__builtin_inff();
-                    int bi = 0;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const bool up = ri_q(meta[i]) == (unsigned)jq && v[i] > best;
-                        best = up ? v[i] : best;
-                        bi = up ? (int)meta[i] : bi;
-                    }
-                    int kpos = (int)ri_slot((unsigned)bi);
-                    const float obest = __shfl_xor(best, 32);
-                    const int okpos = __shfl_xor(kpos, 32);
-                    if (obest > best || (obest == best && okpos < kpos)) { best = obest; kpos = okpos; }
-                    if (h == 0) {
-                        ysel[(size_t)(q0 + jq) * SA_C2 + 32 * t + r] = sg[t] * best;
-                        ksel[(size_t)(q0 + jq) * SA_C2 + 32 * t + r] = (unsigned char)kpos;
-                    }
-                }
                 continue;
             }
             float best = sg[t] * y2[0];
@@ -568,9 +593,40 @@ __global__ __launch_bounds__(SA_WAVES * 64, 3) void sa_fwd_main_kernel(
                 ksel[(size_t)tile * SA_C2 + 32 * t + r] = (unsigned char)kpos;
             }
         }
+        if (CP) {
+            // The pool, query by query: lane (r, h) owns out channel 32 h + r and walks the query's rows of ITS tile in
+            // ascending order (rows ascend with the slot, a row's slot = its offset from the query's first row: the
+            // first maximum is the lowest slot).  ~5 instructions per row where the compare/select form over the
+            // accumulator registers took ~85 per query and channel half.
+            asm volatile("" ::: "memory");
+            const float *mine = pt + h * (32 * 33) + r;
+            const float sgn = h ? sg[1] : sg[0];
+            float *ys = ysel + (size_t)q0 * SA_C2 + lane;
+            unsigned char *ks = ksel + (size_t)q0 * SA_C2 + lane;
+            unsigned todo = starts;
+#pragma unroll 1
+            for (int jq = 0; jq < nq; ++jq) {
+                const int ra = __builtin_ctz(todo);
+                todo &= todo - 1u;
+                const int rb = todo ? __builtin_ctz(todo) : 32;
+                float best = mine[ra * 33];
+                int kpos = 0;
+#pragma unroll 1
+                for (int rho = ra + 1; rho < rb; ++rho) {
+                    const float v = mine[rho * 33];
+                    const bool up = v > best;
+                    best = up ? v : best;
+                    kpos = up ? rho - ra : kpos;
+                }
+                ys[(size_t)jq * SA_C2] = sgn * best;
+                ks[(size_t)jq * SA_C2] = (unsigned char)kpos;
+            }
+            asm volatile("" ::: "memory");
+        }
     });
     const float tot = fold_partials<4>(st, lane, wave);
     if (threadIdx.x < 128) acc_add(acc2, 128, blockIdx.x % ACC_COPIES, threadIdx.x, tot);
+    stamp(a, wave, 7);
 }
 
 // ---------------------------------------------------------------------------
@@ -641,6 +697,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     __shared__ __attribute__((aligned(16))) float sw2[SA_C2][SA_C1 + 4];   // W2 (prologue products, epilogue row)
     __shared__ float sD[SA_C2], sE[SA_C2];
     __shared__ __attribute__((aligned(16))) float sqm[SA_C1 + 1][SA_C1 + 4];   // Qm[k][mid]; row 32 = evec; later Gram | suma
+    stamp(a, wave, 0);
     const float sc1 = g.scale1[r], sh1 = g.shift1[r], mu1 = g.mean1[r], iv1 = g.inv1[r];
     float ev = 0.0f;
     float sacc[32];           // lane c: sparse part of dL/dW2[c][mid], mid = acc_row(i, 0) | acc_row(i, 1)
@@ -688,8 +745,9 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 const double sc = p_sc, mu = p_mu, iv = p_iv, s1 = sv, s2 = sS2[tid];
                 double d = 0.0, e = 0.0;
                 if (g.train2) {
-                    d = -sc * iv * s2 / count;
-                    e = -sc * s1 / count + sc * mu * iv * s2 / count;
+                    const double rc = 1.0 / count;
+                    d = -sc * iv * s2 * rc;
+                    e = (-sc * s1 + sc * mu * iv * s2) * rc;
                 }
                 sD[tid] = (float)d;
                 sE[tid] = (float)e;
@@ -699,52 +757,40 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 bn1v[0][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = g.scale1[i];
                 bn1v[1][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = g.shift1[i];
             }
-            for (int e = lane; e < NS * SP_TILE; e += 64) sp_img[e] = (__bf16)0.0f;
-        }
-        __syncthreads();
-        {   // Qm[k][mid] = sum_c W2[c][k] D[c] W2[c][mid]: thread (k = tid >> 3, four mids); evec by threads 0..31
-            const int k = tid >> 3, m0 = (tid & 7) * 4;
-            float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
-#pragma unroll 8
-            for (int c = 0; c < ((g.knock & 1) ? 0 : SA_C2); ++c) {
-                const float wd = sw2[c][k] * sD[c];
-                const float4 w4 = *reinterpret_cast<const float4 *>(&sw2[c][m0]);
-                q0 = __builtin_fmaf(wd, w4.x, q0);
-                q1 = __builtin_fmaf(wd, w4.y, q1);
-                q2 = __builtin_fmaf(wd, w4.z, q2);
-                q3 = __builtin_fmaf(wd, w4.w, q3);
-            }
-            *reinterpret_cast<float4 *>(&sqm[k][m0]) = make_float4(q0, q1, q2, q3);   // (S2's readers are behind the barrier above)
-            if (tid < 32) {
-                float e = 0.0f;
-#pragma unroll 8
-                for (int c = 0; c < SA_C2; ++c) e = __builtin_fmaf(sE[c], sw2[c][tid], e);
-                sqm[32][tid] = e;
+            {
+                uint4 *z = reinterpret_cast<uint4 *>(sp_img);
+                for (int e = lane; e < SP_WAVE / 16; e += 64) z[e] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
         __syncthreads();
-        if (wave == 1) {
-            // term 1 of dL/da1: B fragments of Qm, k slot (h,j) of step s <-> mid' = row(8s+j,h)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float tmp[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) tmp[j] = sqm[acc_row(8 * s + j, h)][r];
-                put_frag<NS>(cfrag, F_QM + s, lane, make_frag<NS>(tmp));
-            }
-        }
         if (wave == 2) {
-            // term 3: B fragments of W2 with k = output channel in natural order 16 s + 8 h + j
+            // term 3's B fragments of W2 with k = output channel in natural order 16 s + 8 h + j -- and, from the same
+            // values, Qm = W2^T diag(D2) W2 and evec = E2 W2 as two small MFMA products (A = the D2-weighted /
+            // the E2-in-row-0 image of W2): Qm lands as [lane = mid, register = mid' in accumulator-row order], which IS
+            // the fragment order of term 1's B operand (the accumulator-as-next-operand rule): no LDS round trip.
+            // (A 64-iteration multiply-add loop over LDS by all four waves took ~1.2 us of every workgroup's start.)
+            f32x16 qacc = {0}, eacc = {0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float tmp[8];
+                float tmp[8], tmpd[8], tmpe[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tmp[j] = sw2[16 * s + 8 * h + j][r];
-                put_frag<NS>(cfrag, F_W2T + s, lane, make_frag<NS>(tmp));
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 16 * s + 8 * h + j;
+                    tmp[j] = sw2[c][r];
+                    tmpd[j] = tmp[j] * sD[c];
+                    tmpe[j] = r == 0 ? sE[c] : 0.0f;
+                }
+                const Frag<NS> wt = make_frag<NS>(tmp);
+                put_frag<NS>(cfrag, F_W2T + s, lane, wt);
+                qacc = mfma<NS>(make_frag<NS>(tmpd), wt, qacc);
+                eacc = mfma<NS>(make_frag<NS>(tmpe), wt, eacc);
             }
+            put_frag<NS>(cfrag, F_QM, lane, pack8<NS>(qacc, 0));
+            put_frag<NS>(cfrag, F_QM + 1, lane, pack8<NS>(qacc, 8));
+            if (h == 0) sqm[32][r] = eacc[0];                     // row 0 of the product = evec
         }
-        ev = sqm[32][r];
         __syncthreads();
+        ev = sqm[32][r];
     };
 
     // the previous tile's per-point sums, scattered at the top of the next iteration (see for_each_tile)
@@ -1083,6 +1129,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         row[1] = make_float4(sp8[4] + d * acc[4] + e * s1.x, sp8[5] + d * acc[5] + e * s1.y,
                              sp8[6] + d * acc[6] + e * s1.z, sp8[7] + d * acc[7] + e * s1.w);
     }
+    stamp(a, wave, 7);
 }
 
 static int sa_grid(int tiles, bool compact = false) {
@@ -1141,11 +1188,17 @@ extern "C" int apn_sa_prep_stats(int b, int n, const float *f, const void *geo, 
     return APN_OK;
 }
 
+static unsigned long long *g_stamps = nullptr;
+// Diagnostics: attach (or detach: NULL) a buffer of 8 x (workgroups x 4) 64-bit stamps; the next launches of the two
+// tile passes record per wave the wall clock at {0: entry, 1: tile count known, 2: prologue done, 3..5: tiles done,
+// 6: loop done, 7: kernel end} (scripts/stamp_passes.py).  Not for concurrent use.
+extern "C" int apn_sa_debug_stamps(void *buf) { g_stamps = (unsigned long long *)buf; return APN_OK; }
+
 static apn::SaArgs sa_args(int b, int n, int m, const float *xyz, const float *new_xyz, const void *ft,
                            int precision, const int *idx, const float *w1, float radius, const int *tmap) {
     const __bf16 *hi = (const __bf16 *)ft;
     return apn::SaArgs{b, n, m, xyz, new_xyz, hi,
-                       precision == 2 ? hi + (size_t)b * n * apn::SA_C : nullptr, idx, w1, radius, tmap};
+                       precision == 2 ? hi + (size_t)b * n * apn::SA_C : nullptr, idx, w1, radius, tmap, g_stamps};
 }
 
 static int sa_check(int b, int n, int m, int precision) {

@@ -273,6 +273,10 @@ APN_API int apn_sa_bwd_finalize(const float *partW, int rows_w, float radius, fl
                                 const void *accT, const double *sumsT, float *g_bs, float *g_g2, float *g_b2,
                                 float *g_g1, float *g_b1, void *stream);
 
+/* Diagnostics: attach (NULL: detach) a buffer of 8 x 4 x workgroups 64-bit wall-clock stamps that the next
+ * launches of the two tile passes fill per wave (scripts/stamp_passes.py).  Not for concurrent use. */
+APN_API int apn_sa_debug_stamps(void *buf);
+
 /* Whole-direction launch sequences (csrc/sa_seq.hip): the same kernels as above, enqueued
  * back-to-back by ONE call so that an eager step stays GPU-bound.  `phases` (bit mask
  * 1|2|4) selects the part to enqueue, so a caller can all-reduce the BatchNorm sums between

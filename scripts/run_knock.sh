@@ -1,6 +1,5 @@
 R=$GRAFT_REPO_ROOT; cd /tmp
-timeout -k 10 300 python -m pytest $R/tests/test_gpu_fused.py -q -m gpu -x -k "tile_map or backward_matches" 2>&1 | tail -5
-for t in 0 1; do
-  APN_TMAP_BWD=$t timeout -k 10 200 python $R/bench.py --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('tmap_bwd $t', d['value'], d['ms_per_step'], d['roofline']['kernels']['sa_bwd_main']['avg_us'])"
+for spg in 8 16 20 25 40; do
+  timeout -k 10 200 python $R/bench.py --no-cpu-baseline --no-secondary --steps 2000 --steps-per-graph $spg 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernels']; print('spg $spg', d['value'], d['ms_per_step'], k['fps']['avg_us'], k['sa_prep_stats']['avg_us'], k['sa_bwd_point_grads']['avg_us'])"
 done
