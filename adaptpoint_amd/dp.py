@@ -90,7 +90,10 @@ def _common_span(tensors):
     lo = min(t.storage_offset() for t in tensors)
     hi = max(t.storage_offset() + t.numel() for t in tensors)
     payload = sum(t.numel() for t in tensors)
-    if hi - lo > 2 * payload + 4096:
+    # the span is reduced (and scaled) WHOLE: only the alignment padding of the producer's carve (64 elements per
+    # view, adaptpoint_amd.fused._carve) may lie between the views -- anything else living in that storage
+    # would be averaged with them
+    if hi - lo > payload + 64 * len(tensors):
         return None
     return torch.empty(0, dtype=t0.dtype, device=t0.device).set_(t0.untyped_storage(), lo, (hi - lo,))
 

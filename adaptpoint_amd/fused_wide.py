@@ -30,13 +30,16 @@ LEAN_MAX = 64        # widest C_in / C_mid whose dense products run in csrc/sa_w
 WIDTHS = (32, 64, 128, 256)
 
 
-def supported(p, f, idx_or_k, conv1, conv2, bns=()):
+def supported(p, f, idx_or_k, conv1, conv2, bns=(), npoint=None):
+    """npoint: the number of queries when `idx_or_k` is the neighbourhood size alone (the kernels pack query ids
+    into 24 bits: B * npoint is bounded)."""
     k = idx_or_k.shape[2] if torch.is_tensor(idx_or_k) else int(idx_or_k)
+    m = idx_or_k.shape[1] if torch.is_tensor(idx_or_k) else (p.shape[1] if npoint is None else int(npoint))
     H, O = conv1.weight.shape[0], conv2.weight.shape[0]
     return (f.is_cuda and f.dtype == torch.float32 and p.dtype == torch.float32 and k == K_NS
             and H in WIDTHS and O == 2 * H and conv1.weight.shape[1] == f.shape[1] + 3
             and conv2.weight.shape[1] == H and conv1.bias is None and conv2.bias is None
-            and p.shape[0] * (idx_or_k.shape[1] if torch.is_tensor(idx_or_k) else 1) < 2 ** 24
+            and p.shape[0] * m < 2 ** 24
             and (64 * (H + 1) + (f.shape[1] + 3) * 65) * 4 <= 160 * 1024        # LDS of the per-point gradient kernel
             and all(bn.momentum is not None for bn in bns))
 

@@ -38,12 +38,18 @@ def resample(points, npoints, in_channels, choice=None):
     point_all = min(point_all, N)
     points = points.contiguous()
     fidx = furthest_point_sample(points[:, :, :3].contiguous(), point_all)
-    if choice is None:
-        choice = np.random.choice(point_all, npoints, False)
-    choice = np.asarray(choice)
-    if choice.size != npoints or choice.min() < 0 or choice.max() >= point_all:
-        raise RuntimeError("resample: choice must hold npoints indices in [0, point_all)")
-    choice = torch.from_numpy(choice.astype(np.int32)).to(points.device)
+    if torch.is_tensor(choice):
+        # already on the device (int32, npoints indices in [0, point_all)): no host-to-device copy, so the step can be
+        # captured in a hipGraph
+        if choice.dtype != torch.int32 or choice.numel() != npoints or choice.device != points.device:
+            raise RuntimeError("resample: a tensor `choice` must be int32, on the points' device, npoints long")
+    else:
+        if choice is None:
+            choice = np.random.choice(point_all, npoints, False)
+        choice = np.asarray(choice)
+        if choice.size != npoints or choice.min() < 0 or choice.max() >= point_all:
+            raise RuntimeError("resample: choice must hold npoints indices in [0, point_all)")
+        choice = torch.from_numpy(choice.astype(np.int32)).to(points.device)
     pos = torch.empty(B, npoints, 3, dtype=torch.float32, device=points.device)
     x = torch.empty(B, in_channels, npoints, dtype=torch.float32, device=points.device)
     ops.resample_points_wrapper(B, N, C, point_all, npoints, in_channels, points, fidx, choice, pos, x)
@@ -54,8 +60,12 @@ class ClassifierStep:
     """One iteration of `train_one_epoch` (train_autoaug.py:471-512) for step_per_update = 1."""
 
     def __init__(self, model, lr=2e-3, weight_decay=0.05, grad_norm_clip=10.0, npoints=1024,
-                 in_channels=4, optimizer=None):
+                 in_channels=4, optimizer=None, grad_sync=None):
         self.model = model
+        # grad_sync(list of .grad tensors): called before clipping and the optimizer step -- under data parallelism
+        # `adaptpoint_amd.dp.allreduce_mean_`, what the reference's DistributedDataParallel wrapper of the classifier
+        # does (train_autoaug.py:275-282, with BatchNorm converted to SyncBatchNorm there)
+        self.grad_sync = grad_sync
         self.npoints, self.in_channels, self.clip = npoints, in_channels, grad_norm_clip
         self.opt = optimizer or torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
 
@@ -65,6 +75,8 @@ class ClassifierStep:
         pos, x = resample(points, self.npoints, self.in_channels, choice)
         logits, loss = self.model.get_logits_loss({'pos': pos, 'x': x}, target)
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync([q.grad for q in self.model.parameters() if q.grad is not None])
         if self.clip is not None and self.clip > 0:
             nn.utils.clip_grad_norm_(self.model.parameters(), self.clip, norm_type=2)
         self.opt.step()

@@ -196,7 +196,7 @@ class SetAbstraction(nn.Module):
             return None
         conv1, bn1, conv2, bn2, relu_after = parts
         g = self.grouper
-        if not fused_wide.supported(p, f, g.nsample, conv1, conv2, bns=(bn1, bn2)):
+        if not fused_wide.supported(p, f, g.nsample, conv1, conv2, bns=(bn1, bn2), npoint=p.shape[1] // self.stride):
             return None
         C, H = f.shape[1], conv1.weight.shape[0]
         skip = self._skip_conv1d()

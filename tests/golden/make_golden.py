@@ -25,7 +25,7 @@ observable here), else the seed is rejected.
 Fixtures store OUTPUTS (and small state_dicts); inputs are regenerated from
 seeds by tests/golden_inputs.py.
 
-    python tests/golden/make_golden.py [all | pointnet2 | adaptpoint]
+    python tests/golden/make_golden.py [all | pointnet2 | adaptpoint | pins]
 
 `pointnet2` writes pointnet2_golden.npz (G1-G8: operators, SetAbstraction, the PointNeXt-S
 classifier, the imitator's grouper / attention / predictor network); `adaptpoint` writes
@@ -499,8 +499,6 @@ def main_adaptpoint():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
     cls = _reference_classifier()
-    pos = _t(GI.unit_sphere_cloud(2, 512, seed=111))
-    points = torch.cat([pos, height_channel(pos)], -1)                      # (2,512,4)
     label = torch.tensor([3, 11])
     cfg = EasyDict(criterion_args=dict(NAME='SmoothCrossEntropy', label_smoothing=0.3),
                    adaptpoint_params=dict(hardratio_s=3, hardratio=3), epochs=300,
@@ -516,6 +514,33 @@ def main_adaptpoint():
     gen.train(); dis.train(); cls.eval()
     gen.predict_prob_layer.fuse_masking.register_forward_hook(
         lambda mod, inp, outp: grabbed.__setitem__("logits", outp.detach().permute(0, 2, 1).clone()))
+    # The anchor head selects 24 of the coarsest level's points per anchor (knn_point, top-k unsorted) and takes a
+    # max over their features (generator_component4_15.py:565-567): a near-tie in either is decided by 1e-7-level
+    # rounding upstream and switches whole gradient entries (round 2's golden had one: the head gradient had two
+    # outcomes, 1e-5 or 2.8e-3 from the reference).  The golden's INPUT is therefore chosen among seeds >= 111
+    # such that the 24th / 25th distances differ by > 1e-3 relative and every max over the 24 leads its runner-up by
+    # > 2e-5 of the feature scale.
+    gen.predict_prob_layer.head.register_forward_pre_hook(
+        lambda mod, inp, kw: grabbed.__setitem__("head_in", (inp, kw)), with_kwargs=True)
+
+    def g11_head_margins():
+        inp, kw = grabbed["head_in"]
+        names = ("a_points", "sa_x", "sa_xyz")
+        a_points, sa_x, sa_xyz = [kw[n] if n in kw else inp[i] for i, n in enumerate(names)]
+        d = ref_gen.square_distance(a_points, sa_xyz).sort(dim=-1)[0]
+        knn_gap = float(((d[..., 24] - d[..., 23]) / d[..., 24]).min())
+        feats = ref_gen.index_points(sa_x, ref_gen.knn_point(24, sa_xyz, a_points))          # (B,4,24,C)
+        top2 = feats.topk(2, dim=2)[0]
+        lead = (top2[:, :, 0] - top2[:, :, 1]) / feats.abs().max()
+        # (EXACT ties are structural -- a grouper output whose maximum is the query's own row is exactly its beta, for
+        # every such query -- and bit-identical in any implementation: the first index wins in torch and in the
+        # kernels alike; what must not occur is a maximum decided by rounding)
+        max_gap = float(lead[lead > 0].min())
+        return knn_gap, max_gap
+
+    def g11_input(seed):
+        pos = _t(GI.unit_sphere_cloud(2, 512, seed=seed))
+        return torch.cat([pos, height_channel(pos)], -1)                        # (2,512,4)
 
     def g11_logits():
         state = {k: v.clone() for k, v in gen.state_dict().items()}
@@ -523,6 +548,20 @@ def main_adaptpoint():
             gen(points[:, :, :3].contiguous())
         gen.load_state_dict(state)
         return grabbed["logits"]
+    # (8192 maxima over 24 candidates each: the smallest lead of any input is a few 1e-6 of the feature scale --
+    # ~50 float32 ulps, against 1e-7-level differences between implementations; the input with the LARGEST smallest
+    # lead among seeds 111..399 whose top-24 gap exceeds 1e-3 is taken)
+    scan = []
+    for cand in range(111, 400):
+        points = g11_input(cand)
+        g11_logits()
+        knn_gap, max_gap = g11_head_margins()
+        if knn_gap > 1e-3:
+            scan.append((max_gap, knn_gap, cand))
+    max_gap, knn_gap, g11_pos_seed = max(scan)
+    if max_gap < 2e-6:
+        raise SystemExit("G11: no input seed clears the anchor head's margins")
+    points = g11_input(g11_pos_seed)
     g11_seed = _seed_with_margin(g11_logits, 11)
     torch.manual_seed(g11_seed)
     # -- the body of the loop, statement for statement (without .cuda(), PointWOLF's dump and logging)
@@ -552,13 +591,15 @@ def main_adaptpoint():
     d_loss.backward()
     g11_grad_fc3 = dis.fc3.parametrizations.weight.original.grad.clone()
     opt_d.step()
-    out.update(g11_seed=np.array(g11_seed), g11_gen=gen_imgs.detach().numpy(),
+    out.update(g11_seed=np.array(g11_seed), g11_pos_seed=np.array(g11_pos_seed),
+               g11_head_margins=np.array([knn_gap, max_gap]), g11_gen=gen_imgs.detach().numpy(),
                g11_losses=np.array([g_loss_raw.item(), feedback.item(), g_loss.item(), d_loss.item()]),
                g11_grad_embed_w=g11_grad_embed.numpy(), g11_grad_prob_head_w=g11_grad_head.numpy(),
                g11_grad_fc3=g11_grad_fc3.numpy(),
                g11_embed_w_after=gen.predict_prob_layer.embedding.net[0].weight.detach().numpy(),
                g11_fc3_after=dis.fc3.parametrizations.weight.original.detach().numpy())
-    print(f"G11: joint step golden at seed {g11_seed}: g_raw {g_loss_raw.item():.5f} feedback "
+    print(f"G11: joint step golden at input seed {g11_pos_seed} (top-24 gap {knn_gap:.2e}, max gap {max_gap:.2e}), "
+          f"draw seed {g11_seed}: g_raw {g_loss_raw.item():.5f} feedback "
           f"{feedback.item():.5f} d {d_loss.item():.5f}")
 
     # ---- G12: a12 three_interpolation (upsampling.py:92-102) and a14 KNNGroup (group.py:275-320) -----
@@ -637,9 +678,146 @@ def main_adaptpoint():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
 
 
+def _fp_pyramid(seed):
+    """The four feature-propagation levels of the imitator at N = 1024: (unknown, known) clouds."""
+    cloud = GI.unit_sphere_cloud(2, 1024, seed=seed)
+    levels = [cloud]
+    for m in (512, 256, 128, 64):
+        levels.append(GI.take_points(levels[-1], O.furthest_point_sampling(levels[-1], m)))
+    return [(levels[i], levels[i + 1]) for i in range(4)]
+
+
+def main_pins():
+    """G15 / G16 (round 3): the parts of the oracle that no reference-EXECUTED result pinned so far.
+
+    G15: the interpolation half and the scatter-add gradients, against reference-held pure-torch code --
+      * three nearest + inverse-distance interpolation: `square_distance` (curvenet.py:213-222) and the forward of
+        `PointNetFeaturePropagation` (curvenet.py:428-455: sort, first three, 1 / (d + 1e-8) weights on the SQUARED
+        distances, index_points * weight) -> oracle.three_nn must give the same indices (a case is rejected unless the
+        four smallest distances of every point are separated by 1e-4 relative: the matmul form of the distance and
+        the kernel's difference form may otherwise order near-ties differently), oracle.three_interpolate with the
+        reference's weights the same values (1e-6), and autograd through the reference's forward the same gradient
+        as oracle.three_interpolate_grad (1e-6);
+      * autograd through `torch_grouping_operation` (group.py:120-137) and through `torch.gather` (what
+        `GatherOperation`'s own self-check compares with, subsample.py:176-185) -> oracle.group_points_grad /
+        oracle.gather_points_grad (1e-6).
+      The reference's outputs are committed (tests/golden/pins_golden.npz) so that the CPU suite re-checks the oracle
+      and the GPU suite the kernels against them.
+    G16: SURVEY 8f row 4, second half -- PointNet++ through the boundary: the reference's `PointNetSAModuleMSG` (one
+      plain multi-scale stage and one residual stage, pointnetv2.py:17-106 over ConvPool, local_aggregation.py:140-239)
+      and `PointNetFPModule` (pointnetv2.py:108-150) over the oracle operators."""
+    ref_group, ref_pointnext, ref_pointmlp = import_reference()
+    import openpoints.models.backbone.curvenet as ref_curve
+    import openpoints.models.backbone.pointnetv2 as ref_pn2
+    import openpoints.models.layers.upsampling as ref_up
+    from adaptpoint_amd.pointnext import fill_parameters_by_name
+    from easydict import EasyDict
+    out = {}
+
+    # ---- G15a: three nearest + interpolation --------------------------------------------------------------
+    cases = [("cfg1", GI.config1_xyz(), GI.take_points(GI.config1_xyz(), O.furthest_point_sampling(GI.config1_xyz(), 512)))]
+    for lv, (unk, kn) in enumerate(_fp_pyramid(seed=151)):
+        cases.append((f"fp{lv}", unk, kn))
+    for name, unk, kn in cases:
+        d_ref = ref_curve.square_distance(_t(unk), _t(kn))                       # (B,n,m), reference function
+        ds, order = d_ref.sort(dim=-1)                                           # curvenet.py:448-449
+        # the matmul form |a|^2 + |b|^2 - 2ab carries an ABSOLUTE error of a few eps * (|a|^2 + |b|^2) ~ 5e-7 here, the
+        # kernel's difference form a relative one: where two of a point's four smallest distances lie closer than
+        # 4e-6 the two forms may order them differently.  Such points are excluded from the index comparison (the
+        # mask is committed); everywhere else the indices must be identical, and the excluded share small.
+        exact = ((_t(unk).double().unsqueeze(2) - _t(kn).double().unsqueeze(1)) ** 2).sum(-1)      # (B,n,m) float64
+        four = exact.sort(dim=-1)[0][:, :, :4]
+        safe = ((four[:, :, 1:] - four[:, :, :-1]).min(-1)[0] > 4e-6).numpy()
+        assert safe.mean() > 0.97, f"G15 {name}: too many near-ties ({1 - safe.mean():.3f})"
+        idx_ref = order[:, :, :3].numpy()
+        o_d2, o_idx = O.three_nn(unk, kn)
+        assert np.array_equal(o_idx[safe], idx_ref[safe]), f"G15 {name}: oracle three_nn indices != reference sort"
+        assert np.allclose(o_d2[safe], ds[:, :, :3].numpy()[safe], rtol=0, atol=2e-6), "distances (matmul form vs differences)"
+        for v in O.ALL_DIST_VARIANTS:                                             # every rounding of the oracle
+            assert np.array_equal(O.three_nn(unk, kn, v)[1][safe], idx_ref[safe]), f"G15 {name}: rounding variant {v}"
+        out[f"g15_{name}_safe"] = safe
+        o_idx = idx_ref                                  # the interpolation checks below run on the REFERENCE's choice
+        c = 32 if name != "fp3" else 96
+        pts = _t(GI.seeded_normal((2, c, kn.shape[1]), seed=152)).requires_grad_(True)
+        fp_mod = ref_curve.PointNetFeaturePropagation(in_channel=c, mlp=[])       # forward = the interpolation alone
+        got = fp_mod(_t(unk).transpose(1, 2), _t(kn).transpose(1, 2), None, pts)  # (B,c,n)
+        w_ref = (1.0 / (ds[:, :, :3] + 1e-8))
+        w_ref = (w_ref / w_ref.sum(2, keepdim=True)).numpy()                      # curvenet.py:452-454
+        mine = O.three_interpolate(pts.detach().numpy(), o_idx, w_ref)
+        assert np.allclose(mine, got.detach().numpy(), rtol=1e-6, atol=1e-6), f"G15 {name}: three_interpolate"
+        gout = _t(GI.seeded_normal(tuple(got.shape), seed=153))
+        (got * gout).sum().backward()
+        mine_g = O.three_interpolate_grad(gout.numpy(), o_idx, w_ref, kn.shape[1])
+        assert np.allclose(mine_g, pts.grad.numpy(), rtol=1e-6, atol=1e-6), f"G15 {name}: three_interpolate_grad"
+        out[f"g15_{name}_idx"] = idx_ref.astype(np.int32)
+        if name in ("cfg1", "fp3"):
+            out[f"g15_{name}_weight"] = w_ref.astype(np.float32)
+            out[f"g15_{name}_interp"] = got.detach().numpy()
+            out[f"g15_{name}_interp_grad"] = pts.grad.numpy()
+    print("G15a: oracle three_nn / three_interpolate / its gradient == the reference's pure-torch interpolation on",
+          [n for n, _, _ in cases])
+
+    # ---- G15b: scatter-add gradients ------------------------------------------------------------------------
+    xyz = GI.config1_xyz()
+    fps512 = O.furthest_point_sampling(xyz, 512)
+    bq = O.ball_query(0.15, 32, xyz, GI.take_points(xyz, fps512))
+    feats = _t(GI.seeded_normal((2, 32, 1024), seed=11)).requires_grad_(True)
+    grouped = ref_group.torch_grouping_operation(feats, _t(bq).long())
+    gout = _t(GI.seeded_normal((2, 32, 512, 32), seed=12))
+    (grouped * gout).sum().backward()
+    mine = O.group_points_grad(gout.numpy(), bq, 1024)
+    assert np.allclose(mine, feats.grad.numpy(), rtol=1e-6, atol=1e-5), "group_points_grad"
+    out["g15_group_grad"] = feats.grad.numpy()
+    feats2 = _t(GI.seeded_normal((2, 32, 1024), seed=11)).requires_grad_(True)
+    gathered = torch.gather(feats2, 2, _t(fps512).long().unsqueeze(1).expand(-1, 32, -1))   # subsample.py:181-183
+    assert np.array_equal(gathered.detach().numpy(), O.gather_points(feats2.detach().numpy(), fps512))
+    gout2 = _t(GI.seeded_normal((2, 32, 512), seed=13))
+    (gathered * gout2).sum().backward()
+    assert np.allclose(O.gather_points_grad(gout2.numpy(), fps512, 1024), feats2.grad.numpy(), rtol=1e-6, atol=1e-6)
+    out["g15_gather_grad"] = feats2.grad.numpy()
+    print("G15b: oracle group_points_grad / gather_points_grad == autograd through the reference's pure-torch forms")
+
+    # ---- G16: PointNet++ blocks (pointnetv2.py:17-150) over the oracle operators ----------------------------
+    ref_pn2.furthest_point_sample = _OracleOps.furthest_point_sample
+    ref_up.three_nn = _OracleOps.three_nn
+    ref_up.three_interpolate = _OracleOps._Interp.apply
+    ref_pn2.three_interpolation = ref_up.three_interpolation
+    common = dict(aggr_args={'feature_type': 'dp_fj', 'reduction': 'max'}, conv_args={'order': 'conv-norm-act'},
+                  norm_args={'norm': 'bn'}, act_args={'act': 'relu'})
+    sa1 = fill_parameters_by_name(ref_pn2.PointNetSAModuleMSG(
+        stride=4, radii=[0.1, 0.2], nsamples=[16, 32], channel_list=[[4, 16, 32], [4, 16, 32]],
+        group_args=EasyDict(NAME='ballquery', normalize_dp=False), use_res=False, **common))
+    sa2 = fill_parameters_by_name(ref_pn2.PointNetSAModuleMSG(
+        stride=4, radii=[0.4], nsamples=[32], channel_list=[[64, 64, 96]],
+        group_args=EasyDict(NAME='ballquery', normalize_dp=True), use_res=True, **common))
+    fp = fill_parameters_by_name(ref_pn2.PointNetFPModule([96 + 64, 64, 48]))
+    for mod in (sa1, sa2, fp):
+        mod.train()
+    p0 = _t(GI.unit_sphere_cloud(2, 1024, seed=161))
+    f0 = _t(GI.seeded_normal((2, 4, 1024), seed=162)).requires_grad_(True)
+    p1, f1 = sa1(p0, f0)                      # (2,256,3), (2,64,256)
+    p2, f2 = sa2(p1, f1)                      # (2,64,3),  (2,96,64)
+    up = fp(p1, p2, f1, f2)                   # (2,48,256)
+    (up * _t(GI.seeded_normal(tuple(up.shape), seed=163))).sum().backward()
+    out.update(g16_p1=p1.numpy(), g16_f1=f1.detach().numpy(), g16_p2=p2.numpy(), g16_f2=f2.detach().numpy(),
+               g16_up=up.detach().numpy(), g16_grad_f0=f0.grad.numpy(),
+               g16_grad_sa1_w=sa1.local_aggregations[1].SA_CONFIG_operator.convs[0][0].weight.grad.numpy(),
+               g16_grad_sa2_skip=sa2.local_aggregations[0].SA_CONFIG_operator.skipconv[0].weight.grad.numpy(),
+               g16_grad_fp_w=fp.convs[1][0].weight.grad.numpy())
+    for tag, mod in (("sa1", sa1), ("sa2", sa2), ("fp", fp)):
+        out[f"g16_{tag}_keys"] = np.array(sorted(mod.state_dict().keys()))
+    print("G16: PointNet++ SA (multi-scale, residual) + FP goldens:", tuple(f1.shape), tuple(f2.shape), tuple(up.shape))
+
+    path = os.path.join(HERE, "pins_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "pointnet2"):
         main()
     if what in ("all", "adaptpoint"):
         main_adaptpoint()
+    if what in ("all", "pins"):
+        main_pins()

@@ -167,7 +167,7 @@ def test_gan_step_matches_reference_trainer(dev, golden_ap, fused):
     G = fill_parameters_by_name(AdaptPointAugmentor(fused=fused)).to(dev)
     D = no_dropout(fill_parameters_by_name(PointDiscriminator1(num_classes=15, fused=fused))).to(dev)
     C = fill_parameters_by_name(PointNextSClassifier(fused=fused)).to(dev)
-    pos = torch.from_numpy(GI.unit_sphere_cloud(2, 512, seed=111))
+    pos = torch.from_numpy(GI.unit_sphere_cloud(2, 512, seed=int(golden_ap["g11_pos_seed"])))
     points = torch.cat([pos, height_channel(pos)], -1).to(dev)
     step = GanStep(G, D, C, SmoothCrossEntropy(0.3))
     grads = {}
@@ -184,12 +184,13 @@ def test_gan_step_matches_reference_trainer(dev, golden_ap, fused):
                 fc3=rel(grads["fc3"], golden_ap["g11_grad_fc3"]))
     print("train_gan step vs reference golden (fused=%s):" % fused, {k: "%.2e" % v for k, v in errs.items()})
     assert np.array_equal(res["gen"].abs().sum(-1).cpu().numpy() == 0, np.abs(ref).sum(-1) == 0)
-    # measured: gen 5e-7, losses 2e-7, fc3 1e-6, embedding (the deepest gradient) 1e-3 .. 1e-2; the head gradient
-    # has TWO outcomes on this input, 1e-5 or 2.8e-3: a near-tie in the head's neighbour selection / max (top-k of
-    # 24, then a max over them) that rounding differences of 1e-7 upstream decide -- seen with MIOpen's per-box
-    # solver choice (one box of several) and again when the per-point layers moved to csrc/pointwise.hip.
-    assert errs["gen"] < 1e-5 and errs["losses"] < 1e-5
-    assert errs["head"] < 5e-3 and errs["fc3"] < 1e-4 and errs["embed"] < 4e-2
+    # The golden's input is the one of 289 candidates whose anchor head is furthest from a discrete tie (top-24
+    # selection gap 2e-2, smallest lead of a max over the 24 neighbours 1e-5 of the feature scale; round 2's input had
+    # a near-tie there and the head gradient TWO outcomes, 1e-5 or 2.8e-3).  Measured: fused kernels head 2.2e-4,
+    # embedding (the deepest gradient: ~40 layers, batch-norm over 2 clouds) 2.0e-3; composed from PyTorch / MIOpen
+    # fp32 layers head 5.5e-6, embedding 4.1e-2 (MIOpen's convolution gradients are the less accurate ones).
+    assert errs["gen"] < 1e-5 and errs["losses"] < 1e-5 and errs["fc3"] < 1e-4
+    assert errs["head"] < (5e-4 if fused else 1e-4) and errs["embed"] < (5e-3 if fused else 8e-2)
     # Adam's first step moves every weight by lr * sign(grad): the updated tensors agree wherever the sign does
     after = G.predict_prob_layer.embedding.net[0].weight.detach().cpu().numpy()
     assert (np.abs(after - golden_ap["g11_embed_w_after"]) < 1e-5).mean() > 0.97
@@ -318,3 +319,47 @@ def test_deformation_kernel_matches_composed_form(dev, shape):
     assert rel(out, host(ref)) < 2e-6
     assert rel(lin.grad, host(lin64.grad)) < 2e-5 and rel(off.grad, host(off64.grad)) < 2e-5
     assert rel(mask0.grad, host(m64.grad)) < 2e-5
+
+
+def test_gan_step_at_the_size_the_reference_trains_at(dev):
+    """The joint step at B=32, N=2048 -- what the reference actually feeds `train_gan` (scanobjectnn.py:40: 2048 points;
+    train_autoaug.py:136-148) -- on the fused kernels against the same step composed from the unfused operators
+    (same weights, same random draws): finite, the generator moves, the two agree.  Bars a small factor above the
+    measured differences (printed), which come from the fused blocks' split-bf16 contractions (5e-5 per block)."""
+    from adaptpoint_amd.augmentor import AdaptPointAugmentor, draw_noise_on
+    from adaptpoint_amd.discriminator import PointDiscriminator1
+    from adaptpoint_amd.gan import GanStep
+    from adaptpoint_amd.pointnext import PointNextSClassifier, SmoothCrossEntropy, fill_parameters_by_name
+    B, N = 32, 2048
+    pos = torch.from_numpy(GI.unit_sphere_cloud(B, N, seed=9))
+    points = torch.cat([pos, height_channel(pos)], -1).to(dev)
+    label = torch.arange(B, device=dev) % 15
+    torch.manual_seed(3)
+    noise = draw_noise_on(dev, B, N, 4)
+    out = {}
+    for fused in (True, False):
+        G = fill_parameters_by_name(AdaptPointAugmentor(fused=fused)).to(dev)
+        D = no_dropout(fill_parameters_by_name(PointDiscriminator1(num_classes=15, fused=fused))).to(dev)
+        C = fill_parameters_by_name(PointNextSClassifier(fused=fused)).to(dev)
+        grads = {}
+        G.predict_prob_layer.embedding.net[0].weight.register_hook(lambda g, d=grads: d.__setitem__("embed", g.clone()))
+        G.predict_prob_layer.head.prob_head[0].weight.register_hook(lambda g, d=grads: d.__setitem__("head", g.clone()))
+        D.fc3.parametrizations.weight.original.register_hook(lambda g, d=grads: d.__setitem__("fc3", g.clone()))
+        w0 = G.predict_prob_layer.embedding.net[0].weight.detach().clone()
+        res = GanStep(G, D, C, SmoothCrossEntropy(0.3))(points, label, noise=noise)
+        torch.cuda.synchronize()
+        for k in ("g_loss_raw", "feedback_loss", "g_loss", "d_loss"):
+            assert torch.isfinite(res[k]), (fused, k)
+        assert not torch.equal(w0, G.predict_prob_layer.embedding.net[0].weight)
+        assert res["gen"].shape == (B, N, 3) and float(res["gen"].norm(dim=-1).max()) < 1.0
+        out[fused] = (res, grads)
+    (rf, gf), (ru, gu) = out[True], out[False]
+    errs = dict(gen=rel(rf["gen"], ru["gen"].cpu().numpy()),
+                losses=max(abs(rf[k].item() / ru[k].item() - 1) for k in ("g_loss_raw", "feedback_loss", "g_loss", "d_loss")),
+                **{k: rel(gf[k], gu[k].cpu().numpy()) for k in ("embed", "head", "fc3")})
+    print("joint step at B=32, N=2048, fused vs unfused:", {k: "%.2e" % v for k, v in errs.items()})
+    # measured: gen 9e-7, losses 2e-6, fc3 9e-7; the generator's gradients 1.8e-2 (head) and 6.8e-2 (embedding) -- the
+    # distance between the fused kernels and MIOpen's fp32 convolution gradients through ~40 layers (against the
+    # reference's golden the fused path is the closer of the two: test_gan_step_matches_reference_trainer)
+    assert errs["gen"] < 1e-5 and errs["losses"] < 1e-4 and errs["fc3"] < 1e-4
+    assert errs["head"] < 6e-2 and errs["embed"] < 0.2

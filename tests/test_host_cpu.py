@@ -132,3 +132,45 @@ def test_anchor_self_attention_mirror_reproduces_reference_on_cpu(golden):
     finally:
         monkey.undo()
     np.testing.assert_allclose(out.detach().numpy(), golden["g7_att_out"], rtol=1e-5, atol=1e-6)
+
+
+def _pointnet2_blocks():
+    from adaptpoint_amd import pointnet2 as P2
+    from adaptpoint_amd.pointnext import fill_parameters_by_name
+    common = dict(conv_args={'order': 'conv-norm-act'}, norm_args={'norm': 'bn'}, act_args={'act': 'relu'})
+    sa1 = fill_parameters_by_name(P2.SetAbstractionMSG(4, [0.1, 0.2], [16, 32], [[4, 16, 32], [4, 16, 32]],
+                                                       {'NAME': 'ballquery', 'normalize_dp': False}, use_res=False, **common))
+    sa2 = fill_parameters_by_name(P2.SetAbstractionMSG(4, [0.4], [32], [[64, 64, 96]],
+                                                       {'NAME': 'ballquery', 'normalize_dp': True}, use_res=True, **common))
+    fp = fill_parameters_by_name(P2.FeaturePropagation2([96 + 64, 64, 48]))
+    return sa1, sa2, fp
+
+
+def run_pointnet2_blocks(dev, pins, tol, grad_tol=None):
+    """PointNet++ through the boundary (G16): the mirrors of PointNetSAModuleMSG (multi-scale; residual) and
+    PointNetFPModule reproduce the REFERENCE modules' outputs and gradients (pointnetv2.py:17-150 run over the
+    oracle operators by tests/golden/make_golden.py); same parameter names as the reference."""
+    sa1, sa2, fp = (m.to(dev).train() for m in _pointnet2_blocks())
+    for tag, mod in (("sa1", sa1), ("sa2", sa2), ("fp", fp)):
+        assert sorted(mod.state_dict().keys()) == list(pins[f"g16_{tag}_keys"])
+    p0 = torch.from_numpy(GI.unit_sphere_cloud(2, 1024, seed=161)).to(dev)
+    f0 = torch.from_numpy(GI.seeded_normal((2, 4, 1024), seed=162)).to(dev).requires_grad_(True)
+    p1, f1 = sa1(p0, f0)
+    p2, f2 = sa2(p1, f1)
+    up = fp(p1, p2, f1, f2)
+    (up * torch.from_numpy(GI.seeded_normal(tuple(up.shape), seed=163)).to(dev)).sum().backward()
+    np.testing.assert_array_equal(p1.cpu().numpy(), pins["g16_p1"])
+    np.testing.assert_array_equal(p2.cpu().numpy(), pins["g16_p2"])
+    for name, got in (("f1", f1), ("f2", f2), ("up", up), ("grad_f0", f0.grad),
+                      ("grad_sa1_w", sa1.local_aggregations[1].SA_CONFIG_operator.convs[0][0].weight.grad),
+                      ("grad_sa2_skip", sa2.local_aggregations[0].SA_CONFIG_operator.skipconv[0].weight.grad),
+                      ("grad_fp_w", fp.convs[1][0].weight.grad)):
+        want = pins["g16_" + name]
+        err = float(np.abs(got.detach().cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-12))
+        assert err <= (grad_tol if (grad_tol is not None and name.startswith("grad")) else tol), (name, err)
+
+
+def test_pointnet2_blocks_match_the_reference_modules(cpu_mirrors):
+    import os
+    pins = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pins_golden.npz"))
+    run_pointnet2_blocks(torch.device("cpu"), pins, 2e-5)

@@ -172,3 +172,55 @@ def test_pointset_group_oracle_reproduces_reference_module(golden, oracle):
     assert np.abs(gp - golden["g6_pg_grad_points"]).max() < 1e-5
     assert np.abs(ga - golden["g6_pg_grad_alpha"].reshape(-1)).max() < 1e-4
     assert np.abs(gb - golden["g6_pg_grad_beta"].reshape(-1)).max() < 1e-4
+
+
+def _pins():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pins_golden.npz"))
+
+
+def _fp_levels(seed=151):
+    from oracle import oracle as O
+    cloud = GI.unit_sphere_cloud(2, 1024, seed=seed)
+    levels = [cloud]
+    for m in (512, 256, 128, 64):
+        levels.append(GI.take_points(levels[-1], O.furthest_point_sampling(levels[-1], m)))
+    return [(levels[i], levels[i + 1]) for i in range(4)]
+
+
+def three_nn_cases():
+    """(name, unknown, known) of G15: BASELINE config 1 and the four feature-propagation levels at N = 1024."""
+    from oracle import oracle as O
+    xyz = GI.config1_xyz()
+    cases = [("cfg1", xyz, GI.take_points(xyz, O.furthest_point_sampling(xyz, 512)))]
+    return cases + [(f"fp{i}", u, k) for i, (u, k) in enumerate(_fp_levels())]
+
+
+def test_interpolation_half_of_the_oracle_is_pinned_by_reference_held_code():
+    """G15 (tests/golden/make_golden.py pins): indices of the three nearest from the reference's `square_distance` +
+    sort (curvenet.py:213-222, 447-449), the interpolation and its gradient from the reference's forward
+    (curvenet.py:451-455) and autograd through it; the scatter-add gradients from autograd through
+    `torch_grouping_operation` (group.py:120-137) and `torch.gather`.  The oracle reproduces all of them."""
+    from oracle import oracle as O
+    O.build()
+    g = _pins()
+    for name, unk, kn in three_nn_cases():
+        safe = g[f"g15_{name}_safe"]
+        assert safe.mean() > 0.97
+        for v in O.ALL_DIST_VARIANTS:
+            assert np.array_equal(O.three_nn(unk, kn, v)[1][safe], g[f"g15_{name}_idx"][safe]), (name, v)
+    for name, unk, kn in (c for c in three_nn_cases() if c[0] in ("cfg1", "fp3")):
+        c = 32 if name != "fp3" else 96
+        pts = GI.seeded_normal((2, c, kn.shape[1]), seed=152)
+        idx, w = g[f"g15_{name}_idx"], g[f"g15_{name}_weight"]
+        np.testing.assert_allclose(O.three_interpolate(pts, idx, w), g[f"g15_{name}_interp"], rtol=1e-6, atol=1e-6)
+        gout = GI.seeded_normal(tuple(g[f"g15_{name}_interp"].shape), seed=153)
+        np.testing.assert_allclose(O.three_interpolate_grad(gout, idx, w, kn.shape[1]), g[f"g15_{name}_interp_grad"],
+                                   rtol=1e-6, atol=1e-6)
+    xyz = GI.config1_xyz()
+    fps512 = O.furthest_point_sampling(xyz, 512)
+    bq = O.ball_query(0.15, 32, xyz, GI.take_points(xyz, fps512))
+    np.testing.assert_allclose(O.group_points_grad(GI.seeded_normal((2, 32, 512, 32), seed=12), bq, 1024),
+                               g["g15_group_grad"], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(O.gather_points_grad(GI.seeded_normal((2, 32, 512), seed=13), fps512, 1024),
+                               g["g15_gather_grad"], rtol=1e-6, atol=1e-6)

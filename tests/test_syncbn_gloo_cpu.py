@@ -113,3 +113,44 @@ def test_syncbn_allreduce_module_equals_batchnorm_at_world_1():
         assert torch.allclose(bn.running_var, sb.running_var, rtol=1e-5) and torch.allclose(bn.running_mean, sb.running_mean, atol=1e-6)
         sb.eval(); bn.eval()
         assert torch.allclose(bn(x1), sb(x2), rtol=1e-5, atol=1e-6)
+
+
+def _cls_worker(rank, world, port, out_dir):
+    """One `ClassifierStep` (resampler + SyncBatchNorm classifier + clip + AdamW) per rank on its own clouds with
+    grad_sync = the flat all-reduce: what train_autoaug.py:275-282 wraps the classifier in."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import golden_inputs as GI
+    from oracle import cpu_block as CB
+    from adaptpoint_amd import dp
+    from adaptpoint_amd.gan import ClassifierStep
+    dp.init("gloo")
+    model = dp.convert_sync_batchnorm(_model())
+    pos = torch.from_numpy(GI.unit_sphere_cloud(4, NPTS, seed=23))       # (N == npoints: the resampler passes through)
+    points = torch.cat([pos, pos[:, :, 1:2] - pos[:, :, 1:2].min(1, keepdim=True)[0]], -1)
+    target = torch.tensor([1, 7, 3, 12])
+    sl = slice(2 * rank, 2 * rank + 2)
+    step = ClassifierStep(model, npoints=NPTS, grad_sync=dp.allreduce_mean_)
+    with CB.CpuOps():
+        step(points[sl].contiguous(), target[sl])
+    torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, f"cls{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_world2_classifier_step_keeps_the_ranks_weights_identical(tmp_path):
+    """ClassifierStep(grad_sync=...): after one step on different shards both ranks hold bit-identical weights and
+    running statistics (without the hook every rank would step on its local gradients)."""
+    mp.spawn(_cls_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(tmp_path / f"cls{r}.pt") for r in range(2))
+    ref = _model().state_dict()
+    moved = 0
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        if a[k].dtype.is_floating_point and not torch.equal(a[k], ref[k]):
+            moved += 1
+    assert moved > 50                                            # the step did update the model
