@@ -383,10 +383,12 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
             if distributed:
                 dist.barrier()
                 torch.cuda.synchronize()
+            from adaptpoint_amd import graphs
             mlp_graphs, index_graphs = {}, {}
+            r.graph_nodes = {}
             for cur in ((0, 1) if pipelined else (0,)):
                 clear_grads()
-                g = torch.cuda.CUDAGraph()
+                g = graphs.new_graph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local" if distributed else "global"):
                     if capture_collectives:
                         for i in range(spg):          # every step: fwd + bwd (+ statistics exchanges) + gradient all-reduce
@@ -394,13 +396,18 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
                             dp.allreduce_mean_([q.grad for q in params if q.grad is not None])
                     else:
                         mlp_steps(spg, cur)
+                # a memset node (PyTorch's zero fills and multi-block reductions lower to one) writes garbage from the
+                # second replay on, or aborts the process, on this stack: found HERE, before any replay, it only
+                # costs the graph (the except below falls back to eager execution)
+                r.graph_nodes["mlp"] = graphs.assert_replayable(g, "the MLP steps' graph")
                 mlp_graphs[cur] = g
                 # each capture owns its gradient tensors; a replay refreshes them in place
                 graph_grads[cur] = [q.grad for q in params if q.grad is not None]
                 if pipelined:
-                    g = torch.cuda.CUDAGraph()
+                    g = graphs.new_graph()
                     with torch.cuda.graph(g):
                         index_steps(spg, cur)
+                    r.graph_nodes["index"] = graphs.assert_replayable(g, "the index stages' graph")
                     index_graphs[cur] = g
 
             def step():
@@ -657,6 +664,7 @@ def main():
                                 ("all passes over the distinct-hit tile map; per-point sums through its inverse map "
                                  "(no float atomics: gradients bit-reproducible)" if fused_mlp else "none")),
                    "launch": (f"hipGraph replay, {spg} step(s) per graph" if use_graph else "eager"),
+                   "graph_nodes": getattr(m, "graph_nodes", None),     # node census of the captured graphs (no memset nodes)
                    "launches_per_step": ("3 forward + 4 backward on the MLP stream (BatchNorm folds and per-channel "
                                          "constants are prologues of their consumer kernels)" if fused_mlp and args.kernels == "resident" else None),
                    "pipeline": (f"index stages (FPS + ball query + occurrence statistics + tile map) of the NEXT launch's batches on a second stream, "

@@ -71,9 +71,11 @@ def main():
                     step(points, label, device_noise=True)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
+            from adaptpoint_amd import graphs as apn_graphs
+            graph = apn_graphs.new_graph()
             with torch.cuda.graph(graph):
                 captured = step(points, label, device_noise=True)
+            apn_graphs.assert_replayable(graph, "the joint step's graph")     # no memset nodes (adaptpoint_amd/graphs.py)
             run = graph.replay
         torch.cuda.reset_peak_memory_stats()
         sec = timed(run, a.iters, a.warmup)

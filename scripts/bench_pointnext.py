@@ -68,15 +68,18 @@ def main():
         torch.cuda.synchronize()
         graphs, losses, igraphs = {}, {}, {}
         for cur in ((0, 1) if a.pipeline else (0,)):
-            g = torch.cuda.CUDAGraph()
+            from adaptpoint_amd import graphs as apn_graphs
+            g = apn_graphs.new_graph()
             opt.zero_grad(set_to_none=True)
             with torch.cuda.graph(g):
                 losses[cur] = step(cur)
+            apn_graphs.assert_replayable(g, "the classifier step's graph")       # no memset nodes (adaptpoint_amd/graphs.py)
             graphs[cur] = g
             if a.pipeline:
-                g = torch.cuda.CUDAGraph()
+                g = apn_graphs.new_graph()
                 with torch.cuda.graph(g):
                     model.encoder.index_pyramid(pos, out=pyr[cur])
+                apn_graphs.assert_replayable(g, "the index pyramid's graph")
                 igraphs[cur] = g
         state = {"cur": 0}
         index_stream = torch.cuda.Stream()

@@ -157,10 +157,12 @@ def test_joint_step_replayed_from_a_hipgraph_equals_eager(dev):
     eager2, eager_w2 = eager_run()          # the same three steps again: the noise floor of the weights after Adam
     _restore(mods, opts, snap)
     gc.collect()
-    graph = torch.cuda.CUDAGraph()
+    from adaptpoint_amd import graphs
+    graph = graphs.new_graph()
     load(STEPS)
     with torch.cuda.graph(graph):
         captured = step(points, label, noise=noise)
+    print("joint step graph:", graphs.assert_replayable(graph, "the joint step's graph"))
     _restore(mods, opts, snap)                           # (capture runs nothing; make the state explicit anyway)
     replayed = []
     for i in range(STEPS):
@@ -217,10 +219,12 @@ def test_classifier_step_replayed_from_a_hipgraph_equals_eager(dev):
     eager_w = _w
     _restore((C,), (opt,), snap)
     gc.collect()
-    graph = torch.cuda.CUDAGraph()
+    from adaptpoint_amd import graphs
+    graph = graphs.new_graph()
     load(STEPS)
     with torch.cuda.graph(graph):
         _, cap_loss = step(points, target, choice=choice)
+    print("classifier step graph:", graphs.assert_replayable(graph, "the classifier step's graph"))
     _restore((C,), (opt,), snap)
     replayed = []
     for i in range(STEPS):
@@ -229,3 +233,44 @@ def test_classifier_step_replayed_from_a_hipgraph_equals_eager(dev):
         torch.cuda.synchronize()
         replayed.append({"loss": cap_loss.item()})
     _compare("classifier step", eager, replayed, (C,), eager_w, snap[0], floor=eager_w2, floor_losses=eager2)
+
+
+def test_memset_nodes_are_found_before_the_first_replay(dev):
+    """The defect behind round 2's stale reductions, and its guard: a captured hipMemsetAsync is a MEMSET node, which
+    this stack replays correctly once and with a garbage pattern afterwards (scripts/debug_graph_memset.py);
+    `graphs.assert_replayable` finds it in the captured graph, `bench.py` / the step benches then run eagerly."""
+    import ctypes
+    from adaptpoint_amd import graphs
+    hip = ctypes.CDLL("libamdhip64.so")
+    buf = torch.full((256,), 7, dtype=torch.int32, device=dev)
+
+    def with_memset():
+        st = torch.cuda.current_stream().cuda_stream
+        assert hip.hipMemsetAsync(ctypes.c_void_p(buf.data_ptr()), 0, ctypes.c_size_t(1024), ctypes.c_void_p(st)) == 0
+        buf.add_(1)
+
+    def without():
+        buf.zero_()
+        buf.add_(1)
+    for fn, has in ((with_memset, True), (without, False)):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = graphs.new_graph()
+        with torch.cuda.graph(g):
+            fn()
+        census = graphs.node_census(g)
+        print(fn.__name__, census)
+        if has:
+            assert census.get("memset", 0) == 1
+            with pytest.raises(graphs.MemsetNodeInGraph):
+                graphs.assert_replayable(g)
+        else:
+            assert census.get("memset", 0) == 0 and census.get("kernel", 0) >= 2
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            assert int(buf[0]) == 1
