@@ -538,6 +538,17 @@ def main():
     sync_bn = distributed and args.sync_bn != "off"          # auto = on, as the reference (main.py:27)
     # fewer than ~400 steps are less than 0.1 s of work: repeat the K-step block and report the median (keeps `steps` = K)
     repeats = args.repeats if args.repeats > 0 else (25 if args.steps < 400 else 1)
+    # N>1: the SAFE launch structure is measured FIRST (the step run eagerly around its collectives: nothing of RCCL
+    # inside a hipGraph), the captured-collectives structure after it: a capture that fails falls back to the former,
+    # and the line carries both figures.  (No multi-rank run of either exists: one-GPU boxes only.)
+    value_eager_collectives = None
+    if distributed and sync_bn and args.graph_collectives != "off" and not args.no_secondary:
+        import copy as _copy
+        safe_args = _copy.copy(args)
+        safe_args.graph_collectives = "off"
+        sec = max(4, min(args.steps, 40))
+        ms = measure(safe_args, dev, world, rank, local_rank, distributed, args.mlp, sync_bn, sec, 4)
+        value_eager_collectives = round(B_PER_GPU * world * sec / ms.elapsed, 2)
     m = measure(args, dev, world, rank, local_rank, distributed, args.mlp, sync_bn, args.steps, args.warmup, repeats)
     elapsed, spg, use_graph, pipelined, fused_mlp, eager_step = (m.elapsed, m.spg, m.use_graph, m.pipelined,
                                                                  m.fused_mlp, m.eager_step)
@@ -677,6 +688,8 @@ def main():
                                   + ("+collectives-in-graph" if getattr(m, "capture_collectives", False) else "")},
         "roofline": roofline,
     }
+    if value_eager_collectives is not None:
+        result["value_eager_collectives"] = value_eager_collectives
     if not args.no_secondary:
         sec_steps = max(4, min(args.steps, 40))
         if distributed and sync_bn:

@@ -47,3 +47,16 @@ def test_bench_distributed_other_paths_world1(dev):
     assert d["config"]["launch"].startswith("hipGraph replay") and "value_no_syncbn" not in d
     d = _run(["--mlp", "torch-f32", "--steps", "10", "--warmup", "2", "--no-secondary", "--graph-collectives", "off"], 29733)
     assert "syncbn" in d["config"]["parallelism"] and d["value"] > 0
+
+
+def test_captured_and_eager_collectives_give_the_same_gradients_world1(dev):
+    """The two launch structures of the N>1 path -- collectives captured into the hipGraph, or the step run eagerly
+    around them -- are the same computation: identical gradients (up to the order of the backward's float atomics)
+    at world_size 1, and no memset node in the captured graph (tests/dp_structures_helper.py)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29735")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_structures_helper.py")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    print("captured vs eager collectives:", d)
+    assert d["max_rel_diff"] < 1e-4 and d["graph_nodes"].get("memset", 0) == 0 and d["graph_nodes"]["kernel"] >= 7
