@@ -603,23 +603,38 @@ __global__ __launch_bounds__(SA_WAVES * 64, 3) void sa_fwd_main_kernel(
             const float sgn = h ? sg[1] : sg[0];
             float *ys = ysel + (size_t)q0 * SA_C2 + lane;
             unsigned char *ks = ksel + (size_t)q0 * SA_C2 + lane;
-            unsigned todo = starts;
-#pragma unroll 1
-            for (int jq = 0; jq < nq; ++jq) {
-                const int ra = __builtin_ctz(todo);
-                todo &= todo - 1u;
-                const int rb = todo ? __builtin_ctz(todo) : 32;
-                float best = mine[ra * 33];
-                int kpos = 0;
-#pragma unroll 1
-                for (int rho = ra + 1; rho < rb; ++rho) {
-                    const float v = mine[rho * 33];
-                    const bool up = v > best;
-                    best = up ? v : best;
+            // all 32 rows are read, sixteen at a time into registers (independent LDS reads, one wait per half: a loop
+            // over a query's rows paid one LDS round trip per row, ~1.2 us per tile); a row that starts a query
+            // (wave-uniform bit of `starts`; the first padding row starts a segment of its own, never stored) first
+            // flushes the query before it
+            int seg = -1, ra = 0, kpos = 0;
+            float best = 0.0f;
+#pragma unroll
+            for (int half16 = 0; half16 < 2; ++half16) {
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = mine[(16 * half16 + i) * 33];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rho = 16 * half16 + i;
+                    if ((starts >> rho) & 1u) {
+                        if (seg >= 0 && seg < nq) {
+                            ys[(size_t)seg * SA_C2] = sgn * best;
+                            ks[(size_t)seg * SA_C2] = (unsigned char)kpos;
+                        }
+                        ++seg;
+                        best = -__builtin_inff();
+                        kpos = 0;
+                        ra = rho;
+                    }
+                    const bool up = v[i] > best;
+                    best = up ? v[i] : best;
                     kpos = up ? rho - ra : kpos;
                 }
-                ys[(size_t)jq * SA_C2] = sgn * best;
-                ks[(size_t)jq * SA_C2] = (unsigned char)kpos;
+            }
+            if (seg >= 0 && seg < nq) {
+                ys[(size_t)seg * SA_C2] = sgn * best;
+                ks[(size_t)seg * SA_C2] = (unsigned char)kpos;
             }
             asm volatile("" ::: "memory");
         }
@@ -987,17 +1002,26 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 asm volatile("" ::: "memory");
                 const float *mine = gt + h * (32 * 33) + r;
                 float *dst = (h ? HB : HA) + (size_t)q0 * SA_C1 + r;
-                unsigned todo = starts;
-#pragma unroll 1
-                for (int jq = 0; jq < nq; ++jq) {
-                    const int ra = __builtin_ctz(todo);
-                    todo &= todo - 1u;
-                    const int rb = todo ? __builtin_ctz(todo) : 32;
-                    float sum = 0.0f;
-#pragma unroll 1
-                    for (int rho = ra; rho < rb; ++rho) sum += mine[rho * 33];
-                    dst[(size_t)jq * SA_C1] = sum;
+                // (all 32 rows, sixteen at a time into registers: independent LDS reads, one wait per half -- a loop over
+                // a query's rows paid one LDS round trip per row; a row that starts a query flushes the one before it)
+                int seg = -1;
+                float sum = 0.0f;
+#pragma unroll
+                for (int half16 = 0; half16 < 2; ++half16) {
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = mine[(16 * half16 + i) * 33];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if ((starts >> (16 * half16 + i)) & 1u) {
+                            if (seg >= 0 && seg < nq) dst[(size_t)seg * SA_C1] = sum;
+                            ++seg;
+                            sum = 0.0f;
+                        }
+                        sum += v[i];
+                    }
                 }
+                if (seg >= 0 && seg < nq) dst[(size_t)seg * SA_C1] = sum;
                 // the image's region: cleared for the next tile
                 asm volatile("" ::: "memory");
                 {
