@@ -45,7 +45,6 @@
 // Roofline: compulsory HBM traffic of pass 2 at B=32 is xyz 0.4 + idx 2.1 + ft 2.1
 // + out 2 x 4.2 MB ~ 13 MB (1.6 us at 8 TB/s); bf16 MFMA work 7 x 32 cycles per tile.
 // Both are far below the per-tile VALU/gather latency, which is what bounds it.
-#include <stdlib.h>
 #include "apn_common.h"
 #include "apn_mfma.h"
 #include "sa_chain.h"
@@ -103,7 +102,7 @@ struct SaArgs {
 // wall-clock stamp k of this wave (100 MHz counter, chip-wide), when a stamp buffer is attached
 __device__ __forceinline__ void stamp(const SaArgs &a, int wave, int k) {
     if (a.stamps && (threadIdx.x & 63) == 0)
-        a.stamps[((size_t)blockIdx.x * SA_WAVES + wave) * 8 + k] = wall_clock64();
+        a.stamps[((size_t)blockIdx.x * SA_WAVES + wave) * 16 + k] = wall_clock64();
 }
 
 // With a tile map (CP) a tile is 32 ROWS = (query, distinct neighbour, multiplicity) instead of one query's 32
@@ -349,6 +348,15 @@ __device__ __forceinline__ void build_frags(const SaArgs &a, const TileRaw<NS> &
 // after the last tile: the place for stores / atomics deferred from the previous tile.  The
 // memory counter is in order, so anything issued between a prefetch and the wait for it is
 // waited for too; deferred to here, the atomics of tile t have the whole of tile t+1 to retire.
+// Make a tile head's three words ARRIVE here.  The wait the compiler places before a dependent use is vmcnt(0)
+// whenever the number of memory operations issued since the load is not a compile-time constant (loops over a
+// tile's queries, stores under wave-uniform branches): placed where only older loads are in flight it costs
+// nothing; placed behind a tile's scatter atomics / pooled stores -- where the next prefetch used to meet it -- it
+// drained those first (measured: 2.4 us between two tiles of the backward pass).
+__device__ __forceinline__ void touch(const TileHead &hd) {
+    asm volatile("" ::"v"(hd.nb), "v"(hd.info), "v"(hd.q0));
+}
+
 template <int NS, bool CP, typename Pro, typename Pre, typename Body>
 __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Pro prologue, Pre pre, Body body) {
     const int cap = a.b * a.m, stride = gridDim.x * SA_WAVES;
@@ -368,10 +376,11 @@ __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, 
     int nst = 3;
     for (; tile < tiles; tile += stride) {
         const bool more = tile + stride < tiles;               // wave-uniform
+        touch(hd_nxt);
         pre();
         if (more) fetch_tile<NS>(a, hd_nxt, h, nxt);
         const TileHead hd_nxt2 = load_head<CP>(a, tile + 2 * stride < tiles ? tile + 2 * stride : tile, r);
-        body(tile, cur);
+        body(tile, cur, nst == 4, [&] { touch(hd_nxt2); });
         stamp(a, wave, nst < 5 ? nst : 5);
         ++nst;
         if (more) cur = nxt;
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 3) void sa_fwd_main_kernel(
         __syncthreads();
     };
 
-    for_each_tile<NS, CP>(a, wave, r, h, prologue, [] {}, [&](int tile, const TileRaw<NS> &raw) {
+    for_each_tile<NS, CP>(a, wave, r, h, prologue, [] {}, [&](int tile, const TileRaw<NS> &raw, bool, auto before_stores) {
         int lane_o = lane;                       // see sa_bwd_kernel: fragments are read per use
         asm volatile("" : "+v"(lane_o));
         Frag<NS> x[3];
@@ -603,6 +612,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 3) void sa_fwd_main_kernel(
             const float sgn = h ? sg[1] : sg[0];
             float *ys = ysel + (size_t)q0 * SA_C2 + lane;
             unsigned char *ks = ksel + (size_t)q0 * SA_C2 + lane;
+            before_stores();
             // all 32 rows are read, sixteen at a time into registers (independent LDS reads, one wait per half: a loop
             // over a query's rows paid one LDS round trip per row, ~1.2 us per tile); a row that starts a query
             // (wave-uniform bit of `starts`; the first padding row starts a segment of its own, never stored) first
@@ -688,7 +698,6 @@ struct SaBwdArgs {
     int train2;
     const float *goa;       // (B,M,64)
     const unsigned char *ksel;  // (B,M,64)
-    int knock;              // EXPERIMENT
 };
 
 // Backward launch 2 of 4.  Prologue (every workgroup, same bits): the per-channel constants of
@@ -742,7 +751,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             for (int k = 0; k < 8; ++k) wv[k] = g.w2[tid + 256 * k];
             double sv = 0.0, count = g.count;                // S[tid] (threads 0..127: one column each)
             float p_sc = 0.0f, p_mu = 0.0f, p_iv = 0.0f;
-            if (tid < 128 && !(g.knock & 1)) sv = g.sumsS ? g.sumsS[tid] : acc_read(g.accS, 128, tid);
+            if (tid < 128) sv = g.sumsS ? g.sumsS[tid] : acc_read(g.accS, 128, tid);
             if (g.sumsS) count = g.sumsS[128];
             if (tid < 64) { p_sc = g.pack2[tid]; p_mu = g.pack2[128 + tid]; p_iv = g.pack2[192 + tid]; }
             if (wave == 0) {
@@ -820,12 +829,14 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 const int n0 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 0));
                 const int n1 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 1));
                 const int nn = h ? n1 : n0;
-                if (acc_row(i, h) < pend_live && !(g.knock & 4)) atomicAdd(Ac + (size_t)nn * SA_C1, pend_g[i]);
+                if (acc_row(i, h) < pend_live) atomicAdd(Ac + (size_t)nn * SA_C1, pend_g[i]);
             }
         }
         pend_live = 0;
     };
-    for_each_tile<NS, CP>(a, wave, r, h, prologue, scatter_pending, [&](int tile, const TileRaw<NS> &raw) {
+    for_each_tile<NS, CP>(a, wave, r, h, prologue, scatter_pending, [&](int tile, const TileRaw<NS> &raw, bool probe, auto before_stores) {
+        auto st2 = [&](int k) { if (probe) stamp(a, wave, 8 + k); };
+        st2(0);
         // the constant fragments are READ PER USE: an opaque copy of the lane id keeps the
         // compiler from hoisting these loop-invariant LDS reads back into ~130 registers
         int lane_o = lane;
@@ -885,6 +896,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 yT[4 * i4 + 3] = __builtin_fmaxf(__builtin_fmaf(yT[4 * i4 + 3], sc.w, sh.w), 0.0f);
             }
         }
+        st2(1);
         // operand of the Qm product: a1, weighted by the row's multiplicity (the dense part of dL/dy2 reaches
         // every one of the positions the row stands for)
         Frag<NS> a0, a1;
@@ -947,6 +959,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 }
             }
         }
+        st2(2);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const __bf16 *src = sp_img + r * SP_ROW + 16 * s + 8 * h;
@@ -968,6 +981,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
 #pragma unroll
         for (int s = 0; s < 4; ++s) ga = mfma<NS>(sp[s], get_frag<NS>(cfrag, F_W2T + s, lane_o), ga);
 
+        st2(3);
         f32x16 an;   // a1 in the [lane = mid] layout: both operands of the Gram product
         // (tile map) g_u and multiplicity * yhat1 of every row also go to two wave-private LDS tiles [row][mid] (the
         // image's region: the image is dead until the next tile), for the sums per query below
@@ -994,6 +1008,8 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         st[0] += s1;
         st[1] += s2;
 
+        st2(4);
+        before_stores();
         {   // sums per query and per source point
             int live;
             if (CP) {
@@ -1059,6 +1075,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 pend_cloud = q0 / a.m;
             }
 
+            st2(5);
             // Gram += a1^T a1 (one side weighted by the multiplicity): the k index (positions, accumulator-row
             // order) pairs the same registers
             {
@@ -1074,6 +1091,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                     gram = mfma<NS>(b1, b1, gram);
                 }
             }
+            st2(6);
             if (CP) {
                 // the tile's per-point sums, scattered at the END of the tile: behind every load of this iteration and
                 // ahead of the next iteration's prefetch (the memory counter is in order: they retire behind a whole
@@ -1085,7 +1103,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                         const int n0 = __builtin_amdgcn_readlane(nb, acc_row(i, 0));
                         const int n1 = __builtin_amdgcn_readlane(nb, acc_row(i, 1));
                         const int nn = h ? n1 : n0;
-                        if (acc_row(i, h) < live && !(g.knock & 4)) atomicAdd(Ac + (size_t)nn * SA_C1, ga[i]);
+                        if (acc_row(i, h) < live) atomicAdd(Ac + (size_t)nn * SA_C1, ga[i]);
                     }
                 }
             }
@@ -1095,7 +1113,6 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         const float tot = fold_partials<2>(st, lane, wave);
         if (threadIdx.x < 64) acc_add(accT, 64, blockIdx.x % ACC_COPIES, threadIdx.x, tot);
     }
-    if (g.knock & 2) return;
     // The workgroup's share of dL/dW2: fold the four waves' sparse parts in LDS (kept in registers: thread t owns
     // elements t + 256 j), then Gram and suma, then  row[c][mid] = sparse + D2[c] (W2 Gram)[c][mid] + E2[c] suma[mid].
     float (*wred)[SA_C2 * SA_C1] = reinterpret_cast<float (*)[SA_C2 * SA_C1]>(sp_raw);   // images are dead
@@ -1171,7 +1188,7 @@ static int sa_grid(int tiles, bool compact = false) {
 // 153k clouds/s, five interleaved runs each).
 static int sa_grid_bwd(int tiles) {
     int g = sa_grid(tiles);
-    return g < 448 ? g : 448;
+    return g < 448 ? g : 448;      // (round 3, over the tile map: 320 / 384 / 448 / 512 workgroups -> 224 / 231 / 233 / 230 k clouds/s)
 }
 
 }  // namespace apn
@@ -1213,7 +1230,7 @@ extern "C" int apn_sa_prep_stats(int b, int n, const float *f, const void *geo, 
 }
 
 static unsigned long long *g_stamps = nullptr;
-// Diagnostics: attach (or detach: NULL) a buffer of 8 x (workgroups x 4) 64-bit stamps; the next launches of the two
+// Diagnostics: attach (or detach: NULL) a buffer of 16 x (workgroups x 4) 64-bit stamps; the next launches of the two
 // tile passes record per wave the wall clock at {0: entry, 1: tile count known, 2: prologue done, 3..5: tiles done,
 // 6: loop done, 7: kernel end} (scripts/stamp_passes.py).  Not for concurrent use.
 extern "C" int apn_sa_debug_stamps(void *buf) { g_stamps = (unsigned long long *)buf; return APN_OK; }
@@ -1272,7 +1289,6 @@ extern "C" int apn_sa_bwd_main(int b, int n, int m, int precision, float radius,
     g.accS = (const unsigned long long *)accS; g.sumsS = sumsS;
     g.count = count; g.train2 = train2;
     g.goa = goa; g.ksel = (const unsigned char *)ksel;
-    { static int kn = -1; if (kn < 0) { const char *e = getenv("APN_KNOCK"); kn = e ? atoi(e) : 0; } g.knock = kn; }
     auto kern = precision == 2 ? (tmap ? sa_bwd_kernel<2, true> : sa_bwd_kernel<2, false>)
                                : (tmap ? sa_bwd_kernel<1, true> : sa_bwd_kernel<1, false>);
     hipLaunchKernelGGL(kern, dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, g,

@@ -17,12 +17,15 @@ from adaptpoint_amd import _lib, fused  # noqa: E402
 
 
 def report(name, st):
-    st = st.reshape(-1, 8).astype(np.int64)
+    st = st.reshape(-1, 16).astype(np.int64)
     live = st[:, 0] > 0
     st = st[live]
     t0 = st[:, 0].min()
     print(f"{name}: {live.sum()} waves")
-    for k, label in enumerate(["entry", "tiles known", "prologue done", "tile 1", "tile 2", "tile 3+", "loop done", "end"]):
+    labels = ["entry", "tiles known", "prologue done", "tile 1", "tile 2", "tile 3+", "loop done", "end",
+              "t2: body start", "t2: conv1+bn", "t2: sparse drops", "t2: dL/da1 mfma", "t2: stats", "t2: per-query sums",
+              "t2: gram", "-"]
+    for k, label in enumerate(labels):
         v = st[:, k]
         v = v[v > 0]
         if len(v):
@@ -44,7 +47,7 @@ def main():
         _, out = blk([p, f], sampling=smp)
         torch.autograd.backward([out], [ones.expand_as(out)])
     torch.cuda.synchronize()
-    buf = torch.zeros(8 * 4 * 1024, dtype=torch.int64, device=dev)
+    buf = torch.zeros(16 * 4 * 1024, dtype=torch.int64, device=dev)
     fused.PER_KERNEL_LAUNCH = True
     orig = fused._call
 
