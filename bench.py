@@ -151,12 +151,13 @@ def instrument(timer, only=None):
         if only is not None and short not in only:
             return orig_call(name, dev, *a, **kw)
         return timer.wrap(short, orig_call)(name, dev, *a, **kw)
-    fused._call = fused_call
+    from adaptpoint_amd import fused_wide
+    fused._call = fused_wide._call = fused_call     # (the width-generic family launches through its own import of it)
 
     def restore():
         for k, v in saved.items():
             setattr(ops, k, v)
-        fused._call = orig_call
+        fused._call = fused_wide._call = orig_call
         fused.PER_KERNEL_LAUNCH = False
     return restore
 
@@ -606,7 +607,7 @@ def main():
     # the index kernels count with their per-step share.
     index_names = {"fps", "ball_query", "fps+ball_query", "sa_point_geo"}
     per_step_us = {k: (us / m.index_batch if k in index_names else us) for k, us in per_kernel_us.items()}
-    cand = {k: v for k, v in per_step_us.items() if not (pipelined and k in index_names)}
+    cand = {k: v for k, v in per_step_us.items() if not (pipelined and k in index_names)} or per_step_us
     dominant = max(cand, key=cand.get)
     dom_us = per_kernel_us[dominant]
     split = 3 if args.mlp.endswith("x3") else 1
@@ -615,7 +616,11 @@ def main():
     # product a1^T a1 (2*32*32) per position (after the Gram reformulation of dL/dW2: DESIGN.md section 4).
     pos = B_PER_GPU * NPOINT * NSAMPLE
     mfma_flops = {"sa_fwd_main": pos * (2 * 35 * 32 + 2 * 32 * 64),
-                  "sa_bwd_main": pos * (2 * 2 * 35 * 32 + 2 * 2 * 32 * 32 + 2 * 64 * 32)}
+                  "sa_bwd_main": pos * (2 * 2 * 35 * 32 + 2 * 2 * 32 * 32 + 2 * 64 * 32),
+                  # the width-generic family: conv1 hoisted to the points, y2 = a1 W2^T forward; dL/da1 over k = [C_out; C_mid]
+                  # and the Gram / pooled-row products backward
+                  "sa_wide_fwd_main": pos * (2 * 32 * 64),
+                  "sa_wide_bwd_main": pos * (2 * (64 + 32) * 32 + 2 * 32 * 32)}
     if dominant in mfma_flops:
         tf = mfma_flops[dominant] / dom_us * 1e-6
         roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS,

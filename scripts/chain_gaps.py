@@ -7,10 +7,10 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 first = sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 def short(n):
-    m = re.search(r"apn::(\w+)", n)
+    m = re.search(r"apn::(\w+)", n) or re.search(r"_ZN3apn\d+([A-Za-z_0-9]+?)(?:ILi|E)", n)
     return m.group(1) if m else n[:40]
 # the feature stream = everything but the index stage's kernels
-SIDE = ("fps_", "ball_query", "tilemap_", "csr_", "sample")
+SIDE = ("fps_", "ball_query", "tilemap_", "csr_", "sample", "sa_geo")
 main = [r for r in rows if not any(k in r["Kernel_Name"] for k in SIDE)]
 marks = [i for i, r in enumerate(main) if first in r["Kernel_Name"]]
 lo, hi = marks[-steps - 1], marks[-1]

@@ -9,7 +9,8 @@ import csv
 import json
 import sys
 
-ALIAS = {"fps_atomic_kernel": "fps", "ball_query_kernel": "ball_query",
+ALIAS = {"fps_atomic_kernel": "fps", "ball_query_kernel": "ball_query", "sa_prep_stats_kernel": "sa_prep_stats",
+         "sa_geo_kernel": "sa_point_geo",
          "sa_prep_features_kernel": "sa_prep_features", "sa_fwd_stats1_kernel": "sa_fwd_stats1",
          "sa_fwd_main_kernel": "sa_fwd_main", "fwd_out_kernel": "sa_fwd_out",
          "bwd_prep_kernel": "sa_bwd_prep", "sa_bwd_kernel": "sa_bwd_main",
@@ -25,10 +26,12 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = ALIAS.get(r["kernel"])
     if k and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
         out[k] = int(round((2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024))
-json.dump({"_note": "HBM bytes per launch at B=32 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
-                    "passes, bench.py --steps 20 --warmup 5 --graph off --pipeline off, default bf16x3 "
-                    "precision; scripts/collect_profiles.sh pmc), averaged over all dispatches of the pass; "
+json.dump({"structure": "default",
+           "_note": "HBM bytes per launch (B=32 per MLP-stream launch; the index-stream launches cover 20 batches) from "
+                    "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over bench.py's DEFAULT launch structure "
+                    "(hipGraph replay, index stages on the second stream, tile map; bf16x3; "
+                    "scripts/collect_profiles.sh pmc), averaged over all dispatches of the pass; "
                     "FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950, WRITE_SIZE "
-                    "taken as is. Summary: " + sys.argv[1],
+                    "taken as is. Summary: profiles/" + __import__("os").path.basename(sys.argv[1]),
            "bytes_per_launch": out}, open(sys.argv[2], "w"), indent=1)
 print(out)

@@ -14,7 +14,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"apn::(\w+)", name)
+    m = re.search(r"apn::(\w+)", name) or re.search(r"_ZN3apn\d+([A-Za-z_0-9]+?)(?:ILi|E)", name)
     if m:
         return "apn::" + m.group(1)
     name = re.sub(r"^void ", "", name)
