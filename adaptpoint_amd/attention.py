@@ -75,6 +75,19 @@ def attention(q, k, v, heads):
     return _Attention.apply(q, k, v, heads)
 
 
+def _mean_over_points(xyz):
+    """xyz (B,M,3) -> (B,1,3): the mean over the M points (generator_component4_15.py:449: torch.mean(xyz, dim=1)).
+    On the GPU in two stages of 64: at M = 2048 PyTorch's strided reduction over dim 1 becomes a multi-block one, whose
+    semaphore buffer is zeroed by a MEMSET before every launch -- captured into a hipGraph that node replays correctly
+    once and with garbage afterwards (adaptpoint_amd/graphs.py): the joint step at N = 2048 then trained on stale
+    centres from its second replay on.  (Contiguous rows of 64, then of M / 64: one block per output, no semaphores.)"""
+    B, M, C = xyz.shape
+    if not xyz.is_cuda or M % 64:
+        return torch.mean(xyz, dim=1, keepdim=True)
+    t = xyz.transpose(1, 2).reshape(B, C, M // 64, 64).sum(-1).sum(-1)
+    return (t / M).unsqueeze(1)
+
+
 class AnchorSelfAttention(nn.Module):
     """generator_component4_15.py:434-481 (`Anchor_selfattention`)."""
 
@@ -90,7 +103,7 @@ class AnchorSelfAttention(nn.Module):
 
     def forward(self, x, xyz=None):
         """x (B,M,C), xyz (B,M,3) -> (B,M,C)."""
-        gravity_center = torch.mean(xyz, dim=1, keepdim=True)
+        gravity_center = _mean_over_points(xyz)
         relative_xyz = xyz - gravity_center
         emb = self.pos_embedding(relative_xyz.permute(0, 2, 1)).permute(0, 2, 1)
         q, k, v = self.to_qkv(x).chunk(3, dim=-1)

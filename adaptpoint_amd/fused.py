@@ -33,6 +33,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import _lib
+from . import ops as _ops
 
 C_IN, C_MID, C_OUT, K_NS = 32, 32, 64, 32
 # The register-resident passes run over the distinct-hit tile map of the index stage (fused_wide.tile_map): 3.7x fewer
@@ -300,7 +301,7 @@ def _backward(fw, g_out, need_p, need_newp):
            ("bs", C_OUT if (has_skip and sv["has_bs"]) else 0)]
     g, _gbuf = _carve(dev, gsz)           # every view is fully written
     g_f = torch.empty(B, C_IN, N, **f32)
-    g_p = torch.zeros(B, N, 3, **f32) if need_p else None
+    g_p = _ops.zeros(B, N, 3, **f32) if need_p else None
     g_newp = torch.empty(B, M, 3, **f32) if need_newp else None
     gws = g["ws"].data_ptr() if has_skip else None
     gbs = g["bs"].data_ptr() if (has_skip and sv["has_bs"]) else None

@@ -60,7 +60,7 @@ def ball_query(radius, nsample, xyz, new_xyz):
     _need_contiguous(xyz=xyz, new_xyz=new_xyz)
     B, N = xyz.shape[:2]
     M = new_xyz.shape[1]
-    nbr = torch.zeros(B, M, nsample, dtype=torch.int32, device=xyz.device)
+    nbr = ops.zeros(B, M, nsample, dtype=torch.int32, device=xyz.device)
     ops.ball_query_wrapper(B, N, M, radius, nsample, new_xyz, xyz, nbr)
     return nbr
 
@@ -102,7 +102,7 @@ class _TakeRows(Function):
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
         B, C = g.shape[:2]
-        acc = torch.zeros(B, C, ctx.n_rows, dtype=torch.float32, device=g.device)
+        acc = ops.zeros(B, C, ctx.n_rows, dtype=torch.float32, device=g.device)
         g = g.contiguous()
         if idx.dim() == 2:
             ops.gather_points_grad_wrapper(B, C, ctx.n_rows, idx.shape[1], g, idx, acc)
@@ -144,7 +144,7 @@ class _Blend3(Function):
     def backward(ctx, g):
         idx, weight = ctx.saved_tensors
         B, C, n = g.shape
-        acc = torch.zeros(B, C, ctx.m, dtype=torch.float32, device=g.device)
+        acc = ops.zeros(B, C, ctx.m, dtype=torch.float32, device=g.device)
         ops.three_interpolate_grad_wrapper(B, C, n, ctx.m, g.contiguous(), idx, weight, acc)
         return acc, None, None
 

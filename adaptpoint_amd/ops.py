@@ -19,7 +19,7 @@ __all__ = [
     "gather_points_wrapper", "gather_points_grad_wrapper",
     "furthest_point_sampling_wrapper", "three_nn_wrapper",
     "three_interpolate_wrapper", "three_interpolate_grad_wrapper",
-    "resample_points_wrapper",
+    "resample_points_wrapper", "zeros",
 ]
 
 
@@ -49,6 +49,23 @@ def _launch(fn_name, dev, *args):
 
 
 f32, i32 = torch.float32, torch.int32
+
+
+def zeros(*shape, dtype=torch.float32, device=None):
+    """A zero-filled tensor whose fill is a KERNEL on the tensor's current stream.  `torch.zeros` lowers to
+    hipMemsetAsync for buffers of a few megabytes; captured into a hipGraph that is a memset node, which this stack
+    replays correctly once and with a garbage pattern afterwards (adaptpoint_amd/graphs.py) -- the caller-zeroed
+    buffers of the extension's contract (ball-query indices, gradient targets) must survive replay."""
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if not t.is_cuda:
+        return t.zero_()
+    nbytes = t.numel() * t.element_size()
+    if nbytes == 0:
+        return t
+    if nbytes % 16 or t.data_ptr() % 16:
+        return t.fill_(0)
+    _launch("apn_zero_fill", t.device, t.data_ptr(), nbytes)
+    return t
 
 
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):

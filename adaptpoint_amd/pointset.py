@@ -12,7 +12,7 @@ state_dict loads unchanged.
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, ops
 from .fused import _call
 from .layers import ball_query, furthest_point_sample
 
@@ -46,7 +46,7 @@ class _GroupMax(torch.autograd.Function):
         B, N, C = points.shape
         M, K = idx.shape[1], idx.shape[2]
         g = g.contiguous().float()
-        g_points = torch.zeros_like(points)
+        g_points = ops.zeros(*points.shape, dtype=points.dtype, device=points.device)
         rows = _lib.load().apn_pointset_group_rows(B, M, C)
         part = torch.empty(rows, 2 * C, dtype=torch.float32, device=points.device)
         _call("apn_pointset_group_max_grad", points.device, B, N, M, C, K, points.data_ptr(),

@@ -605,7 +605,7 @@ def main():
     # stage on its own stream (one sampler launch per `index_batch` steps) that is the MLP stream; its kernels
     # launch once per step, so total = average launch duration.  Without the pipeline everything is one stream and
     # the index kernels count with their per-step share.
-    index_names = {"fps", "ball_query", "fps+ball_query", "sa_point_geo"}
+    index_names = {"fps", "ball_query", "fps+ball_query", "sa_point_geo", "sa_wide_tilemap", "sa_wide_tilemap_many", "sa_wide_csr"}
     per_step_us = {k: (us / m.index_batch if k in index_names else us) for k, us in per_kernel_us.items()}
     cand = {k: v for k, v in per_step_us.items() if not (pipelined and k in index_names)} or per_step_us
     dominant = max(cand, key=cand.get)
