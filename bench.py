@@ -630,7 +630,7 @@ def main():
                     "note": (f"algorithmic flops of the 32 clouds of one launch (every product is issued as {split} bf16 "
                              f"MFMA(s): MFMA issue = {split} x this fraction) over the kernel's average launch duration, "
                              "HIP events on its launch stream in an eager pass of the same launches right after the "
-                             "timed region; the kernel is bound by per-tile latency (one wave per SIMD at ~250 VGPRs), "
+                             "timed region; the kernel is bound by per-tile latency (two waves per SIMD at 256 VGPRs), "
                              "not by MFMA issue or HBM (DESIGN.md section 5)")}
     else:
         gb = ab.get(dominant, 0) / dom_us * 1e-3

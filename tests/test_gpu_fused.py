@@ -167,12 +167,14 @@ def test_set_abstraction_fused_equals_unfused(dev, precision):
     assert torch.equal(pa, pb)
     oa.sum().backward(); ob.sum().backward()
     # the unfused side is MIOpen fp32 (Winograd-class kernels, ~1e-3); bf16x3 sits at that level
-    fo, fg, fw_ = (1.5e-1, 0.25, 0.15) if precision == "bf16" else (1e-2, 2e-2, 2e-2)
+    # ten times the measured differences (bf16x3: out 4.9e-5 max / 5.7e-6 mean, gradients <= 1.9e-3; bf16: 2.6e-2 /
+    # 3.0e-3, gradients <= 1.0e-1 through the arg-max flips at 2^-8)
+    fo, fg, fw_ = (1.5e-1, 0.25, 0.3) if precision == "bf16" else (5e-4, 2e-2, 2e-2)
     werr = {k: _rel_l2(qb.grad, qa.grad) for (k, qa), (_, qb) in zip(a.named_parameters(), b.named_parameters())}
     print("fused vs unfused (%s): out max %.2e mean %.2e, grad f %.2e, weights %s" % (
         precision, (oa - ob).abs().max(), (oa - ob).abs().mean(), _rel_l2(f2.grad, f1.grad),
         {k: "%.1e" % v for k, v in werr.items()}))
-    assert (oa - ob).abs().max() <= fo and (oa - ob).abs().mean() <= fo / 15
+    assert (oa - ob).abs().max() <= fo and (oa - ob).abs().mean() <= fo / 8
     assert _rel_l2(f2.grad, f1.grad) <= fg
     for k, v in werr.items():
         assert v <= fw_, k
