@@ -51,10 +51,10 @@ SIGNATURES = {
                       + [_c_int] + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 2 + [_c_longlong, _c_void_p],
     "apn_sa_bwd_prep_rows": [_c_int] * 2,
     "apn_sa_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] + [_c_int]
-                       + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 7,
-    "apn_sa_bwd_main": [_c_int] * 4 + [_c_float] + [_c_void_p] * 11 + [_c_double, _c_int] + [_c_void_p] * 8,
+                       + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 8,
+    "apn_sa_bwd_main": [_c_int] * 4 + [_c_float] + [_c_void_p] * 11 + [_c_double, _c_int] + [_c_void_p] * 9,
     "apn_sa_bwd_weight_rows": [_c_int] * 2,
-    "apn_sa_bwd_point_grads": [_c_int] * 3 + [_c_void_p] * 6 + [_c_double, _c_int] + [_c_void_p] * 2 + [_c_int]
+    "apn_sa_bwd_point_grads": [_c_int] * 3 + [_c_void_p] * 7 + [_c_double, _c_int] + [_c_void_p] * 2 + [_c_int]
                               + [_c_void_p] * 4 + [_c_float] + [_c_void_p] * 5,
     "apn_sa_bwd_finalize": [_c_void_p, _c_int, _c_float, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int]
                            + [_c_void_p] * 11,
@@ -65,7 +65,7 @@ SIGNATURES = {
     "apn_sa_backward_seq": ([_c_int] * 5 + [_c_float] + [_c_void_p] * 15 + [_c_int] * 3
                             + [_c_double] + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p]
                             + [_c_longlong]
-                            + [_c_void_p] * 24),
+                            + [_c_void_p] * 25),
     "apn_attention_prep": [_c_int] * 3 + [_c_void_p] * 4 + [_c_int, _c_void_p],
     "apn_attention_fwd": [_c_int] * 3 + [_c_void_p] * 4,
     "apn_attention_bwd": [_c_int] * 3 + [_c_void_p] * 9,

@@ -147,6 +147,9 @@ __global__ __launch_bounds__(256) void pointset_group_max_grad_kernel(
 // (ds_add_f32) and the tile leaves with plain coalesced stores -- no global float atomics (the scatter above issues
 // 2 b m c of them: 116 us per stage at b = 32, the atomic units' rate).  Rows of `part`: the cloud's first row holds
 // the block's {dalpha, dbeta} shares, its other rows are zeroed for these channels.
+// NOT run-to-run bit-reproducible: several (query, channel-group) threads of the workgroup can add into the same
+// cell and float addition order follows wave scheduling (last-bit differences in g_points; dalpha / dbeta are
+// fixed-order).  No replay-identity test depends on this gradient (tests compare it to a reference at 1e-5).
 __global__ __launch_bounds__(256) void pointset_group_max_grad_tile_kernel(
     int n, int m, int c, int k, int cb_size, int rows_per_cloud, const float *__restrict__ points,
     const int *__restrict__ idx, const int *__restrict__ fidx, const float *__restrict__ alpha,

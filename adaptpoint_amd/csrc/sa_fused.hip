@@ -47,6 +47,7 @@
 // Both are far below the per-tile VALU/gather latency, which is what bounds it.
 #include "apn_common.h"
 #include "apn_mfma.h"
+#include <type_traits>
 #include "sa_chain.h"
 
 namespace apn {
@@ -698,6 +699,10 @@ struct SaBwdArgs {
     int train2;
     const float *goa;       // (B,M,64)
     const unsigned char *ksel;  // (B,M,64)
+    unsigned *cells;        // optional: bit-reproducible mode.  A is then an int64 array and g_u is added as a 64-bit
+                            // FIXED-POINT integer (order-independent): cells[0] = max |goa| as float bits (apn_sa_bwd_prep),
+                            // cells[1] <- the scale's exponent s (every workgroup derives the same one, prologue),
+                            // cells[2] |= 1 if a term did not fit (cannot happen while the bound below holds)
 };
 
 // Backward launch 2 of 4.  Prologue (every workgroup, same bits): the per-channel constants of
@@ -705,7 +710,7 @@ struct SaBwdArgs {
 // and their images through W2: Qm = W2^T diag(D2) W2 (32x32), evec = E2 W2 -- formerly a launch of its own.
 // Epilogue: the workgroup's share of dL/dW2 = sparse part + D2 (W2 Gram) + E2 (x) suma as ONE partial row
 // partW2[workgroup][64*32] (summed in float64, in a fixed order, by the last launch): no float atomics on dL/dW2.
-template <int NS, bool CP>
+template <int NS, bool CP, bool FX>
 __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
                                                                unsigned long long *__restrict__ accT,
                                                                float *__restrict__ partW2,
@@ -741,6 +746,25 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     __shared__ __attribute__((aligned(16))) unsigned sinfo[SA_WAVES][32];
     __bf16 *sp_img = reinterpret_cast<__bf16 *>(sp_raw + wave * SP_WAVE);
 
+    __shared__ float sbnd[8];                 // bit-reproducible mode: the pieces of the bound (see the prologue's end)
+    float fxs = 0.0f, fxlim = 0.0f;           // ... the fixed-point scale 2^s and the limit of a scaled term (wave-uniform)
+    unsigned long long bad = 0ull;            // ... lanes that met a term beyond the limit (scalar)
+    unsigned gmax_bits = 0u;
+    unsigned long long *A64 = reinterpret_cast<unsigned long long *>(A);
+    // A[off] += v: a float atomic, or (FX, bit-reproducible mode) the 64-bit integer round(v 2^s).  |v 2^s| < 2^47 (the
+    // bound of the prologue), so the integer is read off the mantissa of v 2^s + 1.5 2^52 -- four instructions
+    // instead of a dozen for a float -> int64 conversion; a term beyond the limit raises a (scalar) mark.
+    auto a_add = [&](size_t off, float v) {
+        if (FX) {
+            const float vs = v * fxs;
+            bad |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(vs) < fxlim));
+            const double dm = (double)vs + 6755399441055744.0;
+            atomicAdd(A64 + off, (unsigned long long)(__double_as_longlong(dm) - 0x4338000000000000ll));
+        } else {
+            atomicAdd(A + off, v);
+        }
+    };
+
     auto prologue = [&]() {
         const int tid = threadIdx.x;
         {   // requested first: everything the constants need
@@ -754,6 +778,15 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             if (tid < 128) sv = g.sumsS ? g.sumsS[tid] : acc_read(g.accS, 128, tid);
             if (g.sumsS) count = g.sumsS[128];
             if (tid < 64) { p_sc = g.pack2[tid]; p_mu = g.pack2[128 + tid]; p_iv = g.pack2[192 + tid]; }
+            if (FX) {
+                gmax_bits = g.cells[0];
+                float wm = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) wm = __builtin_fmaxf(wm, __builtin_fabsf(wv[k]));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) wm = __builtin_fmaxf(wm, __shfl_xor(wm, o));
+                if (lane == 0) sbnd[wave] = wm;
+            }
             if (wave == 0) {
 #pragma unroll
                 for (int s = 0; s < 3; ++s) put_frag<NS>(cfrag, F_W1 + s, lane, w1f[s]);
@@ -775,11 +808,30 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 }
                 sD[tid] = (float)d;
                 sE[tid] = (float)e;
+                if (FX) {                                         // wave 0: max |D2|, max |E2|
+                    float dm = __builtin_fabsf((float)d), em = __builtin_fabsf((float)e);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        dm = __builtin_fmaxf(dm, __shfl_xor(dm, o));
+                        em = __builtin_fmaxf(em, __shfl_xor(em, o));
+                    }
+                    if (lane == 0) { sbnd[4] = dm; sbnd[5] = em; }
+                }
             }
             if (tid >= 64 && tid < 96) {
                 const int i = tid - 64;          // channel i sits in half (i >> 2) & 1, register (i & 3) + 4 (i >> 3)
-                bn1v[0][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = g.scale1[i];
-                bn1v[1][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = g.shift1[i];
+                const float sci = g.scale1[i], shi = g.shift1[i];
+                bn1v[0][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = sci;
+                bn1v[1][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = shi;
+                if (FX) {
+                    // a1 = relu(gamma1 yhat1 + beta1) <= |gamma1| sqrt(P) + |beta1|: a channel's normalised values
+                    // cannot exceed sqrt(P - 1) in magnitude (batch statistics)
+                    float am = __builtin_fabsf(sci / g.inv1[i]) * __builtin_sqrtf((float)count)
+                             + __builtin_fabsf(__builtin_fmaf(sci, g.mean1[i], shi));
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) am = __builtin_fmaxf(am, __shfl_xor(am, o));
+                    if (lane == 0) sbnd[6] = am;
+                }
             }
             {
                 uint4 *z = reinterpret_cast<uint4 *>(sp_img);
@@ -815,6 +867,27 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         }
         __syncthreads();
         ev = sqm[32][r];
+        if (FX) {
+            // |g_u| of a row <= G 64 wmax + 32 (amax 2048 wmax^2 dmax + 64 wmax emax)  (G = max |goa|; the selected part is
+            // a sum of at most 64 products, the dense part -- a1 Qm + evec, Qm = W2^T diag(D2) W2 -- reaches a row at most 32
+            // times); a point gathers at most 32 m rows: with bound < 2^e and 32 m <= 2^rexp the scale 2^s,
+            // s = 60 - rexp - e, keeps every sum below 2^60.  Same inputs, same order: every workgroup finds the same s.
+            const float wmax = __builtin_fmaxf(__builtin_fmaxf(sbnd[0], sbnd[1]), __builtin_fmaxf(sbnd[2], sbnd[3]));
+            const float bound = __uint_as_float(gmax_bits) * 64.0f * wmax
+                              + 32.0f * (sbnd[6] * 2048.0f * wmax * wmax * sbnd[4] + 64.0f * wmax * sbnd[5]);
+            const int rexp = 32 - __builtin_clz((unsigned)(a.m * 32 - 1) | 1u);
+            int e = 0, sexp = 0;
+            if (bound < __builtin_inff()) {
+                (void)frexpf(bound, &e);
+                sexp = 60 - rexp - e;
+                sexp = sexp > 120 ? 120 : (sexp < -120 ? -120 : sexp);
+            } else {
+                bad = ~0ull;                                       // NaN / inf upstream: the result is marked, not trusted
+            }
+            fxs = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ldexpf(1.0f, sexp))));
+            fxlim = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ldexpf(1.0f, 61 - rexp))));
+            if (blockIdx.x == 0 && threadIdx.x == 0) g.cells[1] = (unsigned)sexp;
+        }
     };
 
     // the previous tile's per-point sums, scattered at the top of the next iteration (see for_each_tile)
@@ -822,14 +895,14 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     int pend_nb = 0, pend_live = 0, pend_cloud = 0;      // pend_live == 0: nothing pending
     auto scatter_pending = [&]() {
         if (CP || pend_live == 0) return;                 // wave-uniform (tile map: scattered at the end of the tile)
-        float *Ac = A + (size_t)pend_cloud * a.n * SA_C1 + r;
+        const size_t Ac = (size_t)pend_cloud * a.n * SA_C1 + r;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if (acc_row(i, 0) < pend_live) {              // wave-uniform: is any lane's position live?
                 const int n0 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 0));
                 const int n1 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 1));
                 const int nn = h ? n1 : n0;
-                if (acc_row(i, h) < pend_live) atomicAdd(Ac + (size_t)nn * SA_C1, pend_g[i]);
+                if (acc_row(i, h) < pend_live) a_add(Ac + (size_t)nn * SA_C1, pend_g[i]);
             }
         }
         pend_live = 0;
@@ -1096,19 +1169,20 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 // the tile's per-point sums, scattered at the END of the tile: behind every load of this iteration and
                 // ahead of the next iteration's prefetch (the memory counter is in order: they retire behind a whole
                 // tile of arithmetic; the one-tile-per-query path reaches the same order through scatter_pending)
-                float *Ac = A + (size_t)(q0 / a.m) * a.n * SA_C1 + r;
+                const size_t Ac = (size_t)(q0 / a.m) * a.n * SA_C1 + r;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     if (acc_row(i, 0) < live) {                   // wave-uniform: is any lane's position live?
                         const int n0 = __builtin_amdgcn_readlane(nb, acc_row(i, 0));
                         const int n1 = __builtin_amdgcn_readlane(nb, acc_row(i, 1));
                         const int nn = h ? n1 : n0;
-                        if (acc_row(i, h) < live) atomicAdd(Ac + (size_t)nn * SA_C1, ga[i]);
+                        if (acc_row(i, h) < live) a_add(Ac + (size_t)nn * SA_C1, ga[i]);
                     }
                 }
             }
         }
     });
+    if (FX && bad != 0ull && lane == 0) atomicOr(g.cells + 2, 1u);
     {   // BatchNorm-1's reduction terms {T1, T2}[32] into their accumulator set
         const float tot = fold_partials<2>(st, lane, wave);
         if (threadIdx.x < 64) acc_add(accT, 64, blockIdx.x % ACC_COPIES, threadIdx.x, tot);
@@ -1276,7 +1350,7 @@ extern "C" int apn_sa_bwd_main(int b, int n, int m, int precision, float radius,
                                const float *new_xyz, const void *ft, const int *idx, const int *tmap, const float *w1,
                                const float *w2, const float *pack1, const float *pack2, const void *accS,
                                const double *sumsS, double count, int train2, const float *goa, const void *ksel,
-                               void *accT, float *partW2, float *A, float *HA, float *HB, void *stream) {
+                               void *accT, float *partW2, void *A, unsigned *cells, float *HA, float *HB, void *stream) {
     using namespace apn;
     if (int e = sa_check(b, n, m, precision)) return e;
     if (!w2 || !pack1 || !pack2 || (!accS && !sumsS) || !goa || !ksel || !accT || !partW2 || !A || !HA || !HB)
@@ -1289,10 +1363,15 @@ extern "C" int apn_sa_bwd_main(int b, int n, int m, int precision, float radius,
     g.accS = (const unsigned long long *)accS; g.sumsS = sumsS;
     g.count = count; g.train2 = train2;
     g.goa = goa; g.ksel = (const unsigned char *)ksel;
-    auto kern = precision == 2 ? (tmap ? sa_bwd_kernel<2, true> : sa_bwd_kernel<2, false>)
-                               : (tmap ? sa_bwd_kernel<1, true> : sa_bwd_kernel<1, false>);
+    g.cells = cells;
+    auto pick = [&](auto fx) {
+        constexpr bool F = decltype(fx)::value;
+        return precision == 2 ? (tmap ? sa_bwd_kernel<2, true, F> : sa_bwd_kernel<2, false, F>)
+                              : (tmap ? sa_bwd_kernel<1, true, F> : sa_bwd_kernel<1, false, F>);
+    };
+    auto kern = cells ? pick(std::true_type{}) : pick(std::false_type{});
     hipLaunchKernelGGL(kern, dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, g,
-                       (unsigned long long *)accT, partW2, A, HA, HB);
+                       (unsigned long long *)accT, partW2, (float *)A, HA, HB);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

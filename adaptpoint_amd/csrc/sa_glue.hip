@@ -329,8 +329,10 @@ __global__ __launch_bounds__(1024) void bwd_prep_kernel(int n, int m, const floa
                                                         float *__restrict__ goa,
                                                         unsigned long long *__restrict__ accS,
                                                         float *__restrict__ partWs,
-                                                        float *__restrict__ gip) {
+                                                        float *__restrict__ gip,
+                                                        unsigned *__restrict__ cells) {
     // 1024 threads per 64-query tile (about one tile per CU), as in fwd_out_kernel
+    __shared__ float smax[16];
     __shared__ float tile[64][65];       // g[q][c]
     __shared__ float red[16][2][64];
     __shared__ __attribute__((aligned(8))) float sfi[64][34];
@@ -358,21 +360,39 @@ __global__ __launch_bounds__(1024) void bwd_prep_kernel(int n, int m, const floa
     if (ws) stage_skip_operands<1024, 33, 34>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, ssrc);
     __syncthreads();
     const float sc = pack2[tx], mu = pack2[128 + tx], iv = pack2[192 + tx];
-    float s1 = 0.0f, s2 = 0.0f;
+    float s1 = 0.0f, s2 = 0.0f, gm = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {        // (query j, channel tx): coalesced over channels
         const int j = ty + 16 * k, q = m0 + j;
         if (q < m) {
             const float g = tile[j][tx];
-            goa[((size_t)cloud * m + q) * 64 + tx] = g * sc;
+            const float gs = g * sc;
+            goa[((size_t)cloud * m + q) * 64 + tx] = gs;
+            // (bit-reproducible mode) max |goa|; a NaN must survive the maximum: it compares false everywhere
+            gm = (gs != gs) ? gs : (gm != gm ? gm : __builtin_fmaxf(gm, __builtin_fabsf(gs)));
             s1 += g;
             s2 += g * ((ys[k] - mu) * iv);
         }
     }
     red[ty][0][tx] = s1;
     red[ty][1][tx] = s2;
+    if (cells) {
+        unsigned gb = __float_as_uint(gm) & 0x7fffffffu;          // |.| bits order like unsigned integers (NaN on top)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned other = (unsigned)__shfl_xor((int)gb, o);
+            gb = other > gb ? other : gb;
+        }
+        if (tx == 0) smax[ty] = __uint_as_float(gb);
+    }
     __syncthreads();
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (cells && threadIdx.x == 0) {
+        unsigned gb = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) gb = __float_as_uint(smax[k]) > gb ? __float_as_uint(smax[k]) : gb;
+        atomicMax(cells, gb);                                     // order-independent
+    }
     if (ty < 2) {
         float acc = 0.0f;
 #pragma unroll
@@ -425,7 +445,8 @@ __global__ __launch_bounds__(1024) void bwd_prep_kernel(int n, int m, const floa
 constexpr int WG_PTS = 64;
 
 __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
-    int n, int total_q, int split, const float *__restrict__ A, const long long *__restrict__ geo,
+    int n, int total_q, int split, const float *__restrict__ A, const unsigned *__restrict__ cells,
+    const long long *__restrict__ geo,
     const float *__restrict__ HA, const float *__restrict__ HB, const unsigned long long *__restrict__ accT,
     const double *__restrict__ sumsT, double count, int train1,
     const float *__restrict__ pack1, const __bf16 *__restrict__ ft,
@@ -476,11 +497,19 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
     {
         const int c = tid & 31;                           // fixed per thread: e = tid + 1024 k
         const float ca = sc[0][c], cb = sc[1][c], cc = sc[2][c];
+        const double fx_inv = cells ? ldexp(1.0, -(int)cells[1]) : 0.0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int pt = (tid >> 5) + 32 * k;
             const bool ok = pt < n_here;
-            sG[pt][c] = ok ? A[(p0 + pt) * 32 + c] : 0.0f;
+            float av = 0.0f;
+            if (ok && !cells) av = A[(p0 + pt) * 32 + c];
+            if (ok && cells) {
+                // bit-reproducible mode: A holds 64-bit fixed-point sums in units of 2^-s (apn_sa_bwd_main)
+                const long long q = reinterpret_cast<const long long *>(A)[(p0 + pt) * 32 + c];
+                av = cells[2] ? __builtin_nanf("") : (float)((double)q * fx_inv);
+            }
+            sG[pt][c] = av;
             float fv = ok ? (float)ft[(p0 + pt) * 32 + c] : 0.0f;
             if (ft_lo && ok) fv += (float)ft_lo[(p0 + pt) * 32 + c];     // split mode: hi + lo
             sB[pt][6 + c] = fv;
@@ -743,7 +772,7 @@ extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long lon
                                long long gs_c, long long gs_m, const float *out, int relu,
                                const float *ysel, const float *pack2, const void *ft, int precision,
                                const int *fidx, const float *ws, float *goa, void *accS,
-                               float *partWs, float *gip, void *stream) {
+                               float *partWs, float *gip, unsigned *cells, void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || !g_out || !ysel || !pack2 || !goa || !accS) return APN_EINVAL;
     if (relu && !out) return APN_EINVAL;
     if (ws && (!ft || !fidx || !partWs || !gip || n <= 0 || (precision != 1 && precision != 2)))
@@ -752,14 +781,14 @@ extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long lon
     const __bf16 *lo = (ws && precision == 2) ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::bwd_prep_kernel, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, g_out,
                        gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, (unsigned long long *)accS,
-                       partWs, gip);
+                       partWs, gip, cells);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
 extern "C" int apn_sa_bwd_weight_rows(int b, int n) { return b * ((n + apn::WG_PTS - 1) / apn::WG_PTS); }
 
-extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const float *A, const void *geo,
+extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const void *A, const unsigned *cells, const void *geo,
                                       const float *HA, const float *HB, const void *accT, const double *sumsT,
                                       double count, int train1, const float *pack1, const void *ft, int precision,
                                       const float *xyz, const float *new_xyz, const float *w1,
@@ -773,7 +802,8 @@ extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const float *A, const
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = precision == 2 ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::bwd_point_grads_kernel, dim3((n + apn::WG_PTS - 1) / apn::WG_PTS, b),
-                       dim3(1024), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, A, (const long long *)geo, HA, HB,
+                       dim3(1024), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, (const float *)A, cells,
+                       (const long long *)geo, HA, HB,
                        (const unsigned long long *)accT, sumsT, count, train1,
                        pack1, hi, lo, xyz, new_xyz, w1, gip, 1.0f / radius, partW, g_f, g_p, g_newp);
     APN_LAUNCH_CHECK();

@@ -74,7 +74,10 @@ extern "C" int apn_sa_backward_seq(
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
     // cleared here unless zero_bytes == 0 (then apn_sa_fwd_out cleared them): A (B*N*32) | gip (B*N*32, only with
     // ws) | accS | accT, contiguous from zero_base
-    void *zero_base, long long zero_bytes, float *A, float *gip, void *accS, void *accT,
+    void *zero_base, long long zero_bytes, void *A, float *gip, void *accS, void *accT,
+    // bit-reproducible mode: cells (4 x u32, inside the zeroed region) and A as an int64 array (B*N*32 x 8 bytes):
+    // g_u is summed per point as 64-bit fixed-point integers instead of float atomics
+    unsigned *cells,
     // scratch
     float *goa, float *partWs, float *partW2, float *partW, const double *sumsS, const double *sumsT,
     float *HA, float *HB,
@@ -84,13 +87,13 @@ extern "C" int apn_sa_backward_seq(
     if (phases & 1) {
         if (zero_bytes) APN_TRY(apn_zero_fill(zero_base, zero_bytes, stream));
         APN_TRY(apn_sa_bwd_prep(b, n, m, g_out, gs_b, gs_c, gs_m, out, relu, ysel, pack2, ws ? ft : nullptr, precision,
-                                ws ? fidx : nullptr, ws, goa, accS, partWs, gip, stream));
+                                ws ? fidx : nullptr, ws, goa, accS, partWs, gip, cells, stream));
     }
     if (phases & 2)
         APN_TRY(apn_sa_bwd_main(b, n, m, precision, radius, xyz, new_xyz, ft, idx, tmap, w1, w2, pack1, pack2, accS,
-                                sumsS, count, train2, goa, ksel, accT, partW2, A, HA, HB, stream));
+                                sumsS, count, train2, goa, ksel, accT, partW2, A, cells, HA, HB, stream));
     if (phases & 4) {
-        APN_TRY(apn_sa_bwd_point_grads(b, n, m, A, geo, HA, HB, accT, sumsT, count, train1, pack1, ft, precision, xyz,
+        APN_TRY(apn_sa_bwd_point_grads(b, n, m, A, cells, geo, HA, HB, accT, sumsT, count, train1, pack1, ft, precision, xyz,
                                        new_xyz, w1, gip, radius, partW, g_f, g_p, g_newp, stream));
         APN_TRY(apn_sa_bwd_finalize(partW, apn_sa_bwd_weight_rows(b, n), radius, g_w1, partWs,
                                     apn_sa_bwd_prep_rows(b, m), g_ws, partW2, apn_sa_bwd_main_rows(b, m), g_w2, accS,

@@ -647,7 +647,7 @@ __global__ __launch_bounds__(128) void csr_sort_short_kernel(int nq, long long n
         l[i] = e;
         geo_add(tmap, rows, new_xyz, e, occ, sx, sy, sz);
     }
-    *reinterpret_cast<float4 *>(geo + gn * 4) = make_float4(occ, sx, sy, sz);
+    if (geo) *reinterpret_cast<float4 *>(geo + gn * 4) = make_float4(occ, sx, sy, sz);
 }
 
 __global__ __launch_bounds__(256) void csr_sort_long_kernel(int nq, long long npts, const int *__restrict__ tmap,
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void csr_sort_long_kernel(int nq, long long np
     }
     if (lane == 0) {
         poff[gn] = start;
-        *reinterpret_cast<float4 *>(geo + gn * 4) = make_float4(occ, sx, sy, sz);
+        if (geo) *reinterpret_cast<float4 *>(geo + gn * 4) = make_float4(occ, sx, sy, sz);
     }
 }
 
@@ -767,12 +767,12 @@ extern "C" int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *
     return apn_sa_wide_tilemap_many(1, b, m, mode, idx, tmap, stream);
 }
 
-// pcnt_poff: int32[2 b n] (counts, then list starts); plist: int32[32 b m]; geo: float[4 b n];
+// pcnt_poff: int32[2 b n] (counts, then list starts); plist: int32[32 b m]; geo: float[4 b n] (optional);
 // optional: fidx (b,m) = the point every query is -> fq int32[b n] = the query a point is, or -1.
 extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *new_xyz, const int *tmap,
                                int *pcnt_poff, int *plist, float *geo, const int *fidx, int *fq, void *stream) {
     if (b <= 0 || n <= 0 || m <= 0 || b > 65535 || (long long)b * m > 0x7fffffffLL / 64 ||
-        (long long)b * n > 0x7fffffffLL / 8 || !idx || !new_xyz || !tmap || !pcnt_poff || !plist || !geo ||
+        (long long)b * n > 0x7fffffffLL / 8 || !idx || !new_xyz || !tmap || !pcnt_poff || !plist ||
         ((fidx != nullptr) != (fq != nullptr)))
         return APN_EINVAL;
     const int nq = b * m;

@@ -42,6 +42,10 @@ C_IN, C_MID, C_OUT, K_NS = 32, 32, 64, 32
 # queries' gradients / pooled slots in one batch of loads, per-query sums through two wave-private LDS tiles, the
 # scatter at the end of the tile): 58 -> 44 us, so the map is now used in both directions (APN_TMAP_BWD=0: forward only).
 TILE_MAP_IN_BACKWARD = os.environ.get("APN_TMAP_BWD", "1") == "1"
+# Bit-reproducible gradients: the backward pass adds its per-point sums (A) as 64-bit fixed-point integers -- the
+# only order-dependent sums of the chain were float atomics there; everything else already is an integer accumulator
+# set or a fixed-order fold.  The scale is derived on the device from a bound on the terms (csrc/sa_fused.hip).
+DETERMINISTIC = os.environ.get("APN_DETERMINISTIC", "0") == "1"
 
 # Operand precision of the MFMA contractions:
 #   "bf16x3" (default) every f32 operand is split into hi + lo bf16 parts and each product is
@@ -219,13 +223,15 @@ class _Forward:
         count = float(B * M * K_NS)       # this rank's positions; SyncBatchNorm all-reduces it with the sums
         if geo is None:
             geo, dd = point_geo(p, new_p, idx, radius)
+        self.det = bool(DETERMINISTIC)
         rows1 = lib.apn_sa_prep_rows(B, N)
         v, _buf = _carve(dev, [("ft", prec * B * N * C // 2), ("pack1", 4 * C_MID), ("pack2", 4 * C_OUT),
                                ("ysel", B * M * C_OUT), ("ksel", B * M * C_OUT // 4),
                                ("part1", rows1 * 64), ("acc2", _acc_floats(128))])
         out = torch.empty(B, C_OUT, M, dtype=torch.float32, device=dev)
-        self.zsizes = ([("A", B * N * C_MID)] + ([("gip", B * N * C_MID)] if ws is not None else [])
-                       + [("accS", _acc_floats(128)), ("accT", _acc_floats(64))])
+        # (bit-reproducible mode: A holds 64-bit integers, and four cells carry the scale between the launches)
+        self.zsizes = ([("A", B * N * C_MID * (2 if self.det else 1))] + ([("gip", B * N * C_MID)] if ws is not None else [])
+                       + [("accS", _acc_floats(128)), ("accT", _acc_floats(64))] + ([("cells", 64)] if self.det else []))
         self.zviews = self.zbuf = None
         if want_backward:
             self.zviews, self.zbuf = _carve(dev, self.zsizes)
@@ -317,7 +323,7 @@ def _backward(fw, g_out, need_p, need_newp):
              fw.out.data_ptr(), fw.relu, 1 if fw.train1 else 0, 1 if fw.train2 else 0, float(P),
              g_out.data_ptr(), gs[0], gs[1], gs[2], buf.data_ptr(), zero_floats * 4,
              v["A"].data_ptr(), v["gip"].data_ptr() if has_skip else None, v["accS"].data_ptr(),
-             v["accT"].data_ptr(), v["goa"].data_ptr(),
+             v["accT"].data_ptr(), v["cells"].data_ptr() if fw.det else None, v["goa"].data_ptr(),
              v["partWs"].data_ptr() if has_skip else None, v["partW2"].data_ptr(), v["partW"].data_ptr(),
              _ptr(sumsS), _ptr(sumsT), v["HA"].data_ptr(), v["HB"].data_ptr(),
              g_f.data_ptr(), _ptr(g_p), _ptr(g_newp), g["w1"].data_ptr(), g["w2"].data_ptr(),
@@ -363,6 +369,7 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
     """Python mirror of apn_sa_backward_seq (csrc/sa_seq.hip), one foreign call per kernel."""
     B, N, M = fw.dims
     w1, w2, ws, P = sv["w1"], sv["w2"], sv["ws"], float(sv["count"])
+    cells = v["cells"].data_ptr() if fw.det else None
     gip = v["gip"].data_ptr() if has_skip else None
     if phases & 1:
         if zero_floats:
@@ -370,15 +377,15 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
         call("apn_sa_bwd_prep", B, N, M, g_out.data_ptr(), *g_out.stride(), fw.out.data_ptr(), fw.relu,
              sv["ysel"].data_ptr(), sv["pack2"].data_ptr(), sv["ft"].data_ptr() if has_skip else None,
              fw.prec, _ptr(sv["fidx"]) if has_skip else None, _ptr(ws), v["goa"].data_ptr(),
-             v["accS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None, gip)
+             v["accS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None, gip, cells)
     if phases & 2:
         call("apn_sa_bwd_main", B, N, M, fw.prec, fw.radius, sv["p"].data_ptr(), sv["new_p"].data_ptr(),
              sv["ft"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["tmap"]), w1.data_ptr(), w2.data_ptr(),
              sv["pack1"].data_ptr(), sv["pack2"].data_ptr(), v["accS"].data_ptr(), _ptr(sumsS), P,
              1 if fw.train2 else 0, v["goa"].data_ptr(), sv["ksel"].data_ptr(), v["accT"].data_ptr(),
-             v["partW2"].data_ptr(), v["A"].data_ptr(), v["HA"].data_ptr(), v["HB"].data_ptr())
+             v["partW2"].data_ptr(), v["A"].data_ptr(), cells, v["HA"].data_ptr(), v["HB"].data_ptr())
     if phases & 4:
-        call("apn_sa_bwd_point_grads", B, N, M, v["A"].data_ptr(), sv["geo"].data_ptr(),
+        call("apn_sa_bwd_point_grads", B, N, M, v["A"].data_ptr(), cells, sv["geo"].data_ptr(),
              v["HA"].data_ptr(), v["HB"].data_ptr(), v["accT"].data_ptr(), _ptr(sumsT), P, 1 if fw.train1 else 0,
              sv["pack1"].data_ptr(), sv["ft"].data_ptr(), fw.prec, sv["p"].data_ptr(), sv["new_p"].data_ptr(),
              w1.data_ptr(), gip, fw.radius, v["partW"].data_ptr(), g_f.data_ptr(), _ptr(g_p), _ptr(g_newp))

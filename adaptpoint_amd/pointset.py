@@ -59,7 +59,9 @@ class _GroupMax(torch.autograd.Function):
 
 def group_max(points, idx, fidx, alpha, beta):
     """out (B,C,M) = max_k(alpha * (points[idx] - points[fidx]) + beta); points (B,N,C),
-    idx (B,M,K) int, fidx (B,M) int, alpha/beta with C elements."""
+    idx (B,M,K) int, fidx (B,M) int, alpha/beta with C elements.  The forward is bit-identical to the reference's
+    composition; the gradient w.r.t. `points` is accumulated with float LDS atomics and is therefore equal only up to
+    the order of its additions from run to run (csrc/pointset_group.hip)."""
     return _GroupMax.apply(points, idx, fidx, alpha, beta)
 
 

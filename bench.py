@@ -220,6 +220,7 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
     if fused_mlp:
         from adaptpoint_amd import fused as _f
         _f.PRECISION = mlp.split("-", 1)[1]
+        _f.DETERMINISTIC = bool(args.deterministic)
     blk = make_block(fused=fused_mlp, sync_bn=sync_bn).to(dev)
     blk.train()
     # Gradient exchange.  Without SyncBatchNorm forward+backward contain no collective, so the
@@ -475,6 +476,10 @@ def main():
                          "reference forces (examples/classification/main.py:27): four small statistics "
                          "all-reduces per step inside the fused block + the gradient all-reduce.  off: "
                          "per-rank statistics (NOT the reference's semantics), one exchange per step")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="bit-reproducible gradients (adaptpoint_amd.fused.DETERMINISTIC): the backward pass adds its "
+                         "per-point sums as 64-bit fixed-point integers instead of float atomics; reported beside the "
+                         "default as value_deterministic")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--distribution", choices=["D1", "D2"], default="D1",
                     help="synthetic clouds (SURVEY 8d): D1 uniform cube -> unit sphere; D2 sphere surface + jitter")
@@ -688,6 +693,7 @@ def main():
                                 "current batch(es); the two streams meet once per launch" if pipelined else "none"),
                    "global_batch": B_PER_GPU * world,
                    "fused_fallbacks": sum(_sa.FUSED_FALLBACKS.values()),
+                   "deterministic_gradients": bool(args.deterministic),
                    "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else "")
                                   + ("+flat-allreduce" if distributed else "")
                                   + ("+collectives-in-graph" if getattr(m, "capture_collectives", False) else "")},
@@ -705,6 +711,15 @@ def main():
             # the bit-for-bit interoperable path: nine drop-in operators + PyTorch fp32 conv/BN (eager)
             m2 = measure(args, dev, world, rank, local_rank, distributed, "torch-f32", False, sec_steps, 4)
             result["value_f32_dropin"] = round(B_PER_GPU * sec_steps / m2.elapsed, 2)
+            if not args.deterministic and args.mlp == "fused-bf16x3" and args.steps % 20 == 0:
+                # the same step with bit-reproducible gradients (no float atomics: 64-bit fixed-point sums)
+                args.deterministic = True
+                det_steps = min(args.steps, 400)
+                m3 = measure(args, dev, world, rank, local_rank, distributed, args.mlp, False, det_steps, 40, repeats=5)
+                args.deterministic = False
+                from adaptpoint_amd import fused as _fz
+                _fz.DETERMINISTIC = False
+                result["value_deterministic"] = round(B_PER_GPU * det_steps / m3.elapsed, 2)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if distributed:

@@ -237,27 +237,31 @@ APN_API int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long long g
                             long long gs_c, long long gs_m, const float *out, int relu,
                             const float *ysel, const float *pack2, const void *ft, int precision,
                             const int *fidx, const float *ws, float *goa, void *accS,
-                            float *partWs, float *gip, void *stream);
+                            float *partWs, float *gip, unsigned *cells, void *stream);
 
 /* Backward launch 2 of 4: the pass over the positions.  Prologue (every workgroup): the constants of
  * dL/dy2 = goa*[pos==ksel] + y2*D2 + E2 from accS (or sumsS) and pack2, Qm = W2^T diag(D2) W2, evec = E2 W2.
  * accT (accumulator set, 64 columns, zeroed) += {sum g_u, sum g_u*yhat1}[32] (g_u = dL/da1 * [a1 > 0]);
  * partW2[apn_sa_bwd_main_rows(b, m)][64*32] = the workgroup's share of dL/dW2 (sparse arg-max part +
- * D2 (W2 Gram) + E2 (x) sum a1);  A (B,N,32) += g_u summed per source point (zeroed, float atomics);
+ * D2 (W2 Gram) + E2 (x) sum a1);  A (B,N,32) += g_u summed per source point (zeroed, float atomics).
+ * Bit-reproducible mode (cells != NULL: 4 zeroed u32, cells[0] = max |goa| bits from apn_sa_bwd_prep): A is an
+ * int64 array (B,N,32) and every term is added as the 64-bit integer round(g_u 2^s) -- order-independent; the
+ * exponent s is derived from a bound on |g_u| (max |goa|, |W2|, the BatchNorm constants) by every workgroup alike and
+ * left in cells[1]; cells[2] != 0 marks a term that did not fit (apn_sa_bwd_point_grads then yields NaN);
  * HA, HB (B,M,32) = g_u and yhat1 summed per query.  pack1 = BN1's [4][32] of the forward. */
 APN_API int apn_sa_bwd_main(int b, int n, int m, int precision, float radius, const float *xyz,
                             const float *new_xyz, const void *ft, const int *idx, const int *tmap, const float *w1,
                             const float *w2, const float *pack1, const float *pack2, const void *accS,
                             const double *sumsS, double count, int train2, const float *goa, const void *ksel,
-                            void *accT, float *partW2, float *A, float *HA, float *HB, void *stream);
+                            void *accT, float *partW2, void *A, unsigned *cells, float *HA, float *HB, void *stream);
 
 /* Backward launch 3 of 4.  Prologue: the batch constants of dL/dy1 = g_u*ca + yhat1*cb + cc from accT (or sumsT).
  * dL/dy1 summed per source point (G) and per query (H), formed from A, geo (apn_sa_point_geo), HA, HB, and
  * everything linear in them, one workgroup per 64-point tile: g_f (B,32,N) = G W1[:,3:] (+ gip); optional
  * g_p (B,N,3) += G W1[:,:3]/r and g_newp (B,M,3) = -H W1[:,:3]/r; partW[apn_sa_bwd_weight_rows(b, n)][32*38] =
- * per-block products for dL/dW1 (sa_glue.hip). */
+ * per-block products for dL/dW1 (sa_glue.hip).  cells != NULL: A holds apn_sa_bwd_main's fixed-point sums. */
 APN_API int apn_sa_bwd_weight_rows(int b, int n);
-APN_API int apn_sa_bwd_point_grads(int b, int n, int m, const float *A, const void *geo,
+APN_API int apn_sa_bwd_point_grads(int b, int n, int m, const void *A, const unsigned *cells, const void *geo,
                                    const float *HA, const float *HB, const void *accT, const double *sumsT,
                                    double count, int train1, const float *pack1, const void *ft, int precision,
                                    const float *xyz, const float *new_xyz, const float *w1,
@@ -300,7 +304,8 @@ APN_API int apn_sa_backward_seq(
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
-    void *zero_base, long long zero_bytes, float *A, float *gip, void *accS, void *accT,
+    void *zero_base, long long zero_bytes, void *A, float *gip, void *accS, void *accT,
+    unsigned *cells,   /* bit-reproducible mode: 4 u32 inside the zeroed region, and A an int64 array (apn_sa_bwd_main) */
     float *goa, float *partWs, float *partW2, float *partW, const double *sumsS, const double *sumsT,
     float *HA, float *HB,
     float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_w2, float *g_g1, float *g_b1, float *g_g2,
@@ -450,7 +455,7 @@ APN_API int apn_sa_wide_wgrad(int b, int n, int m, int c_mid, int c_out, const f
 
 /* Inverse map of the tile map (index stage): pcnt_poff int32[2 b n] = for every support point the number of
  * rows that gather it and where its list starts in plist int32[32 b m] (row ids tile * 32 + r, ascending);
- * geo float[4 b n] = {occurrences, sum of the gathering queries' coordinates} per point; with fidx (b,m) = the
+ * geo float[4 b n] (may be NULL) = {occurrences, sum of the gathering queries' coordinates} per point; with fidx (b,m) = the
  * point every query is (FPS picks) also fq int32[b n] = the query a point is, or -1 (both may be NULL). */
 APN_API int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *new_xyz, const int *tmap,
                             int *pcnt_poff, int *plist, float *geo, const int *fidx, int *fq, void *stream);

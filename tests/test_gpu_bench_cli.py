@@ -31,6 +31,7 @@ def _bench(extra):
     (["--steps", "8", "--warmup", "2", "--index-batch", "1", "--distribution", "D2", "--seed", "3"], "hipGraph replay, 4 step(s) per graph"),
     (["--steps", "6", "--warmup", "2", "--graph", "off"], "eager"),
     (["--steps", "6", "--warmup", "2", "--mlp", "fused-bf16"], "hipGraph replay, 2 step(s) per graph"),
+    (["--steps", "20", "--warmup", "2", "--deterministic"], "hipGraph replay, 20 step(s) per graph"),
     (["--steps", "4", "--warmup", "1", "--mlp", "torch-f32"], None),
 ])
 def test_bench_variants_emit_the_contract_line(dev, extra, launch):
@@ -59,6 +60,8 @@ def test_default_line_carries_the_secondary_figures(dev):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["value_f32_dropin"] > 0 and d["value"] > d["value_f32_dropin"]
+    # the same step with bit-reproducible gradients (fused.DETERMINISTIC) beside the default
+    assert d["config"]["deterministic_gradients"] is False and 0.7 * d["value"] < d["value_deterministic"] < 1.05 * d["value"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["value_1_thread"] > 0 and cb["cpu_model"]
     assert d["config"]["fused_fallbacks"] == 0

@@ -595,6 +595,61 @@ def test_register_resident_kernels_over_the_tile_map_equal_one_tile_per_query(ma
         assert torch.allclose(b1.float(), b2.float(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("with_map", [True, False])
+@pytest.mark.parametrize("loss_scale", [1.0, 65536.0, 1e-6])
+def test_deterministic_mode_gives_bit_identical_gradients(dev, monkeypatch, with_map, loss_scale):
+    """fused.DETERMINISTIC: the backward pass adds its per-point sums as 64-bit fixed-point integers (scale derived
+    on the device from a bound on the terms) -- no float atomics left on the chain: three runs of the B=32 block give
+    torch.equal outputs, input gradients and parameter gradients, and they equal the default (float-atomic) mode up
+    to summation order, whatever the magnitude of the upstream gradient (loss scaling)."""
+    import copy
+    from adaptpoint_amd import fused, fused_wide
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    torch.manual_seed(0)
+    blk = SetAbstraction(32, 64, layers=2, stride=2, fused=True, use_res=True,
+                         group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                         norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'}).to(dev)
+    B = 32
+    p = torch.from_numpy(GI.unit_sphere_cloud(B, 1024, seed=14)).to(dev)
+    f = torch.from_numpy(GI.seeded_normal((B, 32, 1024), seed=15)).to(dev)
+    w = torch.from_numpy(GI.seeded_normal((B, 64, 512), seed=16)).to(dev) * loss_scale
+
+    def run(det):
+        monkeypatch.setattr(fused, "DETERMINISTIC", det)
+        b2 = copy.deepcopy(blk)
+        fa = f.clone().requires_grad_(True)
+        smp = b2.sample(p)
+        if with_map:
+            smp.tmap = fused_wide.tile_map(smp.idx)
+        _, o = b2([p, fa], sampling=smp)
+        (o * w).sum().backward()
+        return [o.detach(), fa.grad] + [q.grad for q in b2.parameters()] + [x.clone() for x in b2.buffers()]
+
+    runs = [run(True) for _ in range(3)]
+    for other in runs[1:]:
+        for k, (a, b) in enumerate(zip(runs[0], other)):
+            assert torch.equal(a, b), k
+    ref = run(False)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+    assert torch.equal(runs[0][0], ref[0])                       # the forward is the same launches
+    for k, (a, b) in enumerate(zip(runs[0], ref)):
+        assert torch.isfinite(a).all(), k
+        assert rel(a, b) <= 2e-6, (k, rel(a, b))
+
+
+def test_deterministic_mode_marks_what_it_cannot_represent(dev, monkeypatch):
+    """A non-finite upstream gradient reaches the fixed-point sums as a marked result (NaN), never as a wrong number."""
+    from adaptpoint_amd import fused
+    monkeypatch.setattr(fused, "DETERMINISTIC", True)
+    p, new_p, f, idx, conv1, bn1, conv2, bn2 = _setup(dev, B=2)
+    f = f.clone().requires_grad_(True)
+    out = fused.grouped_mlp_max(p, new_p, f, idx, 0.15, conv1, bn1, conv2, bn2)
+    g = torch.ones_like(out)
+    g[1, 3, 7] = float("inf")
+    out.backward(g)
+    assert torch.isnan(f.grad).any()
+
+
 @pytest.mark.parametrize("kind", ["ball", "random", "partial_fill"])
 def test_point_geo_equals_its_statement(dev, oracle, kind):
     """The index stage's occurrence statistics (csrc/sa_geo.hip): counts and fixed-point sums of the relative
