@@ -30,6 +30,7 @@
 #include "ball_query_body.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace apn {
 
@@ -608,7 +609,8 @@ extern "C" int apn_furthest_point_sampling_tuned(int b, int n, int m, const floa
 extern "C" int apn_furthest_point_sampling_xyz(int b, int n, int m, const float *xyz, float *temp,
                                                int *idxs, float *new_xyz, void *stream) {
     if (n > 16384 || !new_xyz) return APN_EINVAL;
-    return fps_impl(b, n, m, xyz, temp, idxs, new_xyz, 0, 0, stream);
+    static const int env_waves = [] { const char *e = getenv("APN_FPS_WAVES"); return e ? atoi(e) : 0; }();
+    return fps_impl(b, n, m, xyz, temp, idxs, new_xyz, env_waves, 0, stream);
 }
 
 // FPS (+ sampled coordinates) of batch A and, in the same launch, the zero-filling ball query of

@@ -247,12 +247,6 @@ __global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float
         if (threadIdx.x < 128) ftot[threadIdx.x] = sums2 ? sums2[threadIdx.x] : acc_read(acc2, 128, threadIdx.x);
         if (sums2) count2 = sums2[128];
     }
-    // The backward pass accumulates into A / gip / its accumulator sets with atomics; they are zeroed HERE, by the last forward
-    // launch (race-free: their writers run after it), so that the backward needs no fill launch of its own.
-    if (zero) {
-        const long long nb = (long long)gridDim.x * gridDim.y, bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
-        for (long long i = bid * 1024 + threadIdx.x; i < zero_n4; i += nb * 1024) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     __shared__ __attribute__((aligned(16))) float sws[64][36];
     const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..15
@@ -306,6 +300,14 @@ __global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float
         }
         if (relu) v = fmaxf(v, 0.0f);
         if (m0 + tx < m) out[((size_t)cloud * 64 + c) * m + m0 + tx] = v;
+    }
+    // The backward pass accumulates into A / gip / its accumulator sets with atomics; they are zeroed HERE, by the last forward
+    // launch (race-free: their writers run after it), so that the backward needs no fill launch of its own.  At the END of
+    // the kernel: the memory counter is in order, and a variable number of stores ahead of the loads made every wait for
+    // a load wait for the whole fill.
+    if (zero) {
+        const long long nb = (long long)gridDim.x * gridDim.y, bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        for (long long i = bid * 1024 + threadIdx.x; i < zero_n4; i += nb * 1024) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 

@@ -26,6 +26,10 @@ __global__ __launch_bounds__(256) void zero16_kernel(uint4 *__restrict__ p, long
     const long long stride = (long long)gridDim.x * 256;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n16; e += stride) p[e] = make_uint4(0, 0, 0, 0);
 }
+__global__ __launch_bounds__(256) void fill32_kernel(unsigned *__restrict__ p, unsigned word, long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) p[e] = word;
+}
 }  // namespace apn
 
 // bytes a multiple of 16, base 16-byte aligned.  A kernel, not hipMemsetAsync: a captured memset node aborted
@@ -110,10 +114,12 @@ extern "C" int apn_sa_sample_seq(int b, int n, int m, float radius, int nsample,
                                  float *temp, int *fidx, float *new_xyz, int *idx, void *geo, void *dd,
                                  void *stream) {
     if (b <= 0 || n <= 0 || m <= 0) return APN_EINVAL;
-    if (temp) {   // 1e10f = 0x501502F9 as 32-bit words
-        hipError_t me = hipMemsetD32Async((hipDeviceptr_t)temp, 0x501502F9, (size_t)b * n,
-                                          (hipStream_t)stream);
-        if (me != hipSuccess) return (int)me;
+    if (temp) {   // 1e10f = 0x501502F9 as 32-bit words (a kernel, not a memset: the index stage replays from hipGraphs)
+        long long blocks = ((long long)b * n + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(apn::fill32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned *)temp,
+                           0x501502F9u, (long long)b * n);
+        APN_LAUNCH_CHECK();
     }
     APN_TRY(apn_furthest_point_sampling_xyz(b, n, m, xyz, temp, fidx, new_xyz, stream));
     APN_TRY(apn_ball_query_zero(b, n, m, radius, nsample, new_xyz, xyz, idx, stream));

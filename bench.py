@@ -415,7 +415,7 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
             def step():
                 cur = cur_set[0]
                 launch(spg, cur, lambda n, c: mlp_graphs[c].replay(),
-                       lambda n, d: index_graphs[d].replay())
+                       (lambda n, d: None) if args.diag_freeze_index else (lambda n, d: index_graphs[d].replay()))
                 last_grads[0] = graph_grads[cur]
                 if pipelined:
                     cur_set[0] ^= 1
@@ -480,6 +480,9 @@ def main():
                     help="bit-reproducible gradients (adaptpoint_amd.fused.DETERMINISTIC): the backward pass adds its "
                          "per-point sums as 64-bit fixed-point integers instead of float atomics; reported beside the "
                          "default as value_deterministic")
+    ap.add_argument("--diag-freeze-index", action="store_true",
+                    help="DIAGNOSTIC, not the metric: the index stages are computed once and the timed replays run the MLP "
+                         "steps only (kernel tuning without the sampler beside them); the line says so in config.workload")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--distribution", choices=["D1", "D2"], default="D1",
                     help="synthetic clouds (SURVEY 8d): D1 uniform cube -> unit sphere; D2 sphere surface + jitter")
@@ -667,8 +670,10 @@ def main():
         "ms_per_step_max": round(1e3 * max(m.blocks) / args.steps, 4),
         "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if fused_mlp else "f32", "data": "synthetic",
-        "config": {"workload": "PointNeXt-S stage-1 SetAbstraction fwd+bwd, B=32/GPU N=1024 "
-                               "npoint=512 nsample=32 r=0.15 C 32->64 (BASELINE configs[1])",
+        "config": {"workload": ("DIAGNOSTIC (--diag-freeze-index: index stages NOT in the timed region; not the metric): "
+                                if args.diag_freeze_index else "")
+                               + "PointNeXt-S stage-1 SetAbstraction fwd+bwd, B=32/GPU N=1024 "
+                                 "npoint=512 nsample=32 r=0.15 C 32->64 (BASELINE configs[1])",
                    "distribution": {"D1": "D1: uniform cube centred+scaled to the unit sphere",
                                     "D2": "D2: unit-sphere surface + N(0,0.01) jitter"}[args.distribution],
                    "seed": args.seed,

@@ -319,7 +319,8 @@ APN_API int apn_sa_sample_overlap(int b, int n, int m, float radius, int nsample
                                   const float *xyz_b, const float *new_xyz_b, int *idx_b,
                                   void *stream);
 /* Index stage: temp := 1e10, FPS (+ sampled coordinates), ball query (zero-filling) and, with geo != NULL,
- * apn_sa_point_geo.  temp may be NULL (no min-distances kept). */
+ * apn_sa_point_geo.  temp may be NULL (no min-distances kept).  n <= 16384 (the register-resident sampler; larger
+ * clouds: apn_furthest_point_sampling + apn_ball_query). */
 APN_API int apn_sa_sample_seq(int b, int n, int m, float radius, int nsample, const float *xyz,
                               float *temp, int *fidx, float *new_xyz, int *idx, void *geo, void *dd,
                               void *stream);

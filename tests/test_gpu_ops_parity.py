@@ -91,6 +91,29 @@ def test_fps_sizes_vs_oracle(dev, oracle, n, m):
     assert np.array_equal(temp, o_temp)
 
 
+@pytest.mark.parametrize("n,m", [(1200, 300), (16000, 40)])
+def test_index_stage_sequence_with_min_distance_buffer(dev, oracle, n, m):
+    """apn_sa_sample_seq with a caller's `temp` buffer (subsample.py:94: filled with 1e10 -- by a kernel, so that the
+    sequence can replay from a hipGraph -- then the running minimum distances): FPS picks, sampled coordinates,
+    neighbours and the buffer's final contents equal the oracle's."""
+    from adaptpoint_amd import _lib
+    xyz = GI.seeded_uniform((2, n, 3), seed=300 + n).astype(np.float32)
+    p = torch.from_numpy(xyz).to(dev)
+    temp = torch.full((2, n), -1.0, device=dev)
+    fidx = torch.empty(2, m, dtype=torch.int32, device=dev)
+    new_p = torch.empty(2, m, 3, device=dev)
+    idx = torch.empty(2, m, 32, dtype=torch.int32, device=dev)
+    rc = _lib.load().apn_sa_sample_seq(2, n, m, 0.2, 32, p.data_ptr(), temp.data_ptr(), fidx.data_ptr(), new_p.data_ptr(),
+                                       idx.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    o_idx, o_temp = oracle.furthest_point_sampling(xyz, m, return_temp=True)
+    assert np.array_equal(fidx.cpu().numpy(), o_idx)
+    assert np.array_equal(temp.cpu().numpy(), o_temp)
+    q = GI.take_points(xyz, o_idx)
+    assert np.array_equal(new_p.cpu().numpy(), q)
+    assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(0.2, 32, xyz, q))
+
+
 def test_fps_m_zero_and_one(dev):
     xyz = GI.seeded_uniform((2, 33, 3), seed=5).astype(np.float32)
     assert gpu_fps(xyz, 0, dev).shape == (2, 0)
@@ -177,6 +200,27 @@ def test_ball_query_full_size_properties(dev):
 
 
 # ------------------------------------------------------------------ group / gather
+def test_query_and_group_module_matches_reference_golden(dev, golden):
+    """SURVEY 8a row a13 at module level on the GPU: `layers.BallGrouper` (QueryAndGroup, group.py:230-262, with
+    normalize_dp) over the extension's ball query + grouping equals the reference module's own output (G4 `qg`
+    goldens: dp elementwise, the grouped features through their checksums) -- and its backward is the scatter-add."""
+    from adaptpoint_amd.layers import BallGrouper
+    xyz = GI.config1_xyz()
+    q = GI.take_points(xyz, golden["g1_fps512"])
+    feats = torch.from_numpy(GI.seeded_normal((2, 32, 1024), seed=11)).to(dev).requires_grad_(True)
+    dp, fj = BallGrouper(0.15, 32, normalize_dp=True)(torch.from_numpy(q).to(dev), torch.from_numpy(xyz).to(dev), feats)
+    np.testing.assert_allclose(dp.cpu().numpy(), golden["g4_qg_dp"], rtol=1e-6, atol=1e-7)
+    chk = np.array([fj.double().sum().item(), fj.double().abs().sum().item()])
+    np.testing.assert_allclose(chk, golden["g4_qg_fj_checksum"], rtol=1e-12)
+    # backward: every gathered copy returns its gradient to the source point (group.py:120-137 through autograd)
+    idx = torch.from_numpy(golden["g1_bq_r015"].astype(np.int64)).to(dev)
+    w = torch.from_numpy(GI.seeded_normal(tuple(fj.shape), seed=12)).to(dev)
+    (fj * w).sum().backward()
+    ref = torch.zeros(2, 32, 1024, device=dev, dtype=torch.float64)
+    ref.scatter_add_(2, idx.reshape(2, 1, -1).expand(-1, 32, -1), w.double().reshape(2, 32, -1))
+    assert torch.allclose(feats.grad.double(), ref, rtol=1e-5, atol=1e-5)
+
+
 def test_group_points_exact(dev, golden, oracle):
     import pointnet2_batch_cuda as ext
     feats = GI.seeded_normal((2, 32, 1024), seed=11)
