@@ -20,7 +20,7 @@ SOURCES = ["capi.hip", "fps.hip", "ball_query.hip", "group_points.hip", "interpo
 HEADERS = ["apn_common.h", "apn_mfma.h", "sa_chain.h", "ball_query_body.h",
            os.path.join("..", "..", "include", "adaptpoint_amd.h")]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-            "-fvisibility=hidden", "-Wall", "-Wno-unused-command-line-argument"]
+            "-fvisibility=hidden", "-Wall", "-Wno-unused-command-line-argument"] + os.environ.get("APN_EXTRA_CXXFLAGS", "").split()
 
 
 def hipcc():

@@ -23,6 +23,7 @@
 
 #include "../../include/adaptpoint_amd.h"
 #include "apn_mfma.h"
+#include <type_traits>
 
 namespace apn {
 
@@ -196,6 +197,9 @@ __device__ __forceinline__ void pw_halve_max_step(float (&v)[32], int (&ix)[32],
     }
 }
 
+// LDS writes of this wave done, then the workgroup's rendezvous (global loads stay in flight across it)
+__device__ __forceinline__ void pw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool A_KC, bool B_KC, int NS>
 __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_lds[];
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
     int c0 = z * g.cps, c1 = c0 + g.cps;
     if (c1 > g.total) c1 = g.total;
 
-    f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+    f32x16 acc[2][2] = {{f32x16{0}, f32x16{0}}, {f32x16{0}, f32x16{0}}};
     float va0[8], vb0[8], va1[8], vb1[8];
     int ka0 = 0, kb0 = 0, ka1 = 0, kb1 = 0;
     // chunks are fetched in order: (batch entry, chunk inside it) advance by counting, not by a division per fetch
@@ -224,58 +228,114 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         kb = lb.load(g.B, g.B.p + g.B.batch * fz, Q0, g.Q, k0, g.K, g.b_vec, full, xb);
         if (++fk == g.cpb) { fk = 0; ++fz; }
     };
+    // The steady-state form (every chunk whole, k-contiguous operands readable as float4 -- kernel-uniform): the SAME
+    // loads in every step, issued unconditionally (past the slice's end the last chunk is read again and dropped).
+    // With a conditional fetch the compiler cannot count the loads in flight: it waited for ALL of them (vmcnt(0))
+    // before splitting the previous chunk, i.e. for the loads it had just issued -- a full memory round trip per chunk.
+    const bool fast = g.K % PW_KC == 0 && (!A_KC || g.a_vec) && (!B_KC || g.b_vec);
+    int fc = c0;
+    auto fetch_fast = [&](float (&xa)[8], float (&xb)[8]) {
+        const int k0 = fk * PW_KC;
+        (void)la.load(g.A, g.A.p + g.A.batch * fz, R0, g.R, k0, g.K, 1, true, xa);
+        (void)lb.load(g.B, g.B.p + g.B.batch * fz, Q0, g.Q, k0, g.K, 1, true, xb);
+        if (fc + 1 < c1) {
+            ++fc;
+            if (++fk == g.cpb) { fk = 0; ++fz; }
+        }
+    };
+    // Four independent accumulator chains per wave -- (row block i, k-step s) -- issued in turn: a chain's next MFMA
+    // needs the previous one's result (64 cycles away), and with fewer than four the matrix pipe waits on it whenever
+    // this wave is the only one of its SIMD in the compute phase.  The two k-steps' sums are added in the epilogue.
     auto compute = [&](const __bf16 *As, const __bf16 *Bs) {
+        bf16x8 a[2][2][NS], b[2][NS];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 a[2][NS], b[NS];
             const __bf16 *pb = Bs + (wq * 32 + r) * PW_ROW + s * 16 + h * 8;
 #pragma unroll
-            for (int p = 0; p < NS; ++p) b[p] = *reinterpret_cast<const bf16x8 *>(pb + p * PW_T * PW_ROW);
+            for (int p = 0; p < NS; ++p) b[s][p] = *reinterpret_cast<const bf16x8 *>(pb + p * PW_T * PW_ROW);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const __bf16 *pa = As + (wr * 64 + j * 32 + r) * PW_ROW + s * 16 + h * 8;
 #pragma unroll
-                for (int p = 0; p < NS; ++p) a[j][p] = *reinterpret_cast<const bf16x8 *>(pa + p * PW_T * PW_ROW);
+                for (int p = 0; p < NS; ++p) a[s][j][p] = *reinterpret_cast<const bf16x8 *>(pa + p * PW_T * PW_ROW);
             }
+        }
+        // small terms first; (plane of A, plane of B) per term
+        constexpr int TERMS = NS == 3 ? 6 : 3;
+        constexpr int ta[6] = {NS == 3 ? 1 : 0, NS == 3 ? 0 : 1, NS == 3 ? 2 : 0, 0, 1, 0};
+        constexpr int tb[6] = {1, NS == 3 ? 2 : 0, 0, 1, 0, 0};
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                f32x16 d = acc[i];                             // small terms first
-                if (NS == 3) {
-                    d = mfma(a[i][1], b[1], d);
-                    d = mfma(a[i][0], b[NS - 1], d);
-                    d = mfma(a[i][NS - 1], b[0], d);
-                }
-                d = mfma(a[i][0], b[1], d);
-                d = mfma(a[i][1], b[0], d);
-                acc[i] = mfma(a[i][0], b[0], d);
+        for (int t = 0; t < TERMS; ++t) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][s] = mfma(a[s][i][ta[t]], b[s][tb[t]], acc[i][s]);
             }
         }
     };
     // buffer (c & 1) holds chunk c, (xa, xb) chunk c + 1; (fa, fb) are free and take chunk c + 2
-    auto step = [&](int c, float (&fa)[8], float (&fb)[8], int &fka, int &fkb, float (&xa)[8], float (&xb)[8],
-                    int xka, int xkb) {
+    auto step = [&](auto fastc, int c, float (&fa)[8], float (&fb)[8], int &fka, int &fkb, float (&xa)[8],
+                    float (&xb)[8], int xka, int xkb) {
+        constexpr bool FAST = decltype(fastc)::value;
         __bf16 *cur = lds + (c & 1) * 2 * TILE, *nxt = lds + ((c + 1) & 1) * 2 * TILE;
-        if (c + 2 < c1) fetch(fa, fb, fka, fkb);
-        compute(cur, cur + TILE);
-        if (c + 1 < c1) {
-            la.template stage<NS>(nxt, xa, xka);
-            lb.template stage<NS>(nxt + TILE, xb, xkb);
+        if (FAST) fetch_fast(fa, fb);
+        else if (c + 2 < c1) fetch(fa, fb, fka, fkb);
+        auto split = [&]() {
+            if (c + 1 < c1) {
+                la.template stage<NS>(nxt, xa, FAST ? (A_KC ? 4 : 8) : xka);
+                lb.template stage<NS>(nxt + TILE, xb, FAST ? (B_KC ? 4 : 8) : xkb);
+            }
+        };
+#ifdef PW_PINGPONG
+        // experiment: the two waves of a SIMD (w, w + 4) take the chunk's two phases in opposite order
+        if (wave < 4) {
+            if (!FAST || c < c1) compute(cur, cur + TILE);
+            pw_barrier();
+            split();
+        } else {
+            split();
+            pw_barrier();
+            if (!FAST || c < c1) compute(cur, cur + TILE);
+        }
+#else
+        if (!FAST || c < c1) compute(cur, cur + TILE);
+        split();
+#endif
+        pw_barrier();
+    };
+    if (fast && c0 < c1) {                     // (an empty slice reads nothing: its chunk indices lie outside the operands)
+        fetch_fast(va0, vb0);
+        fetch_fast(va1, vb1);
+        {
+            __bf16 *first = lds + (c0 & 1) * 2 * TILE;
+            la.template stage<NS>(first, va0, A_KC ? 4 : 8);
+            lb.template stage<NS>(first + TILE, vb0, B_KC ? 4 : 8);
         }
         __syncthreads();
-    };
-    if (c0 < c1) {
-        fetch(va0, vb0, ka0, kb0);
-        if (c0 + 1 < c1) fetch(va1, vb1, ka1, kb1);
-        __bf16 *first = lds + (c0 & 1) * 2 * TILE;
-        la.template stage<NS>(first, va0, ka0);
-        lb.template stage<NS>(first + TILE, vb0, kb0);
-    }
-    __syncthreads();
-    for (int c = c0; c < c1; c += 2) {
-        step(c, va0, vb0, ka0, kb0, va1, vb1, ka1, kb1);
-        if (c + 1 < c1) step(c + 1, va1, vb1, ka1, kb1, va0, vb0, ka0, kb0);
+        // (two steps per iteration, BOTH unconditional -- an odd last step only fetches and meets the barrier: with the
+        // second step under a condition the two register sets changed roles across the loop's back edge by copies, and
+        // a copy of a load's destination waits for the load)
+        for (int c = c0; c < c1; c += 2) {
+            step(std::true_type{}, c, va0, vb0, ka0, kb0, va1, vb1, 0, 0);
+            step(std::true_type{}, c + 1, va1, vb1, ka1, kb1, va0, vb0, 0, 0);
+        }
+    } else if (!fast) {
+        if (c0 < c1) {
+            fetch(va0, vb0, ka0, kb0);
+            if (c0 + 1 < c1) fetch(va1, vb1, ka1, kb1);
+            __bf16 *first = lds + (c0 & 1) * 2 * TILE;
+            la.template stage<NS>(first, va0, ka0);
+            lb.template stage<NS>(first + TILE, vb0, kb0);
+        }
+        __syncthreads();
+        for (int c = c0; c < c1; c += 2) {
+            step(std::false_type{}, c, va0, vb0, ka0, kb0, va1, vb1, ka1, kb1);
+            if (c + 1 < c1) step(std::false_type{}, c + 1, va1, vb1, ka1, kb1, va0, vb0, ka0, kb0);
+        }
     }
 
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i][0] += acc[i][1];
     const int q = Q0 + wq * 32 + r;
     if (g.pool_val) {
         // row maxima over the tile's columns instead of the tile: value 16 i + e of a lane <-> row
@@ -286,7 +346,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                mv[16 * i + e] = q < g.Q ? acc[i][e] : -__builtin_inff();
+                mv[16 * i + e] = q < g.Q ? acc[i][0][e] : -__builtin_inff();
                 mi[16 * i + e] = q;
             }
         }
@@ -320,7 +380,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = R0 + wr * 64 + i * 32 + acc_row(e, h);
-            if (row < g.R && q < g.Q) D[(size_t)row * g.ldd + q] = acc[i][e];
+            if (row < g.R && q < g.Q) D[(size_t)row * g.ldd + q] = acc[i][0][e];
         }
     }
     if (g.part) {
@@ -331,8 +391,8 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                s1[16 * i + e] = acc[i][e];
-                s2[16 * i + e] = acc[i][e] * acc[i][e];
+                s1[16 * i + e] = acc[i][0][e];
+                s2[16 * i + e] = acc[i][0][e] * acc[i][0][e];
             }
         }
         pw_halving(s1, r);
