@@ -60,6 +60,28 @@ struct PwGemm {
 //   row-contiguous operand (k * ld + i): the lane runs along i (64 consecutive floats per instruction), thread
 //     (i = t & 127, q = t >> 7) holds k = 8 q .. 8 q + 7 of row i.
 // Addresses are clamped into the operand (every load legal and unpredicated); staging zeroes what lies outside.
+typedef float pw_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pw_bf16x2 __attribute__((ext_vector_type(2)));
+
+// NS bf16 planes of the pair (a, b) as packed words (a in the low half): one v_cvt_pk_bf16_f32 per plane for BOTH
+// values, the remainders by one two-wide subtraction -- ~4.5 vector instructions per value instead of ~9 for the
+// value-by-value form (the split is the kernel's largest cost: at eight waves per CU its vector instructions, not
+// the MFMAs, bound the chunk)
+template <int NS>
+__device__ __forceinline__ void pw_split_pair(float a, float b, unsigned (&pl)[NS]) {
+    pw_f32x2 v = {a, b};
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+        const pw_bf16x2 hv = __builtin_convertvector(v, pw_bf16x2);
+        const unsigned w = __builtin_bit_cast(unsigned, hv);
+        pl[p] = w;
+        if (p + 1 < NS) {
+            const pw_f32x2 u = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+            v = v - u;
+        }
+    }
+}
+
 template <bool KCONT>
 struct PwLoader {
     int i0, kofs;            // KCONT: rg, 4 seg; else: i, 8 q
@@ -147,6 +169,33 @@ struct PwLoader {
             __bf16 *dst = tile + i0 * PW_ROW + kofs;
 #pragma unroll
             for (int p = 0; p < NS; ++p) *reinterpret_cast<bf16x8 *>(dst + p * PW_T * PW_ROW) = pl[p];
+        }
+    }
+    // The same for a whole chunk (every k inside K), two values at a time.  ZERO_ROWS: rows outside the operand become
+    // zeros (needed for the B operand only: the statistics epilogue sums over the tile's columns; rows of A outside
+    // R produce rows of D that are never stored).
+    template <int NS, bool ZERO_ROWS>
+    __device__ __forceinline__ void stage_fast(__bf16 *tile, const float (&v)[8]) const {
+        if (KCONT) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool in = !ZERO_ROWS || ((rows >> j) & 1u);
+                unsigned p01[NS], p23[NS];
+                pw_split_pair<NS>(in ? v[4 * j] : 0.0f, in ? v[4 * j + 1] : 0.0f, p01);
+                pw_split_pair<NS>(in ? v[4 * j + 2] : 0.0f, in ? v[4 * j + 3] : 0.0f, p23);
+                __bf16 *dst = tile + (64 * j + i0) * PW_ROW + kofs;
+#pragma unroll
+                for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2 *>(dst + p * PW_T * PW_ROW) = make_uint2(p01[p], p23[p]);
+            }
+        } else {
+            const bool in = !ZERO_ROWS || rows;
+            unsigned q[4][NS];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pw_split_pair<NS>(in ? v[2 * e] : 0.0f, in ? v[2 * e + 1] : 0.0f, q[e]);
+            __bf16 *dst = tile + i0 * PW_ROW + kofs;
+#pragma unroll
+            for (int p = 0; p < NS; ++p)
+                *reinterpret_cast<uint4 *>(dst + p * PW_T * PW_ROW) = make_uint4(q[0][p], q[1][p], q[2][p], q[3][p]);
         }
     }
 };
@@ -238,10 +287,12 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         const int k0 = fk * PW_KC;
         (void)la.load(g.A, g.A.p + g.A.batch * fz, R0, g.R, k0, g.K, 1, true, xa);
         (void)lb.load(g.B, g.B.p + g.B.batch * fz, Q0, g.Q, k0, g.K, 1, true, xb);
-        if (fc + 1 < c1) {
-            ++fc;
-            if (++fk == g.cpb) { fk = 0; ++fz; }
-        }
+        const int adv = fc + 1 < c1 ? 1 : 0;              // (selects, no branch: the step stays one basic block)
+        fc += adv;
+        fk += adv;
+        const int wrap = fk == g.cpb ? 1 : 0;
+        fk = wrap ? 0 : fk;
+        fz += wrap;
     };
     // Four independent accumulator chains per wave -- (row block i, k-step s) -- issued in turn: a chain's next MFMA
     // needs the previous one's result (64 cycles away), and with fewer than four the matrix pipe waits on it whenever
@@ -273,64 +324,73 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
             }
         }
     };
-    // buffer (c & 1) holds chunk c, (xa, xb) chunk c + 1; (fa, fb) are free and take chunk c + 2
-    auto step = [&](auto fastc, int c, float (&fa)[8], float (&fb)[8], int &fka, int &fkb, float (&xa)[8],
+    // buffer PAR holds chunk c, (xa, xb) chunk c + 1; (fa, fb) are free and take chunk c + 2
+    // (the buffer a step reads is a compile-time constant -- chunk parity relative to the slice's first chunk, and the
+    // loop is unrolled by two: the compiler then knows that the MFMA phase's LDS reads and the split phase's LDS writes
+    // never overlap and may interleave the two phases' instructions)
+    // FASTC: 0 = the general form; 1 = steady state, conditions on the slice's end kept; 2 = steady state with at
+    // least two more chunks behind this one: no condition at all -- one basic block per step, in which the scheduler
+    // is free to place the split phase's vector instructions between the MFMAs
+    auto step = [&](auto fastc, auto parc, int c, float (&fa)[8], float (&fb)[8], int &fka, int &fkb, float (&xa)[8],
                     float (&xb)[8], int xka, int xkb) {
-        constexpr bool FAST = decltype(fastc)::value;
-        __bf16 *cur = lds + (c & 1) * 2 * TILE, *nxt = lds + ((c + 1) & 1) * 2 * TILE;
+        constexpr int FASTC = decltype(fastc)::value;
+        constexpr bool FAST = FASTC != 0, FREE = FASTC == 2;
+        constexpr int PAR = decltype(parc)::value;
+        __bf16 *cur = lds + PAR * 2 * TILE, *nxt = lds + (1 - PAR) * 2 * TILE;
         if (FAST) fetch_fast(fa, fb);
         else if (c + 2 < c1) fetch(fa, fb, fka, fkb);
         auto split = [&]() {
-            if (c + 1 < c1) {
-                la.template stage<NS>(nxt, xa, FAST ? (A_KC ? 4 : 8) : xka);
-                lb.template stage<NS>(nxt + TILE, xb, FAST ? (B_KC ? 4 : 8) : xkb);
+            if (FREE || c + 1 < c1) {
+                if (FAST) {
+                    la.template stage_fast<NS, false>(nxt, xa);
+                    lb.template stage_fast<NS, true>(nxt + TILE, xb);
+                } else {
+                    la.template stage<NS>(nxt, xa, xka);
+                    lb.template stage<NS>(nxt + TILE, xb, xkb);
+                }
             }
         };
-#ifdef PW_PINGPONG
-        // experiment: the two waves of a SIMD (w, w + 4) take the chunk's two phases in opposite order
-        if (wave < 4) {
-            if (!FAST || c < c1) compute(cur, cur + TILE);
-            pw_barrier();
-            split();
-        } else {
-            split();
-            pw_barrier();
-            if (!FAST || c < c1) compute(cur, cur + TILE);
-        }
-#else
-        if (!FAST || c < c1) compute(cur, cur + TILE);
+        // (measured and rejected: the two waves of a SIMD taking the two phases in opposite order, two barriers per
+        // chunk -- 3-5 % slower with or without four accumulator chains: DESIGN.md section 7c)
+        if (!FAST || FREE || c < c1) compute(cur, cur + TILE);
         split();
-#endif
         pw_barrier();
     };
     if (fast && c0 < c1) {                     // (an empty slice reads nothing: its chunk indices lie outside the operands)
         fetch_fast(va0, vb0);
         fetch_fast(va1, vb1);
         {
-            __bf16 *first = lds + (c0 & 1) * 2 * TILE;
-            la.template stage<NS>(first, va0, A_KC ? 4 : 8);
-            lb.template stage<NS>(first + TILE, vb0, B_KC ? 4 : 8);
+            __bf16 *first = lds;
+            la.template stage_fast<NS, false>(first, va0);
+            lb.template stage_fast<NS, true>(first + TILE, vb0);
         }
         __syncthreads();
         // (two steps per iteration, BOTH unconditional -- an odd last step only fetches and meets the barrier: with the
         // second step under a condition the two register sets changed roles across the loop's back edge by copies, and
         // a copy of a load's destination waits for the load)
-        for (int c = c0; c < c1; c += 2) {
-            step(std::true_type{}, c, va0, vb0, ka0, kb0, va1, vb1, 0, 0);
-            step(std::true_type{}, c + 1, va1, vb1, ka1, kb1, va0, vb0, 0, 0);
+        int c = c0;
+        for (; c + 2 < c1; c += 2) {               // both chunks of the pair have a successor: nothing conditional
+            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, c, va0, vb0, ka0, kb0, va1, vb1, 0, 0);
+            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, c + 1, va1, vb1, ka1, kb1, va0, vb0, 0, 0);
+        }
+        for (; c < c1; c += 2) {
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, c, va0, vb0, ka0, kb0, va1, vb1, 0, 0);
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, c + 1, va1, vb1, ka1, kb1, va0, vb0, 0, 0);
         }
     } else if (!fast) {
         if (c0 < c1) {
             fetch(va0, vb0, ka0, kb0);
             if (c0 + 1 < c1) fetch(va1, vb1, ka1, kb1);
-            __bf16 *first = lds + (c0 & 1) * 2 * TILE;
+            __bf16 *first = lds;
             la.template stage<NS>(first, va0, ka0);
             lb.template stage<NS>(first + TILE, vb0, kb0);
         }
         __syncthreads();
         for (int c = c0; c < c1; c += 2) {
-            step(std::false_type{}, c, va0, vb0, ka0, kb0, va1, vb1, ka1, kb1);
-            if (c + 1 < c1) step(std::false_type{}, c + 1, va1, vb1, ka1, kb1, va0, vb0, ka0, kb0);
+            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, c, va0, vb0, ka0, kb0, va1, vb1, ka1, kb1);
+            if (c + 1 < c1)
+                step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, c + 1, va1, vb1, ka1, kb1, va0, vb0, ka0,
+                     kb0);
         }
     }
 
