@@ -105,11 +105,13 @@ class AnchorSelfAttention(nn.Module):
         """x (B,M,C), xyz (B,M,3) -> (B,M,C)."""
         gravity_center = _mean_over_points(xyz)
         relative_xyz = xyz - gravity_center
-        emb = self.pos_embedding(relative_xyz.permute(0, 2, 1)).permute(0, 2, 1)
-        q, k, v = self.to_qkv(x).chunk(3, dim=-1)
+        from . import pointwise
+        on = self.fused and x.is_cuda
+        emb = pointwise.conv_then_bn(relative_xyz.permute(0, 2, 1).contiguous(), self.pos_embedding, allow=on).permute(0, 2, 1)
+        q, k, v = (pointwise.linear_nobias(x, self.to_qkv) if on else self.to_qkv(x)).chunk(3, dim=-1)
         q, k, v = q + emb, k + emb, v + emb
         if self.fused or not x.is_cuda:
             o = attention(q, k, v, self.head_num)      # raises on CPU tensors: no CPU fallback
         else:
             o = _reference(q, k, v, self.head_num)
-        return self.res(o.permute(0, 2, 1)).permute(0, 2, 1)
+        return pointwise.conv_then_bn(o.permute(0, 2, 1).contiguous(), self.res, allow=on).permute(0, 2, 1)

@@ -47,7 +47,7 @@ struct PwGemm {
     int cps;                  // chunks per grid.z slice
     int total;                // chunks in all
     int a_vec, b_vec;         // k-contiguous operand readable as float4
-    float *part;              // optional [(z * gridDim.x + x)][2][R]: row sums and sums of squares of this tile
+    float *part;              // optional [(z * gridDim.x + x)][2][R]: this tile's row sums and M2 (squared deviations from the tile's row means)
     float *pool_val;          // optional [(z * gridDim.x + x)][R]: the tile's row maxima (D is then not written) ...
     int *pool_idx;            // ... and the column each was found at (the lowest one among equals)
 };
@@ -444,15 +444,28 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         }
     }
     if (g.part) {
-        // row sums over this tile's columns (columns past Q hold zeros): value 16 i + e of a lane <-> row
-        // 32 i + acc_row(e, h) of the wave; after the halving lane r holds row 32 (r >> 4) + acc_row(r & 15, h)
+        // BatchNorm's statistics of this tile, per row (= channel): {sum, M2 = sum of squared deviations from the
+        // TILE's mean} over its columns < Q -- not {sum, sum of squares}: E[y^2] - mean^2 loses mean^2 / var digits, and
+        // the imitator has channels with a few samples each (BatchNorm over 2 clouds x 4 anchors) whose mean is 100x
+        // their spread.  Each wave's 32 columns are summed around a shift c = the row's value in the wave's first
+        // column (any sample will do: the cancellation left is (mean - c)^2 / var = O(1)); the four waves' blocks and,
+        // in pw_bn_act_kernel, the tiles are combined in float64 by the pairwise update of Chan et al.
+        // value 16 i + e of a lane <-> row 32 i + acc_row(e, h) of the wave; after the halving lane r holds the total
+        // of value r, i.e. row 32 (r >> 4) + acc_row(r & 15, h)
+        float (*cshift)[2][32] = reinterpret_cast<float (*)[2][32]>(pw_lds);                       // [wave][h][value]
+        float (*redc)[PW_T] = reinterpret_cast<float (*)[PW_T]>(pw_lds + 8 * 2 * 32 * 4);          // [wq][row]
         float s1[32], s2[32];
+        const bool valid = q < g.Q;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                s1[16 * i + e] = acc[i][0][e];
-                s2[16 * i + e] = acc[i][0][e] * acc[i][0][e];
+                const float y = acc[i][0][e];
+                const float c = __shfl(y, lane & 32);          // the half-wave's first column
+                if (r == 0) cshift[wave][h][16 * i + e] = y;
+                const float d = valid ? y - c : 0.0f;
+                s1[16 * i + e] = d;
+                s2[16 * i + e] = d * d;
             }
         }
         pw_halving(s1, r);
@@ -460,11 +473,26 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         const int row = wr * 64 + (r >> 4) * 32 + acc_row(r & 15, h);
         red[wq][0][row] = s1[0];
         red[wq][1][row] = s2[0];
+        redc[wq][row] = cshift[wave][h][r];                   // (one wave's LDS operations execute in order)
         __syncthreads();
         if (t < PW_T && R0 + t < g.R) {
+            double n = 0.0, mean = 0.0, m2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                int nw = g.Q - (Q0 + 32 * w);
+                nw = nw < 0 ? 0 : (nw > 32 ? 32 : nw);
+                if (nw > 0) {
+                    const double a = (double)red[w][0][t], b = (double)red[w][1][t];
+                    const double mw = (double)redc[w][t] + a / nw, m2w = b - a * a / nw;
+                    const double tot = n + nw, delta = mw - mean;
+                    m2 += m2w + delta * delta * n * nw / tot;
+                    mean += delta * nw / tot;
+                    n = tot;
+                }
+            }
             float *dst = g.part + ((size_t)z * gridDim.x + blockIdx.x) * 2 * g.R + R0 + t;
-            dst[0] = (red[0][0][t] + red[1][0][t]) + (red[2][0][t] + red[3][0][t]);
-            dst[g.R] = (red[0][1][t] + red[1][1][t]) + (red[2][1][t] + red[3][1][t]);
+            dst[0] = (float)(mean * n);
+            dst[g.R] = (float)(m2 < 0.0 ? 0.0 : m2);
         }
     }
 }
@@ -496,15 +524,22 @@ __global__ __launch_bounds__(256) void pw_bn_act_kernel(int B, int C, int N, con
     const int c = blockIdx.x, t = threadIdx.x;
     float mean, inv;
     if (training) {
-        double a = 0.0, q = 0.0;
-        for (int i = t; i < tiles; i += 256) {
-            a += (double)part[(size_t)i * 2 * C + c];
-            q += (double)part[(size_t)i * 2 * C + C + c];
-        }
+        // part[tile] = {sum, M2 around the tile's mean} (pw_gemm_kernel's epilogue); tile i covers the columns
+        // [128 (i mod tx), ...) of a cloud: M2 = sum_t m2_t + sum_t n_t (mean_t - mean)^2, in float64
+        const int tx = (N + PW_T - 1) / PW_T;
+        double a = 0.0;
+        for (int i = t; i < tiles; i += 256) a += (double)part[(size_t)i * 2 * C + c];
         a = pw_block_sum(a, scratch);
-        q = pw_block_sum(q, scratch);
         const double cnt = (double)B * N, mu = a / cnt;
-        double var = q / cnt - mu * mu;
+        double q = 0.0;
+        for (int i = t; i < tiles; i += 256) {
+            int nt = N - PW_T * (i % tx);
+            nt = nt > PW_T ? PW_T : nt;
+            const double dm = (double)part[(size_t)i * 2 * C + c] / nt - mu;
+            q += (double)part[(size_t)i * 2 * C + C + c] + dm * dm * nt;
+        }
+        q = pw_block_sum(q, scratch);
+        double var = q / cnt;
         if (var < 0.0) var = 0.0;
         mean = (float)mu;
         inv = (float)(1.0 / sqrt(var + (double)eps));

@@ -84,10 +84,11 @@ class Producefactor(nn.Module):
         idx_knn = knn_point(self.keighbors, sa_xyz, a_points)
         local_feat = torch.max(index_points(sa_x, idx_knn), dim=2)[0]
         local_feat = local_feat + self.anchor_selfattention(x=local_feat, xyz=a_points)
-        global_feat = self.global_layer(a_points.permute(0, 2, 1)).permute(0, 2, 1)
+        on = a_points.is_cuda
+        global_feat = pointwise.conv_then_bn(a_points.permute(0, 2, 1).contiguous(), self.global_layer, allow=on).permute(0, 2, 1)
         global_feat = torch.max(global_feat, dim=1, keepdim=True)[0]
         feat = torch.cat([local_feat, global_feat.repeat(1, num_anchor, 1)], dim=-1)
-        return self.prob_head(feat.permute(0, 2, 1)).permute(0, 2, 1)
+        return pointwise.conv_then_bn(feat.permute(0, 2, 1).contiguous(), self.prob_head, allow=on).permute(0, 2, 1)
 
 
 class SAComponent(nn.Module):
@@ -126,10 +127,12 @@ class SAComponent(nn.Module):
         """(:704-713) up to the Gumbel soft-max: (B,N,2)."""
         N = x0.shape[-1]
         local = self.localfeat_mask_selfattention(x=x0.permute(0, 2, 1), xyz=xyz) + x0.permute(0, 2, 1)
-        masking_local = self.extract_local_feat_masking(local.permute(0, 2, 1))
-        masking_global = torch.max(self.extract_global_feat_masking(x_last), dim=2, keepdim=True)[0]
+        on = x0.is_cuda and self.embedding.fused
+        masking_local = pointwise.conv_then_bn(local.permute(0, 2, 1).contiguous(), self.extract_local_feat_masking, allow=on)
+        masking_global = torch.max(pointwise.conv_then_bn(x_last, self.extract_global_feat_masking, allow=on), dim=2,
+                                   keepdim=True)[0]
         masking = torch.cat([masking_local, masking_global.repeat(1, 1, N)], dim=1)
-        return self.fuse_masking(masking).permute(0, 2, 1)
+        return pointwise.conv_then_bn(masking, self.fuse_masking, allow=on).permute(0, 2, 1)
 
     def forward(self, x, a_index=None, return_logits=False):
         """x (B,N,3), a_index (B,M) anchor indices -> prob (B,M,9), masking (B,N,2) one-hot."""

@@ -200,6 +200,62 @@ def conv_max(x, weight, bias=None, relu=True):
     return _ConvMax.apply(x, weight, bias, relu)[0]
 
 
+def conv_then_bn(x, block, allow=True):
+    """Sequential(Conv1d(k = 1[, bias]), BatchNorm1d) on x (B, C, N).  Without a convolution bias the whole block runs on
+    the contraction kernels (`_ConvBNAct`); with one, the convolution + bias does (its weight gradient is a split-K
+    contraction instead of MIOpen's `igemm_wrw`, 130 us for 3 -> 64 channels over 32 x 1024 points) and the BatchNorm
+    module follows on PyTorch -- the bias is NOT dropped although a training-mode BatchNorm cancels it: it still moves
+    the running mean, matters in eval mode, and its (numerically tiny) gradient is what the reference hands Adam."""
+    conv, bn = block[0], block[1]
+    plain = not (block._forward_pre_hooks or conv._forward_hooks or conv._forward_pre_hooks or bn._forward_pre_hooks)
+    if allow and plain and len(block) == 2 and _pointwise_conv(x, conv):
+        out = None
+        if conv.bias is None and supported(x, conv, bn) and not bn._forward_hooks:
+            out = _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, bn, False)
+        elif conv.bias is not None:
+            out = bn(conv_bias_act(x, conv.weight, conv.bias, relu=False))
+        if out is not None:
+            for hook in block._forward_hooks.values():      # the block's own forward hooks see the fused result
+                res = hook(block, (x,), out)
+                if res is not None:
+                    out = res
+            return out
+    return block(x)
+
+
+class _LinearNoBias(torch.autograd.Function):
+    """y (P, O) = x (P, C) W^T with the weight gradient on the contraction kernel's split-K form: W.grad (O, C) =
+    g^T x contracts over the P rows (32768 of them for the imitator's `to_qkv`): the GEMM library ran that product as
+    a handful of workgroups (134 us); the forward and the input gradient are well-shaped library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            P, C = x.shape
+            O = weight.shape[0]
+            gw = torch.empty(O, C, device=x.device)
+            contract(1, O, C, P, g, 0, O, False, x, 0, C, False, gw, reduce=True)
+        return gx, gw
+
+
+def linear_nobias(x, linear):
+    """`linear(x)` for a bias-free nn.Linear and x (..., C) float32 on the GPU (else the module itself)."""
+    if (linear.bias is not None or not x.is_cuda or x.dtype != torch.float32 or x.shape[-1] != linear.in_features
+            or x.numel() // x.shape[-1] < 4096):
+        return linear(x)
+    lead = x.shape[:-1]
+    return _LinearNoBias.apply(x.reshape(-1, x.shape[-1]).contiguous(), linear.weight).reshape(*lead, linear.out_features)
+
+
 def matmul_nt(a, b):
     """a (R, K) @ b (Q, K)^T -> (R, Q) on the contraction kernel in its split-K form (both operands contiguous along
     the contracted index; fixed-order fold).  For the small products of the fused blocks' backward passes whose

@@ -515,7 +515,8 @@ APN_API int apn_sa_wide_colsum_f32(const float *part, int rows, int ncol, float 
  * precision = 2: operands split into two bf16 planes (three MFMAs per product, ~4e-6 of an fp32 contraction);
  *   3: three planes, six MFMAs, fp32-class (~2e-7).  f32 accumulation either way.
  * conv_forward: y = w x per cloud; part (may be NULL)
- *   [apn_pw_conv_tiles(b, n)][2][c_out] = each 128-position tile's {sum, sum of squares} of y per channel.
+ *   [apn_pw_conv_tiles(b, n)][2][c_out] = each 128-position tile's {sum, M2 = sum of squared deviations from the
+ *   tile's own mean} of y per channel (combined over tiles in float64 by bn_act: no E[y^2] - mean^2 cancellation).
  * bn_act: out = [relu](gamma (y - mean) invstd + beta); training: batch statistics folded (float64) from `part`
  *   (tiles rows), running_mean / running_var updated with `momentum` (unbiased variance) and batches[0] += 1
  *   (each may be NULL); otherwise the running statistics are used.  stat [4][c] = {mean, invstd, scale, shift}.

@@ -174,10 +174,15 @@ def test_joint_step_replayed_from_a_hipgraph_equals_eager(dev):
     _compare("joint step", eager, replayed, mods, eager_w, snap[0], floor=eager_w2, floor_losses=eager2)
 
 
-def test_classifier_step_replayed_from_a_hipgraph_equals_eager(dev):
+def test_classifier_step_replayed_from_a_hipgraph_equals_eager(dev, monkeypatch):
     """One `train_one_epoch` iteration (adaptpoint_amd.gan.ClassifierStep: resampler, fused PointNeXt-S, SmoothCE,
-    gradient-norm clipping, capturable fused AdamW)."""
+    gradient-norm clipping, capturable fused AdamW).  With fused.DETERMINISTIC the step has no order-dependent sum
+    left (stage 1: fixed-point sums; stages 2-4: the width-generic family; the per-point layers: fixed-order folds), so
+    two eager runs from the same state agree to the last bit -- and so must the replays (Adam turns a last-bit
+    difference of a near-zero gradient into a full step: without this the comparison needs a run-to-run floor)."""
+    from adaptpoint_amd import fused
     from adaptpoint_amd.gan import ClassifierStep
+    monkeypatch.setattr(fused, "DETERMINISTIC", True)
     from adaptpoint_amd.pointnext import PointNextSClassifier, fill_parameters_by_name
     B, N = 4, 2048
     C = _no_dropout(fill_parameters_by_name(PointNextSClassifier(fused=True))).to(dev)
@@ -232,6 +237,13 @@ def test_classifier_step_replayed_from_a_hipgraph_equals_eager(dev):
         graph.replay()
         torch.cuda.synchronize()
         replayed.append({"loss": cap_loss.item()})
+    exact = all(a["loss"] == b["loss"] for a, b in zip(eager, eager2)) and all(
+        torch.equal(eager_w[0][k], eager_w2[0][k]) for k in eager_w[0])
+    print("classifier step: two eager runs bit-identical:", exact)
+    assert exact
+    assert [d["loss"] for d in replayed] == [d["loss"] for d in eager]
+    now = C.state_dict()
+    assert all(torch.equal(now[k], eager_w[0][k]) for k in now)
     _compare("classifier step", eager, replayed, (C,), eager_w, snap[0], floor=eager_w2, floor_losses=eager2)
 
 
