@@ -13,8 +13,23 @@
 // for the scatters into per-point buffers).  bn_fold / reduce_rows remain for the width-generic family.
 #include "apn_common.h"
 #include "sa_chain.h"
+#include "apn_mfma.h"
 
 namespace apn {
+
+// Diagnostics (builds with -DAPN_WG_STAMPS only: scripts/stamp_glue.py): wall-clock stamps of a workgroup's phases,
+// 16 per workgroup, written by thread 0 -- where the few microseconds of these latency-bound kernels go.
+#ifdef APN_WG_STAMPS
+__device__ unsigned long long *d_wg_stamps = nullptr;
+__device__ __forceinline__ void wg_stamp(int k) {
+    unsigned long long *st = d_wg_stamps;
+    if (st && threadIdx.x == 0)
+        st[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + k] = wall_clock64();
+}
+#else
+__device__ __forceinline__ void wg_stamp(int) {}
+#endif
+
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
@@ -182,37 +197,48 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(
 // Loads are issued in independent batches (indices, then rows) so that the dependent
 // index -> row chain is paid once, not once per loop iteration.  Optionally records the source
 // point of each query.
-template <int NT, int WST, int FST>
+template <int NT, int QT, int WST, int FST>
 __device__ __forceinline__ void stage_skip_operands(int cloud, int n, int m, int m0,
                                                     const __bf16 *__restrict__ ft,
                                                     const __bf16 *__restrict__ ft_lo,
                                                     const int *__restrict__ fidx,
                                                     const float *__restrict__ ws,
                                                     float (*sws)[WST], float (*sfi)[FST], int *ssrc) {
-    constexpr int G = NT / 32, QPT = 64 / G;        // row groups, queries per thread
+    constexpr int G = NT / 32, QPT = QT / G, WPT = 64 / G;     // row groups; queries and weight rows per thread
     const int tid = threadIdx.x, i = tid & 31, q0 = tid >> 5;     // queries q0 + G t
     int src[QPT];
 #pragma unroll
     for (int t = 0; t < QPT; ++t) {
         const int q = m0 + q0 + G * t;
-        src[t] = q < m ? fidx[(size_t)cloud * m + q] : -1;
+        const int got = fidx[(size_t)cloud * m + (q < m ? q : m - 1)];
+        src[t] = q < m ? got : -1;
+    }
+    float wv[WPT];
+#pragma unroll
+    for (int t = 0; t < WPT; ++t) wv[t] = ws[(q0 + G * t) * 32 + i];
+    // (every load unconditional, on a clamped index, and selected afterwards: a load under a condition sits in a
+    // basic block of its own and is waited for before the next one is issued -- four serial round trips here)
+    const __bf16 *lo_tab = ft_lo ? ft_lo : ft;
+    __bf16 hv[QPT], lv[QPT];
+#pragma unroll
+    for (int t = 0; t < QPT; ++t) {
+        const size_t o = ((size_t)cloud * n + (src[t] < 0 ? 0 : src[t])) * 32 + i;
+        hv[t] = ft[o];
+        lv[t] = lo_tab[o];
     }
     float v[QPT];
 #pragma unroll
     for (int t = 0; t < QPT; ++t) {
-        v[t] = 0.0f;
-        if (src[t] >= 0) {
-            const size_t o = ((size_t)cloud * n + src[t]) * 32 + i;
-            v[t] = (float)ft[o];
-            if (ft_lo) v[t] += (float)ft_lo[o];
-        }
+        const float f = (float)hv[t] + (ft_lo ? (float)lv[t] : 0.0f);
+        v[t] = src[t] >= 0 ? f : 0.0f;
     }
 #pragma unroll
     for (int t = 0; t < QPT; ++t) {
         sfi[q0 + G * t][i] = v[t];
         if (ssrc && i == 0) ssrc[q0 + G * t] = src[t] < 0 ? 0 : src[t];
-        sws[q0 + G * t][i] = ws[(q0 + G * t) * 32 + i];
     }
+#pragma unroll
+    for (int t = 0; t < WPT; ++t) sws[q0 + G * t][i] = wv[t];
 }
 
 // out[b][c][m] = act( ysel[b][m][c] * scale2[c] + shift2[c] + identity[b][c][m] )   (C = 64)
@@ -220,44 +246,52 @@ __device__ __forceinline__ void stage_skip_operands(int cloud, int n, int m, int
 // pointnext.py:157-161) when ws != null; act = ReLU when relu != 0 (pointnext.py:167-168).
 // The sampled points' features come from the point-major bf16 table(s) of the block
 // (hi [+ lo]): one contiguous 64-byte row per query instead of 32 strided 4-byte loads.
-// One workgroup of 1024 threads per 64-query tile (there are only B*M/64 tiles, about one
-// per CU: sixteen waves keep enough loads in flight and split the 64x64x32 product);
-// thread = (query tx, 4 channels of wave ty): the query's 32 inputs sit in registers, the
-// weight rows are wave-uniform 16-byte LDS broadcasts.
-__global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float *__restrict__ ysel,
-                                                       const unsigned long long *__restrict__ acc2,
-                                                       const double *__restrict__ sums2, BnArgs bn2,
-                                                       float *__restrict__ pack2,
-                                                       const __bf16 *__restrict__ ft,
-                                                       const __bf16 *__restrict__ ft_lo,
-                                                       const int *__restrict__ fidx,
-                                                       const float *__restrict__ ws,
-                                                       const float *__restrict__ bs, int relu,
-                                                       float *__restrict__ out, float4 *__restrict__ zero,
-                                                       long long zero_n4) {
-    __shared__ float tile[64][65];
-    __shared__ float sfi[64][33];
+// One workgroup of 16 QT threads per tile of QT queries (QT = 64: sixteen waves; QT = 32: eight waves, twice the
+// workgroups -- the headline shape has only B*M/64 = 256 tiles of 64, ONE workgroup per CU, and the kernel is a chain of
+// dependent phases (index -> row gather, fold, normalise, product, store): with two workgroups per CU one's loads run
+// under the other's arithmetic).  thread = (query, 4 channels): the query's 32 inputs sit in registers, the weight rows
+// are 16-byte LDS broadcasts.
+template <int QT>
+__global__ __launch_bounds__(QT * 16) void fwd_out_kernel(int n, int m, const float *__restrict__ ysel,
+                                                          const unsigned long long *__restrict__ acc2,
+                                                          const double *__restrict__ sums2, BnArgs bn2,
+                                                          float *__restrict__ pack2,
+                                                          const __bf16 *__restrict__ ft,
+                                                          const __bf16 *__restrict__ ft_lo,
+                                                          const int *__restrict__ fidx,
+                                                          const float *__restrict__ ws,
+                                                          const float *__restrict__ bs, int relu,
+                                                          float *__restrict__ out, float4 *__restrict__ zero,
+                                                          long long zero_n4) {
+    constexpr int NT = QT * 16, NW = NT / 64, HALVES = 64 / QT;   // waves; query groups per wave
+    __shared__ float tile[QT][65];
+    __shared__ __attribute__((aligned(16))) float sfi[QT][36];
     __shared__ double ftot[128];
     __shared__ float s_sc[64], s_sh[64];
     // BatchNorm-2 folded here (formerly a launch of its own): {sum, sumsq}[64] of y2 from the forward pass's
     // accumulator set (integer atomics: the same bits in every workgroup and every run) or from reduced sums
     const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+    wg_stamp(0);
     double count2 = bn2.count;
     if (bn2.training) {
         if (threadIdx.x < 128) ftot[threadIdx.x] = sums2 ? sums2[threadIdx.x] : acc_read(acc2, 128, threadIdx.x);
         if (sums2) count2 = sums2[128];
     }
     __shared__ __attribute__((aligned(16))) float sws[64][36];
-    const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..15
+    __shared__ float s_bs[64];
+    const int cloud = blockIdx.y, m0 = blockIdx.x * QT;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..NW-1
+    if (threadIdx.x >= 128 && threadIdx.x < 192) s_bs[tx] = (ws && bs) ? bs[tx] : 0.0f;   // (one load, not one per output)
     float ys4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // j = query within tile, tx = channel (requested before the fold's barrier)
-        const int q = m0 + ty + 16 * k;
-        ys4[k] = q < m ? ysel[((size_t)cloud * m + q) * 64 + tx] : 0.f;
+        const int q = m0 + ty + NW * k;
+        ys4[k] = ysel[((size_t)cloud * m + (q < m ? q : m - 1)) * 64 + tx];     // (rows past m: dropped below)
     }
-    if (ws) stage_skip_operands<1024, 36, 33>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, nullptr);
+    if (ws) stage_skip_operands<NT, QT, 36, 36>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, nullptr);
+    wg_stamp(1);
     __syncthreads();
+    wg_stamp(2);
     if (threadIdx.x < 64) {
         if (first && threadIdx.x == 0 && bn2.training && bn2.nbt) *bn2.nbt += 1;
         float sc, sh;
@@ -271,44 +305,61 @@ __global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float
         const float sc = s_sc[tx], sh = s_sh[tx];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int j = ty + 16 * k;
+            const int j = ty + NW * k;
             tile[j][tx] = m0 + j < m ? ys4[k] * sc + sh : 0.f;
         }
     }
+    wg_stamp(3);
     __syncthreads();
-    float fi[32];
+    wg_stamp(4);
     if (ws) {
+        // identity branch: Ws (64 x 32) times the tile's sampled features (32 x QT) as MFMA products on split (hi + lo)
+        // operands -- six MFMAs per 32 x 32 block of outputs, one wave per block (the multiply-add loop over LDS that
+        // stood here took 2.3 us of the kernel's 7: two LDS reads per multiply-add)
+        constexpr int QB = QT / 32;
+        if (ty < 2 * QB) {                               // wave-uniform
+            const int cb = ty & 1, qb = ty >> 1, r = tx & 31, h = tx >> 5;
+            f32x16 acc = {0};
 #pragma unroll
-        for (int i = 0; i < 32; ++i) fi[i] = sfi[tx][i];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {        // c = channel (wave-uniform), tx = query
-        const int c = 4 * ty + k;
-        float v = tile[tx][c];
-        if (ws) {
-            float idn = bs ? bs[c] : 0.0f;
-            const float4 *wrow = reinterpret_cast<const float4 *>(sws[c]);
-#pragma unroll
-            for (int i4 = 0; i4 < 8; ++i4) {
-                const float4 w = wrow[i4];
-                idn = __builtin_fmaf(w.x, fi[4 * i4], idn);
-                idn = __builtin_fmaf(w.y, fi[4 * i4 + 1], idn);
-                idn = __builtin_fmaf(w.z, fi[4 * i4 + 2], idn);
-                idn = __builtin_fmaf(w.w, fi[4 * i4 + 3], idn);
+            for (int st = 0; st < 2; ++st) {
+                float av[8], bv[8];
+                const float4 a0 = *reinterpret_cast<const float4 *>(&sws[32 * cb + r][16 * st + 8 * h]);
+                const float4 a1 = *reinterpret_cast<const float4 *>(&sws[32 * cb + r][16 * st + 8 * h + 4]);
+                const float4 b0 = *reinterpret_cast<const float4 *>(&sfi[32 * qb + r][16 * st + 8 * h]);
+                const float4 b1 = *reinterpret_cast<const float4 *>(&sfi[32 * qb + r][16 * st + 8 * h + 4]);
+                av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+                bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+                acc = mfma<2>(make_frag<2>(av), make_frag<2>(bv), acc);
             }
-            v += idn;
+            const int ql = 32 * qb + r;                  // lane = query (column), register e <-> channel (row)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = 32 * cb + acc_row(e, h);
+                float v = tile[ql][c] + (acc[e] + s_bs[c]);
+                if (relu) v = fmaxf(v, 0.0f);
+                if (m0 + ql < m) out[((size_t)cloud * 64 + c) * m + m0 + ql] = v;
+            }
         }
-        if (relu) v = fmaxf(v, 0.0f);
-        if (m0 + tx < m) out[((size_t)cloud * 64 + c) * m + m0 + tx] = v;
+    } else {
+        const int ql = tx % QT, hh = tx / QT;     // query of the tile; which four-channel group of the wave
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * (ty * HALVES + hh) + k;
+            float v = tile[ql][c];
+            if (relu) v = fmaxf(v, 0.0f);
+            if (m0 + ql < m) out[((size_t)cloud * 64 + c) * m + m0 + ql] = v;
+        }
     }
+    wg_stamp(5);
     // The backward pass accumulates into A / gip / its accumulator sets with atomics; they are zeroed HERE, by the last forward
     // launch (race-free: their writers run after it), so that the backward needs no fill launch of its own.  At the END of
     // the kernel: the memory counter is in order, and a variable number of stores ahead of the loads made every wait for
     // a load wait for the whole fill.
     if (zero) {
         const long long nb = (long long)gridDim.x * gridDim.y, bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
-        for (long long i = bid * 1024 + threadIdx.x; i < zero_n4; i += nb * 1024) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long i = bid * NT + threadIdx.x; i < zero_n4; i += nb * NT) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    wg_stamp(6);
 }
 
 // Backward entry.  g = g_out * [out > 0] (when relu) is dL/d(pre-activation).
@@ -319,53 +370,63 @@ __global__ __launch_bounds__(1024) void fwd_out_kernel(int n, int m, const float
 //   partWs[blk][64*32] = sum_q g[q][c] * fi[q][i]        (dL/dWs of the block's queries)
 //   gip[b][n][i]   += sum_c ws[c][i] * g[q][c]  at n = fidx[b][q]   (dL/df through the skip,
 //                     point-major rows: 128-byte atomic segments)
-__global__ __launch_bounds__(1024) void bwd_prep_kernel(int n, int m, const float *__restrict__ g_out,
-                                                        long long gs_b, long long gs_c, long long gs_m,
-                                                        const float *__restrict__ out, int relu,
-                                                        const float *__restrict__ ysel,
-                                                        const float *__restrict__ pack2,
-                                                        const __bf16 *__restrict__ ft,
-                                                        const __bf16 *__restrict__ ft_lo,
-                                                        const int *__restrict__ fidx,
-                                                        const float *__restrict__ ws,
-                                                        float *__restrict__ goa,
-                                                        unsigned long long *__restrict__ accS,
-                                                        float *__restrict__ partWs,
-                                                        float *__restrict__ gip,
-                                                        unsigned *__restrict__ cells) {
-    // 1024 threads per 64-query tile (about one tile per CU), as in fwd_out_kernel
-    __shared__ float smax[16];
-    __shared__ float tile[64][65];       // g[q][c]
-    __shared__ float red[16][2][64];
-    __shared__ __attribute__((aligned(8))) float sfi[64][34];
+template <int QT>
+__global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const float *__restrict__ g_out,
+                                                           long long gs_b, long long gs_c, long long gs_m,
+                                                           const float *__restrict__ out, int relu,
+                                                           const float *__restrict__ ysel,
+                                                           const float *__restrict__ pack2,
+                                                           const __bf16 *__restrict__ ft,
+                                                           const __bf16 *__restrict__ ft_lo,
+                                                           const int *__restrict__ fidx,
+                                                           const float *__restrict__ ws,
+                                                           float *__restrict__ goa,
+                                                           unsigned long long *__restrict__ accS,
+                                                           float *__restrict__ partWs,
+                                                           float *__restrict__ gip,
+                                                           unsigned *__restrict__ cells) {
+    // 16 QT threads per tile of QT queries, as in fwd_out_kernel
+    constexpr int NT = QT * 16, NW = NT / 64, HALVES = 64 / QT;
+    __shared__ float smax[NW];
+    __shared__ float tile[QT][65];       // g[q][c]
+    __shared__ float red[NW][2][64];
+    __shared__ __attribute__((aligned(16))) float sfi[QT][36];
     __shared__ float sws[64][33];
-    __shared__ int ssrc[64];
-    const int cloud = blockIdx.y, m0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..15
+    __shared__ int ssrc[QT];
+    const int cloud = blockIdx.y, m0 = blockIdx.x * QT;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..NW-1
+    const int ql = tx % QT, hh = tx / QT;
+    wg_stamp(0);
+    // every load of the phase is issued before the first one is used (clamped indices, selected afterwards)
+    const int qc = m0 + ql < m ? m0 + ql : m - 1;
+    const float *outp = relu ? out : g_out;               // (no activation: any readable address, value unused)
+    float gv[4], ov[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {        // read (c, query tx): coalesced over queries
-        const int c = ty + 16 * k;
-        float g = 0.0f;
-        if (m0 + tx < m) {
-            const size_t o = ((size_t)cloud * 64 + c) * m + m0 + tx;
-            g = g_out[cloud * gs_b + c * gs_c + (m0 + tx) * gs_m];
-            if (relu && !(out[o] > 0.0f)) g = 0.0f;
-        }
-        tile[tx][c] = g;
+    for (int k = 0; k < 4; ++k) {        // read (c, query ql): coalesced over queries
+        const int c = (ty + NW * k) * HALVES + hh;
+        gv[k] = g_out[cloud * gs_b + c * gs_c + qc * gs_m];
+        ov[k] = relu ? outp[((size_t)cloud * 64 + c) * m + qc] : 1.0f;
     }
-    float ys[4];                         // ysel of (query ty + 16 k, channel tx), used after the barrier
+    float ys[4];                         // ysel of (query ty + NW k, channel tx), used after the barrier
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int q = m0 + ty + 16 * k;
-        ys[k] = q < m ? ysel[((size_t)cloud * m + q) * 64 + tx] : 0.0f;
+        const int q = m0 + ty + NW * k;
+        ys[k] = ysel[((size_t)cloud * m + (q < m ? q : m - 1)) * 64 + tx];
     }
-    if (ws) stage_skip_operands<1024, 33, 34>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, ssrc);
+    if (ws) stage_skip_operands<NT, QT, 33, 36>(cloud, n, m, m0, ft, ft_lo, fidx, ws, sws, sfi, ssrc);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = (ty + NW * k) * HALVES + hh;
+        tile[ql][c] = (m0 + ql < m && ov[k] > 0.0f) ? gv[k] : 0.0f;
+    }
+    wg_stamp(1);
     __syncthreads();
+    wg_stamp(2);
     const float sc = pack2[tx], mu = pack2[128 + tx], iv = pack2[192 + tx];
     float s1 = 0.0f, s2 = 0.0f, gm = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {        // (query j, channel tx): coalesced over channels
-        const int j = ty + 16 * k, q = m0 + j;
+        const int j = ty + NW * k, q = m0 + j;
         if (q < m) {
             const float g = tile[j][tx];
             const float gs = g * sc;
@@ -387,43 +448,69 @@ __global__ __launch_bounds__(1024) void bwd_prep_kernel(int n, int m, const floa
         }
         if (tx == 0) smax[ty] = __uint_as_float(gb);
     }
+    wg_stamp(3);
     __syncthreads();
+    wg_stamp(4);
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     if (cells && threadIdx.x == 0) {
         unsigned gb = 0u;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) gb = __float_as_uint(smax[k]) > gb ? __float_as_uint(smax[k]) : gb;
+        for (int k = 0; k < NW; ++k) gb = __float_as_uint(smax[k]) > gb ? __float_as_uint(smax[k]) : gb;
         atomicMax(cells, gb);                                     // order-independent
     }
+    float sacc = 0.0f;
     if (ty < 2) {
-        float acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc += red[k][ty][tx];
-        acc_add(accS, 128, (int)(blk % ACC_COPIES), ty * 64 + tx, acc);
+        for (int k = 0; k < NW; ++k) sacc += red[k][ty][tx];
     }
+    wg_stamp(5);
     if (ws) {
-        // dL/dWs[c][i]: thread (c = tx, inputs i = 2 ty, 2 ty + 1)
-        float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll 8
-        for (int q = 0; q < 64; ++q) {
-            const float g = tile[q][tx];
-            const float2 fv = *reinterpret_cast<const float2 *>(&sfi[q][2 * ty]);
-            a0 = __builtin_fmaf(g, fv.x, a0);
-            a1 = __builtin_fmaf(g, fv.y, a1);
+        // The block's two products as MFMAs on split (hi + lo) operands, one wave per 32 x 32 block of results (the
+        // multiply-add loops over LDS that stood here took 1.5 + 4 us of the kernel's 12):
+        //   dL/dfi[q][i] = sum_c g[q][c] ws[c][i]   (QT x 32, K = 64)   -> point-major gip rows, atomics
+        //   dL/dWs[c][i] = sum_q g[q][c] fi[q][i]   (64 x 32, K = QT)   -> this block's partial row
+        constexpr int QB = QT / 32;
+        const int r = tx & 31, h = tx >> 5;
+        if (ty < QB) {                                   // wave-uniform: query block ty
+            f32x16 acc = {0};
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    av[j] = tile[32 * ty + r][16 * st + 8 * h + j];
+                    bv[j] = sws[16 * st + 8 * h + j][r];
+                }
+                acc = mfma<2>(make_frag<2>(av), make_frag<2>(bv), acc);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {                // lane = input i (column), register e <-> query (row)
+                const int q = 32 * ty + acc_row(e, h);
+                if (m0 + q < m) atomicAdd(gip + ((size_t)cloud * n + ssrc[q]) * 32 + r, acc[e]);
+            }
+        } else if (ty < QB + 2) {                        // channel block ty - QB
+            const int cb = ty - QB;
+            f32x16 acc = {0};
+#pragma unroll
+            for (int st = 0; st < QT / 16; ++st) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    av[j] = tile[16 * st + 8 * h + j][32 * cb + r];
+                    bv[j] = sfi[16 * st + 8 * h + j][r];
+                }
+                acc = mfma<2>(make_frag<2>(av), make_frag<2>(bv), acc);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e)                  // lane = input i, register e <-> channel
+                partWs[blk * 2048 + (32 * cb + acc_row(e, h)) * 32 + r] = acc[e];
         }
-        *reinterpret_cast<float2 *>(partWs + blk * 2048 + tx * 32 + 2 * ty) = make_float2(a0, a1);
-        // dL/dfi[q][i] -> point-major gip rows: thread (i = tid & 31, queries qg, qg + 32)
-        const int i = threadIdx.x & 31, qg = threadIdx.x >> 5;
-        float v0 = 0.0f, v1 = 0.0f;
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) {
-            const float w = sws[c][i];
-            v0 = __builtin_fmaf(w, tile[qg][c], v0);
-            v1 = __builtin_fmaf(w, tile[qg + 32][c], v1);
-        }
-        if (m0 + qg < m) atomicAdd(gip + ((size_t)cloud * n + ssrc[qg]) * 32 + i, v0);
-        if (m0 + qg + 32 < m) atomicAdd(gip + ((size_t)cloud * n + ssrc[qg + 32]) * 32 + i, v1);
+        wg_stamp(6);
     }
+    // the accumulator set's adds LAST: the compiler placed a wait for every outstanding memory operation inside the loop
+    // that followed them (2.5 us of every workgroup, waiting for atomics nobody reads here)
+    if (ty < 2) acc_add(accS, 128, (int)(blk % ACC_COPIES), ty * 64 + tx, sacc);
+    wg_stamp(7);
 }
 
 // Everything downstream of dL/dy1 = g_u*ca + yhat1*cb + cc, which is only ever needed summed
@@ -465,6 +552,7 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
     __shared__ float sGeo[WG_PTS][4];   // count, sum of relative positions
     __shared__ float sc[5][32];         // ca, cb, cc, mean1, inv1
     const int tid = threadIdx.x;
+    wg_stamp(0);
     const int cloud = blockIdx.y, n0 = blockIdx.x * WG_PTS;
     const int block = cloud * gridDim.x + blockIdx.x;
     const size_t p0 = (size_t)cloud * n + n0;            // first point row of the tile
@@ -495,33 +583,43 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
         sc[tid < 32 ? 2 : 1][c] = val;                    // cc from T1, cb from T2
         if (tid < 32) sc[0][c] = sca;
     } else if (tid >= 96 && tid < 160) sc[3 + ((tid - 96) >> 5)][tid & 31] = pack1[64 + tid - 96];   // mean1, inv1
+    wg_stamp(1);
     __syncthreads();
+    wg_stamp(2);
     {
         const int c = tid & 31;                           // fixed per thread: e = tid + 1024 k
         const float ca = sc[0][c], cb = sc[1][c], cc = sc[2][c];
         const double fx_inv = cells ? ldexp(1.0, -(int)cells[1]) : 0.0;
+        // every load of the tile is issued before the first one is used (clamped rows, selected afterwards): under
+        // conditions each sat in a block of its own and was waited for before the next was issued
+        float a_f[2] = {0.0f, 0.0f}, f_hi[2], f_lo[2], g_i[2], h_a[2], h_b[2];
+        long long a_q[2] = {0ll, 0ll};
+        const __bf16 *lo_tab = ft_lo ? ft_lo : ft;
+        const float *gip_tab = gip ? gip : HA;               // (no skip branch: any readable table, value unused)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int pt = (tid >> 5) + 32 * k;
+            const size_t pr = (p0 + (pt < n_here ? pt : 0)) * 32 + c;
+            const size_t qr = (size_t)(q0 + pt < total_q ? q0 + pt : 0) * 32 + c;
+            if (cells) a_q[k] = reinterpret_cast<const long long *>(A)[pr];
+            else a_f[k] = A[pr];
+            f_hi[k] = (float)ft[pr];
+            f_lo[k] = (float)lo_tab[pr];
+            g_i[k] = gip_tab[gip ? pr : qr];
+            h_a[k] = HA[qr];
+            h_b[k] = HB[qr];
+        }
+        const bool marked = cells && cells[2] != 0u;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int pt = (tid >> 5) + 32 * k;
             const bool ok = pt < n_here;
-            float av = 0.0f;
-            if (ok && !cells) av = A[(p0 + pt) * 32 + c];
-            if (ok && cells) {
-                // bit-reproducible mode: A holds 64-bit fixed-point sums in units of 2^-s (apn_sa_bwd_main)
-                const long long q = reinterpret_cast<const long long *>(A)[(p0 + pt) * 32 + c];
-                av = cells[2] ? __builtin_nanf("") : (float)((double)q * fx_inv);
-            }
-            sG[pt][c] = av;
-            float fv = ok ? (float)ft[(p0 + pt) * 32 + c] : 0.0f;
-            if (ft_lo && ok) fv += (float)ft_lo[(p0 + pt) * 32 + c];     // split mode: hi + lo
-            sB[pt][6 + c] = fv;
-            sI[pt][c] = (gip && ok) ? gip[(p0 + pt) * 32 + c] : 0.0f;
-            float hv = 0.0f;
-            if (q0 + pt < total_q) {
-                const size_t o = (size_t)(q0 + pt) * 32 + c;
-                hv = __builtin_fmaf(ca, HA[o], __builtin_fmaf(cb, HB[o], cc * 32.0f));
-            }
-            sH[pt][c] = hv;
+            // bit-reproducible mode: A holds 64-bit fixed-point sums in units of 2^-s (apn_sa_bwd_main)
+            float av = cells ? (marked ? __builtin_nanf("") : (float)((double)a_q[k] * fx_inv)) : a_f[k];
+            sG[pt][c] = ok ? av : 0.0f;
+            sB[pt][6 + c] = ok ? f_hi[k] + (ft_lo ? f_lo[k] : 0.0f) : 0.0f;
+            sI[pt][c] = (gip && ok) ? g_i[k] : 0.0f;
+            sH[pt][c] = q0 + pt < total_q ? __builtin_fmaf(ca, h_a[k], __builtin_fmaf(cb, h_b[k], cc * 32.0f)) : 0.0f;
         }
     }
     if (tid < WG_PTS * 3) {
@@ -537,7 +635,9 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
         const long long gv = pt < n_here ? geo[(p0 + pt) * 4 + j] : 0ll;
         sGeo[pt][j] = j == 0 ? (float)gv : (float)((double)gv * (1.0 / 68719476736.0));
     }
+    wg_stamp(3);
     __syncthreads();
+    wg_stamp(4);
 
     const int tx = tid & 63, ty = tid >> 6;               // ty = 0..15, wave-uniform
     {   // G in place of A: thread (point tx, mid channels 2 ty, 2 ty + 1)
@@ -564,7 +664,9 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
             sG[tx][mid] = sc[0][mid] * sG[tx][mid] + sc[1][mid] * yhs + sc[2][mid] * cnt;
         }
     }
+    wg_stamp(5);
     __syncthreads();
+    wg_stamp(6);
 
     {   // products for dL/dW1: thread (mid, column group grp 0..31) owns columns grp, grp + 32
         const int mid = tid & 31, grp = tid >> 5;
@@ -614,6 +716,7 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
         for (int mid = 0; mid < 32; ++mid) hr[mid] = sH[tx][mid];
         g_q[(size_t)(q0 + tx) * 3 + ty - 4] = -dot_col(hr, ty - 4) * inv_r;
     }
+    wg_stamp(7);
 }
 
 // Backward launch 4 of 4: every parameter gradient out of the partial rows (column sums in float64, fixed order)
@@ -748,6 +851,9 @@ extern "C" int apn_sa_bn_fold(const float *part, int rows, const double *sums, i
     return APN_OK;
 }
 
+// queries per workgroup of the output / backward-entry kernels: 32 while tiles of 64 would leave CUs with one workgroup
+static int apn_sa_glue_tile(int b, int m) { return (long long)b * ((m + 63) / 64) <= 512 ? 32 : 64; }
+
 extern "C" int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const void *acc2, const double *sums2,
                               const float *g2, const float *b2, float *rm2, float *rv2, void *nbt2, float eps2,
                               float mom2, int train2, double count, float *pack2, const void *ft, int precision,
@@ -761,14 +867,22 @@ extern "C" int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const void
     const __bf16 *lo = (ws && precision == 2) ? hi + (size_t)b * n * 32 : nullptr;
     if (zero_base && (zero_floats < 0 || (zero_floats & 3) || ((uintptr_t)zero_base & 15))) return APN_EINVAL;
     apn::BnArgs bn{g2, b2, rm2, rv2, (long long *)nbt2, eps2, mom2, train2, count};
-    hipLaunchKernelGGL(apn::fwd_out_kernel, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, ysel,
-                       (const unsigned long long *)(sums2 ? nullptr : acc2), sums2, bn, pack2, hi, lo, fidx, ws, bs, relu,
-                       out, (float4 *)zero_base, zero_base ? zero_floats / 4 : 0);
+    if (apn_sa_glue_tile(b, m) == 32)
+        hipLaunchKernelGGL(apn::fwd_out_kernel<32>, dim3((m + 31) / 32, b), dim3(512), 0, APN_ST, n, m, ysel,
+                           (const unsigned long long *)(sums2 ? nullptr : acc2), sums2, bn, pack2, hi, lo, fidx, ws, bs,
+                           relu, out, (float4 *)zero_base, zero_base ? zero_floats / 4 : 0);
+    else
+        hipLaunchKernelGGL(apn::fwd_out_kernel<64>, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, ysel,
+                           (const unsigned long long *)(sums2 ? nullptr : acc2), sums2, bn, pack2, hi, lo, fidx, ws, bs,
+                           relu, out, (float4 *)zero_base, zero_base ? zero_floats / 4 : 0);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
 
-extern "C" int apn_sa_bwd_prep_rows(int b, int m) { return b * ((m + 63) / 64); }
+extern "C" int apn_sa_bwd_prep_rows(int b, int m) {
+    const int qt = apn_sa_glue_tile(b, m);
+    return b * ((m + qt - 1) / qt);
+}
 
 extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long long gs_b,
                                long long gs_c, long long gs_m, const float *out, int relu,
@@ -781,12 +895,24 @@ extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long lon
         return APN_EINVAL;
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = (ws && precision == 2) ? hi + (size_t)b * n * 32 : nullptr;
-    hipLaunchKernelGGL(apn::bwd_prep_kernel, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, g_out,
-                       gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, (unsigned long long *)accS,
-                       partWs, gip, cells);
+    if (apn_sa_glue_tile(b, m) == 32)
+        hipLaunchKernelGGL(apn::bwd_prep_kernel<32>, dim3((m + 31) / 32, b), dim3(512), 0, APN_ST, n, m, g_out,
+                           gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, (unsigned long long *)accS,
+                           partWs, gip, cells);
+    else
+        hipLaunchKernelGGL(apn::bwd_prep_kernel<64>, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, g_out,
+                           gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, (unsigned long long *)accS,
+                           partWs, gip, cells);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
+
+#ifdef APN_WG_STAMPS
+// (diagnostic builds only) attach a buffer of 16 stamps per workgroup for the next launches of this file's kernels
+extern "C" __attribute__((visibility("default"))) int apn_sa_debug_wg_stamps(void *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(apn::d_wg_stamps), &buf, sizeof(buf));
+}
+#endif
 
 extern "C" int apn_sa_bwd_weight_rows(int b, int n) { return b * ((n + apn::WG_PTS - 1) / apn::WG_PTS); }
 
