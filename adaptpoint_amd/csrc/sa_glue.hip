@@ -668,25 +668,60 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
     __syncthreads();
     wg_stamp(6);
 
-    {   // products for dL/dW1: thread (mid, column group grp 0..31) owns columns grp, grp + 32
-        const int mid = tid & 31, grp = tid >> 5;
-        const bool qcol = grp >= 3 && grp <= 5;           // query columns: new_xyz x H
-        const bool two = grp + 32 < 38;
-        float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll 8
-        for (int pt = 0; pt < WG_PTS; ++pt) {
-            const float g = sG[pt][mid];
-            const float a0 = qcol ? sH[pt][mid] : g;
-            acc0 = __builtin_fmaf(a0, sB[pt][grp], acc0);
-            if (two) acc1 = __builtin_fmaf(g, sB[pt][grp + 32], acc1);
+    // The tile's two dense products as MFMAs on split (hi + lo) operands, one wave per 32 x 32 block of results (the
+    // multiply-add loops over LDS that stood here took 6 of the workgroup's 12 us):
+    //   partW[mid][col] = sum_pt X[pt][mid] sB[pt][col]   (32 x 38, K = 64; X = H for the query columns 3..5, else G)
+    //   dL/df[i][pt]    = sum_mid W1[mid][3 + i] G[pt][mid] (+ gip)   (32 x 64, K = 32)
+    {
+        const int r = tx & 31, h = tx >> 5;
+        if (ty < 3) {
+            // wave 0: columns 0..31 but 3..5 (from G); wave 1: columns 32..37 (from G); wave 2: columns 3..5 (from H)
+            const float (*X)[33] = ty == 2 ? sH : sG;
+            const int col = ty == 1 ? 32 + r : r;
+            const bool mine = ty == 0 ? !(r >= 3 && r <= 5) : (ty == 1 ? r < 6 : (r >= 3 && r <= 5));
+            f32x16 acc = {0};
+#pragma unroll
+            for (int st = 0; st < WG_PTS / 16; ++st) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    av[j] = X[16 * st + 8 * h + j][r];                       // rows = mid, k = point
+                    bv[j] = mine ? sB[16 * st + 8 * h + j][col] : 0.0f;      // columns, k = point
+                }
+                acc = mfma<2>(make_frag<2>(av), make_frag<2>(bv), acc);
+            }
+            float *row = partW + (size_t)block * 32 * 38;
+            if (mine) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) row[acc_row(e, h) * 38 + col] = acc[e];     // lane = column, register <-> mid
+            }
+        } else if (ty < 5) {
+            const int pb = ty - 3;                               // point block
+            f32x16 acc = {0};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                float av[8], bv[8];
+                const float4 a0 = *reinterpret_cast<const float4 *>(&swt[3 + r][16 * st + 8 * h]);
+                const float4 a1 = *reinterpret_cast<const float4 *>(&swt[3 + r][16 * st + 8 * h + 4]);
+                av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bv[j] = sG[32 * pb + r][16 * st + 8 * h + j];
+                acc = mfma<2>(make_frag<2>(av), make_frag<2>(bv), acc);
+            }
+            const int pt = 32 * pb + r;                          // lane = point (column), register <-> input channel
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = acc_row(e, h);
+                if (pt < n_here) g_f[((size_t)cloud * 32 + i) * n + n0 + pt] = acc[e] + sI[pt][i];
+            }
         }
-        float *row = partW + (size_t)block * 32 * 38;
-        row[mid * 38 + grp] = acc0;
-        if (two) row[mid * 38 + grp + 32] = acc1;
+    }
+    if (!g_p && !g_q) {                                          // (wave-uniform; the common case)
+        wg_stamp(7);
+        return;
     }
 
-    // dL/df (2 channels per thread), dL/dp, dL/dnew_p: the point's / query's 32 mid values in
-    // registers, W1 columns as wave-uniform 16-byte broadcasts
+    // dL/dp, dL/dnew_p: the point's / query's 32 mid values in registers, W1 columns as wave-uniform 16-byte broadcasts
     float gr[32];
 #pragma unroll
     for (int mid = 0; mid < 32; ++mid) gr[mid] = sG[tx][mid];
@@ -703,12 +738,6 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
         }
         return s;
     };
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int i = ty + 16 * k;
-        const float s = sI[tx][i] + dot_col(gr, 3 + i);
-        if (tx < n_here) g_f[((size_t)cloud * 32 + i) * n + n0 + tx] = s;
-    }
     if (ty < 3 && g_p && tx < n_here) g_p[(p0 + tx) * 3 + ty] += dot_col(gr, ty) * inv_r;
     if (ty >= 4 && ty < 7 && g_q && q0 + tx < total_q) {
         float hr[32];
