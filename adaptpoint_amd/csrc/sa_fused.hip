@@ -158,6 +158,17 @@ __device__ __forceinline__ void load_w1_frags(const float *__restrict__ w1, int 
 constexpr int PS_PTS = 512, PS_MAX_ROWS = 64;
 constexpr double GEO_INV_UNIT = 1.0 / 68719476736.0;       // sa_geo.hip: D in units of 2^-36
 
+#ifdef APN_WG_STAMPS
+// (diagnostic builds only, scripts/stamp_glue.py) wall-clock stamps of a workgroup's phases, 16 per workgroup
+__device__ unsigned long long *d_wg_stamps_f = nullptr;
+__device__ __forceinline__ void wg_stamp(int k) {
+    unsigned long long *st = d_wg_stamps_f;
+    if (st && threadIdx.x == 0) st[(size_t)blockIdx.x * 16 + k] = wall_clock64();
+}
+#else
+__device__ __forceinline__ void wg_stamp(int) {}
+#endif
+
 template <int NS>
 __global__ __launch_bounds__(1024) void sa_prep_stats_kernel(
     int n, int tiles_per_cloud, int total_tiles, const float *__restrict__ f, const long long *__restrict__ geo,
@@ -170,6 +181,7 @@ __global__ __launch_bounds__(1024) void sa_prep_stats_kernel(
     __shared__ double sdd[6];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    wg_stamp(0);
     // accumulators of LATER launches (BatchNorm-2's sums) are cleared here
     for (long long e = (long long)blockIdx.x * 1024 + tid; e < zero_words; e += (long long)gridDim.x * 1024) zero[e] = 0ull;
     Frag<NS> wf[3];                                              // W1f^T as B operand: lane = mid channel r (step 2 unused)
@@ -191,12 +203,15 @@ __global__ __launch_bounds__(1024) void sa_prep_stats_kernel(
                 gv = make_float4((float)g0.x, (float)((double)g0.y * GEO_INV_UNIT), (float)((double)g1.x * GEO_INV_UNIT),
                                  (float)((double)g1.y * GEO_INV_UNIT));
             }
+            wg_stamp(1);
             __syncthreads();                                        // the previous tile's readers
 #pragma unroll
             for (int k = 0; k < 16; ++k) sf[cg + 2 * k][pt] = v[k];
             if (cg == 0) sgeo[pt] = gv;
+            wg_stamp(2);
         }
         __syncthreads();
+        wg_stamp(3);
         const int pt = 32 * wave + r;                               // this lane's point: channels 8h.., 16 + 8h..
         float x0[8], x1[8];
 #pragma unroll
@@ -212,6 +227,7 @@ __global__ __launch_bounds__(1024) void sa_prep_stats_kernel(
                 rl[2 + h] = __builtin_bit_cast(uint4, a1.p[NS - 1]);
             }
         }
+        wg_stamp(4);
         if (stats) {
             f32x16 y = {0};
             y = mfma<NS>(a0, wf[0], y);                             // F: lane = mid channel r, register = point
@@ -226,14 +242,19 @@ __global__ __launch_bounds__(1024) void sa_prep_stats_kernel(
             }
         }
     }
+    wg_stamp(5);
     if (!stats) return;
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
     if (lane < 32) { red[wave][r] = s1; red[wave][32 + r] = s2; }
-    if (blockIdx.x == 0 && tid >= 64 && tid < 70) {          // the batch's second moments: its clouds' shares, in order
+    if (blockIdx.x == 0 && wave >= 1 && wave < 7) {          // the batch's second moments: its clouds' shares
+        // one wave per moment: lane l sums rows l, l + 64, ... in order, then a fixed butterfly -- the same bits in every
+        // run (a single thread walking the rows one dependent load at a time held workgroup 0 back by 2.4 us)
         double s = 0.0;
-        for (int e = 0; e < dd_rows; ++e) s += dd[(size_t)e * 6 + (tid - 64)];
-        sdd[tid - 64] = s;
+        for (int e = lane; e < dd_rows; e += 64) s += dd[(size_t)e * 6 + (wave - 1)];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) sdd[wave - 1] = s;
     }
     __syncthreads();
     if (tid < 64) {
@@ -249,6 +270,7 @@ __global__ __launch_bounds__(1024) void sa_prep_stats_kernel(
         }
         part[(size_t)blockIdx.x * 64 + tid] = val;
     }
+    wg_stamp(6);
 }
 
 // Gathering one tile.  Lane (pos, h) fetches 2 x 16 bytes of its neighbour's bf16 row (and of
@@ -1302,6 +1324,12 @@ extern "C" int apn_sa_prep_stats(int b, int n, const float *f, const void *geo, 
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
+
+#ifdef APN_WG_STAMPS
+extern "C" __attribute__((visibility("default"))) int apn_sa_debug_wg_stamps_fused(void *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(apn::d_wg_stamps_f), &buf, sizeof(buf));
+}
+#endif
 
 static unsigned long long *g_stamps = nullptr;
 // Diagnostics: attach (or detach: NULL) a buffer of 16 x (workgroups x 4) 64-bit stamps; the next launches of the two

@@ -532,8 +532,11 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
 //   dL/dnew_p[q][d] = -sum_mid H[q][mid] * W1[mid][d] / r            (optional)
 // One workgroup of 1024 threads per tile (there are B*N/64 tiles, two per CU).
 constexpr int WG_PTS = 64;
+// threads per workgroup of bwd_point_grads_kernel: 512 -- two workgroups fit a CU (1024: one, and the grid of B*N/64
+// workgroups ran as two rounds of latency chains), rows of the tile per thread, mid channels per thread
+constexpr int PG_NT = 512, PG_K = WG_PTS * 32 / PG_NT, PG_M = 32 * 64 / PG_NT;
 
-__global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
+__global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
     int n, int total_q, int split, const float *__restrict__ A, const unsigned *__restrict__ cells,
     const long long *__restrict__ geo,
     const float *__restrict__ HA, const float *__restrict__ HB, const unsigned long long *__restrict__ accT,
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
     const size_t p0 = (size_t)cloud * n + n0;            // first point row of the tile
     const int q0 = block * WG_PTS;                       // first query row (flat)
     const int n_here = n - n0 < WG_PTS ? n - n0 : WG_PTS;
-    for (int e = tid; e < 32 * 35; e += 1024) {
+    for (int e = tid; e < 32 * 35; e += PG_NT) {
         const int mid = e / 35, col = e % 35;
         const float w = w1[e];
         const __bf16 hi = (__bf16)w;
@@ -592,13 +595,13 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
         const double fx_inv = cells ? ldexp(1.0, -(int)cells[1]) : 0.0;
         // every load of the tile is issued before the first one is used (clamped rows, selected afterwards): under
         // conditions each sat in a block of its own and was waited for before the next was issued
-        float a_f[2] = {0.0f, 0.0f}, f_hi[2], f_lo[2], g_i[2], h_a[2], h_b[2];
-        long long a_q[2] = {0ll, 0ll};
+        float a_f[PG_K] = {}, f_hi[PG_K], f_lo[PG_K], g_i[PG_K], h_a[PG_K], h_b[PG_K];
+        long long a_q[PG_K] = {};
         const __bf16 *lo_tab = ft_lo ? ft_lo : ft;
         const float *gip_tab = gip ? gip : HA;               // (no skip branch: any readable table, value unused)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int pt = (tid >> 5) + 32 * k;
+        for (int k = 0; k < PG_K; ++k) {
+            const int pt = (tid >> 5) + (PG_NT / 32) * k;
             const size_t pr = (p0 + (pt < n_here ? pt : 0)) * 32 + c;
             const size_t qr = (size_t)(q0 + pt < total_q ? q0 + pt : 0) * 32 + c;
             if (cells) a_q[k] = reinterpret_cast<const long long *>(A)[pr];
@@ -611,8 +614,8 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
         }
         const bool marked = cells && cells[2] != 0u;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int pt = (tid >> 5) + 32 * k;
+        for (int k = 0; k < PG_K; ++k) {
+            const int pt = (tid >> 5) + (PG_NT / 32) * k;
             const bool ok = pt < n_here;
             // bit-reproducible mode: A holds 64-bit fixed-point sums in units of 2^-s (apn_sa_bwd_main)
             float av = cells ? (marked ? __builtin_nanf("") : (float)((double)a_q[k] * fx_inv)) : a_f[k];
@@ -624,30 +627,31 @@ __global__ __launch_bounds__(1024) void bwd_point_grads_kernel(
     }
     if (tid < WG_PTS * 3) {
         const int pt = tid / 3, d = tid % 3;
-        sB[pt][d] = pt < n_here ? xyz[(p0 + pt) * 3 + d] : 0.0f;
-        sB[pt][3 + d] = q0 + pt < total_q ? new_xyz[(size_t)(q0 + pt) * 3 + d] : 0.0f;
-    } else if (tid < WG_PTS * 3 + WG_PTS * 3) {
-        const int e = tid - WG_PTS * 3;
-        sB[e / 3][38 + e % 3] = 0.0f;                     // pad columns
-    } else if (tid < WG_PTS * 6 + WG_PTS * 4) {
-        const int e = tid - WG_PTS * 6, pt = e >> 2, j = e & 3;
+        const float xv = xyz[(p0 + (pt < n_here ? pt : 0)) * 3 + d];
+        const float qv = new_xyz[(size_t)(q0 + pt < total_q ? q0 + pt : 0) * 3 + d];
+        sB[pt][d] = pt < n_here ? xv : 0.0f;
+        sB[pt][3 + d] = q0 + pt < total_q ? qv : 0.0f;
+        sB[pt][38 + d] = 0.0f;                            // pad columns
+    } else if (tid >= PG_NT - WG_PTS * 4) {               // (the last four waves: the first three take the rows above)
+        const int e = tid - (PG_NT - WG_PTS * 4), pt = e >> 2, j = e & 3;
         // the index stage's occurrence statistics (sa_geo.hip): {count, sum of relative positions in units of 2^-36}
-        const long long gv = pt < n_here ? geo[(p0 + pt) * 4 + j] : 0ll;
+        const long long got = geo[(p0 + (pt < n_here ? pt : 0)) * 4 + j];
+        const long long gv = pt < n_here ? got : 0ll;
         sGeo[pt][j] = j == 0 ? (float)gv : (float)((double)gv * (1.0 / 68719476736.0));
     }
     wg_stamp(3);
     __syncthreads();
     wg_stamp(4);
 
-    const int tx = tid & 63, ty = tid >> 6;               // ty = 0..15, wave-uniform
-    {   // G in place of A: thread (point tx, mid channels 2 ty, 2 ty + 1)
+    const int tx = tid & 63, ty = tid >> 6;               // ty = 0..PG_NT/64-1, wave-uniform
+    {   // G in place of A: thread (point tx, mid channels PG_M ty .. PG_M ty + PG_M - 1)
         const float cnt = sGeo[tx][0], gx = sGeo[tx][1], gy = sGeo[tx][2], gz = sGeo[tx][3];
         float fx[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) fx[i] = sB[tx][6 + i];
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm) {
-            const int mid = 2 * ty + mm;
+        for (int mm = 0; mm < PG_M; ++mm) {
+            const int mid = PG_M * ty + mm;
             const float4 *wrow = reinterpret_cast<const float4 *>(swr[mid]);
             float accf = 0.0f;
 #pragma unroll
@@ -959,7 +963,7 @@ extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const void *A, const 
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = precision == 2 ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::bwd_point_grads_kernel, dim3((n + apn::WG_PTS - 1) / apn::WG_PTS, b),
-                       dim3(1024), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, (const float *)A, cells,
+                       dim3(apn::PG_NT), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, (const float *)A, cells,
                        (const long long *)geo, HA, HB,
                        (const unsigned long long *)accT, sumsT, count, train1,
                        pack1, hi, lo, xyz, new_xyz, w1, gip, 1.0f / radius, partW, g_f, g_p, g_newp);

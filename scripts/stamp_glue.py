@@ -16,6 +16,7 @@ import bench as BN  # noqa: E402
 from adaptpoint_amd import _lib, fused  # noqa: E402
 
 LABELS = {
+    "apn_sa_prep_stats": ["entry", "loads arrived", "LDS written", "barrier 2", "table rows stored", "statistics", "end"],
     "apn_sa_fwd_out": ["entry", "loads issued", "barrier 1", "fold + normalise", "barrier 3", "outputs stored", "zero fill issued"],
     "apn_sa_bwd_prep": ["entry", "loads issued", "barrier 1", "goa + sums", "barrier 2", "acc adds", "dWs share", "gip adds"],
     "apn_sa_bwd_point_grads": ["entry", "W1 + constants", "barrier 1", "tile loads", "barrier 2", "G formed", "barrier 3", "end"],
@@ -46,6 +47,8 @@ def main():
     except AttributeError:
         raise SystemExit("libadaptpoint_amd.so was built without -DAPN_WG_STAMPS")
     attach.argtypes, attach.restype = [ctypes.c_void_p], ctypes.c_int
+    attach_f = lib.apn_sa_debug_wg_stamps_fused
+    attach_f.argtypes, attach_f.restype = [ctypes.c_void_p], ctypes.c_int
     torch.manual_seed(0)
     blk = BN.make_block(fused=True).to(dev).train()
     p, f = BN.make_inputs(32, 0)
@@ -66,10 +69,10 @@ def main():
         if name in LABELS:
             buf.zero_()
             torch.cuda.synchronize()
-            assert attach(buf.data_ptr()) == 0
+            assert (attach_f if name == 'apn_sa_prep_stats' else attach)(buf.data_ptr()) == 0
             orig(name, d, *a, **k)
             torch.cuda.synchronize()
-            assert attach(None) == 0
+            assert (attach_f if name == 'apn_sa_prep_stats' else attach)(None) == 0
             got[name] = buf.cpu().numpy().copy()
         else:
             orig(name, d, *a, **k)
