@@ -155,7 +155,7 @@ __device__ __forceinline__ void load_w1_frags(const float *__restrict__ w1, int 
 // statistics are 16 fused multiply-adds per lane.  At most PS_MAX_ROWS workgroups of 16 waves, each walking
 // tiles of 512 points: few enough partial rows that every workgroup of the next launch folds them itself
 // (no fold launch, fixed order: deterministic).
-constexpr int PS_PTS = 512, PS_MAX_ROWS = 64;
+constexpr int PS_PTS = 512, PS_MAX_ROWS = 64, PS_NT = 2 * PS_PTS;   // points per tile, rows, threads (256 / 128 / 512: the per-point pass 4 us shorter, the forward pass's fold of 128 rows 2 us longer, the step 1 % slower)
 constexpr double GEO_INV_UNIT = 1.0 / 68719476736.0;       // sa_geo.hip: D in units of 2^-36
 
 #ifdef APN_WG_STAMPS
@@ -170,20 +170,20 @@ __device__ __forceinline__ void wg_stamp(int) {}
 #endif
 
 template <int NS>
-__global__ __launch_bounds__(1024) void sa_prep_stats_kernel(
+__global__ __launch_bounds__(PS_NT) void sa_prep_stats_kernel(
     int n, int tiles_per_cloud, int total_tiles, const float *__restrict__ f, const long long *__restrict__ geo,
     const double *__restrict__ dd, int dd_rows, const float *__restrict__ w1, int stats, __bf16 *__restrict__ ft,
     __bf16 *__restrict__ ft_lo, float *__restrict__ part, unsigned long long *__restrict__ zero, long long zero_words) {
     extern __shared__ float sf_raw[];                            // [32][PS_PTS + 1] the tile, channel-major
     float (*sf)[PS_PTS + 1] = reinterpret_cast<float (*)[PS_PTS + 1]>(sf_raw);
     __shared__ float4 sgeo[PS_PTS];                              // {occ, Dx, Dy, Dz} of the tile's points
-    __shared__ float red[16][64];
+    __shared__ float red[PS_NT / 64][64];
     __shared__ double sdd[6];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     wg_stamp(0);
     // accumulators of LATER launches (BatchNorm-2's sums) are cleared here
-    for (long long e = (long long)blockIdx.x * 1024 + tid; e < zero_words; e += (long long)gridDim.x * 1024) zero[e] = 0ull;
+    for (long long e = (long long)blockIdx.x * PS_NT + tid; e < zero_words; e += (long long)gridDim.x * PS_NT) zero[e] = 0ull;
     Frag<NS> wf[3];                                              // W1f^T as B operand: lane = mid channel r (step 2 unused)
     load_w1_frags<NS>(w1, r, h, wf);
     const float wp0 = eff<NS>(w1[r * 35]), wp1 = eff<NS>(w1[r * 35 + 1]), wp2 = eff<NS>(w1[r * 35 + 2]);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void sa_prep_stats_kernel(
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
         const int cloud = tile / tiles_per_cloud, n0 = (tile % tiles_per_cloud) * PS_PTS;
         {
-            const int pt = tid & (PS_PTS - 1), cg = tid >> 9;
+            const int pt = tid & (PS_PTS - 1), cg = tid / PS_PTS;
             const bool in = n0 + pt < n;
             float v[16];
 #pragma unroll
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(1024) void sa_prep_stats_kernel(
     if (tid < 64) {
         float val = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) val += red[w][tid];
+        for (int w = 0; w < PS_NT / 64; ++w) val += red[w][tid];
         if (tid >= 32 && blockIdx.x == 0) {
             // the per-position term of sum y1^2: (W1p d)^2 summed over all positions = W1p DD W1p^T
             const double wx = wp0, wy = wp1, wz = wp2;           // tid & 31 == r
@@ -1318,7 +1318,7 @@ extern "C" int apn_sa_prep_stats(int b, int n, const float *f, const void *geo, 
             return (int)e;
         lds_set[precision - 1] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(apn_sa_prep_rows(b, n)), dim3(1024), lds, (hipStream_t)stream, n, tpc, b * tpc, f,
+    hipLaunchKernelGGL(kern, dim3(apn_sa_prep_rows(b, n)), dim3(PS_NT), lds, (hipStream_t)stream, n, tpc, b * tpc, f,
                        (const long long *)geo, (const double *)dd, b * (apn_sa_geo_dd_doubles(n) / 6), w1, stats, hi, lo, part1,
                        (unsigned long long *)zero, zero_words);
     APN_LAUNCH_CHECK();
