@@ -108,8 +108,13 @@ class KernelTimer:
         return timed
 
     def mean_us(self):
+        """(the median pair per kernel: one pair in a pass can sit behind a late host launch)"""
         torch.cuda.synchronize()
-        return {k: 1e3 * sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in self.pairs.items()}
+        out = {}
+        for k, v in self.pairs.items():
+            t = sorted(s.elapsed_time(e) for s, e in v)
+            out[k] = 1e3 * t[len(t) // 2]
+        return out
 
 
 def instrument(timer, only=None):
@@ -573,10 +578,15 @@ def main():
     fps_clouds = B_PER_GPU * m.index_batch            # clouds (= workgroups = serial chains) per sampler launch
 
     # per-kernel view (un-timed extra pass): events around every extension launch
+    # (every pass is enqueued behind a ~1 ms spin on the launch stream: the GPU then runs the launches back to back, as in
+    # the replayed graph -- issued onto an idle queue each event pair also measured the host's launch latency, and the
+    # dominant kernel read 45 us against rocprof's 39.8 of the replay)
     timer_all = KernelTimer()
     restore = instrument(timer_all)
-    for _ in range(max(2, min(args.steps, 20) // spg)):
+    for _ in range(max(6, min(args.steps, 20) // spg)):
+        torch.cuda._sleep(2_000_000)
         eager_step()
+        torch.cuda.synchronize()
     per_kernel_us = timer_all.mean_us()
     restore()
 
