@@ -380,7 +380,13 @@ __device__ __forceinline__ void touch(const TileHead &hd) {
     asm volatile("" ::"v"(hd.nb), "v"(hd.info), "v"(hd.q0));
 }
 
-template <int NS, bool CP, typename Pro, typename Pre, typename Body>
+// LATE (backward pass over the tile map): ONE register set for the tile's rows.  The pass runs at the register
+// file's limit (two waves of 256 registers per SIMD) and the second set did not fit: the compiler spilled the next
+// tile's rows to scratch AS THEY WERE LOADED -- load, wait for it, store it, four to six times in a row at the top of
+// every tile, 2.3 us of serial round trips (ISA; stamps).  Here the next tile's rows are requested at the END of a
+// tile's arithmetic, into the registers its own rows left at the tile's start: one batch in flight during the tile's
+// stores and atomics.  BODY must not read its `raw` argument after it has called `before_stores`.
+template <int NS, bool CP, bool LATE = false, typename Pro, typename Pre, typename Body>
 __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Pro prologue, Pre pre, Body body) {
     const int cap = a.b * a.m, stride = gridDim.x * SA_WAVES;
     int tile = blockIdx.x * SA_WAVES + wave;
@@ -399,6 +405,17 @@ __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, 
     int nst = 3;
     for (; tile < tiles; tile += stride) {
         const bool more = tile + stride < tiles;               // wave-uniform
+        if (LATE) {
+            const TileHead hd_nxt2 = load_head<CP>(a, tile + 2 * stride < tiles ? tile + 2 * stride : tile, r);
+            body(tile, cur, nst == 4, [&] {
+                touch(hd_nxt);
+                if (more) fetch_tile<NS>(a, hd_nxt, h, cur);
+            });
+            stamp(a, wave, nst < 5 ? nst : 5);
+            ++nst;
+            hd_nxt = hd_nxt2;
+            continue;
+        }
         touch(hd_nxt);
         pre();
         if (more) fetch_tile<NS>(a, hd_nxt, h, nxt);
@@ -929,7 +946,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         }
         pend_live = 0;
     };
-    for_each_tile<NS, CP>(a, wave, r, h, prologue, scatter_pending, [&](int tile, const TileRaw<NS> &raw, bool probe, auto before_stores) {
+    for_each_tile<NS, CP, CP>(a, wave, r, h, prologue, scatter_pending, [&](int tile, const TileRaw<NS> &raw, bool probe, auto before_stores) {
         auto st2 = [&](int k) { if (probe) stamp(a, wave, 8 + k); };
         st2(0);
         // the constant fragments are READ PER USE: an opaque copy of the lane id keeps the
