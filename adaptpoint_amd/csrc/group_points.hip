@@ -92,13 +92,60 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_rows_lds_kernel(
     __syncthreads();
     const int *ix = idx + (size_t)cloud * len;
     const float *g = grad_out + ((size_t)cloud * c + c0) * len;
-    for (int j = tid; j < len; j += SC_THREADS) {
-        const int t = ix[j];
-        for (int ch = 0; ch < nc; ++ch) atomicAdd(&acc[ch * n + t], g[(size_t)ch * len + j]);
+    // Eight positions per thread and step, every load of the step issued before its first use (clamped positions, the
+    // surplus dropped): one position and one channel at a time each load was waited for before the next was issued -- a
+    // chain of dependent round trips per thread (106 us for 78 MB at B = 32)
+    constexpr int U = 8;
+    for (int j0 = tid; j0 < len; j0 += U * SC_THREADS) {
+        int t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * SC_THREADS;
+            t[u] = ix[j < len ? j : len - 1];
+        }
+        for (int ch = 0; ch < nc; ++ch) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * SC_THREADS;
+                v[u] = g[(size_t)ch * len + (j < len ? j : len - 1)];
+            }
+            // Same-address LDS atomics serialise, and a ball query's row ends in a run of copies of its first hit
+            // (ball_query_gpu.cu:41-45) -- with 32 slots and ~8 hits, 24 lanes of a half-wave add into ONE cell.  The lanes
+            // of each group of 32 that hold their group's first target are summed in registers (five exchanges) and added
+            // once by the group's first lane; the others add for themselves.
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = j0 + u * SC_THREADS < len;
+                const int t0 = __shfl(t[u], (int)(threadIdx.x & 32u));
+                const bool lead = (threadIdx.x & 31u) == 0u;
+                const bool same = live && t[u] == t0;
+                float s = same ? v[u] : 0.0f;
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 8);
+                s += __shfl_xor(s, 4);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 1);
+                if (live && (lead || !same)) atomicAdd(&acc[ch * n + t[u]], lead ? s : v[u]);
+            }
+        }
     }
     __syncthreads();
     float *dst = grad_points + ((size_t)cloud * c + c0) * n;
-    for (int i = tid; i < nc * n; i += SC_THREADS) dst[i] += acc[i];
+    const int total = nc * n;
+    for (int i0 = tid; i0 < total; i0 += 4 * SC_THREADS) {
+        float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * SC_THREADS;
+            d[u] = dst[i < total ? i : total - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * SC_THREADS;
+            if (i < total) dst[i] = d[u] + acc[i];
+        }
+    }
 }
 
 __global__ __launch_bounds__(GP_THREADS) void scatter_rows_atomic_kernel(

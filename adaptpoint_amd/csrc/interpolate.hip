@@ -162,16 +162,38 @@ __global__ __launch_bounds__(TG_THREADS) void three_interpolate_grad_lds_kernel(
         const float *w = weight + ((size_t)cloud * n + pt) * 3;
         const int ia = ix[0], ib = ix[1], ic = ix[2];
         const float w0 = w[0], w1 = w[1], w2 = w[2];
-        for (int ch = 0; ch < nc; ++ch) {
-            const float go = g[(size_t)ch * n + pt];
-            atomicAdd(&acc[ch * m + ia], go * w0);
-            atomicAdd(&acc[ch * m + ib], go * w1);
-            atomicAdd(&acc[ch * m + ic], go * w2);
+        // eight channels per step, their gradients requested together (one channel at a time each load was waited for
+        // before the next: a chain of dependent round trips per thread)
+        for (int ch0 = 0; ch0 < nc; ch0 += 8) {
+            float go[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) go[u] = g[(size_t)(ch0 + u < nc ? ch0 + u : nc - 1) * n + pt];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (ch0 + u < nc) {
+                    atomicAdd(&acc[(ch0 + u) * m + ia], go[u] * w0);
+                    atomicAdd(&acc[(ch0 + u) * m + ib], go[u] * w1);
+                    atomicAdd(&acc[(ch0 + u) * m + ic], go[u] * w2);
+                }
+            }
         }
     }
     __syncthreads();
     float *dst = grad_points + ((size_t)cloud * c + c0) * m;
-    for (int i = tid; i < nc * m; i += TG_THREADS) dst[i] += acc[i];
+    const int total = nc * m;
+    for (int i0 = tid; i0 < total; i0 += 4 * TG_THREADS) {
+        float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * TG_THREADS;
+            d[u] = dst[i < total ? i : total - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * TG_THREADS;
+            if (i < total) dst[i] = d[u] + acc[i];
+        }
+    }
 }
 
 __global__ __launch_bounds__(TI_THREADS) void three_interpolate_grad_atomic_kernel(
