@@ -811,14 +811,25 @@ __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const f
         Frag<2> af[2];
         if (s_rows) {                   // A = S^T: row = channel c of this lane, k = row of the tile
             const int c = rb * 32 + r;
+            // (all sixteen slots and gradients requested before the first is used: `mult && ksel == slot ? goa : 0` was a
+            // chain of up to 32 dependent loads per lane and tile -- padding rows name query 0 of the tile: valid addresses)
+            unsigned char ks[2][8];
+            float gv[2][8];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const size_t qc = (size_t)(q0 + ri_q(rinfo[s * 16 + h * 8 + e])) * O + c;
+                    ks[s][e] = ksel[qc];
+                    gv[s][e] = goa[qc];
+                }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float t[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const unsigned info = rinfo[s * 16 + h * 8 + e];
-                    const size_t qc = (size_t)(q0 + ri_q(info)) * O + c;
-                    t[e] = (ri_mult(info) != 0 && (int)ksel[qc] == ri_slot(info)) ? goa[qc] : 0.0f;
+                    t[e] = (ri_mult(info) != 0 && (int)ks[s][e] == ri_slot(info)) ? gv[s][e] : 0.0f;
                 }
                 af[s] = make_frag<2>(t);
             }
