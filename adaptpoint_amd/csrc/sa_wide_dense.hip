@@ -285,9 +285,12 @@ __global__ __launch_bounds__(1024) void wide_bwd_mid_kernel(const float *__restr
         for (int r0 = grp; r0 < rows; r0 += 16 * groups) {        // 16 independent loads in flight
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = r0 + u * groups < rows ? partS[(size_t)(r0 + u * groups) * ncol + col] : 0.0f;
+            for (int u = 0; u < 16; ++u) {      // (clamped row, dropped below: a load under a condition is waited for on the spot)
+                const int rr = r0 + u * groups;
+                v[u] = partS[(size_t)(rr < rows ? rr : rows - 1) * ncol + col];
+            }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc += (double)v[u];
+            for (int u = 0; u < 16; ++u) acc += r0 + u * groups < rows ? (double)v[u] : 0.0;
         }
     }
     for (int e = t; e < O * H; e += 1024) w2s[(e / H) * (H + 1) + e % H] = w2[e];
@@ -389,9 +392,12 @@ __global__ __launch_bounds__(1024) void wide_bwd_fin_kernel(const float *__restr
             for (int r0 = grp; r0 < rows; r0 += 16 * groups) {
                 float v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = r0 + u * groups < rows ? partT[(size_t)(r0 + u * groups) * ncol + col] : 0.0f;
+                for (int u = 0; u < 16; ++u) {
+                    const int rr = r0 + u * groups;
+                    v[u] = partT[(size_t)(rr < rows ? rr : rows - 1) * ncol + col];
+                }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc += (double)v[u];
+                for (int u = 0; u < 16; ++u) acc += r0 + u * groups < rows ? (double)v[u] : 0.0;
             }
         }
         red[t] = acc;
@@ -484,13 +490,15 @@ struct PgLds {
 };
 
 // n values through registers, NB loads in flight per thread: the fills of the LDS tiles below are dependent chains
-// (index -> row) only across phases, never inside a loop
+// (index -> row) only across phases, never inside a loop.  `load` must itself be free of conditions around its loads
+// (clamp the address, select the value): a load under a condition sits in a basic block of its own, next to its
+// first use, and is waited for before the next one is issued
 template <int NB, typename Load, typename Store>
 __device__ __forceinline__ void fill_batched(int n, Load load, Store store, int tid = threadIdx.x, int nthreads = 256) {
     for (int e0 = tid; e0 < n; e0 += nthreads * NB) {
         float v[NB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) v[u] = e0 + nthreads * u < n ? load(e0 + nthreads * u) : 0.0f;
+        for (int u = 0; u < NB; ++u) v[u] = load(e0 + nthreads * u < n ? e0 + nthreads * u : n - 1);   // (the surplus: dropped)
 #pragma unroll
         for (int u = 0; u < NB; ++u)
             if (e0 + nthreads * u < n) store(e0 + nthreads * u, v[u]);
@@ -539,12 +547,15 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
     }
     // the tiles of this phase, one wave each: four independent load chains in flight instead of one after the other
     if (ty == 0) {
-        fill_batched<16>(ldw * 64, [&](int e) {                  // X tile: coordinates / r, then the features
-            const int cc = e >> 6, pl = e & 63;
-            const long long g = pbase + pl;
-            if (g >= npts) return 0.0f;
-            return cc < 3 ? a.p[g * 3 + cc] * a.inv_r : a.f[((size_t)(g / a.N) * C + (cc - 3)) * a.N + (int)(g % a.N)];
-        }, [&](int e, float v) { Xs[(e >> 6) * 65 + (e & 63)] = v; }, tx, 64);
+        // X tile: coordinates / r, then the features
+        fill_batched<4>(3 * 64, [&](int e) {
+            const long long g = pbase + (e & 63);
+            return a.p[(g < npts ? g : npts - 1) * 3 + (e >> 6)] * a.inv_r;
+        }, [&](int e, float v) { Xs[(e >> 6) * 65 + (e & 63)] = pbase + (e & 63) < npts ? v : 0.0f; }, tx, 64);
+        fill_batched<16>(C * 64, [&](int e) {
+            const long long g0 = pbase + (e & 63), g = g0 < npts ? g0 : npts - 1;
+            return a.f[((size_t)(g / a.N) * C + (e >> 6)) * a.N + (int)(g % a.N)];
+        }, [&](int e, float v) { Xs[(3 + (e >> 6)) * 65 + (e & 63)] = pbase + (e & 63) < npts ? v : 0.0f; }, tx, 64);
     } else if (ty == 1) {
         fill_batched<16>(H * ldw, [&](int e) { return a.w1[e]; }, [&](int e, float v) {
             const int hh = e / ldw, cc = e - hh * ldw;
@@ -571,28 +582,32 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
     for (int i0 = 0; i0 < cnt; i0 += 4) {                      // four rows in flight
         int rr[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rr[u] = i0 + u < cnt ? l[i0 + u] : -1;
+        for (int u = 0; u < 4; ++u) rr[u] = l[i0 + u < cnt ? i0 + u : cnt - 1];       // (clamped: the surplus is dropped)
         float4 x[4][HPW / 4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float4 *__restrict__ g = reinterpret_cast<const float4 *>(a.GU + (size_t)(rr[u] < 0 ? 0 : rr[u]) * H + h0);
+            const float4 *__restrict__ g = reinterpret_cast<const float4 *>(a.GU + (size_t)rr[u] * H + h0);
 #pragma unroll
-            for (int v = 0; v < HPW / 4; ++v) x[u][v] = rr[u] < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : g[v];
+            for (int v = 0; v < HPW / 4; ++v) x[u][v] = g[v];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u < cnt) {                       // (registers only: no load inside)
 #pragma unroll
-            for (int v = 0; v < HPW / 4; ++v) {
-                acc[4 * v] += x[u][v].x; acc[4 * v + 1] += x[u][v].y; acc[4 * v + 2] += x[u][v].z; acc[4 * v + 3] += x[u][v].w;
+                for (int v = 0; v < HPW / 4; ++v) {
+                    acc[4 * v] += x[u][v].x; acc[4 * v + 1] += x[u][v].y; acc[4 * v + 2] += x[u][v].z; acc[4 * v + 3] += x[u][v].w;
+                }
             }
+        }
     }
     if (O) {
         if (ty < 3)
             fill_batched<16>(64 * O, [&](int e) {
                 const int pl = e / O, o = e - pl * O;
                 const int q = fqs[pl];
-                return q >= 0 ? a.gpre[((size_t)((pbase + pl) / a.N) * a.M + q) * O + o] : 0.0f;
-            }, [&](int e, float v) { gpt[(e / O) * (O + 1) + e % O] = v; }, (int)threadIdx.x, 192);
+                const long long g0 = pbase + pl, g = g0 < npts ? g0 : npts - 1;
+                return a.gpre[((size_t)(g / a.N) * a.M + (q >= 0 ? q : 0)) * O + o];
+            }, [&](int e, float v) { gpt[(e / O) * (O + 1) + e % O] = fqs[e / O] >= 0 ? v : 0.0f; }, (int)threadIdx.x, 192);
         else
             fill_batched<16>(nq * C, [&](int e) { return a.fs[(size_t)q0 * C + e]; },
                              [&](int e, float v) { fgs[(e % C) * (qpb + 1) + e / C] = v; }, tx, 64);
@@ -753,9 +768,12 @@ __global__ __launch_bounds__(1024) void wide_colsum_f32_kernel(const float *__re
         for (int r0 = g; r0 < rows; r0 += 512) {                                   // 16 independent loads in flight
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = r0 + 32 * u < rows ? part[(size_t)(r0 + 32 * u) * ncol + c] : 0.0f;
+            for (int u = 0; u < 16; ++u) {
+                const int rr = r0 + 32 * u;
+                v[u] = part[(size_t)(rr < rows ? rr : rows - 1) * ncol + c];
+            }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) s += (double)v[u];
+            for (int u = 0; u < 16; ++u) s += r0 + 32 * u < rows ? (double)v[u] : 0.0;
         }
     }
     red[g][tx] = s;
