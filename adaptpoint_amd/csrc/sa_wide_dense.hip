@@ -202,11 +202,25 @@ __global__ __launch_bounds__(256) void wide_out_kernel(int M, int O, int C, cons
     __shared__ float wt[64][65];      // [o][c]
     const int b = blockIdx.z, c0 = blockIdx.y * 64, m0 = blockIdx.x * 32;
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+    // (every load of a phase unconditional on a clamped index, the surplus dropped: a load under a condition is
+    // waited for before the next one is issued)
+    {
+        float yv[8];
+        const float sc2 = pack2[c0 + (t & 63)], sh2 = pack2[O + c0 + (t & 63)];       // c = e & 63 = t & 63 for every k
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int e = t + 256 * k, q = e >> 6, c = e & 63;
-        tile[q][c] = m0 + q < M ? __builtin_fmaf(ysel[((size_t)b * M + m0 + q) * O + c0 + c], pack2[c0 + c], pack2[O + c0 + c]) : 0.0f;
+        for (int k = 0; k < 8; ++k) {
+            const int q = (t + 256 * k) >> 6;
+            yv[k] = ysel[((size_t)b * M + (m0 + q < M ? m0 + q : M - 1)) * O + c0 + (t & 63)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = (t + 256 * k) >> 6;
+            tile[q][t & 63] = m0 + q < M ? __builtin_fmaf(yv[k], sc2, sh2) : 0.0f;
+        }
     }
+    float bsv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsv[i] = bs ? bs[c0 + (t >> 5) + 8 * i] : 0.0f;
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
@@ -217,17 +231,19 @@ __global__ __launch_bounds__(256) void wide_out_kernel(int M, int O, int C, cons
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int e = t + 256 * k, q = e >> 6, c = e & 63;
-                fv[k] = (k0 + c < C && m0 + q < M) ? fs[((size_t)b * M + m0 + q) * C + k0 + c] : 0.0f;
+                fv[k] = fs[((size_t)b * M + (m0 + q < M ? m0 + q : M - 1)) * C + (k0 + c < C ? k0 + c : C - 1)];
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int e = t + 256 * k, o = e >> 6, c = e & 63;
-                wv[k] = k0 + c < C ? ws[(size_t)(c0 + o) * C + k0 + c] : 0.0f;
+                wv[k] = ws[(size_t)(c0 + o) * C + (k0 + c < C ? k0 + c : C - 1)];
             }
+            const bool cin = k0 + (t & 63) < C;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) fg[(t + 256 * k) >> 6][(t + 256 * k) & 63] = fv[k];
+            for (int k = 0; k < 8; ++k)
+                fg[(t + 256 * k) >> 6][t & 63] = (cin && m0 + ((t + 256 * k) >> 6) < M) ? fv[k] : 0.0f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) wt[(t + 256 * k) >> 6][(t + 256 * k) & 63] = wv[k];
+            for (int k = 0; k < 16; ++k) wt[(t + 256 * k) >> 6][t & 63] = cin ? wv[k] : 0.0f;
             __syncthreads();
             const int kn = C - k0 < 64 ? C - k0 : 64;
 #pragma unroll 4
@@ -243,8 +259,7 @@ __global__ __launch_bounds__(256) void wide_out_kernel(int M, int O, int C, cons
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int cc = ty + 8 * i;
-        float v = tile[tx][cc] + acc[i];
-        if (bs) v += bs[c0 + cc];
+        float v = tile[tx][cc] + acc[i] + bsv[i];
         if (relu) v = v > 0.0f ? v : 0.0f;
         if (q < M) out[((size_t)b * O + c0 + cc) * M + q] = v;
     }
