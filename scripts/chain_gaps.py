@@ -4,6 +4,10 @@ import csv, re, sys
 from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+for i, r in enumerate(rows):            # bench.py's per-kernel event pass starts at the first spin kernel: not the steady state
+    if "spin_kernel" in r["Kernel_Name"]:
+        rows = rows[:i]
+        break
 first = sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 def short(n):

@@ -17,7 +17,6 @@ if [ "$what" = bench ]; then
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o b -- python $R/bench.py --steps 2000 --warmup 200 $B > $O/prof_bench.log 2>&1
     cp $O/prof_bench/b_kernel_stats.csv $O/${T}_bench_default_kernel_stats.csv
     python $R/scripts/steady_stats.py $O/prof_bench/b_kernel_trace.csv sa_prep_stats 20 3 --csv $O/${T}_bench_default_steady_per_replay.csv > $O/${T}_bench_default_steady.txt
-    python $R/scripts/chain_gaps.py $O/prof_bench/b_kernel_trace.csv sa_prep_stats 40 > $O/${T}_bench_default_chain.txt
     rm -rf $O/prof_bench
     # the same step on the width-generic kernels (deterministic: no float atomics), for comparison
     python $R/bench.py --steps 2000 --warmup 200 --kernels wide $B 2>/dev/null | grep '^{' > $O/${T}_bench_wide.json
