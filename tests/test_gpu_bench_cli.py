@@ -53,6 +53,14 @@ def test_bench_variants_emit_the_contract_line(dev, extra, launch):
         assert d["config"]["launch"] == launch
 
 
+def test_diagnostic_line_says_it_is_not_the_metric(dev):
+    """--diag-freeze-index (kernel tuning: the index stages are not refreshed inside the timed region) labels its line."""
+    d = _bench(["--steps", "20", "--warmup", "2", "--diag-freeze-index"])
+    assert d["config"]["workload"].startswith("DIAGNOSTIC") and d["value"] > 0
+    d = _bench(["--steps", "20", "--warmup", "2"])
+    assert not d["config"]["workload"].startswith("DIAGNOSTIC")
+
+
 def test_default_line_carries_the_secondary_figures(dev):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"], env=env,
