@@ -15,6 +15,11 @@ from .fused import _call
 HEAD_DIM = 16
 
 
+# calls that ran the composition instead of the kernel, by reason (the imitator's 4-anchor attention, M = 4, is the one
+# caller: 128 rows of 16 numbers -- a launch of its own would cost what the five library launches do)
+COMPOSED_CALLS = {}
+
+
 def supported(q, heads):
     return (q.is_cuda and q.dim() == 3 and q.shape[-1] == heads * HEAD_DIM and q.shape[1] % 32 == 0
             and q.shape[1] > 0)
@@ -70,7 +75,9 @@ def attention(q, k, v, heads):
         raise RuntimeError("adaptpoint_amd.attention needs CUDA/HIP tensors: the product path has no "
                            "CPU fallback")
     _lib.load()
-    if not supported(q, heads):                      # other head dims / ragged M: composed on the GPU
+    if not supported(q, heads):                      # other head dims / ragged M: composed on the GPU, and counted
+        why = "M=%d not a multiple of 32" % q.shape[1] if q.shape[-1] == heads * HEAD_DIM else "head dim %d" % (q.shape[-1] // heads)
+        COMPOSED_CALLS[why] = COMPOSED_CALLS.get(why, 0) + 1
         return _reference(q, k, v, heads)
     return _Attention.apply(q, k, v, heads)
 

@@ -46,7 +46,10 @@ def test_attention_large_scores_and_fallback_shapes(dev, oracle):
     # M not a multiple of 32: the reference's composition runs instead (same result)
     q, k, v = (torch.from_numpy(GI.seeded_normal((2, 50, 64), seed=95 + i)).to(dev) for i in range(3))
     assert not supported(q, 4)
+    from adaptpoint_amd import attention as A
+    before = sum(A.COMPOSED_CALLS.values())
     out = attention(q, k, v, 4)
+    assert sum(A.COMPOSED_CALLS.values()) == before + 1 and any("M=50" in k_ for k_ in A.COMPOSED_CALLS)   # counted, not silent
     assert np.abs(out.cpu().numpy() - oracle.attention(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), 4)).max() <= 1e-5
     with pytest.raises(RuntimeError):
         attention(q.cpu(), k.cpu(), v.cpu(), 4)
