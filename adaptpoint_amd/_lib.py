@@ -66,6 +66,9 @@ SIGNATURES = {
                             + [_c_double] + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p]
                             + [_c_longlong]
                             + [_c_void_p] * 25),
+    "apn_attention_small_max": [],
+    "apn_attention_small_fwd": [_c_int] * 3 + [_c_void_p] * 5,
+    "apn_attention_small_bwd": [_c_int] * 3 + [_c_void_p] * 8,
     "apn_attention_prep": [_c_int] * 3 + [_c_void_p] * 4 + [_c_int, _c_void_p],
     "apn_attention_fwd": [_c_int] * 3 + [_c_void_p] * 4,
     "apn_attention_bwd": [_c_int] * 3 + [_c_void_p] * 9,

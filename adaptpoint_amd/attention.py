@@ -69,13 +69,41 @@ class _Attention(torch.autograd.Function):
         return dq, dk, dv, None
 
 
+SMALL_MAX = 32       # apn_attention_small_max(): few points go to the one-wave float32 kernel
+
+
+class _AttentionSmall(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        q, k, v = (t.contiguous().float() for t in (q, k, v))
+        B, M, C = q.shape
+        out = torch.empty(B, M, C, dtype=torch.float32, device=q.device)
+        _call("apn_attention_small_fwd", q.device, B, M, heads, q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr())
+        ctx.save_for_backward(q, k, v)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v = ctx.saved_tensors
+        B, M, C = q.shape
+        g = g.contiguous().float()
+        dq, dk, dv = (torch.empty_like(q) for _ in range(3))
+        _call("apn_attention_small_bwd", q.device, B, M, ctx.heads, q.data_ptr(), k.data_ptr(), v.data_ptr(), g.data_ptr(),
+              dq.data_ptr(), dk.data_ptr(), dv.data_ptr())
+        return dq, dk, dv, None
+
+
 def attention(q, k, v, heads):
     """softmax(q k^T / sqrt(16)) v per head; q, k, v (B, M, heads*16) -> (B, M, heads*16)."""
     if not q.is_cuda:
         raise RuntimeError("adaptpoint_amd.attention needs CUDA/HIP tensors: the product path has no "
                            "CPU fallback")
     _lib.load()
-    if not supported(q, heads):                      # other head dims / ragged M: composed on the GPU, and counted
+    if (q.dim() == 3 and q.shape[-1] == heads * HEAD_DIM and 0 < q.shape[1] <= SMALL_MAX and q.shape[1] % 32
+            and 0 < q.shape[0] <= 65535):
+        return _AttentionSmall.apply(q, k, v, heads)   # few points (the 4-anchor head): one wave per (cloud, head)
+    if not supported(q, heads):                      # other head dims / ragged M > 32: composed on the GPU, and counted
         why = "M=%d not a multiple of 32" % q.shape[1] if q.shape[-1] == heads * HEAD_DIM else "head dim %d" % (q.shape[-1] // heads)
         COMPOSED_CALLS[why] = COMPOSED_CALLS.get(why, 0) + 1
         return _reference(q, k, v, heads)

@@ -343,6 +343,157 @@ static int attn_check(int b, int m, int heads) {
 // Operand images: six of b*heads*m*32 bf16 (64 bytes per point and head) each, in `images`:
 //   [0] Qs rows (q * log2(e)/4)   [1] Ks rows   [2] Vt trans   [3] Vs rows   [4] Qt4 trans (q/4)
 //   [5] Kt4 trans (k/4);  the forward uses 0..2, the backward all six.
+namespace apn {
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same attention for FEW points (m <= 32: the imitator's 4-anchor head, generator_component4_15.py:572): one wave
+// per (cloud, head), lane i = query i, everything in float32 registers -- the keys and values of the head are 2 x m x 16
+// numbers.  Forward saves nothing but `out`; the backward recomputes the probabilities.  Sums over the queries (dK, dV)
+// are wave reductions in a fixed order: bit-reproducible.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int AT_SMALL_MAX = 32;
+
+__device__ __forceinline__ float at_wave_sum32(float v) {         // over lanes 0..31 (both halves hold their own sum)
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(64) void attn_small_kernel(int m, int heads, const float *__restrict__ q,
+                                                        const float *__restrict__ k, const float *__restrict__ v,
+                                                        const float *__restrict__ g_out, float *__restrict__ out,
+                                                        float *__restrict__ dq, float *__restrict__ dk,
+                                                        float *__restrict__ dv) {
+    __shared__ float sk[AT_SMALL_MAX][AT_D + 1], sv[AT_SMALL_MAX][AT_D + 1];
+    const int head = blockIdx.x, cloud = blockIdx.y, lane = threadIdx.x, c = heads * AT_D;
+    const size_t base = (size_t)cloud * m * c + head * AT_D;
+    for (int e = lane; e < m * AT_D; e += 64) {
+        const int j = e / AT_D, d = e % AT_D;
+        sk[j][d] = k[base + (size_t)j * c + d];
+        sv[j][d] = v[base + (size_t)j * c + d];
+    }
+    const int i = lane < m ? lane : m - 1;                         // (lanes past m compute a copy of the last query, dropped)
+    float qi[AT_D], go[AT_D];
+#pragma unroll
+    for (int d = 0; d < AT_D; ++d) {
+        qi[d] = q[base + (size_t)i * c + d];
+        go[d] = BWD ? g_out[base + (size_t)i * c + d] : 0.0f;
+    }
+    __syncthreads();
+    // scores / sqrt(16), soft-max over the keys (generator_component4_15.py:468-470)
+    float p[AT_SMALL_MAX];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < AT_SMALL_MAX; ++j) {
+        float sc = 0.0f;
+        if (j < m) {
+#pragma unroll
+            for (int d = 0; d < AT_D; ++d) sc = __builtin_fmaf(qi[d], sk[j][d], sc);
+            sc *= 0.25f;
+            mx = __builtin_fmaxf(mx, sc);
+        }
+        p[j] = sc;
+    }
+    float z = 0.0f;
+#pragma unroll
+    for (int j = 0; j < AT_SMALL_MAX; ++j) {
+        p[j] = j < m ? __expf(p[j] - mx) : 0.0f;
+        z += p[j];
+    }
+    const float rz = 1.0f / z;
+#pragma unroll
+    for (int j = 0; j < AT_SMALL_MAX; ++j) p[j] *= rz;
+    if (!BWD) {
+        float o[AT_D];
+#pragma unroll
+        for (int d = 0; d < AT_D; ++d) o[d] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < AT_SMALL_MAX; ++j)
+            if (j < m) {
+#pragma unroll
+                for (int d = 0; d < AT_D; ++d) o[d] = __builtin_fmaf(p[j], sv[j][d], o[d]);
+            }
+        if (lane < m) {
+#pragma unroll
+            for (int d = 0; d < AT_D; ++d) out[base + (size_t)lane * c + d] = o[d];
+        }
+        return;
+    }
+    // backward: dP = dO V^T, dS = P (dP - rowsum(P dP)), dQ = dS K / 4, dK = dS^T Q / 4, dV = P^T dO
+    const bool live = lane < m;
+    float ds[AT_SMALL_MAX], dot = 0.0f;
+#pragma unroll
+    for (int j = 0; j < AT_SMALL_MAX; ++j) {
+        float dp = 0.0f;
+        if (j < m) {
+#pragma unroll
+            for (int d = 0; d < AT_D; ++d) dp = __builtin_fmaf(go[d], sv[j][d], dp);
+        }
+        ds[j] = dp;
+        dot = __builtin_fmaf(p[j], dp, dot);
+    }
+    float gq[AT_D];
+#pragma unroll
+    for (int d = 0; d < AT_D; ++d) gq[d] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < AT_SMALL_MAX; ++j) {
+        ds[j] = j < m ? p[j] * (ds[j] - dot) * 0.25f : 0.0f;
+        if (j < m) {
+#pragma unroll
+            for (int d = 0; d < AT_D; ++d) gq[d] = __builtin_fmaf(ds[j], sk[j][d], gq[d]);
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int d = 0; d < AT_D; ++d) dq[base + (size_t)lane * c + d] = gq[d];
+    }
+    // column sums over the queries: lanes 0..31 carry the queries (lanes >= m and the upper half add zero)
+    const bool mine = lane < m && lane < 32;
+#pragma unroll
+    for (int j = 0; j < AT_SMALL_MAX; ++j) {
+        if (j < m) {                                             // wave-uniform
+#pragma unroll
+            for (int d = 0; d < AT_D; ++d) {
+                const float a = at_wave_sum32(mine ? ds[j] * qi[d] : 0.0f);
+                const float b = at_wave_sum32(mine ? p[j] * go[d] : 0.0f);
+                if (lane == 0) {
+                    dk[base + (size_t)j * c + d] = a;
+                    dv[base + (size_t)j * c + d] = b;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace apn
+
+// Few points (0 < m <= 32): out, or (g_out given) dq, dk, dv; q, k, v, g_out, out, d* are (B, m, heads*16) f32.
+extern "C" int apn_attention_small_max(void) { return apn::AT_SMALL_MAX; }
+
+extern "C" int apn_attention_small_fwd(int b, int m, int heads, const float *q, const float *k, const float *v,
+                                       float *out, void *stream) {
+    using namespace apn;
+    if (b <= 0 || m <= 0 || m > AT_SMALL_MAX || heads <= 0 || heads > 65535 || b > 65535 || !q || !k || !v || !out)
+        return APN_EINVAL;
+    hipLaunchKernelGGL(attn_small_kernel<false>, dim3(heads, b), dim3(64), 0, (hipStream_t)stream, m, heads, q, k, v,
+                       (const float *)nullptr, out, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_attention_small_bwd(int b, int m, int heads, const float *q, const float *k, const float *v,
+                                       const float *g_out, float *dq, float *dk, float *dv, void *stream) {
+    using namespace apn;
+    if (b <= 0 || m <= 0 || m > AT_SMALL_MAX || heads <= 0 || heads > 65535 || b > 65535 || !q || !k || !v || !g_out ||
+        !dq || !dk || !dv)
+        return APN_EINVAL;
+    hipLaunchKernelGGL(attn_small_kernel<true>, dim3(heads, b), dim3(64), 0, (hipStream_t)stream, m, heads, q, k, v, g_out,
+                       (float *)nullptr, dq, dk, dv);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
 extern "C" int apn_attention_prep(int b, int m, int heads, const float *q, const float *k,
                                   const float *v, void *images, int for_backward, void *stream) {
     using namespace apn;

@@ -360,6 +360,13 @@ APN_API int apn_pointset_group_max_grad(int b, int n, int m, int c, int k, const
  * apn_attention_bwd: g_out = dL/d out -> dq, dk, dv (B,M,heads*16); scratch = 2 * b*heads*m*32
  * bf16 + b*heads*m floats.
  * ------------------------------------------------------------------------ */
+/* The same attention for few points (0 < m <= apn_attention_small_max() = 32; the imitator's 4-anchor head): one wave
+ * per (cloud, head) in float32; the backward recomputes the probabilities from q, k, v. */
+APN_API int apn_attention_small_max(void);
+APN_API int apn_attention_small_fwd(int b, int m, int heads, const float *q, const float *k, const float *v,
+                                    float *out, void *stream);
+APN_API int apn_attention_small_bwd(int b, int m, int heads, const float *q, const float *k, const float *v,
+                                    const float *g_out, float *dq, float *dk, float *dv, void *stream);
 APN_API int apn_attention_prep(int b, int m, int heads, const float *q, const float *k,
                                const float *v, void *images, int for_backward, void *stream);
 APN_API int apn_attention_fwd(int b, int m, int heads, const void *images, float *out, float *lse,

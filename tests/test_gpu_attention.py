@@ -55,6 +55,31 @@ def test_attention_large_scores_and_fallback_shapes(dev, oracle):
         attention(q.cpu(), k.cpu(), v.cpu(), 4)
 
 
+@pytest.mark.parametrize("B,M,H", [(32, 4, 4), (3, 1, 2), (2, 7, 4), (5, 31, 1), (2, 24, 16)])
+def test_attention_for_few_points_matches_float64(dev, B, M, H):
+    """m <= 32 that is no multiple of 32 (the imitator's 4-anchor head, generator_component4_15.py:572): the one-wave
+    float32 kernel, forward and the three gradients, against the composition in float64; not counted as composed;
+    two runs bit-identical (fixed-order sums)."""
+    from adaptpoint_amd import attention as A
+    q, k, v, w = (torch.from_numpy(GI.seeded_normal((B, M, 16 * H), seed=300 + i)).to(dev) for i in range(4))
+    q = q * 2.0
+    before = sum(A.COMPOSED_CALLS.values())
+    outs = []
+    for _ in range(2):
+        a = [t.clone().requires_grad_(True) for t in (q, k, v)]
+        o = A.attention(*a, H)
+        (o * w).sum().backward()
+        outs.append([o.detach()] + [t.grad for t in a])
+    assert sum(A.COMPOSED_CALLS.values()) == before
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    d = [t.double().clone().requires_grad_(True) for t in (q, k, v)]
+    ref = A._reference(*d, H)
+    (ref * w.double()).sum().backward()
+    for got, want in zip(outs[0], [ref.detach()] + [t.grad for t in d]):
+        assert float((got.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+
+
 def test_anchor_self_attention_module_matches_reference_golden(dev, golden):
     """The mirror module on the GPU (fused attention core) against the reference's
     Anchor_selfattention run on CPU (tests/golden/make_golden.py, G7)."""
