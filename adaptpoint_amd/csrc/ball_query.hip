@@ -25,13 +25,18 @@ namespace apn {
 
 constexpr int BQ_WAVES = 4;                // waves per workgroup
 
-// Grid: (ceil(M / queries_per_block), B).
+// Grid: 8 * ceil(B / 8) * blocks_x workgroups, numbered so that ALL the tiles of a cloud run on one XCD (workgroups w
+// and w + 8 share an XCD and its L2 under round-robin placement -- a speed assumption only): workgroup w = 8 s + x is
+// tile s mod blocks_x of cloud 8 (s / blocks_x) + x.  With a (tiles, clouds) grid a cloud's sixteen tiles were dealt to
+// all eight XCDs and each pulled the cloud through its own L2 (PMC: 111 MB per stacked launch for 54 MB of payload).
 __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
-    int n, int m, float radius2, int nsample, int q_per_block, int zero_empty,
+    int b, int blocks_x, int n, int m, float radius2, int nsample, int q_per_block, int zero_empty,
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, int *__restrict__ idx) {
     extern __shared__ float s_dyn[];
-    ball_query_body<BQ_WAVES>(n, m, radius2, nsample, q_per_block, zero_empty, new_xyz, xyz, idx,
-                              blockIdx.y, blockIdx.x, s_dyn);
+    const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
+    const int cloud = 8 * (s / blocks_x) + x, bx = s % blocks_x;
+    if (cloud >= b) return;
+    ball_query_body<BQ_WAVES>(n, m, radius2, nsample, q_per_block, zero_empty, new_xyz, xyz, idx, cloud, bx, s_dyn);
 }
 
 }  // namespace apn
@@ -49,10 +54,12 @@ static int ball_query_impl(int b, int n, int m, float radius, int nsample, const
     int q_per_block = 32;
     while (q_per_block > 4 && (long long)b * ((m + q_per_block - 1) / q_per_block) < 1024)
         q_per_block >>= 1;
-    dim3 grid((m + q_per_block - 1) / q_per_block, b);
+    const int blocks_x = (m + q_per_block - 1) / q_per_block;
+    const long long wgs = 8LL * ((b + 7) / 8) * blocks_x;
+    if (wgs > 0x7fffffffLL) return APN_EINVAL;
     const int chunk = n < BQ_CHUNK ? n : BQ_CHUNK;
     const size_t dyn = sizeof(float) * 3 * chunk + sizeof(int) * 2 * q_per_block;
-    hipLaunchKernelGGL(ball_query_kernel, grid, dim3(BQ_WAVES * 64), dyn, (hipStream_t)stream, n,
+    hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)wgs), dim3(BQ_WAVES * 64), dyn, (hipStream_t)stream, b, blocks_x, n,
                        m, radius2, nsample, q_per_block, zero_empty, new_xyz, xyz, idx);
     APN_LAUNCH_CHECK();
     return APN_OK;

@@ -388,13 +388,27 @@ __device__ __forceinline__ void touch(const TileHead &hd) {
 // stores and atomics.  BODY must not read its `raw` argument after it has called `before_stores`.
 template <int NS, bool CP, bool LATE = false, typename Pro, typename Pre, typename Body>
 __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Pro prologue, Pre pre, Body body) {
+    // XCD-aware tile numbers: workgroups w and w + 8 share an XCD (round-robin placement: a speed assumption, never a
+    // correctness one) and its L2.  Dealt out in launch order, a cloud's ~130 tiles went to all eight XCDs and every
+    // XCD pulled every cloud's rows through its own L2 (PMC: 35 MB fetched for a 4 MB table).  Tile number
+    // t = 8 u + x is therefore mapped to tile (x, u) of a layout in which XCD x owns the x-th EIGHTH of the tiles -- four
+    // whole clouds at B = 32 -- so a cloud's rows are fetched by one L2 only.  (gridDim.x a multiple of 8: else identity.)
     const int cap = a.b * a.m, stride = gridDim.x * SA_WAVES;
-    int tile = blockIdx.x * SA_WAVES + wave;
+    const int tiles = CP ? tm_tiles(a) : cap;
+    const bool xcd = (gridDim.x & 7) == 0;
+    const int per_x = (tiles + 7) >> 3;                         // tiles of one XCD's eighth
+    auto remap = [&](int t) {                                    // launch-order number -> tile (>= tiles: none)
+        if (!xcd) return t;
+        const int wg = t / SA_WAVES, wv = t - wg * SA_WAVES;     // t = (workgroup-slot, wave)
+        const int x = wg & 7, u = (wg >> 3) * SA_WAVES + wv;     // XCD, and the slot's number inside it
+        return u < per_x ? x * per_x + u : tiles;
+    };
+    int slot = blockIdx.x * SA_WAVES + wave;                     // advances by `stride`
+    int tile = remap(slot);
     // the heads of the wave's first TWO tiles, both before anything else (the second was requested after the
     // prologue: the first iteration then stalled a full memory round trip on it before its own tile's arithmetic)
-    const TileHead hd0 = load_head<CP>(a, tile < cap ? tile : 0, r);
-    TileHead hd_nxt = load_head<CP>(a, tile + stride < cap ? tile + stride : 0, r);
-    const int tiles = CP ? tm_tiles(a) : cap;
+    const TileHead hd0 = load_head<CP>(a, tile < tiles ? tile : 0, r);
+    TileHead hd_nxt = load_head<CP>(a, remap(slot + stride) < tiles ? remap(slot + stride) : 0, r);
     TileRaw<NS> cur, nxt;
     const bool any = tile < tiles;                                 // wave-uniform
     stamp(a, wave, 1);
@@ -403,10 +417,11 @@ __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, 
     stamp(a, wave, 2);
     if (!any) return;
     int nst = 3;
-    for (; tile < tiles; tile += stride) {
-        const bool more = tile + stride < tiles;               // wave-uniform
+    for (; tile < tiles; slot += stride, tile = remap(slot)) {
+        const bool more = remap(slot + stride) < tiles;        // wave-uniform
+        const int tile2 = remap(slot + 2 * stride);
         if (LATE) {
-            const TileHead hd_nxt2 = load_head<CP>(a, tile + 2 * stride < tiles ? tile + 2 * stride : tile, r);
+            const TileHead hd_nxt2 = load_head<CP>(a, tile2 < tiles ? tile2 : tile, r);
             body(tile, cur, nst == 4, [&] {
                 touch(hd_nxt);
                 if (more) fetch_tile<NS>(a, hd_nxt, h, cur);
@@ -419,7 +434,7 @@ __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, 
         touch(hd_nxt);
         pre();
         if (more) fetch_tile<NS>(a, hd_nxt, h, nxt);
-        const TileHead hd_nxt2 = load_head<CP>(a, tile + 2 * stride < tiles ? tile + 2 * stride : tile, r);
+        const TileHead hd_nxt2 = load_head<CP>(a, tile2 < tiles ? tile2 : tile, r);
         body(tile, cur, nst == 4, [&] { touch(hd_nxt2); });
         stamp(a, wave, nst < 5 ? nst : 5);
         ++nst;
