@@ -257,7 +257,20 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
     float (*red)[2][PW_T] = reinterpret_cast<float (*)[2][PW_T]>(pw_lds + 2 * 2 * TILE * 2);
     const int t = threadIdx.x, lane = t & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), wr = wave >> 2, wq = wave & 3;
-    const int R0 = blockIdx.y * PW_T, Q0 = blockIdx.x * PW_T, z = blockIdx.z;
+    // XCD-aware tile numbers (gridDim.z a multiple of 8: one batch entry per z): workgroups w and w + 8 share an XCD and
+    // its L2 under round-robin placement (a speed assumption only); dealt out in launch order the tiles of one batch entry
+    // -- which read the same operand slices -- went to all eight XCDs and each pulled the slice through its own L2.  Here
+    // all gridDim.x * gridDim.y tiles of an entry run on one XCD.
+    int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+    if ((gridDim.z & 7u) == 0u) {
+        const unsigned per = gridDim.x * gridDim.y;
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned slot = lin >> 3, w = slot % per;
+        bzi = (int)((slot / per) * 8u + (lin & 7u));
+        bxi = (int)(w % gridDim.x);
+        byi = (int)(w / gridDim.x);
+    }
+    const int R0 = byi * PW_T, Q0 = bxi * PW_T, z = bzi;
     PwLoader<A_KC> la;
     PwLoader<B_KC> lb;
     la.init(t, R0, g.R);
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
                 const float cand = red[w][0][t];
                 if (cand > best) { best = cand; bi = reinterpret_cast<int *>(&red[w][1][0])[t]; }
             }
-            const size_t o = ((size_t)z * gridDim.x + blockIdx.x) * g.R + R0 + t;
+            const size_t o = ((size_t)z * gridDim.x + bxi) * g.R + R0 + t;
             g.pool_val[o] = best;
             g.pool_idx[o] = bi;
         }
@@ -490,7 +503,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
                     n = tot;
                 }
             }
-            float *dst = g.part + ((size_t)z * gridDim.x + blockIdx.x) * 2 * g.R + R0 + t;
+            float *dst = g.part + ((size_t)z * gridDim.x + bxi) * 2 * g.R + R0 + t;
             dst[0] = (float)(mean * n);
             dst[g.R] = (float)(m2 < 0.0 ? 0.0 : m2);
         }
