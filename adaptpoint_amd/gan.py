@@ -101,19 +101,20 @@ class _frozen:
             q.requires_grad_(True)
 
 
-def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=True, frozen=False):
+def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=True, frozen=False, pyramid=None):
     """ganloss_cls.py:31-65: how much harder the augmented clouds are than the real ones for the
     CURRENT classifier, pulled towards `hard_ratio`: |1 - exp(L(fake) - hard_ratio * L(real))|.
     The classifier runs in eval mode (running BatchNorm statistics, no dropout), so every cloud
     is processed independently of its batch: `batched` stacks fake and real into ONE 2B pass
     (their FPS chains then run side by side) with the same result per cloud.
     `real` / `fake`: dicts with 'pos' (B,N,3) and 'x' (B,C,N).  frozen: only the inputs receive gradients (what
-    the generator step needs)."""
+    the generator step needs).  pyramid (batched only): the encoder's `index_pyramid` of cat([fake, real]) positions,
+    computed ahead (GanStep(overlap=True) runs it on a second stream beside the discriminator's forward)."""
     classifier.eval()
     with (_frozen(classifier) if frozen else contextlib.nullcontext()):
         if batched:
             both = classifier({'pos': torch.cat([fake['pos'], real['pos']], 0),
-                               'x': torch.cat([fake['x'], real['x']], 0)})
+                               'x': torch.cat([fake['x'], real['x']], 0)}, **({} if pyramid is None else {'pyramid': pyramid}))
             pred_fake, pred_real = both.chunk(2, 0)
         else:
             pred_fake = classifier(fake)
@@ -139,7 +140,7 @@ class GanStep:
 
     def __init__(self, generator, discriminator, classifier, criterion, lr_generator=1e-4,
                  lr_discriminator=4e-4, betas=(0.5, 0.999), hard_ratio=3.0, feedback_ratio=1.0,
-                 in_channels=4, batched_feedback=True, capturable=False, grad_sync=None):
+                 in_channels=4, batched_feedback=True, capturable=False, grad_sync=None, overlap=False):
         self.G, self.D, self.C = generator, discriminator, classifier
         # grad_sync(list of .grad tensors): called before each optimizer step -- under data parallelism
         # `adaptpoint_amd.dp.allreduce_mean_`, what the reference's DistributedDataParallel wrappers of the
@@ -155,6 +156,27 @@ class GanStep:
         self.bce = nn.BCELoss()
         self.hard_ratio, self.feedback_ratio = hard_ratio, feedback_ratio
         self.in_channels, self.batched_feedback = in_channels, batched_feedback
+        # overlap: the step's two independent side branches run on their own HIP streams (forked from and joined
+        # to the caller's stream, so a capture of the step holds them as parallel branches of the graph):
+        #   (1) the index pyramid of the 2B feedback pass -- FPS chains, ball queries, tile / inverse maps: functions of
+        #       the coordinates alone -- beside the discriminator's forward on the generated clouds;
+        #   (2) the discriminator's own step (two forwards, backward) beside the feedback pass, the generator's backward
+        #       and its optimizer; only `opt_d.step()` waits for both.
+        # Same arithmetic in the same order per tensor: the discriminator's power-iteration state is advanced by
+        # D(gen), D(real), D(gen.detach()) in that order on either schedule, its weights change after the generator's
+        # backward has read them, and the draws (dropout, generator switches) are requested in the same sequence.
+        self.overlap = overlap
+        self._side = None
+
+    def _discriminator_losses(self, xyz, gen, real_t, fake_t):
+        """train_autoaug.py:181-196 up to the optimizer step: two forwards (each one spectral-norm power iteration),
+        the mean of the two BCE terms, backward into the discriminator's .grad."""
+        real_loss = self.bce(self.D(xyz), real_t)
+        fake_loss = self.bce(self.D(gen.detach()), fake_t)
+        d_loss = (real_loss + fake_loss) / 2
+        self.opt_d.zero_grad()
+        d_loss.backward()
+        return d_loss
 
     def __call__(self, points, label, noise=None, device_noise=False):
         """points (B,N,C>=in_channels) with xyz first, label (B,) -> dict of the step's scalars
@@ -175,14 +197,36 @@ class GanStep:
             from .augmentor import draw_noise_on
             noise = draw_noise_on(xyz.device, B, xyz.shape[1], G.num_anchor)
         _, gen = G(xyz) if noise is None else G(xyz, noise)
-        g_raw = self.bce(D(gen), real_t)
+        overlap = self.overlap and points.is_cuda
+        pyramid = None
+        if overlap:
+            main = torch.cuda.current_stream(points.device)
+            if self._side is None:
+                self._side = (torch.cuda.Stream(points.device), torch.cuda.Stream(points.device))
+            s_idx, s_dis = self._side
+            if self.feedback_ratio > 0 and self.batched_feedback and hasattr(self.C, 'encoder') \
+                    and hasattr(self.C.encoder, 'index_pyramid'):
+                s_idx.wait_stream(main)
+                with torch.cuda.stream(s_idx):
+                    pos2 = torch.cat([gen.detach(), xyz], 0)
+                    pyramid = self.C.encoder.index_pyramid(pos2)
+        # (the discriminator's weights are frozen inside this forward: the generator step needs dL/d(gen) only, so its
+        # backward launches none of D's weight-gradient kernels -- and no gradient accumulator of D lives on this stream)
+        with _frozen(D):
+            g_raw = self.bce(D(gen), real_t)
+        if overlap:
+            s_dis.wait_stream(main)
+            with torch.cuda.stream(s_dis):
+                d_loss = self._discriminator_losses(xyz, gen, real_t, fake_t)
+            if pyramid is not None:
+                main.wait_stream(s_idx)
         g_loss, fb = g_raw, None
         if self.feedback_ratio > 0:
             tail = points[:, :, 3:self.in_channels]
             fake = {'pos': gen, 'x': torch.cat([gen, tail], -1).transpose(1, 2).contiguous()}
             real = {'pos': xyz, 'x': points[:, :, :self.in_channels].transpose(1, 2).contiguous()}
             fb, _, _ = feedback_loss(self.C, self.criterion, real, fake, label, self.hard_ratio,
-                                     self.batched_feedback, frozen=True)
+                                     self.batched_feedback, frozen=True, pyramid=pyramid)
             g_loss = g_raw + fb * self.feedback_ratio
         self.opt_g.zero_grad()
         torch.autograd.backward(g_loss, inputs=[q for q in G.parameters() if q.requires_grad])
@@ -191,11 +235,10 @@ class GanStep:
         self.opt_g.step()
 
         # ---- discriminator (two forwards, as the reference: each is one spectral-norm power iteration)
-        real_loss = self.bce(D(xyz), real_t)
-        fake_loss = self.bce(D(gen.detach()), fake_t)
-        d_loss = (real_loss + fake_loss) / 2
-        self.opt_d.zero_grad()
-        d_loss.backward()
+        if overlap:
+            main.wait_stream(s_dis)
+        else:
+            d_loss = self._discriminator_losses(xyz, gen, real_t, fake_t)
         if self.grad_sync is not None:
             self.grad_sync([q.grad for q in D.parameters() if q.grad is not None])
         self.opt_d.step()

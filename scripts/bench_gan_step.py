@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole joint step from a hipGraph (random draws of the generator then come "
                          "from the device generator, capturable Adam)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="GanStep(overlap=True): the feedback pass's index pyramid and the discriminator's own step on "
+                         "side streams (parallel branches of the captured graph)")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     a = ap.parse_args()
@@ -61,7 +64,8 @@ def main():
         G = AdaptPointAugmentor(fused=fused).to(dev)
         D = PointDiscriminator1(num_classes=15, fused=fused).to(dev)
         C = PointNextSClassifier(fused=fused).to(dev)
-        step = GanStep(G, D, C, SmoothCrossEntropy(0.3), batched_feedback=fused, capturable=a.graph)
+        step = GanStep(G, D, C, SmoothCrossEntropy(0.3), batched_feedback=fused, capturable=a.graph,
+                       overlap=a.overlap and fused)
         run = lambda: step(points, label)
         if a.graph:
             side = torch.cuda.Stream()
@@ -82,7 +86,7 @@ def main():
         res = {"config": "train_gan step (BASELINE configs[3])", "mode": mode, "B": a.batch, "N": a.points,
                "ms_per_step": round(sec * 1e3, 3), "clouds_per_s": round(a.batch / sec, 1),
                "peak_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-               "launch": "hipGraph replay" if a.graph else "eager"}
+               "launch": "hipGraph replay" if a.graph else "eager", "overlap": bool(a.overlap and fused)}
         out = captured if a.graph else step(points, label)
         res["losses"] = {k: round(float(out[k]), 5) for k in ("g_loss_raw", "feedback_loss", "d_loss")}
         print(json.dumps(res), flush=True)

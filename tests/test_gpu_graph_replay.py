@@ -105,8 +105,11 @@ def _compare(tag, eager_losses, replay_losses, mods, eager_weights, before, floo
           [{k: round(float(v), 6) for k, v in d.items()} for d in replay_losses], "update cosines", cos)
 
 
-def test_joint_step_replayed_from_a_hipgraph_equals_eager(dev):
-    """One `train_gan` iteration (adaptpoint_amd.gan.GanStep, device-side draws handed in, capturable fused Adam)."""
+@pytest.mark.parametrize("overlap", [False, True])
+def test_joint_step_replayed_from_a_hipgraph_equals_eager(dev, overlap):
+    """One `train_gan` iteration (adaptpoint_amd.gan.GanStep, device-side draws handed in, capturable fused Adam).
+    overlap: the step with its two side branches on their own streams (GanStep(overlap=True): parallel branches of the
+    captured graph) -- run eagerly AND replayed -- against the single-stream eager step."""
     from adaptpoint_amd.augmentor import AdaptPointAugmentor, Noise, draw_noise_on
     from adaptpoint_amd.discriminator import PointDiscriminator1
     from adaptpoint_amd.gan import GanStep
@@ -156,6 +159,16 @@ def test_joint_step_replayed_from_a_hipgraph_equals_eager(dev):
     _restore(mods, opts, snap)
     eager2, eager_w2 = eager_run()          # the same three steps again: the noise floor of the weights after Adam
     _restore(mods, opts, snap)
+    if overlap:
+        step.overlap = True
+        for _ in range(2):                               # the side streams' allocator pools
+            load(STEPS)
+            step(points, label, noise=noise)
+        torch.cuda.synchronize()
+        _restore(mods, opts, snap)
+        eager3, eager_w3 = eager_run()
+        _compare("joint step, side streams, eager", eager, eager3, mods, eager_w, snap[0], floor=eager_w2, floor_losses=eager2)
+        _restore(mods, opts, snap)
     gc.collect()
     from adaptpoint_amd import graphs
     graph = graphs.new_graph()
@@ -171,7 +184,8 @@ def test_joint_step_replayed_from_a_hipgraph_equals_eager(dev):
         torch.cuda.synchronize()
         replayed.append({k: captured[k].item() for k in keys})
     assert eager2 is not None
-    _compare("joint step", eager, replayed, mods, eager_w, snap[0], floor=eager_w2, floor_losses=eager2)
+    _compare("joint step" + (", side streams" if overlap else ""), eager, replayed, mods, eager_w, snap[0],
+             floor=eager_w2, floor_losses=eager2)
 
 
 def test_classifier_step_replayed_from_a_hipgraph_equals_eager(dev, monkeypatch):
