@@ -451,6 +451,7 @@ class Sampling:
         self.tmap = None         # adaptpoint_amd.fused_wide.tile_map of idx, for the register-resident kernels
         self.geo = None          # (B,N,4) int64 occurrence statistics of the neighbourhoods (csrc/sa_geo.hip) and
         self.dd = None           # (B, 6 * slabs) float64 their second moments, for the register-resident kernels
+        self.ready = None        # event recorded behind the index stage when it ran on another stream (graphs.wait_ready)
 
     def alloc_geo(self, n_points):
         if self.geo is None or self.geo.shape[1] != n_points:
@@ -470,6 +471,7 @@ class Sampling:
         v.index = None
         v.tmap = None
         v.geo = v.dd = None
+        v.ready = None
         if self.geo is not None:
             v.geo, v.dd = self.geo[lo:hi], self.dd[lo:hi]
         return v

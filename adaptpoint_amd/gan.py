@@ -21,6 +21,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import graphs
+from .graphs import mark, mark_grad
 from .layers import furthest_point_sample
 
 
@@ -156,17 +158,21 @@ class GanStep:
         self.bce = nn.BCELoss()
         self.hard_ratio, self.feedback_ratio = hard_ratio, feedback_ratio
         self.in_channels, self.batched_feedback = in_channels, batched_feedback
-        # overlap: the step's two independent side branches run on their own HIP streams (forked from and joined
-        # to the caller's stream, so a capture of the step holds them as parallel branches of the graph):
-        #   (1) the index pyramid of the 2B feedback pass -- FPS chains, ball queries, tile / inverse maps: functions of
-        #       the coordinates alone -- beside the discriminator's forward on the generated clouds;
-        #   (2) the discriminator's own step (two forwards, backward) beside the feedback pass, the generator's backward
-        #       and its optimizer; only `opt_d.step()` waits for both.
+        # overlap: the step runs as TWO lanes -- the caller's stream and one side stream forked from and joined to it, so
+        # that a capture of the step holds them as parallel branches (a replayed hipGraph runs two branches
+        # concurrently on this stack; a third one waits: scripts/experiment_graph_branches.py):
+        #   generator forward    lane 1: the imitator's feature path            lane 2: its index plan (FPS chain, ball
+        #                        (stages, decoders, masking branch)                      queries, three_nn, kNN), then
+        #                                                                               the anchor head
+        #   after it             lane 1: the feedback pass (index pyramid,      lane 2: D(gen), then the discriminator's
+        #                        2B classifier forward)                                  own step (two forwards, backward)
+        #   backward             autograd runs a node on its forward's stream: the same split, mirrored
         # Same arithmetic in the same order per tensor: the discriminator's power-iteration state is advanced by
         # D(gen), D(real), D(gen.detach()) in that order on either schedule, its weights change after the generator's
         # backward has read them, and the draws (dropout, generator switches) are requested in the same sequence.
         self.overlap = overlap
-        self._side = None
+
+    OVERLAP_PARTS = frozenset(("imitator",))        # + the discriminator chain on the second lane, always
 
     def _discriminator_losses(self, xyz, gen, real_t, fake_t):
         """train_autoaug.py:181-196 up to the optimizer step: two forwards (each one spectral-norm power iteration),
@@ -196,30 +202,41 @@ class GanStep:
         if noise is None and device_noise:
             from .augmentor import draw_noise_on
             noise = draw_noise_on(xyz.device, B, xyz.shape[1], G.num_anchor)
-        _, gen = G(xyz) if noise is None else G(xyz, noise)
-        overlap = self.overlap and points.is_cuda
+        mark("step: start")
+        overlap = bool(self.overlap) and points.is_cuda
+        parts = self.overlap if isinstance(self.overlap, (set, frozenset)) else self.OVERLAP_PARTS
+        with graphs.overlapping(overlap and ("plan" if "plan" in parts else "imitator" in parts)):
+            _, gen = G(xyz) if noise is None else G(xyz, noise)
+        mark("generator forward done")
+        mark_grad(gen, "backward: dL/d(generated clouds) formed (feedback + D backward done)")
         pyramid = None
         if overlap:
-            main = torch.cuda.current_stream(points.device)
-            if self._side is None:
-                self._side = (torch.cuda.Stream(points.device), torch.cuda.Stream(points.device))
-            s_idx, s_dis = self._side
-            if self.feedback_ratio > 0 and self.batched_feedback and hasattr(self.C, 'encoder') \
-                    and hasattr(self.C.encoder, 'index_pyramid'):
-                s_idx.wait_stream(main)
+            dev = points.device
+            if "pyramid" in parts and self.feedback_ratio > 0 and self.batched_feedback:
+                # (experiment: a third branch -- measured slower, two branches at a time is what a replayed graph runs
+                # concurrently on this stack; scripts/experiment_graph_branches.py)
+                s_idx = graphs.fork("lane3", dev, gen, xyz)
                 with torch.cuda.stream(s_idx):
-                    pos2 = torch.cat([gen.detach(), xyz], 0)
-                    pyramid = self.C.encoder.index_pyramid(pos2)
-        # (the discriminator's weights are frozen inside this forward: the generator step needs dL/d(gen) only, so its
-        # backward launches none of D's weight-gradient kernels -- and no gradient accumulator of D lives on this stream)
-        with _frozen(D):
-            g_raw = self.bce(D(gen), real_t)
-        if overlap:
-            s_dis.wait_stream(main)
+                    pyramid = self.C.encoder.index_pyramid(torch.cat([gen.detach(), xyz], 0))
+                    mark("feedback index pyramid done (side stream)")
+            # the discriminator's three forwards, in the reference's order, on the second lane: D(gen) for the generator's
+            # loss (its backward then runs there too, beside the feedback pass's), then the discriminator's own step;
+            # the first lane meanwhile runs the feedback pass (index pyramid, 2B classifier forward)
+            s_dis = graphs.fork(graphs.LANE2, dev, gen, xyz, real_t, fake_t)
             with torch.cuda.stream(s_dis):
+                with _frozen(D):
+                    g_raw = self.bce(D(gen), real_t)
+                mark("D(gen) forward done (second lane)")
                 d_loss = self._discriminator_losses(xyz, gen, real_t, fake_t)
+                mark("discriminator losses + backward done (second lane)")
             if pyramid is not None:
-                main.wait_stream(s_idx)
+                graphs.join(s_idx)
+        else:
+            # (the discriminator's weights are frozen inside this forward: the generator step needs dL/d(gen) only, so its
+            # backward launches none of D's weight-gradient kernels -- and no gradient accumulator of D lives on this stream)
+            with _frozen(D):
+                g_raw = self.bce(D(gen), real_t)
+            mark("D(gen) forward done")
         g_loss, fb = g_raw, None
         if self.feedback_ratio > 0:
             tail = points[:, :, 3:self.in_channels]
@@ -227,20 +244,27 @@ class GanStep:
             real = {'pos': xyz, 'x': points[:, :, :self.in_channels].transpose(1, 2).contiguous()}
             fb, _, _ = feedback_loss(self.C, self.criterion, real, fake, label, self.hard_ratio,
                                      self.batched_feedback, frozen=True, pyramid=pyramid)
+            mark("feedback forward done")
+            if overlap:
+                graphs.join(s_dis, g_raw, d_loss)
             g_loss = g_raw + fb * self.feedback_ratio
+        elif overlap:
+            graphs.join(s_dis, g_raw, d_loss)
         self.opt_g.zero_grad()
         torch.autograd.backward(g_loss, inputs=[q for q in G.parameters() if q.requires_grad])
+        mark("generator-step backward done")
         if self.grad_sync is not None:
             self.grad_sync([q.grad for q in G.parameters() if q.grad is not None])
         self.opt_g.step()
+        mark("generator optimizer done")
 
         # ---- discriminator (two forwards, as the reference: each is one spectral-norm power iteration)
-        if overlap:
-            main.wait_stream(s_dis)
-        else:
+        if not overlap:
             d_loss = self._discriminator_losses(xyz, gen, real_t, fake_t)
+            mark("discriminator losses + backward done")
         if self.grad_sync is not None:
             self.grad_sync([q.grad for q in D.parameters() if q.grad is not None])
         self.opt_d.step()
+        mark("step: end")
         return {'g_loss_raw': g_raw.detach(), 'feedback_loss': None if fb is None else fb.detach(),
                 'g_loss': g_loss.detach(), 'd_loss': d_loss.detach(), 'gen': gen.detach()}

@@ -73,3 +73,123 @@ def assert_replayable(graph, what="captured graph"):
                                 "hipMemsetAsync writes garbage from the second replay on (adaptpoint_amd/graphs.py); "
                                 "run this step eagerly or replace the memset's producer")
     return census
+
+
+class PhaseStamps:
+    """Diagnostic: device wall-clock stamps at named points of a step, taken by one-thread launches on whatever stream
+    is current (`apn_debug_stamp`) -- capturable, so a replayed graph reports when each of its branches reached each
+    point, with no profiler attached.  Install with `graphs.STAMPS = PhaseStamps(dev)`; the steps call
+    `graphs.mark(name)`, which does nothing while STAMPS is None."""
+
+    def __init__(self, dev, slots=256):
+        self.dev = dev
+        self.buf = torch.zeros(slots, dtype=torch.int64, device=dev)
+        self.names = []
+
+    def mark(self, name):
+        from .fused import _call
+        if len(self.names) >= self.buf.numel():
+            raise RuntimeError("PhaseStamps: out of slots")
+        _call("apn_debug_stamp", self.dev, self.buf.data_ptr(), len(self.names))
+        self.names.append(name)
+
+    def report(self):
+        """[(name, microseconds since the first stamp)] in time order (the clock runs at 100 MHz)."""
+        t = self.buf[:len(self.names)].cpu().tolist()
+        t0 = min(t)
+        return sorted(((n, (v - t0) / 100.0) for n, v in zip(self.names, t)), key=lambda x: x[1])
+
+
+STAMPS = None
+
+
+def mark(name):
+    if STAMPS is not None:
+        STAMPS.mark(name)
+
+
+def mark_grad(tensor, name):
+    """Stamp the moment the backward pass has formed the gradient of `tensor` (a hook; only while STAMPS is set)."""
+    if STAMPS is not None and torch.is_tensor(tensor) and tensor.requires_grad:
+        def hook(g, _name=name):
+            mark(_name)
+        tensor.register_hook(hook)
+    return tensor
+
+
+# ------------------------------------------------------------------ side streams (parallel branches of a captured step)
+# A replayed hipGraph runs independent branches concurrently (scripts/experiment_graph_branches.py: two chains of 40
+# low-occupancy kernels on two forked streams replay in half the time of one chain).  The training steps use that for
+# work that depends on coordinates only (FPS chains, ball queries, three_nn, tile / inverse maps) and for sub-networks
+# that do not feed each other.  Autograd runs a backward node on the stream its forward ran on, so a branch forked in
+# the forward pass is a branch of the backward pass too.  Everything here is a no-op unless `overlapping(True)` is active.
+_OVERLAP = False
+_SIDE = {}
+LANE2 = "lane2"          # the ONE side stream the steps fork onto (two concurrent branches is what replays concurrently)
+
+
+def overlap_enabled():
+    return _OVERLAP
+
+
+class overlapping:
+    """`with overlapping(on):` -- the modules called inside fork their independent parts onto side streams."""
+
+    def __init__(self, on=True):
+        self.on = on if isinstance(on, str) else bool(on)
+
+    def __enter__(self):
+        global _OVERLAP
+        self.prev, _OVERLAP = _OVERLAP, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _OVERLAP
+        _OVERLAP = self.prev
+
+
+def side_stream(key, dev):
+    dev = torch.device(dev)
+    k = (key, dev.index if dev.index is not None else torch.cuda.current_device())
+    if k not in _SIDE:
+        _SIDE[k] = torch.cuda.Stream(dev)
+    return _SIDE[k]
+
+
+def fork(key, dev, *inputs):
+    """The side stream `key` of `dev`, made to wait for everything queued on the current stream; `inputs`: tensors of
+    the current stream that the branch reads (the caching allocator is told, so that a block freed by the caller is
+    not handed out again before the branch has read it)."""
+    main = torch.cuda.current_stream(dev)
+    s = side_stream(key, dev)
+    s.wait_stream(main)
+    for t in inputs:
+        if torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(s)
+    return s
+
+
+def join(s, *outputs):
+    """The current stream waits for the side stream `s`; `outputs`: tensors the branch allocated that the caller goes on
+    to read."""
+    main = torch.cuda.current_stream(s.device)
+    main.wait_stream(s)
+    for t in outputs:
+        if torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(main)
+
+
+def ready_event():
+    """An event recorded on the current stream (a branch's 'this part is ready' signal; `wait_ready` is its other end)."""
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
+
+
+def wait_ready(ev, *tensors):
+    if ev is not None:
+        main = torch.cuda.current_stream()
+        main.wait_event(ev)
+        for t in tensors:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)

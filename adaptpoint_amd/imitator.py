@@ -15,8 +15,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .attention import AnchorSelfAttention
+from . import graphs
+from .graphs import mark, mark_grad
 from . import pointwise
-from .layers import three_interpolation
+from .layers import inverse_distance_weights, three_interpolate, three_interpolation, three_nn
 from .pointset import PointsetGrouper
 
 
@@ -62,8 +64,12 @@ class PointNetFeaturePropagation(nn.Module):
         super().__init__()
         self.fuse = ConvBNReLU1D(in_channel, out_channel, 1, bias=bias, fused=fused)
 
-    def forward(self, xyz1, xyz2, points1, points2):
-        interpolated = three_interpolation(xyz1, xyz2, points2)
+    def forward(self, xyz1, xyz2, points1, points2, nearest=None):
+        """nearest: (indices, weights) of `three_nn` + `inverse_distance_weights` computed ahead (index work)."""
+        if nearest is None:
+            interpolated = three_interpolation(xyz1, xyz2, points2)
+        else:
+            interpolated = three_interpolate(points2.contiguous(), nearest[0], nearest[1])
         new_points = interpolated if points1 is None else torch.cat([points1, interpolated], dim=1)
         return self.fuse(new_points)
 
@@ -79,9 +85,10 @@ class Producefactor(nn.Module):
         self.prob_head = nn.Sequential(nn.Conv1d(out_channels * 2, 3 * 3, 1, bias=False), nn.BatchNorm1d(3 * 3))
         self.anchor_selfattention = AnchorSelfAttention(dim=out_channels, head_num=4)
 
-    def forward(self, a_points, sa_x, sa_xyz, xyz_raw):
+    def forward(self, a_points, sa_x, sa_xyz, xyz_raw, idx_knn=None):
         num_anchor = a_points.shape[1]
-        idx_knn = knn_point(self.keighbors, sa_xyz, a_points)
+        if idx_knn is None:
+            idx_knn = knn_point(self.keighbors, sa_xyz, a_points)
         local_feat = torch.max(index_points(sa_x, idx_knn), dim=2)[0]
         local_feat = local_feat + self.anchor_selfattention(x=local_feat, xyz=a_points)
         on = a_points.is_cuda
@@ -134,22 +141,86 @@ class SAComponent(nn.Module):
         masking = torch.cat([masking_local, masking_global.repeat(1, 1, N)], dim=1)
         return pointwise.conv_then_bn(masking, self.fuse_masking, allow=on).permute(0, 2, 1)
 
+    @torch.no_grad()
+    def index_plan(self, x, a_points):
+        """Everything in the forward pass that is a function of the COORDINATES alone, in the order the feature path
+        asks for it: per stage the grouper's (FPS picks, sampled points, ball-query neighbours), then per decoder the
+        three nearest coarse points and their weights (behind the anchor head's nearest neighbours).  Each part comes with
+        an event recorded behind it: `forward` runs the plan on a side stream and waits part by part."""
+        plan = {"stages": [], "nearest": [], "knn": None}
+        xyz, xyz_list = x.contiguous(), [x.contiguous()]
+        for i in range(self.stages):
+            part = self.pointset_grouper_list[i].index(xyz)
+            plan["stages"].append((part, graphs.ready_event()))
+            xyz = part[1]
+            xyz_list.append(xyz)
+        plan["knn"] = (knn_point(self.head.keighbors, xyz, a_points), graphs.ready_event())
+        for i in range(self.stages):
+            dist, nearest = three_nn(xyz_list[-(i + 2)], xyz_list[-(i + 1)])
+            plan["nearest"].append(((nearest, inverse_distance_weights(dist)), graphs.ready_event()))
+        return plan
+
     def forward(self, x, a_index=None, return_logits=False):
-        """x (B,N,3), a_index (B,M) anchor indices -> prob (B,M,9), masking (B,N,2) one-hot."""
+        """x (B,N,3), a_index (B,M) anchor indices -> prob (B,M,9), masking (B,N,2) one-hot.
+
+        Under `graphs.overlapping()` (and for coordinates that need no gradient) the step's independent parts run as
+        a second lane (ONE side stream): first the index plan, consumed part by part through its events, then the anchor
+        head -- which reads the last stage's output, not the decoders' -- beside the decoders and the masking branch; the
+        backward pass inherits the split."""
         a_points = index_points(x, a_index)
         xyz = x
+        dev = x.device
+        overlap = graphs.overlap_enabled() and x.is_cuda and not x.requires_grad
+        plan = None
+        if overlap and graphs.overlap_enabled() == "plan":
+            # (experiment, off by default: the same lane re-forked from the main stream after the main stream has waited
+            # for events inside it crashed hipGraph capture; on a lane of its own it is a third branch)
+            s_idx = graphs.fork("lane3", dev, x, a_points)
+            with torch.cuda.stream(s_idx):
+                plan = self.index_plan(x, a_points)
         f = self.embedding(x.permute(0, 2, 1).contiguous())
+        mark("imitator: embedding done")
+        mark_grad(f, "backward: embedding output gradient formed")
         xyz_list, x_list = [xyz], [f]
         for i in range(self.stages):
             f = self.extract_feat_list[i](f)
-            xyz, f = self.pointset_grouper_list[i](xyz, f.permute(0, 2, 1))
+            part = None
+            if plan is not None:
+                part, ev = plan["stages"][i]
+                graphs.wait_ready(ev, *part)
+            xyz, f = self.pointset_grouper_list[i](xyz, f.permute(0, 2, 1), index=part)
             xyz_list.append(xyz)
             x_list.append(f)
+            mark(f"imitator: stage {i + 1} done")
+            mark_grad(f, f"backward: imitator stage {i + 1} output gradient formed")
+        idx_knn = None
+        if overlap:
+            s_head = graphs.fork(graphs.LANE2, dev, a_points, f, xyz)       # (the same lane: behind the index plan)
+            with torch.cuda.stream(s_head):
+                if plan is not None:
+                    idx_knn, ev = plan["knn"]
+                    graphs.wait_ready(ev, idx_knn)
+                prob = self.head(a_points=a_points, sa_x=f.permute(0, 2, 1), sa_xyz=xyz, xyz_raw=x, idx_knn=idx_knn)
+                mark("imitator: anchor head done (side stream)")
         for i in range(self.stages):
+            near = None
+            if plan is not None:
+                near, ev = plan["nearest"][i]
+                graphs.wait_ready(ev, *near)
             x_list[-(i + 2)] = self.decode_list[i](xyz1=xyz_list[-(i + 2)], xyz2=xyz_list[-(i + 1)],
-                                                   points1=x_list[-(i + 2)], points2=x_list[-(i + 1)])
-        prob = self.head(a_points=a_points, sa_x=f.permute(0, 2, 1), sa_xyz=xyz, xyz_raw=x)
+                                                   points1=x_list[-(i + 2)], points2=x_list[-(i + 1)], nearest=near)
+        mark("imitator: decoders done")
+        mark_grad(x_list[0], "backward: decoders' output gradient formed (masking branch done)")
+        if not overlap:
+            prob = self.head(a_points=a_points, sa_x=f.permute(0, 2, 1), sa_xyz=xyz, xyz_raw=x, idx_knn=idx_knn)
+            mark("imitator: anchor head done")
+        mark_grad(prob, "backward: anchor head output gradient formed")
         logits = self.masking_logits(x_list[0], x_list[-1], xyz_list[0])
+        mark("imitator: masking logits done")
+        if overlap:
+            graphs.join(s_head, prob)
+            if plan is not None:
+                graphs.join(s_idx)
         if return_logits:
             return prob, logits
         return prob, self.hard_mask(logits)

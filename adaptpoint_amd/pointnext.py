@@ -49,12 +49,14 @@ class PointNextEncoderS(nn.Module):
         self.radii = radii
 
     @torch.no_grad()
-    def index_pyramid(self, p0, out=None):
+    def index_pyramid(self, p0, out=None, events=False):
         """The index stages of ALL blocks -- FPS (+ sampled coordinates) and ball query per
         down-sampling block -- for a batch of coordinates p0 (B,N,3).  They depend on coordinates
         only (block k samples from block k-1's samples), so the whole pyramid can be computed ahead of
         the feature path: on another stream, for the next batch (scripts/bench_pointnext.py --pipeline).
-        Returns one `adaptpoint_amd.fused.Sampling` (or None) per block; `out`: buffers to fill."""
+        Returns one `adaptpoint_amd.fused.Sampling` (or None) per block; `out`: buffers to fill.  events: record an
+        event behind every block's index stage (`Sampling.ready`); `forward_cls_feat` then waits block by block, so
+        a pyramid running on a side stream is consumed level by level instead of as a whole."""
         from . import fused
         res, p = [], p0.contiguous()
         for i, stage in enumerate(self.encoder):
@@ -66,6 +68,9 @@ class PointNextEncoderS(nn.Module):
                                          out=None if out is None else out[i], geo=sa._resident())
             # tile map + inverse map of the neighbourhoods, for the blocks on the width-generic kernels
             sa.index_for(smp, p.shape[1], sa.convs[0][0].in_channels - 3, out=smp.index)
+            if events:
+                from . import graphs
+                smp.ready = graphs.ready_event()
             res.append(smp)
             p = smp.new_p
         return res
@@ -90,6 +95,8 @@ class PointNextEncoderS(nn.Module):
             f0 = p0.clone().transpose(1, 2).contiguous()
         for i, stage in enumerate(self.encoder):
             smp = None if pyramid is None else pyramid[i]
+            if smp is not None and getattr(smp, 'ready', None) is not None:
+                torch.cuda.current_stream(p0.device).wait_event(smp.ready)
             p0, f0 = stage[0]([p0, f0], sampling=smp) if smp is not None else stage[0]([p0, f0])
         return f0.squeeze(-1)
 

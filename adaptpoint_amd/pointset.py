@@ -86,12 +86,26 @@ class PointsetGrouper(nn.Module):
             self.affine_alpha = nn.Parameter(torch.ones([1, 1, 1, channel]))
             self.affine_beta = nn.Parameter(torch.zeros([1, 1, 1, channel]))
 
-    def forward(self, xyz, points):
-        """xyz (B,N,3), points (B,N,C) -> new_xyz (B,np,3), new_points (B,C,np)."""
+    @torch.no_grad()
+    def index(self, xyz):
+        """The stage's index work -- a function of the coordinates alone: (fps_idx (B,np), new_xyz (B,np,3),
+        idx (B,np,K)).  `forward(..., index=...)` takes it, so a caller can run it ahead of the features (the imitator
+        does, on a side stream)."""
         xyz = xyz.contiguous()
         fps_idx = furthest_point_sample(xyz, xyz.shape[1] // self.reduce)               # :406
         new_xyz = torch.gather(xyz, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3))   # :407
         idx = ball_query(self.radi, self.kneighbors, xyz, new_xyz)                       # :412
+        return fps_idx, new_xyz, idx
+
+    def forward(self, xyz, points, index=None):
+        """xyz (B,N,3), points (B,N,C) -> new_xyz (B,np,3), new_points (B,C,np)."""
+        xyz = xyz.contiguous()
+        if index is not None and not xyz.requires_grad:
+            fps_idx, new_xyz, idx = index
+        else:
+            fps_idx = furthest_point_sample(xyz, xyz.shape[1] // self.reduce)               # :406
+            new_xyz = torch.gather(xyz, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3))   # :407
+            idx = ball_query(self.radi, self.kneighbors, xyz, new_xyz)                       # :412
         if self.fused and self.normalize == "anchor" and group_max_supported(points, self.kneighbors):
             return new_xyz, group_max(points, idx, fps_idx, self.affine_alpha, self.affine_beta)
         # the other modes, as the reference composes them (:413-429)

@@ -156,6 +156,9 @@ APN_API int apn_sa_bwd_main_rows(int b, int m);
 APN_API int apn_sa_acc_words(int ncol);
 /* 16-byte granular zero fill by a kernel (graph-capturable) */
 APN_API int apn_zero_fill(void *base, long long bytes, void *stream);
+/* Diagnostic: stamps[slot] = the device's 100 MHz wall clock when the launch runs (one thread; graph-capturable:
+ * phase boundaries of a replayed step on every branch of the graph).  stamps: unsigned 64-bit words. */
+APN_API int apn_debug_stamp(void *stamps, int slot, void *stream);
 
 /* `precision` (every function that takes ft): 1 = operands rounded to bf16; 2 = operands split
  * into hi + lo bf16 parts, each product three MFMAs (hi*hi + hi*lo + lo*hi, "bf16x3"): fp32-grade

@@ -51,6 +51,11 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="GanStep(overlap=True): the feedback pass's index pyramid and the discriminator's own step on "
                          "side streams (parallel branches of the captured graph)")
+    ap.add_argument("--overlap-parts", default="",
+                    help="comma-separated subset of imitator,pyramid (experiments; default: imitator)")
+    ap.add_argument("--stamps", action="store_true",
+                    help="capture device wall-clock stamps at the step's phase boundaries (adaptpoint_amd.graphs."
+                         "PhaseStamps) and print them after the run")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     a = ap.parse_args()
@@ -65,7 +70,7 @@ def main():
         D = PointDiscriminator1(num_classes=15, fused=fused).to(dev)
         C = PointNextSClassifier(fused=fused).to(dev)
         step = GanStep(G, D, C, SmoothCrossEntropy(0.3), batched_feedback=fused, capturable=a.graph,
-                       overlap=a.overlap and fused)
+                       overlap=(frozenset(a.overlap_parts.split(",")) if a.overlap_parts else True) if (a.overlap and fused) else False)
         run = lambda: step(points, label)
         if a.graph:
             side = torch.cuda.Stream()
@@ -76,6 +81,8 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             from adaptpoint_amd import graphs as apn_graphs
+            if a.stamps:
+                apn_graphs.STAMPS = apn_graphs.PhaseStamps(dev)
             graph = apn_graphs.new_graph()
             with torch.cuda.graph(graph):
                 captured = step(points, label, device_noise=True)
@@ -90,6 +97,12 @@ def main():
         out = captured if a.graph else step(points, label)
         res["losses"] = {k: round(float(out[k]), 5) for k in ("g_loss_raw", "feedback_loss", "d_loss")}
         print(json.dumps(res), flush=True)
+        if a.graph and a.stamps:
+            prev = 0.0
+            for name, us in apn_graphs.STAMPS.report():
+                print(f"  {us:9.1f} us  (+{us - prev:8.1f})  {name}")
+                prev = us
+            apn_graphs.STAMPS = None
         if a.points > 1024 and not a.graph:
             cstep = ClassifierStep(C)
             sec = timed(lambda: cstep(points, label), a.iters, a.warmup)
