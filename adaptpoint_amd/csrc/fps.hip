@@ -258,7 +258,8 @@ __device__ __forceinline__ void fps_atomic_body(const FpsOrder &o, int m,
             dmin[s] = 0u;
         }
     }
-    if (tid < 3) slot[tid] = 0ull;
+    constexpr unsigned long long FPS_KEY_NONE = 0x00000000FFFFFFFFull;       // (distance +0.0, rank 0)
+    if (tid < 3) slot[tid] = FPS_KEY_NONE;
     float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
     if (tid == 0) {
         idxs[0] = 0;
@@ -287,17 +288,22 @@ __device__ __forceinline__ void fps_atomic_body(const FpsOrder &o, int m,
             }
         }
         const unsigned wmax = wave_max_u32(best);
-        if (best == wmax) {
+        if (best == wmax && best != 0u) {
             // hand-issued so that the compiler's atomic optimizer does not wrap the (almost
-            // always single-lane) atomic in a scalar reduction loop
+            // always single-lane) atomic in a scalar reduction loop.  A wave whose maximum is +0.0 stays out: every
+            // one of its lanes ties there (points already picked, duplicates of picked points -- the augmentor
+            // moves its masked points to the origin, half of a generated cloud), and 64 lanes x 8 waves on ONE LDS
+            // address cost microseconds per step (1024 -> 512 on such clouds: 276 us against 162).  Such a wave can
+            // only win when EVERY distance is zero, and then the winner is rank 0 -- which is what an untouched slot
+            // holds (FPS_KEY_NONE = the key of distance +0.0 at rank 0).
             const unsigned long long key =
                 ((unsigned long long)best << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(tid * S + bslot));
             asm volatile("ds_max_u64 %0, %1" :: "v"(slot0 + 8u * (unsigned)cur), "v"(key) : "memory");
         }
-        if (tid == 0) slot[nxt] = 0ull;
+        if (tid == 0) slot[nxt] = FPS_KEY_NONE;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const unsigned long long k = slot[cur];
-        const unsigned rank = 0xFFFFFFFFu - (unsigned)k;
+        const unsigned rank = 0xFFFFFFFFu - (unsigned)k;               // (an untouched slot holds FPS_KEY_NONE: rank 0)
         const float4 w = tab[rank];
         x1 = w.x; y1 = w.y; z1 = w.z;
         if (tid == 0) idxs[j] = __float_as_int(w.w);

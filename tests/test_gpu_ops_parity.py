@@ -114,6 +114,31 @@ def test_index_stage_sequence_with_min_distance_buffer(dev, oracle, n, m):
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(0.2, 32, xyz, q))
 
 
+@pytest.mark.parametrize("share,m", [(0.5, 512), (0.5, 640), (0.9, 300), (1.0, 64)])
+def test_fps_clouds_with_points_moved_to_the_origin(dev, oracle, share, m):
+    """What the AdaptPoint augmentor hands the feedback pass: masked points sit at the origin (half of a generated
+    cloud), so late steps see whole waves whose distances are all +0.0 -- and, for m beyond the distinct points, steps
+    in which EVERY distance is zero (the pick is then the first point in the reference's tie order).  Both sampler
+    entries, bit-exact against the oracle."""
+    from adaptpoint_amd import _lib
+    rng = np.random.RandomState(11)
+    xyz = GI.unit_sphere_cloud(3, 1024, seed=21).copy()
+    gone = rng.rand(3, 1024) < share
+    xyz[gone] = 0.0
+    idx, temp = gpu_fps(xyz, m, dev, return_temp=True)
+    o_idx, o_temp = oracle.furthest_point_sampling(xyz, m, return_temp=True)
+    assert np.array_equal(idx, o_idx)
+    assert np.array_equal(temp, o_temp)
+    p = torch.from_numpy(xyz).to(dev)
+    fidx = torch.empty(3, m, dtype=torch.int32, device=dev)
+    new_p = torch.empty(3, m, 3, device=dev)
+    rc = _lib.load().apn_furthest_point_sampling_xyz(3, 1024, m, p.data_ptr(), None, fidx.data_ptr(), new_p.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert np.array_equal(fidx.cpu().numpy(), o_idx)
+    assert np.array_equal(new_p.cpu().numpy(), GI.take_points(xyz, o_idx))
+
+
 def test_fps_m_zero_and_one(dev):
     xyz = GI.seeded_uniform((2, 33, 3), seed=5).astype(np.float32)
     assert gpu_fps(xyz, 0, dev).shape == (2, 0)
