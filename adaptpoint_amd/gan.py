@@ -103,7 +103,8 @@ class _frozen:
             q.requires_grad_(True)
 
 
-def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=True, frozen=False, pyramid=None):
+def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=True, frozen=False, pyramid=None,
+                  loss_real=None):
     """ganloss_cls.py:31-65: how much harder the augmented clouds are than the real ones for the
     CURRENT classifier, pulled towards `hard_ratio`: |1 - exp(L(fake) - hard_ratio * L(real))|.
     The classifier runs in eval mode (running BatchNorm statistics, no dropout), so every cloud
@@ -111,8 +112,13 @@ def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=
     (their FPS chains then run side by side) with the same result per cloud.
     `real` / `fake`: dicts with 'pos' (B,N,3) and 'x' (B,C,N).  frozen: only the inputs receive gradients (what
     the generator step needs).  pyramid (batched only): the encoder's `index_pyramid` of cat([fake, real]) positions,
-    computed ahead (GanStep(overlap=True) runs it on a second stream beside the discriminator's forward)."""
+    computed ahead.  loss_real: the real clouds' loss computed ahead (`real_loss_ahead`); only the fake clouds then
+    pass through the classifier here."""
     classifier.eval()
+    if loss_real is not None:
+        with (_frozen(classifier) if frozen else contextlib.nullcontext()):
+            loss_fake = criterion(classifier(fake), label.long())
+        return torch.abs(1 - torch.exp(loss_fake - hard_ratio * loss_real)), loss_fake, loss_real
     with (_frozen(classifier) if frozen else contextlib.nullcontext()):
         if batched:
             both = classifier({'pos': torch.cat([fake['pos'], real['pos']], 0),
@@ -124,6 +130,15 @@ def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=
     loss_fake = criterion(pred_fake, label.long())
     loss_real = criterion(pred_real, label.long())
     return torch.abs(1 - torch.exp(loss_fake - hard_ratio * loss_real)), loss_fake, loss_real
+
+
+@torch.no_grad()
+def real_loss_ahead(classifier, criterion, real, label):
+    """The real clouds' half of the feedback loss on its own: in the generator step it is a constant (the real clouds
+    need no gradient and the classifier's weights get none), so it needs no backward pass -- the 2B batched pass runs
+    its backward over both halves -- and, a function of the batch alone, it can run before / beside the generator."""
+    classifier.eval()
+    return criterion(classifier(real), label.long())
 
 
 def hard_ratio_at(epoch, epochs, start=3.0, end=3.0):
@@ -172,7 +187,7 @@ class GanStep:
         # backward has read them, and the draws (dropout, generator switches) are requested in the same sequence.
         self.overlap = overlap
 
-    OVERLAP_PARTS = frozenset(("imitator",))        # + the discriminator chain on the second lane, always
+    OVERLAP_PARTS = frozenset(("imitator", "real"))        # + the discriminator chain on the second lane, always
 
     def _discriminator_losses(self, xyz, gen, real_t, fake_t):
         """train_autoaug.py:181-196 up to the optimizer step: two forwards (each one spectral-norm power iteration),
@@ -205,6 +220,16 @@ class GanStep:
         mark("step: start")
         overlap = bool(self.overlap) and points.is_cuda
         parts = self.overlap if isinstance(self.overlap, (set, frozenset)) else self.OVERLAP_PARTS
+        loss_real = real = None
+        if self.feedback_ratio > 0:
+            real = {'pos': xyz, 'x': points[:, :, :self.in_channels].transpose(1, 2).contiguous()}
+        if overlap and real is not None and "real" in parts:
+            # the real clouds' classifier pass (no gradient, a function of the batch alone) opens the second lane, beside
+            # the generator's forward; the feedback pass proper then carries the B generated clouds only, forward and backward
+            s_real = graphs.fork(graphs.LANE2, points.device, xyz, real['x'], label)
+            with torch.cuda.stream(s_real):
+                loss_real = real_loss_ahead(self.C, self.criterion, real, label)
+                mark("real clouds' classifier pass done (second lane)")
         with graphs.overlapping(overlap and ("plan" if "plan" in parts else "imitator" in parts)):
             _, gen = G(xyz) if noise is None else G(xyz, noise)
         mark("generator forward done")
@@ -241,9 +266,10 @@ class GanStep:
         if self.feedback_ratio > 0:
             tail = points[:, :, 3:self.in_channels]
             fake = {'pos': gen, 'x': torch.cat([gen, tail], -1).transpose(1, 2).contiguous()}
-            real = {'pos': xyz, 'x': points[:, :, :self.in_channels].transpose(1, 2).contiguous()}
+            if loss_real is not None and not ("imitator" in parts):
+                graphs.join(s_real, loss_real)      # (with the imitator's head on the lane the generator joined it already)
             fb, _, _ = feedback_loss(self.C, self.criterion, real, fake, label, self.hard_ratio,
-                                     self.batched_feedback, frozen=True, pyramid=pyramid)
+                                     self.batched_feedback, frozen=True, pyramid=pyramid, loss_real=loss_real)
             mark("feedback forward done")
             if overlap:
                 graphs.join(s_dis, g_raw, d_loss)

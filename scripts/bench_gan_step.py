@@ -52,7 +52,7 @@ def main():
                     help="GanStep(overlap=True): the feedback pass's index pyramid and the discriminator's own step on "
                          "side streams (parallel branches of the captured graph)")
     ap.add_argument("--overlap-parts", default="",
-                    help="comma-separated subset of imitator,pyramid (experiments; default: imitator)")
+                    help="comma-separated subset of imitator,real,pyramid (experiments; default: imitator,real)")
     ap.add_argument("--stamps", action="store_true",
                     help="capture device wall-clock stamps at the step's phase boundaries (adaptpoint_amd.graphs."
                          "PhaseStamps) and print them after the run")
@@ -94,6 +94,14 @@ def main():
                "ms_per_step": round(sec * 1e3, 3), "clouds_per_s": round(a.batch / sec, 1),
                "peak_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                "launch": "hipGraph replay" if a.graph else "eager", "overlap": bool(a.overlap and fused)}
+        if a.graph:
+            # host time of a replay call alone (hipGraphLaunch enqueues the nodes one by one on this stack: a step
+            # of ~900 nodes can be bound by the enqueue, not by the device)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run()
+            res["host_ms_per_replay_call"] = round((time.perf_counter() - t0) * 1e3, 3)
+            torch.cuda.synchronize()
         out = captured if a.graph else step(points, label)
         res["losses"] = {k: round(float(out[k]), 5) for k in ("g_loss_raw", "feedback_loss", "d_loss")}
         print(json.dumps(res), flush=True)
