@@ -187,7 +187,11 @@ class GanStep:
         # backward has read them, and the draws (dropout, generator switches) are requested in the same sequence.
         self.overlap = overlap
 
-    OVERLAP_PARTS = frozenset(("imitator", "real"))        # + the discriminator chain on the second lane, always
+    # + the discriminator chain on the second lane, always.  ("real" -- the real clouds' classifier pass beside the
+    # generator's forward -- is NOT in the default set: replayed from a graph it disturbs the generator (update cosine
+    # 0.76-0.90 against the single-stream step, varying from run to run, while the eager two-lane step and the replayed
+    # step with the pass synchronised are exact): an unexplained hazard, kept out until it is understood.)
+    OVERLAP_PARTS = frozenset(("imitator",))
 
     def _discriminator_losses(self, xyz, gen, real_t, fake_t):
         """train_autoaug.py:181-196 up to the optimizer step: two forwards (each one spectral-norm power iteration),
@@ -230,6 +234,8 @@ class GanStep:
             with torch.cuda.stream(s_real):
                 loss_real = real_loss_ahead(self.C, self.criterion, real, label)
                 mark("real clouds' classifier pass done (second lane)")
+            if "real_sync" in parts:
+                graphs.join(s_real, loss_real)
         with graphs.overlapping(overlap and ("plan" if "plan" in parts else "imitator" in parts)):
             _, gen = G(xyz) if noise is None else G(xyz, noise)
         mark("generator forward done")

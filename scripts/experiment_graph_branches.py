@@ -5,7 +5,8 @@ waits for both, (E) branch 2 forked late: behind half of branch 1.  Prints ms pe
 (F) three chains: the main chain waits, quarter by quarter, for EVENTS recorded inside side chain 1 (a producer consumed
 part by part), side chain 2 is independent: ideal ~ K kernels + a quarter; (G) as F with one wait for all of chain 1
 before the main chain: ideal 2K; (J) the producer's parts each on a stream of their own, joined by wait_stream where
-they are consumed; (K) = J without the independent chain.  (Recording an event in chain 1, waiting for it on the main
+they are consumed; (K) = J without the independent chain.  (L) a lane with work queued is re-forked from the main stream: part 2 must start behind
+part 1.  (Recording an event in chain 1, waiting for it on the main
 stream and then continuing chain 1 -- capture in the order of use -- crashed the process in hipGraph capture.)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -105,6 +106,21 @@ def variant(kind):
             for i in range(K // 4):
                 keep.append(work(xc))
             graphs.mark(f"main: quarter {q + 1} done")
+    elif kind == "L":
+        # a lane that is re-forked from the main stream while it still has work of its own queued: does the captured
+        # graph keep the lane's own order (part 1 -> part 2) next to the new dependency on the main stream?
+        with torch.cuda.stream(s1):
+            for i in range(K // 2):
+                keep.append(work(xa))
+            graphs.mark("lane: part 1 done")
+        for i in range(K // 8):
+            keep.append(work(xc))
+        graphs.mark("main: its own part done")
+        s1.wait_stream(main)
+        with torch.cuda.stream(s1):
+            graphs.mark("lane: part 2 starts")
+            for i in range(K // 8):
+                keep.append(work(xa))
     main.wait_stream(s1); main.wait_stream(s2)
     if kind == "D":
         for i in range(4):

@@ -71,7 +71,7 @@ def _update_cosine(after_a, after_b, before):
     return float((ua * ub).sum() / (ua.norm() * ub.norm()).clamp_min(1e-30))
 
 
-def _compare(tag, eager_losses, replay_losses, mods, eager_weights, before, floor=None, floor_losses=None):
+def _compare(tag, eager_losses, replay_losses, mods, eager_weights, before, floor=None, floor_losses=None, buffer_bar=2e-3):
     """Losses of every step (each has its own batch: a reduction that kept an earlier replay's value is an O(1) error
     here); BatchNorm running statistics after the steps (reductions themselves); the parameters' total update.
     floor = the weights of a SECOND eager run from the same state: what two runs of the same kernels differ by."""
@@ -83,6 +83,8 @@ def _compare(tag, eager_losses, replay_losses, mods, eager_weights, before, floo
                 tol = max(tol, 3.0 * abs(float(floor_losses[i][k]) - ea))
             assert np.isfinite(ea) and abs(ea - rb) <= tol and tol <= 2e-3 * max(1.0, abs(ea)), (tag, "step", i, k, ea, rb, tol)
     cos = []
+    worst = [0.0]
+    bad = []
     for j, (m, ref) in enumerate(zip(mods, eager_weights)):
         now = m.state_dict()
         params = {k for k, _ in m.named_parameters()}
@@ -93,7 +95,10 @@ def _compare(tag, eager_losses, replay_losses, mods, eager_weights, before, floo
                 assert torch.equal(q, ref[k]), (tag, k)
             else:
                 # (2e-3 of the tensor's scale: after three updates at lr 2e-3 two eager runs differ by ~1e-4 of it)
-                assert float((q - ref[k]).abs().max()) <= 2e-3 * float(ref[k].abs().max()) + 1e-6, (tag, k)
+                err, scale = float((q - ref[k]).abs().max()), float(ref[k].abs().max())
+                worst[0] = max(worst[0], err / max(scale, 1e-30))
+                if err > buffer_bar * scale + 1e-6:
+                    bad.append((k, err / max(scale, 1e-30)))
         if not any(q.requires_grad for q in m.parameters()) or all(torch.equal(now[k], before[j][k]) for k in params):
             continue
         pb = {k: before[j][k] for k in params}
@@ -101,8 +106,10 @@ def _compare(tag, eager_losses, replay_losses, mods, eager_weights, before, floo
         need = 0.95 if floor is None else min(0.95, _update_cosine(floor[j], ref, pb) - 0.03)
         cos.append(round(c, 4))
         assert c >= need, (tag, j, c, need)
+    assert not bad, (tag, "buffers beyond the bar (name, deviation / scale):", bad)
     print(f"{tag}: replayed == eager over {STEPS} steps; losses",
-          [{k: round(float(v), 6) for k, v in d.items()} for d in replay_losses], "update cosines", cos)
+          [{k: round(float(v), 6) for k, v in d.items()} for d in replay_losses], "update cosines", cos,
+          "worst buffer deviation / scale %.2e" % worst[0])
 
 
 @pytest.mark.parametrize("overlap", [False, True])
@@ -160,7 +167,8 @@ def test_joint_step_replayed_from_a_hipgraph_equals_eager(dev, overlap):
     eager2, eager_w2 = eager_run()          # the same three steps again: the noise floor of the weights after Adam
     _restore(mods, opts, snap)
     if overlap:
-        step.overlap = True
+        import os
+        step.overlap = frozenset(os.environ["APN_OVERLAP_PARTS"].split(",")) if os.environ.get("APN_OVERLAP_PARTS") else True
         for _ in range(2):                               # the side streams' allocator pools
             load(STEPS)
             step(points, label, noise=noise)
