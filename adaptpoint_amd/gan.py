@@ -187,10 +187,12 @@ class GanStep:
         # backward has read them, and the draws (dropout, generator switches) are requested in the same sequence.
         self.overlap = overlap
 
-    # + the discriminator chain on the second lane, always.  ("real" -- the real clouds' classifier pass beside the
-    # generator's forward -- is NOT in the default set: replayed from a graph it disturbs the generator (update cosine
-    # 0.76-0.90 against the single-stream step, varying from run to run, while the eager two-lane step and the replayed
-    # step with the pass synchronised are exact): an unexplained hazard, kept out until it is understood.)
+    # + the discriminator chain on the second lane, always.  "real" (the real clouds' classifier pass beside the
+    # generator's forward, `real_loss_ahead`) is NOT in the default set: replayed from a graph -- as one two-lane graph or as
+    # two single-branch graphs on two streams -- the generator's FPS picks come out wrong when a classifier block's index +
+    # wide-kernel sequence runs beside them (update cosine 0.76-0.90 against the single-stream step; eager launches are
+    # exact; no pair of kernels reproduces it in isolation; scripts/debug_two_lane_forward.py, debug_fps_beside.py,
+    # redzone_run.py).  Unexplained, so kept out: DESIGN.md section 7c.
     OVERLAP_PARTS = frozenset(("imitator",))
 
     def _discriminator_losses(self, xyz, gen, real_t, fake_t):

@@ -16,6 +16,7 @@ value minus 0.03).
 """
 import copy
 import gc
+import os
 
 import numpy as np
 import pytest
@@ -121,7 +122,7 @@ def test_joint_step_replayed_from_a_hipgraph_equals_eager(dev, overlap):
     from adaptpoint_amd.discriminator import PointDiscriminator1
     from adaptpoint_amd.gan import GanStep
     from adaptpoint_amd.pointnext import PointNextSClassifier, SmoothCrossEntropy, fill_parameters_by_name
-    B, N = 4, 1024
+    B, N = int(os.environ.get("APN_REPLAY_BATCH", 4)), 1024          # (the bench's batch of 32 by hand: timing-dependent hazards)
     G = fill_parameters_by_name(AdaptPointAugmentor(fused=True)).to(dev)
     D = _no_dropout(fill_parameters_by_name(PointDiscriminator1(num_classes=15, fused=True))).to(dev)
     C = fill_parameters_by_name(PointNextSClassifier(fused=True)).to(dev)
@@ -167,7 +168,6 @@ def test_joint_step_replayed_from_a_hipgraph_equals_eager(dev, overlap):
     eager2, eager_w2 = eager_run()          # the same three steps again: the noise floor of the weights after Adam
     _restore(mods, opts, snap)
     if overlap:
-        import os
         step.overlap = frozenset(os.environ["APN_OVERLAP_PARTS"].split(",")) if os.environ.get("APN_OVERLAP_PARTS") else True
         for _ in range(2):                               # the side streams' allocator pools
             load(STEPS)
