@@ -187,13 +187,10 @@ class GanStep:
         # backward has read them, and the draws (dropout, generator switches) are requested in the same sequence.
         self.overlap = overlap
 
-    # + the discriminator chain on the second lane, always.  "real" (the real clouds' classifier pass beside the
-    # generator's forward, `real_loss_ahead`) is NOT in the default set: replayed from a graph -- as one two-lane graph or as
-    # two single-branch graphs on two streams -- the generator's FPS picks come out wrong when a classifier block's index +
-    # wide-kernel sequence runs beside them (update cosine 0.76-0.90 against the single-stream step; eager launches are
-    # exact; no pair of kernels reproduces it in isolation; scripts/debug_two_lane_forward.py, debug_fps_beside.py,
-    # redzone_run.py).  Unexplained, so kept out: DESIGN.md section 7c.
-    OVERLAP_PARTS = frozenset(("imitator",))
+    # + the discriminator chain on the second lane, always.  ("real" was held back for a while: replayed, the generator's
+    # updates came out wrong -- the cause was the LDS-atomic FPS step returning wrong picks beside other kernels, not the
+    # schedule; csrc/fps.hip, fps_default_algo.)
+    OVERLAP_PARTS = frozenset(("imitator", "real"))
 
     def _discriminator_losses(self, xyz, gen, real_t, fake_t):
         """train_autoaug.py:181-196 up to the optimizer step: two forwards (each one spectral-norm power iteration),

@@ -453,6 +453,43 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
         r.elapsed = sorted(r.blocks)[len(r.blocks) // 2]
     r.steps, r.spg, r.use_graph, r.pipelined, r.fused_mlp = steps, spg, use_graph, pipelined, fused_mlp
     r.index_batch = index_batch if pipelined and args.index_overlap != "on" else 1
+    r.index_verified = None
+    if pipelined:
+        # The index stages ran BESIDE the MLP kernels all through the timed region (two graphs on two streams).  Their
+        # inputs never change, so both sets must hold exactly what the same index stage yields on an idle device:
+        # FPS picks, sampled coordinates, neighbours and occurrence counts, bit for bit.
+        torch.cuda.synchronize()
+        ref = Sampling(spg * B_PER_GPU, NPOINT, NSAMPLE, dev)
+        ref.alloc_geo(N_PTS)
+        blk.sample(p_all, out=ref)
+        torch.cuda.synchronize()
+        r.index_verified = bool(all(torch.equal(b.buf, ref.buf) and torch.equal(b.geo, ref.geo) for b in big))
+        if not r.index_verified:
+            # say what differs (clouds per set): a wrong index stage voids the run's parity claim
+            r.index_verified = {"sets": [{"clouds_with_other_fps_picks": int((b.fidx != ref.fidx).any(1).sum()),
+                                          "clouds_with_other_neighbours": int((b.idx != ref.idx).flatten(1).any(1).sum()),
+                                          "clouds_with_other_counts": int((b.geo != ref.geo).flatten(1).any(1).sum())}
+                                         for b in big], "clouds": spg * B_PER_GPU}
+            if os.environ.get("APN_BENCH_INDEX_DIAG"):
+                import ctypes
+                from adaptpoint_amd import _lib as _L
+                cells = (ctypes.c_uint * 8)()
+                fn = getattr(ctypes.CDLL(_L.LIB_PATH), "apn_fps_debug_cells", None)
+                if fn is not None:
+                    fn(cells)
+                    print("[index diag] FPS threads whose LDS table entry changed under them:", cells[0], "of", cells[1],
+                          "| steps where a wave's maximum beat the slot's:", cells[2], "| where no lane of a wave fired:", cells[3],
+                          "| where several fired:", cells[4],
+                          "| steps whose slot paired one lane's rank with another's distance:", cells[5], "of", cells[6], file=sys.stderr)
+                for b in big:
+                    wrong = (b.fidx != ref.fidx).any(1).nonzero().flatten().tolist()
+                    for c in wrong[:6]:
+                        j = int((b.fidx[c] != ref.fidx[c]).nonzero()[0])
+                        print(f"[index diag] cloud {c}: first differing pick at step {j}: got {int(b.fidx[c, j])}, alone "
+                              f"{int(ref.fidx[c, j])}; previous picks {b.fidx[c, max(0, j - 3):j].tolist()}; got-pick seen "
+                              f"before: {int(b.fidx[c, j]) in b.fidx[c, :j].tolist()}; next {b.fidx[c, j + 1:j + 4].tolist()} vs "
+                              f"{ref.fidx[c, j + 1:j + 4].tolist()}", file=sys.stderr, flush=True)
+        del ref
 
     def eager_launch():
         """One whole launch (spg steps and, pipelined, the index stages of the next spg) issued
@@ -665,7 +702,9 @@ def main():
         # FPS is a serial chain of npoint-1 dependent arg-max steps, one workgroup per cloud: bound by per-step
         # latency, neither HBM nor MFMA; it runs on the index stream
         "index_stream": {"fps_step_ns": round(fps_us * 1e3 / (NPOINT - 1), 1), "fps_clouds_per_launch": fps_clouds,
-                         "fps_us_per_batch": round(fps_us / m.index_batch, 2)},
+                         "fps_us_per_batch": round(fps_us / m.index_batch, 2),
+                         # both index sets after the timed region == the index stage run alone (bit for bit)
+                         "verified_after_timed_region": m.index_verified},
         "kernels": kernels,
     })
 
