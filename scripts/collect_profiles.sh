@@ -57,7 +57,13 @@ if [ "$what" = models ]; then
     for n in 1024 2048; do
         python $R/scripts/bench_gan_step.py --points $n 2>/dev/null | grep '^{' >> $O/${T}_gan_step_bench.jsonl
         python $R/scripts/bench_gan_step.py --points $n --graph 2>/dev/null | grep '^{' >> $O/${T}_gan_step_bench.jsonl
+        # the step as two lanes of one captured graph (GanStep(overlap=True))
+        python $R/scripts/bench_gan_step.py --points $n --mode fused --graph --overlap 2>/dev/null | grep '^{' >> $O/${T}_gan_step_bench.jsonl
     done
+    python $R/scripts/bench_gan_step.py --mode fused --graph --overlap --stamps 2>/dev/null > $O/${T}_gan_step_stamps_two_lanes.txt
+    python $R/scripts/bench_gan_step.py --mode fused --graph --stamps 2>/dev/null > $O/${T}_gan_step_stamps_single_stream.txt
+    python $R/scripts/fps_batch_probe.py 2>/dev/null > $O/${T}_fps_batch_probe.txt
+    APN_FPS_LDS_ATOMIC=1 python $R/scripts/fps_batch_probe.py 2>/dev/null > $O/${T}_fps_batch_probe_lds_atomic.txt
     python $R/scripts/bench_wide.py 2>/dev/null | grep '^{' > $O/${T}_wide_kernels.jsonl
     python $R/scripts/bench_pointwise.py 2>/dev/null | grep '^{' > $O/${T}_pointwise_layers.jsonl
     rocprofv3 --kernel-trace --output-format csv -d $O/prof_pn -o pn -- python $R/scripts/bench_pointnext.py --fused --graph --steps 12 --warmup 6 > $O/prof_pn.log 2>&1

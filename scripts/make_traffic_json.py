@@ -9,7 +9,7 @@ import csv
 import json
 import sys
 
-ALIAS = {"fps_atomic_kernel": "fps", "ball_query_kernel": "ball_query", "sa_prep_stats_kernel": "sa_prep_stats",
+ALIAS = {"fps_atomic_kernel": "fps", "fps_reg_kernel": "fps", "ball_query_kernel": "ball_query", "sa_prep_stats_kernel": "sa_prep_stats",
          "sa_geo_kernel": "sa_point_geo",
          "sa_prep_features_kernel": "sa_prep_features", "sa_fwd_stats1_kernel": "sa_fwd_stats1",
          "sa_fwd_main_kernel": "sa_fwd_main", "fwd_out_kernel": "sa_fwd_out",
