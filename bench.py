@@ -491,6 +491,19 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
                               f"{ref.fidx[c, j + 1:j + 4].tolist()}", file=sys.stderr, flush=True)
         del ref
 
+    r.mlp_verified = None
+    if pipelined and use_graph and fused_mlp and not distributed and r.index_verified is True:
+        # ... and the MLP kernels ran beside the index kernels: the parameter gradients the LAST replayed step left
+        # against the same step launched eagerly on the idle device (same index set).  Default mode: equal up to the
+        # order of one float-atomic sum (the per-point sums A); --deterministic: bit for bit.
+        torch.cuda.synchronize()
+        got = [g_.detach().clone() for g_ in last_grads[0]]
+        mlp_steps(1, cur_set[0] ^ 1, first=spg - 1)
+        torch.cuda.synchronize()
+        want = [q.grad for q in params if q.grad is not None]
+        dev_ = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(got, want))
+        r.mlp_verified = {"max_gradient_deviation_rel": dev_, "bit_identical": bool(all(torch.equal(a, b) for a, b in zip(got, want)))}
+
     def eager_launch():
         """One whole launch (spg steps and, pipelined, the index stages of the next spg) issued
         eagerly, kernel by kernel: what the per-kernel event passes time."""
@@ -704,7 +717,10 @@ def main():
         "index_stream": {"fps_step_ns": round(fps_us * 1e3 / (NPOINT - 1), 1), "fps_clouds_per_launch": fps_clouds,
                          "fps_us_per_batch": round(fps_us / m.index_batch, 2),
                          # both index sets after the timed region == the index stage run alone (bit for bit)
-                         "verified_after_timed_region": m.index_verified},
+                         "verified_after_timed_region": m.index_verified,
+                         # the last replayed step's parameter gradients (formed beside the index kernels) against the same
+                         # step launched alone
+                         "mlp_stream_verified_after_timed_region": m.mlp_verified},
         "kernels": kernels,
     })
 

@@ -112,13 +112,20 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    verified = None
+    if a.pipeline and a.graph:
+        # the pyramids were filled BESIDE the feature stream all along: both sets against a pyramid built on the idle device
+        ref = model.encoder.index_pyramid(pos)
+        torch.cuda.synchronize()
+        verified = all(torch.equal(x.buf, y.buf) for st in pyr for x, y in zip(st, ref) if x is not None)
     print(json.dumps({"config": "PointNeXt-S classifier train step, B=%d N=1024" % a.batch,
                       "stages": ("fused (1: %s kernels; 2-4: width-generic kernels)" % ("width-generic" if a.wide_first else "register-resident")
                                  if a.fused else "unfused ops + PyTorch fp32"),
                       "launch": ("hipGraph replay" + (", index pyramid of the next batch on a second stream" if a.pipeline else "")
                                  if a.graph else "eager"),
                       "ms_per_step": round(1e3 * el / a.steps, 3),
-                      "clouds_per_s": round(a.batch * a.steps / el, 1), "loss": float(loss)}))
+                      "clouds_per_s": round(a.batch * a.steps / el, 1), "loss": float(loss),
+                      **({"index_pyramids_verified_after_the_run": bool(verified)} if verified is not None else {})}))
 
 
 if __name__ == "__main__":
