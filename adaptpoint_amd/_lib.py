@@ -118,6 +118,8 @@ SIGNATURES = {
     "apn_pw_contract_splits": [_c_int] * 4,
     "apn_pw_contract": [_c_int] * 4 + [_c_void_p, _c_longlong, _c_int, _c_int] * 2 + [_c_void_p, _c_longlong, _c_int, _c_int,
                                                                                          _c_void_p, _c_int, _c_void_p],
+    "apn_pw_transpose": [_c_int] * 3 + [_c_void_p] * 3,
+    "apn_three_nn_weights": [_c_longlong] + [_c_void_p] * 3,
     "apn_anchor_transforms": [_c_int] + [_c_void_p] * 3 + [_c_float] * 3 + [_c_void_p] * 3,
     "apn_anchor_transforms_grad": [_c_int] + [_c_void_p] * 3 + [_c_float] * 3 + [_c_void_p] * 4,
     "apn_pw_conv_max_tiles": [_c_int],

@@ -149,4 +149,4 @@ class AnchorSelfAttention(nn.Module):
             o = attention(q, k, v, self.head_num)      # raises on CPU tensors: no CPU fallback
         else:
             o = _reference(q, k, v, self.head_num)
-        return pointwise.conv_then_bn(o.permute(0, 2, 1).contiguous(), self.res, allow=on).permute(0, 2, 1)
+        return pointwise.transpose12(pointwise.conv_then_bn(pointwise.transpose12(o), self.res, allow=on))

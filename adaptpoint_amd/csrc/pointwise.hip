@@ -1041,3 +1041,63 @@ extern "C" int apn_pw_contract(int nbatch, int r, int q, int k, const float *a, 
     }
     return APN_OK;
 }
+
+// ---- layout change between the per-point layers (B, C, N) and the grouper / attention side (B, N, C) ----------------
+// out[z][j][i] = in[z][i][j] for in (nbatch, r, c): 64 x 64 tiles through LDS, both sides in whole 256-byte lines.
+// (The generator made these copies with PyTorch's strided copy kernel: 25 us for 16 MB, eight times per step.)
+namespace apn {
+__global__ __launch_bounds__(256) void pw_transpose_kernel(int r, int c, const float *__restrict__ in, float *__restrict__ out) {
+    __shared__ float tile[64][65];
+    const int z = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    in += (size_t)z * r * c;
+    out += (size_t)z * r * c;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                          // all sixteen loads requested together (clamped addresses)
+        const int rr = r0 + ty * 16 + i, cc = c0 + tx;
+        v[i] = in[(size_t)(rr < r ? rr : r - 1) * c + (cc < c ? cc : c - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tile[ty * 16 + i][tx] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = c0 + ty * 16 + i, rr = r0 + tx;
+        if (cc < c && rr < r) out[(size_t)cc * r + rr] = tile[tx][ty * 16 + i];
+    }
+}
+
+// three_nn's squared distances -> the interpolation weights of upsampling.py:97-100 in one launch:
+// w_j = (1 / (sqrt(d2_j) + 1e-8)) / sum_j (1 / (sqrt(d2_j) + 1e-8)), the sum taken left to right.
+__global__ __launch_bounds__(256) void idw3_kernel(long long n, const float *__restrict__ d2, float *__restrict__ w) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = 1.0f / (__fsqrt_rn(d2[3 * i + 0]) + 1e-8f);
+    const float b = 1.0f / (__fsqrt_rn(d2[3 * i + 1]) + 1e-8f);
+    const float c = 1.0f / (__fsqrt_rn(d2[3 * i + 2]) + 1e-8f);
+    const float sum = (a + b) + c;
+    w[3 * i + 0] = a / sum;
+    w[3 * i + 1] = b / sum;
+    w[3 * i + 2] = c / sum;
+}
+}  // namespace apn
+
+extern "C" int apn_pw_transpose(int nbatch, int r, int c, const float *in, float *out, void *stream) {
+    if (nbatch < 0 || r < 0 || c < 0) return APN_EINVAL;
+    if (nbatch == 0 || r == 0 || c == 0) return APN_OK;
+    if (!in || !out || nbatch > 65535 || (r + 63) / 64 > 65535) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::pw_transpose_kernel, dim3((c + 63) / 64, (r + 63) / 64, nbatch), dim3(256), 0, (hipStream_t)stream,
+                       r, c, in, out);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}
+
+extern "C" int apn_three_nn_weights(long long n, const float *dist2, float *weight, void *stream) {
+    if (n < 0) return APN_EINVAL;
+    if (n == 0) return APN_OK;
+    if (!dist2 || !weight || (n + 255) / 256 > 0x7FFFFFFF) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::idw3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, dist2, weight);
+    APN_LAUNCH_CHECK();
+    return APN_OK;
+}

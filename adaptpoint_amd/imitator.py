@@ -133,9 +133,10 @@ class SAComponent(nn.Module):
     def masking_logits(self, x0, x_last, xyz):
         """(:704-713) up to the Gumbel soft-max: (B,N,2)."""
         N = x0.shape[-1]
-        local = self.localfeat_mask_selfattention(x=x0.permute(0, 2, 1), xyz=xyz) + x0.permute(0, 2, 1)
+        x0t = pointwise.transpose12(x0)
+        local = self.localfeat_mask_selfattention(x=x0t, xyz=xyz) + x0t
         on = x0.is_cuda and self.embedding.fused
-        masking_local = pointwise.conv_then_bn(local.permute(0, 2, 1).contiguous(), self.extract_local_feat_masking, allow=on)
+        masking_local = pointwise.conv_then_bn(pointwise.transpose12(local), self.extract_local_feat_masking, allow=on)
         masking_global = torch.max(pointwise.conv_then_bn(x_last, self.extract_global_feat_masking, allow=on), dim=2,
                                    keepdim=True)[0]
         masking = torch.cat([masking_local, masking_global.repeat(1, 1, N)], dim=1)
@@ -188,7 +189,7 @@ class SAComponent(nn.Module):
             if plan is not None:
                 part, ev = plan["stages"][i]
                 graphs.wait_ready(ev, *part)
-            xyz, f = self.pointset_grouper_list[i](xyz, f.permute(0, 2, 1), index=part)
+            xyz, f = self.pointset_grouper_list[i](xyz, pointwise.transpose12(f), index=part)
             xyz_list.append(xyz)
             x_list.append(f)
             mark(f"imitator: stage {i + 1} done")

@@ -158,11 +158,29 @@ def inverse_distance_weights(dist, eps=1e-8):
     return inv / inv.sum(dim=2, keepdim=True)
 
 
+@torch.no_grad()
+def three_nn_weights(unknown, known):
+    """`three_nn` + `inverse_distance_weights` for the feature-propagation stages: (nearest (B,n,3) int32, weights
+    (B,n,3)) with the weights formed from the kernel's squared distances in ONE launch (`apn_three_nn_weights`: the
+    square root, the reciprocals, the sum and the division of upsampling.py:97-100 in that order) instead of five."""
+    _need_contiguous(unknown=unknown, known=known)
+    B, n = unknown.shape[:2]
+    d2 = _alloc(unknown, B, n, 3)
+    nearest = _alloc(unknown, B, n, 3, dtype=torch.int32)
+    ops.three_nn_wrapper(B, n, known.shape[1], unknown, known, d2, nearest)
+    if not d2.is_cuda:
+        return nearest, inverse_distance_weights(d2.sqrt_())
+    from .fused import _call
+    w = _alloc(unknown, B, n, 3)
+    _call("apn_three_nn_weights", d2.device, B * n, d2.data_ptr(), w.data_ptr())
+    return nearest, w
+
+
 def three_interpolation(unknown_xyz, known_xyz, know_feat):
     """Features (B,C,m) known at known_xyz (B,m,3), carried to unknown_xyz (B,n,3) by
     inverse-distance weighting over the three nearest known points -> (B,C,n) (upsampling.py:92-102)."""
-    dist, nearest = three_nn(unknown_xyz.contiguous(), known_xyz.contiguous())
-    return three_interpolate(know_feat.contiguous(), nearest, inverse_distance_weights(dist))
+    nearest, weights = three_nn_weights(unknown_xyz.contiguous(), known_xyz.contiguous())
+    return three_interpolate(know_feat.contiguous(), nearest, weights)
 
 
 # ---------------------------------------------------------------- neighbourhood grouping

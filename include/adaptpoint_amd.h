@@ -560,6 +560,12 @@ APN_API int apn_pw_contract_splits(int nbatch, int r, int q, int k);
 APN_API int apn_pw_contract(int nbatch, int r, int q, int k, const float *a, long long a_batch, int lda, int a_kcont,
                             const float *b, long long b_batch, int ldb, int b_kcont, float *d, long long d_batch, int ldd,
                             int splits, float *scratch, int precision, void *stream);
+/* out[z][j][i] = in[z][i][j] for in (nbatch, r, c) float32, contiguous: the layout change between the per-point layers'
+ * (B, C, N) and the grouper's / attention's (B, N, C) (generator_component4_15.py:650-657 permutes and lets PyTorch copy). */
+APN_API int apn_pw_transpose(int nbatch, int r, int c, const float *in, float *out, void *stream);
+/* three_nn's squared distances (n, 3) -> the inverse-distance weights of openpoints/models/layers/upsampling.py:97-100,
+ * w_j = (1 / (sqrt(d2_j) + 1e-8)) / sum_j (...): one launch for the five elementwise ones of the PyTorch form. */
+APN_API int apn_three_nn_weights(long long n, const float *dist2, float *weight, void *stream);
 
 /* the per-anchor transforms of AdaptPoint_Augmentor.local_transformaton
  * (openpoints/models_adaptpoint/generator_component4_15.py:236-297): prob (n,9) the imitator's numbers per anchor,

@@ -160,3 +160,32 @@ def test_conv_max_matches_float64_composition(dev, shape, relu):
     out.backward(gout)
     assert _rel(out, ref.detach()) < 1e-6
     assert _rel(x.grad, x64.grad) < 5e-6 and _rel(w.grad, w64.grad) < 5e-6 and _rel(bias.grad, b64.grad) < 5e-6
+
+
+@pytest.mark.parametrize("shape", [(32, 128, 1024), (3, 70, 77), (1, 1, 5), (2, 1024, 128), (5, 64, 1), (4, 65, 129)])
+def test_transpose12_is_the_permuted_copy_both_ways(dev, shape):
+    """`pointwise.transpose12` (apn_pw_transpose): bit-identical to `permute(0, 2, 1).contiguous()`, gradient included."""
+    from adaptpoint_amd import pointwise
+    torch.manual_seed(3)
+    x = torch.randn(*shape, device=dev, requires_grad=True)
+    y = pointwise.transpose12(x)
+    assert y.is_contiguous() and torch.equal(y, x.detach().permute(0, 2, 1).contiguous())
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert torch.equal(x.grad, g.permute(0, 2, 1).contiguous())
+
+
+@pytest.mark.parametrize("n,m", [(1024, 512), (512, 256), (77, 5), (128, 64)])
+def test_three_nn_weights_equal_the_composed_form(dev, n, m):
+    """`layers.three_nn_weights` (one launch for the weights) against `three_nn` + `inverse_distance_weights` (the
+    reference's five elementwise operators, upsampling.py:97-100): same neighbours, weights to the last bit or one ulp."""
+    from adaptpoint_amd import layers
+    torch.manual_seed(4)
+    unknown = torch.rand(3, n, 3, device=dev)
+    known = torch.rand(3, m, 3, device=dev)
+    known[0, :3] = unknown[0, :3]                      # exact hits: a zero distance (weight ~1, the others ~1e-8 x)
+    dist, nearest = layers.three_nn(unknown, known)
+    want = layers.inverse_distance_weights(dist)
+    got_nearest, got = layers.three_nn_weights(unknown, known)
+    assert torch.equal(got_nearest, nearest)
+    assert float((got - want).abs().max()) <= 2e-7 and float((got.sum(-1) - 1).abs().max()) <= 3e-7
