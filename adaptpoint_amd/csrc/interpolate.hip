@@ -196,6 +196,147 @@ __global__ __launch_bounds__(TG_THREADS) void three_interpolate_grad_lds_kernel(
     }
 }
 
+// Gradient as a GATHER (round 3): the three (target, weight) pairs of every fine point are turned, per cloud and in LDS,
+// into the list of pairs each coarse point receives -- counts by integer LDS atomics (order-free), offsets by a scan,
+// the lists filled and then SORTED by target, so the sums below run in a fixed order: bit-reproducible, and no float
+// atomic anywhere (the scatter form queues the runs of equal neighbours that nearby fine points share on one LDS
+// address: 66 us for 16 MB at c = 1024 .. 128).  Then the workgroup's [ct][n] tile of the upstream gradient is staged
+// in LDS with whole-line loads and every (coarse point, channel) sums its entries from there; the result is ADDED to
+// the caller's buffer with plain, coalesced read-modify-writes (the contract: the buffer arrives zeroed, group.py-style).
+// Threads: J along the coarse points x CG channel groups (small clouds: m = 64 would leave 7/8 of a flat mapping idle).
+// LDS: off[m + 1] | cur[m] | ent_i[3n] | ent_w[3n] | part[NT] | tile[ct][n]
+constexpr int TGG_THREADS = 512;
+constexpr int TGG_CPT = 16;                       // channels per thread (accumulators)
+
+__global__ __launch_bounds__(TGG_THREADS) void three_interpolate_grad_gather_kernel(
+    int c, int n, int m, int ct, int J, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ grad_points) {
+    extern __shared__ int tg_lds[];
+    int *off = tg_lds;                               // [m + 1]
+    int *cur = off + (m + 1);                        // [m]
+    int *ent_i = cur + m;                            // [3n]
+    float *ent_w = reinterpret_cast<float *>(ent_i + 3 * n);     // [3n]
+    int *part = reinterpret_cast<int *>(ent_w + 3 * n);          // [NT]
+    float *tile = reinterpret_cast<float *>(part + TGG_THREADS); // [ct][n]
+    const int cloud = blockIdx.y, c0 = blockIdx.x * ct, nc = min(ct, c - c0), tid = threadIdx.x;
+    const int *ix = idx + (size_t)cloud * n * 3;
+    const float *wv = weight + (size_t)cloud * n * 3;
+    const int ne = 3 * n;
+
+    // the tile's loads first: they are in flight while the map is built
+    const float *g = grad_out + ((size_t)cloud * c + c0) * n;
+    const int total = nc * n;
+    for (int i0 = tid; i0 < total; i0 += 8 * TGG_THREADS) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * TGG_THREADS;
+            v[u] = g[i < total ? i : total - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * TGG_THREADS;
+            if (i < total) tile[i] = v[u];
+        }
+    }
+    for (int j = tid; j <= m; j += TGG_THREADS) off[j] = 0;
+    __syncthreads();
+    for (int e = tid; e < ne; e += TGG_THREADS) {
+        const int j = ix[e];
+        if ((unsigned)j < (unsigned)m) atomicAdd(&off[j + 1], 1);        // (an index outside the cloud is dropped, not followed)
+    }
+    __syncthreads();
+    // exclusive scan of off[1 .. m] in place: K consecutive entries per thread, the threads' totals by one wave
+    const int K = (m + TGG_THREADS - 1) / TGG_THREADS;
+    int local = 0;
+    for (int k = 0; k < K; ++k) {
+        const int j = tid * K + k;
+        if (j < m) local += off[j + 1];
+    }
+    part[tid] = local;
+    __syncthreads();
+    if (tid < 64) {
+        int s8[TGG_THREADS / 64], sum = 0;
+#pragma unroll
+        for (int u = 0; u < TGG_THREADS / 64; ++u) { s8[u] = part[tid * (TGG_THREADS / 64) + u]; sum += s8[u]; }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (tid >= d) incl += o;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int u = 0; u < TGG_THREADS / 64; ++u) { part[tid * (TGG_THREADS / 64) + u] = run; run += s8[u]; }
+    }
+    __syncthreads();
+    {
+        int run = part[tid];
+        for (int k = 0; k < K; ++k) {
+            const int j = tid * K + k;
+            if (j < m) {
+                const int cnt = off[j + 1];
+                cur[j] = run;                        // where coarse point j's list starts (also its fill cursor)
+                run += cnt;
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += TGG_THREADS) off[j] = cur[j];
+    __syncthreads();
+    for (int e = tid; e < ne; e += TGG_THREADS) {
+        const int j = ix[e];
+        if ((unsigned)j < (unsigned)m) {
+            const int pos = atomicAdd(&cur[j], 1);
+            ent_i[pos] = e / 3;
+            ent_w[pos] = wv[e];
+        }
+    }
+    __syncthreads();
+    // cur[j] is now the END of list j; sort every list by target (insertion sort: lists hold ~3n/m entries), equal
+    // targets (a fine point naming one coarse point twice) by their weights' bits: the order of the addends is a function
+    // of the inputs alone.
+    for (int j = tid; j < m; j += TGG_THREADS) {
+        const int lo = off[j], hi = cur[j];
+        for (int a = lo + 1; a < hi; ++a) {
+            const int ki = ent_i[a];
+            const float kw = ent_w[a];
+            int b = a - 1;
+            while (b >= lo && (ent_i[b] > ki || (ent_i[b] == ki && __float_as_uint(ent_w[b]) > __float_as_uint(kw)))) {
+                ent_i[b + 1] = ent_i[b];
+                ent_w[b + 1] = ent_w[b];
+                --b;
+            }
+            ent_i[b + 1] = ki;
+            ent_w[b + 1] = kw;
+        }
+    }
+    __syncthreads();
+    // gather: thread (jj, cg) owns coarse points jj, jj + J, ... and channels cg, cg + CG, ... (at most TGG_CPT of them)
+    const int CG = TGG_THREADS / J, jj = tid % J, cg = tid / J;
+    float *dst = grad_points + ((size_t)cloud * c + c0) * m;
+    for (int j = jj; j < m; j += J) {
+        const int lo = off[j], hi = cur[j];
+        float acc[TGG_CPT];
+#pragma unroll
+        for (int u = 0; u < TGG_CPT; ++u) acc[u] = 0.0f;
+        for (int a = lo; a < hi; ++a) {
+            const int i = ent_i[a];
+            const float w = ent_w[a];
+#pragma unroll
+            for (int u = 0; u < TGG_CPT; ++u) {
+                const int ch = cg + u * CG;
+                if (ch < nc) acc[u] = __builtin_fmaf(w, tile[ch * n + i], acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TGG_CPT; ++u) {
+            const int ch = cg + u * CG;
+            if (ch < nc) dst[(size_t)ch * m + j] += acc[u];
+        }
+    }
+}
+
 __global__ __launch_bounds__(TI_THREADS) void three_interpolate_grad_atomic_kernel(
     int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ idx,
     const float *__restrict__ weight, float *__restrict__ grad_points) {
@@ -252,6 +393,34 @@ extern "C" int apn_three_interpolate_grad(int b, int c, int n, int m, const floa
     if (b == 0 || c == 0 || n == 0 || m == 0) return APN_OK;
     if (!grad_out || !idx || !weight || !grad_points) return APN_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    {
+        // the gather form, while the cloud's map and at least one channel row fit the LDS budget
+        const size_t meta = sizeof(int) * ((size_t)2 * m + 1 + TGG_THREADS) + (size_t)24 * n;
+        const size_t budget = 96 * 1024;
+        if (meta + (size_t)4 * n <= budget && m <= 8192) {
+            int J = 64;
+            while (J < TGG_THREADS && J < m) J *= 2;
+            const int CG = TGG_THREADS / J;
+            int ct = (int)((budget - meta) / ((size_t)4 * n));
+            if (ct > TGG_CPT * CG) ct = TGG_CPT * CG;
+            if (ct > c) ct = c;
+            while (ct > CG && (long long)b * ((c + ct - 1) / ct) < 256) ct = (ct + 1) / 2;
+            dim3 grid((c + ct - 1) / ct, b);
+            if (grid.x <= 65535) {
+                const size_t dyn = meta + (size_t)4 * n * ct;
+                static const bool raised = [] {
+                    return hipFuncSetAttribute((const void *)three_interpolate_grad_gather_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+                }();
+                if (raised || dyn <= 64 * 1024) {
+                    hipLaunchKernelGGL(three_interpolate_grad_gather_kernel, grid, dim3(TGG_THREADS), dyn, st, c, n, m, ct, J,
+                                       grad_out, idx, weight, grad_points);
+                    APN_LAUNCH_CHECK();
+                    return APN_OK;
+                }
+            }
+        }
+    }
     const size_t lds_budget = 64 * 1024;
     if ((size_t)m * sizeof(float) <= lds_budget) {
         int ct = (int)(lds_budget / ((size_t)m * sizeof(float)));
