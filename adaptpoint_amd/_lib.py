@@ -128,6 +128,8 @@ SIGNATURES = {
     "apn_spectral_norm_blocks": [_c_int] * 2,
     "apn_spectral_norm": [_c_int] * 2 + [_c_void_p, _c_int, _c_float] + [_c_void_p] * 8,
     "apn_spectral_norm_grad": [_c_int] * 2 + [_c_void_p] * 8,
+    "apn_spectral_norm_many": [_c_int] + [_c_void_p] * 3 + [_c_int, _c_float] + [_c_void_p] * 8,
+    "apn_spectral_norm_grad_many": [_c_int] + [_c_void_p] * 10,
     "apn_sa_sample_overlap": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 7,
     "apn_sa_sample_seq": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 8,
 }

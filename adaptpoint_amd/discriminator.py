@@ -77,8 +77,29 @@ class PointDiscriminator1(nn.Module):
         self.fc3 = spectral_norm(nn.Linear(256, num_classes))
         self.prob_head = nn.Sequential(spectral_norm(nn.Linear(num_classes, 1)), nn.Sigmoid())
 
+    def _forward_all_weights_at_once(self, xyz, wn):
+        """The same forward with the seven spectral-normalised weights handed in (spectral.normalise_many)."""
+        convs = self.sa1.mlp_convs
+        x = xyz.permute(0, 2, 1).contiguous()
+        for conv, w in zip(convs[:-1], wn[:len(convs) - 1]):
+            x = pointwise.conv_bias_act(x, w, conv.bias, relu=True)
+        x = pointwise.conv_max(x, wn[len(convs) - 1], convs[-1].bias, relu=True)
+        w1, w2, w3, wh = wn[len(convs):]
+        x = self.drop1(F.relu(F.linear(x, w1, self.fc1.bias)))
+        x = self.drop2(F.relu(F.linear(x, w2, self.fc2.bias)))
+        x = F.linear(x, w3, self.fc3.bias)
+        return self.prob_head[1](F.linear(x, wh, self.prob_head[0].bias))
+
     def forward(self, xyz):
         """xyz (B,N,3) -> probability of "real" (B,1)."""
+        if self.sa1.fused and xyz.is_cuda and len(self.sa1.mlp_convs) == 3:
+            x0 = xyz.permute(0, 2, 1)
+            if pointwise.conv_max_supported(x0, 3) and self.sa1.mlp_convs[-1].in_channels <= 128:
+                # every layer's spectral normalisation (a power iteration each in training mode) in one set of launches
+                from .spectral import normalise_many
+                wn = normalise_many([*self.sa1.mlp_convs, self.fc1, self.fc2, self.fc3, self.prob_head[0]])
+                if wn is not None:
+                    return self._forward_all_weights_at_once(xyz, wn)
         x = self.sa1(xyz.permute(0, 2, 1).contiguous())
         x = self.drop1(F.relu(self.fc1(x)))
         x = self.drop2(F.relu(self.fc2(x)))

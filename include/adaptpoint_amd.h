@@ -622,6 +622,19 @@ APN_API int apn_spectral_norm(int rows, int cols, const float *w, int training, 
 APN_API int apn_spectral_norm_grad(int rows, int cols, const float *g, const float *w_normalized, const float *sigma,
                                    const float *u_used, const float *v_used, double *part, float *g_w, void *stream);
 
+/* The same for ALL layers of a network in one set of launches (3 forward, 2 backward; the layer rides on blockIdx.y): arrays
+ * of n_layers (<= 8) entries with the meaning of the arguments above; scratch[i]: rows[i] + cols[i] floats; part[i]:
+ * apn_spectral_norm_blocks(rows[i], cols[i]) doubles.  (PointDiscriminator1 holds seven spectral-normalised layers and is
+ * evaluated three times per train_gan iteration, point_discriminator.py:17-73, train_autoaug.py:150-196.) */
+APN_API int apn_spectral_norm_many(int n_layers, const int *rows, const int *cols, const float *const *w, int training,
+                                   float eps, float *const *u, float *const *v, float *const *scratch,
+                                   float *const *u_used, float *const *v_used, float *const *sigma,
+                                   float *const *w_normalized, void *stream);
+APN_API int apn_spectral_norm_grad_many(int n_layers, const int *rows, const int *cols, const float *const *g,
+                                        const float *const *w_normalized, const float *const *sigma,
+                                        const float *const *u_used, const float *const *v_used, double *const *part,
+                                        float *const *g_w, void *stream);
+
 /* Tuning / diagnostic entry, NOT part of the reference boundary: apn_furthest_point_sampling
  * with the number of wavefronts that cooperate on one cloud (1, 2, 4, 8 or 16; 0 = the built-in
  * heuristic) and the step algorithm (0 = one LDS 64-bit atomic max per step for n <= 4096; 1 = per-wave

@@ -82,3 +82,64 @@ def test_results_are_bit_reproducible(dev):
         runs.append((w.detach().clone(), p.original.grad.clone(), p[0]._u.clone(), p[0]._v.clone()))
     for a, b in zip(*runs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_all_layers_at_once_equal_layer_by_layer(dev, training):
+    """`spectral.normalise_many` (3 + 2 launches for the discriminator's seven layers) against the per-layer kernels on the
+    same state: normalised weights, the updated `_u` / `_v`, the gradients -- bit for bit (same arithmetic, same orders);
+    two passes, so that the second starts from the first one's power-iteration state; a layer whose gradient is not asked
+    for gets none."""
+    from adaptpoint_amd.spectral import normalise_many
+    one = [_pair(*layer, dev, seed=11 + i)[1] for i, layer in enumerate(LAYERS[:7])]
+    many = [copy.deepcopy(m) for m in one]
+    gen = torch.Generator(dev).manual_seed(9)
+    for rep in range(2):
+        gs = [torch.randn(m.parametrizations.weight.original.shape, device=dev, generator=gen) for m in one]
+        for m in one + many:
+            m.train(training)
+            m.zero_grad(set_to_none=True)
+        w_one = [m.weight for m in one]
+        w_many = normalise_many(many)
+        assert w_many is not None and len(w_many) == 7
+        skip = 4                                                 # this layer's weight takes no part in the loss
+        sum((w * g).sum() for i, (w, g) in enumerate(zip(w_one, gs)) if i != skip).backward()
+        sum((w * g).sum() for i, (w, g) in enumerate(zip(w_many, gs)) if i != skip).backward()
+        for i, (a, b) in enumerate(zip(one, many)):
+            pa, pb = a.parametrizations.weight, b.parametrizations.weight
+            assert torch.equal(w_one[i], w_many[i]) and w_many[i].shape == pa.original.shape
+            assert torch.equal(pa[0]._u, pb[0]._u) and torch.equal(pa[0]._v, pb[0]._v)
+            if i == skip:
+                assert pa.original.grad is None and pb.original.grad is None
+            else:
+                assert torch.equal(pa.original.grad, pb.original.grad)
+
+
+def test_discriminator_forward_uses_one_set_of_launches_and_matches(dev):
+    """PointDiscriminator1(fused=True) normalises its seven weights at once; output, gradient w.r.t. the cloud, weight
+    gradients and the buffers equal the layer-by-layer path of the same module (normalise_many switched off)."""
+    from adaptpoint_amd import spectral
+    from adaptpoint_amd.discriminator import PointDiscriminator1
+    from adaptpoint_amd.pointnext import fill_parameters_by_name
+    torch.manual_seed(0)
+    a = fill_parameters_by_name(PointDiscriminator1(num_classes=15, fused=True)).to(dev).train()
+    b = copy.deepcopy(a)
+    for m in list(a.modules()) + list(b.modules()):
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    x1 = torch.rand(4, 512, 3, device=dev).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    ya = a(x1)
+    keep = spectral.normalise_many
+    spectral.normalise_many = lambda mods, name="weight": None
+    try:
+        yb = b(x2)
+    finally:
+        spectral.normalise_many = keep
+    ya.sum().backward()
+    yb.sum().backward()
+    assert torch.equal(ya, yb) and torch.equal(x1.grad, x2.grad)
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert na == nb and torch.equal(pa.grad, pb.grad), na
+    for (na, ba), (nb, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(ba, bb), na
