@@ -1,0 +1,110 @@
+"""GPU: operators BESIDE each other.  Every isolated parity test launches one kernel stream on an idle device; the
+benches and the two-lane training step do not.  Here two captured graphs are replayed at the same time on two streams
+-- the index stages of the classifier and of the imitator on one, feature kernels (the classifier's blocks, the fused
+set-abstraction step) on the other -- and the index results must equal the ones formed alone, bit for bit, round after
+round.  (This is the situation in which the LDS-atomic FPS step returned wrong picks for ~2 % of the clouds while
+passing every isolated test: DESIGN.md section 4c.)"""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as GI
+
+pytestmark = pytest.mark.gpu
+ROUNDS = 8
+
+
+def _replay_beside(ga, gb, rounds, check):
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for it in range(rounds):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(sb):
+            gb.replay()
+        with torch.cuda.stream(sa):
+            ga.replay()
+        torch.cuda.synchronize()
+        check(it)
+
+
+def _capture(fn):
+    warm = torch.cuda.Stream()
+    warm.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(warm):
+        fn()
+    torch.cuda.current_stream().wait_stream(warm)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    return g, out
+
+
+@pytest.mark.parametrize("partner", ["classifier blocks", "fused set-abstraction steps"])
+def test_index_stages_beside_feature_kernels_are_bit_exact(dev, partner):
+    from adaptpoint_amd.layers import ball_query, furthest_point_sample
+    from adaptpoint_amd.pointnext import PointNextSClassifier, fill_parameters_by_name
+    B = 32
+    pos = torch.from_numpy(GI.unit_sphere_cloud(B, 1024, seed=900)).to(dev)
+    pts = torch.cat([pos, pos[:, :, 1:2]], -1).transpose(1, 2).contiguous()
+    C = fill_parameters_by_name(PointNextSClassifier(fused=True)).to(dev).eval()
+    enc = C.encoder
+
+    def index_work():
+        out = []
+        for smp in enc.index_pyramid(pos):                         # the classifier's four index stages (sampler entry)
+            if smp is not None:
+                out += [smp.fidx, smp.new_p, smp.idx]
+        xyz = pos                                                  # the imitator's grouper chain (drop-in entries)
+        for r in (0.1, 0.2, 0.4, 0.8):
+            fidx = furthest_point_sample(xyz, xyz.shape[1] // 2)
+            new = torch.gather(xyz, 1, fidx.long().unsqueeze(-1).expand(-1, -1, 3))
+            out += [fidx, ball_query(r, 24, xyz, new)]
+            xyz = new
+        return out
+
+    if partner == "classifier blocks":
+        def feature_work():
+            keep = []
+            for _ in range(3):
+                p0, f0 = pos, pts
+                for stage in enc.encoder:
+                    p0, f0 = stage[0]([p0, f0])
+                keep.append(f0)
+            return keep
+    else:
+        from adaptpoint_amd.set_abstraction import SetAbstraction
+        torch.manual_seed(0)
+        sa = SetAbstraction(32, 64, layers=2, stride=2, fused=True,
+                            group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                            norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+                            use_res=True).to(dev).train()
+        f = torch.randn(B, 32, 1024, device=dev)
+        smp = sa.sample(pos)
+
+        def feature_work():
+            keep = []
+            for _ in range(12):
+                fi = f.clone().requires_grad_(True)
+                _, out = sa([pos, fi], sampling=smp)
+                out.sum().backward()
+                keep.append(fi.grad)
+            return keep
+
+    with torch.no_grad() if partner == "classifier blocks" else torch.enable_grad():
+        with torch.no_grad():
+            ref = [t.clone() for t in index_work()]
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            ga, got = _capture(index_work)
+        gb, _keep = _capture(feature_work)
+
+    bad = []
+
+    def check(it):
+        for k, (a, b) in enumerate(zip(got, ref)):
+            if not torch.equal(a, b):
+                bad.append((it, k, int((a != b).flatten(1).any(1).sum())))
+
+    _replay_beside(ga, gb, ROUNDS, check)
+    assert not bad, ("index results formed beside the feature kernels differ from the ones formed alone "
+                     "(round, tensor, clouds):", bad[:10])
