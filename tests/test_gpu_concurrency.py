@@ -98,13 +98,24 @@ def test_index_stages_beside_feature_kernels_are_bit_exact(dev, partner):
             ga, got = _capture(index_work)
         gb, _keep = _capture(feature_work)
 
-    bad = []
+    # the partner's own results alone (one replay on the idle device): the eval-mode classifier blocks are deterministic
+    # kernels (fixed-order sums), so beside the index stream they must give the same bits too
+    gb.replay()
+    torch.cuda.synchronize()
+    feat_ref = [t.clone() for t in _keep] if partner == "classifier blocks" else None
+    bad, bad_feat = [], []
 
     def check(it):
         for k, (a, b) in enumerate(zip(got, ref)):
             if not torch.equal(a, b):
                 bad.append((it, k, int((a != b).flatten(1).any(1).sum())))
+        if feat_ref is not None:
+            for k, (a, b) in enumerate(zip(_keep, feat_ref)):
+                if not torch.equal(a, b):
+                    bad_feat.append((it, k, float((a - b).abs().max())))
 
     _replay_beside(ga, gb, ROUNDS, check)
     assert not bad, ("index results formed beside the feature kernels differ from the ones formed alone "
                      "(round, tensor, clouds):", bad[:10])
+    assert not bad_feat, ("the classifier's features formed beside the index kernels differ from the ones formed alone "
+                          "(round, tensor, max deviation):", bad_feat[:10])
