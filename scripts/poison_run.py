@@ -9,4 +9,4 @@ pat = pat - (1 << 32) if pat >= (1 << 31) else pat
 blocks = [torch.full((64 << 20,), pat, dtype=torch.int32, device="cuda:0") for _ in range(24)]     # 24 x 256 MB
 small = [torch.full((1 << 16,), pat, dtype=torch.int32, device="cuda:0") for _ in range(512)]
 del blocks, small
-sys.exit(pytest.main(["tests/test_gpu_adaptpoint.py", "tests/test_gpu_fused_wide.py", "tests/test_gpu_fused.py", "tests/test_gpu_pointwise.py", "-q", "-m", "gpu", "-x", "-s", "-k", sys.argv[1] if len(sys.argv) > 1 else "gan_step or block or reproducible"]))
+sys.exit(pytest.main(["tests/test_gpu_adaptpoint.py", "tests/test_gpu_fused_wide.py", "tests/test_gpu_fused.py", "tests/test_gpu_pointwise.py", "tests/test_gpu_spectral.py", "tests/test_gpu_ops_parity.py", "tests/test_gpu_graph_replay.py", "tests/test_gpu_concurrency.py", "-q", "-m", "gpu", "-x", "-s", "-k", sys.argv[1] if len(sys.argv) > 1 else "gan_step or block or reproducible or interp or transpose or three_nn or all_layers or joint or index_stages or propagation"]))
