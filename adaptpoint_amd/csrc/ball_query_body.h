@@ -6,12 +6,12 @@
 namespace apn {
 
 constexpr int BQ_CHUNK = 4096;             // support points staged per LDS pass (48 KiB)
-constexpr int BQ_QPW = 4;                  // queries a wave tests each staged point against
+constexpr int BQ_QPW = 4;                  // queries a wave tests each staged point against (8 for full tiles: ball_query.hip)
 
 // One workgroup of WAVES waves: tile `bx` of cloud `cloud`; each wave owns queries
 // q0 + wave, q0 + wave + WAVES, ... of the tile.  s_dyn: three coordinate planes of
 // min(n, BQ_CHUNK) floats, then 2 * q_per_block ints.
-template <int WAVES>
+template <int WAVES, int QPW = BQ_QPW>
 __device__ __forceinline__ void ball_query_body(
     int n, int m, float radius2, int nsample, int q_per_block, int zero_empty,
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, int *__restrict__ idx,
@@ -47,15 +47,15 @@ __device__ __forceinline__ void ball_query_body(
         }
         __syncthreads();
 
-        // A wave takes BQ_QPW consecutive queries per pass over the chunk: a point's coordinates are read from LDS
+        // A wave takes QPW consecutive queries per pass over the chunk: a point's coordinates are read from LDS
         // once for all of them (one query per pass spent most of its instructions on the three LDS reads and the
         // loop; the per-query part -- distance, ballot, slot arithmetic -- and the order of the hits are unchanged)
-        for (int qb = q_begin + wave * BQ_QPW; qb < q_end; qb += WAVES * BQ_QPW) {
-            int cnt[BQ_QPW], first[BQ_QPW];
-            float qx[BQ_QPW], qy[BQ_QPW], qz[BQ_QPW];
+        for (int qb = q_begin + wave * QPW; qb < q_end; qb += WAVES * QPW) {
+            int cnt[QPW], first[QPW];
+            float qx[QPW], qy[QPW], qz[QPW];
             bool open = false;
 #pragma unroll
-            for (int j = 0; j < BQ_QPW; ++j) {
+            for (int j = 0; j < QPW; ++j) {
                 const int q = qb + j;
                 const bool in = q < q_end;
                 cnt[j] = in ? __builtin_amdgcn_readfirstlane(cnt_of[q - q_begin]) : nsample;   // wave-uniform
@@ -73,7 +73,7 @@ __device__ __forceinline__ void ball_query_body(
                 const float px = inside ? sx[k] : 0.0f, py = inside ? sy[k] : 0.0f, pz = inside ? sz[k] : 0.0f;
                 bool any_open = false;
 #pragma unroll
-                for (int j = 0; j < BQ_QPW; ++j) {
+                for (int j = 0; j < QPW; ++j) {
                     if (cnt[j] >= nsample) continue;              // wave-uniform
                     const bool hit = inside && dist2(qx[j] - px, qy[j] - py, qz[j] - pz) < radius2;
                     const unsigned long long mask = __ballot(hit);
@@ -91,13 +91,13 @@ __device__ __forceinline__ void ball_query_body(
             }
             if (lane == 0) {
 #pragma unroll
-                for (int j = 0; j < BQ_QPW; ++j)
+                for (int j = 0; j < QPW; ++j)
                     if (qb + j < q_end) { cnt_of[qb + j - q_begin] = cnt[j]; first_of[qb + j - q_begin] = first[j]; }
             }
         }
     }
 
-    __syncthreads();   // the counts were left by the wave that scanned the query's group of BQ_QPW, read below per query
+    __syncthreads();   // the counts were left by the wave that scanned the query's group of QPW, read below per query
     // Tail of each row: slots the scan never reached repeat the first hit
     // (ball_query_gpu.cu:41-45).  Rows of empty balls stay untouched.
     for (int q = q_begin + wave; q < q_end; q += WAVES) {
