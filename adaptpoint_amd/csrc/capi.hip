@@ -21,3 +21,41 @@ extern "C" int apn_debug_stamp(void *stamps, int slot, void *stream) {
     hipLaunchKernelGGL(apn::stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long *)stamps, slot);
     return (int)hipGetLastError();
 }
+
+// Diagnostic (scripts/debug_vgpr_hold.py): a long-running kernel that only HOLDS values -- 24 registers per lane, kept
+// live by opaque asm statements, a workgroup barrier and one LDS atomic per turn (the rhythm of the FPS step) -- and checks
+// them at the end.  bad[i] counts lanes whose i-th value changed; bad[24 + k] (k < 8) samples of (index << 32 | value).
+namespace apn {
+__global__ __launch_bounds__(256) void vgpr_hold_kernel(int turns, unsigned long long *bad) {
+    __shared__ unsigned long long slot[4];
+    const unsigned lane = threadIdx.x;
+    unsigned r[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) r[i] = 0x10000u * (unsigned)(i + 1) + lane * 131u + blockIdx.x;
+    if (lane < 4) slot[lane] = 0ull;
+    __syncthreads();
+    for (int t = 0; t < turns; ++t) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) asm volatile("" : "+v"(r[i]));
+        if ((lane & 63) == (unsigned)(t & 63))
+            atomicMax(&slot[t & 3], ((unsigned long long)r[0] << 32) | (unsigned)t);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned k = (unsigned)slot[t & 3];
+        if (k == 0xFFFFFFFFu) r[23] ^= 1u;                     // (never true: keeps the read alive)
+    }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const unsigned want = 0x10000u * (unsigned)(i + 1) + lane * 131u + blockIdx.x;
+        if (r[i] != want) {
+            const unsigned long long n = atomicAdd(&bad[i], 1ull);
+            if (n < 8) bad[24 + (i & 7)] = ((unsigned long long)i << 32) | r[i];
+        }
+    }
+}
+}  // namespace apn
+
+extern "C" int apn_debug_vgpr_hold(int blocks, int turns, unsigned long long *bad, void *stream) {
+    if (blocks <= 0 || turns < 0 || !bad) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::vgpr_hold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, turns, bad);
+    return (int)hipGetLastError();
+}

@@ -159,6 +159,10 @@ APN_API int apn_zero_fill(void *base, long long bytes, void *stream);
 /* Diagnostic: stamps[slot] = the device's 100 MHz wall clock when the launch runs (one thread; graph-capturable:
  * phase boundaries of a replayed step on every branch of the graph).  stamps: unsigned 64-bit words. */
 APN_API int apn_debug_stamp(void *stamps, int slot, void *stream);
+/* Diagnostic: `blocks` workgroups of 256 lanes hold 24 register values each for `turns` barrier-and-LDS-atomic turns and
+ * check them: bad[i] (i < 24) = lanes whose i-th value changed, bad[24 .. 31] samples (index << 32 | value found).
+ * bad: 32 unsigned 64-bit words, zeroed by the caller.  (Does register state survive beside other kernels?) */
+APN_API int apn_debug_vgpr_hold(int blocks, int turns, unsigned long long *bad, void *stream);
 
 /* `precision` (every function that takes ft): 1 = operands rounded to bf16; 2 = operands split
  * into hi + lo bf16 parts, each product three MFMAs (hi*hi + hi*lo + lo*hi, "bf16x3"): fp32-grade

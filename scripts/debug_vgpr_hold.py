@@ -1,0 +1,67 @@
+"""Does plain register state survive a long kernel that runs BESIDE other kernels?  `apn_debug_vgpr_hold` keeps 24 values
+per lane live for ~250 us (a barrier and an LDS atomic per turn, as the FPS step) and checks them; here it is replayed
+from a graph on one stream while the classifier's blocks replay on another, as in tests/test_gpu_concurrency.py."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import golden_inputs as GI
+from adaptpoint_amd.fused import _call
+from adaptpoint_amd.pointnext import PointNextSClassifier, fill_parameters_by_name
+
+dev = torch.device("cuda:0")
+B = 32
+pos = torch.from_numpy(GI.unit_sphere_cloud(B, 1024, seed=900)).to(dev)
+pts = torch.cat([pos, pos[:, :, 1:2]], -1).transpose(1, 2).contiguous()
+C = fill_parameters_by_name(PointNextSClassifier(fused=True)).to(dev).eval()
+bad = torch.zeros(32, dtype=torch.int64, device=dev)
+turns = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+
+
+def hold():
+    for _ in range(6):
+        _call("apn_debug_vgpr_hold", dev, 640, turns, bad.data_ptr())
+
+
+def feature_work():
+    keep = []
+    with torch.no_grad():
+        for _ in range(3):
+            p0, f0 = pos, pts
+            for stage in C.encoder.encoder:
+                p0, f0 = stage[0]([p0, f0])
+            keep.append(f0)
+    return keep
+
+
+def capture(fn):
+    warm = torch.cuda.Stream()
+    warm.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(warm):
+        fn()
+    torch.cuda.current_stream().wait_stream(warm)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    return g, out
+
+
+ga, _ = capture(hold)
+gb, keep = capture(feature_work)
+bad.zero_()
+for _ in range(3):
+    ga.replay()
+torch.cuda.synchronize()
+print("alone:   lanes with a changed value, per held value:", bad[:24].tolist())
+bad.zero_()
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+for it in range(12):
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sb):
+        gb.replay()
+    with torch.cuda.stream(sa):
+        ga.replay()
+torch.cuda.synchronize()
+print("beside the classifier's blocks:", bad[:24].tolist())
+print("samples (index, value found):", [(int(v) >> 32, hex(int(v) & 0xFFFFFFFF)) for v in bad[24:].tolist() if v])
