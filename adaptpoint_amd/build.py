@@ -23,6 +23,14 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
             "-fvisibility=hidden", "-Wall", "-Wno-unused-command-line-argument"] + os.environ.get("APN_EXTRA_CXXFLAGS", "").split()
 
 
+# Per-file flags.  fps.hip: no SLP vectorisation, i.e. no packed-FP32 instructions (v_pk_add / mul / fma_f32 with op_sel on
+# VGPR pairs) in the sampler's step.  With them the LDS-atomic step returned wrong picks for ~2 % of the clouds whenever
+# MFMA-heavy kernels shared the device (never alone); every build of the step without them -- this flag, a build whose
+# extra registers happened to keep the vectoriser off, the per-wave-record kernel whose centre lives in SGPRs -- passes
+# the same checks (tests/test_gpu_concurrency.py).
+FILE_FLAGS = {"fps.hip": ["-fno-slp-vectorize"]}
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -48,13 +56,13 @@ def build(force=False, asm=False, verbose=False):
         objs.append(obj)
         if not force and _newer(obj, [src] + hdrs + [os.path.abspath(__file__)]):
             continue
-        cmd = [hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
         if asm:
             s_out = os.path.join(OBJ, os.path.basename(src)[:-4] + ".s")
-            subprocess.run([hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, "--cuda-device-only",
+            subprocess.run([hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "--cuda-device-only",
                             "-S", src, "-o", s_out], check=True)
     for src, p in procs:
         if p.wait() != 0:

@@ -565,16 +565,19 @@ static apn::FpsOrder fps_order(int n) {
     return o;
 }
 
-// Which step the operator entries run.  The LDS-atomic step (algo 0) is ~16 % faster per step (314 against 370 ns at
-// 1024 points) and bit-exact in every isolated test -- but BESIDE other kernels (the benches' index stream next to the
-// MLP stream, two lanes of a captured training step) it returned wrong picks for ~2 % of the clouds: one spurious
-// arg-max per affected cloud, the right sequence continuing one step late (bench.py's verification of the index sets;
-// scripts/debug_two_lane_forward.py).  Its LDS table is intact at the end, no step's slot pairs one lane's rank with
-// another's distance, the waves' maxima never beat the slot, a second barrier per step and a returning atomic change
-// nothing: the cause is not known.  The per-wave-record step (algo 1) has never failed the same checks, so it is what
-// the operators run; APN_FPS_LDS_ATOMIC=1 (read once) and the tuned entry select the other one for study.
+// Which step the operator entries run: the LDS-atomic step (algo 0; 314 against 370 ns per step at 1024 points).
+// History worth keeping: BESIDE MFMA-heavy kernels (the benches' index stream next to the MLP
+// stream, two lanes of a captured training step) this step returned wrong picks for ~2 % of the clouds -- one spurious
+// arg-max per affected cloud -- while every isolated test was bit-exact.  The cause was not in this file's logic: the
+// compiler's SLP vectoriser had turned the distance update into packed-FP32 instructions (v_pk_add_f32 ... v[0:1]
+// op_sel_hi:[1,0], the pair's other half being a live running minimum), and those intermittently computed with the
+// wrong half when MFMA kernels shared the SIMDs.  Every build of the step WITHOUT packed FP32 passes the checks that
+// caught it (bench.py's verification of the index sets, tests/test_gpu_concurrency.py), so this translation unit is
+// compiled with -fno-slp-vectorize (adaptpoint_amd/build.py, FILE_FLAGS) and tests/test_host_cpu.py asserts that the
+// sampler kernels hold no v_pk_ instruction.  APN_FPS_RECORDS=1 (read once) selects the per-wave-record step, which
+// never had them (its centre lives in SGPRs).
 static int fps_default_algo() {
-    static const int algo = [] { const char *e = getenv("APN_FPS_LDS_ATOMIC"); return (e && atoi(e) == 1) ? 0 : 1; }();
+    static const int algo = [] { const char *e = getenv("APN_FPS_RECORDS"); return (e && atoi(e) == 1) ? 1 : 0; }();
     return algo;
 }
 

@@ -641,10 +641,9 @@ APN_API int apn_spectral_norm_grad_many(int n_layers, const int *rows, const int
 
 /* Tuning / diagnostic entry, NOT part of the reference boundary: apn_furthest_point_sampling
  * with the number of wavefronts that cooperate on one cloud (1, 2, 4, 8 or 16; 0 = the built-in
- * heuristic) and the step algorithm (0 = one LDS 64-bit atomic max per step for n <= 4096; 1 = per-wave
- * records + second reduction: what the operator entries run) chosen PER CALL.  Results do not depend on
- * either argument when the launch has the device to itself; beside other kernels the LDS-atomic step has
- * returned wrong picks (csrc/fps.hip, fps_default_algo), which is why the operators do not use it. */
+ * heuristic) and the step algorithm (0 = one LDS 64-bit atomic max per step for n <= 4096: what the operator
+ * entries run; 1 = per-wave records + second reduction) chosen PER CALL.  No process-wide state: every entry
+ * point of this library is re-entrant.  Results do not depend on either argument. */
 APN_API int apn_furthest_point_sampling_tuned(int b, int n, int m, const float *xyz, float *temp,
                                               int *idx, int waves, int algo, void *stream);
 

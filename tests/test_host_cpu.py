@@ -1,4 +1,6 @@
 """CPU suite: host-side logic of the drop-in boundary and of the layer mirror."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -174,3 +176,36 @@ def test_pointnet2_blocks_match_the_reference_modules(cpu_mirrors):
     import os
     pins = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pins_golden.npz"))
     run_pointnet2_blocks(torch.device("cpu"), pins, 2e-5)
+
+
+def test_sampler_kernels_hold_no_packed_fp32_instruction():
+    """csrc/fps.hip is compiled without SLP vectorisation: packed-FP32 instructions in the sampler's distance update
+    computed with the wrong half of a register pair now and then when MFMA kernels shared the device (DESIGN.md section
+    4c) -- wrong FPS picks for ~2 % of the clouds, invisible to every isolated test.  The device code of every sampler
+    kernel must hold none."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from adaptpoint_amd import build
+    assert "-fno-slp-vectorize" in build.FILE_FLAGS.get("fps.hip", [])
+    obj = os.path.join(build.OBJ, "fps.o")
+    if not os.path.exists(obj):
+        build.build()
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, "fps.o")
+        shutil.copy(obj, local)
+        subprocess.run([objdump, "--offloading", local], cwd=tmp, check=True, capture_output=True)
+        cos = [f for f in glob.glob(os.path.join(tmp, "fps.o.*gfx950*"))]
+        assert cos, "no gfx950 code object in fps.o"
+        text = subprocess.run([objdump, "-d", cos[0]], check=True, capture_output=True, text=True).stdout
+    kernel, hits = None, {}
+    for line in text.splitlines():
+        if line.endswith(">:") and "<" in line:
+            kernel = line.split("<")[1].split(">")[0]
+        elif kernel and "fps_" in kernel and "v_pk_" in line and "_f32" in line:
+            hits[kernel] = hits.get(kernel, 0) + 1
+    assert not hits, ("packed-FP32 instructions in sampler kernels:", hits)
