@@ -38,6 +38,7 @@ SIGNATURES = {
     "apn_zero_fill": [_c_void_p, _c_longlong, _c_void_p],
     "apn_debug_stamp": [_c_void_p, _c_int, _c_void_p],
     "apn_debug_vgpr_hold": [_c_int, _c_int, _c_void_p, _c_void_p],
+    "apn_debug_vpk_probe": [_c_int, _c_int, _c_void_p, _c_void_p],
     "apn_sa_geo_dd_doubles": [_c_int],
     "apn_sa_point_geo": [_c_int] * 4 + [_c_float] + [_c_void_p] * 6,
     "apn_sa_prep_rows": [_c_int] * 2,

@@ -59,3 +59,48 @@ extern "C" int apn_debug_vgpr_hold(int blocks, int turns, unsigned long long *ba
     hipLaunchKernelGGL(apn::vgpr_hold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, turns, bad);
     return (int)hipGetLastError();
 }
+
+// Diagnostic (scripts/debug_vgpr_hold.py vpk): the instruction form the SLP vectoriser had put into the FPS step,
+//     v_pk_add_f32 d, a, pair  op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]        (d.lo = a.lo - pair.lo, d.hi = a.hi - pair.lo)
+// with pair.lo rewritten every turn (a v_mov just ahead of it, as there) and pair.hi a LIVE unrelated value, in a loop that
+// checks every result.  bad[0] = results whose high half is wrong, bad[1] = of those, the ones that equal a.hi - pair.hi
+// (the other half used), bad[2] = low half wrong, bad[3] = results checked.
+namespace apn {
+typedef float vpk_f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void vpk_probe_kernel(int turns, unsigned long long *bad) {
+    __shared__ unsigned long long slot[4];
+    const unsigned lane = threadIdx.x;
+    const float a0 = 0.25f + 0.001f * (float)lane, a1 = -0.5f + 0.002f * (float)lane;
+    const float other = 1000.0f + (float)lane;                 // what the pair's other half holds (a live value)
+    unsigned long long wrong_hi = 0, other_half = 0, wrong_lo = 0, seen = 0;
+    if (lane < 4) slot[lane] = 0ull;
+    __syncthreads();
+    for (int t = 0; t < turns; ++t) {
+        const float c = 0.001f * (float)(t & 1023) + 0.01f * (float)(lane & 7);
+        vpk_f2 a = {a0, a1}, pair, d;
+        float lo = 0.0f, hi = other;
+        asm volatile("" : "+v"(hi));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(lo) : "v"(c));
+        pair = (vpk_f2){lo, hi};
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(pair));
+        const float want_lo = a0 - c, want_hi = a1 - c;
+        if (d.y != want_hi) { ++wrong_hi; if (d.y == a1 - hi) ++other_half; }
+        if (d.x != want_lo) ++wrong_lo;
+        ++seen;
+        if ((t & 7) == 0) {                                    // the FPS step's rhythm: an LDS atomic and a barrier now and then
+            if ((lane & 63) == (unsigned)(t & 63)) atomicMax(&slot[t & 3], (unsigned long long)t);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    if (wrong_hi) atomicAdd(&bad[0], wrong_hi);
+    if (other_half) atomicAdd(&bad[1], other_half);
+    if (wrong_lo) atomicAdd(&bad[2], wrong_lo);
+    atomicAdd(&bad[3], seen);
+}
+}  // namespace apn
+
+extern "C" int apn_debug_vpk_probe(int blocks, int turns, unsigned long long *bad, void *stream) {
+    if (blocks <= 0 || turns < 0 || !bad) return APN_EINVAL;
+    hipLaunchKernelGGL(apn::vpk_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, turns, bad);
+    return (int)hipGetLastError();
+}

@@ -163,6 +163,10 @@ APN_API int apn_debug_stamp(void *stamps, int slot, void *stream);
  * check them: bad[i] (i < 24) = lanes whose i-th value changed, bad[24 .. 31] samples (index << 32 | value found).
  * bad: 32 unsigned 64-bit words, zeroed by the caller.  (Does register state survive beside other kernels?) */
 APN_API int apn_debug_vgpr_hold(int blocks, int turns, unsigned long long *bad, void *stream);
+/* Diagnostic: the packed-FP32 instruction form that returned wrong FPS picks beside MFMA kernels, checked result by result:
+ * bad[0] high halves wrong, bad[1] of those computed with the pair's OTHER half, bad[2] low halves wrong, bad[3] results
+ * checked.  bad: 4 unsigned 64-bit words, zeroed by the caller. */
+APN_API int apn_debug_vpk_probe(int blocks, int turns, unsigned long long *bad, void *stream);
 
 /* `precision` (every function that takes ft): 1 = operands rounded to bf16; 2 = operands split
  * into hi + lo bf16 parts, each product three MFMAs (hi*hi + hi*lo + lo*hi, "bf16x3"): fp32-grade

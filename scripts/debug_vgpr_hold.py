@@ -15,12 +15,13 @@ pos = torch.from_numpy(GI.unit_sphere_cloud(B, 1024, seed=900)).to(dev)
 pts = torch.cat([pos, pos[:, :, 1:2]], -1).transpose(1, 2).contiguous()
 C = fill_parameters_by_name(PointNextSClassifier(fused=True)).to(dev).eval()
 bad = torch.zeros(32, dtype=torch.int64, device=dev)
-turns = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+turns = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 600
+VPK = "vpk" in sys.argv          # the packed-FP32 probe instead of the register-hold kernel
 
 
 def hold():
     for _ in range(6):
-        _call("apn_debug_vgpr_hold", dev, 640, turns, bad.data_ptr())
+        _call("apn_debug_vpk_probe" if VPK else "apn_debug_vgpr_hold", dev, 640, turns * (20 if VPK else 1), bad.data_ptr())
 
 
 def feature_work():
@@ -53,7 +54,7 @@ bad.zero_()
 for _ in range(3):
     ga.replay()
 torch.cuda.synchronize()
-print("alone:   lanes with a changed value, per held value:", bad[:24].tolist())
+print("alone:  ", bad[:4].tolist() if VPK else bad[:24].tolist(), "(high halves wrong, of those with the other half, low halves wrong, results checked)" if VPK else "lanes with a changed value, per held value")
 bad.zero_()
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 for it in range(12):
@@ -63,5 +64,5 @@ for it in range(12):
     with torch.cuda.stream(sa):
         ga.replay()
 torch.cuda.synchronize()
-print("beside the classifier's blocks:", bad[:24].tolist())
+print("beside the classifier's blocks:", bad[:4].tolist() if VPK else bad[:24].tolist())
 print("samples (index, value found):", [(int(v) >> 32, hex(int(v) & 0xFFFFFFFF)) for v in bad[24:].tolist() if v])
