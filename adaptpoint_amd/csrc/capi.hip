@@ -76,14 +76,22 @@ __global__ __launch_bounds__(256) void vpk_probe_kernel(int turns, unsigned long
     if (lane < 4) slot[lane] = 0ull;
     __syncthreads();
     for (int t = 0; t < turns; ++t) {
-        const float c = 0.001f * (float)(t & 1023) + 0.01f * (float)(lane & 7);
+        // the operand arrives as in the FPS step: one lane leaves it in an LDS table entry, every lane reads the entry back
+        // with a 96-bit broadcast read behind a barrier, and the third word is moved into the pair's low half
+        __shared__ float4 entry[2];
+        const float cw = 0.001f * (float)(t & 1023) + 0.01f * (float)(blockIdx.x & 7);
+        if (lane == (unsigned)(t & 255)) entry[t & 1] = make_float4(cw + 1.0f, cw + 2.0f, cw, 0.0f);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const float4 e = entry[t & 1];
+        const float c = e.z;
         vpk_f2 a = {a0, a1}, pair, d;
         float lo = 0.0f, hi = other;
         asm volatile("" : "+v"(hi));
         asm volatile("v_mov_b32 %0, %1" : "=v"(lo) : "v"(c));
         pair = (vpk_f2){lo, hi};
         asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(pair));
-        const float want_lo = a0 - c, want_hi = a1 - c;
+        const float want_lo = a0 - cw, want_hi = a1 - cw;
+        if (e.x != cw + 1.0f || e.y != cw + 2.0f) ++wrong_lo;     // (the read itself)
         if (d.y != want_hi) { ++wrong_hi; if (d.y == a1 - hi) ++other_half; }
         if (d.x != want_lo) ++wrong_lo;
         ++seen;
