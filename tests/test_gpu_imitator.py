@@ -41,13 +41,15 @@ def test_sa_component_matches_reference_golden(dev, golden, oracle):
     (whose algorithm choice is tuned per machine) differ by ~1e-4 in the outputs and a few 1e-3 of
     their scale in gradients through the whole stack -- bars 1e-2 / 5e-2.  (2) The fused operators
     against the composed forms of the same mirror ON THE SAME GPU (same MIOpen kernels either side):
-    the grouping stage is bit-exact, the attention core 1e-5 -- bars 1e-4 / 1e-3 / 1e-2."""
+    the grouping stage is bit-exact, the attention core 1e-5 -- bars 1e-4 / 1e-3 / 2e-2."""
     fused = _run(dev, oracle, True)
     composed = _run(dev, oracle, False)
     for key, tol in (("g8_sac_prob", 1e-2), ("g8_sac_mask_logits", 1e-2),
                      ("g8_sac_grad_embed_w", 5e-2), ("g8_sac_grad_alpha0", 5e-2)):
         assert _err(fused[key], golden[key]) <= tol, (key, "fused vs reference", _err(fused[key], golden[key]))
         assert _err(composed[key], golden[key]) <= tol, (key, "composed vs reference")
+    # (gradient bars 2e-2: the grouper's gradient sums with LDS float atomics whose order varies from run to run, and ~40
+    # training-mode BatchNorm layers over few points amplify that -- typically 2e-3, once 1.27e-2 in a full-suite run)
     for key, tol in (("g8_sac_prob", 1e-4), ("g8_sac_mask_logits", 1e-3),
-                     ("g8_sac_grad_embed_w", 1e-2), ("g8_sac_grad_alpha0", 1e-2)):
+                     ("g8_sac_grad_embed_w", 2e-2), ("g8_sac_grad_alpha0", 2e-2)):
         assert _err(fused[key], composed[key]) <= tol, (key, "fused vs composed", _err(fused[key], composed[key]))
