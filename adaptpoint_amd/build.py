@@ -19,22 +19,19 @@ ARCH = "gfx950"
 SOURCES = ["capi.hip", "fps.hip", "ball_query.hip", "group_points.hip", "interpolate.hip", "sa_fused.hip", "sa_glue.hip", "sa_seq.hip", "sa_geo.hip", "sa_wide.hip", "sa_wide_glue.hip", "sa_wide_dense.hip", "pointwise.hip", "spectral.hip", "augment.hip", "pointset_group.hip", "attention.hip"]
 HEADERS = ["apn_common.h", "apn_mfma.h", "sa_chain.h", "ball_query_body.h",
            os.path.join("..", "..", "include", "adaptpoint_amd.h")]
-CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
             "-fvisibility=hidden", "-Wall", "-Wno-unused-command-line-argument"] + os.environ.get("APN_EXTRA_CXXFLAGS", "").split()
 
 
-# Per-file flags.  fps.hip: no SLP vectorisation, i.e. no packed-FP32 instructions (v_pk_add / mul / fma_f32 with op_sel on
-# VGPR pairs) in the sampler's step.  With them the LDS-atomic step returned wrong picks for ~2 % of the clouds whenever
-# MFMA-heavy kernels shared the device (never alone); every build of the step without them -- this flag, a build whose
-# extra registers happened to keep the vectoriser off, the per-wave-record kernel whose centre lives in SGPRs -- passes
-# the same checks (tests/test_gpu_concurrency.py).
-# The same flag for the other translation units whose kernels issue no MFMA themselves but run BESIDE MFMA kernels (the
-# index stream, the generator's geometry kernels on a lane of the joint step) and held packed-FP32 instructions: the
-# exposure that bit the sampler.  No failure of theirs was ever observed; the flag costs them nothing measurable.
-# (The MFMA kernels keep their packed arithmetic: they run among MFMA waves all the time and are bit-reproducible.)
-# (sa_geo.hip keeps its eight packed instructions: its counts are verified against a run alone in every bench line, and
-# without them the headline measured ~0.5 % lower.)
-FILE_FLAGS = {f: ["-fno-slp-vectorize"] for f in ("fps.hip", "pointset_group.hip", "augment.hip")}
+# -fno-slp-vectorize, for every translation unit: NO packed-FP32 instructions made by the compiler's SLP vectoriser
+# (v_pk_add / mul / fma_f32 with op_sel on VGPR pairs).  With them two different kernels returned wrong results whenever
+# OTHER MFMA-heavy kernels shared the device -- never alone: the FPS step (wrong picks for ~2 % of the clouds beside the
+# benches' MLP stream; rounds 1-3) and the width-generic block (features off by 0.1-0.3 beside the fused training step) --
+# and every build without them passes the same checks (bench.py's verification, tests/test_gpu_concurrency.py); DESIGN.md
+# section 4c.  It costs nothing measurable (headline 278.6 k against 279.3 k clouds/s).  The explicitly two-wide
+# arithmetic of csrc/pointwise.hip (vector types, no operand selection) stays.
+NO_SLP = ["-fno-slp-vectorize"]
+FILE_FLAGS = {}
 
 
 def hipcc():

@@ -119,3 +119,61 @@ def test_index_stages_beside_feature_kernels_are_bit_exact(dev, partner):
                      "(round, tensor, clouds):", bad[:10])
     assert not bad_feat, ("the classifier's features formed beside the index kernels differ from the ones formed alone "
                           "(round, tensor, max deviation):", bad_feat[:10])
+
+
+def test_feature_kernels_beside_other_feature_kernels_are_bit_exact(dev):
+    """MFMA kernels beside MFMA kernels: the eval-mode classifier blocks (deterministic kernels: fixed-order sums) replayed
+    on one stream while the fused set-abstraction training step (forward + backward, MFMA-heavy) replays on another must
+    give the bits they give alone -- the packed-FP32 arithmetic inside these kernels was never seen to fail, and this is
+    where it would show."""
+    from adaptpoint_amd.pointnext import PointNextSClassifier, fill_parameters_by_name
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    B = 32
+    pos = torch.from_numpy(GI.unit_sphere_cloud(B, 1024, seed=901)).to(dev)
+    pts = torch.cat([pos, pos[:, :, 1:2]], -1).transpose(1, 2).contiguous()
+    C = fill_parameters_by_name(PointNextSClassifier(fused=True)).to(dev).eval()
+    pyr = C.encoder.index_pyramid(pos)
+
+    def blocks():
+        keep = []
+        with torch.no_grad():
+            for _ in range(3):
+                p0, f0 = pos, pts
+                for i, stage in enumerate(C.encoder.encoder):
+                    smp = pyr[i]
+                    p0, f0 = stage[0]([p0, f0], sampling=smp) if smp is not None else stage[0]([p0, f0])
+                    keep.append(f0)
+        return keep
+
+    torch.manual_seed(0)
+    sa = SetAbstraction(32, 64, layers=2, stride=2, fused=True,
+                        group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                        norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+                        use_res=True).to(dev).train()
+    f = torch.randn(B, 32, 1024, device=dev)
+    smp1 = sa.sample(pos)
+
+    def steps():
+        keep = []
+        for _ in range(12):
+            fi = f.clone().requires_grad_(True)
+            _, out = sa([pos, fi], sampling=smp1)
+            out.sum().backward()
+            keep.append(fi.grad)
+        return keep
+
+    ga, got = _capture(blocks)
+    gb, _keep = _capture(steps)
+    ga.replay()
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in got]
+    bad = []
+
+    def check(it):
+        for k, (a, b) in enumerate(zip(got, ref)):
+            if not torch.equal(a, b):
+                bad.append((it, k, float((a - b).abs().max())))
+
+    _replay_beside(ga, gb, ROUNDS, check)
+    assert not bad, ("classifier features formed beside the fused training step differ from the ones formed alone "
+                     "(round, tensor, max deviation):", bad[:10])

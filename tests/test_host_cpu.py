@@ -178,34 +178,36 @@ def test_pointnet2_blocks_match_the_reference_modules(cpu_mirrors):
     run_pointnet2_blocks(torch.device("cpu"), pins, 2e-5)
 
 
-def test_sampler_kernels_hold_no_packed_fp32_instruction():
-    """csrc/fps.hip is compiled without SLP vectorisation: packed-FP32 instructions in the sampler's distance update
-    computed with the wrong half of a register pair now and then when MFMA kernels shared the device (DESIGN.md section
-    4c) -- wrong FPS picks for ~2 % of the clouds, invisible to every isolated test.  The device code of every sampler
-    kernel must hold none."""
+def test_no_kernel_holds_packed_fp32_instructions_made_by_the_vectoriser():
+    """The library is compiled without SLP vectorisation: packed-FP32 instructions the vectoriser made (v_pk_*_f32 with
+    op_sel on register pairs) computed wrongly now and then when OTHER MFMA kernels shared the device -- wrong FPS picks
+    for ~2 % of the clouds, width-generic features off by 0.1-0.3 -- invisible to every isolated test (DESIGN.md section
+    4c).  Disassembly of every translation unit: none anywhere, except csrc/pointwise.hip's explicitly two-wide arithmetic
+    (no operand selection) and the diagnostic probe in csrc/capi.hip."""
     import glob
     import shutil
     import subprocess
     import tempfile
     from adaptpoint_amd import build
-    assert "-fno-slp-vectorize" in build.FILE_FLAGS.get("fps.hip", [])
-    obj = os.path.join(build.OBJ, "fps.o")
-    if not os.path.exists(obj):
-        build.build()
+    assert "-fno-slp-vectorize" in build.CXXFLAGS
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("llvm-objdump not available")
+    if not os.path.exists(os.path.join(build.OBJ, "fps.o")):
+        build.build()
+    found = {}
     with tempfile.TemporaryDirectory() as tmp:
-        local = os.path.join(tmp, "fps.o")
-        shutil.copy(obj, local)
-        subprocess.run([objdump, "--offloading", local], cwd=tmp, check=True, capture_output=True)
-        cos = [f for f in glob.glob(os.path.join(tmp, "fps.o.*gfx950*"))]
-        assert cos, "no gfx950 code object in fps.o"
-        text = subprocess.run([objdump, "-d", cos[0]], check=True, capture_output=True, text=True).stdout
-    kernel, hits = None, {}
-    for line in text.splitlines():
-        if line.endswith(">:") and "<" in line:
-            kernel = line.split("<")[1].split(">")[0]
-        elif kernel and "fps_" in kernel and "v_pk_" in line and "_f32" in line:
-            hits[kernel] = hits.get(kernel, 0) + 1
-    assert not hits, ("packed-FP32 instructions in sampler kernels:", hits)
+        for obj in sorted(glob.glob(os.path.join(build.OBJ, "*.o"))):
+            local = os.path.join(tmp, os.path.basename(obj))
+            shutil.copy(obj, local)
+            subprocess.run([objdump, "--offloading", local], cwd=tmp, check=True, capture_output=True)
+            cos = glob.glob(local + ".*gfx950*")
+            if not cos:
+                continue
+            text = subprocess.run([objdump, "-d", cos[0]], check=True, capture_output=True, text=True).stdout
+            lines = [l for l in text.splitlines() if "v_pk_" in l and "_f32" in l]
+            if lines:
+                found[os.path.basename(obj)] = (len(lines), sum("op_sel" in l for l in lines))
+    allowed = {"pointwise.o": lambda n, sel: sel == 0, "capi.o": lambda n, sel: n <= 2}
+    bad = {k: v for k, v in found.items() if not (k in allowed and allowed[k](*v))}
+    assert not bad, ("packed-FP32 instructions (count, with op_sel) in:", bad)
