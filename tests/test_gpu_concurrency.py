@@ -177,3 +177,63 @@ def test_feature_kernels_beside_other_feature_kernels_are_bit_exact(dev):
     _replay_beside(ga, gb, ROUNDS, check)
     assert not bad, ("classifier features formed beside the fused training step differ from the ones formed alone "
                      "(round, tensor, max deviation):", bad[:10])
+
+
+def test_generator_forward_beside_the_fused_training_step_is_bit_exact(dev):
+    """The AdaptPoint generator's forward pass (per-point contraction kernels with their explicitly two-wide arithmetic,
+    grouper, attention, deformation kernels; training-mode BatchNorm from fixed-order folds: deterministic) replayed beside
+    the fused set-abstraction training step on another stream: the augmented clouds and the imitator's outputs must be the
+    bits they are alone."""
+    from adaptpoint_amd.augmentor import AdaptPointAugmentor, draw_noise_on
+    from adaptpoint_amd.pointnext import fill_parameters_by_name
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    B = 32
+    pos = torch.from_numpy(GI.unit_sphere_cloud(B, 1024, seed=902)).to(dev)
+    G = fill_parameters_by_name(AdaptPointAugmentor(fused=True)).to(dev).train()
+    noise = draw_noise_on(dev, B, 1024, G.num_anchor)
+    taps = {}
+    sac = G.predict_prob_layer
+    hooks = [sac.embedding.register_forward_hook(lambda m, i, o: taps.__setitem__("embedding", o.detach())),
+             sac.head.register_forward_hook(lambda m, i, o: taps.__setitem__("head", o.detach()))]
+    for i in range(4):
+        hooks.append(sac.decode_list[i].register_forward_hook(lambda m, i_, o, k=i: taps.__setitem__(f"decode{k}", o.detach())))
+
+    def generator():
+        with torch.no_grad():
+            out = G(pos, noise)[1]
+        return [out] + [taps[k] for k in sorted(taps)]
+
+    torch.manual_seed(0)
+    sa = SetAbstraction(32, 64, layers=2, stride=2, fused=True,
+                        group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                        norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+                        use_res=True).to(dev).train()
+    f = torch.randn(B, 32, 1024, device=dev)
+    smp1 = sa.sample(pos)
+
+    def steps():
+        keep = []
+        for _ in range(16):
+            fi = f.clone().requires_grad_(True)
+            _, out = sa([pos, fi], sampling=smp1)
+            out.sum().backward()
+            keep.append(fi.grad)
+        return keep
+
+    ga, got = _capture(generator)
+    gb, _keep = _capture(steps)
+    for h in hooks:
+        h.remove()
+    ga.replay()
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in got]
+    bad = []
+
+    def check(it):
+        for k, (a, b) in enumerate(zip(got, ref)):
+            if not torch.equal(a, b):
+                bad.append((it, k, float((a - b).abs().max())))
+
+    _replay_beside(ga, gb, ROUNDS, check)
+    assert not bad, ("the generator's results formed beside the fused training step differ from the ones formed alone "
+                     "(round, tensor, max deviation):", bad[:10])
