@@ -3,7 +3,9 @@
     python -m adaptpoint_amd.build [--force] [--asm]
 
 Every translation unit is compiled with -ffp-contract=off: the kernels pin
-their float rounding with explicit fma builtins (csrc/apn_common.h).
+their float rounding with explicit fma builtins (csrc/apn_common.h) -- and
+with -fno-slp-vectorize: see the note at CXXFLAGS below (a correctness flag,
+not a tuning one).
 """
 import argparse
 import os

@@ -572,9 +572,9 @@ static apn::FpsOrder fps_order(int n) {
 // compiler's SLP vectoriser had turned the distance update into packed-FP32 instructions (v_pk_add_f32 ... v[0:1]
 // op_sel_hi:[1,0], the pair's other half being a live running minimum), and those intermittently computed with the
 // wrong half when MFMA kernels shared the SIMDs.  Every build of the step WITHOUT packed FP32 passes the checks that
-// caught it (bench.py's verification of the index sets, tests/test_gpu_concurrency.py), so this translation unit is
-// compiled with -fno-slp-vectorize (adaptpoint_amd/build.py, FILE_FLAGS) and tests/test_host_cpu.py asserts that the
-// sampler kernels hold no v_pk_ instruction.  APN_FPS_RECORDS=1 (read once) selects the per-wave-record step, which
+// caught it (bench.py's verification of the index sets, tests/test_gpu_concurrency.py), so the library is compiled with
+// -fno-slp-vectorize (adaptpoint_amd/build.py: the width-generic block had the same problem) and tests/test_host_cpu.py
+// asserts that no kernel holds a vectoriser-made v_pk_*_f32 instruction.  APN_FPS_RECORDS=1 (read once) selects the per-wave-record step, which
 // never had them (its centre lives in SGPRs).
 static int fps_default_algo() {
     static const int algo = [] { const char *e = getenv("APN_FPS_RECORDS"); return (e && atoi(e) == 1) ? 1 : 0; }();
