@@ -237,3 +237,67 @@ def test_generator_forward_beside_the_fused_training_step_is_bit_exact(dev):
     _replay_beside(ga, gb, ROUNDS, check)
     assert not bad, ("the generator's results formed beside the fused training step differ from the ones formed alone "
                      "(round, tensor, max deviation):", bad[:10])
+
+
+def test_classifier_training_pass_beside_the_fused_training_step_is_bit_exact(dev, monkeypatch):
+    """Forward AND backward of the PointNeXt-S classifier in training mode with `fused.DETERMINISTIC` (no order-dependent
+    sum anywhere: stage 1 fixed-point, stages 2-4 the width-generic family, per-point layers fixed-order folds) beside
+    the fused set-abstraction training step on another stream: logits and every parameter gradient equal the bits they
+    have alone."""
+    from adaptpoint_amd import fused
+    from adaptpoint_amd.pointnext import PointNextSClassifier, fill_parameters_by_name
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    monkeypatch.setattr(fused, "DETERMINISTIC", True)
+    B = 16
+    pos = torch.from_numpy(GI.unit_sphere_cloud(B, 1024, seed=903)).to(dev)
+    pts = torch.cat([pos, pos[:, :, 1:2]], -1).transpose(1, 2).contiguous()
+    gt = (torch.arange(B, device=dev) % 15)
+    C = fill_parameters_by_name(PointNextSClassifier(fused=True)).to(dev).train()
+    for m in C.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    params = [q for q in C.parameters() if q.requires_grad]
+
+    def train_pass():
+        for q in params:
+            q.grad = None
+        logits, loss = C.get_logits_loss({'pos': pos, 'x': pts}, gt)
+        loss.backward()
+        return [logits.detach()] + [q.grad for q in params]
+
+    torch.manual_seed(0)
+    sa = SetAbstraction(32, 64, layers=2, stride=2, fused=True,
+                        group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                        norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+                        use_res=True).to(dev).train()
+    pos32 = torch.from_numpy(GI.unit_sphere_cloud(32, 1024, seed=904)).to(dev)
+    f = torch.randn(32, 32, 1024, device=dev)
+    smp1 = sa.sample(pos32)
+
+    def steps():
+        keep = []
+        for _ in range(24):
+            fi = f.clone().requires_grad_(True)
+            _, out = sa([pos32, fi], sampling=smp1)
+            out.sum().backward()
+            keep.append(fi.grad)
+        return keep
+
+    ga, got = _capture(train_pass)
+    gb, _keep = _capture(steps)
+    ga.replay()
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in got]
+    ga.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, ref)), "the pass is not bit-reproducible even alone"
+    bad = []
+
+    def check(it):
+        for k, (a, b) in enumerate(zip(got, ref)):
+            if not torch.equal(a, b):
+                bad.append((it, k, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))))
+
+    _replay_beside(ga, gb, ROUNDS, check)
+    assert not bad, ("the classifier's training pass formed beside the fused training step differs from the one formed "
+                     "alone (round, tensor, relative deviation):", bad[:10])
