@@ -63,7 +63,7 @@ if [ "$what" = models ]; then
     python $R/scripts/bench_gan_step.py --mode fused --graph --overlap --stamps 2>/dev/null > $O/${T}_gan_step_stamps_two_lanes.txt
     python $R/scripts/bench_gan_step.py --mode fused --graph --stamps 2>/dev/null > $O/${T}_gan_step_stamps_single_stream.txt
     python $R/scripts/fps_batch_probe.py 2>/dev/null > $O/${T}_fps_batch_probe.txt
-    APN_FPS_LDS_ATOMIC=1 python $R/scripts/fps_batch_probe.py 2>/dev/null > $O/${T}_fps_batch_probe_lds_atomic.txt
+    APN_FPS_RECORDS=1 python $R/scripts/fps_batch_probe.py 2>/dev/null > $O/${T}_fps_batch_probe_records.txt
     python $R/scripts/bench_wide.py 2>/dev/null | grep '^{' > $O/${T}_wide_kernels.jsonl
     python $R/scripts/bench_pointwise.py 2>/dev/null | grep '^{' > $O/${T}_pointwise_layers.jsonl
     rocprofv3 --kernel-trace --output-format csv -d $O/prof_pn -o pn -- python $R/scripts/bench_pointnext.py --fused --graph --steps 12 --warmup 6 > $O/prof_pn.log 2>&1

@@ -12,7 +12,6 @@ inconsistent with the instruction stream: below what this kernel's source can ex
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["APN_FPS_LDS_ATOMIC"] = "1"
 import numpy as np
 import torch
 import golden_inputs as GI
