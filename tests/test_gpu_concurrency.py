@@ -301,3 +301,59 @@ def test_classifier_training_pass_beside_the_fused_training_step_is_bit_exact(de
     _replay_beside(ga, gb, ROUNDS, check)
     assert not bad, ("the classifier's training pass formed beside the fused training step differs from the one formed "
                      "alone (round, tensor, relative deviation):", bad[:10])
+
+
+def test_discriminator_training_pass_beside_the_fused_training_step_is_bit_exact(dev):
+    """The discriminator's forward + backward (batched spectral normalisation, per-point contraction layers, the pooled
+    last layer with its ballot-compaction gradient: all fixed-order) beside the fused set-abstraction training step."""
+    from adaptpoint_amd.discriminator import PointDiscriminator1
+    from adaptpoint_amd.pointnext import fill_parameters_by_name
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    B = 32
+    pos = torch.from_numpy(GI.unit_sphere_cloud(B, 1024, seed=905)).to(dev)
+    D = fill_parameters_by_name(PointDiscriminator1(num_classes=15, fused=True)).to(dev).eval()   # (eval: no power iteration, no dropout: the same state every replay)
+    params = [q for q in D.parameters() if q.requires_grad]
+
+    def d_pass():
+        for q in params:
+            q.grad = None
+        x = pos.clone().requires_grad_(True)
+        y = D(x)
+        y.sum().backward()
+        return [y.detach(), x.grad] + [q.grad for q in params]
+
+    torch.manual_seed(0)
+    sa = SetAbstraction(32, 64, layers=2, stride=2, fused=True,
+                        group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                        norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+                        use_res=True).to(dev).train()
+    f = torch.randn(B, 32, 1024, device=dev)
+    smp1 = sa.sample(pos)
+
+    def steps():
+        keep = []
+        for _ in range(12):
+            fi = f.clone().requires_grad_(True)
+            _, out = sa([pos, fi], sampling=smp1)
+            out.sum().backward()
+            keep.append(fi.grad)
+        return keep
+
+    ga, got = _capture(d_pass)
+    gb, _keep = _capture(steps)
+    ga.replay()
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in got]
+    ga.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, ref)), "the pass is not bit-reproducible even alone"
+    bad = []
+
+    def check(it):
+        for k, (a, b) in enumerate(zip(got, ref)):
+            if not torch.equal(a, b):
+                bad.append((it, k, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))))
+
+    _replay_beside(ga, gb, ROUNDS, check)
+    assert not bad, ("the discriminator's pass formed beside the fused training step differs from the one formed alone "
+                     "(round, tensor, relative deviation):", bad[:10])
