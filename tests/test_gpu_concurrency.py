@@ -357,3 +357,65 @@ def test_discriminator_training_pass_beside_the_fused_training_step_is_bit_exact
     _replay_beside(ga, gb, ROUNDS, check)
     assert not bad, ("the discriminator's pass formed beside the fused training step differs from the one formed alone "
                      "(round, tensor, relative deviation):", bad[:10])
+
+
+def test_fused_training_step_beside_the_classifier_blocks_is_bit_exact(dev, monkeypatch):
+    """The headline block itself (register-resident kernels, `fused.DETERMINISTIC`: every sum order-independent) as the
+    one under test: its outputs and gradients beside the eval-mode classifier's blocks (width-generic MFMA kernels) on
+    another stream equal the bits they have alone."""
+    from adaptpoint_amd import fused
+    from adaptpoint_amd.pointnext import PointNextSClassifier, fill_parameters_by_name
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    monkeypatch.setattr(fused, "DETERMINISTIC", True)
+    B = 32
+    pos = torch.from_numpy(GI.unit_sphere_cloud(B, 1024, seed=906)).to(dev)
+    pts = torch.cat([pos, pos[:, :, 1:2]], -1).transpose(1, 2).contiguous()
+    C = fill_parameters_by_name(PointNextSClassifier(fused=True)).to(dev).eval()
+    torch.manual_seed(0)
+    sa = SetAbstraction(32, 64, layers=2, stride=2, fused=True,
+                        group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                        norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+                        use_res=True).to(dev).train()
+    params = [q for q in sa.parameters() if q.requires_grad]
+    f = torch.randn(B, 32, 1024, device=dev)
+    smp1 = sa.sample(pos)
+
+    def step():
+        res = []
+        for _ in range(4):
+            for q in params:
+                q.grad = None
+            fi = f.clone().requires_grad_(True)
+            _, out = sa([pos, fi], sampling=smp1)
+            out.sum().backward()
+            res += [out.detach(), fi.grad] + [q.grad for q in params]
+        return res
+
+    def blocks():
+        keep = []
+        with torch.no_grad():
+            for _ in range(3):
+                p0, f0 = pos, pts
+                for stage in C.encoder.encoder:
+                    p0, f0 = stage[0]([p0, f0])
+                keep.append(f0)
+        return keep
+
+    ga, got = _capture(step)
+    gb, _keep = _capture(blocks)
+    ga.replay()
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in got]
+    ga.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, ref)), "the step is not bit-reproducible even alone"
+    bad = []
+
+    def check(it):
+        for k, (a, b) in enumerate(zip(got, ref)):
+            if not torch.equal(a, b):
+                bad.append((it, k, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))))
+
+    _replay_beside(ga, gb, ROUNDS, check)
+    assert not bad, ("the fused step formed beside the classifier's blocks differs from the one formed alone "
+                     "(round, tensor, relative deviation):", bad[:10])
