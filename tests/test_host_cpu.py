@@ -211,3 +211,19 @@ def test_no_kernel_holds_packed_fp32_instructions_made_by_the_vectoriser():
     allowed = {"pointwise.o": lambda n, sel: sel == 0, "capi.o": lambda n, sel: n <= 2}
     bad = {k: v for k, v in found.items() if not (k in allowed and allowed[k](*v))}
     assert not bad, ("packed-FP32 instructions (count, with op_sel) in:", bad)
+
+
+def test_profiles_index_names_every_round3_file():
+    """profiles/README.md says for each committed round-3 measurement which command made it and what it backs."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "profiles", "README.md")).read()
+    named = set(re.findall(r"r03_[A-Za-z0-9_]+", text))
+    missing = []
+    for f in sorted(os.listdir(os.path.join(root, "profiles"))):
+        if not f.startswith("r03_"):
+            continue
+        stem = f.split(".")[0]
+        if not any(stem == n or stem.startswith(n) for n in named):
+            missing.append(f)
+    assert not missing, missing
