@@ -7,7 +7,14 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# APN_LIB_PATH selects another build of the library for A/B measurements and the diagnostic variants of
+# scripts/asm_variants.py -- instead of overwriting the shipped file -- and only together with APN_ALLOW_UNSAFE_LIB=1.
 LIB_PATH = os.path.join(_HERE, "libadaptpoint_amd.so")
+if os.environ.get("APN_LIB_PATH"):
+    if os.environ.get("APN_ALLOW_UNSAFE_LIB") != "1":
+        raise RuntimeError("APN_LIB_PATH is for diagnostic builds: set APN_ALLOW_UNSAFE_LIB=1 with it")
+    LIB_PATH = os.path.abspath(os.environ["APN_LIB_PATH"])
+REQUIRED_BUILD_FLAGS = ("-ffp-contract=off", "-fno-slp-vectorize")
 
 _c_int, _c_float, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _c_double = ctypes.c_double
@@ -38,7 +45,7 @@ SIGNATURES = {
     "apn_zero_fill": [_c_void_p, _c_longlong, _c_void_p],
     "apn_debug_stamp": [_c_void_p, _c_int, _c_void_p],
     "apn_debug_vgpr_hold": [_c_int, _c_int, _c_void_p, _c_void_p],
-    "apn_debug_vpk_probe": [_c_int, _c_int, _c_void_p, _c_void_p],
+    "apn_debug_vpk_probe": [_c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "apn_sa_geo_dd_doubles": [_c_int],
     "apn_sa_point_geo": [_c_int] * 4 + [_c_float] + [_c_void_p] * 6,
     "apn_sa_prep_rows": [_c_int] * 2,
@@ -159,6 +166,14 @@ def load():
         fn.restype = _c_int
     lib.apn_error_string.argtypes = [_c_int]
     lib.apn_error_string.restype = ctypes.c_char_p
+    lib.apn_build_flags.argtypes = []
+    lib.apn_build_flags.restype = ctypes.c_char_p
+    # a build without the two correctness flags gives wrong results beside other streams' kernels: refuse it
+    flags = lib.apn_build_flags().decode("utf-8", "replace").split()
+    missing = [f for f in REQUIRED_BUILD_FLAGS if f not in flags]
+    if missing and os.environ.get("APN_ALLOW_UNSAFE_LIB") != "1":
+        raise ExtensionMissing(f"{LIB_PATH} was built without {missing} (its flags: {' '.join(flags)}): rebuild with "
+                               "`python -m adaptpoint_amd.build --force`")
     _lib = lib
     return lib
 

@@ -23,6 +23,10 @@ HEADERS = ["apn_common.h", "apn_mfma.h", "sa_chain.h", "ball_query_body.h",
            os.path.join("..", "..", "include", "adaptpoint_amd.h")]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
             "-fvisibility=hidden", "-Wall", "-Wno-unused-command-line-argument"] + os.environ.get("APN_EXTRA_CXXFLAGS", "").split()
+# flags the correctness of the library rests on: a later flag that switches one of them back is refused here, and the
+# library carries its flag line (apn_build_flags) so that adaptpoint_amd/_lib.py can refuse a build made without them
+REQUIRED_FLAGS = ("-ffp-contract=off", "-fno-slp-vectorize")
+FORBIDDEN_FLAGS = ("-fslp-vectorize", "-ffp-contract=fast", "-ffp-contract=on", "-ffast-math", "-Ofast")
 
 
 # -fno-slp-vectorize, for every translation unit: NO packed-FP32 instructions made by the compiler's SLP vectoriser
@@ -50,7 +54,27 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+def flag_line(src):
+    return " ".join([*CXXFLAGS, *FILE_FLAGS.get(os.path.basename(src), [])])
+
+
+def check_flags():
+    bad = [f for f in CXXFLAGS if f in FORBIDDEN_FLAGS] + [f for f in REQUIRED_FLAGS if f not in CXXFLAGS]
+    if bad:
+        raise RuntimeError(f"adaptpoint_amd.build: flag set refused ({bad}): the library's results depend on "
+                           f"{REQUIRED_FLAGS} (DESIGN.md section 4c); diagnostic builds go through scripts/asm_variants.py")
+
+
+def _same_flags(obj, src):
+    """An object is stale when the flags it was compiled with differ from today's (recorded next to it)."""
+    try:
+        return open(obj + ".flags").read() == flag_line(src)
+    except OSError:
+        return False
+
+
 def build(force=False, asm=False, verbose=False):
+    check_flags()
     os.makedirs(OBJ, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -59,9 +83,12 @@ def build(force=False, asm=False, verbose=False):
     for src in srcs:
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if not force and _newer(obj, [src] + hdrs + [os.path.abspath(__file__)]):
+        if not force and _newer(obj, [src] + hdrs + [os.path.abspath(__file__)]) and _same_flags(obj, src):
             continue
-        cmd = [hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+        if os.path.exists(obj + ".flags"):
+            os.remove(obj + ".flags")
+        stamp = ["-DAPN_BUILD_FLAGS=\"" + flag_line(src) + "\""] if os.path.basename(src) == "capi.hip" else []
+        cmd = [hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, *FILE_FLAGS.get(os.path.basename(src), []), *stamp, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
@@ -72,6 +99,8 @@ def build(force=False, asm=False, verbose=False):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+        with open(os.path.join(OBJ, os.path.basename(src)[:-4] + ".o.flags"), "w") as fh:
+            fh.write(flag_line(src))
     if force or procs or not _newer(LIB, objs):
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
         if verbose:

@@ -3,6 +3,13 @@
 
 extern "C" int apn_version(void) { return 100; /* 0.1.0 */ }
 
+// The compiler flags this library was built with (adaptpoint_amd/build.py stamps them in): the loader refuses a build
+// without -fno-slp-vectorize / -ffp-contract=off, the two flags the results depend on.
+#ifndef APN_BUILD_FLAGS
+#define APN_BUILD_FLAGS "unknown"
+#endif
+extern "C" const char *apn_build_flags(void) { return APN_BUILD_FLAGS; }
+
 extern "C" const char *apn_error_string(int code) {
     if (code == APN_OK) return "success";
     if (code == APN_EINVAL) return "invalid argument (negative size, null pointer or size beyond the launch limits)";
@@ -67,6 +74,10 @@ extern "C" int apn_debug_vgpr_hold(int blocks, int turns, unsigned long long *ba
 // (the other half used), bad[2] = low half wrong, bad[3] = results checked.
 namespace apn {
 typedef float vpk_f2 __attribute__((ext_vector_type(2)));
+// FORM 0: `op_sel_hi:[1,0]` -- the pair's LOW register feeds both lanes (round 3's suspect; 1.6e11 results, no error).
+// FORM 1: `op_sel:[0,1]` -- the pair's HIGH register feeds both lanes: the form round 4's instruction-by-instruction edits of
+// the vectorised builds blame (profiles/r04_packed_fp32_op_sel.md); the operand is moved into the HIGH half, the low half live.
+template <int FORM>
 __global__ __launch_bounds__(256) void vpk_probe_kernel(int turns, unsigned long long *bad) {
     __shared__ unsigned long long slot[4];
     const unsigned lane = threadIdx.x;
@@ -88,12 +99,22 @@ __global__ __launch_bounds__(256) void vpk_probe_kernel(int turns, unsigned long
         float lo = 0.0f, hi = other;
         asm volatile("" : "+v"(hi));
         asm volatile("v_mov_b32 %0, %1" : "=v"(lo) : "v"(c));
-        pair = (vpk_f2){lo, hi};
-        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(pair));
+        if (FORM == 0) {
+            pair = (vpk_f2){lo, hi};
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(pair));
+        } else {
+            pair = (vpk_f2){hi, lo};
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(pair));
+        }
         const float want_lo = a0 - cw, want_hi = a1 - cw;
         if (e.x != cw + 1.0f || e.y != cw + 2.0f) ++wrong_lo;     // (the read itself)
-        if (d.y != want_hi) { ++wrong_hi; if (d.y == a1 - hi) ++other_half; }
-        if (d.x != want_lo) ++wrong_lo;
+        if (FORM == 0) {
+            if (d.y != want_hi) { ++wrong_hi; if (d.y == a1 - hi) ++other_half; }
+            if (d.x != want_lo) ++wrong_lo;
+        } else {                                                  // (here the LOW lane is the one that crosses halves)
+            if (d.x != want_lo) { ++wrong_hi; if (d.x == a0 - hi) ++other_half; }
+            if (d.y != want_hi) ++wrong_lo;
+        }
         ++seen;
         if ((t & 7) == 0) {                                    // the FPS step's rhythm: an LDS atomic and a barrier now and then
             if ((lane & 63) == (unsigned)(t & 63)) atomicMax(&slot[t & 3], (unsigned long long)t);
@@ -107,8 +128,11 @@ __global__ __launch_bounds__(256) void vpk_probe_kernel(int turns, unsigned long
 }
 }  // namespace apn
 
-extern "C" int apn_debug_vpk_probe(int blocks, int turns, unsigned long long *bad, void *stream) {
-    if (blocks <= 0 || turns < 0 || !bad) return APN_EINVAL;
-    hipLaunchKernelGGL(apn::vpk_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, turns, bad);
+extern "C" int apn_debug_vpk_probe(int blocks, int turns, int form, unsigned long long *bad, void *stream) {
+    if (blocks <= 0 || turns < 0 || !bad || (form != 0 && form != 1)) return APN_EINVAL;
+    if (form == 0)
+        hipLaunchKernelGGL(apn::vpk_probe_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, turns, bad);
+    else
+        hipLaunchKernelGGL(apn::vpk_probe_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, turns, bad);
     return (int)hipGetLastError();
 }

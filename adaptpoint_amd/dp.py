@@ -140,8 +140,11 @@ def allreduce_mean_(tensors):
 # semantics are torch.nn.SyncBatchNorm's: dL/dx uses the global sums; dL/dgamma, dL/dbeta stay
 # rank-local and are averaged with the other parameters' gradients.
 # ---------------------------------------------------------------------------------------------
+FORCE_COLLECTIVES = False      # testing hook: issue the statistics all-reduces at world size 1 too (one-GPU RCCL runs)
+
+
 def _sum_over_ranks_(t):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES):
         dist.all_reduce(t)
     return t
 

@@ -134,7 +134,8 @@ def _world(sync):
 
 def _allreduce_sum_(t):
     """In-place sum over ranks (the one collective of the SyncBatchNorm exchange; a seam for tests)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    # (FORCE_PHASED: the collective is issued at world size 1 too, so that a one-GPU box runs the RCCL call itself)
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_PHASED):
         dist.all_reduce(t)
 
 

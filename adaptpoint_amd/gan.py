@@ -72,7 +72,9 @@ class ClassifierStep:
         self.opt = optimizer or torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
 
     def __call__(self, points, target, choice=None):
-        """points (B,N,C>=in_channels), target (B,) -> (logits, loss)."""
+        """points (B,N,C>=in_channels), target (B,) -> (logits, loss), both detached: a caller that keeps them must not
+        keep this step's autograd graph alive with them (its AccumulateGrad nodes would belong to THIS step's stream; a
+        later capture of the step then synchronises with that stream and dies inside hipStreamEndCapture -- graphs.py)."""
         self.model.train()
         pos, x = resample(points, self.npoints, self.in_channels, choice)
         logits, loss = self.model.get_logits_loss({'pos': pos, 'x': x}, target)
@@ -83,7 +85,7 @@ class ClassifierStep:
             nn.utils.clip_grad_norm_(self.model.parameters(), self.clip, norm_type=2)
         self.opt.step()
         self.model.zero_grad()
-        return logits, loss
+        return logits.detach(), loss.detach()
 
 
 class _frozen:
@@ -103,17 +105,15 @@ class _frozen:
             q.requires_grad_(True)
 
 
-def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=True, frozen=False, pyramid=None,
-                  loss_real=None):
+def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=True, frozen=False, loss_real=None):
     """ganloss_cls.py:31-65: how much harder the augmented clouds are than the real ones for the
     CURRENT classifier, pulled towards `hard_ratio`: |1 - exp(L(fake) - hard_ratio * L(real))|.
     The classifier runs in eval mode (running BatchNorm statistics, no dropout), so every cloud
     is processed independently of its batch: `batched` stacks fake and real into ONE 2B pass
     (their FPS chains then run side by side) with the same result per cloud.
     `real` / `fake`: dicts with 'pos' (B,N,3) and 'x' (B,C,N).  frozen: only the inputs receive gradients (what
-    the generator step needs).  pyramid (batched only): the encoder's `index_pyramid` of cat([fake, real]) positions,
-    computed ahead.  loss_real: the real clouds' loss computed ahead (`real_loss_ahead`); only the fake clouds then
-    pass through the classifier here."""
+    the generator step needs).  loss_real: the real clouds' loss computed ahead (`real_loss_ahead`); only the fake
+    clouds then pass through the classifier here."""
     classifier.eval()
     if loss_real is not None:
         with (_frozen(classifier) if frozen else contextlib.nullcontext()):
@@ -122,7 +122,7 @@ def feedback_loss(classifier, criterion, real, fake, label, hard_ratio, batched=
     with (_frozen(classifier) if frozen else contextlib.nullcontext()):
         if batched:
             both = classifier({'pos': torch.cat([fake['pos'], real['pos']], 0),
-                               'x': torch.cat([fake['x'], real['x']], 0)}, **({} if pyramid is None else {'pyramid': pyramid}))
+                               'x': torch.cat([fake['x'], real['x']], 0)})
             pred_fake, pred_real = both.chunk(2, 0)
         else:
             pred_fake = classifier(fake)
@@ -176,11 +176,10 @@ class GanStep:
         # overlap: the step runs as TWO lanes -- the caller's stream and one side stream forked from and joined to it, so
         # that a capture of the step holds them as parallel branches (a replayed hipGraph runs two branches
         # concurrently on this stack; a third one waits: scripts/experiment_graph_branches.py):
-        #   generator forward    lane 1: the imitator's feature path            lane 2: its index plan (FPS chain, ball
-        #                        (stages, decoders, masking branch)                      queries, three_nn, kNN), then
-        #                                                                               the anchor head
-        #   after it             lane 1: the feedback pass (index pyramid,      lane 2: D(gen), then the discriminator's
-        #                        2B classifier forward)                                  own step (two forwards, backward)
+        #   generator forward    lane 1: the imitator's feature path            lane 2: the real clouds' classifier pass,
+        #                        (stages, decoders, masking branch)                      then the anchor head
+        #   after it             lane 1: the feedback pass (classifier          lane 2: D(gen), then the discriminator's
+        #                        forward on the generated clouds)                        own step (two forwards, backward)
         #   backward             autograd runs a node on its forward's stream: the same split, mirrored
         # Same arithmetic in the same order per tensor: the discriminator's power-iteration state is advanced by
         # D(gen), D(real), D(gen.detach()) in that order on either schedule, its weights change after the generator's
@@ -223,7 +222,10 @@ class GanStep:
         mark("step: start")
         overlap = bool(self.overlap) and points.is_cuda
         parts = self.overlap if isinstance(self.overlap, (set, frozenset)) else self.OVERLAP_PARTS
-        loss_real = real = None
+        if not set(parts) <= set(self.OVERLAP_PARTS):
+            raise ValueError(f"GanStep(overlap=...): parts must be among {sorted(self.OVERLAP_PARTS)} (the experimental "
+                             "'plan' / 'pyramid' / 'real_sync' schedules live in scripts/, not in the library)")
+        loss_real = real = s_real = None
         if self.feedback_ratio > 0:
             real = {'pos': xyz, 'x': points[:, :, :self.in_channels].transpose(1, 2).contiguous()}
         if overlap and real is not None and "real" in parts:
@@ -233,22 +235,18 @@ class GanStep:
             with torch.cuda.stream(s_real):
                 loss_real = real_loss_ahead(self.C, self.criterion, real, label)
                 mark("real clouds' classifier pass done (second lane)")
-            if "real_sync" in parts:
-                graphs.join(s_real, loss_real)
-        with graphs.overlapping(overlap and ("plan" if "plan" in parts else "imitator" in parts)):
+            joins_before = graphs.joins(s_real)
+        with graphs.overlapping(overlap and "imitator" in parts):
             _, gen = G(xyz) if noise is None else G(xyz, noise)
+        if s_real is not None and graphs.joins(s_real) == joins_before:
+            # nobody joined the lane meanwhile (the imitator forks and joins it only when its coordinates need no gradient
+            # and "imitator" is among the parts): the main stream reads loss_real below, so it joins the lane HERE, while
+            # the real clouds' pass is still the lane's tail -- before the discriminator chain is queued behind it
+            graphs.join(s_real, loss_real)
         mark("generator forward done")
         mark_grad(gen, "backward: dL/d(generated clouds) formed (feedback + D backward done)")
-        pyramid = None
         if overlap:
             dev = points.device
-            if "pyramid" in parts and self.feedback_ratio > 0 and self.batched_feedback:
-                # (experiment: a third branch -- measured slower, two branches at a time is what a replayed graph runs
-                # concurrently on this stack; scripts/experiment_graph_branches.py)
-                s_idx = graphs.fork("lane3", dev, gen, xyz)
-                with torch.cuda.stream(s_idx):
-                    pyramid = self.C.encoder.index_pyramid(torch.cat([gen.detach(), xyz], 0))
-                    mark("feedback index pyramid done (side stream)")
             # the discriminator's three forwards, in the reference's order, on the second lane: D(gen) for the generator's
             # loss (its backward then runs there too, beside the feedback pass's), then the discriminator's own step;
             # the first lane meanwhile runs the feedback pass (index pyramid, 2B classifier forward)
@@ -259,8 +257,6 @@ class GanStep:
                 mark("D(gen) forward done (second lane)")
                 d_loss = self._discriminator_losses(xyz, gen, real_t, fake_t)
                 mark("discriminator losses + backward done (second lane)")
-            if pyramid is not None:
-                graphs.join(s_idx)
         else:
             # (the discriminator's weights are frozen inside this forward: the generator step needs dL/d(gen) only, so its
             # backward launches none of D's weight-gradient kernels -- and no gradient accumulator of D lives on this stream)
@@ -271,10 +267,8 @@ class GanStep:
         if self.feedback_ratio > 0:
             tail = points[:, :, 3:self.in_channels]
             fake = {'pos': gen, 'x': torch.cat([gen, tail], -1).transpose(1, 2).contiguous()}
-            if loss_real is not None and not ("imitator" in parts):
-                graphs.join(s_real, loss_real)      # (with the imitator's head on the lane the generator joined it already)
             fb, _, _ = feedback_loss(self.C, self.criterion, real, fake, label, self.hard_ratio,
-                                     self.batched_feedback, frozen=True, pyramid=pyramid, loss_real=loss_real)
+                                     self.batched_feedback, frozen=True, loss_real=loss_real)
             mark("feedback forward done")
             if overlap:
                 graphs.join(s_dis, g_raw, d_loss)

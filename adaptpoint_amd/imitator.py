@@ -142,74 +142,36 @@ class SAComponent(nn.Module):
         masking = torch.cat([masking_local, masking_global.repeat(1, 1, N)], dim=1)
         return pointwise.conv_then_bn(masking, self.fuse_masking, allow=on).permute(0, 2, 1)
 
-    @torch.no_grad()
-    def index_plan(self, x, a_points):
-        """Everything in the forward pass that is a function of the COORDINATES alone, in the order the feature path
-        asks for it: per stage the grouper's (FPS picks, sampled points, ball-query neighbours), then per decoder the
-        three nearest coarse points and their weights (behind the anchor head's nearest neighbours).  Each part comes with
-        an event recorded behind it: `forward` runs the plan on a side stream and waits part by part."""
-        plan = {"stages": [], "nearest": [], "knn": None}
-        xyz, xyz_list = x.contiguous(), [x.contiguous()]
-        for i in range(self.stages):
-            part = self.pointset_grouper_list[i].index(xyz)
-            plan["stages"].append((part, graphs.ready_event()))
-            xyz = part[1]
-            xyz_list.append(xyz)
-        plan["knn"] = (knn_point(self.head.keighbors, xyz, a_points), graphs.ready_event())
-        for i in range(self.stages):
-            dist, nearest = three_nn(xyz_list[-(i + 2)], xyz_list[-(i + 1)])
-            plan["nearest"].append(((nearest, inverse_distance_weights(dist)), graphs.ready_event()))
-        return plan
-
     def forward(self, x, a_index=None, return_logits=False):
         """x (B,N,3), a_index (B,M) anchor indices -> prob (B,M,9), masking (B,N,2) one-hot.
 
         Under `graphs.overlapping()` (and for coordinates that need no gradient) the step's independent parts run as
-        a second lane (ONE side stream): first the index plan, consumed part by part through its events, then the anchor
-        head -- which reads the last stage's output, not the decoders' -- beside the decoders and the masking branch; the
-        backward pass inherits the split."""
+        a second lane (ONE side stream): the anchor head -- which reads the last stage's output, not the decoders' --
+        beside the decoders and the masking branch; the backward pass inherits the split."""
         a_points = index_points(x, a_index)
         xyz = x
         dev = x.device
         overlap = graphs.overlap_enabled() and x.is_cuda and not x.requires_grad
-        plan = None
-        if overlap and graphs.overlap_enabled() == "plan":
-            # (experiment, off by default: the same lane re-forked from the main stream after the main stream has waited
-            # for events inside it crashed hipGraph capture; on a lane of its own it is a third branch)
-            s_idx = graphs.fork("lane3", dev, x, a_points)
-            with torch.cuda.stream(s_idx):
-                plan = self.index_plan(x, a_points)
         f = self.embedding(x.permute(0, 2, 1).contiguous())
         mark("imitator: embedding done")
         mark_grad(f, "backward: embedding output gradient formed")
         xyz_list, x_list = [xyz], [f]
         for i in range(self.stages):
             f = self.extract_feat_list[i](f)
-            part = None
-            if plan is not None:
-                part, ev = plan["stages"][i]
-                graphs.wait_ready(ev, *part)
-            xyz, f = self.pointset_grouper_list[i](xyz, pointwise.transpose12(f), index=part)
+            xyz, f = self.pointset_grouper_list[i](xyz, pointwise.transpose12(f))
             xyz_list.append(xyz)
             x_list.append(f)
             mark(f"imitator: stage {i + 1} done")
             mark_grad(f, f"backward: imitator stage {i + 1} output gradient formed")
         idx_knn = None
         if overlap:
-            s_head = graphs.fork(graphs.LANE2, dev, a_points, f, xyz)       # (the same lane: behind the index plan)
+            s_head = graphs.fork(graphs.LANE2, dev, a_points, f, xyz)
             with torch.cuda.stream(s_head):
-                if plan is not None:
-                    idx_knn, ev = plan["knn"]
-                    graphs.wait_ready(ev, idx_knn)
                 prob = self.head(a_points=a_points, sa_x=f.permute(0, 2, 1), sa_xyz=xyz, xyz_raw=x, idx_knn=idx_knn)
                 mark("imitator: anchor head done (side stream)")
         for i in range(self.stages):
-            near = None
-            if plan is not None:
-                near, ev = plan["nearest"][i]
-                graphs.wait_ready(ev, *near)
             x_list[-(i + 2)] = self.decode_list[i](xyz1=xyz_list[-(i + 2)], xyz2=xyz_list[-(i + 1)],
-                                                   points1=x_list[-(i + 2)], points2=x_list[-(i + 1)], nearest=near)
+                                                   points1=x_list[-(i + 2)], points2=x_list[-(i + 1)])
         mark("imitator: decoders done")
         mark_grad(x_list[0], "backward: decoders' output gradient formed (masking branch done)")
         if not overlap:
@@ -220,8 +182,6 @@ class SAComponent(nn.Module):
         mark("imitator: masking logits done")
         if overlap:
             graphs.join(s_head, prob)
-            if plan is not None:
-                graphs.join(s_idx)
         if return_logits:
             return prob, logits
         return prob, self.hard_mask(logits)

@@ -395,27 +395,26 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
             r.graph_nodes = {}
             for cur in ((0, 1) if pipelined else (0,)):
                 clear_grads()
-                g = graphs.new_graph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local" if distributed else "global"):
+
+                def mlp_capture():
                     if capture_collectives:
                         for i in range(spg):          # every step: fwd + bwd (+ statistics exchanges) + gradient all-reduce
                             mlp_steps(1, cur, first=i)
                             dp.allreduce_mean_([q.grad for q in params if q.grad is not None])
                     else:
                         mlp_steps(spg, cur)
-                # a memset node (PyTorch's zero fills and multi-block reductions lower to one) writes garbage from the
-                # second replay on, or aborts the process, on this stack: found HERE, before any replay, it only
-                # costs the graph (the except below falls back to eager execution)
-                r.graph_nodes["mlp"] = graphs.assert_replayable(g, "the MLP steps' graph")
+                # graphs.capture: no autograd graph of an earlier step may be alive (a crash inside hipStreamEndCapture
+                # otherwise), and a memset node (PyTorch's zero fills and multi-block reductions lower to one) writes
+                # garbage from the second replay on, or aborts the process, on this stack: found HERE, before any replay,
+                # either only costs the graph (the except below falls back to eager execution)
+                g, _, r.graph_nodes["mlp"] = graphs.capture(mlp_capture, leaves=params + fs, what="the MLP steps' graph",
+                                                            capture_error_mode="thread_local" if distributed else "global")
                 mlp_graphs[cur] = g
                 # each capture owns its gradient tensors; a replay refreshes them in place
                 graph_grads[cur] = [q.grad for q in params if q.grad is not None]
                 if pipelined:
-                    g = graphs.new_graph()
-                    with torch.cuda.graph(g):
-                        index_steps(spg, cur)
-                    r.graph_nodes["index"] = graphs.assert_replayable(g, "the index stages' graph")
-                    index_graphs[cur] = g
+                    index_graphs[cur], _, r.graph_nodes["index"] = graphs.capture(lambda: index_steps(spg, cur),
+                                                                                  what="the index stages' graph")
 
             def step():
                 cur = cur_set[0]
@@ -514,13 +513,92 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
     return r
 
 
+def workload_main(args, dev, world, rank, distributed):
+    """--workload classifier | gan | adaptpoint: BASELINE configs[2] / [3] / [4] per GPU (B=32 clouds each), the same
+    contract as the block: W warm-up steps, K timed steps between barrier + synchronize fences, MAX over ranks, one
+    JSON line.  Under torch.distributed the networks are wrapped as the reference wraps them
+    (adaptpoint_amd/workloads.py); the SAFE launch structure (the step run eagerly around its collectives) is measured
+    FIRST, the captured one (collectives inside the hipGraph, thread-local capture) after it; `value` is the captured
+    figure when the capture succeeds, else the eager one."""
+    from adaptpoint_amd import dp, graphs, workloads
+    from adaptpoint_amd import set_abstraction as _sa
+    steps = args.steps if args.steps is not None else 40
+    warmup = args.warmup if args.warmup is not None else 5
+    job = workloads.build(args.workload, dev, batch=B_PER_GPU, npoints=args.points, fused=True, distributed=distributed,
+                          capturable=True, overlap=(args.overlap == "on"), seed=args.seed)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up off the default stream (optimizer state, autotuning)
+        for _ in range(3):
+            job.step()
+        coll = workloads.collectives_per_step(job) if distributed else {}
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        el_eager = dp.timed_steps(job.step, steps, warmup, dev)
+    value_eager = B_PER_GPU * world * steps / el_eager
+    launch, value, elapsed, nodes, last = "eager", value_eager, el_eager, None, None
+    if args.graph != "off":
+        try:
+            torch.cuda.synchronize()
+            if distributed:
+                dist.barrier()
+                torch.cuda.synchronize()
+            for q in job.parameters():
+                q.grad = None
+            g, last, nodes = graphs.capture(job.step, leaves=job.parameters(), what=f"the {args.workload} step's graph",
+                                            capture_error_mode="thread_local" if distributed else "global")
+            elapsed = dp.timed_steps(g.replay, steps, warmup, dev)
+            value = B_PER_GPU * world * steps / elapsed
+            launch = "hipGraph replay" + (", collectives captured" if distributed else "")
+        except Exception as exc:                      # capture is an optimisation, never a requirement
+            print(f"[bench] hipGraph capture of the {args.workload} step failed ({type(exc).__name__}: {exc}); "
+                  "reporting the eager figure", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+    names = {"classifier": "PointNeXt-S classifier training step (fwd + SmoothCE + bwd + clip + AdamW), BASELINE configs[2]",
+             "gan": "AdaptPoint joint step: generator (Deformation + Mask controllers) + discriminator + feedback through the "
+                    "eval-mode classifier, two Adam steps, BASELINE configs[3]",
+             "adaptpoint": "PointNeXt-S + AdaptPoint end-to-end training step: one train_gan iteration, then one classifier "
+                           "iteration on the generated clouds (train_autoaug.py:368-394), BASELINE configs[4] per GPU"}
+    result = {
+        "metric": f"{args.workload} training-step point-clouds/sec (B={B_PER_GPU}/GPU, N={args.points})",
+        "value": round(value, 2), "unit": "point-clouds/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "value_eager_collectives" if distributed else "value_eager": round(value_eager, 2),
+        "config": {"workload": names[args.workload] + f", B={B_PER_GPU}/GPU N={args.points}, random 15-class labels, "
+                               "random-init weights", "global_batch": B_PER_GPU * world, "launch": launch,
+                   "graph_nodes": nodes, "two_lane_joint_step": args.overlap == "on" and args.workload != "classifier",
+                   "fused_fallbacks": sum(_sa.FUSED_FALLBACKS.values()),
+                   "syncbn": job.syncbn,
+                   "collectives_per_step": coll or None,
+                   "parallelism": f"dp{world}" + (("+syncbn(classifier)" if job.syncbn else "") + "+flat-allreduce per network: "
+                                                  f"{coll.get('all_reduce', 0)} all-reduces, {coll.get('bytes', 0)} B per step"
+                                                  if distributed else "")},
+        "roofline": None, "cpu_baseline": None,
+        "losses": None if last is None else {k: round(float(v), 5) for k, v in last.items() if v is not None and v.dim() == 0},
+    }
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: a timed region of ~0.4 s (2000 steps of ~0.19 ms); 200 steps (40 ms) sat inside the clock ramp-up and
-    # moved by 5 % from run to run
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    # moved by 5 % from run to run (the other workloads: 40 steps of 2.5-10 ms, 5 warm-up)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["block", "classifier", "gan", "adaptpoint"], default="block",
+                    help="block (default, the metric): one set-abstraction block fwd+bwd, BASELINE configs[1].  classifier / gan "
+                         "/ adaptpoint: the training steps of configs[2] / [3] / [4] (per GPU B=32), wrapped for data "
+                         "parallelism as the reference wraps them when launched through torch.distributed.run")
+    ap.add_argument("--points", type=int, default=1024, help="points per cloud of the training-step workloads")
+    ap.add_argument("--overlap", choices=["on", "off"], default="on",
+                    help="training-step workloads: the joint step as two lanes of one captured graph (GanStep(overlap=True))")
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed blocks of --steps steps each (median reported; 0 = auto: 25 when --steps < 400, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -569,6 +647,9 @@ def main():
                          "hi+lo operands (fp32-grade, default) or plain bf16 operands, or the unfused "
                          "drop-in path (nine extension ops + PyTorch conv/BN in fp32)")
     args = ap.parse_args()
+    if args.workload == "block":
+        args.steps = 2000 if args.steps is None else args.steps
+        args.warmup = 200 if args.warmup is None else args.warmup
 
     from adaptpoint_amd import dp
     world, rank, local_rank = dp.env_world()
@@ -595,6 +676,9 @@ def main():
     if force_dist:
         from adaptpoint_amd import fused as _fused
         _fused.FORCE_PHASED = True
+        dp.FORCE_COLLECTIVES = True
+    if args.workload != "block":
+        return workload_main(args, dev, world, rank, distributed)
 
     if args.kernels == "wide":
         from adaptpoint_amd import set_abstraction as _sa_mod

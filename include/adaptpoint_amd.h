@@ -45,6 +45,12 @@ APN_API int apn_version(void);
 /* Text for a return code of any function below (static storage). */
 APN_API const char *apn_error_string(int code);
 
+/* The compiler flag line the library was built with (static storage).  No reference counterpart: the
+ * reference's setup.py (openpoints/cpp/pointnet2_batch/setup.py) fixes its nvcc flags; here two flags are
+ * part of correctness (-ffp-contract=off pins the float rounding of every distance, -fno-slp-vectorize
+ * keeps compiler-made packed-FP32 out), and the loader checks for them. */
+APN_API const char *apn_build_flags(void);
+
 /* Replaces furthest_point_sampling_wrapper (pointnet2_api.cpp:18,
  * sampling.cpp:39-48 -> sampling_gpu.cu:101-260).
  *   xyz  (B,N,3) in; temp (B,N) in/out, pre-filled by the caller (1e10,
@@ -163,10 +169,12 @@ APN_API int apn_debug_stamp(void *stamps, int slot, void *stream);
  * check them: bad[i] (i < 24) = lanes whose i-th value changed, bad[24 .. 31] samples (index << 32 | value found).
  * bad: 32 unsigned 64-bit words, zeroed by the caller.  (Does register state survive beside other kernels?) */
 APN_API int apn_debug_vgpr_hold(int blocks, int turns, unsigned long long *bad, void *stream);
-/* Diagnostic: the packed-FP32 instruction form that returned wrong FPS picks beside MFMA kernels, checked result by result:
- * bad[0] high halves wrong, bad[1] of those computed with the pair's OTHER half, bad[2] low halves wrong, bad[3] results
- * checked.  bad: 4 unsigned 64-bit words, zeroed by the caller. */
-APN_API int apn_debug_vpk_probe(int blocks, int turns, unsigned long long *bad, void *stream);
+/* Diagnostic: a packed-FP32 instruction with operand selection, checked result by result beside whatever else runs.
+ * form 0: v_pk_add_f32 ... op_sel_hi:[1,0] (a pair's LOW register feeds both lanes); form 1: ... op_sel:[0,1] (its HIGH
+ * register feeds both lanes: the form blamed in profiles/r04_packed_fp32_op_sel.md).  bad[0] results of the lane that
+ * crosses halves wrong, bad[1] of those computed with the pair's OTHER register, bad[2] other results wrong, bad[3]
+ * results checked.  bad: 4 unsigned 64-bit words, zeroed by the caller. */
+APN_API int apn_debug_vpk_probe(int blocks, int turns, int form, unsigned long long *bad, void *stream);
 
 /* `precision` (every function that takes ft): 1 = operands rounded to bf16; 2 = operands split
  * into hi + lo bf16 parts, each product three MFMAs (hi*hi + hi*lo + lo*hi, "bf16x3"): fp32-grade

@@ -52,7 +52,7 @@ def main():
                     help="GanStep(overlap=True): the feedback pass's index pyramid and the discriminator's own step on "
                          "side streams (parallel branches of the captured graph)")
     ap.add_argument("--overlap-parts", default="",
-                    help="comma-separated subset of imitator,real,pyramid (experiments; default: imitator,real)")
+                    help="comma-separated subset of imitator,real (default: both)")
     ap.add_argument("--stamps", action="store_true",
                     help="capture device wall-clock stamps at the step's phase boundaries (adaptpoint_amd.graphs."
                          "PhaseStamps) and print them after the run")
@@ -83,10 +83,9 @@ def main():
             from adaptpoint_amd import graphs as apn_graphs
             if a.stamps:
                 apn_graphs.STAMPS = apn_graphs.PhaseStamps(dev)
-            graph = apn_graphs.new_graph()
-            with torch.cuda.graph(graph):
-                captured = step(points, label, device_noise=True)
-            apn_graphs.assert_replayable(graph, "the joint step's graph")     # no memset nodes (adaptpoint_amd/graphs.py)
+            # (no memset nodes, no autograd graph of an earlier step alive: adaptpoint_amd/graphs.py)
+            graph, captured, _ = apn_graphs.capture(lambda: step(points, label, device_noise=True), what="the joint step's graph",
+                                                    leaves=[q for net in (G, D, C) for q in net.parameters()])
             run = graph.replay
         torch.cuda.reset_peak_memory_stats()
         sec = timed(run, a.iters, a.warmup)

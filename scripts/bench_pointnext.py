@@ -56,7 +56,7 @@ def main():
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10, norm_type=2)     # train_autoaug.py:505-508
         opt.step()
-        return loss
+        return loss.detach()
 
     if a.graph:
         side = torch.cuda.Stream()
@@ -69,18 +69,14 @@ def main():
         graphs, losses, igraphs = {}, {}, {}
         for cur in ((0, 1) if a.pipeline else (0,)):
             from adaptpoint_amd import graphs as apn_graphs
-            g = apn_graphs.new_graph()
             opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(g):
-                losses[cur] = step(cur)
-            apn_graphs.assert_replayable(g, "the classifier step's graph")       # no memset nodes (adaptpoint_amd/graphs.py)
+            # (no memset nodes, no autograd graph of an earlier step alive: adaptpoint_amd/graphs.py)
+            g, losses[cur], _ = apn_graphs.capture(lambda: step(cur).detach(), leaves=list(model.parameters()),
+                                                   what="the classifier step's graph")
             graphs[cur] = g
             if a.pipeline:
-                g = apn_graphs.new_graph()
-                with torch.cuda.graph(g):
-                    model.encoder.index_pyramid(pos, out=pyr[cur])
-                apn_graphs.assert_replayable(g, "the index pyramid's graph")
-                igraphs[cur] = g
+                igraphs[cur], _, _ = apn_graphs.capture(lambda: model.encoder.index_pyramid(pos, out=pyr[cur]),
+                                                        what="the index pyramid's graph")
         state = {"cur": 0}
         index_stream = torch.cuda.Stream()
         main_done, index_done = torch.cuda.Event(), torch.cuda.Event()

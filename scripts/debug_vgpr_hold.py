@@ -16,12 +16,16 @@ pts = torch.cat([pos, pos[:, :, 1:2]], -1).transpose(1, 2).contiguous()
 C = fill_parameters_by_name(PointNextSClassifier(fused=True)).to(dev).eval()
 bad = torch.zeros(32, dtype=torch.int64, device=dev)
 turns = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 600
-VPK = "vpk" in sys.argv          # the packed-FP32 probe instead of the register-hold kernel
+VPK = "vpk" in sys.argv or "vpk1" in sys.argv    # the packed-FP32 probe instead of the register-hold kernel
+FORM = 1 if "vpk1" in sys.argv else 0           # vpk1: the op_sel:[0,1] form (a pair's high register feeds both lanes)
 
 
 def hold():
     for _ in range(6):
-        _call("apn_debug_vpk_probe" if VPK else "apn_debug_vgpr_hold", dev, 640, turns * (20 if VPK else 1), bad.data_ptr())
+        if VPK:
+            _call("apn_debug_vpk_probe", dev, 640, turns * 20, FORM, bad.data_ptr())
+        else:
+            _call("apn_debug_vgpr_hold", dev, 640, turns, bad.data_ptr())
 
 
 def feature_work():

@@ -59,10 +59,7 @@ def main():
     restore()
     dist.barrier()
     torch.cuda.synchronize()
-    g = graphs.new_graph()
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-        step()
-    census = graphs.assert_replayable(g, "the SyncBatchNorm step with its collectives")
+    g, _, census = graphs.capture(step, what="the SyncBatchNorm step with its collectives", capture_error_mode="thread_local")
     g.replay()
     torch.cuda.synchronize()
     captured = grads()

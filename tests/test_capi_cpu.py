@@ -70,6 +70,27 @@ def test_version_and_error_strings(lib):
     assert b"invalid" in lib.apn_error_string(-1)
 
 
+def test_library_carries_its_flag_line_and_the_loader_checks_it(lib, monkeypatch):
+    """a library built with the vectoriser back on (or contraction on) must not load silently.  build.py
+    stamps the flag line into the library, refuses flag sets that undo the two correctness flags, treats an object whose
+    recorded flags differ from today's as stale; _lib.load() refuses a library whose line lacks them."""
+    from adaptpoint_amd import _lib, build as apn_build
+    lib.apn_build_flags.restype = ctypes.c_char_p
+    flags = lib.apn_build_flags().decode().split()
+    assert "-fno-slp-vectorize" in flags and "-ffp-contract=off" in flags and "-O3" in flags
+    assert _lib.REQUIRED_BUILD_FLAGS == apn_build.REQUIRED_FLAGS
+    obj = os.path.join(apn_build.OBJ, "fps.o")
+    assert apn_build._same_flags(obj, os.path.join(apn_build.CSRC, "fps.hip"))
+    monkeypatch.setattr(apn_build, "CXXFLAGS", apn_build.CXXFLAGS + ["-DAPN_SOMETHING_ELSE"])
+    assert not apn_build._same_flags(obj, os.path.join(apn_build.CSRC, "fps.hip"))       # changed flags: stale object
+    monkeypatch.setattr(apn_build, "CXXFLAGS", apn_build.CXXFLAGS + ["-fslp-vectorize"])
+    with pytest.raises(RuntimeError, match="refused"):
+        apn_build.build()
+    monkeypatch.setattr(apn_build, "CXXFLAGS", [f for f in apn_build.CXXFLAGS if "slp" not in f])
+    with pytest.raises(RuntimeError, match="refused"):
+        apn_build.check_flags()
+
+
 def test_argument_validation_needs_no_gpu(lib):
     """Bad sizes are rejected before any HIP call; zero sizes are no-ops."""
     f = lib.apn_furthest_point_sampling

@@ -378,14 +378,17 @@ def test_wide_block_replays_identically_from_a_hipgraph(dev, cin, N, M, radius):
             fb()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        out = fb()
+    from adaptpoint_amd import graphs
+    # (the captured output is kept DETACHED: holding the captured autograd graph would keep its AccumulateGrad nodes, made
+    # on the capture stream, alive into the eager run below -- PyTorch warns about exactly that, and under a later capture
+    # the same mistake is a crash: graphs.capture checks for it)
+    g, out, _ = graphs.capture(lambda: fb().detach(), leaves=[f] + params, what="the width-generic block")
     res = []
     for _ in range(3):
         g.replay()
         torch.cuda.synchronize()
-        res.append([out.detach().clone(), f.grad.clone()] + [q.grad.clone() for q in params])
+        res.append([out.clone(), f.grad.clone()] + [q.grad.clone() for q in params])
+    assert not graphs.held_accumulators([f] + params)
     ref = [fb().detach().clone(), f.grad.clone()] + [q.grad.clone() for q in params]
     for r in res:
         for a, b in zip(r, ref):

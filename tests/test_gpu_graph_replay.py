@@ -179,11 +179,10 @@ def test_joint_step_replayed_from_a_hipgraph_equals_eager(dev, overlap):
         _restore(mods, opts, snap)
     gc.collect()
     from adaptpoint_amd import graphs
-    graph = graphs.new_graph()
     load(STEPS)
-    with torch.cuda.graph(graph):
-        captured = step(points, label, noise=noise)
-    print("joint step graph:", graphs.assert_replayable(graph, "the joint step's graph"))
+    graph, captured, census = graphs.capture(lambda: step(points, label, noise=noise), what="the joint step's graph",
+                                             leaves=[q for m in mods for q in m.parameters()])
+    print("joint step graph:", census)
     _restore(mods, opts, snap)                           # (capture runs nothing; make the state explicit anyway)
     replayed = []
     for i in range(STEPS):
@@ -247,11 +246,10 @@ def test_classifier_step_replayed_from_a_hipgraph_equals_eager(dev, monkeypatch)
     _restore((C,), (opt,), snap)
     gc.collect()
     from adaptpoint_amd import graphs
-    graph = graphs.new_graph()
     load(STEPS)
-    with torch.cuda.graph(graph):
-        _, cap_loss = step(points, target, choice=choice)
-    print("classifier step graph:", graphs.assert_replayable(graph, "the classifier step's graph"))
+    graph, (_, cap_loss), census = graphs.capture(lambda: step(points, target, choice=choice), leaves=list(C.parameters()),
+                                                  what="the classifier step's graph")
+    print("classifier step graph:", census)
     _restore((C,), (opt,), snap)
     replayed = []
     for i in range(STEPS):
@@ -308,3 +306,77 @@ def test_memset_nodes_are_found_before_the_first_replay(dev):
                 g.replay()
             torch.cuda.synchronize()
             assert int(buf[0]) == 1
+
+
+def test_capture_refuses_an_autograd_graph_kept_alive_instead_of_crashing(dev):
+    """Round 3's first capture crash (a host segfault inside hipStreamEndCapture: gpurun_out/tnew.log, tc.log): a tensor
+    with a grad_fn from an EARLIER eager step kept alive across the capture.  graphs.capture finds the live graph from
+    the leaves' accumulator nodes and raises before capturing; with the tensor dropped the same capture goes through."""
+    from adaptpoint_amd import graphs
+    lin = torch.nn.Linear(64, 64).to(dev)
+    x = torch.randn(32, 64, device=dev, requires_grad=True)
+
+    def step():
+        x.grad = None
+        lin.zero_grad(set_to_none=True)
+        loss = lin(x).square().sum()
+        loss.backward()
+        return loss
+    kept = step()                                   # eager, on the default stream -- and its graph stays alive through `kept`
+    torch.cuda.synchronize()
+    leaves = [x] + list(lin.parameters())
+    with pytest.raises(graphs.StaleAutogradGraph, match="earlier step"):
+        graphs.capture(lambda: step().detach(), leaves=leaves, what="a step captured beside a kept loss")
+    assert not torch.cuda.is_current_stream_capturing()
+    kept = kept.detach()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g, out, census = graphs.capture(lambda: step().detach(), leaves=leaves, what="the same step")
+    g.replay()
+    torch.cuda.synchronize()
+    assert census.get("memset", 0) == 0 and torch.isfinite(out) and abs(float(out) - float(kept)) <= 1e-3 * abs(float(kept))
+
+
+def test_fork_refuses_the_lane_topology_that_crashed_capture(dev):
+    """Round 3's second capture crash (gpurun_out/wg2.log): a lane forked again from the main stream after the main
+    stream waited for an event recorded INSIDE that lane, in one capture.  graphs.fork raises LaneTopology at the second
+    fork (a Python error before the runtime sees the topology); eagerly -- where the topology is harmless -- it runs;
+    fork / join by wait_stream alone captures and replays."""
+    from adaptpoint_amd import graphs
+    a = torch.ones(1 << 16, device=dev)
+    b = torch.zeros(1 << 16, device=dev)
+
+    def lanes(mid_wait):
+        s = graphs.fork("test-lane", dev, a)
+        with torch.cuda.stream(s):
+            b.add_(a)
+            ev = graphs.ready_event()
+            b.add_(a)
+        if mid_wait:
+            graphs.wait_ready(ev, b)
+        graphs.join(s, b)                            # (everything joined: the capture below can end cleanly)
+        s = graphs.fork("test-lane", dev, a)         # <- refused under capture after a mid-lane wait
+        with torch.cuda.stream(s):
+            b.add_(a)
+        graphs.join(s, b)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        lanes(True)                                  # eager: allowed
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert float(b[0]) == 3.0
+    with pytest.raises(graphs.LaneTopology, match="forked again"):
+        graphs.capture(lambda: lanes(True), what="a lane re-forked after a mid-lane wait")
+    assert not torch.cuda.is_current_stream_capturing()
+    torch.cuda.synchronize()
+    b.zero_()
+    g, _, census = graphs.capture(lambda: lanes(False), what="fork / join by wait_stream only")
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(b[0]) == 6.0 and census["kernel"] == 3

@@ -227,3 +227,40 @@ def test_profiles_index_names_every_round3_file():
         if not any(stem == n or stem.startswith(n) for n in named):
             missing.append(f)
     assert not missing, missing
+
+
+def test_held_accumulators_finds_autograd_graphs_kept_alive():
+    """graphs.held_accumulators: the check behind graphs.capture's StaleAutogradGraph (an autograd graph of an earlier step
+    kept alive across a capture ends the capture with a host segfault on the GPU stack; here the detection itself, which
+    is device-independent)."""
+    from adaptpoint_amd import graphs
+    lin = torch.nn.Linear(4, 3)
+    x = torch.randn(5, 4, requires_grad=True)
+    leaves = [x] + list(lin.parameters()) + [torch.randn(2)]            # (the last one needs no gradient: never reported)
+    assert graphs.held_accumulators(leaves) == []
+    loss = lin(x).sum()
+    assert graphs.held_accumulators(leaves) == [0, 1, 2]                # the live graph holds all three accumulators
+    loss.backward()
+    assert graphs.held_accumulators(leaves) == [0, 1, 2]                # backward frees buffers, not nodes
+    kept = loss.detach()
+    del loss
+    assert graphs.held_accumulators(leaves) == [] and float(kept) == float(kept)
+    logits = lin(x.detach())                                            # a graph that reaches the weights only
+    assert graphs.held_accumulators(leaves) == [1, 2]
+    del logits
+    assert graphs.held_accumulators(leaves) == []
+    assert graphs.held_accumulators(leaves) == []                       # (the probe leaves nothing behind)
+
+
+def test_classifier_step_returns_tensors_without_a_graph(cpu_mirrors):
+    """ClassifierStep hands back detached logits / loss: keeping them cannot keep the step's autograd graph alive."""
+    from adaptpoint_amd import graphs
+    from adaptpoint_amd.gan import ClassifierStep
+    from adaptpoint_amd.pointnext import PointNextSClassifier, fill_parameters_by_name
+    import golden_inputs as GI
+    C = fill_parameters_by_name(PointNextSClassifier())
+    pos = torch.from_numpy(GI.unit_sphere_cloud(2, 256, seed=3))
+    points = torch.cat([pos, pos[:, :, 1:2]], -1)
+    logits, loss = ClassifierStep(C, npoints=256)(points, torch.tensor([1, 2]))
+    assert logits.grad_fn is None and loss.grad_fn is None
+    assert graphs.held_accumulators(list(C.parameters())) == []
