@@ -29,13 +29,14 @@ REQUIRED_FLAGS = ("-ffp-contract=off", "-fno-slp-vectorize")
 FORBIDDEN_FLAGS = ("-fslp-vectorize", "-ffp-contract=fast", "-ffp-contract=on", "-ffast-math", "-Ofast")
 
 
-# -fno-slp-vectorize, for every translation unit: NO packed-FP32 instructions made by the compiler's SLP vectoriser
-# (v_pk_add / mul / fma_f32 with op_sel on VGPR pairs).  With them two different kernels returned wrong results whenever
-# OTHER MFMA-heavy kernels shared the device -- never alone: the FPS step (wrong picks for ~2 % of the clouds beside the
-# benches' MLP stream; rounds 1-3) and the width-generic block (features off by 0.1-0.3 beside the fused training step) --
-# and every build without them passes the same checks (bench.py's verification, tests/test_gpu_concurrency.py); DESIGN.md
-# section 4c.  It costs nothing measurable (headline 278.6 k against 279.3 k clouds/s).  The explicitly two-wide
-# arithmetic of csrc/pointwise.hip (vector types, no operand selection) stays.
+# -fno-slp-vectorize, for every translation unit: the SLP vectoriser makes packed-FP32 instructions with operand selection,
+# and ONE such form -- v_pk_{add,mul,fma}_f32 with an `op_sel` bit on a VGPR-pair source (the low lane reads the pair's high
+# register) -- computes that lane as if the operand were 0.0, now and then, while another stream's MFMA kernels are resident
+# (never alone).  Pinned in round 4 by editing the failing builds instruction by instruction and by a synthetic probe:
+# profiles/r04_packed_fp32_op_sel.md, DESIGN.md section 4c.  With the form present: wrong FPS picks for ~2 % of the clouds
+# beside the benches' MLP stream (rounds 1-3), width-generic features off by 0.1-0.3 beside the fused training step.  The flag
+# costs nothing measurable (headline 278.6 k against 279.3 k clouds/s).  csrc/pointwise.hip's explicitly two-wide arithmetic
+# (vector types, no operand selection: the form that never failed) stays; tests/test_host_cpu.py disassembles every unit.
 NO_SLP = ["-fno-slp-vectorize"]
 FILE_FLAGS = {}
 

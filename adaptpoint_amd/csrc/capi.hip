@@ -102,9 +102,12 @@ __global__ __launch_bounds__(256) void vpk_probe_kernel(int turns, unsigned long
         if (FORM == 0) {
             pair = (vpk_f2){lo, hi};
             asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(pair));
-        } else {
+        } else if (FORM == 1) {
             pair = (vpk_f2){hi, lo};
             asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(pair));
+        } else {                                                  // FORM 2: form 1 behind eight idle cycles
+            pair = (vpk_f2){hi, lo};
+            asm volatile("s_nop 7\n\tv_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(pair));
         }
         const float want_lo = a0 - cw, want_hi = a1 - cw;
         if (e.x != cw + 1.0f || e.y != cw + 2.0f) ++wrong_lo;     // (the read itself)
@@ -112,7 +115,18 @@ __global__ __launch_bounds__(256) void vpk_probe_kernel(int turns, unsigned long
             if (d.y != want_hi) { ++wrong_hi; if (d.y == a1 - hi) ++other_half; }
             if (d.x != want_lo) ++wrong_lo;
         } else {                                                  // (here the LOW lane is the one that crosses halves)
-            if (d.x != want_lo) { ++wrong_hi; if (d.x == a0 - hi) ++other_half; }
+            if (d.x != want_lo) {
+                if (wrong_hi == 0) {                              // a few samples: {turn, block, lane}, {found, wanted}, {operand, other}
+                    const unsigned long long k = atomicAdd(&bad[7], 1ull);
+                    if (k < 8) {
+                        bad[8 + 3 * k] = ((unsigned long long)t << 32) | (blockIdx.x << 8) | lane;
+                        bad[9 + 3 * k] = ((unsigned long long)__float_as_uint(d.x) << 32) | __float_as_uint(want_lo);
+                        bad[10 + 3 * k] = ((unsigned long long)__float_as_uint(c) << 32) | __float_as_uint(d.y);
+                    }
+                }
+                ++wrong_hi;
+                if (d.x == a0 - hi) ++other_half;
+            }
             if (d.y != want_hi) ++wrong_lo;
         }
         ++seen;
@@ -129,10 +143,12 @@ __global__ __launch_bounds__(256) void vpk_probe_kernel(int turns, unsigned long
 }  // namespace apn
 
 extern "C" int apn_debug_vpk_probe(int blocks, int turns, int form, unsigned long long *bad, void *stream) {
-    if (blocks <= 0 || turns < 0 || !bad || (form != 0 && form != 1)) return APN_EINVAL;
+    if (blocks <= 0 || turns < 0 || !bad || form < 0 || form > 2) return APN_EINVAL;
     if (form == 0)
         hipLaunchKernelGGL(apn::vpk_probe_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, turns, bad);
-    else
+    else if (form == 1)
         hipLaunchKernelGGL(apn::vpk_probe_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, turns, bad);
+    else
+        hipLaunchKernelGGL(apn::vpk_probe_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, turns, bad);
     return (int)hipGetLastError();
 }

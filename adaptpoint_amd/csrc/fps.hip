@@ -566,16 +566,17 @@ static apn::FpsOrder fps_order(int n) {
 }
 
 // Which step the operator entries run: the LDS-atomic step (algo 0; 314 against 370 ns per step at 1024 points).
-// History worth keeping: BESIDE MFMA-heavy kernels (the benches' index stream next to the MLP
-// stream, two lanes of a captured training step) this step returned wrong picks for ~2 % of the clouds -- one spurious
-// arg-max per affected cloud -- while every isolated test was bit-exact.  The cause was not in this file's logic: the
-// compiler's SLP vectoriser had turned the distance update into packed-FP32 instructions (v_pk_add_f32 ... v[0:1]
-// op_sel_hi:[1,0], the pair's other half being a live running minimum), and those intermittently computed with the
-// wrong half when MFMA kernels shared the SIMDs.  Every build of the step WITHOUT packed FP32 passes the checks that
-// caught it (bench.py's verification of the index sets, tests/test_gpu_concurrency.py), so the library is compiled with
-// -fno-slp-vectorize (adaptpoint_amd/build.py: the width-generic block had the same problem) and tests/test_host_cpu.py
-// asserts that no kernel holds a vectoriser-made v_pk_*_f32 instruction.  APN_FPS_RECORDS=1 (read once) selects the per-wave-record step, which
-// never had them (its centre lives in SGPRs).
+// History worth keeping (profiles/r04_packed_fp32_op_sel.md): BESIDE MFMA-heavy kernels (the benches'
+// index stream next to the MLP stream, two lanes of a captured training step) this step returned wrong picks for ~2 % of the
+// clouds -- one spurious arg-max per affected cloud -- while every isolated test was bit-exact.  The cause was not in this
+// file's logic: the compiler's SLP vectoriser had turned the distance update into packed-FP32 instructions, among them
+// `v_pk_add_f32 v[6:7], v[12:13], v[6:7] op_sel:[0,1]` (py[0..1] - y1 with the centre's y in the pair's HIGH register), and
+// that form -- an op_sel bit on a VGPR pair -- intermittently computes its low lane as `py[0] - 0` while another stream's MFMA
+// kernels are resident.  (Round 3 suspected the z update's `op_sel_hi:[1,0]` form; round 4 edited the failing build
+// instruction by instruction: with only the 132 op_sel forms of this file replaced by scalar pairs it passes, with only the
+// 642 op_sel_hi forms replaced it fails; a synthetic probe reproduces it.)  The library is compiled with -fno-slp-vectorize
+// (adaptpoint_amd/build.py) and tests/test_host_cpu.py asserts that no kernel holds the form.
+// APN_FPS_RECORDS=1 (read once) selects the per-wave-record step, which never had packed instructions (its centre lives in SGPRs).
 static int fps_default_algo() {
     static const int algo = [] { const char *e = getenv("APN_FPS_RECORDS"); return (e && atoi(e) == 1) ? 1 : 0; }();
     return algo;

@@ -171,9 +171,11 @@ APN_API int apn_debug_stamp(void *stamps, int slot, void *stream);
 APN_API int apn_debug_vgpr_hold(int blocks, int turns, unsigned long long *bad, void *stream);
 /* Diagnostic: a packed-FP32 instruction with operand selection, checked result by result beside whatever else runs.
  * form 0: v_pk_add_f32 ... op_sel_hi:[1,0] (a pair's LOW register feeds both lanes); form 1: ... op_sel:[0,1] (its HIGH
- * register feeds both lanes: the form blamed in profiles/r04_packed_fp32_op_sel.md).  bad[0] results of the lane that
- * crosses halves wrong, bad[1] of those computed with the pair's OTHER register, bad[2] other results wrong, bad[3]
- * results checked.  bad: 4 unsigned 64-bit words, zeroed by the caller. */
+ * register feeds both lanes: the form blamed in profiles/r04_packed_fp32_op_sel.md); form 2: form 1 behind `s_nop 7`.
+ * bad[0] results of the lane that crosses halves wrong, bad[1] of those computed with the pair's OTHER register, bad[2]
+ * other results wrong, bad[3] results checked, bad[7] samples taken, bad[8 + 3k ..] sample k (k < 8): {turn << 32 | block
+ * << 8 | lane}, {found << 32 | wanted}, {operand << 32 | the other lane's result}.  bad: 32 unsigned 64-bit words,
+ * zeroed by the caller. */
 APN_API int apn_debug_vpk_probe(int blocks, int turns, int form, unsigned long long *bad, void *stream);
 
 /* `precision` (every function that takes ft): 1 = operands rounded to bf16; 2 = operands split

@@ -22,3 +22,10 @@ from adaptpoint_amd import _lib as _apn_lib
 
 # Fail at import time, like a missing compiled extension would.
 _apn_lib.load()
+
+# APN_PATCH_OPENPOINTS=1: besides the nine operators, route the reference's SetAbstraction / PointsetGrouper /
+# Anchor_selfattention / ConvBNReLU1D forwards to the fused kernels -- without touching the reference tree
+# (adaptpoint_amd/integrate.py; the classes are patched as their modules are imported).
+from adaptpoint_amd import integrate as _apn_integrate
+if _apn_integrate.requested_by_environment():
+    _apn_integrate.patch_openpoints(lazy=True)

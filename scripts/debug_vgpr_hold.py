@@ -16,8 +16,9 @@ pts = torch.cat([pos, pos[:, :, 1:2]], -1).transpose(1, 2).contiguous()
 C = fill_parameters_by_name(PointNextSClassifier(fused=True)).to(dev).eval()
 bad = torch.zeros(32, dtype=torch.int64, device=dev)
 turns = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 600
-VPK = "vpk" in sys.argv or "vpk1" in sys.argv    # the packed-FP32 probe instead of the register-hold kernel
-FORM = 1 if "vpk1" in sys.argv else 0           # vpk1: the op_sel:[0,1] form (a pair's high register feeds both lanes)
+VPK = any(a in sys.argv for a in ("vpk", "vpk1", "vpk2"))    # the packed-FP32 probe instead of the register-hold kernel
+# vpk1: the op_sel:[0,1] form (a pair's high register feeds both lanes); vpk2: the same behind `s_nop 7`
+FORM = 2 if "vpk2" in sys.argv else 1 if "vpk1" in sys.argv else 0
 
 
 def hold():
@@ -69,4 +70,14 @@ for it in range(12):
         ga.replay()
 torch.cuda.synchronize()
 print("beside the classifier's blocks:", bad[:4].tolist() if VPK else bad[:24].tolist())
-print("samples (index, value found):", [(int(v) >> 32, hex(int(v) & 0xFFFFFFFF)) for v in bad[24:].tolist() if v])
+if VPK:
+    import struct
+    f32 = lambda u: struct.unpack("<f", struct.pack("<I", u & 0xFFFFFFFF))[0]
+    w = [int(v) & 0xFFFFFFFFFFFFFFFF for v in bad.tolist()]
+    for k in range(min(8, w[7])):
+        a, b, c = w[8 + 3 * k], w[9 + 3 * k], w[10 + 3 * k]
+        lane = a & 255
+        print(f"sample: turn {a >> 32} block {(a >> 8) & 0xFFFFFF} lane {lane}: found {f32(b >> 32)!r} wanted {f32(b)!r} "
+              f"(a0 = {0.25 + 0.001 * lane:.6f}, operand {f32(c >> 32)!r}, live other half {1000.0 + lane}); other lane's result {f32(c)!r}")
+else:
+    print("samples (index, value found):", [(int(v) >> 32, hex(int(v) & 0xFFFFFFFF)) for v in bad[24:].tolist() if v])

@@ -55,3 +55,10 @@ def cpu_mirrors(monkeypatch):
     monkeypatch.setattr(A, "attention", A._reference)
     with CB.CpuOps():
         yield
+
+
+@pytest.fixture(scope="session")
+def golden_b8():
+    """G17 / G18: the reference classifier at B = 8 in training mode, per-parameter gradients (make_golden.py classifier)."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "classifier_b8_golden.npz"))

@@ -25,7 +25,7 @@ observable here), else the seed is rejected.
 Fixtures store OUTPUTS (and small state_dicts); inputs are regenerated from
 seeds by tests/golden_inputs.py.
 
-    python tests/golden/make_golden.py [all | pointnet2 | adaptpoint | pins]
+    python tests/golden/make_golden.py [all | pointnet2 | adaptpoint | pins | classifier]
 
 `pointnet2` writes pointnet2_golden.npz (G1-G8: operators, SetAbstraction, the PointNeXt-S
 classifier, the imitator's grouper / attention / predictor network); `adaptpoint` writes
@@ -433,6 +433,72 @@ def _reference_classifier():
     return fill_parameters_by_name(_Cls())
 
 
+def main_classifier_b8():
+    """G17 / G18: the classifier at B = 8 in TRAINING mode (dropout off), per-parameter gradients -- the sharp model-level
+    pins (round 3's G5 training golden sat at B = 2, where the head's BatchNorm1d maps every feature to +-gamma and the
+    fused path could only be compared with the build's own unfused mirror).  G17: forward + SmoothCE + backward on
+    1024-point clouds (BASELINE configs[2]).  G18: one whole `train_one_epoch` iteration (train_autoaug.py:471-512) on
+    2048-point clouds: resampler, forward, loss, backward, clip, AdamW."""
+    import_reference()
+    out = {}
+
+    def grads_of(model, prefix):
+        for name, q in model.named_parameters():
+            g = q.grad.detach().numpy().reshape(-1)
+            out[f"{prefix}_grad/{name}"] = g[GI.gradient_sample_index(name, g.size)].copy()
+            out[f"{prefix}_gnorm/{name}"] = np.array(np.linalg.norm(g.astype(np.float64)))
+
+    def no_dropout(model):
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return model.train()
+    # ---- G17
+    cls = no_dropout(_reference_classifier())
+    pos = _t(GI.unit_sphere_cloud(8, 1024, seed=171))
+    x = torch.cat([pos, height_channel(pos)], -1).transpose(1, 2).contiguous().requires_grad_(True)
+    target = torch.tensor([5, 14, 0, 7, 3, 11, 9, 2])
+    logits, loss = cls.get_logits_loss({'pos': pos, 'x': x}, target)
+    loss.backward()
+    out.update(g17_logits=logits.detach().numpy(), g17_loss=np.array(loss.item()), g17_grad_x=x.grad.numpy(),
+               g17_target=target.numpy())
+    grads_of(cls, "g17")
+    for name, b in cls.named_buffers():
+        if name.endswith("running_mean"):
+            out[f"g17_bn/{name}"] = b.numpy().copy()
+    print(f"G17: classifier fwd+bwd at B=8 (training mode): loss {loss.item():.5f}")
+    # ---- G18
+    cls = no_dropout(_reference_classifier())
+    pos2k = _t(GI.unit_sphere_cloud(8, 2048, seed=181))
+    points = torch.cat([pos2k, height_channel(pos2k)], -1)
+    opt = torch.optim.AdamW(cls.parameters(), lr=2e-3, weight_decay=0.05)       # default.yaml:41-46
+    npoints, point_all = 1024, 1200
+    np.random.seed(18)
+    fps_idx = _OracleOps.furthest_point_sample(points[:, :, :3].contiguous(), point_all)
+    choice = np.random.choice(point_all, npoints, False)
+    fps_idx = fps_idx[:, choice]
+    points = torch.gather(points, 1, fps_idx.unsqueeze(-1).long().expand(-1, -1, points.shape[-1]))
+    data = {'pos': points[:, :, :3].contiguous(), 'x': points[:, :, :4].transpose(1, 2).contiguous()}
+    logits, loss = cls.get_logits_loss(data, target)
+    loss.backward()
+    grads_of(cls, "g18")                                                        # before clipping
+    gnorm = torch.nn.utils.clip_grad_norm_(cls.parameters(), 10, norm_type=2)
+    before = {n: q.detach().clone() for n, q in cls.named_parameters()}
+    opt.step()
+    for name, q in cls.named_parameters():                                      # the step each sampled weight took
+        d = (q.detach() - before[name]).numpy().reshape(-1)
+        out[f"g18_step/{name}"] = d[GI.gradient_sample_index(name, d.size)].copy()
+    out.update(g18_choice=choice.astype(np.int32), g18_logits=logits.detach().numpy(), g18_loss=np.array(loss.item()),
+               g18_grad_norm=np.array(gnorm.item()), g18_target=target.numpy())
+    for name, b in cls.named_buffers():
+        if name.endswith("running_mean"):
+            out[f"g18_bn/{name}"] = b.numpy().copy()
+    print(f"G18: train_one_epoch iteration at B=8: loss {loss.item():.5f}, grad norm {gnorm.item():.4f}")
+    path = os.path.join(HERE, "classifier_b8_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 def main_adaptpoint():
     import_reference()
     from easydict import EasyDict
@@ -821,3 +887,5 @@ if __name__ == "__main__":
         main_adaptpoint()
     if what in ("all", "pins"):
         main_pins()
+    if what in ("all", "classifier"):
+        main_classifier_b8()

@@ -363,3 +363,23 @@ def test_gan_step_at_the_size_the_reference_trains_at(dev):
     # reference's golden the fused path is the closer of the two: test_gan_step_matches_reference_trainer)
     assert errs["gen"] < 1e-5 and errs["losses"] < 1e-4 and errs["fc3"] < 1e-4
     assert errs["head"] < 6e-2 and errs["embed"] < 0.2
+
+
+G18_BARS = {False: dict(logits=2e-3, loss=2e-4, grads=5e-2), True: dict(logits=2e-3, loss=2e-4, grads=5e-2)}
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_classifier_iteration_at_b8_matches_reference_trainer(dev, golden_b8, fused):
+    """G18: one `train_one_epoch` iteration at B = 8, N = 2048 (resampler, forward, SmoothCE, backward, clip, AdamW) against
+    the reference trainer's golden: logits, loss, every parameter's pre-clip gradient in relative L2, BatchNorm running
+    means, and EVERY sampled weight whose reference gradient exceeds ten times the gradient bar takes the reference's step."""
+    import classifier_b8_checks as K
+    from adaptpoint_amd.pointnext import PointNextSClassifier, fill_parameters_by_name
+    bar = G18_BARS[fused]
+    r = K.run_g18(fill_parameters_by_name(PointNextSClassifier(fused=fused)), dev, golden_b8, grad_bar=bar["grads"])
+    print("G18 on the GPU (fused=%s):" % fused,
+          {k: ("%.2e" % r[k] if isinstance(r[k], float) else r[k]) for k in ("logits", "loss", "bn", "steps_checked", "step_mismatch")},
+          "worst parameter gradients:", [("%.2e" % v, n) for v, n in K.worst(r["grads"], 4)])
+    assert r["logits"] < bar["logits"] and r["loss"] < bar["loss"] and r["bn"] < 1e-4
+    assert max(r["grads"].values()) < bar["grads"], K.worst(r["grads"])
+    assert r["steps_checked"] > 20000 and r["step_mismatch"] == 0

@@ -369,7 +369,9 @@ def test_wide_block_replays_identically_from_a_hipgraph(dev, cin, N, M, radius):
         for q in params:
             q.grad = None
         out = grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2)
-        out.square().sum().backward()
+        # loss = sum(out^2), its gradient handed over directly: `.sum()` over 262144 elements is a multi-block PyTorch
+        # reduction, i.e. a MEMSET node under capture (graphs.capture refuses those; the scalar itself is not needed)
+        out.backward(2.0 * out.detach())
         return out
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())

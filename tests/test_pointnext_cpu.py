@@ -63,3 +63,31 @@ def test_smooth_cross_entropy():
     oh = torch.nn.functional.one_hot(gt, n).float()
     tgt = oh * (1 - eps) + (1 - oh) * eps / (n - 1)
     assert torch.allclose(SmoothCrossEntropy(0.3)(pred, gt), -(tgt * torch.log_softmax(pred, 1)).sum(1).mean())
+
+
+def test_training_mode_at_b8_matches_the_reference_parameter_by_parameter(golden_b8):
+    """G17: forward + SmoothCE + backward at B = 8 in training mode (dropout off) against the reference classifier run
+    over the oracle operators: logits, loss, input gradient and EVERY parameter's gradient in relative L2."""
+    from oracle import cpu_block as CB
+    import classifier_b8_checks as K
+    with CB.CpuOps():
+        r = K.run_g17(_model(), torch.device("cpu"), golden_b8)
+    print("G17 on CPU:", {k: "%.2e" % r[k] for k in ("logits", "loss", "grad_x", "bn")}, "worst gradients:", K.worst(r["grads"]))
+    # measured: 0.0 everywhere (the mirror issues the same torch-CPU calls in the same order over the same oracle operators)
+    assert r["logits"] < 1e-6 and r["loss"] < 1e-6 and r["grad_x"] < 1e-6 and r["bn"] < 1e-6
+    assert max(r["grads"].values()) < 1e-6, K.worst(r["grads"])
+    assert max(r["norms"].values()) < 1e-6, K.worst(r["norms"])
+
+
+def test_training_iteration_at_b8_matches_the_reference_trainer(golden_b8):
+    """G18: one `train_one_epoch` iteration at B = 8 (resampler, forward, loss, backward, clip, AdamW): pre-clip gradients
+    per parameter, and every sampled weight with a gradient above the noise takes exactly the reference's step."""
+    from oracle import cpu_block as CB
+    import classifier_b8_checks as K
+    with CB.CpuOps():
+        r = K.run_g18(_model(), torch.device("cpu"), golden_b8, grad_bar=2e-4)
+    print("G18 on CPU:", {k: ("%.2e" % r[k] if isinstance(r[k], float) else r[k]) for k in ("logits", "loss", "bn", "steps_checked", "step_mismatch")},
+          "worst gradients:", K.worst(r["grads"]))
+    assert r["logits"] < 1e-6 and r["loss"] < 1e-6 and r["bn"] < 1e-6            # measured: 0.0
+    assert max(r["grads"].values()) < 1e-6, K.worst(r["grads"])
+    assert r["steps_checked"] > 100000 and r["step_mismatch"] == 0
