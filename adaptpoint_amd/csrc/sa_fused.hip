@@ -308,23 +308,33 @@ __device__ __forceinline__ TileHead load_head(const SaArgs &a, int tile, int r) 
     return t;
 }
 
+// Addresses are a kernel argument (scalar registers) plus a 32-BIT byte offset per lane: the compiler then uses the
+// scalar-base + vector-offset form of the load; with 64-bit element indices it kept whole 64-bit addresses (base + lane
+// part) in vector registers across the tile loop -- eight registers, spilled to scratch in the backward pass.  The
+// entry points check that every table is smaller than 4 GB (sa_check).
+template <typename T>
+__device__ __forceinline__ T ld_off(const void *base, unsigned byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 template <int NS>
 __device__ __forceinline__ void fetch_tile(const SaArgs &a, const TileHead &hd, int h, TileRaw<NS> &t) {
     const int nb = hd.nb;
-    const int cloud = hd.q0 / a.m;
-    const size_t rowoff = ((size_t)cloud * a.n + nb) * SA_C;
-    const uint4 *row = reinterpret_cast<const uint4 *>(a.ft + rowoff);
-    t.f[0] = row[h];
-    t.f[1] = row[2 + h];
+    const unsigned cloud = (unsigned)(hd.q0 / a.m);
+    const unsigned pt = cloud * (unsigned)a.n + (unsigned)nb;
+    const unsigned rowoff = pt * (unsigned)(SA_C * 2) + 16u * (unsigned)h;        // bytes into the bf16 table
+    t.f[0] = ld_off<uint4>(a.ft, rowoff);
+    t.f[1] = ld_off<uint4>(a.ft, rowoff + 32u);
     if (NS == 2) {
-        const uint4 *rl = reinterpret_cast<const uint4 *>(a.ft_lo + rowoff);
-        t.fl[0] = rl[h];
-        t.fl[NS - 1] = rl[2 + h];
+        t.fl[0] = ld_off<uint4>(a.ft_lo, rowoff);
+        t.fl[NS - 1] = ld_off<uint4>(a.ft_lo, rowoff + 32u);
     }
-    const float *p = a.xyz + ((size_t)cloud * a.n + nb) * 3;
-    t.px = p[0]; t.py = p[1]; t.pz = p[2];
-    const float *q = a.new_xyz + (size_t)(hd.q0 + (ri_mult(hd.info) ? ri_q(hd.info) : 0u)) * 3;
-    t.qx = q[0]; t.qy = q[1]; t.qz = q[2];
+    struct xyz3 { float x, y, z; };                                                 // one 12-byte load
+    const xyz3 pp = ld_off<xyz3>(a.xyz, pt * 12u);
+    t.px = pp.x; t.py = pp.y; t.pz = pp.z;
+    const unsigned q = (unsigned)hd.q0 + (ri_mult(hd.info) ? ri_q(hd.info) : 0u);
+    const xyz3 qq = ld_off<xyz3>(a.new_xyz, q * 12u);
+    t.qx = qq.x; t.qy = qq.y; t.qz = qq.z;
     t.nb = nb;
     t.info = hd.info;
     t.q0 = hd.q0;
@@ -386,8 +396,15 @@ __device__ __forceinline__ void touch(const TileHead &hd) {
 // every tile, 2.3 us of serial round trips (ISA; stamps).  Here the next tile's rows are requested at the END of a
 // tile's arithmetic, into the registers its own rows left at the tile's start: one batch in flight during the tile's
 // stores and atomics.  BODY must not read its `raw` argument after it has called `before_stores`.
-template <int NS, bool CP, bool LATE = false, typename Pro, typename Pre, typename Body>
-__device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Pro prologue, Pre pre, Body body) {
+// AHEAD(head) (LATE only) is called right before a tile's rows are requested -- one tile ahead of its arithmetic: the place
+// for asynchronous copies into LDS of whatever else the tile needs (the memory counter is in order: once the rows have
+// arrived, so has everything requested before them).
+struct NoAhead {
+    __device__ __forceinline__ void operator()(const TileHead &) const {}
+};
+template <int NS, bool CP, bool LATE = false, typename Pro, typename Pre, typename Body, typename Ahead = NoAhead>
+__device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, int h, Pro prologue, Pre pre, Body body,
+                                              Ahead ahead = Ahead()) {
     // XCD-aware tile numbers: workgroups w and w + 8 share an XCD (round-robin placement: a speed assumption, never a
     // correctness one) and its L2.  Dealt out in launch order, a cloud's ~130 tiles went to all eight XCDs and every
     // XCD pulled every cloud's rows through its own L2 (PMC: 35 MB fetched for a 4 MB table).  Tile number
@@ -412,7 +429,10 @@ __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, 
     TileRaw<NS> cur, nxt;
     const bool any = tile < tiles;                                 // wave-uniform
     stamp(a, wave, 1);
-    if (any) fetch_tile<NS>(a, hd0, h, cur);
+    if (any) {
+        ahead(hd0);
+        fetch_tile<NS>(a, hd0, h, cur);
+    }
     prologue();
     stamp(a, wave, 2);
     if (!any) return;
@@ -423,8 +443,14 @@ __device__ __forceinline__ void for_each_tile(const SaArgs &a, int wave, int r, 
         if (LATE) {
             const TileHead hd_nxt2 = load_head<CP>(a, tile2 < tiles ? tile2 : tile, r);
             body(tile, cur, nst == 4, [&] {
+                // (a scheduling fence: hoisted above the tile's last arithmetic these loads find no free registers and are
+                // spilled to scratch as they arrive -- load, wait, store, one after the other)
+                asm volatile("" ::: "memory");
                 touch(hd_nxt);
-                if (more) fetch_tile<NS>(a, hd_nxt, h, cur);
+                if (more) {
+                    ahead(hd_nxt);
+                    fetch_tile<NS>(a, hd_nxt, h, cur);
+                }
             });
             stamp(a, wave, nst < 5 ? nst : 5);
             ++nst;
@@ -781,11 +807,13 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     __shared__ float sD[SA_C2], sE[SA_C2];
     __shared__ __attribute__((aligned(16))) float sqm[SA_C1 + 1][SA_C1 + 4];   // Qm[k][mid]; row 32 = evec; later Gram | suma
     stamp(a, wave, 0);
-    const float sc1 = g.scale1[r], sh1 = g.shift1[r], mu1 = g.mean1[r], iv1 = g.inv1[r];
-    float ev = 0.0f;
-    float sacc[32];           // lane c: sparse part of dL/dW2[c][mid], mid = acc_row(i, 0) | acc_row(i, 1)
-#pragma unroll
-    for (int i = 0; i < 32; ++i) sacc[i] = 0.0f;
+    // BatchNorm-1's constants of channel r and evec[r]: kept in LDS and READ PER TILE (five registers less across the loop:
+    // the pass runs at the register file's limit, see for_each_tile)
+    __shared__ float chan[5][32];                 // {scale1, shift1, mean1, inv1, evec}[channel]
+    // sparse part of dL/dW2, S^T a1 over the tile's positions, as MFMA accumulators: dsp[t] holds
+    // dL/dW2[c = 32 t + acc_row(i, h)][mid = r]  (round 3: 32 f32 accumulators per lane fed by 32 ds_bpermute + 32 FMAs
+    // PER QUERY -- ~260 LDS-crossbar and vector instructions per tile; now 16 transposed LDS reads + 12 MFMAs per tile)
+    f32x16 dsp[2] = {{0}, {0}};
     f32x16 gram = {0};        // sum_pos a1^T a1: row mid' = acc_row(i, h), column mid = r
     float suma = 0.0f;        // sum_pos a1[pos][mid = r] (this half's positions)
     float st[2] = {0.0f, 0.0f};
@@ -798,6 +826,11 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     constexpr int SP_BYTES = SA_WAVES * SP_WAVE, WRED_BYTES = SA_WAVES * SA_C2 * SA_C1 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char sp_raw[SP_BYTES > WRED_BYTES ? SP_BYTES : WRED_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned sinfo[SA_WAVES][32];
+    __shared__ __attribute__((aligned(16))) int snb[CP ? SA_WAVES : 1][32];     // (tile map) the rows' neighbours, for the scatter
+    // (tile map) goa / ksel of a tile's first four queries, copied here one tile ahead by two asynchronous global -> LDS
+    // loads (four consecutive queries are 1024 / 256 contiguous bytes): no registers held across the previous tile
+    __shared__ __attribute__((aligned(16))) float qgoa[CP ? SA_WAVES : 1][4 * SA_C2];
+    __shared__ __attribute__((aligned(16))) unsigned char qksel[CP ? SA_WAVES : 1][4 * SA_C2];
     __bf16 *sp_img = reinterpret_cast<__bf16 *>(sp_raw + wave * SP_WAVE);
 
     __shared__ float sbnd[8];                 // bit-reproducible mode: the pieces of the bound (see the prologue's end)
@@ -808,14 +841,17 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     // A[off] += v: a float atomic, or (FX, bit-reproducible mode) the 64-bit integer round(v 2^s).  |v 2^s| < 2^47 (the
     // bound of the prologue), so the integer is read off the mantissa of v 2^s + 1.5 2^52 -- four instructions
     // instead of a dozen for a float -> int64 conversion; a term beyond the limit raises a (scalar) mark.
-    auto a_add = [&](size_t off, float v) {
+    // (`off`: a 32-bit ELEMENT offset; the address is the scalar base + a 32-bit byte offset: no 64-bit vector arithmetic
+    // per atomic.  B * N * 32 * 8 < 2^32 is checked at the entry.)
+    auto a_add = [&](unsigned off, float v) {
         if (FX) {
             const float vs = v * fxs;
             bad |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(vs) < fxlim));
             const double dm = (double)vs + 6755399441055744.0;
-            atomicAdd(A64 + off, (unsigned long long)(__double_as_longlong(dm) - 0x4338000000000000ll));
+            atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(A64) + (off << 3)),
+                      (unsigned long long)(__double_as_longlong(dm) - 0x4338000000000000ll));
         } else {
-            atomicAdd(A + off, v);
+            atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(A) + (off << 2)), v);
         }
     };
 
@@ -920,7 +956,12 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             if (h == 0) sqm[32][r] = eacc[0];                     // row 0 of the product = evec
         }
         __syncthreads();
-        ev = sqm[32][r];
+        if (threadIdx.x < 32) {
+            chan[0][threadIdx.x] = g.scale1[threadIdx.x]; chan[1][threadIdx.x] = g.shift1[threadIdx.x];
+            chan[2][threadIdx.x] = g.mean1[threadIdx.x]; chan[3][threadIdx.x] = g.inv1[threadIdx.x];
+            chan[4][threadIdx.x] = sqm[32][threadIdx.x];
+        }
+        __syncthreads();
         if (FX) {
             // |g_u| of a row <= G 64 wmax + 32 (amax 2048 wmax^2 dmax + 64 wmax emax)  (G = max |goa|; the selected part is
             // a sum of at most 64 products, the dense part -- a1 Qm + evec, Qm = W2^T diag(D2) W2 -- reaches a row at most 32
@@ -949,17 +990,30 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     int pend_nb = 0, pend_live = 0, pend_cloud = 0;      // pend_live == 0: nothing pending
     auto scatter_pending = [&]() {
         if (CP || pend_live == 0) return;                 // wave-uniform (tile map: scattered at the end of the tile)
-        const size_t Ac = (size_t)pend_cloud * a.n * SA_C1 + r;
+        const unsigned Ac = (unsigned)pend_cloud * (unsigned)a.n * SA_C1 + (unsigned)r;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if (acc_row(i, 0) < pend_live) {              // wave-uniform: is any lane's position live?
                 const int n0 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 0));
                 const int n1 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 1));
                 const int nn = h ? n1 : n0;
-                if (acc_row(i, h) < pend_live) a_add(Ac + (size_t)nn * SA_C1, pend_g[i]);
+                if (acc_row(i, h) < pend_live) a_add(Ac + (unsigned)nn * SA_C1, pend_g[i]);
             }
         }
         pend_live = 0;
+    };
+    auto ahead = [&](const TileHead &hd) {
+        if (!CP) return;
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef __attribute__((address_space(1))) const void glb_void;
+        const int q0n = __builtin_amdgcn_readfirstlane(hd.q0);
+        const int qbn = q0n < a.b * a.m - 4 ? q0n : a.b * a.m - 4;
+        int l_o = lane;                                  // (opaque: keeps base + 16 * lane out of two hoisted register pairs)
+        asm volatile("" : "+v"(l_o));
+        const char *gb = reinterpret_cast<const char *>(g.goa) + (size_t)qbn * (SA_C2 * 4);
+        const char *kb = reinterpret_cast<const char *>(g.ksel) + (size_t)qbn * SA_C2;
+        __builtin_amdgcn_global_load_lds((glb_void *)(gb + (unsigned)(16 * l_o)), (lds_void *)&qgoa[wave][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(kb + (unsigned)(4 * l_o)), (lds_void *)&qksel[wave][0], 4, 0, 0);
     };
     for_each_tile<NS, CP, CP>(a, wave, r, h, prologue, scatter_pending, [&](int tile, const TileRaw<NS> &raw, bool probe, auto before_stores) {
         auto st2 = [&](int k) { if (probe) stamp(a, wave, 8 + k); };
@@ -977,32 +1031,44 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         const float mrow = CP ? (float)ri_mult(raw.info) : 1.0f;       // multiplicity of position r
         // (tile map) the gradients and pooled slots of the tile's first four queries are requested NOW, one batch
         // of loads: a query-by-query chain paid one memory round trip per query (~4 per tile)
+        // (over the tile map they were copied into the wave's LDS buffer one tile ahead, with the tile's rows: `ahead` below)
         float gv4[4];
         int kc4[4];
+        const int qb = q0 < a.b * a.m - 4 ? q0 : a.b * a.m - 4;        // first query of the copied block of four
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            gv4[u] = 0.0f;
-            kc4[u] = 0;
-            if (u == 0 || (CP && u < nq)) {
-                gv4[u] = g.goa[(size_t)(q0 + u) * SA_C2 + lane];
-                kc4[u] = g.ksel[(size_t)(q0 + u) * SA_C2 + lane];
+            if (CP) {
+                gv4[u] = 0.0f;
+                kc4[u] = 0;
+            } else {
+                gv4[u] = 0.0f;
+                kc4[u] = 0;
+                if (u == 0) {
+                    gv4[u] = g.goa[(size_t)(q0 + u) * SA_C2 + lane];
+                    kc4[u] = g.ksel[(size_t)(q0 + u) * SA_C2 + lane];
+                }
             }
         }
         // tile map: multiplicities of this lane's sixteen accumulator rows acc_row(i, h) (the row records go through
         // a wave-private LDS line: one write, four 16-byte broadcast reads), and where the queries' rows start
-        float multf[16];
+        // (kept PACKED, four 8-bit multiplicities per register, and converted at each use -- one v_cvt_f32_ubyteN each:
+        // sixteen floats held across the whole tile were what pushed the pass over 256 registers)
+        unsigned mpk[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
         unsigned starts = 1u;                                          // bit = a query's first row (wave-uniform)
         if (CP) {
-            if (lane < 32) sinfo[wave][lane] = raw.info;
+            if (lane < 32) {
+                sinfo[wave][lane] = raw.info;
+                snb[wave][lane] = nb;
+            }
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(&sinfo[wave][8 * gq + 4 * (lane_o >> 5)]);
-                multf[4 * gq] = (float)ri_mult(v.x); multf[4 * gq + 1] = (float)ri_mult(v.y);
-                multf[4 * gq + 2] = (float)ri_mult(v.z); multf[4 * gq + 3] = (float)ri_mult(v.w);
+                mpk[gq] = ri_mult(v.x) | (ri_mult(v.y) << 8) | (ri_mult(v.z) << 16) | (ri_mult(v.w) << 24);
             }
             const unsigned prev = (unsigned)__shfl_up((int)raw.info, 1);
             starts = (unsigned)__ballot(lane < 32 && (lane == 0 || ri_q(raw.info) != ri_q(prev)));
         }
+        auto multf = [&](int i) { return (float)((mpk[i >> 2] >> (8 * (i & 3))) & 0xffu); };   // of accumulator row acc_row(i, h)
         // conv1 in both layouts (3 + 3 k-steps on the same fragments)
         f32x16 yT = {0}, y1 = {0};
 #pragma unroll
@@ -1048,6 +1114,17 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         Frag<NS> sp[4];
         {
             unsigned todo = starts;                                     // consumed query by query
+            if (CP) {
+                // the block of four queries copied ahead starts at qb <= q0 (== q0 except at the very end of the tensor)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (older than the tile's rows: long arrived)
+                const int dq = q0 - qb;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = (u + dq < 4 ? u + dq : 3) * SA_C2 + lane_o;
+                    gv4[u] = qgoa[wave][e];
+                    kc4[u] = qksel[wave][e];
+                }
+            }
 #pragma unroll 1
             for (int jb = 0; jb < nq; jb += 4) {
                 if (jb) {                                               // (rare) the tile's queries beyond the first four
@@ -1073,16 +1150,58 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                         cell[0] = ghi;
                         if (NS == 2) cell[SP_TILE] = glo;
                         if (!CP) kc4[u] = kc;
-                        // sparse part of dL/dW2: lane c adds goa[c] * a1[pos = ksel[c]][:]; that row of a1 sits in
-                        // lanes kc (mids acc_row(i, 0)) and kc + 32 (mids acc_row(i, 1)), register i
-                        const int src0 = kc << 2, src1 = (kc + 32) << 2;      // ds_bpermute takes byte addresses
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int bits = __float_as_int(yT[i]);
-                            sacc[i] = __builtin_fmaf(gv, __int_as_float(__builtin_amdgcn_ds_bpermute(src0, bits)), sacc[i]);
-                            sacc[16 + i] = __builtin_fmaf(gv, __int_as_float(__builtin_amdgcn_ds_bpermute(src1, bits)), sacc[16 + i]);
-                        }
                     }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");      // (the image's cells were written through another type)
+        {
+            // a1 in the [lane = mid, register = position] layout: both operands of the Gram product and the B operand of
+            // the sparse part of dL/dW2 (the k index -- positions in accumulator-row order -- pairs the same registers)
+            f32x16 an;
+            const float sc1 = chan[0][lane_o & 31], sh1 = chan[1][lane_o & 31];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                an[i] = __builtin_fmaxf(__builtin_fmaf(y1[i], sc1, sh1), 0.0f);
+                if (CP) suma = __builtin_fmaf(multf(i), an[i], suma);
+                else suma += an[i];
+            }
+            const Frag<NS> b0 = pack8<NS>(an, 0), b1 = pack8<NS>(an, 8);
+            // Gram += a1^T a1 (one side weighted by the multiplicity)
+            if (CP) {
+                f32x16 aw;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) aw[i] = an[i] * multf(i);
+                gram = mfma<NS>(pack8<NS>(aw, 0), b0, gram);
+                gram = mfma<NS>(pack8<NS>(aw, 8), b1, gram);
+            } else {
+                gram = mfma<NS>(b0, b0, gram);
+                gram = mfma<NS>(b1, b1, gram);
+            }
+            // dL/dW2's sparse part += S^T a1: the A operand (rows = output channels, k = positions) is the image read
+            // TRANSPOSED (ds_read_b64_tr_b16: a 16-lane group reads a block of 4 position rows x 16 channels and every
+            // lane receives its channel's 4 positions; lane 4q + p of a group addresses row q, channels 4p .. 4p + 3).
+            // Fragment (t, s) of lane (r, h): channel 32 t + r, positions acc_row(8 s + j, h) = rows 16 s + 4 h + j (j < 4)
+            // and 16 s + 8 + 4 h + (j - 4): two reads per part, immediate offsets from one base address.
+            typedef short tr_s4 __attribute__((ext_vector_type(4)));
+            typedef short tr_s8 __attribute__((ext_vector_type(8)));
+            typedef __attribute__((address_space(3))) tr_s4 tr_lds;
+            const int li = lane_o & 15, gq = li >> 2, gp = li & 3, grh = (lane_o >> 4) & 1;
+            const __bf16 *tb = sp_img + (4 * (lane_o >> 5) + gq) * SP_ROW + 16 * grh + 4 * gp;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk) {
+                    Frag<NS> at;
+#pragma unroll
+                    for (int pp = 0; pp < NS; ++pp) {
+                        const __bf16 *src = tb + pp * SP_TILE + (16 * sk) * SP_ROW + 32 * t;
+                        const tr_s4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds *)(src));
+                        const tr_s4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds *)(src + 8 * SP_ROW));
+                        const tr_s8 v8 = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                        at.p[pp] = __builtin_bit_cast(bf16x8, v8);
+                    }
+                    dsp[t] = mfma<NS>(at, sk ? b1 : b0, dsp[t]);
                 }
             }
         }
@@ -1101,33 +1220,32 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         }
         // dL/da1 [lane = mid, register = position]
         f32x16 ga;
+        const float ev = chan[4][lane_o & 31];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ga[i] = CP ? ev * multf[i] : ev;
+        for (int i = 0; i < 16; ++i) ga[i] = CP ? ev * multf(i) : ev;
         ga = mfma<NS>(a0, get_frag<NS>(cfrag, F_QM, lane_o), ga);
         ga = mfma<NS>(a1, get_frag<NS>(cfrag, F_QM + 1, lane_o), ga);
 #pragma unroll
         for (int s = 0; s < 4; ++s) ga = mfma<NS>(sp[s], get_frag<NS>(cfrag, F_W2T + s, lane_o), ga);
 
         st2(3);
-        f32x16 an;   // a1 in the [lane = mid] layout: both operands of the Gram product
         // (tile map) g_u and multiplicity * yhat1 of every row also go to two wave-private LDS tiles [row][mid] (the
         // image's region: the image is dead until the next tile), for the sums per query below
         float *gt = reinterpret_cast<float *>(sp_img);
         asm volatile("" ::: "memory");
         float s1 = 0.0f, s2 = 0.0f, hb = 0.0f;
+        const float sc1l = chan[0][lane_o & 31], sh1l = chan[1][lane_o & 31], iv1 = chan[3][lane_o & 31];
+        const float nmi = -chan[2][lane_o & 31] * iv1;                  // yhat = y1 inv1 - mean1 inv1
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float u = __builtin_fmaf(y1[i], sc1, sh1);
-            const float yhat = (y1[i] - mu1) * iv1;
-            an[i] = __builtin_fmaxf(u, 0.0f);
-            if (CP) suma = __builtin_fmaf(multf[i], an[i], suma);
-            else suma += an[i];
+            const float u = __builtin_fmaf(y1[i], sc1l, sh1l);
+            const float yhat = __builtin_fmaf(y1[i], iv1, nmi);
             ga[i] = u > 0.0f ? ga[i] : 0.0f;   // g_u
             s1 += ga[i];
             s2 += ga[i] * yhat;
             if (CP) {
                 gt[acc_row(i, h) * 33 + r] = ga[i];
-                gt[32 * 33 + acc_row(i, h) * 33 + r] = multf[i] * yhat;
+                gt[32 * 33 + acc_row(i, h) * 33 + r] = multf(i) * yhat;
             } else {
                 hb += yhat;
             }
@@ -1203,39 +1321,29 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             }
 
             st2(5);
-            // Gram += a1^T a1 (one side weighted by the multiplicity): the k index (positions, accumulator-row
-            // order) pairs the same registers
-            {
-                const Frag<NS> b0 = pack8<NS>(an, 0), b1 = pack8<NS>(an, 8);
-                if (CP) {
-                    f32x16 aw;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) aw[i] = an[i] * multf[i];
-                    gram = mfma<NS>(pack8<NS>(aw, 0), b0, gram);
-                    gram = mfma<NS>(pack8<NS>(aw, 8), b1, gram);
-                } else {
-                    gram = mfma<NS>(b0, b0, gram);
-                    gram = mfma<NS>(b1, b1, gram);
-                }
-            }
             st2(6);
             if (CP) {
                 // the tile's per-point sums, scattered at the END of the tile: behind every load of this iteration and
                 // ahead of the next iteration's prefetch (the memory counter is in order: they retire behind a whole
                 // tile of arithmetic; the one-tile-per-query path reaches the same order through scatter_pending)
-                const size_t Ac = (size_t)(q0 / a.m) * a.n * SA_C1 + r;
+                // (the neighbours of this lane's sixteen rows come back from the wave's LDS line, four 16-byte reads -- the
+                // readlane pairs + selects of round 3 were ~50 vector instructions per tile; element offsets are 32-bit:
+                // B * N * 32 < 2^31 is checked at the entry)
+                const unsigned Ac = (unsigned)(q0 / a.m) * (unsigned)a.n * SA_C1 + (unsigned)r;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (acc_row(i, 0) < live) {                   // wave-uniform: is any lane's position live?
-                        const int n0 = __builtin_amdgcn_readlane(nb, acc_row(i, 0));
-                        const int n1 = __builtin_amdgcn_readlane(nb, acc_row(i, 1));
-                        const int nn = h ? n1 : n0;
-                        if (acc_row(i, h) < live) a_add(Ac + (size_t)nn * SA_C1, ga[i]);
+                for (int gq = 0; gq < 4; ++gq) {
+                    if (8 * gq < live) {                          // wave-uniform: is any lane's position live?
+                        const int4 nn = *reinterpret_cast<const int4 *>(&snb[wave][8 * gq + 4 * (lane_o >> 5)]);
+                        const int base = 8 * gq + 4 * h;
+                        if (base + 0 < live) a_add(Ac + (unsigned)nn.x * SA_C1, ga[4 * gq + 0]);
+                        if (base + 1 < live) a_add(Ac + (unsigned)nn.y * SA_C1, ga[4 * gq + 1]);
+                        if (base + 2 < live) a_add(Ac + (unsigned)nn.z * SA_C1, ga[4 * gq + 2]);
+                        if (base + 3 < live) a_add(Ac + (unsigned)nn.w * SA_C1, ga[4 * gq + 3]);
                     }
                 }
             }
         }
-    });
+    }, ahead);
     if (FX && bad != 0ull && lane == 0) atomicOr(g.cells + 2, 1u);
     {   // BatchNorm-1's reduction terms {T1, T2}[32] into their accumulator set
         const float tot = fold_partials<2>(st, lane, wave);
@@ -1247,8 +1355,8 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        wred[wave][lane * SA_C1 + acc_row(i, 0)] = sacc[i];
-        wred[wave][lane * SA_C1 + acc_row(i, 1)] = sacc[16 + i];
+        wred[wave][acc_row(i, h) * SA_C1 + r] = dsp[0][i];
+        wred[wave][(32 + acc_row(i, h)) * SA_C1 + r] = dsp[1][i];
     }
     __syncthreads();
     // thread (c = tid >> 2, eight mids from mid0 = 8 (tid & 3)): its eight elements of the workgroup's row
@@ -1380,6 +1488,7 @@ static int sa_check(int b, int n, int m, int precision) {
     if (precision != 1 && precision != 2) return APN_EINVAL;
     if (b <= 0 || n <= 0 || m <= 0) return APN_EINVAL;
     if ((long long)b * m > 0x7fffffffLL / 64) return APN_EINVAL;
+    if ((long long)b * n > 0xffffffffLL / 256) return APN_EINVAL;     // 32-bit byte offsets: bf16 tables (fetch_tile), A as int64 (a_add)
     return APN_OK;
 }
 
