@@ -760,26 +760,35 @@ __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
 // gscale = 1, or 1 / world with reduced sums (SyncBatchNorm: global sum / world = the mean over ranks of the
 // rank-local sums -- what torch.nn.SyncBatchNorm + DistributedDataParallel leave in .grad; g_bs is a conv bias
 // gradient and stays this rank's own sum).
-// A workgroup owns 16 output elements x 16 row groups; loads are issued 8 deep.
+// A workgroup owns 32 output elements x 16 row groups (round 3: 16 x 16 -- 64-byte segments of every 128-byte line, PMC
+// 23 MB for 10 MB of rows); loads are issued 16 deep: the ~30 rows of a thread are two round trips instead of four.
+constexpr int FIN_COLS = 32, FIN_GROUPS = 16;
 __device__ __forceinline__ double col_sum(const float *__restrict__ base, int rows, int stride,
                                           int col, int g) {
     double s = 0.0;
     int r = g;
-    for (; r + 7 * 16 < rows; r += 8 * 16) {
-        float v[8];
+    for (; r + 15 * FIN_GROUPS < rows; r += 16 * FIN_GROUPS) {
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r + 16 * u) * stride + col];
+        for (int u = 0; u < 16; ++u) v[u] = base[(size_t)(r + FIN_GROUPS * u) * stride + col];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += (double)v[u];
+        for (int u = 0; u < 16; ++u) s += (double)v[u];
     }
-    for (; r < rows; r += 16) s += (double)base[(size_t)r * stride + col];
+    for (; r + 3 * FIN_GROUPS < rows; r += 4 * FIN_GROUPS) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = base[(size_t)(r + FIN_GROUPS * u) * stride + col];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += (double)v[u];
+    }
+    for (; r < rows; r += FIN_GROUPS) s += (double)base[(size_t)r * stride + col];
     return s;
 }
 
 constexpr int FIN_W1 = 32 * 35, FIN_WS = 2048, FIN_W2 = 2048, FIN_SMALL = 64 * 3 + 32 * 2;
 constexpr int FIN_TOTAL = FIN_W1 + FIN_WS + FIN_W2 + FIN_SMALL;
 
-__global__ __launch_bounds__(256) void bwd_finalize_kernel(
+__global__ __launch_bounds__(FIN_COLS * FIN_GROUPS) void bwd_finalize_kernel(
     const float *__restrict__ partW, int rowsW, double inv_r, float *__restrict__ g_w1,
     const float *__restrict__ partWs, int rowsS, float *__restrict__ g_ws,
     const float *__restrict__ partW2, int rows2, float *__restrict__ g_w2,
@@ -787,9 +796,9 @@ __global__ __launch_bounds__(256) void bwd_finalize_kernel(
     const unsigned long long *__restrict__ accT, const double *__restrict__ sumsT,
     float *__restrict__ g_bs, float *__restrict__ g_g2, float *__restrict__ g_b2, float *__restrict__ g_g1,
     float *__restrict__ g_b1) {
-    __shared__ double red[16][16];
-    const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int e = blockIdx.x * 16 + o;
+    __shared__ double red[FIN_GROUPS][FIN_COLS];
+    const int o = threadIdx.x % FIN_COLS, g = threadIdx.x / FIN_COLS;
+    const int e = blockIdx.x * FIN_COLS + o;
     double v = 0.0;
     float *dst = nullptr;
     if (e < FIN_W1) {
@@ -831,7 +840,7 @@ __global__ __launch_bounds__(256) void bwd_finalize_kernel(
     if (g == 0 && dst) {
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc += red[k][o];
+        for (int k = 0; k < FIN_GROUPS; ++k) acc += red[k][o];
         *dst = (float)acc;
     }
 }
@@ -978,7 +987,8 @@ extern "C" int apn_sa_bwd_finalize(const float *partW, int rows_w, float radius,
                                    float *g_g1, float *g_b1, void *stream) {
     if (!partW || !g_w1 || (g_ws && !partWs) || (g_w2 && !partW2) || !accS || (!accT && !sumsT))
         return APN_EINVAL;
-    hipLaunchKernelGGL(apn::bwd_finalize_kernel, dim3((apn::FIN_TOTAL + 15) / 16), dim3(256), 0, APN_ST, partW,
+    hipLaunchKernelGGL(apn::bwd_finalize_kernel, dim3((apn::FIN_TOTAL + apn::FIN_COLS - 1) / apn::FIN_COLS),
+                       dim3(apn::FIN_COLS * apn::FIN_GROUPS), 0, APN_ST, partW,
                        rows_w, 1.0 / (double)radius, g_w1, partWs, rows_s, g_ws, partW2, rows_2, g_w2,
                        (const unsigned long long *)accS, sumsS, (const unsigned long long *)accT, sumsT, g_bs,
                        g_g2, g_b2, g_g1, g_b1);

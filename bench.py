@@ -36,6 +36,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 B_PER_GPU, N_PTS, NPOINT, NSAMPLE, C_IN, C_OUT, RADIUS = 32, 1024, 512, 32, 32, 64, 0.15
+# What the DEFAULT configuration launches (short names of the per-kernel pass): seven on the MLP stream per step, four on
+# the index stream per 20 batches.  The committed PMC traffic file (profiles/r0N_traffic.json) must cover exactly this
+# set -- tests/test_host_cpu.py checks it, and the line says whether the kernels seen at run time equal it.
+DEFAULT_KERNELS = ("sa_prep_stats", "sa_fwd_main", "sa_fwd_out", "sa_bwd_prep", "sa_bwd_main", "sa_bwd_point_grads",
+                   "sa_bwd_finalize", "fps", "ball_query", "sa_point_geo", "sa_wide_tilemap_many")
+TRAFFIC_FILE = "r04_traffic.json"        # PMC bytes per launch of the kernels above (scripts/collect_profiles.sh pmc)
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -741,7 +747,7 @@ def main():
     # corrected as MI355X_MICROARCH.md prescribes; scripts/collect_profiles.sh pmc -> scripts/make_traffic_json.py).
     # A committed constant, labelled as such: bench.py cannot run the profiler on itself.
     traffic, traffic_src = {}, None
-    for name in ("r03_traffic.json",):
+    for name in (TRAFFIC_FILE,):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -806,6 +812,9 @@ def main():
                          # step launched alone
                          "mlp_stream_verified_after_timed_region": m.mlp_verified},
         "kernels": kernels,
+        # the kernels this run launched == the set the committed traffic file was collected for
+        "kernel_set_is_default": sorted(kernels) == sorted(DEFAULT_KERNELS),
+        "traffic_file_covers_kernel_set": bool(traffic) and sorted(traffic) == sorted(kernels),
     })
 
     from adaptpoint_amd import set_abstraction as _sa
@@ -865,6 +874,23 @@ def main():
             # the bit-for-bit interoperable path: nine drop-in operators + PyTorch fp32 conv/BN (eager)
             m2 = measure(args, dev, world, rank, local_rank, distributed, "torch-f32", False, sec_steps, 4)
             result["value_f32_dropin"] = round(B_PER_GPU * sec_steps / m2.elapsed, 2)
+            if pipelined and args.index_batch == 0 and args.steps % 20 == 0:
+                # What the headline assumes, stated beside it: `value` runs the index stages (FPS + ball query) of 20 batches
+                # in ONE stacked launch on a second stream, a replay ahead of the MLP steps that consume them.  The same
+                # run batch by batch (one index launch per step, still a replay ahead), and with no second stream at all
+                # (index stage in line, in front of each step's MLP -- what a consumer of freshly GENERATED coordinates,
+                # e.g. the AdaptPoint feedback pass, gets):
+                import copy as _copy
+                v_steps = min(args.steps, 400)
+                a1 = _copy.copy(args)
+                a1.index_batch = 1
+                m4 = measure(a1, dev, world, rank, local_rank, distributed, args.mlp, False, v_steps, 40, repeats=5)
+                result["value_index_batch_1"] = round(B_PER_GPU * v_steps / m4.elapsed, 2)
+                result["index_batch_1_verified"] = m4.index_verified
+                a2 = _copy.copy(args)
+                a2.pipeline = "off"
+                m5 = measure(a2, dev, world, rank, local_rank, distributed, args.mlp, False, v_steps, 40, repeats=5)
+                result["value_no_pipeline"] = round(B_PER_GPU * v_steps / m5.elapsed, 2)
             if not args.deterministic and args.mlp == "fused-bf16x3" and args.steps % 20 == 0:
                 # the same step with bit-reproducible gradients (no float atomics: 64-bit fixed-point sums)
                 args.deterministic = True

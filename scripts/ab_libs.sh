@@ -1,16 +1,14 @@
 #!/bin/bash
 # A/B of two builds of the library on one box: scripts/ab_libs.sh A.so B.so [bench flags]
-# (alternates the two, three rounds each; prints value and ms_per_step)
+# (alternates the two, three rounds each; prints value and ms_per_step).  The builds are selected through APN_LIB_PATH
+# (adaptpoint_amd/_lib.py): the shipped libadaptpoint_amd.so is never overwritten, so an interrupted run leaves nothing behind.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 A=$1; B=$2; shift 2
-L=$R/adaptpoint_amd/libadaptpoint_amd.so
-cp $L /tmp/lib_keep.so
 for i in 1 2 3; do
-  for x in $A $B; do
-    cp $R/$x $L
+  for x in "$A" "$B"; do
     echo -n "$x  "
-    python $R/bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-secondary "$@" 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+    APN_LIB_PATH="$R/$x" APN_ALLOW_UNSAFE_LIB=1 python "$R/bench.py" --steps 2000 --warmup 200 --no-cpu-baseline --no-secondary "$@" 2>/dev/null \
+      | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
   done
 done
-cp /tmp/lib_keep.so $L

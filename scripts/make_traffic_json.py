@@ -21,11 +21,13 @@ ALIAS.update({k: k.replace("_kernel", "") for k in (
     "wide_stats1_kernel", "wide_fwd_main_kernel", "wide_bwd_main_kernel", "wide_wgrad_kernel", "wide_bwd_prep_kernel",
     "wide_point_terms_kernel", "wide_geo_kernel", "wide_colsum_kernel", "wide_image_kernel")})
 
+# one bench-line entry, two kernels: their bytes add (both run once per launch of the entry)
+ALIAS.update({"tilemap_pack_kernel": "sa_wide_tilemap_many", "tilemap_fill_kernel": "sa_wide_tilemap_many"})
 out = {}
 for r in csv.DictReader(open(sys.argv[1])):
     k = ALIAS.get(r["kernel"])
     if k and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
-        out[k] = int(round((2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024))
+        out[k] = out.get(k, 0) + int(round((2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024))
 json.dump({"structure": "default",
            "_note": "HBM bytes per launch (B=32 per MLP-stream launch; the index-stream launches cover 20 batches) from "
                     "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over bench.py's DEFAULT launch structure "

@@ -273,3 +273,24 @@ def test_classifier_step_returns_tensors_without_a_graph(cpu_mirrors):
     logits, loss = ClassifierStep(C, npoints=256)(points, torch.tensor([1, 2]))
     assert logits.grad_fn is None and loss.grad_fn is None
     assert graphs.held_accumulators(list(C.parameters())) == []
+
+
+def test_traffic_file_covers_exactly_the_kernels_the_default_bench_launches():
+    """bench.py's `roofline.traffic` is a committed constant (bench.py cannot run the profiler on itself): the PMC file it
+    reads must have been collected for the kernels the default configuration launches TODAY -- same set, this round's
+    file, default launch structure -- and the per-kernel bytes must be plausible against the algorithmic ones."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    path = os.path.join(root, "profiles", bench.TRAFFIC_FILE)
+    assert os.path.exists(path), f"profiles/{bench.TRAFFIC_FILE} missing: run scripts/collect_profiles.sh pmc"
+    tj = json.load(open(path))
+    assert tj["structure"] == "default"
+    assert sorted(tj["bytes_per_launch"]) == sorted(bench.DEFAULT_KERNELS)
+    ab = bench.algorithmic_bytes(bench.B_PER_GPU, fused=True)
+    for k in ("sa_fwd_main", "sa_bwd_main", "sa_prep_stats"):
+        ratio = tj["bytes_per_launch"][k] / ab[k]
+        assert 0.5 < ratio < 8.0, (k, ratio)
