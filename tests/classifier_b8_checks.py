@@ -85,7 +85,9 @@ def run_g18(model, dev, golden, grad_bar):
         want = golden[f"g18_grad/{name}"]
         grads[name] = _rel_sampled(g[idx], want, float(golden[f"g18_gnorm/{name}"]), g.size, floor)
         moved = (q.detach() - before[name]).cpu().numpy().reshape(-1)[idx]
-        sure = np.abs(want) > 10 * grad_bar * np.sqrt(np.mean(want.astype(np.float64) ** 2))
+        # (an analytic-zero gradient -- see norm_floor -- is rounding noise on both sides: its signs are not "sure")
+        rms = max(float(np.sqrt(np.mean(want.astype(np.float64) ** 2))), floor / g.size ** 0.5)
+        sure = np.abs(want) > 10 * grad_bar * rms
         checked += int(sure.sum())
         mismatch += int((np.abs(moved[sure] - golden[f"g18_step/{name}"][sure]) > 2e-6).sum())
     bn = max(_rel(b.detach().cpu().numpy(), golden[f"g18_bn/{n}"]) for n, b in model.named_buffers() if n.endswith("running_mean"))

@@ -191,11 +191,17 @@ def test_gan_step_matches_reference_trainer(dev, golden_ap, fused):
     # fp32 layers head 5.5e-6, embedding 4.1e-2 (MIOpen's convolution gradients are the less accurate ones).
     assert errs["gen"] < 1e-5 and errs["losses"] < 1e-5 and errs["fc3"] < 1e-4
     assert errs["head"] < (5e-4 if fused else 1e-4) and errs["embed"] < (5e-3 if fused else 8e-2)
-    # Adam's first step moves every weight by lr * sign(grad): the updated tensors agree wherever the sign does
-    after = G.predict_prob_layer.embedding.net[0].weight.detach().cpu().numpy()
-    assert (np.abs(after - golden_ap["g11_embed_w_after"]) < 1e-5).mean() > 0.97
-    after = D.fc3.parametrizations.weight.original.detach().cpu().numpy()
-    assert (np.abs(after - golden_ap["g11_fc3_after"]) < 1e-5).mean() > 0.97
+    # Adam's first step moves every weight by lr * sign(grad): EVERY weight whose reference gradient exceeds ten times the
+    # gradient bar of its tensor (x the tensor's rms) must land exactly where the reference's did (round 3: "97 % of the
+    # entries", which allowed 3 % arbitrarily far off)
+    for after, name_after, name_grad, bar in (
+            (G.predict_prob_layer.embedding.net[0].weight, "g11_embed_w_after", "g11_grad_embed_w", 5e-3 if fused else 8e-2),
+            (D.fc3.parametrizations.weight.original, "g11_fc3_after", "g11_grad_fc3", 1e-4)):
+        gref = golden_ap[name_grad]
+        sure = np.abs(gref) > 10 * bar * np.sqrt(np.mean(gref.astype(np.float64) ** 2))
+        assert sure.sum() >= 0.3 * sure.size or bar > 1e-2, (name_grad, int(sure.sum()), sure.size)
+        off = np.abs(after.detach().cpu().numpy() - golden_ap[name_after])[sure]
+        assert (off < 1e-5).all(), (name_after, int((off >= 1e-5).sum()), int(sure.sum()))
 
 
 def test_gan_step_full_size_runs(dev):
@@ -236,6 +242,8 @@ def test_classifier_step_matches_reference_trainer(dev, golden_ap, fused):
     print("train_one_epoch step vs reference golden (fused=%s):" % fused, {k: "%.2e" % v for k, v in errs.items()})
     # measured: unfused logits 1e-4 / loss 3e-5; fused 2e-3 / 5e-4 (four fused stages' discontinuities at B=2)
     assert errs["logits"] < (1e-2 if fused else 1e-3) and errs["loss"] < (2e-3 if fused else 2e-4) and errs["bn"] < 1e-5
+    # (the updated weights are held to the reference entry by entry at B = 8, where per-parameter gradients are pinned:
+    # test_classifier_iteration_at_b8_matches_reference_trainer; G13 at B = 2 stores no gradient to say which signs are sure)
     assert errs["head_sign_agree"] > 0.95
 
 
@@ -365,7 +373,9 @@ def test_gan_step_at_the_size_the_reference_trains_at(dev):
     assert errs["head"] < 6e-2 and errs["embed"] < 0.2
 
 
-G18_BARS = {False: dict(logits=2e-3, loss=2e-4, grads=5e-2), True: dict(logits=2e-3, loss=2e-4, grads=5e-2)}
+# Measured (round 4): unfused logits 1.2e-5 / loss 4e-7 / worst parameter gradient 3.0e-3 on one box and 1.1e-2 on another
+# (MIOpen picks its convolution-gradient solvers per box); fused 2.1e-4 / 1.3e-5 / 1.4e-2 on both
+G18_BARS = {False: dict(logits=1e-4, loss=1e-5, grads=3e-2), True: dict(logits=1e-3, loss=1e-4, grads=4e-2)}
 
 
 @pytest.mark.parametrize("fused", [True, False])

@@ -315,43 +315,30 @@ def test_wide_eval_mode_and_ragged_tile_count(dev):
     assert torch.equal(before[0], bn1.running_mean) and torch.equal(before[1], bn2.running_var)
 
 
-def test_classifier_with_every_stage_fused(dev, golden):
+def test_classifier_with_every_stage_fused(dev, golden, golden_b8):
     """PointNextSClassifier(fused=True): stage 1 on the register-resident kernels, stages 2-4 on the
     width-generic ones, none unfused.  (1) eval mode against the REFERENCE model's golden logits (G5);
-    (2) training mode at B=8 against the unfused mirror: logits, loss, gradient direction.  (The
-    B=2 training-mode golden is not used here: the head's BatchNorm1d over TWO samples maps every
-    feature to +-gamma, i.e. it amplifies a 1e-5 difference between the two clouds' features without
-    bound -- 4e-2 observed for fused and 1e-4-level for unfused, both against the same golden.)"""
+    (2) training mode at B = 8 against the REFERENCE model's golden G17 -- logits, loss, input gradient and every
+    parameter's gradient in relative L2 (round 3 compared with the build's own unfused mirror, `cos >= 0.98`: the B = 2
+    training golden was unusable, its head BatchNorm1d over TWO samples maps every feature to +-gamma)."""
+    import classifier_b8_checks as K
     from adaptpoint_amd import set_abstraction as SA
     from adaptpoint_amd.pointnext import PointNextSClassifier, fill_parameters_by_name
     SA.FUSED_FALLBACKS.clear()
     m = fill_parameters_by_name(PointNextSClassifier(fused=True)).to(dev)
-    u = fill_parameters_by_name(PointNextSClassifier()).to(dev)
     pos = torch.from_numpy(GI.unit_sphere_cloud(2, 1024, seed=31)).to(dev)
     x = torch.cat([pos, pos[:, :, 1:2] - pos[:, :, 1:2].min(1, keepdim=True)[0]], -1).transpose(1, 2).contiguous()
     m.eval()
     with torch.no_grad():
         e_eval = float(np.abs(m({'pos': pos, 'x': x}).cpu().numpy() - golden["g5_logits_eval"]).max())
-    pos = torch.from_numpy(GI.unit_sphere_cloud(8, 1024, seed=5)).to(dev)
-    x = torch.cat([pos, pos[:, :, 1:2] - pos[:, :, 1:2].min(1, keepdim=True)[0]], -1).transpose(1, 2).contiguous()
-    gt = torch.arange(8, device=dev) % 15
-    for net in (m, u):
-        net.train()
-        for mod in net.modules():
-            if isinstance(mod, torch.nn.Dropout):
-                mod.p = 0.0
-    lm, lossm = m.get_logits_loss({'pos': pos, 'x': x}, gt)
-    lu, lossu = u.get_logits_loss({'pos': pos, 'x': x}, gt)
-    lossm.backward(); lossu.backward()
+    r = K.run_g17(fill_parameters_by_name(PointNextSClassifier(fused=True)), dev, golden_b8)
     assert not SA.FUSED_FALLBACKS, SA.FUSED_FALLBACKS            # nothing ran unfused
-    gm = torch.cat([q.grad.flatten() for q in m.parameters()])
-    gu = torch.cat([q.grad.flatten() for q in u.parameters()])
-    cos = torch.nn.functional.cosine_similarity(gm, gu, dim=0).item()
-    e_tr = float((lm - lu).abs().max())
-    print("all stages fused: eval logits vs reference golden %.2e; train B=8 vs unfused mirror: logits %.2e, "
-          "loss %.2e, grad cosine %.5f" % (e_eval, e_tr, abs(lossm.item() - lossu.item()), cos))
+    print("all stages fused: eval logits vs reference golden %.2e; train B=8 vs the reference's G17: logits %.2e, "
+          "loss %.2e, input gradient %.2e, parameter gradients median %.2e worst %.2e"
+          % (e_eval, r["logits"], r["loss"], r["grad_x"], float(np.median(list(r["grads"].values()))), max(r["grads"].values())))
     assert e_eval <= 2e-3
-    assert e_tr <= 1e-2 and abs(lossm.item() - lossu.item()) <= 2.5e-3 and cos >= 0.98
+    # measured: 2.3e-4 / 5.4e-6 / 1.3e-2 / median 9.4e-3, worst 1.8e-2 (bars as tests/test_gpu_pointnext.py G17_BARS[True])
+    assert r["logits"] < 1e-3 and r["loss"] < 5e-5 and r["grad_x"] < 4e-2 and max(r["grads"].values()) < 5e-2, K.worst(r["grads"])
 
 
 @pytest.mark.parametrize("cin,N,M,radius", [STAGES[0], STAGES[3]])

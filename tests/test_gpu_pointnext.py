@@ -35,37 +35,19 @@ def test_classifier_unfused_matches_reference_goldens(dev, golden):
     np.testing.assert_allclose(lt.detach().cpu().numpy(), golden["g5_logits_train"], rtol=1e-2, atol=5e-3)
     chk = np.array([xt.grad.double().sum().item(), xt.grad.double().abs().sum().item()])
     np.testing.assert_allclose(chk[1], golden["g5_grad_x_checksum"][1], rtol=2e-2)
-
-
-def test_classifier_fused_stage1_close_to_unfused(dev):
-    from adaptpoint_amd.pointnext import PointNextSClassifier, fill_parameters_by_name
-    a = fill_parameters_by_name(PointNextSClassifier()).to(dev)
-    b = fill_parameters_by_name(PointNextSClassifier(fused=True)).to(dev)
-    pos, x = _inputs(dev, b=8, seed=5)
-    gt = torch.arange(8, device=dev) % 15
-    for m in (a, b):
-        m.train()
-        for mod in m.modules():
-            if isinstance(mod, torch.nn.Dropout):
-                mod.p = 0.0
-    la, lossa = a.get_logits_loss({'pos': pos, 'x': x}, gt)
-    lb, lossb = b.get_logits_loss({'pos': pos, 'x': x}, gt)
-    lossa.backward(); lossb.backward()
-    # Stage 1 differs only by the rounding of the fused contraction; five more stages of
-    # train-mode BatchNorm at batch 8 on UNTRAINED weights amplify it.  Bars (observed): plain
-    # bf16 0.16 max on O(1) logits; the split-bf16 ("bf16x3") default is held to 1e-2.
-    from adaptpoint_amd import fused
-    tol = 1e-2 if getattr(fused, "PRECISION", "bf16") == "bf16x3" else 0.25
-    assert (la - lb).abs().max() <= tol and abs(lossa.item() - lossb.item()) <= tol / 4
-    ga = torch.cat([q.grad.flatten() for q in a.parameters()])
-    gb = torch.cat([q.grad.flatten() for q in b.parameters()])
-    cos = torch.nn.functional.cosine_similarity(ga, gb, dim=0).item()
-    assert cos >= 0.98, cos
+    # the signed sum too (round 3 computed it and never asserted it): measured against the sum of magnitudes, since the
+    # signed sum of this gradient is two orders smaller than that
+    assert abs(chk[0] - golden["g5_grad_x_checksum"][0]) <= 2e-2 * golden["g5_grad_x_checksum"][1]
 
 
 # Bars of the two tests below, by path: (logits, loss, input gradient, worst parameter gradient).  Measured values are
 # printed by the tests and recorded in DESIGN.md section 3.
-G17_BARS = {False: dict(logits=2e-3, loss=2e-4, grad_x=2e-2, grads=5e-2), True: dict(logits=2e-3, loss=2e-4, grad_x=2e-2, grads=5e-2)}
+# Measured (round 4): unfused logits 1.2e-5 / loss 8e-7 / input gradient 6.5e-4 / parameter gradients median 6e-4, worst
+# 1.6e-3 (MIOpen's convolution gradients); every stage fused: 2.3e-4 / 5.4e-6 / 1.3e-2 / median 9.4e-3, worst 1.8e-2 -- the
+# split-operand contraction moves ~1e-5 of the ReLU gates and pool winners of four stacked blocks, and at B = 8 every
+# BatchNorm spreads each switched gate over its whole channel.
+# (unfused gradient bars leave room for MIOpen's per-box solver choice: 1.1e-2 was seen on the sibling test G18)
+G17_BARS = {False: dict(logits=1e-4, loss=1e-5, grad_x=1e-2, grads=3e-2), True: dict(logits=1e-3, loss=5e-5, grad_x=4e-2, grads=5e-2)}
 
 
 @pytest.mark.parametrize("fused", [False, True])

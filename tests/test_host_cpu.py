@@ -222,15 +222,15 @@ def test_no_kernel_holds_packed_fp32_instructions_made_by_the_vectoriser():
     assert found.get("capi.o", (0, 0, 0))[2] == 2              # the probe does hold the failing form (forms 1 and 2)
 
 
-def test_profiles_index_names_every_round3_file():
-    """profiles/README.md says for each committed round-3 measurement which command made it and what it backs."""
+def test_profiles_index_names_every_round3_and_round4_file():
+    """profiles/README.md says for each committed round-3 / round-4 measurement which command made it and what it backs."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     text = open(os.path.join(root, "profiles", "README.md")).read()
-    named = set(re.findall(r"r03_[A-Za-z0-9_]+", text))
+    named = set(re.findall(r"r0[34]_[A-Za-z0-9_]+", text))
     missing = []
     for f in sorted(os.listdir(os.path.join(root, "profiles"))):
-        if not f.startswith("r03_"):
+        if not (f.startswith("r03_") or f.startswith("r04_")):
             continue
         stem = f.split(".")[0]
         if not any(stem == n or stem.startswith(n) for n in named):
