@@ -161,6 +161,13 @@ def build(workload, dev, batch=32, npoints=1024, fused=True, distributed=None, c
                 turn[0] += 1
             job.gan_step.grad_sync = both
     job.points = _clouds(batch, npoints, dp.shard_seed(seed, rank)).to(dev)
+    # More than 1024 points: the classifier iteration resamples (FPS to 1200, a random 1024 of them; train_autoaug.py:481-501).
+    # The reference draws the subset on the host per batch (np.random.choice); here ONE draw per job, kept on the device, so
+    # that the step stays capturable (no host-to-device copy inside it) -- the bench line says so.
+    job.choice = None
+    if npoints > 1024 and workload in ("classifier", "adaptpoint"):
+        import numpy as np
+        job.choice = torch.from_numpy(np.random.RandomState(1000 + seed).choice(min(1200, npoints), 1024, False).astype(np.int32)).to(dev)
     job.label = ((torch.arange(batch) + 3 * rank) % classes).to(dev)
     device_noise = (dev.type == "cuda") if noise_on_device is None else noise_on_device
 
@@ -174,7 +181,7 @@ def build(workload, dev, batch=32, npoints=1024, fused=True, distributed=None, c
                 # channel keeps the real cloud's height (Form_dataset_cls stores `points` with xyz replaced, :155)
                 pts = torch.cat([out['gen'], job.points[:, :, 3:]], -1)
         if workload in ("classifier", "adaptpoint"):
-            logits, loss = job.cls_step(pts, job.label, choice)
+            logits, loss = job.cls_step(pts, job.label, choice if choice is not None else job.choice)
             out['cls_loss'] = loss.detach()
         return out
     job.step = step

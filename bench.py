@@ -576,6 +576,8 @@ def workload_main(args, dev, world, rank, distributed):
                                "random-init weights", "global_batch": B_PER_GPU * world, "launch": launch,
                    "graph_nodes": nodes, "two_lane_joint_step": args.overlap == "on" and args.workload != "classifier",
                    "fused_fallbacks": sum(_sa.FUSED_FALLBACKS.values()),
+                   "resampler": ("FPS to 1200 + a random 1024 of them, the subset drawn ONCE per run and kept on the device "
+                                 "(the reference draws it per batch on the host)" if job.choice is not None else None),
                    "syncbn": job.syncbn,
                    "collectives_per_step": coll or None,
                    "parallelism": f"dp{world}" + (("+syncbn(classifier)" if job.syncbn else "") + "+flat-allreduce per network: "
