@@ -141,6 +141,8 @@ SIGNATURES = {
     "apn_spectral_norm_grad_many": [_c_int] + [_c_void_p] * 10,
     "apn_sa_sample_overlap": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 7,
     "apn_sa_sample_seq": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 8,
+    "apn_furthest_point_sampling_nested": [_c_int] * 3 + [_c_void_p] * 6,
+    "apn_sa_sample_seq_nested": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 9,
 }
 
 _lib = None

@@ -226,15 +226,34 @@ __global__ __launch_bounds__(W * 64) void fps_reg_kernel(FpsOrder o, int m,
 // critical path.  Three key slots rotate; slot (j+1)%3 is zeroed during step j, after
 // barrier j-1 proved that every wave finished reading it and before barrier j lets
 // anyone use it again.
-template <int W, int S>
+// NEST (the index pyramids: block k + 1 samples from block k's samples).  FPS is PROGRESSIVE: run on the first sample's
+// picks, in pick order, it returns picks 0, 1, 2, ... of that sample again -- pick j is the point of largest distance to
+// picks 0 .. j-1 over ALL points, it lies in the sample, so it is also the largest over the sample, and the running
+// minima are the same float operations on the same coordinates.  That holds whenever every arg-max was UNIQUE; among
+// equal maxima the winner depends on the tie rule, which is positional (bit-reversed thread id) and differs between the
+// two arrays.  So the step also records the FIRST step at which its maximum was not unique (or was 0: the cloud is
+// exhausted): tie_out[cloud].  A following level of m' <= that many picks IS the prefix 0 .. m'-1 and costs a copy
+// (tie_prev given and tie_prev[cloud] >= m); any other cloud runs the full sampler, bit-exact as ever.
+template <int W, int S, bool NEST = false>
 __device__ __forceinline__ void fps_atomic_body(const FpsOrder &o, int m,
                                                 const float *__restrict__ xyz,
                                                 float *__restrict__ temp,
                                                 int *__restrict__ idxs,
                                                 float *__restrict__ new_xyz, int cloud,
-                                                float4 *tab /* LDS [n] {x, y, z, id} by priority rank */) {
+                                                float4 *tab /* LDS [n] {x, y, z, id} by priority rank */,
+                                                const int *__restrict__ tie_prev = nullptr,
+                                                int *__restrict__ tie_out = nullptr) {
     __shared__ unsigned long long slot[3];
+    __shared__ int tie_first;
     const int n = o.n;
+    if (NEST && tie_prev && tie_prev[cloud] >= m) {       // workgroup-uniform: the prefix of the previous level's picks
+        const float *src = xyz + (size_t)cloud * n * 3;
+        for (int i = threadIdx.x; i < m; i += W * 64) idxs[(size_t)cloud * m + i] = i;
+        for (int i = threadIdx.x; i < m * 3; i += W * 64) new_xyz[(size_t)cloud * m * 3 + i] = src[i];
+        if (threadIdx.x == 0 && tie_out) tie_out[cloud] = tie_prev[cloud];
+        return;
+    }
+    int my_tie = 0x7fffffff;                                // wave-uniform: this wave's first ambiguous step
     xyz += (size_t)cloud * n * 3;
     if (temp) temp += (size_t)cloud * n;   // null: start from 1e10 everywhere, no write-back
     idxs += (size_t)cloud * m;
@@ -260,6 +279,7 @@ __device__ __forceinline__ void fps_atomic_body(const FpsOrder &o, int m,
     }
     constexpr unsigned long long FPS_KEY_NONE = 0x00000000FFFFFFFFull;       // (distance +0.0, rank 0)
     if (tid < 3) slot[tid] = FPS_KEY_NONE;
+    if (NEST && tid == 0) tie_first = 0x7fffffff;
     float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
     if (tid == 0) {
         idxs[0] = 0;
@@ -288,6 +308,14 @@ __device__ __forceinline__ void fps_atomic_body(const FpsOrder &o, int m,
             }
         }
         const unsigned wmax = wave_max_u32(best);
+        bool wave_tie = false;                             // this wave holds its maximum more than once (wave-uniform)
+        if (NEST) {
+            int c = 0;
+#pragma unroll
+            for (int s = 0; s < S; ++s) c += dmin[s] == wmax ? 1 : 0;
+            const unsigned long long once = __ballot(c >= 1), twice = __ballot(c >= 2);
+            wave_tie = twice != 0ull || (once & (once - 1ull)) != 0ull;
+        }
         if (best == wmax && best != 0u) {
             // hand-issued so that the compiler's atomic optimizer does not wrap the (almost
             // always single-lane) atomic in a scalar reduction loop.  A wave whose maximum is +0.0 stays out: every
@@ -306,6 +334,13 @@ __device__ __forceinline__ void fps_atomic_body(const FpsOrder &o, int m,
         const unsigned rank = 0xFFFFFFFFu - (unsigned)k;               // (an untouched slot holds FPS_KEY_NONE: rank 0)
         const float4 w = tab[rank];
         x1 = w.x; y1 = w.y; z1 = w.z;
+        if (NEST) {
+            // the winning distance was held more than once: inside its owner's wave, or by another wave too; or it is 0
+            const unsigned wdist = (unsigned)(k >> 32);
+            const int owner_wave = (int)((rank / (unsigned)S) >> 6);
+            const bool amb = wdist == 0u || (wmax == wdist && (wave_tie || owner_wave != (tid >> 6)));
+            if (amb && j < my_tie) my_tie = j;
+        }
         if (tid == 0) idxs[j] = __float_as_int(w.w);
         if (new_xyz && tid >= (W - 1) * 64 && tid < (W - 1) * 64 + 3) {
             const int d = tid - (W - 1) * 64;
@@ -319,6 +354,21 @@ __device__ __forceinline__ void fps_atomic_body(const FpsOrder &o, int m,
         const int q = tid * S + s;
         if (temp && q < n) temp[__float_as_int(tab[q].w)] = __uint_as_float(dmin[s]);
     }
+    if (NEST && tie_out) {
+        if ((tid & 63) == 0 && my_tie != 0x7fffffff) atomicMin(&tie_first, my_tie);
+        __syncthreads();
+        if (tid == 0) tie_out[cloud] = tie_first;
+    }
+}
+
+// The pyramid's sampler (see NEST above): level 1 with tie_prev == null records the first ambiguous step; deeper levels
+// take the previous level's record and are a copy wherever it allows.
+template <int W, int S>
+__global__ __launch_bounds__(W * 64) void fps_nested_kernel(FpsOrder o, int m, const float *__restrict__ xyz,
+                                                            const int *__restrict__ tie_prev, int *__restrict__ idxs,
+                                                            float *__restrict__ new_xyz, int *__restrict__ tie_out) {
+    extern __shared__ float4 tab[];
+    fps_atomic_body<W, S, true>(o, m, xyz, nullptr, idxs, new_xyz, blockIdx.x, tab, tie_prev, tie_out);
 }
 
 template <int W, int S>
@@ -640,6 +690,59 @@ extern "C" int apn_furthest_point_sampling_xyz(int b, int n, int m, const float 
     if (n > 16384 || !new_xyz) return APN_EINVAL;
     static const int env_waves = [] { const char *e = getenv("APN_FPS_WAVES"); return e ? atoi(e) : 0; }();
     return fps_impl(b, n, m, xyz, temp, idxs, new_xyz, env_waves, fps_default_algo(), stream);
+}
+
+namespace apn {
+__global__ __launch_bounds__(256) void fps_fill_int_kernel(int *__restrict__ p, int v, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+template <int W>
+static int launch_nested(const FpsOrder &o, int b, int m, const float *xyz, const int *tie_prev, int *idxs, float *new_xyz,
+                         int *tie_out, hipStream_t st) {
+    const int need = (o.n + W * 64 - 1) / (W * 64);
+#define APN_FPSN_CASE(SS)                                                                                              \
+    if (need <= SS) {                                                                                                  \
+        hipLaunchKernelGGL((fps_nested_kernel<W, SS>), dim3(b), dim3(W * 64), sizeof(float4) * o.n, st, o, m, xyz,     \
+                           tie_prev, idxs, new_xyz, tie_out);                                                          \
+        APN_LAUNCH_CHECK();                                                                                            \
+        return APN_OK;                                                                                                 \
+    }
+    APN_FPSN_CASE(1)
+    APN_FPSN_CASE(2)
+    APN_FPSN_CASE(4)
+    APN_FPSN_CASE(8)
+#undef APN_FPSN_CASE
+    return APN_EINVAL;
+}
+}  // namespace apn
+
+// FPS of an index PYRAMID's level (no reference counterpart: the reference runs the full sampler at every level,
+// pointnext.py:146 per block / generator_component4_15.py:406 per stage; the picks are the same, see NEST in the step).
+// xyz (B,n,3): level 1: the cloud; deeper: the previous level's sampled coordinates IN PICK ORDER.  tie_prev (B) or null:
+// the previous level's record; tie_out (B): this level's (first step whose arg-max was not unique, or INT_MAX).
+// Outside the LDS-atomic step's range (n <= 128, n > 4096) the full sampler runs and the record says 0 (never a prefix).
+extern "C" int apn_furthest_point_sampling_nested(int b, int n, int m, const float *xyz, const int *tie_prev, int *idxs,
+                                                  float *new_xyz, int *tie_out, void *stream) {
+    using namespace apn;
+    if (b < 0) return APN_EINVAL;
+    if (b == 0 || m <= 0) return APN_OK;
+    if (n <= 0 || m > n || !xyz || !idxs || !new_xyz || !tie_out) return APN_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 128 || n > 4096 || fps_default_algo() != 0) {
+        if (int rc = apn_furthest_point_sampling_xyz(b, n, m, xyz, nullptr, idxs, new_xyz, stream)) return rc;
+        hipLaunchKernelGGL(fps_fill_int_kernel, dim3((b + 255) / 256), dim3(256), 0, st, tie_out, 0, b);
+        APN_LAUNCH_CHECK();
+        return APN_OK;
+    }
+    const FpsOrder o = fps_order(n);
+    int w = n <= 256 ? 2 : n <= 512 ? 4 : 8;
+    if (b >= 256 && w == 8 && n <= 2048) w = 4;
+    switch (w) {
+    case 2: return launch_nested<2>(o, b, m, xyz, tie_prev, idxs, new_xyz, tie_out, st);
+    case 4: return launch_nested<4>(o, b, m, xyz, tie_prev, idxs, new_xyz, tie_out, st);
+    default: return launch_nested<8>(o, b, m, xyz, tie_prev, idxs, new_xyz, tie_out, st);
+    }
 }
 
 // FPS (+ sampled coordinates) of batch A and, in the same launch, the zero-filling ball query of

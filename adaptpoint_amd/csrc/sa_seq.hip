@@ -110,6 +110,19 @@ extern "C" int apn_sa_backward_seq(
 // stage of a block.  temp (B,N) is filled with 1e10 here (subsample.py:94); with temp == null (n <= 16384) the
 // sampler starts from 1e10 in registers and leaves no min-distances behind: one launch less.
 // geo / dd (optional, nsample == 32): apn_sa_point_geo's outputs.
+// The same for a level of an index PYRAMID (block k + 1 samples from block k's samples, in pick order): the sampler is
+// apn_furthest_point_sampling_nested -- a copy of the previous level's first m picks wherever that level's record
+// (tie_prev) says every arg-max up to there was unique, the full sampler elsewhere; tie_out: this level's record.
+extern "C" int apn_sa_sample_seq_nested(int b, int n, int m, float radius, int nsample, const float *xyz,
+                                        const int *tie_prev, int *tie_out, int *fidx, float *new_xyz, int *idx, void *geo,
+                                        void *dd, void *stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || !tie_out) return APN_EINVAL;
+    APN_TRY(apn_furthest_point_sampling_nested(b, n, m, xyz, tie_prev, fidx, new_xyz, tie_out, stream));
+    APN_TRY(apn_ball_query_zero(b, n, m, radius, nsample, new_xyz, xyz, idx, stream));
+    if (geo) APN_TRY(apn_sa_point_geo(b, n, m, nsample, radius, xyz, new_xyz, idx, geo, dd, stream));
+    return APN_OK;
+}
+
 extern "C" int apn_sa_sample_seq(int b, int n, int m, float radius, int nsample, const float *xyz,
                                  float *temp, int *fidx, float *new_xyz, int *idx, void *geo, void *dd,
                                  void *stream) {

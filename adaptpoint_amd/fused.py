@@ -453,6 +453,7 @@ class Sampling:
         self.geo = None          # (B,N,4) int64 occurrence statistics of the neighbourhoods (csrc/sa_geo.hip) and
         self.dd = None           # (B, 6 * slabs) float64 their second moments, for the register-resident kernels
         self.ready = None        # event recorded behind the index stage when it ran on another stream (graphs.wait_ready)
+        self.ties = None         # (B,) int32: the nested sampler's record (first step whose arg-max was not unique)
 
     def alloc_geo(self, n_points):
         if self.geo is None or self.geo.shape[1] != n_points:
@@ -473,6 +474,7 @@ class Sampling:
         v.tmap = None
         v.geo = v.dd = None
         v.ready = None
+        v.ties = None if self.ties is None else self.ties[lo:hi]
         if self.geo is not None:
             v.geo, v.dd = self.geo[lo:hi], self.dd[lo:hi]
         return v
@@ -497,10 +499,12 @@ def point_geo(p, new_p, idx, radius, out=None):
 
 
 @torch.no_grad()
-def sample_and_query(p, npoint, radius, nsample=K_NS, out=None, geo=False):
+def sample_and_query(p, npoint, radius, nsample=K_NS, out=None, geo=False, nested=False, ties=None):
     """FPS (+ gather of the sampled coordinates, one launch; pointnext.py:146-147) and ball
     query (group.py:245) on the current stream; geo=True: also the occurrence statistics the
-    register-resident fused block takes (`point_geo`)."""
+    register-resident fused block takes (`point_geo`).  nested=True (the levels of an index pyramid): the sampler
+    records its first non-unique arg-max in `Sampling.ties`, and with `ties` = the PREVIOUS level's record (p = that
+    level's new_p) the level is a copy of the first npoint picks wherever the record allows (csrc/fps.hip, NEST)."""
     p = p.contiguous()
     dev = p.device
     B, N, _ = p.shape
@@ -513,6 +517,21 @@ def sample_and_query(p, npoint, radius, nsample=K_NS, out=None, geo=False):
     elif geo and nsample == K_NS and smp.geo is not None:
         gptr, dptr = smp.geo.data_ptr(), smp.dd.data_ptr()
     call = _Launcher(dev)
+    if nested and N <= 4096:
+        if smp.ties is None:
+            smp.ties = torch.empty(B, dtype=torch.int32, device=dev)
+        if PER_KERNEL_LAUNCH:
+            call("apn_furthest_point_sampling_nested", B, N, npoint, p.data_ptr(), _ptr(ties), smp.fidx.data_ptr(),
+                 smp.new_p.data_ptr(), smp.ties.data_ptr())
+            call("apn_ball_query_zero", B, N, npoint, float(radius), nsample, smp.new_p.data_ptr(), p.data_ptr(),
+                 smp.idx.data_ptr())
+            if gptr is not None:
+                call("apn_sa_point_geo", B, N, npoint, nsample, float(radius), p.data_ptr(), smp.new_p.data_ptr(),
+                     smp.idx.data_ptr(), gptr, dptr)
+            return smp
+        call("apn_sa_sample_seq_nested", B, N, npoint, float(radius), nsample, p.data_ptr(), _ptr(ties), smp.ties.data_ptr(),
+             smp.fidx.data_ptr(), smp.new_p.data_ptr(), smp.idx.data_ptr(), gptr, dptr)
+        return smp
     if PER_KERNEL_LAUNCH:
         call("apn_furthest_point_sampling_xyz", B, N, npoint, p.data_ptr(), None,
              smp.fidx.data_ptr(), smp.new_p.data_ptr())

@@ -22,6 +22,11 @@ from .layers import inverse_distance_weights, three_interpolate, three_interpola
 from .pointset import PointsetGrouper
 
 
+# The four grouper stages sample from each other's samples: deeper stages through the nested sampler (a copy of the previous
+# stage's first picks wherever every arg-max was unique).  False: every stage runs the full sampler, as the reference does.
+NESTED_SAMPLING = True
+
+
 def index_points(points, idx):
     """points (B,N,C), idx (B,S[,K]) -> (B,S[,K],C)   (:74-90)."""
     B = points.shape[0]
@@ -156,9 +161,15 @@ class SAComponent(nn.Module):
         mark("imitator: embedding done")
         mark_grad(f, "backward: embedding output gradient formed")
         xyz_list, x_list = [xyz], [f]
+        ties = None
         for i in range(self.stages):
             f = self.extract_feat_list[i](f)
-            xyz, f = self.pointset_grouper_list[i](xyz, pointwise.transpose12(f))
+            part = None
+            if NESTED_SAMPLING and xyz.is_cuda and not xyz.requires_grad:
+                # stage i + 1 samples from stage i's samples: the nested sampler (same picks; csrc/fps.hip, NEST)
+                part = self.pointset_grouper_list[i].index(xyz, ties=ties, nested=True)
+                ties = part[3] if len(part) > 3 else None
+            xyz, f = self.pointset_grouper_list[i](xyz, pointwise.transpose12(f), index=part)
             xyz_list.append(xyz)
             x_list.append(f)
             mark(f"imitator: stage {i + 1} done")

@@ -53,6 +53,27 @@ def furthest_point_sample(xyz, npoint):
 
 
 @torch.no_grad()
+def furthest_point_sample_nested(xyz, npoint, ties=None):
+    """One level of a sampling PYRAMID (a block / stage that samples from the previous one's samples): FPS is
+    progressive -- on a sample's picks, in pick order, it returns picks 0, 1, 2, ... again as long as every arg-max was
+    unique -- so a deeper level is a copy wherever the previous level's record `ties` (B,) int32 says so, the full
+    sampler elsewhere (csrc/fps.hip, NEST): the same indices as `furthest_point_sample`, bit for bit.
+    xyz (B,N,3): the cloud (ties=None) or the previous level's `new_xyz`.  -> (picks (B,npoint) int32, new_xyz
+    (B,npoint,3) = xyz[picks], this level's record)."""
+    from .fused import _call
+    _need_contiguous(xyz=xyz)
+    if not xyz.is_cuda:
+        raise RuntimeError("adaptpoint_amd.layers needs CUDA/HIP tensors: the product path has no CPU fallback")
+    B, N = xyz.shape[:2]
+    picks = _alloc(xyz, B, npoint, dtype=torch.int32)
+    new_xyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device)
+    rec = torch.empty(B, dtype=torch.int32, device=xyz.device)
+    _call("apn_furthest_point_sampling_nested", xyz.device, B, N, npoint, xyz.data_ptr(),
+          None if ties is None else ties.data_ptr(), picks.data_ptr(), new_xyz.data_ptr(), rec.data_ptr())
+    return picks, new_xyz, rec
+
+
+@torch.no_grad()
 def ball_query(radius, nsample, xyz, new_xyz):
     """The first `nsample` points of xyz (B,N,3) inside the ball around each new_xyz (B,M,3),
     in index order, padded with the first hit; all-zero rows for empty balls: (B,M,nsample) int32

@@ -13,6 +13,10 @@ import torch.nn as nn
 
 from .set_abstraction import SetAbstraction
 
+# forward_cls_feat without a pyramid handed in builds one itself (nested sampler: blocks 2-4 sample from the previous
+# block's samples, which FPS returns as a prefix).  False: every block runs its own full sampler, as the reference does.
+NESTED_PYRAMID = True
+
 
 class PointNextEncoderS(nn.Module):
     """pointnext.py:338-441 for sa_layers=2, sa_use_res=True, one block per stage."""
@@ -59,13 +63,15 @@ class PointNextEncoderS(nn.Module):
         a pyramid running on a side stream is consumed level by level instead of as a whole."""
         from . import fused
         res, p = [], p0.contiguous()
+        ties = None          # block k + 1 samples from block k's samples: the nested sampler (csrc/fps.hip, NEST)
         for i, stage in enumerate(self.encoder):
             sa = stage[0]
             if sa.is_head or sa.all_aggr:
                 res.append(None)
                 continue
             smp = fused.sample_and_query(p, p.shape[1] // sa.stride, sa.grouper.radius, sa.grouper.nsample,
-                                         out=None if out is None else out[i], geo=sa._resident())
+                                         out=None if out is None else out[i], geo=sa._resident(), nested=True, ties=ties)
+            ties = smp.ties
             # tile map + inverse map of the neighbourhoods, for the blocks on the width-generic kernels
             sa.index_for(smp, p.shape[1], sa.convs[0][0].in_channels - 3, out=smp.index)
             if events:
@@ -93,6 +99,10 @@ class PointNextEncoderS(nn.Module):
             p0, f0 = p0['pos'], p0.get('x', None)
         if f0 is None:
             f0 = p0.clone().transpose(1, 2).contiguous()
+        if pyramid is None and p0.is_cuda and NESTED_PYRAMID:
+            # the index stages of all blocks first (coordinates only; gradients reach p0 through the blocks' own
+            # differentiable gathers): deeper levels then cost a copy instead of a sampler chain
+            pyramid = self.index_pyramid(p0.detach())
         for i, stage in enumerate(self.encoder):
             smp = None if pyramid is None else pyramid[i]
             if smp is not None and getattr(smp, 'ready', None) is not None:

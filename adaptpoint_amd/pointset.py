@@ -87,11 +87,17 @@ class PointsetGrouper(nn.Module):
             self.affine_beta = nn.Parameter(torch.zeros([1, 1, 1, channel]))
 
     @torch.no_grad()
-    def index(self, xyz):
+    def index(self, xyz, ties=None, nested=False):
         """The stage's index work -- a function of the coordinates alone: (fps_idx (B,np), new_xyz (B,np,3),
-        idx (B,np,K)).  `forward(..., index=...)` takes it, so a caller can run it ahead of the features (the imitator
-        does, on a side stream)."""
+        idx (B,np,K)).  `forward(..., index=...)` takes it, so a caller can run it ahead of the features.
+        nested=True (the imitator's four stages sample from each other's samples): the nested sampler
+        (`layers.furthest_point_sample_nested`; same picks, a copy of the previous stage's first np picks wherever its
+        record `ties` allows) -- the tuple then carries this stage's record as a fourth element."""
         xyz = xyz.contiguous()
+        if nested and xyz.is_cuda and xyz.shape[1] <= 4096:
+            from .layers import furthest_point_sample_nested
+            fps_idx, new_xyz, rec = furthest_point_sample_nested(xyz, xyz.shape[1] // self.reduce, ties)
+            return fps_idx, new_xyz, ball_query(self.radi, self.kneighbors, xyz, new_xyz), rec
         fps_idx = furthest_point_sample(xyz, xyz.shape[1] // self.reduce)               # :406
         new_xyz = torch.gather(xyz, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3))   # :407
         idx = ball_query(self.radi, self.kneighbors, xyz, new_xyz)                       # :412
@@ -101,7 +107,7 @@ class PointsetGrouper(nn.Module):
         """xyz (B,N,3), points (B,N,C) -> new_xyz (B,np,3), new_points (B,C,np)."""
         xyz = xyz.contiguous()
         if index is not None and not xyz.requires_grad:
-            fps_idx, new_xyz, idx = index
+            fps_idx, new_xyz, idx = index[:3]
         else:
             fps_idx = furthest_point_sample(xyz, xyz.shape[1] // self.reduce)               # :406
             new_xyz = torch.gather(xyz, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3))   # :407

@@ -339,6 +339,19 @@ APN_API int apn_sa_sample_overlap(int b, int n, int m, float radius, int nsample
                                   const float *xyz_a, int *fidx_a, float *new_xyz_a,
                                   const float *xyz_b, const float *new_xyz_b, int *idx_b,
                                   void *stream);
+/* FPS of one level of an index PYRAMID (no reference counterpart: the reference runs the full sampler at every level --
+ * pointnext.py:146 per block, models_adaptpoint/generator_component4_15.py:406 per stage -- with the same result).
+ * FPS is progressive: run on a sample's picks in pick order it returns picks 0, 1, 2, ... again whenever every arg-max
+ * was unique.  xyz (B,n,3): the cloud (level 1) or the previous level's sampled coordinates in pick order; tie_prev (B)
+ * or null: the previous level's record; tie_out (B): the first step whose arg-max was not unique (INT_MAX: none; 0: not
+ * recorded).  A cloud with tie_prev[cloud] >= m gets idxs = 0 .. m-1 and a copy of its first m rows; any other cloud
+ * the full sampler.  idxs (B,m) int32, new_xyz (B,m,3). */
+APN_API int apn_furthest_point_sampling_nested(int b, int n, int m, const float *xyz, const int *tie_prev, int *idxs,
+                                               float *new_xyz, int *tie_out, void *stream);
+/* apn_sa_sample_seq (below) with the nested sampler: one level of an index pyramid. */
+APN_API int apn_sa_sample_seq_nested(int b, int n, int m, float radius, int nsample, const float *xyz,
+                                     const int *tie_prev, int *tie_out, int *fidx, float *new_xyz, int *idx, void *geo,
+                                     void *dd, void *stream);
 /* Index stage: temp := 1e10, FPS (+ sampled coordinates), ball query (zero-filling) and, with geo != NULL,
  * apn_sa_point_geo.  temp may be NULL (no min-distances kept).  n <= 16384 (the register-resident sampler; larger
  * clouds: apn_furthest_point_sampling + apn_ball_query). */
