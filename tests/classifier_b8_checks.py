@@ -23,29 +23,38 @@ def _rel(a, b):
 
 
 def norm_floor(golden, prefix):
-    """Gradients below 1e-4 of the median parameter-gradient norm are analytic zeros -- e.g. the shift of the last stage's
-    BatchNorm, whose effect the batch-normalised head removes (reference norm 2e-7 against 0.14 .. 25 for all others): both
-    sides hold rounding noise there, so their difference is measured against this floor instead of against the noise."""
-    return 1e-4 * float(np.median([float(golden[k]) for k in golden.files if k.startswith(f"{prefix}_gnorm/")]))
+    """Gradients below 1e-3 of the median parameter-gradient norm are analytic zeros -- a per-channel shift in front of a
+    training-mode BatchNorm (the last stage's BatchNorm shift ahead of the batch-normalised head: reference norm 2e-7 against
+    0.14 .. 25 for all others; in the generator every convolution bias and grouper `affine_beta` ahead of a BatchNorm:
+    1e-11 .. 1.3e-7 against 1.7e-5 .. 3e-2).  Both sides hold rounding noise there: such a parameter is not held to a
+    relative bar; it must stay what it is -- below 1e-2 of the median norm (`gradient_errors` reports it under "zero: ").
+    (The gap between the two groups is two decades or more in every golden.)"""
+    return 1e-3 * float(np.median([float(golden[k]) for k in golden.files if k.startswith(f"{prefix}_gnorm/")]))
 
 
-def _rel_sampled(got, want, full_norm, numel, floor):
-    """relative L2 over the sampled entries, the reference norm floored (scaled to the sample's share of the tensor)"""
+def _rel_sampled(got, want):
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
-    share = (want.size / numel) ** 0.5
-    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), floor * share, 1e-300))
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300))
 
 
 def gradient_errors(model, golden, prefix):
-    """{parameter name: relative L2 of its gradient against the golden's sampled entries}, and the same for the norms."""
+    """({parameter name: relative L2 of its gradient against the golden's sampled entries}, {name: relative error of its
+    norm}) over the parameters with a real gradient; an analytic zero (see norm_floor) appears as "zero: <name>" with its
+    norm over 1e-2 of the median norm (so that the same bars apply: it must stay below 1)."""
     errs, norms = {}, {}
     floor = norm_floor(golden, prefix)
     for name, q in model.named_parameters():
+        if q.grad is None:
+            continue
         g = q.grad.detach().cpu().numpy().reshape(-1)
         want = golden[f"{prefix}_grad/{name}"]
         ref_norm = float(golden[f"{prefix}_gnorm/{name}"])
-        errs[name] = _rel_sampled(g[GI.gradient_sample_index(name, g.size)], want, ref_norm, g.size, floor)
-        norms[name] = abs(float(np.linalg.norm(g.astype(np.float64))) - ref_norm) / max(ref_norm, floor)
+        got_norm = float(np.linalg.norm(g.astype(np.float64)))
+        if ref_norm < floor:
+            errs["zero: " + name] = 1e-3 * got_norm / (10.0 * floor)        # < 1e-3 <=> the norm is below 1e-2 of the median
+            continue
+        errs[name] = _rel_sampled(g[GI.gradient_sample_index(name, g.size)], want)
+        norms[name] = abs(got_norm - ref_norm) / ref_norm
     return errs, norms
 
 
@@ -83,7 +92,10 @@ def run_g18(model, dev, golden, grad_bar):
         g = taps[name].cpu().numpy().reshape(-1)
         idx = GI.gradient_sample_index(name, g.size)
         want = golden[f"g18_grad/{name}"]
-        grads[name] = _rel_sampled(g[idx], want, float(golden[f"g18_gnorm/{name}"]), g.size, floor)
+        if float(golden[f"g18_gnorm/{name}"]) < floor:                      # an analytic zero: not held to a relative bar
+            grads["zero: " + name] = 1e-3 * float(np.linalg.norm(g.astype(np.float64))) / (10.0 * floor)
+        else:
+            grads[name] = _rel_sampled(g[idx], want)
         moved = (q.detach() - before[name]).cpu().numpy().reshape(-1)[idx]
         # (an analytic-zero gradient -- see norm_floor -- is rounding noise on both sides: its signs are not "sure")
         rms = max(float(np.sqrt(np.mean(want.astype(np.float64) ** 2))), floor / g.size ** 0.5)

@@ -649,6 +649,12 @@ def main_adaptpoint():
     g_loss.backward()
     g11_grad_embed = gen.predict_prob_layer.embedding.net[0].weight.grad.clone()
     g11_grad_head = gen.predict_prob_layer.head.prob_head[0].weight.grad.clone()
+    # (round 4) EVERY parameter's gradient of the generator step, sampled as the B = 8 classifier goldens are
+    for name, q in gen.named_parameters():
+        if q.grad is not None:
+            gq = q.grad.detach().numpy().reshape(-1)
+            out[f"g11_gen_grad/{name}"] = gq[GI.gradient_sample_index(name, gq.size)].copy()
+            out[f"g11_gen_gnorm/{name}"] = np.array(np.linalg.norm(gq.astype(np.float64)))
     opt_g.step()
     real_loss = bce(dis(input_pointcloud), real_label)
     fake_loss = bce(dis(gen_imgs.detach()), fake_label)
@@ -656,6 +662,11 @@ def main_adaptpoint():
     opt_d.zero_grad()
     d_loss.backward()
     g11_grad_fc3 = dis.fc3.parametrizations.weight.original.grad.clone()
+    for name, q in dis.named_parameters():
+        if q.grad is not None:
+            gq = q.grad.detach().numpy().reshape(-1)
+            out[f"g11_dis_grad/{name}"] = gq[GI.gradient_sample_index(name, gq.size)].copy()
+            out[f"g11_dis_gnorm/{name}"] = np.array(np.linalg.norm(gq.astype(np.float64)))
     opt_d.step()
     out.update(g11_seed=np.array(g11_seed), g11_pos_seed=np.array(g11_pos_seed),
                g11_head_margins=np.array([knn_gap, max_gap]), g11_gen=gen_imgs.detach().numpy(),
