@@ -863,6 +863,10 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             float wv[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) wv[k] = g.w2[tid + 256 * k];
+            float c1[4] = {0.f, 0.f, 0.f, 0.f};              // BatchNorm-1's constants of channel tid (threads 128..159)
+            if (tid >= 128 && tid < 160) {
+                c1[0] = g.scale1[tid - 128]; c1[1] = g.shift1[tid - 128]; c1[2] = g.mean1[tid - 128]; c1[3] = g.inv1[tid - 128];
+            }
             double sv = 0.0, count = g.count;                // S[tid] (threads 0..127: one column each)
             float p_sc = 0.0f, p_mu = 0.0f, p_iv = 0.0f;
             if (tid < 128) sv = g.sumsS ? g.sumsS[tid] : acc_read(g.accS, 128, tid);
@@ -883,6 +887,10 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) sw2[(tid + 256 * k) >> 5][tid & 31] = wv[k];
+            if (tid >= 128 && tid < 160) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) chan[k][tid - 128] = c1[k];
+            }
             // S2 (threads 64..127) meets S1 (threads 0..63) in the same wave's other half: lanes l and l + 64 are
             // different waves, so it goes through LDS (sqm is free until the barrier below)
             double *sS2 = reinterpret_cast<double *>(&sqm[0][0]);
@@ -953,13 +961,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             }
             put_frag<NS>(cfrag, F_QM, lane, pack8<NS>(qacc, 0));
             put_frag<NS>(cfrag, F_QM + 1, lane, pack8<NS>(qacc, 8));
-            if (h == 0) sqm[32][r] = eacc[0];                     // row 0 of the product = evec
-        }
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            chan[0][threadIdx.x] = g.scale1[threadIdx.x]; chan[1][threadIdx.x] = g.shift1[threadIdx.x];
-            chan[2][threadIdx.x] = g.mean1[threadIdx.x]; chan[3][threadIdx.x] = g.inv1[threadIdx.x];
-            chan[4][threadIdx.x] = sqm[32][threadIdx.x];
+            if (h == 0) chan[4][r] = eacc[0];                     // row 0 of the product = evec
         }
         __syncthreads();
         if (FX) {
