@@ -18,9 +18,11 @@ struct BnArgs {
 // {scale, shift, mean, invstd} of channel i from its float64 sum / sum of squares over `count` positions;
 // `writer` (one thread per channel in the whole grid) also updates the running buffers and leaves the four
 // values in pack[4][c] for the backward.
+// (g, b: the channel's gamma and beta, loaded by the caller TOGETHER with its first loads: read here, behind the fold's
+// barriers, they were one more dependent memory round trip in every consumer's prologue)
 __device__ __forceinline__ void bn_channel(const BnArgs &bn, int c, int i, double sum, double sumsq, double count,
-                                           bool writer, float *__restrict__ pack, float &scale, float &shift) {
-    const double g = bn.gamma ? (double)bn.gamma[i] : 1.0, b = bn.beta ? (double)bn.beta[i] : 0.0;
+                                           bool writer, float *__restrict__ pack, float &scale, float &shift,
+                                           double g, double b) {
     double mean, var;
     if (bn.training) {
         mean = sum / count;
@@ -44,6 +46,12 @@ __device__ __forceinline__ void bn_channel(const BnArgs &bn, int c, int i, doubl
         pack[2 * c + i] = (float)mean;
         pack[3 * c + i] = (float)inv;
     }
+}
+
+__device__ __forceinline__ void bn_channel(const BnArgs &bn, int c, int i, double sum, double sumsq, double count,
+                                           bool writer, float *__restrict__ pack, float &scale, float &shift) {
+    bn_channel(bn, c, i, sum, sumsq, count, writer, pack, scale, shift, bn.gamma ? (double)bn.gamma[i] : 1.0,
+               bn.beta ? (double)bn.beta[i] : 0.0);
 }
 
 }  // namespace apn

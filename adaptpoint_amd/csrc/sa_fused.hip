@@ -504,6 +504,11 @@ __device__ __forceinline__ void fold_rows32(const float *__restrict__ part, int 
     double *ftot = scratch + 16 * 64;
     const int tid = threadIdx.x;
     double count = bn.count;
+    double gpre = 1.0, bpre = 0.0;                 // requested with the partial rows, used behind the barriers
+    if (tid < 32) {
+        if (bn.gamma) gpre = (double)bn.gamma[tid];
+        if (bn.beta) bpre = (double)bn.beta[tid];
+    }
     if (bn.training) {
         if (part) {
             const int quad = tid & 15, rg = tid >> 4;
@@ -549,7 +554,7 @@ __device__ __forceinline__ void fold_rows32(const float *__restrict__ part, int 
     if (tid < 32) {
         if (tid == 0 && blockIdx.x == 0 && bn.training && bn.nbt) *bn.nbt += 1;
         bn_channel(bn, 32, tid, bn.training ? ftot[tid] : 0.0, bn.training ? ftot[32 + tid] : 0.0, count,
-                   blockIdx.x == 0, pack, scale, shift);
+                   blockIdx.x == 0, pack, scale, shift, gpre, bpre);
     }
 }
 

@@ -273,6 +273,11 @@ __global__ __launch_bounds__(QT * 16) void fwd_out_kernel(int n, int m, const fl
     const bool first = blockIdx.x == 0 && blockIdx.y == 0;
     wg_stamp(0);
     double count2 = bn2.count;
+    double g2pre = 1.0, b2pre = 0.0;               // requested with the first loads, used behind the barrier
+    if (threadIdx.x < 64) {
+        if (bn2.gamma) g2pre = (double)bn2.gamma[threadIdx.x];
+        if (bn2.beta) b2pre = (double)bn2.beta[threadIdx.x];
+    }
     if (bn2.training) {
         if (threadIdx.x < 128) ftot[threadIdx.x] = sums2 ? sums2[threadIdx.x] : acc_read(acc2, 128, threadIdx.x);
         if (sums2) count2 = sums2[128];
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(QT * 16) void fwd_out_kernel(int n, int m, const fl
         if (first && threadIdx.x == 0 && bn2.training && bn2.nbt) *bn2.nbt += 1;
         float sc, sh;
         bn_channel(bn2, 64, threadIdx.x, bn2.training ? ftot[threadIdx.x] : 0.0, bn2.training ? ftot[64 + threadIdx.x] : 0.0,
-                   count2, first, pack2, sc, sh);
+                   count2, first, pack2, sc, sh, g2pre, b2pre);
         s_sc[threadIdx.x] = sc;
         s_sh[threadIdx.x] = sh;
     }
@@ -419,10 +424,10 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
         const int c = (ty + NW * k) * HALVES + hh;
         tile[ql][c] = (m0 + ql < m && ov[k] > 0.0f) ? gv[k] : 0.0f;
     }
+    const float sc = pack2[tx], mu = pack2[128 + tx], iv = pack2[192 + tx];     // (requested in front of the barrier, not behind it)
     wg_stamp(1);
     __syncthreads();
     wg_stamp(2);
-    const float sc = pack2[tx], mu = pack2[128 + tx], iv = pack2[192 + tx];
     float s1 = 0.0f, s2 = 0.0f, gm = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {        // (query j, channel tx): coalesced over channels
