@@ -566,6 +566,39 @@ __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
     const size_t p0 = (size_t)cloud * n + n0;            // first point row of the tile
     const int q0 = block * WG_PTS;                       // first query row (flat)
     const int n_here = n - n0 < WG_PTS ? n - n0 : WG_PTS;
+    // every load of the tile is issued FIRST, before the constants' own chain (accumulator set -> barrier): they depend on
+    // nothing but the block's position (round 3 issued them behind that barrier: one more memory round trip, ~1.5 us of
+    // the kernel's 10); clamped rows, selected afterwards: under conditions each load sat in a block of its own
+    const int c_ld = tid & 31;
+    float a_f[PG_K] = {}, f_hi[PG_K], f_lo[PG_K], g_i[PG_K], h_a[PG_K], h_b[PG_K];
+    long long a_q[PG_K] = {};
+    {
+        const __bf16 *lo_tab = ft_lo ? ft_lo : ft;
+        const float *gip_tab = gip ? gip : HA;               // (no skip branch: any readable table, value unused)
+#pragma unroll
+        for (int k = 0; k < PG_K; ++k) {
+            const int pt = (tid >> 5) + (PG_NT / 32) * k;
+            const size_t pr = (p0 + (pt < n_here ? pt : 0)) * 32 + c_ld;
+            const size_t qr = (size_t)(q0 + pt < total_q ? q0 + pt : 0) * 32 + c_ld;
+            if (cells) a_q[k] = reinterpret_cast<const long long *>(A)[pr];
+            else a_f[k] = A[pr];
+            f_hi[k] = (float)ft[pr];
+            f_lo[k] = (float)lo_tab[pr];
+            g_i[k] = gip_tab[gip ? pr : qr];
+            h_a[k] = HA[qr];
+            h_b[k] = HB[qr];
+        }
+    }
+    float xq_v[2] = {0.0f, 0.0f};
+    long long geo_v = 0ll;
+    if (tid < WG_PTS * 3) {
+        const int pt = tid / 3, d = tid % 3;
+        xq_v[0] = xyz[(p0 + (pt < n_here ? pt : 0)) * 3 + d];
+        xq_v[1] = new_xyz[(size_t)(q0 + pt < total_q ? q0 + pt : 0) * 3 + d];
+    } else if (tid >= PG_NT - WG_PTS * 4) {
+        const int e = tid - (PG_NT - WG_PTS * 4), pt = e >> 2, j = e & 3;
+        geo_v = geo[(p0 + (pt < n_here ? pt : 0)) * 4 + j];
+    }
     for (int e = tid; e < 32 * 35; e += PG_NT) {
         const int mid = e / 35, col = e % 35;
         const float w = w1[e];
@@ -598,25 +631,6 @@ __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
         const int c = tid & 31;                           // fixed per thread: e = tid + 1024 k
         const float ca = sc[0][c], cb = sc[1][c], cc = sc[2][c];
         const double fx_inv = cells ? ldexp(1.0, -(int)cells[1]) : 0.0;
-        // every load of the tile is issued before the first one is used (clamped rows, selected afterwards): under
-        // conditions each sat in a block of its own and was waited for before the next was issued
-        float a_f[PG_K] = {}, f_hi[PG_K], f_lo[PG_K], g_i[PG_K], h_a[PG_K], h_b[PG_K];
-        long long a_q[PG_K] = {};
-        const __bf16 *lo_tab = ft_lo ? ft_lo : ft;
-        const float *gip_tab = gip ? gip : HA;               // (no skip branch: any readable table, value unused)
-#pragma unroll
-        for (int k = 0; k < PG_K; ++k) {
-            const int pt = (tid >> 5) + (PG_NT / 32) * k;
-            const size_t pr = (p0 + (pt < n_here ? pt : 0)) * 32 + c;
-            const size_t qr = (size_t)(q0 + pt < total_q ? q0 + pt : 0) * 32 + c;
-            if (cells) a_q[k] = reinterpret_cast<const long long *>(A)[pr];
-            else a_f[k] = A[pr];
-            f_hi[k] = (float)ft[pr];
-            f_lo[k] = (float)lo_tab[pr];
-            g_i[k] = gip_tab[gip ? pr : qr];
-            h_a[k] = HA[qr];
-            h_b[k] = HB[qr];
-        }
         const bool marked = cells && cells[2] != 0u;
 #pragma unroll
         for (int k = 0; k < PG_K; ++k) {
@@ -632,16 +646,14 @@ __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
     }
     if (tid < WG_PTS * 3) {
         const int pt = tid / 3, d = tid % 3;
-        const float xv = xyz[(p0 + (pt < n_here ? pt : 0)) * 3 + d];
-        const float qv = new_xyz[(size_t)(q0 + pt < total_q ? q0 + pt : 0) * 3 + d];
+        const float xv = xq_v[0], qv = xq_v[1];
         sB[pt][d] = pt < n_here ? xv : 0.0f;
         sB[pt][3 + d] = q0 + pt < total_q ? qv : 0.0f;
         sB[pt][38 + d] = 0.0f;                            // pad columns
     } else if (tid >= PG_NT - WG_PTS * 4) {               // (the last four waves: the first three take the rows above)
         const int e = tid - (PG_NT - WG_PTS * 4), pt = e >> 2, j = e & 3;
         // the index stage's occurrence statistics (sa_geo.hip): {count, sum of relative positions in units of 2^-36}
-        const long long got = geo[(p0 + (pt < n_here ? pt : 0)) * 4 + j];
-        const long long gv = pt < n_here ? got : 0ll;
+        const long long gv = pt < n_here ? geo_v : 0ll;
         sGeo[pt][j] = j == 0 ? (float)gv : (float)((double)gv * (1.0 / 68719476736.0));
     }
     wg_stamp(3);
