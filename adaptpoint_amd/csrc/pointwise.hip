@@ -30,6 +30,8 @@ namespace apn {
 constexpr int PW_T = 128;     // workgroup tile: 128 x 128 outputs, eight waves of 64 x 32
 constexpr int PW_KC = 32;     // contraction indices per chunk (two MFMA k-steps)
 constexpr int PW_ROW = 40;    // bf16 per LDS row: 32 + 8 pad (80-byte rows: 16 lanes' 16-byte reads cover all banks)
+constexpr int PW_TROW = 144;  // bf16 per LDS row of a row-contiguous operand's tile, kept [k][i] as it lies: 128 + 16 pad
+                              // (288-byte rows: the four 32-byte row pieces of a transposed read fall into distinct banks)
 
 struct PwOperand {
     const float *p;
@@ -46,27 +48,46 @@ struct PwGemm {
     int cpb;                  // chunks per batch entry = ceil(K / 32)
     int cps;                  // chunks per grid.z slice
     int total;                // chunks in all
-    int a_vec, b_vec;         // k-contiguous operand readable as float4
+    int a_vec, b_vec;         // operand readable as aligned float4 at 32-bit byte offsets (k-contiguous: along k;
+                              // row-contiguous: along the rows, which then come in whole quads: R resp. Q a multiple of 4)
     float *part;              // optional [(z * gridDim.x + x)][2][R]: this tile's row sums and M2 (squared deviations from the tile's row means)
     float *pool_val;          // optional [(z * gridDim.x + x)][R]: the tile's row maxima (D is then not written) ...
     int *pool_idx;            // ... and the column each was found at (the lowest one among equals)
 };
 
-// Loader roles of the 512 threads for one 128 x 32 operand chunk (8 values per thread), chosen so that every
-// wave-instruction reads whole 128-byte lines:
+// Loader roles of the 512 threads for one 128 x 32 operand chunk (8 values = two float4 per thread), chosen so that
+// every wave-instruction reads whole lines:
 //   k-contiguous operand (element (i, k) at i * ld + k): 8 lanes x float4 cover the 32 k of a row, a wave-instruction
 //     covers 8 rows; thread (seg = t & 7, rg = t >> 3) holds k = 4 seg .. 4 seg + 3 of rows rg and 64 + rg
 //     (a first version gave a thread 16 k of ONE row, 32 lines of 16 bytes per instruction: 3x slower end to end);
-//   row-contiguous operand (k * ld + i): the lane runs along i (64 consecutive floats per instruction), thread
-//     (i = t & 127, q = t >> 7) holds k = 8 q .. 8 q + 7 of row i.
-// Addresses are clamped into the operand (every load legal and unpredicated); staging zeroes what lies outside.
+//   row-contiguous operand (k * ld + i): 32 lanes x float4 cover the 128 rows at one k; thread (i4 = 4 (t & 31),
+//     kq = t >> 5) holds rows i4 .. i4 + 3 at k = kq and kq + 16, and the tile stays in LDS as it lies, [k][row]: the
+//     MFMA fragments come out of it by TRANSPOSED reads (pw_fragment).  Until round 4 such an operand was read value by
+//     value (lane along the rows, 8 loads of 4 bytes per thread) so that the tile could be written [row][k]: four times
+//     the vector-memory instructions, and their issue -- not the bytes -- is what the loads cost this kernel.
+//   The general form (a chunk that ends inside K, an operand that is not 16-byte regular) keeps value-by-value loads.
+// Addresses are clamped into the operand (every load legal and unpredicated).
 typedef float pw_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 pw_bf16x2 __attribute__((ext_vector_type(2)));
+#ifdef PW_STAMPS              // diagnostic builds (scripts/pw_stamps.py): wall-clock stamps of a workgroup's phases, by thread 0
+__device__ unsigned long long *d_pw_stamps = nullptr;
+__device__ __forceinline__ void pw_stamp(int k) {
+    unsigned long long *st = d_pw_stamps;
+    if (st && threadIdx.x == 0)
+        st[(blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 8 + k] = wall_clock64();
+}
+#else
+__device__ __forceinline__ void pw_stamp(int) {}
+#endif
+constexpr int PW_NLT = 512;                       // loader threads: all of the workgroup's
+constexpr int PW_LV = 128 * 32 / PW_NLT;          // values per thread, operand and chunk
+constexpr int PW_LJ = PW_LV / 4;                  // ... as float4s
+constexpr int PW_KCR = PW_NLT / 8;                // k-contiguous operand: rows between a thread's float4s
+constexpr int PW_RCK = PW_NLT / 32;               // row-contiguous operand: k between a thread's float4s
 
 // NS bf16 planes of the pair (a, b) as packed words (a in the low half): one v_cvt_pk_bf16_f32 per plane for BOTH
 // values, the remainders by one two-wide subtraction -- ~4.5 vector instructions per value instead of ~9 for the
-// value-by-value form (the split is the kernel's largest cost: at eight waves per CU its vector instructions, not
-// the MFMAs, bound the chunk)
+// value-by-value form
 template <int NS>
 __device__ __forceinline__ void pw_split_pair(float a, float b, unsigned (&pl)[NS]) {
     pw_f32x2 v = {a, b};
@@ -84,28 +105,61 @@ __device__ __forceinline__ void pw_split_pair(float a, float b, unsigned (&pl)[N
 
 template <bool KCONT>
 struct PwLoader {
-    int i0, kofs;            // KCONT: rg, 4 seg; else: i, 8 q
+    int i0, kofs;            // general form.  KCONT: rg, 4 seg; else: i, PW_LV q
     unsigned rows;           // bit j: row j of this thread lies inside the operand
+    int i4, kq;              // steady-state form of a row-contiguous operand: rows i4 .. i4 + 3 (one float4) at k = kq + PW_RCK j
+    bool quad;               // ... and whether that quad lies inside the operand (whole quads: lim % 4 == 0)
+    unsigned off[PW_LJ];     // steady-state form: byte offsets of this thread's float4s from the chunk's (uniform) origin
 
     __device__ __forceinline__ void init(int t, int origin, int lim) {
         if (KCONT) {
             i0 = t >> 3; kofs = 4 * (t & 7);
-            rows = (origin + i0 < lim ? 1u : 0u) | (origin + 64 + i0 < lim ? 2u : 0u);
+            rows = 0u;
+#pragma unroll
+            for (int j = 0; j < PW_LJ; ++j) rows |= origin + PW_KCR * j + i0 < lim ? 1u << j : 0u;
+            i4 = kq = 0; quad = false;
         } else {
-            i0 = t & 127; kofs = 8 * (t >> 7);
+            i0 = t & 127; kofs = PW_LV * (t >> 7);
             rows = origin + i0 < lim ? 1u : 0u;
+            i4 = 4 * (t & 31); kq = t >> 5;
+            quad = origin + i4 < lim;
         }
     }
-    // -> the number of leading k of this thread's values that lie inside the operand.  `full`: the chunk lies
-    // wholly inside K (wave-uniform): no clamping of the k indices (the common case; the address arithmetic is most
-    // of this function's instructions, and the kernel's VALU time is as large as its MFMA time)
+    // The steady-state loads (chunk wholly inside K, operand readable as float4): 16-byte loads whatever the layout -- a
+    // row-contiguous operand was read value by value until round 4 (a vector-memory instruction issued beside the
+    // matrix waves' MFMAs costs the loader ~60 cycles whatever its width) -- at 32-bit offsets that do not change
+    // from chunk to chunk, from an origin that is the same for the whole wave (a scalar register pair: no vector
+    // address arithmetic per chunk; the host checks that the operand's slice per batch entry is under 4 GB).
+    __device__ __forceinline__ void init_fast(const PwOperand &op, int origin, int lim) {
+#pragma unroll
+        for (int j = 0; j < PW_LJ; ++j) {
+            if (KCONT) {
+                const int i = origin + PW_KCR * j + i0;
+                off[j] = 4u * ((unsigned)(i < lim ? i : lim - 1) * (unsigned)op.ld + (unsigned)kofs);
+            } else {
+                off[j] = 4u * ((unsigned)(kq + PW_RCK * j) * (unsigned)op.ld + (unsigned)(quad ? origin + i4 : lim - 4));
+            }
+        }
+    }
+    // base: the batch entry's origin (uniform)
+    __device__ __forceinline__ void load_fast(const PwOperand &op, const float *__restrict__ base, int k0,
+                                              float (&v)[PW_LV]) const {
+        const char *org = reinterpret_cast<const char *>(base + (KCONT ? (size_t)k0 : (size_t)k0 * op.ld));
+#pragma unroll
+        for (int j = 0; j < PW_LJ; ++j) {
+            const float4 q = *reinterpret_cast<const float4 *>(org + off[j]);
+            v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+        }
+    }
+    // The general loads -> the number of leading k of this thread's values that lie inside the operand.  `full`: the
+    // chunk lies wholly inside K (wave-uniform): no clamping of the k indices
     __device__ __forceinline__ int load(const PwOperand &op, const float *__restrict__ base, int origin, int lim,
-                                        int k0, int K, int vec, bool full, float (&v)[8]) const {
+                                        int k0, int K, int vec, bool full, float (&v)[PW_LV]) const {
         const int kk = k0 + kofs, left = K - kk;
         if (KCONT) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = origin + 64 * j + i0;
+            for (int j = 0; j < PW_LJ; ++j) {
+                const int i = origin + PW_KCR * j + i0;
                 const float *src = base + (size_t)(i < lim ? i : lim - 1) * op.ld;
                 if (vec) {
                     const float4 q = *reinterpret_cast<const float4 *>(src + (full || kk < K - 4 ? kk : K - 4));
@@ -119,25 +173,19 @@ struct PwLoader {
         } else {
             const int i = origin + i0;
             const float *src = base + (i < lim ? i : lim - 1);
-            if (full) {
-                const float *row = src + (size_t)kk * op.ld;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = row[(size_t)j * op.ld];
-                return 8;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(kk + j < K ? kk + j : K - 1) * op.ld];
-            return left < 0 ? 0 : (left > 8 ? 8 : left);
+            for (int j = 0; j < PW_LV; ++j) v[j] = src[(size_t)(full || kk + j < K ? kk + j : K - 1) * op.ld];
+            return full ? PW_LV : (left < 0 ? 0 : (left > PW_LV ? PW_LV : left));
         }
     }
     // NS bf16 planes of every value (hi, the rounded remainder, (NS = 3) the remainder of that: 16 or 24 significant
-    // bits) into the LDS tile [plane][row][k]
+    // bits) into the LDS tile: [plane][row][k] for a k-contiguous operand, [plane][k][row] for a row-contiguous one
     template <int NS>
-    __device__ __forceinline__ void stage(__bf16 *tile, const float (&v)[8], int nk) const {
+    __device__ __forceinline__ void stage(__bf16 *tile, const float (&v)[PW_LV], int nk) const {
         if (KCONT) {
             typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < PW_LJ; ++j) {
                 bf16x4 pl[NS];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -149,76 +197,66 @@ struct PwLoader {
                         f -= (float)x;
                     }
                 }
-                __bf16 *dst = tile + (64 * j + i0) * PW_ROW + kofs;
+                __bf16 *dst = tile + (PW_KCR * j + i0) * PW_ROW + kofs;
 #pragma unroll
                 for (int p = 0; p < NS; ++p) *reinterpret_cast<bf16x4 *>(dst + p * PW_T * PW_ROW) = pl[p];
             }
         } else {
-            bf16x8 pl[NS];
             const int n = rows ? nk : 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < PW_LV; ++j) {
                 float f = j < n ? v[j] : 0.0f;
+                __bf16 *dst = tile + (kofs + j) * PW_TROW + i0;
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
                     const __bf16 x = (__bf16)f;
-                    pl[p][j] = x;
+                    dst[p * PW_T * PW_ROW] = x;
                     f -= (float)x;
                 }
             }
-            __bf16 *dst = tile + i0 * PW_ROW + kofs;
-#pragma unroll
-            for (int p = 0; p < NS; ++p) *reinterpret_cast<bf16x8 *>(dst + p * PW_T * PW_ROW) = pl[p];
         }
     }
-    // The same for a whole chunk (every k inside K), two values at a time.  ZERO_ROWS: rows outside the operand become
-    // zeros (needed for the B operand only: the statistics epilogue sums over the tile's columns; rows of A outside
-    // R produce rows of D that are never stored).
-    template <int NS, bool ZERO_ROWS>
-    __device__ __forceinline__ void stage_fast(__bf16 *tile, const float (&v)[8]) const {
-        if (KCONT) {
+    // The same for the steady-state form, two values at a time.  Rows outside the operand hold copies of its last rows
+    // (the clamped loads): rows of A outside R produce rows of D that are never stored, rows of B outside Q columns
+    // that every epilogue masks (the stores, the statistics' `valid`, the pooling's -inf).
+    template <int NS>
+    __device__ __forceinline__ void stage_fast(__bf16 *tile, const float (&v)[PW_LV]) const {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool in = !ZERO_ROWS || ((rows >> j) & 1u);
-                unsigned p01[NS], p23[NS];
-                pw_split_pair<NS>(in ? v[4 * j] : 0.0f, in ? v[4 * j + 1] : 0.0f, p01);
-                pw_split_pair<NS>(in ? v[4 * j + 2] : 0.0f, in ? v[4 * j + 3] : 0.0f, p23);
-                __bf16 *dst = tile + (64 * j + i0) * PW_ROW + kofs;
+        for (int j = 0; j < PW_LJ; ++j) {
+            unsigned p01[NS], p23[NS];
+            pw_split_pair<NS>(v[4 * j], v[4 * j + 1], p01);
+            pw_split_pair<NS>(v[4 * j + 2], v[4 * j + 3], p23);
+            __bf16 *dst = KCONT ? tile + (PW_KCR * j + i0) * PW_ROW + kofs : tile + (kq + PW_RCK * j) * PW_TROW + i4;
 #pragma unroll
-                for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2 *>(dst + p * PW_T * PW_ROW) = make_uint2(p01[p], p23[p]);
-            }
-        } else {
-            const bool in = !ZERO_ROWS || rows;
-            unsigned q[4][NS];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pw_split_pair<NS>(in ? v[2 * e] : 0.0f, in ? v[2 * e + 1] : 0.0f, q[e]);
-            __bf16 *dst = tile + i0 * PW_ROW + kofs;
-#pragma unroll
-            for (int p = 0; p < NS; ++p)
-                *reinterpret_cast<uint4 *>(dst + p * PW_T * PW_ROW) = make_uint4(q[0][p], q[1][p], q[2][p], q[3][p]);
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2 *>(dst + p * PW_T * PW_ROW) = make_uint2(p01[p], p23[p]);
         }
     }
 };
 
-// sums over the 32 lanes of a half-wave of 32 values per lane by recursive halving (31 exchanges instead of 160):
-// afterwards lane r holds the total of value r in v[0]
-template <int M>
-__device__ __forceinline__ void pw_halve_step(float (&v)[32], int r) {
-    const bool up = (r & M) != 0;
+// One operand fragment of a matrix wave -- rows blk .. blk + 31 (lane r its row), the eight k of half h of k-step s -- per
+// plane: one 16-byte read of a k-contiguous tile, or two transposed reads of a row-contiguous one (ds_read_b64_tr_b16:
+// a 16-lane group reads a block of 4 k-rows x 16 rows and every lane receives its row's 4 k; lane 4 q + p of a group
+// addresses k-row q, rows 4 p .. 4 p + 3).
+template <bool KCONT, int NS>
+__device__ __forceinline__ void pw_fragment(const __bf16 *tile, int blk, int s, int r, int h, bf16x8 (&f)[NS]) {
+    if (KCONT) {
+        const __bf16 *src = tile + (blk + r) * PW_ROW + s * 16 + h * 8;
 #pragma unroll
-    for (int j = 0; j < M; ++j) {
-        const float keep = up ? v[j + M] : v[j];
-        const float send = up ? v[j] : v[j + M];
-        v[j] = keep + __shfl_xor(send, M);
+        for (int p = 0; p < NS; ++p) f[p] = *reinterpret_cast<const bf16x8 *>(src + p * PW_T * PW_ROW);
+    } else {
+        typedef short tr_s4 __attribute__((ext_vector_type(4)));
+        typedef short tr_s8 __attribute__((ext_vector_type(8)));
+        typedef __attribute__((address_space(3))) tr_s4 tr_lds;
+        const int li = r & 15;
+        const __bf16 *src = tile + (s * 16 + h * 8 + (li >> 2)) * PW_TROW + blk + (r & 16) + 4 * (li & 3);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+            const tr_s4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds *)(src + p * PW_T * PW_ROW));
+            const tr_s4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds *)(src + p * PW_T * PW_ROW + 4 * PW_TROW));
+            const tr_s8 v8 = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            f[p] = __builtin_bit_cast(bf16x8, v8);
+        }
     }
-}
-
-__device__ __forceinline__ void pw_halving(float (&v)[32], int r) {
-    pw_halve_step<16>(v, r);
-    pw_halve_step<8>(v, r);
-    pw_halve_step<4>(v, r);
-    pw_halve_step<2>(v, r);
-    pw_halve_step<1>(v, r);
 }
 
 // NS = 2: products as hi*hi + hi*lo + lo*hi (three MFMAs, ~4e-6 of an fp32 contraction: the operands keep 16 bits);
@@ -230,7 +268,9 @@ __device__ __forceinline__ void pw_halving(float (&v)[32], int r) {
 template <int NS>
 constexpr int pw_lds_bytes() { return 2 * 2 * NS * PW_T * PW_ROW * 2 + 4 * 2 * PW_T * 4; }
 
-// the same halving for (maximum, column) pairs: the larger value wins, among equal values the lower column
+// maxima over the 32 lanes of a half-wave of 32 (value, column) pairs per lane by recursive halving (31 exchanges
+// instead of 160; afterwards lane r holds the result of pair r in v[0], ix[0]): the larger value wins, among equal values
+// the lower column
 template <int M>
 __device__ __forceinline__ void pw_halve_max_step(float (&v)[32], int (&ix)[32], int r) {
     const bool up = (r & M) != 0;
@@ -255,6 +295,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
     constexpr int TILE = NS * PW_T * PW_ROW;                       // bf16 per operand tile
     __bf16 *lds = reinterpret_cast<__bf16 *>(pw_lds);              // [buffer][A | B][plane][row][k]
     float (*red)[2][PW_T] = reinterpret_cast<float (*)[2][PW_T]>(pw_lds + 2 * 2 * TILE * 2);
+    pw_stamp(0);
     const int t = threadIdx.x, lane = t & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), wr = wave >> 2, wq = wave & 3;
     // XCD-aware tile numbers (gridDim.z a multiple of 8: one batch entry per z): workgroups w and w + 8 share an XCD and
@@ -279,27 +320,31 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
     if (c1 > g.total) c1 = g.total;
 
     f32x16 acc[2][2] = {{f32x16{0}, f32x16{0}}, {f32x16{0}, f32x16{0}}};
-    float va0[8], vb0[8], va1[8], vb1[8];
+    float va0[PW_LV], vb0[PW_LV], va1[PW_LV], vb1[PW_LV];
     int ka0 = 0, kb0 = 0, ka1 = 0, kb1 = 0;
     // chunks are fetched in order: (batch entry, chunk inside it) advance by counting, not by a division per fetch
     int fz = c0 / g.cpb, fk = c0 - fz * g.cpb;
-    auto fetch = [&](float (&xa)[8], float (&xb)[8], int &ka, int &kb) {
+    auto fetch = [&](float (&xa)[PW_LV], float (&xb)[PW_LV], int &ka, int &kb) {
         const int k0 = fk * PW_KC;
         const bool full = k0 + PW_KC <= g.K;
-        ka = la.load(g.A, g.A.p + g.A.batch * fz, R0, g.R, k0, g.K, g.a_vec, full, xa);
-        kb = lb.load(g.B, g.B.p + g.B.batch * fz, Q0, g.Q, k0, g.K, g.b_vec, full, xb);
+        ka = la.load(g.A, g.A.p + g.A.batch * fz, R0, g.R, k0, g.K, A_KC && g.a_vec, full, xa);
+        kb = lb.load(g.B, g.B.p + g.B.batch * fz, Q0, g.Q, k0, g.K, B_KC && g.b_vec, full, xb);
         if (++fk == g.cpb) { fk = 0; ++fz; }
     };
     // The steady-state form (every chunk whole, k-contiguous operands readable as float4 -- kernel-uniform): the SAME
     // loads in every step, issued unconditionally (past the slice's end the last chunk is read again and dropped).
     // With a conditional fetch the compiler cannot count the loads in flight: it waited for ALL of them (vmcnt(0))
     // before splitting the previous chunk, i.e. for the loads it had just issued -- a full memory round trip per chunk.
-    const bool fast = g.K % PW_KC == 0 && (!A_KC || g.a_vec) && (!B_KC || g.b_vec);
+    const bool fast = g.K % PW_KC == 0 && g.a_vec && g.b_vec;
+    if (fast) {
+        la.init_fast(g.A, R0, g.R);
+        lb.init_fast(g.B, Q0, g.Q);
+    }
     int fc = c0;
-    auto fetch_fast = [&](float (&xa)[8], float (&xb)[8]) {
+    auto fetch_fast = [&](float (&xa)[PW_LV], float (&xb)[PW_LV]) {
         const int k0 = fk * PW_KC;
-        (void)la.load(g.A, g.A.p + g.A.batch * fz, R0, g.R, k0, g.K, 1, true, xa);
-        (void)lb.load(g.B, g.B.p + g.B.batch * fz, Q0, g.Q, k0, g.K, 1, true, xb);
+        la.load_fast(g.A, g.A.p + g.A.batch * fz, k0, xa);
+        lb.load_fast(g.B, g.B.p + g.B.batch * fz, k0, xb);
         const int adv = fc + 1 < c1 ? 1 : 0;              // (selects, no branch: the step stays one basic block)
         fc += adv;
         fk += adv;
@@ -314,15 +359,9 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         bf16x8 a[2][2][NS], b[2][NS];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const __bf16 *pb = Bs + (wq * 32 + r) * PW_ROW + s * 16 + h * 8;
+            pw_fragment<B_KC, NS>(Bs, wq * 32, s, r, h, b[s]);
 #pragma unroll
-            for (int p = 0; p < NS; ++p) b[s][p] = *reinterpret_cast<const bf16x8 *>(pb + p * PW_T * PW_ROW);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const __bf16 *pa = As + (wr * 64 + j * 32 + r) * PW_ROW + s * 16 + h * 8;
-#pragma unroll
-                for (int p = 0; p < NS; ++p) a[s][j][p] = *reinterpret_cast<const bf16x8 *>(pa + p * PW_T * PW_ROW);
-            }
+            for (int j = 0; j < 2; ++j) pw_fragment<A_KC, NS>(As, wr * 64 + j * 32, s, r, h, a[s][j]);
         }
         // small terms first; (plane of A, plane of B) per term
         constexpr int TERMS = NS == 3 ? 6 : 3;
@@ -344,8 +383,8 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
     // FASTC: 0 = the general form; 1 = steady state, conditions on the slice's end kept; 2 = steady state with at
     // least two more chunks behind this one: no condition at all -- one basic block per step, in which the scheduler
     // is free to place the split phase's vector instructions between the MFMAs
-    auto step = [&](auto fastc, auto parc, int c, float (&fa)[8], float (&fb)[8], int &fka, int &fkb, float (&xa)[8],
-                    float (&xb)[8], int xka, int xkb) {
+    auto step = [&](auto fastc, auto parc, int c, float (&fa)[PW_LV], float (&fb)[PW_LV], int &fka, int &fkb,
+                    float (&xa)[PW_LV], float (&xb)[PW_LV], int xka, int xkb) {
         constexpr int FASTC = decltype(fastc)::value;
         constexpr bool FAST = FASTC != 0, FREE = FASTC == 2;
         constexpr int PAR = decltype(parc)::value;
@@ -355,8 +394,8 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         auto split = [&]() {
             if (FREE || c + 1 < c1) {
                 if (FAST) {
-                    la.template stage_fast<NS, false>(nxt, xa);
-                    lb.template stage_fast<NS, true>(nxt + TILE, xb);
+                    la.template stage_fast<NS>(nxt, xa);
+                    lb.template stage_fast<NS>(nxt + TILE, xb);
                 } else {
                     la.template stage<NS>(nxt, xa, xka);
                     lb.template stage<NS>(nxt + TILE, xb, xkb);
@@ -374,10 +413,11 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         fetch_fast(va1, vb1);
         {
             __bf16 *first = lds;
-            la.template stage_fast<NS, false>(first, va0);
-            lb.template stage_fast<NS, true>(first + TILE, vb0);
+            la.template stage_fast<NS>(first, va0);
+            lb.template stage_fast<NS>(first + TILE, vb0);
         }
         __syncthreads();
+        pw_stamp(1);
         // (two steps per iteration, BOTH unconditional -- an odd last step only fetches and meets the barrier: with the
         // second step under a condition the two register sets changed roles across the loop's back edge by copies, and
         // a copy of a load's destination waits for the load)
@@ -409,6 +449,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
 
 #pragma unroll
     for (int i = 0; i < 2; ++i) acc[i][0] += acc[i][1];
+    pw_stamp(2);
     const int q = Q0 + wq * 32 + r;
     if (g.pool_val) {
         // row maxima over the tile's columns instead of the tile: value 16 i + e of a lane <-> row
@@ -456,6 +497,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
             if (row < g.R && q < g.Q) D[(size_t)row * g.ldd + q] = acc[i][0][e];
         }
     }
+    pw_stamp(3);
     if (g.part) {
         // BatchNorm's statistics of this tile, per row (= channel): {sum, M2 = sum of squared deviations from the
         // TILE's mean} over its columns < Q -- not {sum, sum of squares}: E[y^2] - mean^2 loses mean^2 / var digits, and
@@ -463,32 +505,57 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
         // their spread.  Each wave's 32 columns are summed around a shift c = the row's value in the wave's first
         // column (any sample will do: the cancellation left is (mean - c)^2 / var = O(1)); the four waves' blocks and,
         // in pw_bn_act_kernel, the tiles are combined in float64 by the pairwise update of Chan et al.
-        // value 16 i + e of a lane <-> row 32 i + acc_row(e, h) of the wave; after the halving lane r holds the total
-        // of value r, i.e. row 32 (r >> 4) + acc_row(r & 15, h)
-        float (*cshift)[2][32] = reinterpret_cast<float (*)[2][32]>(pw_lds);                       // [wave][h][value]
-        float (*redc)[PW_T] = reinterpret_cast<float (*)[PW_T]>(pw_lds + 8 * 2 * 32 * 4);          // [wq][row]
-        float s1[32], s2[32];
-        const bool valid = q < g.Q;
+        // The wave's 64 x 32 block goes through LDS (the operand tiles are free behind the main loop's last barrier):
+        // written as it lies in the accumulators (lane = column), read back with lane = ROW -- every lane then sums
+        // its row's 32 columns itself.  (Until round 4 the sums were formed across the lanes: 94 lane exchanges and
+        // ~600 vector instructions per wave, 3.5-4 us of every forward contraction, a third of a small layer's.)
+        constexpr int SROW = 36;                                                                    // floats per row: 32 + 4 pad
+        float *ytile = reinterpret_cast<float *>(pw_lds) + wave * (64 * SROW);
+        float (*redc)[PW_T] = reinterpret_cast<float (*)[PW_T]>(pw_lds + 8 * 64 * SROW * 4);       // [wq][row]
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float y = acc[i][0][e];
-                const float c = __shfl(y, lane & 32);          // the half-wave's first column
-                if (r == 0) cshift[wave][h][16 * i + e] = y;
-                const float d = valid ? y - c : 0.0f;
-                s1[16 * i + e] = d;
-                s2[16 * i + e] = d * d;
-            }
+            for (int e = 0; e < 16; ++e) ytile[(i * 32 + acc_row(e, h)) * SROW + r] = acc[i][0][e];
         }
-        pw_halving(s1, r);
-        pw_halving(s2, r);
-        const int row = wr * 64 + (r >> 4) * 32 + acc_row(r & 15, h);
-        red[wq][0][row] = s1[0];
-        red[wq][1][row] = s2[0];
-        redc[wq][row] = cshift[wave][h][r];                   // (one wave's LDS operations execute in order)
+        int nw = g.Q - (Q0 + 32 * wq);                          // this block's columns inside Q (wave-uniform)
+        nw = nw < 0 ? 0 : (nw > 32 ? 32 : nw);
+        const float *src = ytile + lane * SROW;                 // (one wave's LDS operations execute in order)
+        const float c = src[0];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + 4 * j);
+            const float d0 = 4 * j < nw ? v.x - c : 0.0f, d1 = 4 * j + 1 < nw ? v.y - c : 0.0f;
+            const float d2 = 4 * j + 2 < nw ? v.z - c : 0.0f, d3 = 4 * j + 3 < nw ? v.w - c : 0.0f;
+            s1 += d0; s2 = __builtin_fmaf(d0, d0, s2);
+            s1 += d1; s2 = __builtin_fmaf(d1, d1, s2);
+            s1 += d2; s2 = __builtin_fmaf(d2, d2, s2);
+            s1 += d3; s2 = __builtin_fmaf(d3, d3, s2);
+        }
+        red[wq][0][wr * 64 + lane] = s1;
+        red[wq][1][wr * 64 + lane] = s2;
+        redc[wq][wr * 64 + lane] = c;
         __syncthreads();
-        if (t < PW_T && R0 + t < g.R) {
+        if (t < PW_T && R0 + t < g.R && Q0 + PW_T <= g.Q) {
+            // a tile wholly inside Q (workgroup-uniform): four blocks of 32 columns, every count a power of two -- the
+            // same combination without a division (the general form below makes sixteen float64 divisions per row:
+            // 1.5 of this epilogue's 4 us)
+            double mw[4], m2w[4], sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const double a = (double)red[w][0][t], b = (double)red[w][1][t];
+                mw[w] = (double)redc[w][t] + a * 0.03125;
+                m2w[w] = b - a * a * 0.03125;
+                sum += mw[w];
+            }
+            const double mean = sum * 0.25;
+            double m2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) m2 += m2w[w] + 32.0 * (mw[w] - mean) * (mw[w] - mean);
+            float *dst = g.part + ((size_t)z * gridDim.x + bxi) * 2 * g.R + R0 + t;
+            dst[0] = (float)(mean * 128.0);
+            dst[g.R] = (float)(m2 < 0.0 ? 0.0 : m2);
+        } else if (t < PW_T && R0 + t < g.R) {
             double n = 0.0, mean = 0.0, m2 = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -508,6 +575,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
             dst[g.R] = (float)(m2 < 0.0 ? 0.0 : m2);
         }
     }
+    pw_stamp(4);
 }
 
 // sum of one double per thread over the workgroup, returned to every thread
@@ -826,11 +894,26 @@ static int pw_weight_splits(int b, int c_in, int c_out, int n) {
     return (int)s;
 }
 
-static bool pw_vec(const float *p, long long batch, int ld, int K) {
-    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (batch % 4 == 0) && (ld % 4 == 0) && (K % 4 == 0);
+// k-contiguous operand (rows x K, element (i, k) at i * ld + k) readable as aligned float4 along k at 32-bit byte offsets
+static bool pw_vec(const float *p, long long batch, int ld, int K, int rows) {
+    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (batch % 4 == 0) && (ld % 4 == 0) && (K % 4 == 0) &&
+           (long long)rows * ld < (1ll << 29);
+}
+// the same for a row-contiguous operand (K x rows, element (i, k) at k * ld + i): float4 along its rows, whole quads
+static bool pw_vec_rows(const float *p, long long batch, int ld, int rows, int K) {
+    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (batch % 4 == 0) && (ld % 4 == 0) && (rows % 4 == 0) &&
+           ((long long)K + PW_KC) * ld < (1ll << 29);
 }
 
+
 }  // namespace apn
+
+#ifdef PW_STAMPS
+// (diagnostic builds only) attach a buffer of 8 stamps per workgroup for the next launches of the contraction kernel
+extern "C" __attribute__((visibility("default"))) int apn_pw_debug_stamps(void *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(apn::d_pw_stamps), &buf, sizeof(buf));
+}
+#endif
 
 extern "C" int apn_pw_conv_tiles(int b, int n) { return b * ((n + apn::PW_T - 1) / apn::PW_T); }
 
@@ -868,7 +951,7 @@ extern "C" int apn_pw_conv_forward(int b, int c_in, int c_out, int n, int precis
     g.D = y; g.d_batch = (long long)c_out * n; g.ldd = n;
     g.R = c_out; g.Q = n; g.K = c_in;
     g.cpb = (c_in + PW_KC - 1) / PW_KC; g.cps = g.cpb; g.total = b * g.cpb;
-    g.a_vec = pw_vec(w, 0, c_in, c_in); g.b_vec = 0;
+    g.a_vec = pw_vec(w, 0, c_in, c_in, c_out); g.b_vec = pw_vec_rows(x, g.B.batch, n, n, c_in);
     g.part = part;
     PW_LAUNCH(true, false, dim3((n + PW_T - 1) / PW_T, (c_out + PW_T - 1) / PW_T, b), g);
     APN_LAUNCH_CHECK();
@@ -919,6 +1002,7 @@ extern "C" int apn_pw_conv_grad_input(int b, int c_in, int c_out, int n, int pre
     g.D = gx; g.d_batch = (long long)c_in * n; g.ldd = n;
     g.R = c_in; g.Q = n; g.K = c_out;
     g.cpb = (c_out + PW_KC - 1) / PW_KC; g.cps = g.cpb; g.total = b * g.cpb;
+    g.a_vec = pw_vec_rows(w, 0, c_in, c_in, c_out); g.b_vec = pw_vec_rows(gy, g.B.batch, n, n, c_out);
     PW_LAUNCH(false, false, dim3((n + PW_T - 1) / PW_T, (c_in + PW_T - 1) / PW_T, b), g);
     APN_LAUNCH_CHECK();
     return APN_OK;
@@ -940,7 +1024,7 @@ extern "C" int apn_pw_conv_grad_weight(int b, int c_in, int c_out, int n, int pr
     g.D = scratch; g.d_batch = (long long)c_out * c_in; g.ldd = c_in;
     g.R = c_out; g.Q = c_in; g.K = n;
     g.cpb = (n + PW_KC - 1) / PW_KC; g.total = b * g.cpb; g.cps = (g.total + s - 1) / s;
-    g.a_vec = pw_vec(gy, g.A.batch, n, n); g.b_vec = pw_vec(x, g.B.batch, n, n);
+    g.a_vec = pw_vec(gy, g.A.batch, n, n, c_out); g.b_vec = pw_vec(x, g.B.batch, n, n, c_in);
     PW_LAUNCH(true, true, dim3((c_in + PW_T - 1) / PW_T, (c_out + PW_T - 1) / PW_T, s), g);
     APN_LAUNCH_CHECK();
     const size_t ne = (size_t)c_out * c_in;
@@ -965,7 +1049,7 @@ extern "C" int apn_pw_conv_max_forward(int b, int c_in, int c_out, int n, int pr
     g.B = PwOperand{x, (long long)c_in * n, n};
     g.R = c_out; g.Q = n; g.K = c_in;
     g.cpb = (c_in + PW_KC - 1) / PW_KC; g.cps = g.cpb; g.total = b * g.cpb;
-    g.a_vec = pw_vec(w, 0, c_in, c_in);
+    g.a_vec = pw_vec(w, 0, c_in, c_in, c_out); g.b_vec = pw_vec_rows(x, g.B.batch, n, n, c_in);
     g.pool_val = tile_val; g.pool_idx = tile_idx;
     PW_LAUNCH(true, false, dim3(tiles, (c_out + PW_T - 1) / PW_T, b), g);
     const int total = b * c_out;
@@ -1017,8 +1101,8 @@ extern "C" int apn_pw_contract(int nbatch, int r, int q, int k, const float *a, 
     g.R = r; g.Q = q; g.K = k;
     g.cpb = (k + PW_KC - 1) / PW_KC;
     g.total = nbatch * g.cpb;
-    g.a_vec = a_kcont && pw_vec(a, a_batch, lda, k);
-    g.b_vec = b_kcont && pw_vec(b, b_batch, ldb, k);
+    g.a_vec = a_kcont ? pw_vec(a, a_batch, lda, k, r) : pw_vec_rows(a, a_batch, lda, r, k);
+    g.b_vec = b_kcont ? pw_vec(b, b_batch, ldb, k, q) : pw_vec_rows(b, b_batch, ldb, q, k);
     int nz = nbatch;
     if (splits > 0) {
         g.D = scratch; g.d_batch = (long long)r * q; g.ldd = q;
