@@ -549,7 +549,8 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
     const int h0 = ty * HPW;
     // ---- phase 0: everything that does not depend on another load
     const int cnt = ok ? a.pcnt[ptc] : 0;
-    const int *__restrict__ l = a.plist + a.poff[ptc];
+    const int poff = a.poff[ptc];
+    const int *__restrict__ l = a.plist + poff;
     const float4 ge = *reinterpret_cast<const float4 *>(a.geo + ptc * 4);
     float ur[HPW];
 #pragma unroll
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
     } else if (O) {
         if (ty == 2)
             fill_batched<16>(O * C, [&](int e) { return a.ws[e]; }, [&](int e, float v) { Wss[(e / C) * C4 + e % C] = v; }, tx, 64);
-        else
+        else if (a.Wpart)
             fill_batched<16>(nq * O, [&](int e) { return a.gpre[(size_t)q0 * O + e]; },
                              [&](int e, float v) { gps[(e / O) * (O + 1) + e % O] = v; }, tx, 64);
     }
@@ -594,10 +595,17 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
     float acc[HPW];
 #pragma unroll
     for (int v = 0; v < HPW; ++v) acc[v] = 0.0f;
-    for (int i0 = 0; i0 < cnt; i0 += 4) {                      // four rows in flight
+    // A point's first PG_CAP rows are summed by its own lane; what a HOT point has beyond them (a point of a cluster of
+    // duplicates is a neighbour of every query around it: AdaptPoint's masked points collapse onto each other, and a list
+    // reaches M rows) is summed by the whole wave, lane = row -- with one lane per point the wave walked the longest of
+    // its 64 lists four rows per dependent round trip: 298 us for the classifier's second stage on generated clouds
+    // against 64 us on the real ones.  Fixed orders both (ascending rows, then a butterfly): bit-reproducible.
+    constexpr int PG_CAP = 32;
+    const int cnt_own = cnt < PG_CAP ? cnt : PG_CAP;
+    for (int i0 = 0; i0 < cnt_own; i0 += 4) {                  // four rows in flight
         int rr[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rr[u] = l[i0 + u < cnt ? i0 + u : cnt - 1];       // (clamped: the surplus is dropped)
+        for (int u = 0; u < 4; ++u) rr[u] = l[i0 + u < cnt_own ? i0 + u : cnt_own - 1];   // (clamped: the surplus is dropped)
         float4 x[4][HPW / 4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -607,12 +615,41 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i0 + u < cnt) {                       // (registers only: no load inside)
+            if (i0 + u < cnt_own) {                   // (registers only: no load inside)
 #pragma unroll
                 for (int v = 0; v < HPW / 4; ++v) {
                     acc[4 * v] += x[u][v].x; acc[4 * v + 1] += x[u][v].y; acc[4 * v + 2] += x[u][v].z; acc[4 * v + 3] += x[u][v].w;
                 }
             }
+        }
+    }
+    for (unsigned long long hot = __builtin_amdgcn_ballot_w64(cnt > PG_CAP); hot; hot &= hot - 1) {     // (wave-uniform)
+        const int src = __builtin_ctzll(hot);
+        const int pc = __builtin_amdgcn_readlane(cnt, src);
+        const int *__restrict__ pl = a.plist + __builtin_amdgcn_readlane(poff, src);
+        float part[HPW];
+#pragma unroll
+        for (int v = 0; v < HPW; ++v) part[v] = 0.0f;
+        for (int i0 = PG_CAP; i0 < pc; i0 += 64) {
+            const int i = i0 + tx;
+            const int row = pl[i < pc ? i : pc - 1];
+            const float4 *__restrict__ g = reinterpret_cast<const float4 *>(a.GU + (size_t)row * H + h0);
+            float4 x[HPW / 4];
+#pragma unroll
+            for (int v = 0; v < HPW / 4; ++v) x[v] = g[v];
+            if (i < pc) {
+#pragma unroll
+                for (int v = 0; v < HPW / 4; ++v) {
+                    part[4 * v] += x[v].x; part[4 * v + 1] += x[v].y; part[4 * v + 2] += x[v].z; part[4 * v + 3] += x[v].w;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < HPW; ++v) {
+            float t = part[v];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            if (tx == src) acc[v] += t;
         }
     }
     if (O) {
@@ -623,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
                 const long long g0 = pbase + pl, g = g0 < npts ? g0 : npts - 1;
                 return a.gpre[((size_t)(g / a.N) * a.M + (q >= 0 ? q : 0)) * O + o];
             }, [&](int e, float v) { gpt[(e / O) * (O + 1) + e % O] = fqs[e / O] >= 0 ? v : 0.0f; }, (int)threadIdx.x, 192);
-        else
+        else if (a.Wpart)
             fill_batched<16>(nq * C, [&](int e) { return a.fs[(size_t)q0 * C + e]; },
                              [&](int e, float v) { fgs[(e % C) * (qpb + 1) + e / C] = v; }, tx, 64);
     }
@@ -691,10 +728,12 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
         }
     }
     // 3. 4 x 4 register tiles of dW1[h][c'] over the 64 points (columns cq, cq + tcols, ...: lanes consecutive),
-    //    then of dWs[o][c] over the block's queries
+    //    then of dWs[o][c] over the block's queries -- unless no weight takes a gradient (Wpart null: the GAN's feedback
+    //    pass runs the classifier with frozen weights; its second stage spent most of this kernel's 300 us here)
+    const bool wshare = a.Wpart != nullptr;
     float *__restrict__ wrow = a.Wpart + (size_t)blockIdx.x * ((size_t)H * ldw + (size_t)O * C + O);
-    const int tcols = (ldw + 3) / 4, ntile = (H / 4) * tcols;
-    const int scols = (C + 3) / 4, stiles = O ? (O / 4) * scols : 0;
+    const int tcols = (ldw + 3) / 4, ntile = wshare ? (H / 4) * tcols : 0;
+    const int scols = (C + 3) / 4, stiles = O && wshare ? (O / 4) * scols : 0;
     for (int tile = threadIdx.x; tile < ntile + stiles; tile += 256) {
         float t4[4][4];
 #pragma unroll
@@ -753,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
                     if (cq + j * scols < C) srow[(size_t)(ob + i) * C + cq + j * scols] = t4[i][j];
         }
     }
-    if (O) {
+    if (O && wshare) {
         for (int o = threadIdx.x; o < O; o += 256) {
             float s = 0.0f;
             for (int q = 0; q < nq; ++q) s += gps[q * (O + 1) + o];
@@ -914,7 +953,7 @@ extern "C" int apn_sa_wide_point_grads(int b, int c_in, int n, int m, int c_mid,
                                        float *g_f, float *g_p, float *g_q, float *w_part, void *stream) {
     if (b <= 0 || c_in <= 0 || c_in > 64 || (c_in % 4) || n <= 0 || m <= 0 || (c_mid != 32 && c_mid != 64) || !(radius > 0.0f) ||
         !GU || !pcnt_poff || !plist || !geo || !U || !f || !p || !new_p || !HA || !HB || !cabc || !pack1 || !w1 || !g_f ||
-        !w_part || c_skip < 0 || (c_skip % 4) || (c_skip && (!gpre || !fq || !fs || !ws)))
+        c_skip < 0 || (c_skip % 4) || (c_skip && (!gpre || !fq || !fs || !ws)))
         return APN_EINVAL;
     const long long npts = (long long)b * n, nqry = (long long)b * m;
     const long long blocks = (npts + 63) / 64;

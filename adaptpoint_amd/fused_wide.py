@@ -343,18 +343,20 @@ class _WideBlock(torch.autograd.Function):
             g_f = torch.empty(B, C, N, **f32)
             g_p = torch.empty(B, N, 3, **f32) if need_p else None
             g_q = torch.empty(B, M, 3, **f32) if need_q else None
-            Wpart = torch.empty(wrows, wcols, **f32)
+            Wpart = torch.empty(wrows, wcols, **f32) if need_w else None     # (no weight takes a gradient: no shares)
             _call("apn_sa_wide_point_grads", dev, B, C, N, M, H, float(radius), GU.data_ptr(), nbr.pcnt_poff.data_ptr(),
                   nbr.plist.data_ptr(), nbr.geo.data_ptr(), U.data_ptr(), f.data_ptr(), p.data_ptr(), new_p.data_ptr(),
                   HA.data_ptr(), HB.data_ptr(), cabc.data_ptr(), pack1.data_ptr(), W1.data_ptr(), Os, _fz._ptr(gpre),
                   _fz._ptr(nbr.fq if Os else None), _fz._ptr(fs), _fz._ptr(Ws), g_f.data_ptr(),
-                  _fz._ptr(g_p), _fz._ptr(g_q), Wpart.data_ptr())
-            wsum = torch.empty(wcols, **f32)
-            _call("apn_sa_wide_colsum_f32", dev, Wpart.data_ptr(), wrows, wcols, wsum.data_ptr())
-            g_w1 = wsum[:H * (C + 3)].view(H, C + 3, 1, 1)
-            if Os:
-                g_ws = wsum[H * (C + 3):H * (C + 3) + O * C].view(O, C, 1)
-                g_bs = wsum[H * (C + 3) + O * C:] if a5 else None
+                  _fz._ptr(g_p), _fz._ptr(g_q), _fz._ptr(Wpart))
+            g_w1 = None
+            if need_w:
+                wsum = torch.empty(wcols, **f32)
+                _call("apn_sa_wide_colsum_f32", dev, Wpart.data_ptr(), wrows, wcols, wsum.data_ptr())
+                g_w1 = wsum[:H * (C + 3)].view(H, C + 3, 1, 1)
+                if Os:
+                    g_ws = wsum[H * (C + 3):H * (C + 3) + O * C].view(O, C, 1)
+                    g_bs = wsum[H * (C + 3) + O * C:] if a5 else None
         else:
             D2, E2 = d2e2[:O], d2e2[O:]
             Rm, suma = R[:rows * H].view(rows, H), R[rows * H:]

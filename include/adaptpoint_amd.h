@@ -520,7 +520,8 @@ APN_API int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float *ne
  *   be NULL); with a residual branch (c_skip = O > 0: gpre (B,M,O) from bwd_prep, fq (B,N) = the query a point
  *   is or -1, fs (B,M,C) of fwd_prep, ws (O x C)) g_f also receives ws^T gpre at the sampled points;
  *   w_part[apn_sa_wide_point_grads_rows(b, n)][apn_sa_wide_point_grads_cols(C, H, O)] = the workgroups' shares
- *   of {dL/dW1 (H x (C+3)), dL/dws (O x C), dL/dbs (O)}.
+ *   of {dL/dW1 (H x (C+3)), dL/dws (O x C), dL/dbs (O)}; w_part NULL: no weight takes a gradient, the shares are
+ *   not formed (the frozen classifier of the GAN's feedback pass).
  * colsum_f32: out[ncol] (float32) = column sums (in float64, fixed order) of part[rows][ncol]. */
 APN_API int apn_sa_wide_fwd_prep(int b, int c_in, int n, int m, int c_mid, int c_out, float radius, const float *f,
                                  const float *p, const float *new_p, const float *w1, const float *w2, float *U,

@@ -23,9 +23,15 @@ def _rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-12))
 
 
-def _setup(dev, cin, N, M, radius, B=4, seed=0, neg_gamma=False):
+def _setup(dev, cin, N, M, radius, B=4, seed=0, neg_gamma=False, clustered=False):
     from adaptpoint_amd.layers import ball_query, furthest_point_sample
     p = torch.from_numpy(GI.unit_sphere_cloud(B, N, seed=seed)).to(dev)
+    if clustered:
+        # every second cloud shrunk to a fraction of the query radius (a collapsed generated cloud): every query's ball
+        # holds the whole cloud, the ball query keeps its first 32 points -- those points are neighbours of ALL M queries,
+        # their lists in the inverse map are M rows long, every other point's list is empty
+        p[1::2] *= 0.25 * radius
+        p = p.contiguous()
     f = torch.from_numpy(GI.seeded_normal((B, cin, N), seed=seed + 1)).to(dev)
     fidx = furthest_point_sample(p, M).long()
     new_p = torch.gather(p, 1, fidx.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
@@ -108,6 +114,43 @@ def test_wide_backward_matches_autograd(dev, cin, N, M, radius, neg_gamma):
     print("wide bwd C_in=%d (%.4f%% of the pool masked) rel-L2:" % (cin, 100 * (1 - keep.mean().item())),
           {k: "%.1e" % v for k, v in l2.items()})
     assert keep.mean().item() > 0.99
+    for k, v in l2.items():
+        assert v <= 1e-4, (k, v)
+
+
+@pytest.mark.parametrize("cin,N,M,radius", STAGES[:2])
+def test_wide_backward_on_clustered_clouds(dev, cin, N, M, radius):
+    """Clouds with clusters of duplicate points: a point's list in the inverse map passes the 32 rows its own lane sums
+    in wide_point_grads, the rest goes through the wave-cooperative form; gradients against the float64 chain as in
+    test_wide_backward_matches_autograd."""
+    from adaptpoint_amd.fused_wide import grouped_mlp_max
+    p, new_p, f, idx, conv1, bn1, conv2, bn2 = _setup(dev, cin, N, M, radius, seed=11, clustered=True)
+    B = p.shape[0]
+    member = torch.zeros(B, M, N, dtype=torch.bool, device=dev)
+    member.scatter_(2, idx.long(), True)
+    longest = int(member.sum(1).max())
+    assert longest > 64, longest                    # (the hot path runs, more than one 64-row step of it)
+    H, O = conv1.weight.shape[0], conv2.weight.shape[0]
+    wts = torch.randn(B, O, M, device=dev, generator=torch.Generator(dev).manual_seed(9))
+    leaves = [t.detach().clone().requires_grad_(True) for t in _chain_args(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2)
+              if torch.is_tensor(t) and t.is_floating_point()]
+    rp, rq, rf, rw1, rg1, rb1, rw2, rg2, rb2 = leaves
+    ref, mid = chain_grad(rp, rq, rf, idx, radius, rw1, rg1, rb1, rw2, rg2, rb2)
+    with torch.no_grad():
+        z = ((mid["y2"] - mid["m2"]) / torch.sqrt(mid["v2"] + 1e-5) * bn2.weight.double().view(1, -1, 1, 1)
+             + bn2.bias.double().view(1, -1, 1, 1))
+        top2 = z.topk(2, dim=-1).values
+        gap = torch.where(top2[..., 0] == top2[..., 1], torch.ones_like(top2[..., 0]), top2[..., 0] - top2[..., 1])
+        keep = (gap > 1e-4).to(wts.dtype)
+    (ref * (wts * keep).double()).sum().backward()
+    want = dict(f=rf.grad, p=rp.grad, newp=rq.grad, w1=rw1.grad)
+    p.requires_grad_(True); new_p.requires_grad_(True); f.requires_grad_(True)
+    out = grouped_mlp_max(p, new_p, f, idx, radius, conv1, bn1, conv2, bn2)
+    (out * wts * keep).sum().backward()
+    got = dict(f=f.grad, p=p.grad, newp=new_p.grad, w1=conv1.weight.grad.view(H, -1))
+    l2 = {k: _rel_l2(got[k], want[k]) for k in got}
+    print("wide bwd, clustered, C_in=%d, longest list %d rows:" % (cin, longest), {k: "%.1e" % v for k, v in l2.items()})
+    assert keep.mean().item() > 0.98
     for k, v in l2.items():
         assert v <= 1e-4, (k, v)
 
