@@ -268,24 +268,6 @@ __device__ __forceinline__ void pw_fragment(const __bf16 *tile, int blk, int s, 
 template <int NS>
 constexpr int pw_lds_bytes() { return 2 * 2 * NS * PW_T * PW_ROW * 2 + 4 * 2 * PW_T * 4; }
 
-// maxima over the 32 lanes of a half-wave of 32 (value, column) pairs per lane by recursive halving (31 exchanges
-// instead of 160; afterwards lane r holds the result of pair r in v[0], ix[0]): the larger value wins, among equal values
-// the lower column
-template <int M>
-__device__ __forceinline__ void pw_halve_max_step(float (&v)[32], int (&ix)[32], int r) {
-    const bool up = (r & M) != 0;
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        const float keep = up ? v[j + M] : v[j], send = up ? v[j] : v[j + M];
-        const int keepi = up ? ix[j + M] : ix[j], sendi = up ? ix[j] : ix[j + M];
-        const float rv = __shfl_xor(send, M);
-        const int ri = __shfl_xor(sendi, M);
-        const bool take = rv > keep || (rv == keep && ri < keepi);
-        v[j] = take ? rv : keep;
-        ix[j] = take ? ri : keepi;
-    }
-}
-
 // LDS writes of this wave done, then the workgroup's rendezvous (global loads stay in flight across it)
 __device__ __forceinline__ void pw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -452,26 +434,34 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_kernel(PwGemm g) {
     pw_stamp(2);
     const int q = Q0 + wq * 32 + r;
     if (g.pool_val) {
-        // row maxima over the tile's columns instead of the tile: value 16 i + e of a lane <-> row
-        // 32 i + acc_row(e, h) of the wave, as in the statistics epilogue below
-        float mv[32];
-        int mi[32];
+        // row maxima over the tile's columns instead of the tile: the wave's 64 x 32 block through LDS as in the
+        // statistics epilogue below (written with lane = column, read back with lane = row), every lane scanning its
+        // row's columns in ascending order -- a later column wins only if larger, so among equals the lowest stays
+        constexpr int PROW = 36;
+        float *ptile = reinterpret_cast<float *>(pw_lds) + wave * (64 * PROW);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                mv[16 * i + e] = q < g.Q ? acc[i][0][e] : -__builtin_inff();
-                mi[16 * i + e] = q;
+            for (int e = 0; e < 16; ++e) ptile[(i * 32 + acc_row(e, h)) * PROW + r] = acc[i][0][e];
+        }
+        int nwp = g.Q - (Q0 + 32 * wq);                         // this block's columns inside Q (wave-uniform)
+        nwp = nwp < 0 ? 0 : (nwp > 32 ? 32 : nwp);
+        const float *prow = ptile + lane * PROW;                // (one wave's LDS operations execute in order)
+        float bestv = -__builtin_inff();
+        int besti = Q0 + 32 * wq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(prow + 4 * j);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool up = 4 * j + e < nwp && vv[e] > bestv;
+                bestv = up ? vv[e] : bestv;
+                besti = up ? Q0 + 32 * wq + 4 * j + e : besti;
             }
         }
-        pw_halve_max_step<16>(mv, mi, r);
-        pw_halve_max_step<8>(mv, mi, r);
-        pw_halve_max_step<4>(mv, mi, r);
-        pw_halve_max_step<2>(mv, mi, r);
-        pw_halve_max_step<1>(mv, mi, r);
-        const int row = wr * 64 + (r >> 4) * 32 + acc_row(r & 15, h);
-        red[wq][0][row] = mv[0];
-        reinterpret_cast<int *>(&red[wq][1][0])[row] = mi[0];
+        red[wq][0][wr * 64 + lane] = bestv;
+        reinterpret_cast<int *>(&red[wq][1][0])[wr * 64 + lane] = besti;
         __syncthreads();
         if (t < PW_T && R0 + t < g.R) {
             float best = red[0][0][t];
