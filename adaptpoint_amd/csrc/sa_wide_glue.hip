@@ -708,6 +708,148 @@ __global__ __launch_bounds__(256) void csr_sort_long_kernel(int nq, long long np
     }
 }
 
+
+// The same inverse map by ONE launch, one workgroup per cloud, everything in LDS (round 4: the six launches above cost
+// 46-72 us per stage on the classifier's critical path for a few thousand rows per cloud).  A list entry travels as
+//   (row within the cloud) << 16 | mult << 10 | (query within the cloud)
+// so that sorting the words sorts the rows and geo needs nothing but the cloud's query coordinates (LDS too).
+// Counts and cursors by LDS integer atomics (order-free); lists of up to CSR_INS entries sorted by their point's thread
+// (insertion, in place), longer ones by a wave (ranks: the entries of a list are distinct).  plist / pcnt / poff are the
+// pure function of idx the kernels above compute; geo is summed in ascending row order (lists up to CSR_INS) or
+// lane-strided + butterfly (longer): fixed orders.  For m <= 1024 (query bits), rows <= 65536 and what fits in LDS.
+constexpr int CSR_INS = 64;
+__global__ __launch_bounds__(1024) void csr_cloud_kernel(int nq, int b, int n, int m, const int *__restrict__ tmap,
+                                                         const float *__restrict__ new_xyz, int *__restrict__ pcnt,
+                                                         int *__restrict__ poff, int *__restrict__ plist,
+                                                         float *__restrict__ geo, const int *__restrict__ fidx,
+                                                         int *__restrict__ fq, int rows_cap) {
+    extern __shared__ int csm[];
+    __shared__ int part[1024];
+    __shared__ int nlong;
+    int *scnt = csm, *soff = csm + n, *slist = csm + 2 * n;
+    float *sq = reinterpret_cast<float *>(slist + rows_cap);            // [m][3]
+    int *slong = reinterpret_cast<int *>(sq + 3 * m);                    // points with long lists (at most rows_cap / CSR_INS)
+    const int cloud = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int *__restrict__ tq0 = tmap + 4;
+    const unsigned *__restrict__ rows = reinterpret_cast<const unsigned *>(tmap + 4 + ((nq + 3) & ~3));
+    const int *__restrict__ rownn = reinterpret_cast<const int *>(rows + (size_t)32 * nq);
+    const int *__restrict__ tcount = rownn + (size_t)32 * nq, *__restrict__ toff = tcount + b;
+    const int row0 = toff[cloud] * 32, nrows = tcount[cloud] * 32;
+    const size_t cbase = (size_t)cloud * n;
+    const int qbase = cloud * m;
+    for (int k = t; k < n; k += 1024) { scnt[k] = 0; if (fq) fq[cbase + k] = -1; }
+    for (int e = t; e < 3 * m; e += 1024) sq[e] = new_xyz[(size_t)qbase * 3 + e];
+    if (t == 0) nlong = 0;
+    __syncthreads();
+    // count (and which query each sampled point is: one row per query has slot 0)
+    for (int e = t; e < nrows; e += 1024) {
+        const unsigned info = rows[row0 + e];
+        if (((info >> 16) & 0xffu) == 0) continue;
+        atomicAdd(&scnt[rownn[row0 + e]], 1);
+        if (fq && ((info >> 8) & 0xffu) == 0) {
+            const int q = tq0[(row0 + e) >> 5] + (int)(info & 0xffu);
+            fq[cbase + fidx[q]] = q - qbase;
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the counts: soff = where a point's list starts (within the cloud)
+    const int per = (n + 1023) / 1024;
+    int sum = 0;
+    for (int i = 0; i < per; ++i) {
+        const int k = t * per + i;
+        if (k < n) sum += scnt[k];
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    {
+        int run = part[t] - sum;
+        for (int i = 0; i < per; ++i) {
+            const int k = t * per + i;
+            if (k < n) {
+                const int c = scnt[k];
+                soff[k] = run;
+                pcnt[cbase + k] = c;
+                poff[cbase + k] = row0 + run;
+                if (c > CSR_INS) slong[atomicAdd(&nlong, 1)] = k;
+                scnt[k] = run;                                  // from here on: the list's cursor
+                run += c;
+            }
+        }
+    }
+    __syncthreads();
+    // fill (the order inside a list is the atomics': sorted next)
+    for (int e = t; e < nrows; e += 1024) {
+        const unsigned info = rows[row0 + e];
+        const unsigned mult = (info >> 16) & 0xffu;
+        if (mult == 0) continue;
+        const int q = tq0[(row0 + e) >> 5] + (int)(info & 0xffu) - qbase;
+        slist[atomicAdd(&scnt[rownn[row0 + e]], 1)] = (int)(((unsigned)e << 16) | (mult << 10) | (unsigned)q);
+    }
+    __syncthreads();
+    auto geo_term = [&](int w, float &occ, float &sx, float &sy, float &sz) {
+        const float mult = (float)((w >> 10) & 63);
+        const float *__restrict__ q = sq + 3 * (w & 1023);
+        occ += mult;
+        sx = __builtin_fmaf(mult, q[0], sx);
+        sy = __builtin_fmaf(mult, q[1], sy);
+        sz = __builtin_fmaf(mult, q[2], sz);
+    };
+    // short lists: the point's thread
+    for (int k = t; k < n; k += 1024) {
+        const int start = soff[k], c = scnt[k] - start;
+        if (c > CSR_INS) continue;
+        int *l = slist + start;
+        for (int i = 1; i < c; ++i) {
+            const int v = l[i];
+            int j = i;
+            for (; j > 0 && l[j - 1] > v; --j) l[j] = l[j - 1];
+            l[j] = v;
+        }
+        float occ = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (int i = 0; i < c; ++i) geo_term(l[i], occ, sx, sy, sz);
+        if (geo) *reinterpret_cast<float4 *>(geo + (cbase + k) * 4) = make_float4(occ, sx, sy, sz);
+    }
+    // long lists: a wave each (ranks first, all of them, then the moves: one wave's LDS operations execute in order)
+    for (int li = wave; li < nlong; li += 16) {
+        const int k = slong[li], start = soff[k], c = scnt[k] - start;
+        int *l = slist + start;
+        int mine[16], rank[16];
+        const int cc = c < 1024 ? c : 1024;                     // (c <= m <= 1024: a point is in a query's rows once)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = lane + 64 * u;
+            mine[u] = i < cc ? l[i] : 0x7fffffff;
+            rank[u] = 0;
+        }
+        for (int j = 0; j < cc; ++j) {
+            const int v = l[j];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (64 * u < cc) rank[u] += v < mine[u] ? 1 : 0;         // (wave-uniform)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (lane + 64 * u < cc) l[rank[u]] = mine[u];
+        float occ = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (int i = lane; i < cc; i += 64) geo_term(l[i], occ, sx, sy, sz);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            occ += __shfl_xor(occ, o); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o);
+        }
+        if (lane == 0 && geo) *reinterpret_cast<float4 *>(geo + (cbase + k) * 4) = make_float4(occ, sx, sy, sz);
+    }
+    __syncthreads();
+    const int total = part[1023];
+    for (int i = t; i < total; i += 1024) plist[row0 + i] = row0 + (int)((unsigned)slist[i] >> 16);
+}
+
 }  // namespace apn
 
 // The map is ONE int32 blob (BM = b * m, BM4 = BM rounded up to 4):
@@ -779,6 +921,24 @@ extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float 
     const long long npts = (long long)b * n;
     int *pcnt = pcnt_poff, *poff = pcnt_poff + npts;
     hipStream_t st = (hipStream_t)stream;
+    {
+        // one launch, one workgroup per cloud, when a cloud's map fits in LDS
+        const long long rows_cap = (long long)m * 32;
+        const long long lds = 4 * (2ll * n + rows_cap + 3ll * m + rows_cap / apn::CSR_INS + 1);
+        if (m <= 1024 && rows_cap <= 65536 && lds <= 150 * 1024) {
+            static bool configured = false;
+            if (!configured) {
+                if (hipError_t e = hipFuncSetAttribute((const void *)apn::csr_cloud_kernel,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+                    return (int)e;
+                configured = true;
+            }
+            hipLaunchKernelGGL(apn::csr_cloud_kernel, dim3(b), dim3(1024), (size_t)lds, st, nq, b, n, m, tmap, new_xyz, pcnt,
+                               poff, plist, geo, fidx, fq, (int)rows_cap);
+            APN_LAUNCH_CHECK();
+            return APN_OK;
+        }
+    }
     hipLaunchKernelGGL(apn::csr_init_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, npts, pcnt, fq);
     const unsigned rb = (unsigned)(((long long)nq * 32 + 255) / 256);
     hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 0, idx, tmap, pcnt, poff, plist,

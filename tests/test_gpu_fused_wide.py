@@ -157,16 +157,19 @@ def test_wide_backward_on_clustered_clouds(dev, cin, N, M, radius):
 
 @pytest.mark.parametrize("kind,B,N,M,radius", [("ball", 3, 1024, 512, 0.15), ("ball", 2, 300, 97, 0.3),
                                                ("dense", 2, 128, 64, 0.6), ("random", 2, 256, 130, 0.0),
-                                               ("nofold", 2, 512, 256, 0.2)])
+                                               ("nofold", 2, 512, 256, 0.2), ("collapsed", 2, 512, 256, 0.225),
+                                               ("ball", 2, 4096, 1024, 0.1), ("ball", 1, 8192, 2048, 0.08)])
 def test_tile_map_and_inverse_map_equal_the_oracle_statement(dev, kind, B, N, M, radius):
     """The index-stage structures are integer work: the GPU builders (parallel next-fit packer, counting sort +
-    per-list sort) must reproduce the serial Python statement of their definition (oracle.tile_map /
+    per-list sort: one launch per cloud in LDS up to M = 1024, six launches beyond) must reproduce the serial Python statement of their definition (oracle.tile_map /
     inverse_map) bit for bit -- tile count, first queries, row records, row neighbours, per-point counts and
     ascending lists; geo (float sums) to rounding."""
     from adaptpoint_amd.fused_wide import neighbour_index
     from adaptpoint_amd.layers import ball_query, furthest_point_sample
     from oracle import oracle as O
     p = torch.from_numpy(GI.unit_sphere_cloud(B, N, seed=21)).to(dev)
+    if kind == "collapsed":
+        p[1] *= 0.25 * radius              # every query's ball holds the whole cloud: 32 points with lists M rows long
     fidx = furthest_point_sample(p, M)
     new_p = torch.gather(p, 1, fidx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
     if kind == "random":
@@ -204,6 +207,8 @@ def test_tile_map_and_inverse_map_equal_the_oracle_statement(dev, kind, B, N, M,
     assert np.array_equal(fq, ref_fq)
     if kind == "dense":
         assert max(len(v) for v in inv["lists"].values()) > 16       # the wave-wide sort of long lists ran
+    if kind == "collapsed":
+        assert max(len(v) for v in inv["lists"].values()) == M       # ... and the rank sort of the one-launch builder
 
 
 @pytest.mark.parametrize("cin,N,M,radius", STAGES[:2])
