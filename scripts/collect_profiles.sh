@@ -67,7 +67,7 @@ if [ "$what" = models ]; then
     python $R/scripts/bench_wide.py 2>/dev/null | grep '^{' > $O/${T}_wide_kernels.jsonl
     python $R/scripts/bench_pointwise.py 2>/dev/null | grep '^{' > $O/${T}_pointwise_layers.jsonl
     rocprofv3 --kernel-trace --output-format csv -d $O/prof_pn -o pn -- python $R/scripts/bench_pointnext.py --fused --graph --steps 12 --warmup 6 > $O/prof_pn.log 2>&1
-    python $R/scripts/steady_stats.py $O/prof_pn/pn_kernel_trace.csv fps_ 4 3 --csv $O/${T}_pointnext_fused_graph_steady.csv > $O/${T}_pointnext_fused_graph_steady.txt
+    python $R/scripts/steady_stats.py $O/prof_pn/pn_kernel_trace.csv sa_geo_kernel 1 3 --csv $O/${T}_pointnext_fused_graph_steady.csv > $O/${T}_pointnext_fused_graph_steady.txt
     rocprofv3 --kernel-trace --output-format csv -d $O/prof_gan -o gan -- python $R/scripts/bench_gan_step.py --mode fused --graph --iters 10 --warmup 4 > $O/prof_gan.log 2>&1
     python $R/scripts/steady_stats.py $O/prof_gan/gan_kernel_trace.csv pointset_group_max_kernel 4 3 --csv $O/${T}_gan_step_fused_graph_steady.csv > $O/${T}_gan_step_fused_graph_steady.txt
     rm -rf $O/prof_pn $O/prof_gan
