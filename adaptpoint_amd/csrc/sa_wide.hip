@@ -32,6 +32,7 @@
 // (column block, 32-deep k chunk).
 #include "apn_common.h"
 #include "apn_mfma.h"
+#include <type_traits>
 
 namespace apn {
 
@@ -244,6 +245,12 @@ __device__ __forceinline__ void store_chunk(const ChunkRegs<CT> &r, uint4 *slot)
     for (int i = 0; i < Chunk<CT>::WORDS / 256; ++i) slot[threadIdx.x + 256 * i] = r.v[i];
 }
 
+// The chunk loop's rendezvous: this wave's LDS operations done, then the workgroup's barrier.  (__syncthreads() also waits
+// for every global load in flight -- vmcnt(0) -- i.e. for the prefetches of the NEXT step issued a moment ago: one L2 round
+// trip per chunk step on the critical path.  The slots are handed over through LDS only; the loads the stores depend on are
+// waited for by the stores themselves.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int CT>
 __device__ __forceinline__ Frag<2> chunk_frag(const uint4 *slot, int j, int s, int lane) {
     Frag<2> f;
@@ -268,15 +275,20 @@ __global__ __launch_bounds__(256, (H == 32 ? 3 : 2)) void wide_fwd_main_kernel(W
                                                             float *__restrict__ part) {
     constexpr int NKC = H / 32, NCB = O / (32 * CT), NCH = NKC * NCB;
     constexpr int SLOTS = RES ? NCH : 2;
+    constexpr bool AHEADA = H >= 128;        // a1's rows requested one chunk step ahead, BatchNorm-1's constants in LDS
     extern __shared__ uint4 dyn[];
     uint4 *wl = dyn;                                                 // SLOTS chunks
     float *st = reinterpret_cast<float *>(dyn + SLOTS * Chunk<CT>::WORDS);   // [4 waves][2*O]
+    float *cst = st + WIDE_WAVES * 2 * O;                            // wide blocks (H >= 128): BatchNorm-1's {scale, shift}[H]
     const int lane = lane_id(), r = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int step = gridDim.x * WIDE_WAVES;
     const int first = blockIdx.x * WIDE_WAVES + w;                   // wave-uniform tile numbers
     TileHead head = load_head(a, first < a.ntiles ? first : a.ntiles - 1, r);
     for (int e = threadIdx.x; e < WIDE_WAVES * 2 * O; e += 256) st[e] = 0.0f;
+    if (AHEADA) {
+        for (int e = threadIdx.x; e < 2 * H; e += 256) cst[e] = pack1[e];
+    }
     if (RES) {
         for (int ci = 0; ci < NCH; ++ci) stage_chunk<CT>(img, ci, wl + ci * Chunk<CT>::WORDS);
     }
@@ -309,6 +321,33 @@ __global__ __launch_bounds__(256, (H == 32 ? 3 : 2)) void wide_fwd_main_kernel(W
         unsigned char *__restrict__ ksel0 = ksel + (size_t)q0 * O;
         unsigned meta[16];
         row_meta(cur.info, h, meta);
+        // wide blocks (H >= 128): the rows of U and V a chunk step turns into its a1 fragments are requested ONE STEP
+        // AHEAD and BatchNorm-1's constants come from LDS -- requested and consumed in the same step, sixteen 16-byte loads
+        // stood between the barrier and the step's MFMAs: ~3.5-4 us per step against 0.8 us of MFMAs
+        float4 raw[2][4], rnx[2][4];
+        auto load_uv = [&](int kc, float4 (&f)[2][4]) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const unsigned ch0 = kc * 32 + s2 * 16 + h * 8;
+                f[s2][0] = *reinterpret_cast<const float4 *>(ub + (uo + ch0));
+                f[s2][1] = *reinterpret_cast<const float4 *>(ub + (uo + ch0 + 4));
+                f[s2][2] = *reinterpret_cast<const float4 *>(vb + (vo + ch0));
+                f[s2][3] = *reinterpret_cast<const float4 *>(vb + (vo + ch0 + 4));
+            }
+        };
+        auto a1_lds = [&](const float4 (&f)[4], int ch0) {
+            const float4 c0 = *reinterpret_cast<const float4 *>(cst + ch0), c1 = *reinterpret_cast<const float4 *>(cst + ch0 + 4);
+            const float4 d0 = *reinterpret_cast<const float4 *>(cst + H + ch0), d1 = *reinterpret_cast<const float4 *>(cst + H + ch0 + 4);
+            float t[8];
+            t[0] = __builtin_fmaf(f[0].x - f[2].x, c0.x, d0.x); t[1] = __builtin_fmaf(f[0].y - f[2].y, c0.y, d0.y);
+            t[2] = __builtin_fmaf(f[0].z - f[2].z, c0.z, d0.z); t[3] = __builtin_fmaf(f[0].w - f[2].w, c0.w, d0.w);
+            t[4] = __builtin_fmaf(f[1].x - f[3].x, c1.x, d1.x); t[5] = __builtin_fmaf(f[1].y - f[3].y, c1.y, d1.y);
+            t[6] = __builtin_fmaf(f[1].z - f[3].z, c1.z, d1.z); t[7] = __builtin_fmaf(f[1].w - f[3].w, c1.w, d1.w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = t[e] > 0.0f ? t[e] : 0.0f;
+            return make_frag<2>(t);
+        };
+        if (AHEADA) load_uv(0, raw);
 #pragma unroll 1
         for (int cb = 0; cb < NCB; ++cb) {
             f32x16 acc[CT];
@@ -326,9 +365,15 @@ __global__ __launch_bounds__(256, (H == 32 ? 3 : 2)) void wide_fwd_main_kernel(W
                     slot = wl + (seq & 1) * Chunk<CT>::WORDS;
                     fetch_chunk<CT>(img, ci + 1 == NCH ? 0 : ci + 1, pre);      // in flight behind the MFMAs
                 }
+                if (AHEADA) load_uv(kc + 1 == NKC ? 0 : kc + 1, rnx);           // (a1 does not depend on the column block)
                 Frag<2> af[2];
+                if (!AHEADA) {
 #pragma unroll
-                for (int s = 0; s < 2; ++s) af[s] = a1_frag(ub, uo, vb, vo, pack1, H, kc * 32 + s * 16 + h * 8);
+                    for (int s = 0; s < 2; ++s) af[s] = a1_frag(ub, uo, vb, vo, pack1, H, kc * 32 + s * 16 + h * 8);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) af[s] = a1_lds(raw[s], kc * 32 + s * 16 + h * 8);
+                }
 #pragma unroll
                 for (int j = 0; j < CT; ++j)
 #pragma unroll
@@ -337,8 +382,14 @@ __global__ __launch_bounds__(256, (H == 32 ? 3 : 2)) void wide_fwd_main_kernel(W
                     // the other slot held chunk seq-1: every wave finished reading it before the barrier
                     // that ended the previous iteration, so it can be overwritten now
                     store_chunk<CT>(pre, wl + ((seq + 1) & 1) * Chunk<CT>::WORDS);
-                    __syncthreads();
+                    lds_barrier();
                     ++seq;
+                }
+                if (AHEADA) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) raw[s][e] = rnx[s][e];
                 }
             }
             // epilogue of this column block: lane = channel, register = row acc_row(i, h) of the tile
@@ -434,12 +485,18 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
     float *a1s = wgl + w * 32 * A1LD;                                // this wave's a1 tile [row][mid]
     const int nt = tm_tiles(a);
     const int rounds = (nt + step - 1) / step;
-    ChunkRegs<CT> pre;
+    // streaming blocks: chunk c is read from slot c & 1; chunk c + 1 sits in one register set (requested during step c - 1,
+    // stored into the other slot at the end of step c), chunk c + 2 is requested into the other set at the start of step c
+    static_assert(RES || Chunk<CT>::WORDS == 1024, "the streaming blocks move four words per thread and chunk");
+    // (eight named registers, not two arrays: one of two arrays -- or of two ChunkRegs -- stayed in scratch memory)
+    uint4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
+    pa0 = pa1 = pa2 = pa3 = pb0 = pb1 = pb2 = pb3 = make_uint4(0u, 0u, 0u, 0u);
     if (!RES) {
         stage_chunk<CT>(img, 0, wl);
+        const uint4 *__restrict__ src = img + (size_t)(NCH > 1 ? 1 : 0) * Chunk<CT>::WORDS + threadIdx.x;
+        pb0 = src[0]; pb1 = src[256]; pb2 = src[512]; pb3 = src[768];
         __syncthreads();
     }
-    int seq = 0;
     // fused weight-gradient products (WG): Gram = a1^T diag(mult) a1 (MFMA, H x H), R_S = S^T a1 (O x H: lane =
     // output channel c, exact fp32 sums of the pooled rows of a1), suma
     f32x16 gram;
@@ -534,43 +591,121 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
             // (one wave per SIMD has the registers for two chunks of words; the two-waves-per-SIMD variants request
             // and consume in the same step, as before: their tiles hold fewer chunks and a partner wave covers the wait)
             constexpr bool AHEAD = OCC == 1;
+            static_assert(RES || AHEAD, "the streaming blocks run one wave per SIMD");
+            auto frags_from = [&](int kc, const RawA &rw, Frag<2> (&af)[2]) {
+                if (kc < NKS) {            // rows of S: the upstream gradient at the pooled slot
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const float4 g0 = rw.f[s][0], g1 = rw.f[s][1];
+                        const uint2 kk = rw.kk[s];
+                        float t[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const unsigned sel = ((e < 4 ? kk.x : kk.y) >> (8 * (e & 3))) & 0xffu;
+                            t[e] = (live && sel == (unsigned)rslot) ? t[e] : 0.0f;
+                        }
+                        af[s] = make_frag<2>(t);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) af[s] = a1_from_raw(rw.f[s], wrow);
+                }
+            };
+            if constexpr (!RES) {
+                // Two steps per iteration with the roles of the register sets fixed per step (kend is even): nothing is
+                // copied at the back edge -- a copy of a load's destination waits for the load, i.e. for the prefetch
+                // issued a moment ago.  Per step: request chunk + 2 (registers) and the A words of step + 1, build this
+                // step's fragments from the words requested one step ago, MFMAs, store chunk + 1 into the other slot.
+                auto after = [&](int cbx, int kcx, int &cb2, int &kc2) {      // the chunk behind (cbx, kcx) in the cyclic sequence
+                    if (kcx + 1 < kend) { cb2 = cbx; kc2 = kcx + 1; }
+                    else { cb2 = cbx + 1 < NCB ? cbx + 1 : 0; kc2 = 0; }
+                };
+                // (the two steps are written out with the register sets NAMED: handed to a step function by reference, or
+                // selected inside a lambda, the compiler kept the sets in scratch memory)
+                RawA raw_a, raw_b;
+// CT_ / NT_: what the step's A words are and what the next step's are -- 0 rows of S, 1 rows of a1, 2 none -- as
+// compile-time constants: a load under a run-time condition makes the paths of a step differ in their loads in flight,
+// and the compiler then waits for ALL of them (vmcnt(0)) where the paths meet, the prefetches included
+#define APN_STREAM_STEP(KC, I0, I1, I2, I3, F0, F1, F2, F3, CURR, NXTR, PAR, CT_, NT_)                              \
+    {                                                                                                               \
+        int c1_, k1_, c2_, k2_;                                                                                     \
+        after(cb, (KC), c1_, k1_);                                                                                  \
+        after(c1_, k1_, c2_, k2_);                                                                                  \
+        {                                                                                                           \
+            const uint4 *__restrict__ src_ = img + (size_t)(c2_ * NKC + k2_) * Chunk<CT>::WORDS + threadIdx.x;       \
+            I0 = src_[0]; I1 = src_[256]; I2 = src_[512]; I3 = src_[768];                                            \
+        }                                                                                                           \
+        if ((NT_) == 0) load_raw_s((KC) + 1, NXTR);                                                                 \
+        if ((NT_) == 1) load_raw_a((KC) + 1, NXTR);                                                                 \
+        const uint4 *slot_ = wl + (PAR) * Chunk<CT>::WORDS;                                                         \
+        Frag<2> af_[2];                                                                                             \
+        if ((CT_) == 0) frags_s(CURR, af_);                                                                         \
+        else frags_a(CURR, af_);                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < CT; ++j)                                                              \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                           \
+                acc[j] = mfma<2>(af_[s], chunk_frag<CT>(slot_, j, s, lane), acc[j]);                                 \
+        {                                                                                                           \
+            uint4 *dst_ = wl + (1 - (PAR)) * Chunk<CT>::WORDS + threadIdx.x;                                         \
+            dst_[0] = F0; dst_[256] = F1; dst_[512] = F2; dst_[768] = F3;                                            \
+        }                                                                                                           \
+        lds_barrier();                                                                                              \
+    }
+#define APN_STEP_EVEN(KC, CT_, NT_) APN_STREAM_STEP(KC, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, raw_a, raw_b, 0, CT_, NT_)
+#define APN_STEP_ODD(KC, CT_, NT_) APN_STREAM_STEP(KC, pb0, pb1, pb2, pb3, pa0, pa1, pa2, pa3, raw_b, raw_a, 1, CT_, NT_)
+                auto load_raw_s = [&](int kc, RawA &rw) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const unsigned c0 = go + kc * 32 + s * 16 + h * 8;
+                        rw.f[s][0] = *reinterpret_cast<const float4 *>(gb + c0);
+                        rw.f[s][1] = *reinterpret_cast<const float4 *>(gb + (c0 + 4));
+                        rw.kk[s] = *reinterpret_cast<const uint2 *>(kb + c0);
+                    }
+                };
+                auto load_raw_a = [&](int kc, RawA &rw) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) a1_raw(ub, uo, vb, vo, pack1, H, (kc - NKS) * 32 + s * 16 + h * 8, rw.f[s]);
+                };
+                auto frags_s = [&](const RawA &rw, Frag<2> (&af)[2]) { frags_from(0, rw, af); };
+                auto frags_a = [&](const RawA &rw, Frag<2> (&af)[2]) { frags_from(NKS, rw, af); };
+                static_assert(NKS % 2 == 0 && NKC % 2 == 0 && NKS >= 2 && NKC - NKS >= 2, "steps come in pairs");
+                load_raw_s(0, raw_a);
+                // the rows of S: chunks 0 .. NKS - 1
+#pragma unroll 1
+                for (int kc = 0; kc < NKS - 2; kc += 2) {
+                    APN_STEP_EVEN(kc, 0, 0)
+                    APN_STEP_ODD(kc + 1, 0, 0)
+                }
+                APN_STEP_EVEN(NKS - 2, 0, 0)
+                if (evec) {
+                    APN_STEP_ODD(NKS - 1, 0, 1)
+                    // the rows of a1: chunks NKS .. NKC - 1
+#pragma unroll 1
+                    for (int kc = NKS; kc < NKC - 2; kc += 2) {
+                        APN_STEP_EVEN(kc, 1, 1)
+                        APN_STEP_ODD(kc + 1, 1, 1)
+                    }
+                    APN_STEP_EVEN(NKC - 2, 1, 1)
+                    APN_STEP_ODD(NKC - 1, 1, 2)
+                } else {
+                    APN_STEP_ODD(NKS - 1, 0, 2)
+                }
+#undef APN_STEP_EVEN
+#undef APN_STEP_ODD
+#undef APN_STREAM_STEP
+            } else {
             RawA cur_raw;
             if (AHEAD) load_raw(0, cur_raw);
 #pragma unroll 1
             for (int kc = 0; kc < kend; ++kc) {
                 const int ci = cb * NKC + kc;
-                const uint4 *slot;
-                if (RES) {
-                    slot = wl + ci * Chunk<CT>::WORDS;
-                } else {
-                    slot = wl + (seq & 1) * Chunk<CT>::WORDS;
-                    const int nxt = kc + 1 < kend ? ci + 1 : (cb + 1 < NCB ? (cb + 1) * NKC : 0);
-                    fetch_chunk<CT>(img, nxt, pre);
-                }
+                const uint4 *slot = wl + ci * Chunk<CT>::WORDS;
                 // this chunk's A operand from the words requested one chunk ago; the next chunk's are requested now and
-                // arrive behind the MFMAs (requested and consumed in the same step they put an L2 round trip on the
-                // critical path of every chunk: 48 steps of ~2.5 us on the 256-wide block)
+                // arrive behind the MFMAs
                 RawA nxt;
                 Frag<2> af[2];
                 if (AHEAD) {
                     if (kc + 1 < kend) load_raw(kc + 1, nxt);
-                    if (kc < NKS) {            // rows of S: the upstream gradient at the pooled slot
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const float4 g0 = cur_raw.f[s][0], g1 = cur_raw.f[s][1];
-                            const uint2 kk = cur_raw.kk[s];
-                            float t[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const unsigned sel = ((e < 4 ? kk.x : kk.y) >> (8 * (e & 3))) & 0xffu;
-                                t[e] = (live && sel == (unsigned)rslot) ? t[e] : 0.0f;
-                            }
-                            af[s] = make_frag<2>(t);
-                        }
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) af[s] = a1_from_raw(cur_raw.f[s], wrow);
-                    }
+                    frags_from(kc, cur_raw, af);
                 } else if (kc < NKS) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -595,12 +730,8 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
                 for (int j = 0; j < CT; ++j)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) acc[j] = mfma<2>(af[s], chunk_frag<CT>(slot, j, s, lane), acc[j]);
-                if (!RES) {
-                    store_chunk<CT>(pre, wl + ((seq + 1) & 1) * Chunk<CT>::WORDS);
-                    __syncthreads();
-                    ++seq;
-                }
                 if (AHEAD) cur_raw = nxt;
+            }
             }
             // epilogue: lane = mid channel, register = row of the tile
 #pragma unroll
@@ -924,7 +1055,10 @@ static constexpr int bwd_ct() { return H / 32 >= 4 ? 4 : H / 32; }
 
 // whole image resident in LDS when it and the statistics rows fit comfortably (two workgroups per CU)
 template <int H>
-static constexpr bool fwd_res() { return (size_t)(H / 32) * (2 * H / (32 * fwd_ct<H>())) * Chunk<fwd_ct<H>()>::WORDS * 16 <= 48 * 1024; }
+#ifndef APN_FWD_RES_BYTES
+#define APN_FWD_RES_BYTES (48 * 1024)
+#endif
+static constexpr bool fwd_res() { return (size_t)(H / 32) * (2 * H / (32 * fwd_ct<H>())) * Chunk<fwd_ct<H>()>::WORDS * 16 <= APN_FWD_RES_BYTES; }
 template <int H>
 static constexpr bool bwd_res() { return (size_t)(3 * H / 32) * (H / (32 * bwd_ct<H>())) * Chunk<bwd_ct<H>()>::WORDS * 16 <= 48 * 1024; }
 
@@ -999,7 +1133,17 @@ extern "C" int apn_sa_wide_fwd_main(int b, int n, int m, int c_mid, int c_out, c
         constexpr int O = 2 * H, CT = fwd_ct<H>();
         constexpr bool RES = fwd_res<H>();
         constexpr int NCH = (H / 32) * (O / (32 * CT));
-        const size_t lds = (size_t)(RES ? NCH : 2) * Chunk<CT>::WORDS * 16 + (size_t)WIDE_WAVES * 2 * O * 4;
+        const size_t lds = (size_t)(RES ? NCH : 2) * Chunk<CT>::WORDS * 16 + (size_t)WIDE_WAVES * 2 * O * 4 +
+                           (H >= 128 ? (size_t)2 * H * 4 : 0);
+        if (lds > 64 * 1024) {
+            static bool configured = false;          // (per instantiation)
+            if (!configured) {
+                if (hipError_t e = hipFuncSetAttribute((const void *)wide_fwd_main_kernel<H, O, CT, RES>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+                    return (int)e;
+                configured = true;
+            }
+        }
         hipLaunchKernelGGL((wide_fwd_main_kernel<H, O, CT, RES>), dim3(grid), dim3(256), lds,
                            (hipStream_t)stream, a, (const uint4 *)w2_image, pack1, sgn2, ysel,
                            (unsigned char *)ksel, part);
