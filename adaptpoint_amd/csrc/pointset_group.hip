@@ -174,15 +174,41 @@ __global__ __launch_bounds__(256) void pointset_group_max_grad_tile_kernel(
         }
         __syncthreads();
         const int qe = m - q0 < 64 ? m - q0 : 64;
-        for (int q = grp; q < qe; q += G) {
-            const size_t qa = (size_t)cloud * m + q0 + q;
-            const float g = s_g[cc * 65 + q];
-            const int sel = idx[qa * k + ksel[qa * c + ch]], anc = fidx[qa];
-            const float ag = al * g;
-            atomicAdd(&s_tile[sel * CB + cc], ag);
-            atomicAdd(&s_tile[anc * CB + cc], -ag);
-            da = __builtin_fmaf(g, P[(size_t)sel * c + ch] - P[(size_t)anc * c + ch], da);
-            db += g;
+        // this thread's queries of the chunk, q = grp + G i (at most eight: G >= 8), in PHASES: the pooled slots, then the
+        // neighbours they name, then the two feature values -- three rounds of independent loads per chunk.  (Query by
+        // query the three loads formed a dependent chain per iteration: 64 chains of ~1 us per workgroup at stage 1.)
+        int sl[8], an[8];
+        float gq[8];
+        bool in[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = grp + G * i;
+            in[i] = q < qe;
+            const size_t qa = (size_t)cloud * m + q0 + (in[i] ? q : 0);         // (clamped: every load unconditional)
+            sl[i] = (int)ksel[qa * c + ch];
+            an[i] = fidx[qa];
+            gq[i] = in[i] ? s_g[cc * 65 + q] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const size_t qa = (size_t)cloud * m + q0 + (in[i] ? grp + G * i : 0);
+            sl[i] = idx[qa * k + sl[i]];
+        }
+        float ps[8], pa[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ps[i] = P[(size_t)sl[i] * c + ch];
+            pa[i] = P[(size_t)an[i] * c + ch];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                      // (ascending queries, as before: the same sums)
+            if (in[i]) {
+                const float ag = al * gq[i];
+                atomicAdd(&s_tile[sl[i] * CB + cc], ag);
+                atomicAdd(&s_tile[an[i] * CB + cc], -ag);
+                da = __builtin_fmaf(gq[i], ps[i] - pa[i], da);
+                db += gq[i];
+            }
         }
     }
     __syncthreads();
@@ -248,9 +274,13 @@ extern "C" int apn_pointset_group_max_grad(int b, int n, int m, int c, int k, co
     if (!points || !idx || !fidx || !alpha || !ksel || !g_out || !g_points || !part) return APN_EINVAL;
     const int PG_QT = pg_qt(c);
     // the LDS-tile form where a cloud's slice [n][CB] fits (CB channels per workgroup, a divisor of 256 and of c)
+    // (the widest block that still gives every CU a workgroup, else the narrowest that fits)
     int cbs = 0;
     for (int t = 32; t >= 8; t >>= 1)
-        if (c % t == 0 && (size_t)n * t * sizeof(float) <= 128 * 1024) { cbs = t; break; }
+        if (c % t == 0 && (size_t)n * t * sizeof(float) <= 128 * 1024) {
+            cbs = t;
+            if ((long long)(c / t) * b >= 256) break;
+        }
     if (cbs) {
         const size_t dyn = sizeof(float) * ((size_t)n * cbs + (size_t)cbs * 65 + 512);
         hipError_t ae = hipFuncSetAttribute((const void *)pointset_group_max_grad_tile_kernel,
