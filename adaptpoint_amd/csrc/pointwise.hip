@@ -812,28 +812,25 @@ __global__ __launch_bounds__(256) void pw_pool_grad_points_kernel(int C, int O, 
     }
     const int half = __builtin_amdgcn_readfirstlane(tid >> 7), c = tid & 127, total = nhits;
     float *mine = acc + half * 64 * ld;
-    // four list entries per round: their loads (gradient, weight row) are independent and issued together, the LDS
-    // updates follow in list order (one entry at a time paid a global round trip each: 110 us)
-    for (int k0 = half; k0 < total; k0 += 8) {
-        int o[4], at[4];
-        float gp[4], wv[4];
+    // eight list entries per round: their loads (gradient, weight row) are independent and issued together -- every
+    // load unconditional, entries past the list read entry 0's row and are dropped -- the LDS updates follow in list
+    // order (one entry at a time paid a global round trip each: 110 us; four per round under conditions: 80-112 us)
+    constexpr int PE = 8;
+    const int cw = c < C ? c : 0;
+    for (int k0 = half; k0 < total; k0 += 2 * PE) {
+        int o[PE], at[PE];
+        float gp[PE], wv[PE];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PE; ++j) {
             const int k = k0 + 2 * j;
-            const int h = k < total ? hits[k] : -1;
-            o[j] = h < 0 ? -1 : (h & 0xffffff);
-            at[j] = h < 0 ? 0 : (h >> 24);
+            const int h = hits[k < total ? k : 0];
+            o[j] = k < total ? (h & 0xffffff) : -1;
+            at[j] = h >> 24;
+            gp[j] = hitg[k < total ? k : 0];
+            wv[j] = w[(size_t)(h & 0xffffff) * C + cw];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            gp[j] = 0.0f; wv[j] = 0.0f;
-            if (o[j] >= 0) {
-                gp[j] = hitg[k0 + 2 * j];
-                if (c < C && g_x) wv[j] = w[(size_t)o[j] * C + c];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PE; ++j) {
             if (o[j] >= 0 && c < C) {
                 xsel[((size_t)b * O + o[j]) * C + c] = xt[at[j] * ld + c];
                 if (g_x) mine[at[j] * ld + c] = __builtin_fmaf(wv[j], gp[j], mine[at[j] * ld + c]);
