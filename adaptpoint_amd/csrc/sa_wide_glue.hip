@@ -714,21 +714,24 @@ __global__ __launch_bounds__(256) void csr_sort_long_kernel(int nq, long long np
 //   (row within the cloud) << 16 | mult << 10 | (query within the cloud)
 // so that sorting the words sorts the rows and geo needs nothing but the cloud's query coordinates (LDS too).
 // Counts and cursors by LDS integer atomics (order-free); lists of up to CSR_INS entries sorted by their point's thread
-// (insertion, in place), longer ones by a wave (ranks: the entries of a list are distinct).  plist / pcnt / poff are the
+// (insertion, in place), lists of up to 64 by a wave with one entry per lane (bitonic network over lane exchanges: 21
+// stages), longer ones by a wave through ranks (the entries of a list are distinct).  A thread's insertion sort is a chain
+// of dependent LDS operations: at 64 entries per list it took ~100 us on collapsed clouds.  plist / pcnt / poff are the
 // pure function of idx the kernels above compute; geo is summed in ascending row order (lists up to CSR_INS) or
 // lane-strided + butterfly (longer): fixed orders.  For m <= 1024 (query bits), rows <= 65536 and what fits in LDS.
-constexpr int CSR_INS = 64;
+constexpr int CSR_INS = 16;      // lists up to here: insertion by the point's thread; up to 64: a wave's bitonic network in registers
 __global__ __launch_bounds__(1024) void csr_cloud_kernel(int nq, int b, int n, int m, const int *__restrict__ tmap,
                                                          const float *__restrict__ new_xyz, int *__restrict__ pcnt,
                                                          int *__restrict__ poff, int *__restrict__ plist,
                                                          float *__restrict__ geo, const int *__restrict__ fidx,
-                                                         int *__restrict__ fq, int rows_cap) {
+                                                         int *__restrict__ fq, int rows_cap, int bitonic_words) {
     extern __shared__ int csm[];
     __shared__ int part[1024];
     __shared__ int nlong;
     int *scnt = csm, *soff = csm + n, *slist = csm + 2 * n;
     float *sq = reinterpret_cast<float *>(slist + rows_cap);            // [m][3]
     int *slong = reinterpret_cast<int *>(sq + 3 * m);                    // points with long lists (at most rows_cap / CSR_INS)
+    int *sbit = slong + rows_cap / CSR_INS + 1;                          // [16 waves][bitonic_words]: a long list, padded to a power of two
     const int cloud = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int *__restrict__ tq0 = tmap + 4;
     const unsigned *__restrict__ rows = reinterpret_cast<const unsigned *>(tmap + 4 + ((nq + 3) & ~3));
@@ -815,10 +818,64 @@ __global__ __launch_bounds__(1024) void csr_cloud_kernel(int nq, int b, int n, i
         for (int i = 0; i < c; ++i) geo_term(l[i], occ, sx, sy, sz);
         if (geo) *reinterpret_cast<float4 *>(geo + (cbase + k) * 4) = make_float4(occ, sx, sy, sz);
     }
-    // long lists: a wave each (ranks first, all of them, then the moves: one wave's LDS operations execute in order)
+    // longer lists: a wave each
     for (int li = wave; li < nlong; li += 16) {
         const int k = slong[li], start = soff[k], c = scnt[k] - start;
         int *l = slist + start;
+        if (c <= 64) {                                          // (wave-uniform) one entry per lane, bitonic over the lanes
+            int v = lane < c ? l[lane] : 0x7fffffff;
+#pragma unroll
+            for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    const int o = __shfl_xor(v, j);
+                    const bool up = (lane & kk) == 0, low = (lane & j) == 0;
+                    v = (low == up) ? (v < o ? v : o) : (v > o ? v : o);
+                }
+            }
+            if (lane < c) l[lane] = v;
+            float occ = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+            if (lane < c) geo_term(v, occ, sx, sy, sz);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                occ += __shfl_xor(occ, o); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o);
+            }
+            if (lane == 0 && geo) *reinterpret_cast<float4 *>(geo + (cbase + k) * 4) = make_float4(occ, sx, sy, sz);
+            continue;
+        }
+        if (c <= bitonic_words) {
+            // a bitonic network over this wave's LDS buffer (a thread's insertion sort is a chain of dependent LDS
+            // operations, the rank form below is quadratic: 17 us for a list of 256 -- collapsed clouds have 32 such
+            // lists per cloud)  (one wave owns the buffer: its LDS operations execute in program order)
+            int nn2 = 128;
+            while (nn2 < c) nn2 <<= 1;
+            int *bb = sbit + wave * bitonic_words;
+            for (int i = lane; i < nn2; i += 64) bb[i] = i < c ? l[i] : 0x7fffffff;
+            for (int kk = 2; kk <= nn2; kk <<= 1) {
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    for (int t2 = lane; t2 < nn2 / 2; t2 += 64) {
+                        const int i = ((t2 & ~(j - 1)) << 1) | (t2 & (j - 1));       // the lower index of pair t2 at distance j
+                        const int pp = i | j;
+                        const bool up = (i & kk) == 0;
+                        const int x = bb[i], y = bb[pp];
+                        if ((x > y) == up) { bb[i] = y; bb[pp] = x; }
+                    }
+                }
+            }
+            float occ = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+            for (int i = lane; i < c; i += 64) {
+                const int e2 = bb[i];
+                l[i] = e2;
+                geo_term(e2, occ, sx, sy, sz);
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                occ += __shfl_xor(occ, o); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o);
+            }
+            if (lane == 0 && geo) *reinterpret_cast<float4 *>(geo + (cbase + k) * 4) = make_float4(occ, sx, sy, sz);
+            continue;
+        }
+        // ranks first, all of them, then the moves (one wave's LDS operations execute in order)
         int mine[16], rank[16];
         const int cc = c < 1024 ? c : 1024;                     // (c <= m <= 1024: a point is in a query's rows once)
 #pragma unroll
@@ -924,8 +981,12 @@ extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float 
     {
         // one launch, one workgroup per cloud, when a cloud's map fits in LDS
         const long long rows_cap = (long long)m * 32;
-        const long long lds = 4 * (2ll * n + rows_cap + 3ll * m + rows_cap / apn::CSR_INS + 1);
+        long long lds = 4 * (2ll * n + rows_cap + 3ll * m + rows_cap / apn::CSR_INS + 1);
+        int bitonic_words = 0;                                   // per wave: a buffer for lists of up to this many rows
+        for (int wds = 1024; wds >= 128; wds >>= 1)
+            if (lds + 16ll * wds * 4 <= 150 * 1024) { bitonic_words = wds; break; }
         if (m <= 1024 && rows_cap <= 65536 && lds <= 150 * 1024) {
+            lds += 16ll * bitonic_words * 4;
             static bool configured = false;
             if (!configured) {
                 if (hipError_t e = hipFuncSetAttribute((const void *)apn::csr_cloud_kernel,
@@ -934,7 +995,7 @@ extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float 
                 configured = true;
             }
             hipLaunchKernelGGL(apn::csr_cloud_kernel, dim3(b), dim3(1024), (size_t)lds, st, nq, b, n, m, tmap, new_xyz, pcnt,
-                               poff, plist, geo, fidx, fq, (int)rows_cap);
+                               poff, plist, geo, fidx, fq, (int)rows_cap, bitonic_words);
             APN_LAUNCH_CHECK();
             return APN_OK;
         }
