@@ -630,17 +630,30 @@ __global__ __launch_bounds__(256, 2) void wide_point_grads_kernel(PointGradArgs 
         float part[HPW];
 #pragma unroll
         for (int v = 0; v < HPW; ++v) part[v] = 0.0f;
-        for (int i0 = PG_CAP; i0 < pc; i0 += 64) {
-            const int i = i0 + tx;
-            const int row = pl[i < pc ? i : pc - 1];
-            const float4 *__restrict__ g = reinterpret_cast<const float4 *>(a.GU + (size_t)row * H + h0);
-            float4 x[HPW / 4];
+        // 256 rows per step, four per lane: one round of index loads, one round of row loads (the hot points of a collapsed
+        // cloud are its FIRST 32 points -- one block holds them all, and with 64 rows per step it walked 32 lists of M rows
+        // at two round trips per 64 rows: the whole kernel waited for that block)
+        for (int i0 = PG_CAP; i0 < pc; i0 += 256) {
+            int row[4];
 #pragma unroll
-            for (int v = 0; v < HPW / 4; ++v) x[v] = g[v];
-            if (i < pc) {
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + tx + 64 * u;
+                row[u] = pl[i < pc ? i : pc - 1];
+            }
+            float4 x[4][HPW / 4];
 #pragma unroll
-                for (int v = 0; v < HPW / 4; ++v) {
-                    part[4 * v] += x[v].x; part[4 * v + 1] += x[v].y; part[4 * v + 2] += x[v].z; part[4 * v + 3] += x[v].w;
+            for (int u = 0; u < 4; ++u) {
+                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(a.GU + (size_t)row[u] * H + h0);
+#pragma unroll
+                for (int v = 0; v < HPW / 4; ++v) x[u][v] = g[v];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + tx + 64 * u < pc) {
+#pragma unroll
+                    for (int v = 0; v < HPW / 4; ++v) {
+                        part[4 * v] += x[u][v].x; part[4 * v + 1] += x[u][v].y; part[4 * v + 2] += x[u][v].z; part[4 * v + 3] += x[u][v].w;
+                    }
                 }
             }
         }
