@@ -873,17 +873,50 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
 // workgroup into LDS in fragment order; its a1^T rows are the same fragments.
 // Output: Rpart[split][(O+H) H + H] = {R, suma} (one row per split, summed by the caller in float64).
 // ------------------------------------------------------------------------------------------
+// Round 4: the tile's a1 stays [position][mid channel] in LDS, as it is loaded: every thread reads 16 bytes of four
+// channels of a row of U and of V (the fragment-order build read one float per load: 16 + 16 four-byte loads per
+// fragment-lane, 256 vector-memory instructions per tile and workgroup at H = 256 -- their issue was the tile's time),
+// and the MFMA fragments, whose k index runs over the positions, come out by TRANSPOSED reads (ds_read_b64_tr_b16: a
+// 16-lane group reads 4 positions x 16 channels, every lane receives its channel's 4 positions).  Same bf16 hi / lo
+// values, same products in the same order: R is bit-identical to the fragment-order kernel's.
+template <int H>
+struct WgTile {
+    static constexpr int TR = H + 16;                 // bf16 per position row: + 32 bytes, four consecutive rows on distinct banks
+    static constexpr int PLANE = 32 * TR;
+    static constexpr int BYTES = 2 * 2 * PLANE * 2;   // {a1, mult a1} x {hi, lo}
+};
+
+// fragment (rows / columns blk .. blk + 31 = mid channels, lane r its channel; k = positions 16 s + 8 h .. + 7)
+template <int H>
+__device__ __forceinline__ Frag<2> wg_fragment(const __bf16 *tile, int blk, int s, int r, int h) {
+    typedef short tr_s4 __attribute__((ext_vector_type(4)));
+    typedef short tr_s8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) tr_s4 tr_lds;
+    const int li = r & 15;
+    const __bf16 *src = tile + (s * 16 + h * 8 + (li >> 2)) * WgTile<H>::TR + blk + (r & 16) + 4 * (li & 3);
+    Frag<2> f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const tr_s4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds *)(src + p * WgTile<H>::PLANE));
+        const tr_s4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds *)(src + p * WgTile<H>::PLANE + 4 * WgTile<H>::TR));
+        const tr_s8 v8 = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        f.p[p] = __builtin_bit_cast(bf16x8, v8);
+    }
+    return f;
+}
+
 template <int H, int O, int NW>
 __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const float *__restrict__ pack1,
                                                              const float *__restrict__ goa,
                                                              const unsigned char *__restrict__ ksel,
                                                              float *__restrict__ Rpart) {
-    constexpr int NJ = H / 32, NT = NW * 64, NFRAG = NJ * 2 * 64;      // fragment-lanes per tile
-    __shared__ uint4 bl[NJ * 2 * 2 * 64];                              // a1            [j][s][part][lane]
-    __shared__ uint4 blw[NJ * 2 * 2 * 64];                             // mult * a1 (the Gram product's other side)
-    __shared__ float sred[NFRAG];
+    constexpr int NJ = H / 32, NT = NW * 64;
+    constexpr int C4 = H / 4, PG = NT / C4, PASSES = (32 + PG - 1) / PG;     // float4 per row, position groups, positions per thread
+    static_assert(NT % C4 == 0, "whole rows per pass");
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_raw[];
+    __bf16 *ta = reinterpret_cast<__bf16 *>(wg_raw);                           // a1       [hi | lo][position][TR]
+    __bf16 *tw = ta + 2 * WgTile<H>::PLANE;                                    // mult a1  (the Gram product's other side)
     __shared__ unsigned rinfo[32];
-    __shared__ int rnb[32];
     const int lane = lane_id(), w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int rb = blockIdx.y * NW + w;                                // this wave's row block
     const bool rb_ok = rb < (O + H) / 32;
@@ -893,48 +926,69 @@ __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const f
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
-    constexpr int FPT = (NFRAG + NT - 1) / NT;                         // fragments per thread
-    float suma[FPT];
-#pragma unroll
-    for (int f = 0; f < FPT; ++f) suma[f] = 0.0f;
+    const int c4 = threadIdx.x % C4, pg = threadIdx.x / C4;            // this thread's four channels, its position group
+    const float4 sc = *reinterpret_cast<const float4 *>(pack1 + 4 * c4), sh = *reinterpret_cast<const float4 *>(pack1 + H + 4 * c4);
+    float suma4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int nt = tm_tiles(a);
     const int *__restrict__ tq0 = tm_tq0(a);
     const unsigned *__restrict__ rows = tm_rows(a);
     const int per = (nt + gridDim.x - 1) / gridDim.x;
     const int t0 = blockIdx.x * per, t1 = min(nt, t0 + per);
+    // A tile's row records and neighbours are requested ONE TILE AHEAD, by every thread for the positions it builds (and by
+    // threads 0..31 for the LDS copy the MFMA phase selects with): the build's loads of U and V then start at the top of
+    // the tile instead of behind {records -> LDS -> barrier}, and one barrier per tile goes.
+    unsigned pinf[PASSES], linf = 0u;
+    int pnbr[PASSES];
+    auto request = [&](int tl) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int pos = pg + PG * ps < 32 ? pg + PG * ps : 31;
+            pinf[ps] = rows[(size_t)tl * 32 + pos];
+            pnbr[ps] = tm_nn(a)[(size_t)tl * 32 + pos];
+        }
+        linf = rows[(size_t)tl * 32 + (threadIdx.x & 31)];
+    };
+    if (t0 < t1) request(t0);
     for (int tile = t0; tile < t1; ++tile) {
         const int q0 = tq0[tile];
         const float *__restrict__ ub = a.U + (size_t)(q0 / a.m) * a.n * H;
-        __syncthreads();                                               // previous tile's reads are done
-        if (threadIdx.x < 32) {
-            const unsigned info = rows[(size_t)tile * 32 + threadIdx.x];
-            rinfo[threadIdx.x] = ri_mult(info) ? info : (info & ~0xffu);        // padding: query 0 of the tile
-            rnb[threadIdx.x] = tm_nn(a)[(size_t)tile * 32 + threadIdx.x];
+        float4 uu[PASSES], vv[PASSES];
+        float multv[PASSES];
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {                          // (all loads of the tile, then the arithmetic)
+            const unsigned info = ri_mult(pinf[ps]) ? pinf[ps] : (pinf[ps] & ~0xffu);     // padding: query 0 of the tile
+            uu[ps] = *reinterpret_cast<const float4 *>(ub + (size_t)pnbr[ps] * H + 4 * c4);
+            vv[ps] = *reinterpret_cast<const float4 *>(a.V + (size_t)(q0 + ri_q(info)) * H + 4 * c4);
+            multv[ps] = (float)ri_mult(info);
         }
-        __syncthreads();
+        __syncthreads();                                               // previous tile's reads are done
+        if (threadIdx.x < 32) rinfo[threadIdx.x] = ri_mult(linf) ? linf : (linf & ~0xffu);
+        request(tile + 1 < t1 ? tile + 1 : tile);
+        {
 #pragma unroll
-        for (int f = 0; f < FPT; ++f) {
-            const int fi = threadIdx.x + NT * f;                       // (j, s, lane') = fragment-lane
-            if (fi < NFRAG) {
-                const int fl = fi & 63, s = (fi >> 6) & 1, j = fi >> 7;
-                const int mid = j * 32 + (fl & 31), p0 = s * 16 + (fl >> 5) * 8;
-                const float sc = pack1[mid], sh = pack1[H + mid];
-                float t[8], tw[8], sum = 0.0f;
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int pos = pg + PG * ps;
+                if (pos < 32) {
+                    const float mult = multv[ps];
+                    const float y[4] = {uu[ps].x - vv[ps].x, uu[ps].y - vv[ps].y, uu[ps].z - vv[ps].z, uu[ps].w - vv[ps].w};
+                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                    bf16x4 ah, al, wh, wl;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const unsigned info = rinfo[p0 + e];
-                    const float y1 = ub[(size_t)rnb[p0 + e] * H + mid] - a.V[(size_t)(q0 + ri_q(info)) * H + mid];
-                    const float v = __builtin_fmaf(y1, sc, sh);
-                    t[e] = v > 0.0f ? v : 0.0f;
-                    tw[e] = t[e] * (float)ri_mult(info);
-                    sum += tw[e];
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = __builtin_fmaf(y[e], scv[e], shv[e]);
+                        const float t = v > 0.0f ? v : 0.0f, tw_ = t * mult;
+                        suma4[e] += tw_;
+                        const __bf16 th = (__bf16)t, wh_ = (__bf16)tw_;
+                        ah[e] = th; al[e] = (__bf16)(t - (float)th);
+                        wh[e] = wh_; wl[e] = (__bf16)(tw_ - (float)wh_);
+                    }
+                    const int o = pos * WgTile<H>::TR + 4 * c4;
+                    *reinterpret_cast<bf16x4 *>(ta + o) = ah;
+                    *reinterpret_cast<bf16x4 *>(ta + WgTile<H>::PLANE + o) = al;
+                    *reinterpret_cast<bf16x4 *>(tw + o) = wh;
+                    *reinterpret_cast<bf16x4 *>(tw + WgTile<H>::PLANE + o) = wl;
                 }
-                suma[f] += sum;
-                const Frag<2> fr = make_frag<2>(t), fw = make_frag<2>(tw);
-                bl[((j * 2 + s) * 2 + 0) * 64 + fl] = __builtin_bit_cast(uint4, fr.p[0]);
-                bl[((j * 2 + s) * 2 + 1) * 64 + fl] = __builtin_bit_cast(uint4, fr.p[1]);
-                blw[((j * 2 + s) * 2 + 0) * 64 + fl] = __builtin_bit_cast(uint4, fw.p[0]);
-                blw[((j * 2 + s) * 2 + 1) * 64 + fl] = __builtin_bit_cast(uint4, fw.p[1]);
             }
         }
         __syncthreads();
@@ -944,43 +998,54 @@ __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const f
             const int c = rb * 32 + r;
             // (all sixteen slots and gradients requested before the first is used: `mult && ksel == slot ? goa : 0` was a
             // chain of up to 32 dependent loads per lane and tile -- padding rows name query 0 of the tile: valid addresses)
-            unsigned char ks[2][8];
-            float gv[2][8];
+            const int nq = __builtin_amdgcn_readfirstlane((int)(rinfo[0] >> 24));      // (row 0 holds the tile's query count)
+            if (nq == 1) {
+                // a tile of ONE query (dense neighbourhoods pack that way: stages 3-4): one slot and one gradient per
+                // lane, not sixteen copies of each (32 vector-memory instructions per wave and tile)
+                const size_t qc = (size_t)q0 * O + c;
+                const int k1 = (int)ksel[qc];
+                const float g1 = goa[qc];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < 2; ++s) {
+                    float t[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const size_t qc = (size_t)(q0 + ri_q(rinfo[s * 16 + h * 8 + e])) * O + c;
-                    ks[s][e] = ksel[qc];
-                    gv[s][e] = goa[qc];
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned info = rinfo[s * 16 + h * 8 + e];
+                        t[e] = (ri_mult(info) != 0 && k1 == ri_slot(info)) ? g1 : 0.0f;
+                    }
+                    af[s] = make_frag<2>(t);
                 }
+            } else {
+                unsigned char ks[2][8];
+                float gv[2][8];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float t[8];
+                for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const unsigned info = rinfo[s * 16 + h * 8 + e];
-                    t[e] = (ri_mult(info) != 0 && (int)ks[s][e] == ri_slot(info)) ? gv[s][e] : 0.0f;
+                    for (int e = 0; e < 8; ++e) {
+                        const size_t qc = (size_t)(q0 + ri_q(rinfo[s * 16 + h * 8 + e])) * O + c;
+                        ks[s][e] = ksel[qc];
+                        gv[s][e] = goa[qc];
+                    }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned info = rinfo[s * 16 + h * 8 + e];
+                        t[e] = (ri_mult(info) != 0 && (int)ks[s][e] == ri_slot(info)) ? gv[s][e] : 0.0f;
+                    }
+                    af[s] = make_frag<2>(t);
                 }
-                af[s] = make_frag<2>(t);
             }
         } else {                        // A = (mult a1)^T rows of mid block rb - O/32
             const int j0 = rb - O / 32;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                af[s].p[0] = __builtin_bit_cast(bf16x8, blw[((j0 * 2 + s) * 2 + 0) * 64 + lane]);
-                af[s].p[1] = __builtin_bit_cast(bf16x8, blw[((j0 * 2 + s) * 2 + 1) * 64 + lane]);
-            }
+            for (int s = 0; s < 2; ++s) af[s] = wg_fragment<H>(tw, j0 * 32, s, r, h);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                Frag<2> bf;
-                bf.p[0] = __builtin_bit_cast(bf16x8, bl[((j * 2 + s) * 2 + 0) * 64 + lane]);
-                bf.p[1] = __builtin_bit_cast(bf16x8, bl[((j * 2 + s) * 2 + 1) * 64 + lane]);
-                acc[j] = mfma<2>(af[s], bf, acc[j]);
-            }
+            for (int s = 0; s < 2; ++s) acc[j] = mfma<2>(af[s], wg_fragment<H>(ta, j * 32, s, r, h), acc[j]);
     }
     if (rb_ok) {
         float *__restrict__ out = Rpart + (size_t)blockIdx.x * ((O + H) * H + H) + (size_t)rb * 32 * H;
@@ -989,19 +1054,17 @@ __global__ __launch_bounds__(NW * 64) void wide_wgrad_kernel(WideArgs a, const f
 #pragma unroll
             for (int i = 0; i < 16; ++i) out[(size_t)acc_row(i, h) * H + j * 32 + r] = acc[j][i];
     }
-    // sum a1: the 4 fragment-lanes (s, h) of one mid channel, fixed order
+    // sum a1: the position groups of one mid channel, fixed order
     if (blockIdx.y == 0) {
+        float *sred = reinterpret_cast<float *>(wg_raw);               // [PG][H]
         __syncthreads();
 #pragma unroll
-        for (int f = 0; f < FPT; ++f) {
-            const int fi = threadIdx.x + NT * f;
-            if (fi < NFRAG) sred[fi] = suma[f];
-        }
+        for (int e = 0; e < 4; ++e) sred[pg * H + 4 * c4 + e] = suma4[e];
         __syncthreads();
         for (int mid = threadIdx.x; mid < H; mid += NT) {
-            const int j = mid >> 5, rr = mid & 31;
-            const float v = (sred[(j * 2 + 0) * 64 + rr] + sred[(j * 2 + 0) * 64 + 32 + rr]) +
-                            (sred[(j * 2 + 1) * 64 + rr] + sred[(j * 2 + 1) * 64 + 32 + rr]);
+            float v = 0.0f;
+#pragma unroll 1
+            for (int g = 0; g < PG; ++g) v += sred[g * H + mid];
             Rpart[(size_t)blockIdx.x * ((O + H) * H + H) + (size_t)(O + H) * H + mid] = v;
         }
     }
@@ -1203,7 +1266,17 @@ extern "C" int apn_sa_wide_wgrad(int b, int n, int m, int c_mid, int c_out, cons
     APN_WIDE_DISPATCH(c_mid, {
         constexpr int O = 2 * H, NRB = (O + H) / 32, NW = NRB < 8 ? NRB : 8;
         const dim3 grid(splits, (NRB + NW - 1) / NW);
-        hipLaunchKernelGGL((wide_wgrad_kernel<H, O, NW>), grid, dim3(NW * 64), 0, (hipStream_t)stream, a,
+        constexpr int lds = WgTile<H>::BYTES > NW * 64 / (H / 4) * H * 4 ? WgTile<H>::BYTES : NW * 64 / (H / 4) * H * 4;
+        if (lds > 48 * 1024) {
+            static bool configured = false;          // (per instantiation)
+            if (!configured) {
+                if (hipError_t e = hipFuncSetAttribute((const void *)wide_wgrad_kernel<H, O, NW>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+                    return (int)e;
+                configured = true;
+            }
+        }
+        hipLaunchKernelGGL((wide_wgrad_kernel<H, O, NW>), grid, dim3(NW * 64), lds, (hipStream_t)stream, a,
                            pack1, goa, (const unsigned char *)ksel, r_part);
     });
     APN_LAUNCH_CHECK();
