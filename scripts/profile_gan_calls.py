@@ -1,6 +1,6 @@
 """Every extension launch of one eager joint step between its own HIP events: time, entry point, leading integer arguments.
 
-    python scripts/profile_gan_calls.py [rows to print]
+    python scripts/profile_gan_calls.py [rows to print] [--order]
 """
 import os, sys
 ROOT = "/root/repo"
@@ -40,6 +40,12 @@ torch.cuda.synchronize()
 rows = [(s.elapsed_time(e) * 1e3, n, a) for n, a, s, e in acc]
 tot = sum(r[0] for r in rows)
 print(f"{len(rows)} extension calls, {tot/1e3:.2f} ms between their own events")
-top = int(sys.argv[1]) if len(sys.argv) > 1 else 45
-for us, n, a in sorted(rows, reverse=True)[:top]:
-    print(f"{us:8.1f} us  {n:36s} {a}")
+args = [x for x in sys.argv[1:] if not x.startswith("--")]
+top = int(args[0]) if args else 45
+if "--order" in sys.argv:            # in launch order, with the time since the step's first launch
+    t0 = acc[0][2]
+    for n, a, s, e in acc:
+        print(f"{t0.elapsed_time(s) * 1e3:9.1f} us  +{s.elapsed_time(e) * 1e3:7.1f}  {n:36s} {a}")
+else:
+    for us, n, a in sorted(rows, reverse=True)[:top]:
+        print(f"{us:8.1f} us  {n:36s} {a}")
