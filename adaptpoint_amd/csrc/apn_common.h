@@ -100,12 +100,42 @@ __device__ __forceinline__ double acc_read(const unsigned long long *set, int nc
     return (double)hi + (double)lo * (1.0 / 4503599627370496.0);
 }
 
+// Instruction-issue priority of the CRITICAL stream's waves (s_setprio 0..3, default 0): the seven launches of the fused
+// set-abstraction step raise it at entry, so that on a SIMD they share with the index stream's waves (FPS: five always-ready
+// waves per SIMD in a tight VALU + LDS loop; the ball query: the chip's wave slots full of distance tests) the arbiter issues
+// THEIR ready instructions first.  Inside one kernel every wave has the same priority: nothing changes there.  Measured
+// (profiles/r05_index_interference_*.txt): the MLP-stream kernels were 2-3x slower beside the sampler (issue slots, not
+// registers: the sampler holds 19 VGPRs per wave).
+#ifndef APN_MLP_PRIO
+#define APN_MLP_PRIO 3
+#endif
+__device__ __forceinline__ void critical_stream_priority() {
+    if (APN_MLP_PRIO > 0) __builtin_amdgcn_s_setprio(APN_MLP_PRIO);
+}
+
 __device__ __forceinline__ int lane_id() {
     return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+
+// Raising a kernel's dynamic-LDS limit is a property of the CURRENT DEVICE's copy of the function: the "done" flag is
+// kept per device (bit d of the mask), so a process that launches on a second GPU sets the attribute there too; the
+// atomic mask makes the first launches of two host threads safe (setting the attribute twice is harmless).
+struct DynLdsOnce {
+    unsigned long long mask = 0ull;
+};
+inline hipError_t set_dyn_lds(DynLdsOnce &once, const void *fn, int bytes) {
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && ((__atomic_load_n(&once.mask, __ATOMIC_ACQUIRE) >> dev) & 1ull)) return hipSuccess;
+    if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) return e;
+    if (tracked) __atomic_fetch_or(&once.mask, 1ull << dev, __ATOMIC_RELEASE);
+    return hipSuccess;
 }
 
 }  // namespace apn

@@ -907,13 +907,8 @@ extern "C" int apn_pw_conv_tiles(int b, int n) { return b * ((n + apn::PW_T - 1)
 template <bool AK, bool BK, int NS>
 static int pw_launch(dim3 grid, const apn::PwGemm &g, hipStream_t stream) {
     using namespace apn;
-    static bool configured = false;      // per instantiation; setting it twice is harmless
-    if (!configured) {
-        if (hipError_t e = hipFuncSetAttribute((const void *)pw_gemm_kernel<AK, BK, NS>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, pw_lds_bytes<NS>()))
-            return (int)e;
-        configured = true;
-    }
+    static DynLdsOnce configured;        // per instantiation and device (apn_common.h)
+    if (hipError_t e = set_dyn_lds(configured, (const void *)pw_gemm_kernel<AK, BK, NS>, pw_lds_bytes<NS>())) return (int)e;
     hipLaunchKernelGGL((pw_gemm_kernel<AK, BK, NS>), grid, dim3(512), pw_lds_bytes<NS>(), stream, g);
     APN_LAUNCH_CHECK();
     return APN_OK;

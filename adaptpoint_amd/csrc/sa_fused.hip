@@ -181,6 +181,7 @@ __global__ __launch_bounds__(PS_NT) void sa_prep_stats_kernel(
     __shared__ double sdd[6];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    critical_stream_priority();
     wg_stamp(0);
     // accumulators of LATER launches (BatchNorm-2's sums) are cleared here
     for (long long e = (long long)blockIdx.x * PS_NT + tid; e < zero_words; e += (long long)gridDim.x * PS_NT) zero[e] = 0ull;
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 3) void sa_fwd_main_kernel(
     __shared__ __attribute__((aligned(16))) float ptile[SA_WAVES * PT_WAVE];
     __shared__ __attribute__((aligned(16))) unsigned sinfo[SA_WAVES][32];
     static_assert(SA_WAVES * PT_WAVE * 4 >= 17 * 64 * 8, "fold scratch");
+    critical_stream_priority();
     stamp(a, wave, 0);
     const float sg[2] = {(!gamma2 || gamma2[r] >= 0.0f) ? 1.0f : -1.0f, (!gamma2 || gamma2[32 + r] >= 0.0f) ? 1.0f : -1.0f};
     float st[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // sum t0, sum t1, sumsq t0, sumsq t1
@@ -811,6 +813,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     __shared__ __attribute__((aligned(16))) float sw2[SA_C2][SA_C1 + 4];   // W2 (prologue products, epilogue row)
     __shared__ float sD[SA_C2], sE[SA_C2];
     __shared__ __attribute__((aligned(16))) float sqm[SA_C1 + 1][SA_C1 + 4];   // Qm[k][mid]; row 32 = evec; later Gram | suma
+    critical_stream_priority();
     stamp(a, wave, 0);
     // BatchNorm-1's constants of channel r and evec[r]: kept in LDS and READ PER TILE (five registers less across the loop:
     // the pass runs at the register file's limit, see for_each_tile)
@@ -1459,12 +1462,8 @@ extern "C" int apn_sa_prep_stats(int b, int n, const float *f, const void *geo, 
     const int tpc = (n + PS_PTS - 1) / PS_PTS;
     auto kern = precision == 2 ? sa_prep_stats_kernel<2> : sa_prep_stats_kernel<1>;
     const int lds = SA_C * (PS_PTS + 1) * (int)sizeof(float);
-    static bool lds_set[2] = {false, false};                  // (idempotent: a racing second call sets the same value)
-    if (!lds_set[precision - 1]) {
-        if (hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds))
-            return (int)e;
-        lds_set[precision - 1] = true;
-    }
+    static DynLdsOnce lds_set[2];                             // (per precision and device: apn_common.h)
+    if (hipError_t e = set_dyn_lds(lds_set[precision - 1], (const void *)kern, lds)) return (int)e;
     hipLaunchKernelGGL(kern, dim3(apn_sa_prep_rows(b, n)), dim3(PS_NT), lds, (hipStream_t)stream, n, tpc, b * tpc, f,
                        (const long long *)geo, (const double *)dd, b * (apn_sa_geo_dd_doubles(n) / 6), w1, stats, hi, lo, part1,
                        (unsigned long long *)zero, zero_words);

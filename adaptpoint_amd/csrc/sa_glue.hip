@@ -271,6 +271,7 @@ __global__ __launch_bounds__(QT * 16) void fwd_out_kernel(int n, int m, const fl
     // BatchNorm-2 folded here (formerly a launch of its own): {sum, sumsq}[64] of y2 from the forward pass's
     // accumulator set (integer atomics: the same bits in every workgroup and every run) or from reduced sums
     const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+    critical_stream_priority();
     wg_stamp(0);
     double count2 = bn2.count;
     double g2pre = 1.0, b2pre = 0.0;               // requested with the first loads, used behind the barrier
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
     const int cloud = blockIdx.y, m0 = blockIdx.x * QT;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..NW-1
     const int ql = tx % QT, hh = tx / QT;
+    critical_stream_priority();
     wg_stamp(0);
     // every load of the phase is issued before the first one is used (clamped indices, selected afterwards)
     const int qc = m0 + ql < m ? m0 + ql : m - 1;
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
     __shared__ float sGeo[WG_PTS][4];   // count, sum of relative positions
     __shared__ float sc[5][32];         // ca, cb, cc, mean1, inv1
     const int tid = threadIdx.x;
+    critical_stream_priority();
     wg_stamp(0);
     const int cloud = blockIdx.y, n0 = blockIdx.x * WG_PTS;
     const int block = cloud * gridDim.x + blockIdx.x;
@@ -814,6 +817,7 @@ __global__ __launch_bounds__(FIN_COLS * FIN_GROUPS) void bwd_finalize_kernel(
     float *__restrict__ g_bs, float *__restrict__ g_g2, float *__restrict__ g_b2, float *__restrict__ g_g1,
     float *__restrict__ g_b1) {
     __shared__ double red[FIN_GROUPS][FIN_COLS];
+    critical_stream_priority();
     const int o = threadIdx.x % FIN_COLS, g = threadIdx.x / FIN_COLS;
     const int e = blockIdx.x * FIN_COLS + o;
     double v = 0.0;

@@ -1199,13 +1199,9 @@ extern "C" int apn_sa_wide_fwd_main(int b, int n, int m, int c_mid, int c_out, c
         const size_t lds = (size_t)(RES ? NCH : 2) * Chunk<CT>::WORDS * 16 + (size_t)WIDE_WAVES * 2 * O * 4 +
                            (H >= 128 ? (size_t)2 * H * 4 : 0);
         if (lds > 64 * 1024) {
-            static bool configured = false;          // (per instantiation)
-            if (!configured) {
-                if (hipError_t e = hipFuncSetAttribute((const void *)wide_fwd_main_kernel<H, O, CT, RES>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-                    return (int)e;
-                configured = true;
-            }
+            static DynLdsOnce configured;            // (per instantiation and device)
+            if (hipError_t e = set_dyn_lds(configured, (const void *)wide_fwd_main_kernel<H, O, CT, RES>, (int)lds))
+                return (int)e;
         }
         hipLaunchKernelGGL((wide_fwd_main_kernel<H, O, CT, RES>), dim3(grid), dim3(256), lds,
                            (hipStream_t)stream, a, (const uint4 *)w2_image, pack1, sgn2, ysel,
@@ -1268,13 +1264,8 @@ extern "C" int apn_sa_wide_wgrad(int b, int n, int m, int c_mid, int c_out, cons
         const dim3 grid(splits, (NRB + NW - 1) / NW);
         constexpr int lds = WgTile<H>::BYTES > NW * 64 / (H / 4) * H * 4 ? WgTile<H>::BYTES : NW * 64 / (H / 4) * H * 4;
         if (lds > 48 * 1024) {
-            static bool configured = false;          // (per instantiation)
-            if (!configured) {
-                if (hipError_t e = hipFuncSetAttribute((const void *)wide_wgrad_kernel<H, O, NW>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds))
-                    return (int)e;
-                configured = true;
-            }
+            static DynLdsOnce configured;            // (per instantiation and device)
+            if (hipError_t e = set_dyn_lds(configured, (const void *)wide_wgrad_kernel<H, O, NW>, lds)) return (int)e;
         }
         hipLaunchKernelGGL((wide_wgrad_kernel<H, O, NW>), grid, dim3(NW * 64), lds, (hipStream_t)stream, a,
                            pack1, goa, (const unsigned char *)ksel, r_part);

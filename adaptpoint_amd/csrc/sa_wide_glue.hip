@@ -987,13 +987,8 @@ extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float 
             if (lds + 16ll * wds * 4 <= 150 * 1024) { bitonic_words = wds; break; }
         if (m <= 1024 && rows_cap <= 65536 && lds <= 150 * 1024) {
             lds += 16ll * bitonic_words * 4;
-            static bool configured = false;
-            if (!configured) {
-                if (hipError_t e = hipFuncSetAttribute((const void *)apn::csr_cloud_kernel,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
-                    return (int)e;
-                configured = true;
-            }
+            static apn::DynLdsOnce configured;       // (per device: apn_common.h)
+            if (hipError_t e = apn::set_dyn_lds(configured, (const void *)apn::csr_cloud_kernel, 150 * 1024)) return (int)e;
             hipLaunchKernelGGL(apn::csr_cloud_kernel, dim3(b), dim3(1024), (size_t)lds, st, nq, b, n, m, tmap, new_xyz, pcnt,
                                poff, plist, geo, fidx, fq, (int)rows_cap, bitonic_words);
             APN_LAUNCH_CHECK();

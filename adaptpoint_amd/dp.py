@@ -27,6 +27,19 @@ def init(backend, device=None, force=False):
     return world, rank
 
 
+def all_reduce_sum_(t):
+    """dist.all_reduce(t) (SUM, in place) on whatever backend the group has.  Device tensors over a gloo group (two ranks
+    sharing ONE GPU in tests/test_gpu_syncbn_two_ranks.py: RCCL refuses two ranks on one device) are staged through the
+    host -- the collective itself is `torch.distributed.all_reduce` either way, so `workloads.count_collectives` counts it."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        host = t.detach().cpu()
+        dist.all_reduce(host)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t)
+    return t
+
+
 def fence(device=None):
     """barrier + device synchronize: brackets the timed region on both sides."""
     if dist.is_initialized():
@@ -112,12 +125,12 @@ def allreduce_mean_(tensors):
         if dist.get_backend() == "nccl":
             dist.all_reduce(span, op=dist.ReduceOp.AVG)
         else:
-            dist.all_reduce(span)
+            all_reduce_sum_(span)
             if world > 1:
                 span.div_(world)
         return
     flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.all_reduce(flat)
+    all_reduce_sum_(flat)
     if world > 1:
         flat.div_(world)
     off = 0
@@ -145,7 +158,7 @@ FORCE_COLLECTIVES = False      # testing hook: issue the statistics all-reduces 
 
 def _sum_over_ranks_(t):
     if dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES):
-        dist.all_reduce(t)
+        all_reduce_sum_(t)
     return t
 
 

@@ -136,7 +136,8 @@ def _allreduce_sum_(t):
     """In-place sum over ranks (the one collective of the SyncBatchNorm exchange; a seam for tests)."""
     # (FORCE_PHASED: the collective is issued at world size 1 too, so that a one-GPU box runs the RCCL call itself)
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_PHASED):
-        dist.all_reduce(t)
+        from . import dp
+        dp.all_reduce_sum_(t)
 
 
 def _phased(sync):

@@ -91,9 +91,36 @@ def _sa_forward(self, pf):
     if isinstance(ad, str):
         _count("SetAbstraction.reference: " + ad)
         return _sa_original(self, pf)
+    why = _call_outside_fused(ad, pf)
+    if why is not None:                              # per CALL: the structure fits, this input does not
+        _count("SetAbstraction.reference: " + why)
+        return _sa_original(self, pf)
     ad.training = self.training
     _count("SetAbstraction.fused")
     return ad(pf)
+
+
+# the fused index stage (csrc/sa_seq.hip: apn_sa_sample_seq -> the resident samplers of csrc/fps.hip) takes clouds of at
+# most this many points; larger ones (S3DIS rooms at 24 k) go to the reference's own forward, whose furthest_point_sample
+# reaches the streaming sampler through the drop-in operator
+MAX_FUSED_POINTS = 16384
+
+
+def _call_outside_fused(ad, pf):
+    """Why THIS call cannot take the adapter (None: it can).  The adapter was chosen from the module's structure alone;
+    the tensors are checked here, per call, so that an uncovered input never raises out of a patched tree."""
+    import torch
+    p, f = pf[0], pf[1]
+    if not (torch.is_tensor(p) and torch.is_tensor(f)):
+        return "inputs are not tensors"
+    # (CPU tensors are not diverted: the reference's forward would hand them to the same drop-in operators, which refuse
+    # them just as loudly -- adaptpoint_amd/ops.py has no CPU path -- and tests/test_integrate_reference_cpu.py runs the
+    # adapters' composed mirrors on CPU tensors over the oracle to compare them with the REAL reference classes)
+    if p.dtype != torch.float32 or f.dtype != torch.float32:
+        return f"dtype {p.dtype} / {f.dtype}"
+    if not ad.is_head and not ad.all_aggr and p.shape[1] > MAX_FUSED_POINTS:
+        return f"N > {MAX_FUSED_POINTS}"
+    return None
 
 
 def _sa_original(self, pf):

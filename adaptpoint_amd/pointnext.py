@@ -11,7 +11,7 @@ shape the fused kernels cover; the other stages run the unfused extension operat
 import torch
 import torch.nn as nn
 
-from .set_abstraction import SetAbstraction
+from .set_abstraction import MAX_SAMPLE_SEQ_POINTS, SetAbstraction
 
 # forward_cls_feat without a pyramid handed in builds one itself (nested sampler: blocks 2-4 sample from the previous
 # block's samples, which FPS returns as a prefix).  False: every block runs its own full sampler, as the reference does.
@@ -99,7 +99,9 @@ class PointNextEncoderS(nn.Module):
             p0, f0 = p0['pos'], p0.get('x', None)
         if f0 is None:
             f0 = p0.clone().transpose(1, 2).contiguous()
-        if pyramid is None and p0.is_cuda and NESTED_PYRAMID:
+        if pyramid is None and p0.is_cuda and NESTED_PYRAMID and p0.shape[1] <= MAX_SAMPLE_SEQ_POINTS:
+            # (larger clouds: every block samples itself -- the unfused operators' streaming sampler; the nested copy only
+            # pays off for N <= 4096 anyway)
             # the index stages of all blocks first (coordinates only; gradients reach p0 through the blocks' own
             # differentiable gathers): deeper levels then cost a copy instead of a sampler chain
             pyramid = self.index_pyramid(p0.detach())

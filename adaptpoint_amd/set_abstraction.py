@@ -26,6 +26,7 @@ FUSED_FALLBACKS = {}
 # True: the width-generic kernels (csrc/sa_wide.hip) also take the 32 -> 32 -> 64 shape that the
 # register-resident kernels of csrc/sa_fused.hip specialise in (A/B switch for benchmarks and tests).
 PREFER_WIDE = False
+MAX_SAMPLE_SEQ_POINTS = 16384   # apn_sa_sample_seq / apn_furthest_point_sampling_xyz: clouds kept in registers / LDS
 COMPACT_RESIDENT = True      # the register-resident kernels run over the distinct-hit tile map when a Sampling carries one
 
 
@@ -37,6 +38,11 @@ def _note_fallback(reason):
     if reason not in FUSED_FALLBACKS:
         _log.warning("SetAbstraction(fused=True) runs UNFUSED: %s", reason)
     FUSED_FALLBACKS[reason] = FUSED_FALLBACKS.get(reason, 0) + 1
+
+
+def _ranks():
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
 def _norm(norm_args, channels, dim):
@@ -198,6 +204,11 @@ class SetAbstraction(nn.Module):
         g = self.grouper
         if not fused_wide.supported(p, f, g.nsample, conv1, conv2, bns=(bn1, bn2), npoint=p.shape[1] // self.stride):
             return None
+        if sampling is None and p.shape[1] > MAX_SAMPLE_SEQ_POINTS:
+            # the fused index stage (apn_sa_sample_seq) keeps a cloud resident: larger clouds take the unfused operators,
+            # whose FPS is the streaming sampler (csrc/fps.hip: fps_stream_kernel)
+            _note_fallback(f"N={p.shape[1]} > {MAX_SAMPLE_SEQ_POINTS}: index stage beyond the resident samplers")
+            return None
         C, H = f.shape[1], conv1.weight.shape[0]
         skip = self._skip_conv1d()
         if self.use_res and skip is None:
@@ -236,7 +247,7 @@ class SetAbstraction(nn.Module):
         conv1, bn1, conv2, bn2, relu_after = parts
         g = self.grouper
         if (not fused.supported(p, f, g.nsample, conv1, conv2, bns=(bn1, bn2),
-                               npoint=p.shape[1] // self.stride) or p.shape[1] > 16384
+                               npoint=p.shape[1] // self.stride) or p.shape[1] > MAX_SAMPLE_SEQ_POINTS
                 or fused_wide_first()):
             return None
         skip = None
@@ -306,8 +317,16 @@ class SetAbstraction(nn.Module):
         pooled = self._fused_forward(new_p, p, f, idx) if (self.fused and not self.all_aggr) else None
         if pooled is None:
             if self.fused and not self.all_aggr:
-                _note_fallback(f"C_in={f.shape[1]} -> {[c[0].out_channels for c in self.convs]}, "
-                               f"K={getattr(self.grouper, 'nsample', None)}: no fused kernel for this shape")
+                why = (f"C_in={f.shape[1]} -> {[c[0].out_channels for c in self.convs]}, "
+                       f"K={getattr(self.grouper, 'nsample', None)}: no fused kernel for this shape")
+                if self.sync_bn and _ranks() > 1:
+                    # workloads.sync_batchnorm_ left this block's BatchNorms unconverted because the block exchanges its own
+                    # sums; the composed path below would normalise with RANK-LOCAL statistics -- silently not the reference's
+                    # SyncBatchNorm (train_autoaug.py:275-282).  Loud instead.
+                    raise RuntimeError("SetAbstraction(fused=True, sync_bn=True) cannot run its fused kernels (" + why +
+                                       ") and its BatchNorm modules are plain ones: convert them "
+                                       "(adaptpoint_amd.dp.convert_sync_batchnorm) or build the block with fused=False")
+                _note_fallback(why)
             dp, fj = self.grouper(new_p, p, f, idx) if idx is not None else self.grouper(new_p, p, f)
             x = torch.cat([dp, fj], 1)                                   # 'dp_fj' (group.py:325-326)
             if self.fused and self.all_aggr and x.shape[2] == 1:

@@ -131,16 +131,21 @@ class KernelTimer:
         t = sorted(1e3 * s.elapsed_time(e) / self.burst_n for s, e in self.bursts)
         return t[len(t) // 2]
 
-    def mean_us(self):
-        """(the lower-quartile pair per kernel: a pair can only read LONG -- it sits behind a late host launch, or the
-        dispatch behind its start event is slow -- never short; the median of six pairs read 32-36 us from run to run for
-        a kernel rocprofv3 puts at 31)"""
+    def stats_us(self):
+        """Per kernel: (median, lower quartile) of its event pairs, in us.  The MEDIAN is what `roofline` and the per-kernel
+        table report as the average launch duration (it agrees with rocprofv3's average within the run-to-run spread); the
+        lower quartile is printed beside it as `p25_us` -- a pair can only read long (it sits behind a late host launch, or
+        the dispatch behind its start event is slow), never short, so it is the better estimate of the kernel alone, but it
+        is a selected statistic and never feeds `frac`."""
         torch.cuda.synchronize()
         out = {}
         for k, v in self.pairs.items():
             t = sorted(s.elapsed_time(e) for s, e in v)
-            out[k] = 1e3 * t[len(t) // 4]
+            out[k] = (1e3 * t[len(t) // 2], 1e3 * t[len(t) // 4])
         return out
+
+    def mean_us(self):
+        return {k: v[0] for k, v in self.stats_us().items()}
 
 
 def instrument(timer, only=None):
@@ -294,7 +299,7 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
         index_batch -= 1
     if pipelined:
         from adaptpoint_amd.fused import Sampling
-        side_stream = torch.cuda.Stream()
+        side_stream = torch.cuda.Stream(priority=int(os.environ.get("APN_BENCH_SIDE_PRIORITY", "0")))
         # Two sets of spg index-stage results: a launch of spg steps consumes set `cur` on the
         # main stream while the side stream fills the other set for the NEXT launch -- the
         # streams meet once per launch (fork at its start, join at its end), not once per step:
@@ -695,6 +700,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    if os.environ.get("APN_BENCH_MAIN_PRIORITY"):            # (experiment: the MLP stream as a high-priority stream)
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["APN_BENCH_MAIN_PRIORITY"])))
     dev = torch.device("cuda", local_rank)
     if distributed and args.graph_collectives != "off":
         # collectives inside hipGraphs: the watchdog must not poll events of in-flight work (PyTorch's
@@ -749,7 +756,8 @@ def main():
         torch.cuda._sleep(2_000_000)
         eager_step()
         torch.cuda.synchronize()
-    per_kernel_us = timer_all.mean_us()
+    per_kernel_stats = timer_all.stats_us()
+    per_kernel_us = {k: v[0] for k, v in per_kernel_stats.items()}
     restore()
 
     total_clouds = B_PER_GPU * world * args.steps
@@ -759,7 +767,7 @@ def main():
         ab[k] *= m.index_batch
     kernels = {}
     for k, us in sorted(per_kernel_us.items()):
-        ent = {"avg_us": round(us, 2)}
+        ent = {"avg_us": round(us, 2), "p25_us": round(per_kernel_stats[k][1], 2)}
         if k in ab:
             ent["algorithmic_bytes"] = ab[k]
             ent["achieved_GBps"] = round(ab[k] / us * 1e-3, 2)
@@ -768,13 +776,23 @@ def main():
     # PMC-measured HBM bytes per launch (rocprofv3 --pmc passes over THIS command's default launch structure,
     # corrected as MI355X_MICROARCH.md prescribes; scripts/collect_profiles.sh pmc -> scripts/make_traffic_json.py).
     # A committed constant, labelled as such: bench.py cannot run the profiler on itself.
-    traffic, traffic_src = {}, None
+    traffic, traffic_src, traffic_stamp = {}, None, {}
     for name in (TRAFFIC_FILE,):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("structure", "default") == "default":
                 traffic, traffic_src = tj.get("bytes_per_launch", {}), "profiles/" + name
+                # which tree the constant belongs to: the commit it was collected at, and whether the kernel sources it was
+                # collected from are THIS tree's (scripts/make_traffic_json.py hashes them)
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                try:
+                    import make_traffic_json as _mt
+                    traffic_stamp = {"collected_at_commit": tj.get("collected_at_commit"),
+                                     "sources_match": tj.get("kernel_sources_sha16") == _mt.sources_sha16(ROOT)
+                                     if tj.get("kernel_sources_sha16") else None}
+                finally:
+                    sys.path.pop(0)
             break
     for k, ent in kernels.items():
         if k in traffic:
@@ -822,15 +840,17 @@ def main():
                     "note": (f"algorithmic flops of the 32 clouds of one launch (every product is issued as {split} bf16 "
                              f"MFMA(s): MFMA issue = {split} x this fraction) over the kernel's average launch duration, "
                              "HIP events on its launch stream in an eager pass of the same launches right after the "
-                             "timed region (lower quartile of twelve pairs); the kernel is bound by per-tile latency (two waves per SIMD at 256 VGPRs), "
+                             "timed region (median of twelve pairs; `p25_launch_us` = their lower quartile); the kernel is bound by per-tile latency (two waves per SIMD at 256 VGPRs), "
                              "not by MFMA issue or HBM (DESIGN.md section 5)")}
     else:
         gb = ab.get(dominant, 0) / dom_us * 1e-3
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(gb, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gb / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": ab.get(dominant)}
     roofline.update({
-        "avg_launch_us": round(dom_us, 2),
+        "avg_launch_us": round(dom_us, 2), "p25_launch_us": round(per_kernel_stats[dominant][1], 2),
         "traffic": traffic.get(dominant), "traffic_source": traffic_src if dominant in traffic else None,
+        "traffic_collected_at_commit": traffic_stamp.get("collected_at_commit"),
+        "traffic_sources_match": traffic_stamp.get("sources_match"),
         # the whole step (one batch of 32 clouds through FPS, ball query, fused forward and backward)
         # against the two peaks: SURVEY 8d's per-cloud figures x 32 over the measured step time
         "step": {"flops": step_flops, "bytes": step_bytes,

@@ -83,7 +83,7 @@ def test_wide_backward_matches_autograd(dev, cin, N, M, radius, neg_gamma):
     """Gradients against autograd through the float64 chain.  The chain is discontinuous where a
     K-pool has two candidates within the forward error (1e-5-level): ONE switched winner among
     ~10^5 pooled values moves every gradient by 3e-3..7e-3 in relative L2 (the float64 chain shows the
-    same against itself under a 1e-6 perturbation; scripts/debug_wide2.py).  The pooled values
+    same against itself under a 1e-6 perturbation; scripts/attic/debug_wide2.py).  The pooled values
     whose two best DISTINCT candidates lie within 1e-4 are therefore taken out of the loss on both
     sides (a few in 10^5); what remains must agree to 1e-4 -- measured 4e-6..9e-6, conv1 being an
     exact fp32 difference of hoisted rows in this kernel family."""

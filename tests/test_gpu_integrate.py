@@ -140,3 +140,49 @@ def test_patched_classes_run_on_the_fused_kernels_and_equal_the_package_modules(
         assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
     finally:
         integrate.unpatch_openpoints()
+
+
+def test_clouds_beyond_the_resident_samplers_go_to_the_reference_forward(dev, monkeypatch):
+    """the adapter is chosen from the module's structure, the point count is a property of the
+    CALL.  A patched, unmodified tree on S3DIS-sized clouds (N > 16384: beyond apn_sa_sample_seq) must reach the
+    reference's own forward, counted by reason -- never raise APN_EINVAL out of the fused index stage; other dtypes
+    likewise.  The package's own module takes the unfused index stage (streaming sampler) for such clouds."""
+    from adaptpoint_amd import integrate
+    from adaptpoint_amd import set_abstraction as SA
+    pn, gen = _fake_reference_modules()
+    monkeypatch.setitem(sys.modules, integrate.TARGET_MODULES[0], pn)
+    monkeypatch.setitem(sys.modules, integrate.TARGET_MODULES[1], gen)
+    integrate.COUNTS.clear()
+    integrate.patch_openpoints(lazy=True)
+    try:
+        torch.manual_seed(0)
+        N = 20000
+        p = torch.from_numpy(GI.unit_sphere_cloud(1, N, seed=11)).to(dev)
+        f = torch.from_numpy(GI.seeded_normal((1, 32, N), seed=12)).to(dev)
+        for cin, cout in ((32, 64), (64, 128)):                  # the resident shape and a width-generic one
+            ref = pn.SetAbstraction(cin, cout).to(dev).train()
+            fx = f if cin == 32 else torch.cat([f, f], 1)
+            with pytest.raises(AssertionError, match="reference forward reached"):
+                ref([p, fx])
+            with pytest.raises(AssertionError, match="reference forward reached"):
+                ref([p[:, :1024].double(), fx[:, :, :1024].double()])
+        c = dict(integrate.COUNTS)
+        assert c.get(f"SetAbstraction.reference: N > {integrate.MAX_FUSED_POINTS}") == 2, c
+        assert c.get("SetAbstraction.reference: dtype torch.float64 / torch.float64") == 2, c
+        assert "SetAbstraction.fused" not in c, c
+        # the package's own block: fused=True on a 20000-point cloud runs (unfused index stage + the fused grouped MLP)
+        mine = SA.SetAbstraction(64, 128, layers=2, stride=4, fused=True,
+                                 group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                                 norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+                                 use_res=True).to(dev).train()
+        plain = SA.SetAbstraction(64, 128, layers=2, stride=4, fused=False,
+                                  group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                                  norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'},
+                                  use_res=True).to(dev).train()
+        plain.load_state_dict(mine.state_dict())
+        f64 = torch.cat([f, f], 1)
+        (pa, oa), (pb, ob) = mine([p, f64]), plain([p, f64])
+        assert pa.shape == (1, N // 4, 3) and torch.equal(pa, pb)
+        assert float((oa - ob).abs().max()) <= 2e-3 * float(ob.abs().max())
+    finally:
+        integrate.unpatch_openpoints()
