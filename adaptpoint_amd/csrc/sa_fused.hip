@@ -293,10 +293,12 @@ struct TileRaw {
 struct TileHead {
     int nb, q0;
     unsigned info;
+    int tile;             // the tile's number (wave-uniform)
 };
 template <bool CP>
 __device__ __forceinline__ TileHead load_head(const SaArgs &a, int tile, int r) {
     TileHead t;
+    t.tile = tile;
     if (CP) {
         t.nb = tm_nn(a)[(size_t)tile * SA_K + r];
         t.info = tm_rows(a)[(size_t)tile * SA_K + r];
@@ -786,10 +788,7 @@ struct SaBwdArgs {
     int train2;
     const float *goa;       // (B,M,64)
     const unsigned char *ksel;  // (B,M,64)
-    unsigned *cells;        // optional: bit-reproducible mode.  A is then an int64 array and g_u is added as a 64-bit
-                            // FIXED-POINT integer (order-independent): cells[0] = max |goa| as float bits (apn_sa_bwd_prep),
-                            // cells[1] <- the scale's exponent s (every workgroup derives the same one, prologue),
-                            // cells[2] |= 1 if a term did not fit (cannot happen while the bound below holds)
+    const int *rowdst;      // the row map (apn_sa_rowmap_many): the place of every tile-map row in the point-sorted order
 };
 
 // Backward launch 2 of 4.  Prologue (every workgroup, same bits): the per-channel constants of
@@ -797,13 +796,21 @@ struct SaBwdArgs {
 // and their images through W2: Qm = W2^T diag(D2) W2 (32x32), evec = E2 W2 -- formerly a launch of its own.
 // Epilogue: the workgroup's share of dL/dW2 = sparse part + D2 (W2 Gram) + E2 (x) suma as ONE partial row
 // partW2[workgroup][64*32] (summed in float64, in a fixed order, by the last launch): no float atomics on dL/dW2.
-template <int NS, bool CP, bool FX>
+// Round 5: NO float atomics.  A row's g_u (its 32 mid channels: one 128-byte line) is STORED at the row's place in the
+// point-sorted order (g.rowdst, index-stage data like the tile map): the rows of a support point are then contiguous in GU
+// and the per-point kernel sums them in ascending row order -- bit-reproducible gradients by construction, plain stores
+// (rounds 1-4 added them into A (B,N,32) with memory-side float atomics: 15.9 MB of atomic traffic per launch, the
+// accumulation target cleared by the forward's last launch; knocked out, the step was 6 us shorter, most of it BEHIND the
+// kernel: the atomics' retirement and the next kernel's cold reads of their lines -- profiles/r05_scatter_knockouts.txt).
+// The pass runs over the tile map only (CP): without one the caller builds it (adaptpoint_amd/fused.py).
+template <int NS, bool CP>
 __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBwdArgs g,
                                                                unsigned long long *__restrict__ accT,
                                                                float *__restrict__ partW2,
-                                                               float *__restrict__ A,
+                                                               float *__restrict__ GU,
                                                                float *__restrict__ HA,
                                                                float *__restrict__ HB) {
+    static_assert(CP, "the backward pass runs over a tile map");
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // constant fragments, built once per workgroup (wave w builds every fourth) into LDS
@@ -834,33 +841,20 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
     constexpr int SP_BYTES = SA_WAVES * SP_WAVE, WRED_BYTES = SA_WAVES * SA_C2 * SA_C1 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char sp_raw[SP_BYTES > WRED_BYTES ? SP_BYTES : WRED_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned sinfo[SA_WAVES][32];
-    __shared__ __attribute__((aligned(16))) int snb[CP ? SA_WAVES : 1][32];     // (tile map) the rows' neighbours, for the scatter
     // (tile map) goa / ksel of a tile's first four queries, copied here one tile ahead by two asynchronous global -> LDS
     // loads (four consecutive queries are 1024 / 256 contiguous bytes): no registers held across the previous tile
     __shared__ __attribute__((aligned(16))) float qgoa[CP ? SA_WAVES : 1][4 * SA_C2];
     __shared__ __attribute__((aligned(16))) unsigned char qksel[CP ? SA_WAVES : 1][4 * SA_C2];
     __bf16 *sp_img = reinterpret_cast<__bf16 *>(sp_raw + wave * SP_WAVE);
 
-    __shared__ float sbnd[8];                 // bit-reproducible mode: the pieces of the bound (see the prologue's end)
-    float fxs = 0.0f, fxlim = 0.0f;           // ... the fixed-point scale 2^s and the limit of a scaled term (wave-uniform)
-    unsigned long long bad = 0ull;            // ... lanes that met a term beyond the limit (scalar)
-    unsigned gmax_bits = 0u;
-    unsigned long long *A64 = reinterpret_cast<unsigned long long *>(A);
-    // A[off] += v: a float atomic, or (FX, bit-reproducible mode) the 64-bit integer round(v 2^s).  |v 2^s| < 2^47 (the
-    // bound of the prologue), so the integer is read off the mantissa of v 2^s + 1.5 2^52 -- four instructions
-    // instead of a dozen for a float -> int64 conversion; a term beyond the limit raises a (scalar) mark.
-    // (`off`: a 32-bit ELEMENT offset; the address is the scalar base + a 32-bit byte offset: no 64-bit vector arithmetic
-    // per atomic.  B * N * 32 * 8 < 2^32 is checked at the entry.)
-    auto a_add = [&](unsigned off, float v) {
-        if (FX) {
-            const float vs = v * fxs;
-            bad |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(vs) < fxlim));
-            const double dm = (double)vs + 6755399441055744.0;
-            atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(A64) + (off << 3)),
-                      (unsigned long long)(__double_as_longlong(dm) - 0x4338000000000000ll));
-        } else {
-            atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(A) + (off << 2)), v);
-        }
+    // the places of a tile's rows (g.rowdst), copied here one tile ahead by an asynchronous global -> LDS load; two lines per
+    // wave: the next tile's copy is issued before this tile's stores have read theirs
+    __shared__ __attribute__((aligned(16))) int sdst[SA_WAVES][2][64];
+    int ahead_n = 0, body_n = 0;              // tiles requested / processed by this wave (their parity picks the line)
+    // GU[place][mid] = v  (`place`: a 32-bit row number; the address is the scalar base + a 32-bit byte offset: B * M * 32 * 128
+    // < 2^32 is checked at the entry)
+    auto gu_store = [&](int place, float v) {
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(GU) + (((unsigned)place << 7) + ((unsigned)r << 2))) = v;
     };
 
     auto prologue = [&]() {
@@ -880,15 +874,6 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             if (tid < 128) sv = g.sumsS ? g.sumsS[tid] : acc_read(g.accS, 128, tid);
             if (g.sumsS) count = g.sumsS[128];
             if (tid < 64) { p_sc = g.pack2[tid]; p_mu = g.pack2[128 + tid]; p_iv = g.pack2[192 + tid]; }
-            if (FX) {
-                gmax_bits = g.cells[0];
-                float wm = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) wm = __builtin_fmaxf(wm, __builtin_fabsf(wv[k]));
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) wm = __builtin_fmaxf(wm, __shfl_xor(wm, o));
-                if (lane == 0) sbnd[wave] = wm;
-            }
             if (wave == 0) {
 #pragma unroll
                 for (int s = 0; s < 3; ++s) put_frag<NS>(cfrag, F_W1 + s, lane, w1f[s]);
@@ -914,30 +899,12 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 }
                 sD[tid] = (float)d;
                 sE[tid] = (float)e;
-                if (FX) {                                         // wave 0: max |D2|, max |E2|
-                    float dm = __builtin_fabsf((float)d), em = __builtin_fabsf((float)e);
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        dm = __builtin_fmaxf(dm, __shfl_xor(dm, o));
-                        em = __builtin_fmaxf(em, __shfl_xor(em, o));
-                    }
-                    if (lane == 0) { sbnd[4] = dm; sbnd[5] = em; }
-                }
             }
             if (tid >= 64 && tid < 96) {
                 const int i = tid - 64;          // channel i sits in half (i >> 2) & 1, register (i & 3) + 4 (i >> 3)
                 const float sci = g.scale1[i], shi = g.shift1[i];
                 bn1v[0][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = sci;
                 bn1v[1][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = shi;
-                if (FX) {
-                    // a1 = relu(gamma1 yhat1 + beta1) <= |gamma1| sqrt(P) + |beta1|: a channel's normalised values
-                    // cannot exceed sqrt(P - 1) in magnitude (batch statistics)
-                    float am = __builtin_fabsf(sci / g.inv1[i]) * __builtin_sqrtf((float)count)
-                             + __builtin_fabsf(__builtin_fmaf(sci, g.mean1[i], shi));
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) am = __builtin_fmaxf(am, __shfl_xor(am, o));
-                    if (lane == 0) sbnd[6] = am;
-                }
             }
             {
                 uint4 *z = reinterpret_cast<uint4 *>(sp_img);
@@ -972,46 +939,9 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
             if (h == 0) chan[4][r] = eacc[0];                     // row 0 of the product = evec
         }
         __syncthreads();
-        if (FX) {
-            // |g_u| of a row <= G 64 wmax + 32 (amax 2048 wmax^2 dmax + 64 wmax emax)  (G = max |goa|; the selected part is
-            // a sum of at most 64 products, the dense part -- a1 Qm + evec, Qm = W2^T diag(D2) W2 -- reaches a row at most 32
-            // times); a point gathers at most 32 m rows: with bound < 2^e and 32 m <= 2^rexp the scale 2^s,
-            // s = 60 - rexp - e, keeps every sum below 2^60.  Same inputs, same order: every workgroup finds the same s.
-            const float wmax = __builtin_fmaxf(__builtin_fmaxf(sbnd[0], sbnd[1]), __builtin_fmaxf(sbnd[2], sbnd[3]));
-            const float bound = __uint_as_float(gmax_bits) * 64.0f * wmax
-                              + 32.0f * (sbnd[6] * 2048.0f * wmax * wmax * sbnd[4] + 64.0f * wmax * sbnd[5]);
-            const int rexp = 32 - __builtin_clz((unsigned)(a.m * 32 - 1) | 1u);
-            int e = 0, sexp = 0;
-            if (bound < __builtin_inff()) {
-                (void)frexpf(bound, &e);
-                sexp = 60 - rexp - e;
-                sexp = sexp > 120 ? 120 : (sexp < -120 ? -120 : sexp);
-            } else {
-                bad = ~0ull;                                       // NaN / inf upstream: the result is marked, not trusted
-            }
-            fxs = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ldexpf(1.0f, sexp))));
-            fxlim = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ldexpf(1.0f, 61 - rexp))));
-            if (blockIdx.x == 0 && threadIdx.x == 0) g.cells[1] = (unsigned)sexp;
-        }
     };
 
-    // the previous tile's per-point sums, scattered at the top of the next iteration (see for_each_tile)
-    float pend_g[16];
-    int pend_nb = 0, pend_live = 0, pend_cloud = 0;      // pend_live == 0: nothing pending
-    auto scatter_pending = [&]() {
-        if (CP || pend_live == 0) return;                 // wave-uniform (tile map: scattered at the end of the tile)
-        const unsigned Ac = (unsigned)pend_cloud * (unsigned)a.n * SA_C1 + (unsigned)r;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (acc_row(i, 0) < pend_live) {              // wave-uniform: is any lane's position live?
-                const int n0 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 0));
-                const int n1 = __builtin_amdgcn_readlane(pend_nb, acc_row(i, 1));
-                const int nn = h ? n1 : n0;
-                if (acc_row(i, h) < pend_live) a_add(Ac + (unsigned)nn * SA_C1, pend_g[i]);
-            }
-        }
-        pend_live = 0;
-    };
+    auto scatter_pending = [] {};
     auto ahead = [&](const TileHead &hd) {
         if (!CP) return;
         typedef __attribute__((address_space(3))) void lds_void;
@@ -1024,6 +954,10 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         const char *kb = reinterpret_cast<const char *>(g.ksel) + (size_t)qbn * SA_C2;
         __builtin_amdgcn_global_load_lds((glb_void *)(gb + (unsigned)(16 * l_o)), (lds_void *)&qgoa[wave][0], 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void *)(kb + (unsigned)(4 * l_o)), (lds_void *)&qksel[wave][0], 4, 0, 0);
+        // the tile's 32 places (lanes 32..63 repeat them: never past the array's end)
+        const char *db = reinterpret_cast<const char *>(g.rowdst) + (size_t)__builtin_amdgcn_readfirstlane(hd.tile) * (SA_K * 4);
+        __builtin_amdgcn_global_load_lds((glb_void *)(db + (unsigned)(4 * (l_o & 31))), (lds_void *)&sdst[wave][ahead_n & 1][0], 4, 0, 0);
+        ++ahead_n;
     };
     for_each_tile<NS, CP, CP>(a, wave, r, h, prologue, scatter_pending, [&](int tile, const TileRaw<NS> &raw, bool probe, auto before_stores) {
         auto st2 = [&](int k) { if (probe) stamp(a, wave, 8 + k); };
@@ -1034,7 +968,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         asm volatile("" : "+v"(lane_o));
         Frag<NS> x[3];
         build_frags<NS>(a, raw, h, x);
-        const int nb = raw.nb;
+
         const int q0 = __builtin_amdgcn_readfirstlane(raw.q0);
         const int nq = CP ? __builtin_amdgcn_readfirstlane((int)(raw.info >> 24)) : 1;
         const bool live_row = !CP || ri_mult(raw.info) != 0;
@@ -1066,10 +1000,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
         unsigned mpk[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
         unsigned starts = 1u;                                          // bit = a query's first row (wave-uniform)
         if (CP) {
-            if (lane < 32) {
-                sinfo[wave][lane] = raw.info;
-                snb[wave][lane] = nb;
-            }
+            if (lane < 32) sinfo[wave][lane] = raw.info;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(&sinfo[wave][8 * gq + 4 * (lane_o >> 5)]);
@@ -1311,50 +1242,32 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                     HA[(size_t)tile * SA_C1 + r] = ha;
                     HB[(size_t)tile * SA_C1 + r] = hb;
                 }
-                // Rows produced by ball query end in a run of slots that repeat slot 0
-                // (ball_query_gpu.cu:41-45): fold that run into slot 0 before the atomics.
-                const int nb0 = __builtin_amdgcn_readfirstlane(nb);
-                const unsigned eq = (unsigned)__ballot(nb == nb0);          // lanes 0..31 = positions
-                const int tail = (~eq == 0u) ? 32 : __builtin_clz(~eq);      // leading ones of eq
-                live = SA_K - tail;
-                if (live < 1) live = 1;
-                float extra = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) extra += acc_row(i, h) >= live ? ga[i] : 0.0f;
-                extra += __shfl_xor(extra, 32);
-                // hand the tile's sums to the deferred scatter
-#pragma unroll
-                for (int i = 0; i < 16; ++i) pend_g[i] = (i == 0 && h == 0) ? ga[0] + extra : ga[i];
-                pend_nb = nb;
-                pend_live = live;
-                pend_cloud = q0 / a.m;
+                live = 0;                                         // (not instantiated: the pass runs over a tile map)
             }
 
             st2(5);
             st2(6);
             if (CP) {
-                // the tile's per-point sums, scattered at the END of the tile: behind every load of this iteration and
-                // ahead of the next iteration's prefetch (the memory counter is in order: they retire behind a whole
-                // tile of arithmetic; the one-tile-per-query path reaches the same order through scatter_pending)
-                // (the neighbours of this lane's sixteen rows come back from the wave's LDS line, four 16-byte reads -- the
-                // readlane pairs + selects of round 3 were ~50 vector instructions per tile; element offsets are 32-bit:
-                // B * N * 32 < 2^31 is checked at the entry)
-                const unsigned Ac = (unsigned)(q0 / a.m) * (unsigned)a.n * SA_C1 + (unsigned)r;
+                // the tile's rows of g_u, STORED at their places in the point-sorted order at the END of the tile: behind every
+                // load of this iteration and ahead of the next iteration's prefetch.  The places of this lane's sixteen rows
+                // come back from the wave's LDS line (copied there one tile ahead, `ahead`): four 16-byte reads.  A wave
+                // instruction writes two whole 128-byte lines (lanes 0..31 / 32..63: the 32 mid channels of two rows).
+                const int *dl = &sdst[wave][body_n & 1][0];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     if (8 * gq < live) {                          // wave-uniform: is any lane's position live?
-                        const int4 nn = *reinterpret_cast<const int4 *>(&snb[wave][8 * gq + 4 * (lane_o >> 5)]);
+                        const int4 dd = *reinterpret_cast<const int4 *>(&dl[8 * gq + 4 * (lane_o >> 5)]);
                         const int base = 8 * gq + 4 * h;
-                        if (base + 0 < live) a_add(Ac + (unsigned)nn.x * SA_C1, ga[4 * gq + 0]);
-                        if (base + 1 < live) a_add(Ac + (unsigned)nn.y * SA_C1, ga[4 * gq + 1]);
-                        if (base + 2 < live) a_add(Ac + (unsigned)nn.z * SA_C1, ga[4 * gq + 2]);
-                        if (base + 3 < live) a_add(Ac + (unsigned)nn.w * SA_C1, ga[4 * gq + 3]);
+                        if (base + 0 < live) gu_store(dd.x, ga[4 * gq + 0]);
+                        if (base + 1 < live) gu_store(dd.y, ga[4 * gq + 1]);
+                        if (base + 2 < live) gu_store(dd.z, ga[4 * gq + 2]);
+                        if (base + 3 < live) gu_store(dd.w, ga[4 * gq + 3]);
                     }
                 }
             }
+            ++body_n;
         }
     }, ahead);
-    if (FX && bad != 0ull && lane == 0) atomicOr(g.cells + 2, 1u);
     {   // BatchNorm-1's reduction terms {T1, T2}[32] into their accumulator set
         const float tot = fold_partials<2>(st, lane, wave);
         if (threadIdx.x < 64) acc_add(accT, 64, blockIdx.x % ACC_COPIES, threadIdx.x, tot);
@@ -1494,7 +1407,8 @@ static int sa_check(int b, int n, int m, int precision) {
     if (precision != 1 && precision != 2) return APN_EINVAL;
     if (b <= 0 || n <= 0 || m <= 0) return APN_EINVAL;
     if ((long long)b * m > 0x7fffffffLL / 64) return APN_EINVAL;
-    if ((long long)b * n > 0xffffffffLL / 256) return APN_EINVAL;     // 32-bit byte offsets: bf16 tables (fetch_tile), A as int64 (a_add)
+    if ((long long)b * n > 0xffffffffLL / 256) return APN_EINVAL;     // 32-bit byte offsets: bf16 tables (fetch_tile)
+    if ((long long)b * m > 0xffffffffLL / (32 * 128)) return APN_EINVAL;   // ... and GU's rows (sa_bwd_kernel: gu_store)
     return APN_OK;
 }
 
@@ -1525,11 +1439,12 @@ extern "C" int apn_sa_bwd_main(int b, int n, int m, int precision, float radius,
                                const float *new_xyz, const void *ft, const int *idx, const int *tmap, const float *w1,
                                const float *w2, const float *pack1, const float *pack2, const void *accS,
                                const double *sumsS, double count, int train2, const float *goa, const void *ksel,
-                               void *accT, float *partW2, void *A, unsigned *cells, float *HA, float *HB, void *stream) {
+                               void *accT, float *partW2, const int *rowdst, float *GU, float *HA, float *HB, void *stream) {
     using namespace apn;
     if (int e = sa_check(b, n, m, precision)) return e;
-    if (!w2 || !pack1 || !pack2 || (!accS && !sumsS) || !goa || !ksel || !accT || !partW2 || !A || !HA || !HB)
+    if (!w2 || !pack1 || !pack2 || (!accS && !sumsS) || !goa || !ksel || !accT || !partW2 || !GU || !HA || !HB)
         return APN_EINVAL;
+    if (!tmap || !rowdst) return APN_EINVAL;         // the pass runs over the tile map and stores through its row map
     SaArgs a = sa_args(b, n, m, xyz, new_xyz, ft, precision, idx, w1, radius, tmap);
     SaBwdArgs g;
     g.w2 = w2;
@@ -1538,15 +1453,10 @@ extern "C" int apn_sa_bwd_main(int b, int n, int m, int precision, float radius,
     g.accS = (const unsigned long long *)accS; g.sumsS = sumsS;
     g.count = count; g.train2 = train2;
     g.goa = goa; g.ksel = (const unsigned char *)ksel;
-    g.cells = cells;
-    auto pick = [&](auto fx) {
-        constexpr bool F = decltype(fx)::value;
-        return precision == 2 ? (tmap ? sa_bwd_kernel<2, true, F> : sa_bwd_kernel<2, false, F>)
-                              : (tmap ? sa_bwd_kernel<1, true, F> : sa_bwd_kernel<1, false, F>);
-    };
-    auto kern = cells ? pick(std::true_type{}) : pick(std::false_type{});
+    g.rowdst = rowdst;
+    auto kern = precision == 2 ? sa_bwd_kernel<2, true> : sa_bwd_kernel<1, true>;
     hipLaunchKernelGGL(kern, dim3(sa_grid_bwd(b * m)), dim3(SA_WAVES * 64), 0, (hipStream_t)stream, a, g,
-                       (unsigned long long *)accT, partW2, (float *)A, HA, HB);
+                       (unsigned long long *)accT, partW2, GU, HA, HB);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

@@ -389,11 +389,9 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
                                                            float *__restrict__ goa,
                                                            unsigned long long *__restrict__ accS,
                                                            float *__restrict__ partWs,
-                                                           float *__restrict__ gip,
-                                                           unsigned *__restrict__ cells) {
+                                                           float *__restrict__ gip) {
     // 16 QT threads per tile of QT queries, as in fwd_out_kernel
     constexpr int NT = QT * 16, NW = NT / 64, HALVES = 64 / QT;
-    __shared__ float smax[NW];
     __shared__ float tile[QT][65];       // g[q][c]
     __shared__ float red[NW][2][64];
     __shared__ __attribute__((aligned(16))) float sfi[QT][36];
@@ -430,7 +428,7 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
     wg_stamp(1);
     __syncthreads();
     wg_stamp(2);
-    float s1 = 0.0f, s2 = 0.0f, gm = 0.0f;
+    float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {        // (query j, channel tx): coalesced over channels
         const int j = ty + NW * k, q = m0 + j;
@@ -438,33 +436,16 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
             const float g = tile[j][tx];
             const float gs = g * sc;
             goa[((size_t)cloud * m + q) * 64 + tx] = gs;
-            // (bit-reproducible mode) max |goa|; a NaN must survive the maximum: it compares false everywhere
-            gm = (gs != gs) ? gs : (gm != gm ? gm : __builtin_fmaxf(gm, __builtin_fabsf(gs)));
             s1 += g;
             s2 += g * ((ys[k] - mu) * iv);
         }
     }
     red[ty][0][tx] = s1;
     red[ty][1][tx] = s2;
-    if (cells) {
-        unsigned gb = __float_as_uint(gm) & 0x7fffffffu;          // |.| bits order like unsigned integers (NaN on top)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned other = (unsigned)__shfl_xor((int)gb, o);
-            gb = other > gb ? other : gb;
-        }
-        if (tx == 0) smax[ty] = __uint_as_float(gb);
-    }
     wg_stamp(3);
     __syncthreads();
     wg_stamp(4);
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    if (cells && threadIdx.x == 0) {
-        unsigned gb = 0u;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) gb = __float_as_uint(smax[k]) > gb ? __float_as_uint(smax[k]) : gb;
-        atomicMax(cells, gb);                                     // order-independent
-    }
     float sacc = 0.0f;
     if (ty < 2) {
 #pragma unroll
@@ -542,10 +523,11 @@ constexpr int WG_PTS = 64;
 // threads per workgroup of bwd_point_grads_kernel: 512 -- two workgroups fit a CU (1024: one, and the grid of B*N/64
 // workgroups ran as two rounds of latency chains), rows of the tile per thread, mid channels per thread
 constexpr int PG_NT = 512, PG_K = WG_PTS * 32 / PG_NT, PG_M = 32 * 64 / PG_NT;
+constexpr int PG_ELL = 8;       // the most rows per point requested from map-free places (>= apn_sa_rowmap_ell())
 
 __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
-    int n, int total_q, int split, const float *__restrict__ A, const unsigned *__restrict__ cells,
-    const long long *__restrict__ geo,
+    int n, int total_q, int split, const float *__restrict__ GU, const int *__restrict__ pcnt,
+    const int *__restrict__ poff, int ell, long long ell_rows, const long long *__restrict__ geo,
     const float *__restrict__ HA, const float *__restrict__ HB, const unsigned long long *__restrict__ accT,
     const double *__restrict__ sumsT, double count, int train1,
     const float *__restrict__ pack1, const __bf16 *__restrict__ ft,
@@ -573,8 +555,25 @@ __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
     // nothing but the block's position (round 3 issued them behind that barrier: one more memory round trip, ~1.5 us of
     // the kernel's 10); clamped rows, selected afterwards: under conditions each load sat in a block of its own
     const int c_ld = tid & 31;
-    float a_f[PG_K] = {}, f_hi[PG_K], f_lo[PG_K], g_i[PG_K], h_a[PG_K], h_b[PG_K];
-    long long a_q[PG_K] = {};
+    float f_hi[PG_K], f_lo[PG_K], g_i[PG_K], h_a[PG_K], h_b[PG_K];
+    // the point's rows of g_u (round 5: stored by the backward pass at consecutive places of the point-sorted order --
+    // apn_sa_rowmap_many -- instead of added into A with float atomics): how many and where, requested FIRST: the rows
+    // themselves depend on them (one more memory round trip, issued while the tile's other loads are in flight)
+    // (mapping of this gather: thread = (point tid >> 3, four mid channels 4 (tid & 7)): a row is eight 16-byte loads, a
+    // wave instruction covers eight rows)
+    const int g_pt = tid >> 3, g_c4 = (tid & 7) * 4;
+    int r_cnt, r_off;
+    float4 a_e[PG_ELL];            // the point's first ELL rows: their address needs no map (requested with the count)
+    {
+        const size_t gp = p0 + (g_pt < n_here ? g_pt : 0);
+        r_cnt = g_pt < n_here ? pcnt[gp] : 0;
+        r_off = poff[gp];
+        const float *er = GU + gp * (size_t)(ell * 32) + g_c4;
+#pragma unroll
+        for (int u = 0; u < PG_ELL; ++u)
+            a_e[u] = ell > 0 ? *reinterpret_cast<const float4 *>(er + (size_t)(u < ell ? u : 0) * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 a_g = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         const __bf16 *lo_tab = ft_lo ? ft_lo : ft;
         const float *gip_tab = gip ? gip : HA;               // (no skip branch: any readable table, value unused)
@@ -583,8 +582,6 @@ __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
             const int pt = (tid >> 5) + (PG_NT / 32) * k;
             const size_t pr = (p0 + (pt < n_here ? pt : 0)) * 32 + c_ld;
             const size_t qr = (size_t)(q0 + pt < total_q ? q0 + pt : 0) * 32 + c_ld;
-            if (cells) a_q[k] = reinterpret_cast<const long long *>(A)[pr];
-            else a_f[k] = A[pr];
             f_hi[k] = (float)ft[pr];
             f_lo[k] = (float)lo_tab[pr];
             g_i[k] = gip_tab[gip ? pr : qr];
@@ -627,26 +624,45 @@ __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
         sc[tid < 32 ? 2 : 1][c] = val;                    // cc from T1, cb from T2
         if (tid < 32) sc[0][c] = sca;
     } else if (tid >= 96 && tid < 160) sc[3 + ((tid - 96) >> 5)][tid & 31] = pack1[64 + tid - 96];   // mean1, inv1
+    {
+        // A[point][4 channels] = sum of the point's rows, ascending (a fixed order: bit-reproducible): the first ELL from
+        // their map-free places (slots beyond the count hold stale bytes: masked), the rest -- a point in more than ELL
+        // neighbourhoods: 1-2 % of the headline clouds' points, most of a collapsed cloud's hot ones -- from the overflow
+        // places behind the ELL region, four rows per round trip
+#pragma unroll
+        for (int u = 0; u < PG_ELL; ++u)
+            if (u < r_cnt && u < ell) { a_g.x += a_e[u].x; a_g.y += a_e[u].y; a_g.z += a_e[u].z; a_g.w += a_e[u].w; }
+        const float *rows = GU + ((size_t)ell_rows + (size_t)(r_cnt > ell ? r_off : 0)) * 32 + g_c4;
+        for (int j0 = ell; j0 < r_cnt; j0 += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u < r_cnt ? j0 + u : r_cnt - 1;
+                v[u] = *reinterpret_cast<const float4 *>(rows + (size_t)j * 32);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < r_cnt) { a_g.x += v[u].x; a_g.y += v[u].y; a_g.z += v[u].z; a_g.w += v[u].w; }
+        }
+    }
     wg_stamp(1);
     __syncthreads();
     wg_stamp(2);
     {
         const int c = tid & 31;                           // fixed per thread: e = tid + 1024 k
         const float ca = sc[0][c], cb = sc[1][c], cc = sc[2][c];
-        const double fx_inv = cells ? ldexp(1.0, -(int)cells[1]) : 0.0;
-        const bool marked = cells && cells[2] != 0u;
 #pragma unroll
         for (int k = 0; k < PG_K; ++k) {
             const int pt = (tid >> 5) + (PG_NT / 32) * k;
             const bool ok = pt < n_here;
-            // bit-reproducible mode: A holds 64-bit fixed-point sums in units of 2^-s (apn_sa_bwd_main)
-            float av = cells ? (marked ? __builtin_nanf("") : (float)((double)a_q[k] * fx_inv)) : a_f[k];
-            sG[pt][c] = ok ? av : 0.0f;
+            // (sG: filled below, by the gather's own mapping)
             sB[pt][6 + c] = ok ? f_hi[k] + (ft_lo ? f_lo[k] : 0.0f) : 0.0f;
             sI[pt][c] = (gip && ok) ? g_i[k] : 0.0f;
             sH[pt][c] = q0 + pt < total_q ? __builtin_fmaf(ca, h_a[k], __builtin_fmaf(cb, h_b[k], cc * 32.0f)) : 0.0f;
         }
     }
+    sG[g_pt][g_c4] = a_g.x; sG[g_pt][g_c4 + 1] = a_g.y;          // (points past the cloud's end: r_cnt = 0, zeros)
+    sG[g_pt][g_c4 + 2] = a_g.z; sG[g_pt][g_c4 + 3] = a_g.w;      // (rows of 33 floats: not 16-byte aligned)
     if (tid < WG_PTS * 3) {
         const int pt = tid / 3, d = tid % 3;
         const float xv = xq_v[0], qv = xq_v[1];
@@ -951,7 +967,7 @@ extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long lon
                                long long gs_c, long long gs_m, const float *out, int relu,
                                const float *ysel, const float *pack2, const void *ft, int precision,
                                const int *fidx, const float *ws, float *goa, void *accS,
-                               float *partWs, float *gip, unsigned *cells, void *stream) {
+                               float *partWs, float *gip, void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || !g_out || !ysel || !pack2 || !goa || !accS) return APN_EINVAL;
     if (relu && !out) return APN_EINVAL;
     if (ws && (!ft || !fidx || !partWs || !gip || n <= 0 || (precision != 1 && precision != 2)))
@@ -961,11 +977,11 @@ extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long lon
     if (apn_sa_glue_tile(b, m) == 32)
         hipLaunchKernelGGL(apn::bwd_prep_kernel<32>, dim3((m + 31) / 32, b), dim3(512), 0, APN_ST, n, m, g_out,
                            gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, (unsigned long long *)accS,
-                           partWs, gip, cells);
+                           partWs, gip);
     else
         hipLaunchKernelGGL(apn::bwd_prep_kernel<64>, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, g_out,
                            gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, (unsigned long long *)accS,
-                           partWs, gip, cells);
+                           partWs, gip);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }
@@ -979,22 +995,25 @@ extern "C" __attribute__((visibility("default"))) int apn_sa_debug_wg_stamps(voi
 
 extern "C" int apn_sa_bwd_weight_rows(int b, int n) { return b * ((n + apn::WG_PTS - 1) / apn::WG_PTS); }
 
-extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const void *A, const unsigned *cells, const void *geo,
+extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const float *GU, const int *pcnt_poff, const void *geo,
                                       const float *HA, const float *HB, const void *accT, const double *sumsT,
                                       double count, int train1, const float *pack1, const void *ft, int precision,
                                       const float *xyz, const float *new_xyz, const float *w1,
                                       const float *gip, float radius, float *partW, float *g_f,
                                       float *g_p, float *g_newp, void *stream) {
     if (b <= 0 || n <= 0 || m <= 0 || b > 65535) return APN_EINVAL;
-    if (!A || !geo || !HA || !HB || (!accT && !sumsT) || !pack1 || !ft || !xyz || !new_xyz || !w1 || !partW || !g_f)
+    if (!GU || !pcnt_poff || !geo || !HA || !HB || (!accT && !sumsT) || !pack1 || !ft || !xyz || !new_xyz || !w1 || !partW ||
+        !g_f)
         return APN_EINVAL;
     if (precision != 1 && precision != 2) return APN_EINVAL;
     if (m > n) return APN_EINVAL;                    // query tiles are walked with the point tiles
+    const int ell = apn_sa_rowmap_ell();
+    if (ell > apn::PG_ELL) return APN_EINVAL;
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = precision == 2 ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::bwd_point_grads_kernel, dim3((n + apn::WG_PTS - 1) / apn::WG_PTS, b),
-                       dim3(apn::PG_NT), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, (const float *)A, cells,
-                       (const long long *)geo, HA, HB,
+                       dim3(apn::PG_NT), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, GU, pcnt_poff,
+                       pcnt_poff + (size_t)b * n, ell, (long long)b * n * ell, (const long long *)geo, HA, HB,
                        (const unsigned long long *)accT, sumsT, count, train1,
                        pack1, hi, lo, xyz, new_xyz, w1, gip, 1.0f / radius, partW, g_f, g_p, g_newp);
     APN_LAUNCH_CHECK();

@@ -9,7 +9,8 @@
 // `phases` selects which part of the direction to enqueue, so that the caller can place
 // an all-reduce of the BatchNorm sums between them (SyncBatchNorm):
 //   forward : 1 = prep + BatchNorm-1 sums (per point) | 2 = main pass | 4 = output
-//   backward: 1 = (zero +) entry                      | 2 = main pass | 4 = point gradients + finalize
+//   backward: 1 = (zero +) entry                      | 2 = main pass (over the tile map, g_u rows stored through the row
+//             map: no float atomics)                   | 4 = point gradients + finalize
 // 3 + 4 launches per step (round 2: 6 + 6): every BatchNorm fold / constants kernel became a prologue of its
 // consumer.  Single rank: phases = 7, one call; the consumers read the partial rows / accumulator sets
 // themselves.  With `sums*` pointers (float64, already reduced over ranks) they use those instead.
@@ -76,12 +77,12 @@ extern "C" int apn_sa_backward_seq(
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
-    // cleared here unless zero_bytes == 0 (then apn_sa_fwd_out cleared them): A (B*N*32) | gip (B*N*32, only with
-    // ws) | accS | accT, contiguous from zero_base
-    void *zero_base, long long zero_bytes, void *A, float *gip, void *accS, void *accT,
-    // bit-reproducible mode: cells (4 x u32, inside the zeroed region) and A as an int64 array (B*N*32 x 8 bytes):
-    // g_u is summed per point as 64-bit fixed-point integers instead of float atomics
-    unsigned *cells,
+    // cleared here unless zero_bytes == 0 (then apn_sa_fwd_out cleared them): gip (B*N*32, only with ws) | accS | accT,
+    // contiguous from zero_base
+    void *zero_base, long long zero_bytes, float *gip, void *accS, void *accT,
+    // the row map of the tile map (apn_sa_rowmap_many: index-stage data) and GU (32*B*M rows of 32 floats, scratch): the
+    // backward pass stores a row's g_u at its place in the point-sorted order, the per-point kernel sums a point's rows
+    const int *pcnt_poff, const int *rowdst, float *GU,
     // scratch
     float *goa, float *partWs, float *partW2, float *partW, const double *sumsS, const double *sumsT,
     float *HA, float *HB,
@@ -91,13 +92,13 @@ extern "C" int apn_sa_backward_seq(
     if (phases & 1) {
         if (zero_bytes) APN_TRY(apn_zero_fill(zero_base, zero_bytes, stream));
         APN_TRY(apn_sa_bwd_prep(b, n, m, g_out, gs_b, gs_c, gs_m, out, relu, ysel, pack2, ws ? ft : nullptr, precision,
-                                ws ? fidx : nullptr, ws, goa, accS, partWs, gip, cells, stream));
+                                ws ? fidx : nullptr, ws, goa, accS, partWs, gip, stream));
     }
     if (phases & 2)
         APN_TRY(apn_sa_bwd_main(b, n, m, precision, radius, xyz, new_xyz, ft, idx, tmap, w1, w2, pack1, pack2, accS,
-                                sumsS, count, train2, goa, ksel, accT, partW2, A, cells, HA, HB, stream));
+                                sumsS, count, train2, goa, ksel, accT, partW2, rowdst, GU, HA, HB, stream));
     if (phases & 4) {
-        APN_TRY(apn_sa_bwd_point_grads(b, n, m, A, cells, geo, HA, HB, accT, sumsT, count, train1, pack1, ft, precision, xyz,
+        APN_TRY(apn_sa_bwd_point_grads(b, n, m, GU, pcnt_poff, geo, HA, HB, accT, sumsT, count, train1, pack1, ft, precision, xyz,
                                        new_xyz, w1, gip, radius, partW, g_f, g_p, g_newp, stream));
         APN_TRY(apn_sa_bwd_finalize(partW, apn_sa_bwd_weight_rows(b, n), radius, g_w1, partWs,
                                     apn_sa_bwd_prep_rows(b, m), g_ws, partW2, apn_sa_bwd_main_rows(b, m), g_w2, accS,

@@ -37,17 +37,16 @@ from . import ops as _ops
 
 C_IN, C_MID, C_OUT, K_NS = 32, 32, 64, 32
 # The register-resident passes run over the distinct-hit tile map of the index stage (fused_wide.tile_map): 3.7x fewer
-# tiles at stage 1.  Round 2 measured a LOSS for the backward pass (52.9 -> 60.2 us: one memory round trip and ~90
-# compare/select instructions per QUERY of a tile, 50 spilled registers); round 3 rebuilt its per-query work (the
-# queries' gradients / pooled slots in one batch of loads, per-query sums through two wave-private LDS tiles, the
-# scatter at the end of the tile): 58 -> 44 us, so the map is now used in both directions (APN_TMAP_BWD=0: forward only).
-TILE_MAP_IN_BACKWARD = os.environ.get("APN_TMAP_BWD", "1") == "1"
-# build the tile map in line when the caller hands no index stage in (training: forward + backward)
+# tiles at stage 1.  The BACKWARD pass runs over it always (round 5): it stores the rows of g_u through the map's row map
+# (fused_wide.row_maps: a row's place in the point-sorted order) and the per-point kernel sums a point's consecutive rows
+# in ascending order -- no float atomics anywhere in the chain.  A caller that hands no index stage in gets both maps
+# built in line (two + one launches).
+# build the tile map in line for the FORWARD too when the caller hands no index stage in (training: forward + backward)
 TILE_MAP_INLINE = os.environ.get("APN_TMAP_INLINE", "1") == "1"
-# Bit-reproducible gradients: the backward pass adds its per-point sums (A) as 64-bit fixed-point integers -- the
-# only order-dependent sums of the chain were float atomics there; everything else already is an integer accumulator
-# set or a fixed-order fold.  The scale is derived on the device from a bound on the terms (csrc/sa_fused.hip).
-DETERMINISTIC = os.environ.get("APN_DETERMINISTIC", "0") == "1"
+# Bit-reproducible gradients are the ONLY mode since round 5 (every cross-workgroup sum is an integer accumulator set, a
+# fixed-order fold of partial rows, or the ordered sum of a point's rows); rounds 3-4 had a separate, slower mode
+# (64-bit fixed-point integer atomics for the per-point sums) behind this flag, which is kept as an accepted no-op.
+DETERMINISTIC = True
 
 # Operand precision of the MFMA contractions:
 #   "bf16x3" (default) every f32 operand is split into hi + lo bf16 parts and each product is
@@ -201,11 +200,13 @@ class _Forward:
     """Runs the forward launches and keeps what the backward needs."""
 
     def __init__(self, p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
-                 sync_bn, tmap=None, geo=None, dd=None, want_backward=False):
+                 sync_bn, tmap=None, geo=None, dd=None, want_backward=False, rowmap=None):
         """want_backward: the backward's atomically accumulated region (A | gip | accS | accT) is allocated now and
         cleared by the forward's last launch, so that the backward runs without a fill launch of its own.
         tmap: the distinct-hit tile map of idx (adaptpoint_amd.fused_wide.tile_map; index-stage work) -- the
-        passes over the positions then run over ~1/4 of the tiles at stage 1; None: one tile per query.
+        passes over the positions then run over ~1/4 of the tiles at stage 1; None: one tile per query in the forward
+        (the backward builds one: it runs over a tile map always).  rowmap: (pcnt_poff, rowdst) of tmap
+        (adaptpoint_amd.fused_wide.row_map; index-stage work), built here when a backward will follow and the caller has none.
         geo, dd: the neighbourhoods' occurrence statistics (index-stage work too: `point_geo`; computed here when
         the caller has none)."""
         dev = f.device
@@ -227,15 +228,22 @@ class _Forward:
         count = float(B * M * K_NS)       # this rank's positions; SyncBatchNorm all-reduces it with the sums
         if geo is None:
             geo, dd = point_geo(p, new_p, idx, radius)
-        self.det = bool(DETERMINISTIC)
+        if want_backward:
+            from . import fused_wide
+            if tmap is None:
+                tmap = fused_wide.tile_map(idx)
+                rowmap = None
+            if rowmap is None:
+                rowmap = fused_wide.row_map(tmap, B, N, M)
         rows1 = lib.apn_sa_prep_rows(B, N)
         v, _buf = _carve(dev, [("ft", prec * B * N * C // 2), ("pack1", 4 * C_MID), ("pack2", 4 * C_OUT),
                                ("ysel", B * M * C_OUT), ("ksel", B * M * C_OUT // 4),
                                ("part1", rows1 * 64), ("acc2", _acc_floats(128))])
         out = torch.empty(B, C_OUT, M, dtype=torch.float32, device=dev)
-        # (bit-reproducible mode: A holds 64-bit integers, and four cells carry the scale between the launches)
-        self.zsizes = ([("A", B * N * C_MID * (2 if self.det else 1))] + ([("gip", B * N * C_MID)] if ws is not None else [])
-                       + [("accS", _acc_floats(128)), ("accT", _acc_floats(64))] + ([("cells", 64)] if self.det else []))
+        # what the backward accumulates into with atomics (the skip branch's gradient rows at the sampled points; the two
+        # integer accumulator sets): cleared by the forward's last launch
+        self.zsizes = (([("gip", B * N * C_MID)] if ws is not None else [])
+                       + [("accS", _acc_floats(128)), ("accT", _acc_floats(64))])
         self.zviews = self.zbuf = None
         if want_backward:
             self.zviews, self.zbuf = _carve(dev, self.zsizes)
@@ -264,7 +272,7 @@ class _Forward:
             s2 = _all_reduce_acc(call, v["acc2"], 128, count, dev) if self.train2 else None
             run(4, sums2=s2)
         self.out = out
-        self.saved = dict(p=p, f=f, new_p=new_p, idx=idx, tmap=tmap if TILE_MAP_IN_BACKWARD else None, fidx=fidx,
+        self.saved = dict(p=p, f=f, new_p=new_p, idx=idx, tmap=tmap, rowmap=rowmap, fidx=fidx,
                           geo=geo, ft=v["ft"], w1=w1, w2=w2, ws=ws,
                           has_bs=bs is not None, pack1=v["pack1"], pack2=v["pack2"], ysel=v["ysel"],
                           ksel=v["ksel"], count=count)
@@ -297,9 +305,14 @@ def _backward(fw, g_out, need_p, need_newp):
     # launch already allocated and cleared it (fw.zbuf)
     prezeroed = fw.zbuf is not None
     zsizes = [] if prezeroed else fw.zsizes
+    if sv["rowmap"] is None:
+        raise RuntimeError("fused set abstraction: backward without a row map (the forward was run with want_backward=False)")
+    pcnt_poff, rowdst = sv["rowmap"]
+    # GU: one 128-byte row per tile-map row, at the place its row map names (ELL rows per support point + the overflow's
+    # sorted places; only the map's live rows are written, the per-point kernel reads ELL rows per point and masks)
     sizes = zsizes + [("goa", B * M * C_OUT), ("partWs", prow * C_OUT * C_IN if has_skip else 0),
                       ("partW2", rows * C_OUT * C_MID), ("partW", wrows * 32 * 38),
-                      ("HA", B * M * C_MID), ("HB", B * M * C_MID)]
+                      ("HA", B * M * C_MID), ("HB", B * M * C_MID), ("GU", lib.apn_sa_rowmap_places(B, N, M) * C_MID)]
     v, buf = _carve(dev, sizes)
     zero_floats = sum((nfl + 63) // 64 * 64 for _, nfl in zsizes)
     if prezeroed:
@@ -319,15 +332,15 @@ def _backward(fw, g_out, need_p, need_newp):
     def run(phases, sumsS=None, sumsT=None):
         if PER_KERNEL_LAUNCH:
             return _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, sumsS,
-                                        sumsT, g_f, g_p, g_newp, rows, prow, wrows, has_skip)
+                                        sumsT, g_f, g_p, g_newp, rows, prow, wrows, has_skip, pcnt_poff, rowdst)
         call("apn_sa_backward_seq", phases, fw.prec, B, N, M, fw.radius, sv["p"].data_ptr(),
              sv["new_p"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["tmap"]), _ptr(sv["fidx"]), sv["geo"].data_ptr(),
              w1.data_ptr(), w2.data_ptr(), _ptr(ws), sv["ft"].data_ptr(), sv["pack1"].data_ptr(),
              sv["pack2"].data_ptr(), sv["ysel"].data_ptr(), sv["ksel"].data_ptr(),
              fw.out.data_ptr(), fw.relu, 1 if fw.train1 else 0, 1 if fw.train2 else 0, float(P),
              g_out.data_ptr(), gs[0], gs[1], gs[2], buf.data_ptr(), zero_floats * 4,
-             v["A"].data_ptr(), v["gip"].data_ptr() if has_skip else None, v["accS"].data_ptr(),
-             v["accT"].data_ptr(), v["cells"].data_ptr() if fw.det else None, v["goa"].data_ptr(),
+             v["gip"].data_ptr() if has_skip else None, v["accS"].data_ptr(),
+             v["accT"].data_ptr(), pcnt_poff.data_ptr(), rowdst.data_ptr(), v["GU"].data_ptr(), v["goa"].data_ptr(),
              v["partWs"].data_ptr() if has_skip else None, v["partW2"].data_ptr(), v["partW"].data_ptr(),
              _ptr(sumsS), _ptr(sumsT), v["HA"].data_ptr(), v["HB"].data_ptr(),
              g_f.data_ptr(), _ptr(g_p), _ptr(g_newp), g["w1"].data_ptr(), g["w2"].data_ptr(),
@@ -369,11 +382,10 @@ def _forward_per_kernel(call, phases, prec, B, N, M, radius, p, new_p, f, idx, f
 
 
 def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, sumsS, sumsT, g_f, g_p,
-                         g_newp, rows, prow, wrows, has_skip):
+                         g_newp, rows, prow, wrows, has_skip, pcnt_poff, rowdst):
     """Python mirror of apn_sa_backward_seq (csrc/sa_seq.hip), one foreign call per kernel."""
     B, N, M = fw.dims
     w1, w2, ws, P = sv["w1"], sv["w2"], sv["ws"], float(sv["count"])
-    cells = v["cells"].data_ptr() if fw.det else None
     gip = v["gip"].data_ptr() if has_skip else None
     if phases & 1:
         if zero_floats:
@@ -381,15 +393,15 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
         call("apn_sa_bwd_prep", B, N, M, g_out.data_ptr(), *g_out.stride(), fw.out.data_ptr(), fw.relu,
              sv["ysel"].data_ptr(), sv["pack2"].data_ptr(), sv["ft"].data_ptr() if has_skip else None,
              fw.prec, _ptr(sv["fidx"]) if has_skip else None, _ptr(ws), v["goa"].data_ptr(),
-             v["accS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None, gip, cells)
+             v["accS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None, gip)
     if phases & 2:
         call("apn_sa_bwd_main", B, N, M, fw.prec, fw.radius, sv["p"].data_ptr(), sv["new_p"].data_ptr(),
              sv["ft"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["tmap"]), w1.data_ptr(), w2.data_ptr(),
              sv["pack1"].data_ptr(), sv["pack2"].data_ptr(), v["accS"].data_ptr(), _ptr(sumsS), P,
              1 if fw.train2 else 0, v["goa"].data_ptr(), sv["ksel"].data_ptr(), v["accT"].data_ptr(),
-             v["partW2"].data_ptr(), v["A"].data_ptr(), cells, v["HA"].data_ptr(), v["HB"].data_ptr())
+             v["partW2"].data_ptr(), rowdst.data_ptr(), v["GU"].data_ptr(), v["HA"].data_ptr(), v["HB"].data_ptr())
     if phases & 4:
-        call("apn_sa_bwd_point_grads", B, N, M, v["A"].data_ptr(), cells, sv["geo"].data_ptr(),
+        call("apn_sa_bwd_point_grads", B, N, M, v["GU"].data_ptr(), pcnt_poff.data_ptr(), sv["geo"].data_ptr(),
              v["HA"].data_ptr(), v["HB"].data_ptr(), v["accT"].data_ptr(), _ptr(sumsT), P, 1 if fw.train1 else 0,
              sv["pack1"].data_ptr(), sv["ft"].data_ptr(), fw.prec, sv["p"].data_ptr(), sv["new_p"].data_ptr(),
              w1.data_ptr(), gip, fw.radius, v["partW"].data_ptr(), g_f.data_ptr(), _ptr(g_p), _ptr(g_newp))
@@ -451,6 +463,7 @@ class Sampling:
         self.idx = self.buf[o:o + B * M * K].view(B, M, K)
         self.index = None        # adaptpoint_amd.fused_wide.NeighbourIndex of idx, when the width-generic kernels run
         self.tmap = None         # adaptpoint_amd.fused_wide.tile_map of idx, for the register-resident kernels
+        self.rowmap = None       # (pcnt_poff, rowdst) of tmap (adaptpoint_amd.fused_wide.row_map), for their backward pass
         self.geo = None          # (B,N,4) int64 occurrence statistics of the neighbourhoods (csrc/sa_geo.hip) and
         self.dd = None           # (B, 6 * slabs) float64 their second moments, for the register-resident kernels
         self.ready = None        # event recorded behind the index stage when it ran on another stream (graphs.wait_ready)
@@ -473,6 +486,7 @@ class Sampling:
         v.fidx, v.new_p, v.idx = self.fidx[lo:hi], self.new_p[lo:hi], self.idx[lo:hi]
         v.index = None
         v.tmap = None
+        v.rowmap = None
         v.geo = v.dd = None
         v.ready = None
         v.ties = None if self.ties is None else self.ties[lo:hi]
@@ -588,12 +602,14 @@ class _SetAbstraction(torch.autograd.Function):
             # 29 -> 20 us, backward 66 -> 34 us at B = 32, N = 1024
             from . import fused_wide
             smp.tmap = fused_wide.tile_map(smp.idx)
+            smp.rowmap = fused_wide.row_map(smp.tmap, p.shape[0], p.shape[1], npoint)
         fidx, new_p, idx = smp.fidx, smp.new_p, smp.idx
         if p.requires_grad:
             new_p = new_p.clone()          # returned as a differentiable output
         fw = _Forward(p, f, new_p, idx, fidx, radius, conv1, bn1, conv2, bn2, skip_conv, relu,
                       sync_bn, tmap=getattr(smp, "tmap", None), geo=getattr(smp, "geo", None),
-                      dd=getattr(smp, "dd", None), want_backward=any(ctx.needs_input_grad))
+                      dd=getattr(smp, "dd", None), want_backward=any(ctx.needs_input_grad),
+                      rowmap=getattr(smp, "rowmap", None))
         ctx.fw = fw
         ctx.save_for_backward(p, f)        # autograd's in-place version checks cover the inputs
         ctx.set_materialize_grads(False)   # an unused output's gradient arrives as None, not as zeros

@@ -181,6 +181,9 @@ class SetAbstraction(nn.Module):
             # the register-resident kernels take the tile map alone
             if self.fused and not self.is_head and not self.all_aggr and self._fused_parts() is not None and COMPACT_RESIDENT:
                 smp.tmap = fused_wide.tile_map(smp.idx, out=smp.tmap)
+                # ... and the map's row map, for their backward pass (the rows of g_u stored in point-sorted order)
+                B, M = smp.idx.shape[0], smp.idx.shape[1]
+                smp.rowmap = fused_wide.row_map(smp.tmap, B, n_points, M, out=getattr(smp, "rowmap", None))
             return None
         smp.index = fused_wide.neighbour_index(smp.idx, smp.new_p, n_points, fidx=smp.fidx if skip else None, out=out)
         return smp.index

@@ -36,12 +36,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 B_PER_GPU, N_PTS, NPOINT, NSAMPLE, C_IN, C_OUT, RADIUS = 32, 1024, 512, 32, 32, 64, 0.15
-# What the DEFAULT configuration launches (short names of the per-kernel pass): seven on the MLP stream per step, four on
+# What the DEFAULT configuration launches (short names of the per-kernel pass): seven on the MLP stream per step, five on
 # the index stream per 20 batches.  The committed PMC traffic file (profiles/r0N_traffic.json) must cover exactly this
 # set -- tests/test_host_cpu.py checks it, and the line says whether the kernels seen at run time equal it.
 DEFAULT_KERNELS = ("sa_prep_stats", "sa_fwd_main", "sa_fwd_out", "sa_bwd_prep", "sa_bwd_main", "sa_bwd_point_grads",
-                   "sa_bwd_finalize", "fps", "ball_query", "sa_point_geo", "sa_wide_tilemap_many")
-TRAFFIC_FILE = "r04_traffic.json"        # PMC bytes per launch of the kernels above (scripts/collect_profiles.sh pmc)
+                   "sa_bwd_finalize", "fps", "ball_query", "sa_point_geo", "sa_wide_tilemap_many", "sa_rowmap_many")
+TRAFFIC_FILE = "r05_traffic.json"        # PMC bytes per launch of the kernels above (scripts/collect_profiles.sh pmc)
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -256,7 +256,6 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
     if fused_mlp:
         from adaptpoint_amd import fused as _f
         _f.PRECISION = mlp.split("-", 1)[1]
-        _f.DETERMINISTIC = bool(args.deterministic)
     blk = make_block(fused=fused_mlp, sync_bn=sync_bn).to(dev)
     blk.train()
     # Gradient exchange.  Without SyncBatchNorm forward+backward contain no collective, so the
@@ -326,9 +325,13 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
         if all(x.tmap is not None and x.index is None for st in sets for x in st):
             from adaptpoint_amd import fused_wide
             big_maps = [fused_wide.tile_maps(b.idx, spg) for b in big]
-            for st, maps in zip(sets, big_maps):
+            # ... and their row maps (the backward pass stores g_u's rows in point-sorted order: no float atomics), the twenty
+            # of a replay in ONE launch
+            big_rows = [fused_wide.row_maps(maps, spg, B_PER_GPU, N_PTS, NPOINT) for maps in big_maps]
+            for st, maps, rows_ in zip(sets, big_maps, big_rows):
                 for i in range(spg):
                     st[i].tmap = maps[i]
+                    st[i].rowmap = (rows_[0][i], rows_[1][i])
     cur_set = [0]
     ones = torch.ones(1, 1, 1, device=dev)
     graph_grads, last_grads = {}, [None]
@@ -364,6 +367,7 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
             blk.sample(p_all[g:hi], out=big[dst].clouds(g, hi))
         if big_maps is not None and count == spg:
             fused_wide.tile_maps(big[dst].idx, spg, out=big_maps[dst])
+            fused_wide.row_maps(big_maps[dst], spg, B_PER_GPU, N_PTS, NPOINT, out=big_rows[dst])
             return
         for i in range(count):
             if sets[dst][i].index is not None or sets[dst][i].tmap is not None:
@@ -524,8 +528,8 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
     r.mlp_verified = None
     if pipelined and use_graph and fused_mlp and not distributed and r.index_verified is True:
         # ... and the MLP kernels ran beside the index kernels: the parameter gradients the LAST replayed step left
-        # against the same step launched eagerly on the idle device (same index set).  Default mode: equal up to the
-        # order of one float-atomic sum (the per-point sums A); --deterministic: bit for bit.
+        # against the same step launched eagerly on the idle device (same index set): BIT FOR BIT since round 5 (no float
+        # atomics on the chain: the per-point sums are ordered sums of stored rows).
         torch.cuda.synchronize()
         got = [g_.detach().clone() for g_ in last_grads[0]]
         mlp_steps(1, cur_set[0] ^ 1, first=spg - 1)
@@ -803,7 +807,8 @@ def main():
     # stage on its own stream (one sampler launch per `index_batch` steps) that is the MLP stream; its kernels
     # launch once per step, so total = average launch duration.  Without the pipeline everything is one stream and
     # the index kernels count with their per-step share.
-    index_names = {"fps", "ball_query", "fps+ball_query", "sa_point_geo", "sa_wide_tilemap", "sa_wide_tilemap_many", "sa_wide_csr"}
+    index_names = {"fps", "ball_query", "fps+ball_query", "sa_point_geo", "sa_wide_tilemap", "sa_wide_tilemap_many", "sa_wide_csr",
+                   "sa_rowmap_many"}
     per_step_us = {k: (us / m.index_batch if k in index_names else us) for k, us in per_kernel_us.items()}
     cand = {k: v for k, v in per_step_us.items() if not (pipelined and k in index_names)} or per_step_us
     dominant = max(cand, key=cand.get)
@@ -896,8 +901,10 @@ def main():
                                           "f32 BatchNorm partial sums added exactly (integer accumulators) or in f64",
                             "torch-f32": "unfused: extension ops + PyTorch fp32 conv/BN"}[args.mlp]),
                    "kernels": args.kernels,
-                   "tile_map": ("forward passes over the index stage's distinct-hit tile map (ball-query fill copies "
-                                "folded into one row with a multiplicity: 3.7x fewer MFMA tiles)"
+                   "tile_map": ("both passes over the index stage's distinct-hit tile map (ball-query fill copies "
+                                "folded into one row with a multiplicity: 3.7x fewer MFMA tiles); the backward pass stores its "
+                                "rows of g_u through the map's row map (point-sorted order) and the per-point kernel sums a "
+                                "point's consecutive rows in ascending order: no float atomics, gradients bit-reproducible"
                                 if (fused_mlp and args.kernels == "resident") else
                                 ("all passes over the distinct-hit tile map; per-point sums through its inverse map "
                                  "(no float atomics: gradients bit-reproducible)" if fused_mlp else "none")),
@@ -905,12 +912,12 @@ def main():
                    "graph_nodes": getattr(m, "graph_nodes", None),     # node census of the captured graphs (no memset nodes)
                    "launches_per_step": ("3 forward + 4 backward on the MLP stream (BatchNorm folds and per-channel "
                                          "constants are prologues of their consumer kernels)" if fused_mlp and args.kernels == "resident" else None),
-                   "pipeline": (f"index stages (FPS + ball query + occurrence statistics + tile map) of the NEXT launch's batches on a second stream, "
+                   "pipeline": (f"index stages (FPS + ball query + occurrence statistics + tile map + row map) of the NEXT launch's batches on a second stream, "
                                 f"{m.index_batch} batch(es) per sampler launch, beside the MLP fwd+bwd of the "
                                 "current batch(es); the two streams meet once per launch" if pipelined else "none"),
                    "global_batch": B_PER_GPU * world,
                    "fused_fallbacks": sum(_sa.FUSED_FALLBACKS.values()),
-                   "deterministic_gradients": bool(args.deterministic),
+                   "deterministic_gradients": bool(fused_mlp),       # no float atomics on the fused chain (round 5)
                    "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else "")
                                   + ("+flat-allreduce" if distributed else "")
                                   + ("+collectives-in-graph" if getattr(m, "capture_collectives", False) else "")},
@@ -945,15 +952,10 @@ def main():
                 a2.pipeline = "off"
                 m5 = measure(a2, dev, world, rank, local_rank, distributed, args.mlp, False, v_steps, 40, repeats=5)
                 result["value_no_pipeline"] = round(B_PER_GPU * v_steps / m5.elapsed, 2)
-            if not args.deterministic and args.mlp == "fused-bf16x3" and args.steps % 20 == 0:
-                # the same step with bit-reproducible gradients (no float atomics: 64-bit fixed-point sums)
-                args.deterministic = True
-                det_steps = min(args.steps, 400)
-                m3 = measure(args, dev, world, rank, local_rank, distributed, args.mlp, False, det_steps, 40, repeats=5)
-                args.deterministic = False
-                from adaptpoint_amd import fused as _fz
-                _fz.DETERMINISTIC = False
-                result["value_deterministic"] = round(B_PER_GPU * det_steps / m3.elapsed, 2)
+            if args.mlp == "fused-bf16x3" and fused_mlp:
+                # bit-reproducible gradients are the only mode since round 5 (rounds 3-4: a separate, slower mode with 64-bit
+                # fixed-point atomics, reported here): the figure IS `value`
+                result["value_deterministic"] = result["value"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if distributed:

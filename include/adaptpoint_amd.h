@@ -239,7 +239,7 @@ APN_API int apn_sa_fwd_main(int b, int n, int m, int precision, float radius, co
  * writes pack2 [4][64] and updates the running buffers).
  * out (B,64,M) = act(ysel*scale2 + shift2 + Ws f[:, fidx] + bs); ws/bs/ft/fidx may be null
  * (no skip branch), relu = 0/1.  f is read from the point-major table(s) ft; fidx (B,M), ws (64,32), bs (64).
- * (zero_base, zero_floats: optional region -- the backward's atomically accumulated A | gip | accS | accT --
+ * (zero_base, zero_floats: optional region -- the backward's atomically accumulated gip | accS | accT --
  * cleared by this launch, the forward's last, so that apn_sa_backward_seq(zero_bytes = 0) needs no fill launch) */
 APN_API int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const void *acc2, const double *sums2,
                            const float *g2, const float *b2, float *rm2, float *rv2, void *nbt2, float eps2,
@@ -258,31 +258,33 @@ APN_API int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long long g
                             long long gs_c, long long gs_m, const float *out, int relu,
                             const float *ysel, const float *pack2, const void *ft, int precision,
                             const int *fidx, const float *ws, float *goa, void *accS,
-                            float *partWs, float *gip, unsigned *cells, void *stream);
+                            float *partWs, float *gip, void *stream);
 
 /* Backward launch 2 of 4: the pass over the positions.  Prologue (every workgroup): the constants of
  * dL/dy2 = goa*[pos==ksel] + y2*D2 + E2 from accS (or sumsS) and pack2, Qm = W2^T diag(D2) W2, evec = E2 W2.
  * accT (accumulator set, 64 columns, zeroed) += {sum g_u, sum g_u*yhat1}[32] (g_u = dL/da1 * [a1 > 0]);
  * partW2[apn_sa_bwd_main_rows(b, m)][64*32] = the workgroup's share of dL/dW2 (sparse arg-max part +
- * D2 (W2 Gram) + E2 (x) sum a1);  A (B,N,32) += g_u summed per source point (zeroed, float atomics).
- * Bit-reproducible mode (cells != NULL: 4 zeroed u32, cells[0] = max |goa| bits from apn_sa_bwd_prep): A is an
- * int64 array (B,N,32) and every term is added as the 64-bit integer round(g_u 2^s) -- order-independent; the
- * exponent s is derived from a bound on |g_u| (max |goa|, |W2|, the BatchNorm constants) by every workgroup alike and
- * left in cells[1]; cells[2] != 0 marks a term that did not fit (apn_sa_bwd_point_grads then yields NaN);
- * HA, HB (B,M,32) = g_u and yhat1 summed per query.  pack1 = BN1's [4][32] of the forward. */
+ * D2 (W2 Gram) + E2 (x) sum a1);  GU[place][32] = g_u of every live tile-map row, stored at the row's place in the
+ * point-sorted order (rowdst: apn_sa_rowmap_many; 32 b m rows of 32 floats, nothing to clear) -- round 5: NO float
+ * atomics; a point's rows are consecutive and apn_sa_bwd_point_grads sums them in ascending row order, so every
+ * gradient of the chain is bit-reproducible (rounds 1-4: A (B,N,32) += g_u by memory-side float atomics, or 64-bit
+ * fixed-point integer atomics in a separate "deterministic" mode).  tmap and rowdst are required: the pass runs over the
+ * tile map.  HA, HB (B,M,32) = g_u and yhat1 summed per query.  pack1 = BN1's [4][32] of the forward. */
 APN_API int apn_sa_bwd_main(int b, int n, int m, int precision, float radius, const float *xyz,
                             const float *new_xyz, const void *ft, const int *idx, const int *tmap, const float *w1,
                             const float *w2, const float *pack1, const float *pack2, const void *accS,
                             const double *sumsS, double count, int train2, const float *goa, const void *ksel,
-                            void *accT, float *partW2, void *A, unsigned *cells, float *HA, float *HB, void *stream);
+                            void *accT, float *partW2, const int *rowdst, float *GU, float *HA, float *HB,
+                            void *stream);
 
 /* Backward launch 3 of 4.  Prologue: the batch constants of dL/dy1 = g_u*ca + yhat1*cb + cc from accT (or sumsT).
- * dL/dy1 summed per source point (G) and per query (H), formed from A, geo (apn_sa_point_geo), HA, HB, and
+ * dL/dy1 summed per source point (G) and per query (H), formed from the point's rows of GU (pcnt_poff: int32[2 b n],
+ * how many rows gather a point and the place of the first -- apn_sa_rowmap_many), geo (apn_sa_point_geo), HA, HB, and
  * everything linear in them, one workgroup per 64-point tile: g_f (B,32,N) = G W1[:,3:] (+ gip); optional
  * g_p (B,N,3) += G W1[:,:3]/r and g_newp (B,M,3) = -H W1[:,:3]/r; partW[apn_sa_bwd_weight_rows(b, n)][32*38] =
- * per-block products for dL/dW1 (sa_glue.hip).  cells != NULL: A holds apn_sa_bwd_main's fixed-point sums. */
+ * per-block products for dL/dW1 (sa_glue.hip). */
 APN_API int apn_sa_bwd_weight_rows(int b, int n);
-APN_API int apn_sa_bwd_point_grads(int b, int n, int m, const void *A, const unsigned *cells, const void *geo,
+APN_API int apn_sa_bwd_point_grads(int b, int n, int m, const float *GU, const int *pcnt_poff, const void *geo,
                                    const float *HA, const float *HB, const void *accT, const double *sumsT,
                                    double count, int train1, const float *pack1, const void *ft, int precision,
                                    const float *xyz, const float *new_xyz, const float *w1,
@@ -325,8 +327,8 @@ APN_API int apn_sa_backward_seq(
     const float *ws, const void *ft, const float *pack1, const float *pack2, const float *ysel,
     const void *ksel, const float *out, int relu, int train1, int train2, double count,
     const float *g_out, long long gs_b, long long gs_c, long long gs_m,
-    void *zero_base, long long zero_bytes, void *A, float *gip, void *accS, void *accT,
-    unsigned *cells,   /* bit-reproducible mode: 4 u32 inside the zeroed region, and A an int64 array (apn_sa_bwd_main) */
+    void *zero_base, long long zero_bytes, float *gip, void *accS, void *accT,
+    const int *pcnt_poff, const int *rowdst, float *GU,   /* the row map (apn_sa_rowmap_many) and the rows' scratch */
     float *goa, float *partWs, float *partW2, float *partW, const double *sumsS, const double *sumsT,
     float *HA, float *HB,
     float *g_f, float *g_p, float *g_newp, float *g_w1, float *g_w2, float *g_g1, float *g_b1, float *g_g2,
@@ -431,6 +433,20 @@ APN_API int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *tma
 /* count tile maps in one pair of launches (the batches of a stacked index stage): map z reads idx + z * b * m * 32
  * and fills tmap + z * apn_sa_wide_tilemap_ints(b, m). */
 APN_API int apn_sa_wide_tilemap_many(int count, int b, int m, int mode, const int *idx, int *tmap, void *stream);
+/* The ROW MAP of `count` stacked tile maps (round 5; index-stage data, a pure function of the neighbour indices): per batch z
+ *   pcnt_poff + z * 2 b n  int32[2 b n]: per support point, the number of tile-map rows that gather it and the place of the
+ *                          first of them in the point-sorted order (a cloud's places lie in its own range of row ids);
+ *   rowdst + z * 32 b m    int32[32 b m]: the GU row of every live row of map z = tmap + z * apn_sa_wide_tilemap_ints(b, m):
+ *                          the j-th row of point p (ascending) at p * ELL + j for j < ELL = apn_sa_rowmap_ell() -- an address
+ *                          the per-point kernel knows without the map --, later rows at b n ELL + their sorted place.
+ * GU needs apn_sa_rowmap_places(b, n, m) rows of 32 floats.
+ * Replaces the scatter-add of the reference's grouping backward (group_points_grad_kernel_fast,
+ * openpoints/cpp/pointnet2_batch/src/group_points_gpu.cu:14-46, atomicAdd per element) inside the fused chain by a store +
+ * an ordered sum.  scratch: int32[32 b m] (multi-launch path only). */
+APN_API int apn_sa_rowmap_ell(void);
+APN_API int apn_sa_rowmap_places(int b, int n, int m);
+APN_API int apn_sa_rowmap_many(int count, int b, int n, int m, const int *tmap, int *pcnt_poff, int *rowdst, int *scratch,
+                               void *stream);
 /* out[ncol] (float64) = column sums of part[rows][ncol] (float32) in a fixed order; two passes
  * through scratch[apn_sa_wide_colsum_chunks(rows, ncol)][ncol] (float64) when there is more than one chunk */
 APN_API int apn_sa_wide_colsum_chunks(int rows, int ncol);

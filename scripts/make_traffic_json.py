@@ -32,6 +32,7 @@ ALIAS.update({k: k.replace("_kernel", "") for k in (
     "wide_point_terms_kernel", "wide_geo_kernel", "wide_colsum_kernel", "wide_image_kernel")})
 # one bench-line entry, two kernels: their bytes add (both run once per launch of the entry)
 ALIAS.update({"tilemap_pack_kernel": "sa_wide_tilemap_many", "tilemap_fill_kernel": "sa_wide_tilemap_many"})
+ALIAS["csr_cloud_kernel"] = "sa_rowmap_many"      # the row map of a replay's tile maps (one launch, apn_sa_rowmap_many)
 
 
 def sources_sha16(root=ROOT):

@@ -557,16 +557,15 @@ def test_syncbn_two_ranks_equal_one_double_batch(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("map_in_backward", [False, True])
-def test_register_resident_kernels_over_the_tile_map_equal_one_tile_per_query(map_in_backward, monkeypatch):
+def test_register_resident_kernels_over_the_tile_map_equal_one_tile_per_query():
     """The distinct-hit tile map (index-stage work, fused_wide.tile_map) only regroups the positions: folded fill
     copies are weighted by their multiplicity, the pool runs per query over the distinct rows.  Same block, same
-    inputs, with and without the map: forward equal to summation-order rounding, gradients likewise."""
+    inputs: the forward with and without the map (the backward runs over a map always since round 5 -- the one handed in
+    with its row map, or one it builds): forward equal to summation-order rounding, gradients likewise."""
     import copy
     from adaptpoint_amd import fused, fused_wide
     from adaptpoint_amd.set_abstraction import SetAbstraction
     dev = torch.device("cuda:0")
-    monkeypatch.setattr(fused, "TILE_MAP_IN_BACKWARD", map_in_backward)
     torch.manual_seed(0)
     blk = SetAbstraction(32, 64, layers=2, stride=2, fused=True, use_res=True,
                          group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
@@ -578,6 +577,7 @@ def test_register_resident_kernels_over_the_tile_map_equal_one_tile_per_query(ma
     smp_a = blk.sample(p)
     smp_b = blk2.sample(p)
     smp_b.tmap = fused_wide.tile_map(smp_b.idx)
+    smp_b.rowmap = fused_wide.row_map(smp_b.tmap, 8, 1024, 512)
     assert int(smp_b.tmap[0]) < smp_b.idx.shape[0] * smp_b.idx.shape[1] // 2          # the map does fold
     qa, oa = blk([p, fa], sampling=smp_a)
     qb, ob = blk2([p, fb], sampling=smp_b)
@@ -597,13 +597,14 @@ def test_register_resident_kernels_over_the_tile_map_equal_one_tile_per_query(ma
 
 @pytest.mark.parametrize("with_map", [True, False])
 @pytest.mark.parametrize("loss_scale", [1.0, 65536.0, 1e-6])
-def test_deterministic_mode_gives_bit_identical_gradients(dev, monkeypatch, with_map, loss_scale):
-    """fused.DETERMINISTIC: the backward pass adds its per-point sums as 64-bit fixed-point integers (scale derived
-    on the device from a bound on the terms) -- no float atomics left on the chain: three runs of the B=32 block give
-    torch.equal outputs, input gradients and parameter gradients, and they equal the default (float-atomic) mode up
-    to summation order, whatever the magnitude of the upstream gradient (loss scaling)."""
+def test_gradients_are_bit_identical_run_to_run(dev, with_map, loss_scale):
+    """Round 5: no float atomics on the chain -- the backward pass STORES every row's g_u at its place in the point-sorted
+    order (fused_wide.row_map) and the per-point kernel sums a point's consecutive rows in ascending order; every other
+    cross-workgroup sum is an integer accumulator set or a fixed-order fold.  Three runs of the B=32 block give torch.equal
+    outputs, input gradients and parameter gradients, with the index stage's maps handed in or built in line; and the
+    gradients scale with the upstream gradient (loss scaling): exactly for a power of two, to rounding otherwise."""
     import copy
-    from adaptpoint_amd import fused, fused_wide
+    from adaptpoint_amd import fused_wide
     from adaptpoint_amd.set_abstraction import SetAbstraction
     torch.manual_seed(0)
     blk = SetAbstraction(32, 64, layers=2, stride=2, fused=True, use_res=True,
@@ -612,35 +613,39 @@ def test_deterministic_mode_gives_bit_identical_gradients(dev, monkeypatch, with
     B = 32
     p = torch.from_numpy(GI.unit_sphere_cloud(B, 1024, seed=14)).to(dev)
     f = torch.from_numpy(GI.seeded_normal((B, 32, 1024), seed=15)).to(dev)
-    w = torch.from_numpy(GI.seeded_normal((B, 64, 512), seed=16)).to(dev) * loss_scale
+    w1 = torch.from_numpy(GI.seeded_normal((B, 64, 512), seed=16)).to(dev)
 
-    def run(det):
-        monkeypatch.setattr(fused, "DETERMINISTIC", det)
+    def run(scale):
         b2 = copy.deepcopy(blk)
         fa = f.clone().requires_grad_(True)
         smp = b2.sample(p)
         if with_map:
             smp.tmap = fused_wide.tile_map(smp.idx)
+            smp.rowmap = fused_wide.row_map(smp.tmap, B, 1024, 512)
         _, o = b2([p, fa], sampling=smp)
-        (o * w).sum().backward()
+        (o * (w1 * scale)).sum().backward()
         return [o.detach(), fa.grad] + [q.grad for q in b2.parameters()] + [x.clone() for x in b2.buffers()]
 
-    runs = [run(True) for _ in range(3)]
+    runs = [run(loss_scale) for _ in range(3)]
     for other in runs[1:]:
         for k, (a, b) in enumerate(zip(runs[0], other)):
             assert torch.equal(a, b), k
-    ref = run(False)
+    ref = run(1.0)
+    npar = 1 + len(list(blk.parameters()))
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
-    assert torch.equal(runs[0][0], ref[0])                       # the forward is the same launches
-    for k, (a, b) in enumerate(zip(runs[0], ref)):
+    assert torch.equal(runs[0][0], ref[0])                       # the forward does not see the upstream gradient
+    for k, (a, b) in enumerate(zip(runs[0][1:1 + npar], ref[1:1 + npar])):
         assert torch.isfinite(a).all(), k
-        assert rel(a, b) <= 2e-6, (k, rel(a, b))
+        if loss_scale == 65536.0:
+            assert torch.equal(a, b * loss_scale), k             # a power of two: the same bits, shifted
+        else:
+            # (the upstream gradient is an MFMA operand: its hi + lo split rounds at 2^-17 relative, differently after scaling)
+            assert rel(a, b * loss_scale) <= 2e-5, (k, rel(a, b * loss_scale))
 
 
-def test_deterministic_mode_marks_what_it_cannot_represent(dev, monkeypatch):
-    """A non-finite upstream gradient reaches the fixed-point sums as a marked result (NaN), never as a wrong number."""
+def test_non_finite_upstream_gradient_is_loud(dev):
+    """A non-finite upstream gradient reaches the gradients as NaN (the accumulator sets flag it), never as a wrong number."""
     from adaptpoint_amd import fused
-    monkeypatch.setattr(fused, "DETERMINISTIC", True)
     p, new_p, f, idx, conv1, bn1, conv2, bn2 = _setup(dev, B=2)
     f = f.clone().requires_grad_(True)
     out = fused.grouped_mlp_max(p, new_p, f, idx, 0.15, conv1, bn1, conv2, bn2)
@@ -648,6 +653,75 @@ def test_deterministic_mode_marks_what_it_cannot_represent(dev, monkeypatch):
     g[1, 3, 7] = float("inf")
     out.backward(g)
     assert torch.isnan(f.grad).any()
+
+
+@pytest.mark.parametrize("structure", ["ball", "random"])
+def test_row_map_is_the_point_sorted_order_of_the_tile_map_rows(dev, structure):
+    """fused_wide.row_map (csrc/sa_wide_glue.hip: apn_sa_rowmap_many), index-stage data of the backward pass: every live
+    row of the tile map has a place; the places of a cloud's rows fill a prefix of the cloud's own range of row ids; a
+    point's rows hold consecutive places, in ascending row order; pcnt / poff say how many and where.  Against numpy, for
+    ball-query rows and for arbitrary ones; stacked maps (`row_maps`) equal the maps one by one."""
+    from adaptpoint_amd import _lib, fused_wide
+    B, N, M = 6, 1024, 512
+    p, new_p, f, idx, *_ = _setup(dev, B=B, seed=21)
+    if structure == "random":
+        idx = torch.randint(0, N, (B, M, 32), generator=torch.Generator().manual_seed(3), dtype=torch.int32).to(dev)
+    tmap = fused_wide.tile_map(idx)
+    pcnt_poff, rowdst = fused_wide.row_map(tmap, B, N, M)
+    torch.cuda.synchronize()
+    t = tmap.cpu().numpy()
+    BM = B * M
+    tiles = int(t[0])
+    off = 4 + ((BM + 3) & ~3)
+    info = t[off:off + 32 * BM].view(np.uint32)[:32 * tiles]
+    rownn = t[off + 32 * BM:off + 64 * BM][:32 * tiles]
+    tq0 = t[4:4 + BM]
+    live = ((info >> 16) & 0xff) != 0
+    rows = np.nonzero(live)[0]
+    q = tq0[rows >> 5] + (info[rows] & 0xff).astype(np.int64)
+    pt = (q // M) * N + rownn[rows]
+    pc, po = pcnt_poff[:B * N].cpu().numpy(), pcnt_poff[B * N:].cpu().numpy()
+    rd = rowdst.cpu().numpy()
+    assert np.array_equal(pc, np.bincount(pt, minlength=B * N))
+    order = np.lexsort((rows, pt))                                  # by point, then by row
+    want_place = np.empty(len(rows), dtype=np.int64)
+    # a cloud's places start at the cloud's first row id
+    first_row_of_cloud = {}
+    for c in range(B):
+        rc = rows[(q // M) == c]
+        first_row_of_cloud[c] = int(rc.min()) & ~31 if len(rc) else 0
+    pos_in_cloud = np.zeros(B, dtype=np.int64)
+    for k in order:
+        c = int(q[k] // M)
+        want_place[k] = first_row_of_cloud[c] + pos_in_cloud[c]
+        pos_in_cloud[c] += 1
+    # where a row's g_u is stored: the j-th row of a point (ascending) at point * ELL + j below ELL, else behind the ELL region
+    # at its place in the point-sorted order
+    ell = _lib.load().apn_sa_rowmap_ell()
+    assert _lib.load().apn_sa_rowmap_places(B, N, M) == B * N * ell + 32 * B * M
+    rank = np.empty(len(rows), dtype=np.int64)
+    seen = {}
+    for k in order:
+        rank[k] = seen.get(int(pt[k]), 0)
+        seen[int(pt[k])] = rank[k] + 1
+    want_dst = np.where(rank < ell, pt * ell + rank, B * N * ell + want_place)
+    assert np.array_equal(rd[rows], want_dst)
+    has = pc > 0
+    first = np.full(B * N, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(first, pt, want_place)
+    assert np.array_equal(po[has], first[has])
+    # stacked: three maps in one launch == one by one
+    idx3 = torch.cat([idx, idx.flip(0), idx.roll(1, 0)])
+    maps = fused_wide.tile_maps(idx3, 3)
+    pp, rr = fused_wide.row_maps(maps, 3, B, N, M)
+    torch.cuda.synchronize()
+    for z in range(3):
+        a, b_ = fused_wide.row_map(fused_wide.tile_map(idx3[z * B:(z + 1) * B].contiguous()), B, N, M)
+        t_z = int(maps[z][0])
+        assert torch.equal(pp[z], a)
+        tz = maps[z].cpu().numpy()
+        lz = ((tz[off:off + 32 * BM].view(np.uint32)[:32 * t_z] >> 16) & 0xff) != 0
+        assert np.array_equal(rr[z].cpu().numpy()[:32 * t_z][lz], b_.cpu().numpy()[:32 * t_z][lz])
 
 
 @pytest.mark.parametrize("kind", ["ball", "random", "partial_fill"])
