@@ -81,3 +81,45 @@ def test_world2_training_step_workloads_keep_the_ranks_in_step(tmp_path, workloa
     # 12 layers x (forward + backward) statistics exchanges + one flat gradient all-reduce per trained network
     want = 24 + 1 + (2 if workload == "adaptpoint" else 0)
     assert a["collectives"]["all_reduce"] == want == b["collectives"]["all_reduce"], a["collectives"]
+
+
+def _fallback_worker(rank, world, port, out_dir):
+    """A fused block whose BatchNorms `sync_batchnorm_` left alone (it exchanges its own sums) but whose fused kernels cannot
+    run (CPU tensors here; on a GPU: an unsupported width): the composed path must refuse, not normalise rank-locally."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import golden_inputs as GI
+    from oracle import cpu_block as CB
+    from adaptpoint_amd import dp, workloads
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    dp.init("gloo")
+    blk = SetAbstraction(32, 64, layers=2, stride=2, fused=True, use_res=True,
+                         group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                         norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'}).train()
+    model, n_fused, n_conv = workloads.sync_batchnorm_(torch.nn.Sequential(blk))
+    p = torch.from_numpy(GI.unit_sphere_cloud(2, 256, seed=40 + rank))
+    f = torch.from_numpy(GI.seeded_normal((2, 32, 256), seed=50 + rank))
+    msg = ""
+    try:
+        with CB.CpuOps():
+            blk([p, f])
+    except RuntimeError as exc:
+        msg = str(exc)
+    torch.save({"fused": n_fused, "converted": n_conv, "sync_bn": blk.sync_bn, "error": msg}, os.path.join(out_dir, f"fb{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_world2_fused_block_that_falls_back_under_syncbn_raises(tmp_path):
+    """`sync_batchnorm_` leaves the BatchNorm modules of a fused set-abstraction block unconverted
+    because the block exchanges its own statistics; if the block then cannot run its fused kernels it must not silently
+    normalise with rank-local statistics (not the reference's SyncBatchNorm, train_autoaug.py:275-282)."""
+    mp.spawn(_fallback_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        d = torch.load(os.path.join(tmp_path, f"fb{r}.pt"))
+        assert d["fused"] == 1 and d["converted"] == 0 and d["sync_bn"] is True, d
+        assert "cannot run its fused kernels" in d["error"] and "convert_sync_batchnorm" in d["error"], d["error"]
