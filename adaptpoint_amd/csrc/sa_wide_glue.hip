@@ -770,14 +770,36 @@ __global__ __launch_bounds__(1024) void csr_cloud_kernel(int nq, int b, int n, i
         for (int e = t; e < 3 * m; e += 1024) sq[e] = new_xyz[(size_t)qbase * 3 + e];
     if (t == 0) nlong = 0;
     __syncthreads();
-    // count (and which query each sampled point is: one row per query has slot 0)
-    for (int e = t; e < nrows; e += 1024) {
-        const unsigned info = rows[row0 + e];
-        if (((info >> 16) & 0xffu) == 0) continue;
-        atomicAdd(&scnt[rownn[row0 + e]], 1);
-        if (fq && ((info >> 8) & 0xffu) == 0) {
-            const int q = tq0[(row0 + e) >> 5] + (int)(info & 0xffu);
-            fq[cbase + fidx[q]] = q - qbase;
+    // count (and which query each sampled point is: one row per query has slot 0).  Round 5: a thread's rows are requested
+    // in batches of eight -- record, neighbour and first query of the tile, clamped, unconditional -- and, when the cloud has
+    // at most 8192 rows (always at stage 1), KEPT for the fill pass: a loop of one dependent round trip per row (4-5 per thread
+    // and pass at stage 1) was most of this kernel's 16 us
+    constexpr int RB = 8;
+    unsigned k_info[RB];
+    int k_nn[RB], k_q0[RB];
+    const bool keep = nrows <= RB * 1024;                   // (workgroup-uniform)
+    auto load_rows = [&](int base) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int e = base + t + 1024 * u;
+            const int ec = row0 + (e < nrows ? e : (nrows > 0 ? nrows - 1 : 0));
+            k_info[u] = rows[ec];
+            k_nn[u] = rownn[ec];
+            k_q0[u] = tq0[ec >> 5];
+            if (e >= nrows) k_info[u] = 0u;                 // (multiplicity 0: not a row)
+        }
+    };
+    for (int base = 0; base < nrows; base += RB * 1024) {
+        load_rows(base);
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const unsigned info = k_info[u];
+            if (((info >> 16) & 0xffu) == 0) continue;
+            atomicAdd(&scnt[k_nn[u]], 1);
+            if (fq && ((info >> 8) & 0xffu) == 0) {
+                const int q = k_q0[u] + (int)(info & 0xffu);
+                fq[cbase + fidx[q]] = q - qbase;
+            }
         }
     }
     __syncthreads();
@@ -788,14 +810,31 @@ __global__ __launch_bounds__(1024) void csr_cloud_kernel(int nq, int b, int n, i
         const int k = t * per + i;
         if (k < n) sum += scnt[k];
     }
-    part[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int v = t >= d ? part[t - d] : 0;
+    {
+        // inclusive scan over the 1024 threads: inside a wave by lane exchanges, the sixteen wave totals by wave 0 -- two
+        // barriers (round 5; the Hillis-Steele form over LDS took twenty, ~5 of the kernel's 16 us)
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        __shared__ int wtot[16];
+        if (lane == 63) wtot[wave] = incl;
         __syncthreads();
-        part[t] += v;
+        if (wave == 0) {
+            int w = lane < 16 ? wtot[lane] : 0;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const int v = __shfl_up(w, d);
+                if (lane >= d) w += v;
+            }
+            if (lane < 16) wtot[lane] = w;
+        }
         __syncthreads();
+        part[t] = incl + (wave > 0 ? wtot[wave - 1] : 0);
     }
+    __syncthreads();                                    // (part[1023], the cloud's total, is read by every thread at the end)
     {
         int run = part[t] - sum;
         for (int i = 0; i < per; ++i) {
@@ -813,12 +852,17 @@ __global__ __launch_bounds__(1024) void csr_cloud_kernel(int nq, int b, int n, i
     }
     __syncthreads();
     // fill (the order inside a list is the atomics': sorted next)
-    for (int e = t; e < nrows; e += 1024) {
-        const unsigned info = rows[row0 + e];
-        const unsigned mult = (info >> 16) & 0xffu;
-        if (mult == 0) continue;
-        const int q = tq0[(row0 + e) >> 5] + (int)(info & 0xffu) - qbase;
-        slist[atomicAdd(&scnt[rownn[row0 + e]], 1)] = (int)(((unsigned)e << 16) | (mult << 10) | (unsigned)q);
+    for (int base = 0; base < nrows; base += RB * 1024) {
+        if (!keep) load_rows(base);
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const unsigned info = k_info[u];
+            const unsigned mult = (info >> 16) & 0xffu;
+            if (mult == 0) continue;
+            const int e = base + t + 1024 * u;
+            const int q = k_q0[u] + (int)(info & 0xffu) - qbase;
+            slist[atomicAdd(&scnt[k_nn[u]], 1)] = (int)(((unsigned)e << 16) | (mult << 10) | (unsigned)q);
+        }
     }
     __syncthreads();
     auto geo_term = [&](int w, float &occ, float &sx, float &sy, float &sz) {
