@@ -24,20 +24,24 @@
 namespace apn {
 
 constexpr int BQ_WAVES = 4;                // waves per workgroup
+#ifndef APN_BQ_FAT
+#define APN_BQ_FAT 16                      // waves per workgroup of a LARGE launch (0: the 4-wave form always); see ball_query_impl
+#endif
+constexpr int BQ_FAT_WAVES = APN_BQ_FAT > 0 ? APN_BQ_FAT : 16;
 
 // Grid: 8 * ceil(B / 8) * blocks_x workgroups, numbered so that ALL the tiles of a cloud run on one XCD (workgroups w
 // and w + 8 share an XCD and its L2 under round-robin placement -- a speed assumption only): workgroup w = 8 s + x is
 // tile s mod blocks_x of cloud 8 (s / blocks_x) + x.  With a (tiles, clouds) grid a cloud's sixteen tiles were dealt to
 // all eight XCDs and each pulled the cloud through its own L2 (PMC: 111 MB per stacked launch for 54 MB of payload).
-template <int QPW>
-__global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
+template <int QPW, int WAVES = BQ_WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ball_query_kernel(
     int b, int blocks_x, int n, int m, float radius2, int nsample, int q_per_block, int zero_empty,
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, int *__restrict__ idx) {
     extern __shared__ float s_dyn[];
     const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
     const int cloud = 8 * (s / blocks_x) + x, bx = s % blocks_x;
     if (cloud >= b) return;
-    ball_query_body<BQ_WAVES, QPW>(n, m, radius2, nsample, q_per_block, zero_empty, new_xyz, xyz, idx, cloud, bx, s_dyn);
+    ball_query_body<WAVES, QPW>(n, m, radius2, nsample, q_per_block, zero_empty, new_xyz, xyz, idx, cloud, bx, s_dyn);
 }
 
 }  // namespace apn
@@ -55,6 +59,15 @@ static int ball_query_impl(int b, int n, int m, float radius, int nsample, const
     int q_per_block = 32;
     while (q_per_block > 4 && (long long)b * ((m + q_per_block - 1) / q_per_block) < 1024)
         q_per_block >>= 1;
+    // Large launches (the stacked index stage of a pipelined step: 640 clouds): workgroups of SIXTEEN waves over tiles of 128
+    // queries.  The search fills every wave slot of the chip either way; with 4-wave workgroups a slot group of four falls
+    // free at a time and the next 4-wave workgroup of this launch takes it at once, so an 8- or 16-wave workgroup of ANOTHER
+    // stream's kernel waits until two or four retirements happen to coincide on one CU (round 5's kernel trace: the feature
+    // stream's 8-wave kernels at 90-140 us beside this one against 7-13 alone); a retiring 16-wave workgroup frees room for
+    // them at once.  Same waves, same queries per wave, one staging of the cloud per 128 queries instead of per 32.
+    const int fat_q = 8 * BQ_FAT_WAVES;
+    const bool fat = APN_BQ_FAT > 0 && q_per_block == 32 && (long long)b * ((m + fat_q - 1) / fat_q) >= 1024 && m >= fat_q;
+    if (fat) q_per_block = fat_q;
     const int blocks_x = (m + q_per_block - 1) / q_per_block;
     const long long wgs = 8LL * ((b + 7) / 8) * blocks_x;
     if (wgs > 0x7fffffffLL) return APN_EINVAL;
@@ -63,7 +76,10 @@ static int ball_query_impl(int b, int n, int m, float radius, int nsample, const
     // full tiles (32 queries: the stacked index stages) give every wave EIGHT queries per pass over the staged cloud: more
     // independent ballot / count chains per LDS read (184 -> 173 us for 640 clouds); smaller tiles keep four, so that all
     // four waves have queries
-    if (q_per_block >= BQ_WAVES * 8)
+    if (fat)
+        hipLaunchKernelGGL((ball_query_kernel<8, BQ_FAT_WAVES>), dim3((unsigned)wgs), dim3(BQ_FAT_WAVES * 64), dyn, (hipStream_t)stream, b, blocks_x,
+                           n, m, radius2, nsample, q_per_block, zero_empty, new_xyz, xyz, idx);
+    else if (q_per_block >= BQ_WAVES * 8)
         hipLaunchKernelGGL(ball_query_kernel<8>, dim3((unsigned)wgs), dim3(BQ_WAVES * 64), dyn, (hipStream_t)stream, b, blocks_x,
                            n, m, radius2, nsample, q_per_block, zero_empty, new_xyz, xyz, idx);
     else

@@ -224,6 +224,26 @@ def test_ball_query_full_size_properties(dev):
             assert (row[cut:] == row[0]).all()
 
 
+def test_ball_query_large_batch_launch_equals_batch_by_batch(dev, oracle):
+    """Round 5: a LARGE launch (the stacked index stage of a pipelined step: hundreds of clouds) runs the search with
+    16-wave workgroups over tiles of 128 queries (csrc/ball_query.hip: so that a retiring workgroup frees room for another
+    stream's 8-wave workgroups) -- the same waves, the same queries per wave: its rows must equal, bit for bit, the 4-wave
+    form's on the same clouds taken 32 at a time, and the oracle's on the first clouds; ragged m (not a multiple of 128)
+    and empty balls included."""
+    B, N = 288, 1024
+    xyz = GI.unit_sphere_cloud(B, N, seed=77)
+    for m, r in ((512, 0.15), (500, 0.05)):
+        fps = gpu_fps(xyz, m, dev)
+        q = GI.take_points(xyz, fps)
+        q[3, 7] = 5.0                                               # a query far outside: an empty ball
+        big = gpu_ball(float(np.float32(r)), 32, xyz, q, dev)
+        for lo in range(0, B, 32):
+            part = gpu_ball(float(np.float32(r)), 32, xyz[lo:lo + 32], q[lo:lo + 32], dev)
+            assert np.array_equal(big[lo:lo + 32], part), (m, lo)
+        assert np.array_equal(big[:4], oracle.ball_query(float(np.float32(r)), 32, xyz[:4], q[:4]))
+        assert (big[3, 7] == 0).all()
+
+
 # ------------------------------------------------------------------ group / gather
 def test_query_and_group_module_matches_reference_golden(dev, golden):
     """SURVEY 8a row a13 at module level on the GPU: `layers.BallGrouper` (QueryAndGroup, group.py:230-262, with
