@@ -92,7 +92,6 @@ SIGNATURES = {
     "apn_sa_wide_tilemap": [_c_int] * 3 + [_c_void_p] * 3,
     "apn_sa_wide_tilemap_many": [_c_int] * 4 + [_c_void_p] * 3,
     "apn_sa_rowmap_many": [_c_int] * 4 + [_c_void_p] * 5,
-    "apn_sa_rowmap_ell": [],
     "apn_sa_rowmap_places": [_c_int] * 3,
     "apn_sa_wide_stats1": [_c_int] * 4 + [_c_void_p] * 6,
     "apn_sa_wide_fwd_main": [_c_int] * 5 + [_c_void_p] * 11,

@@ -523,11 +523,11 @@ constexpr int WG_PTS = 64;
 // threads per workgroup of bwd_point_grads_kernel: 512 -- two workgroups fit a CU (1024: one, and the grid of B*N/64
 // workgroups ran as two rounds of latency chains), rows of the tile per thread, mid channels per thread
 constexpr int PG_NT = 512, PG_K = WG_PTS * 32 / PG_NT, PG_M = 32 * 64 / PG_NT;
-constexpr int PG_ELL = 8;       // the most rows per point requested from map-free places (>= apn_sa_rowmap_ell())
+constexpr int PG_RB = 8;        // rows of a point requested per round trip by the gather of bwd_point_grads_kernel
 
 __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
     int n, int total_q, int split, const float *__restrict__ GU, const int *__restrict__ pcnt,
-    const int *__restrict__ poff, int ell, long long ell_rows, const long long *__restrict__ geo,
+    const int *__restrict__ poff, const long long *__restrict__ geo,
     const float *__restrict__ HA, const float *__restrict__ HB, const unsigned long long *__restrict__ accT,
     const double *__restrict__ sumsT, double count, int train1,
     const float *__restrict__ pack1, const __bf16 *__restrict__ ft,
@@ -563,15 +563,10 @@ __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
     // wave instruction covers eight rows)
     const int g_pt = tid >> 3, g_c4 = (tid & 7) * 4;
     int r_cnt, r_off;
-    float4 a_e[PG_ELL];            // the point's first ELL rows: their address needs no map (requested with the count)
     {
         const size_t gp = p0 + (g_pt < n_here ? g_pt : 0);
         r_cnt = g_pt < n_here ? pcnt[gp] : 0;
         r_off = poff[gp];
-        const float *er = GU + gp * (size_t)(ell * 32) + g_c4;
-#pragma unroll
-        for (int u = 0; u < PG_ELL; ++u)
-            a_e[u] = ell > 0 ? *reinterpret_cast<const float4 *>(er + (size_t)(u < ell ? u : 0) * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float4 a_g = make_float4(0.f, 0.f, 0.f, 0.f);
     {
@@ -625,23 +620,20 @@ __global__ __launch_bounds__(PG_NT) void bwd_point_grads_kernel(
         if (tid < 32) sc[0][c] = sca;
     } else if (tid >= 96 && tid < 160) sc[3 + ((tid - 96) >> 5)][tid & 31] = pack1[64 + tid - 96];   // mean1, inv1
     {
-        // A[point][4 channels] = sum of the point's rows, ascending (a fixed order: bit-reproducible): the first ELL from
-        // their map-free places (slots beyond the count hold stale bytes: masked), the rest -- a point in more than ELL
-        // neighbourhoods: 1-2 % of the headline clouds' points, most of a collapsed cloud's hot ones -- from the overflow
-        // places behind the ELL region, four rows per round trip
+        // A[point][4 channels] = sum of the point's rows, ascending (a fixed order: bit-reproducible), EIGHT rows per round
+        // trip: a point of the headline clouds is in 3.8 neighbourhoods on average and in more than eight 2 % of the time, so
+        // all but a few threads are done after one batch (with four rows per batch a third of the points needed a second
+        // dependent round trip: stamps, +1.5 us on the kernel's first phase); a hot point (collapsed clouds) loops on
+        const float *rows = GU + (size_t)(r_cnt > 0 ? r_off : 0) * 32 + g_c4;
+        for (int j0 = 0; j0 < r_cnt; j0 += PG_RB) {
+            float4 v[PG_RB];
 #pragma unroll
-        for (int u = 0; u < PG_ELL; ++u)
-            if (u < r_cnt && u < ell) { a_g.x += a_e[u].x; a_g.y += a_e[u].y; a_g.z += a_e[u].z; a_g.w += a_e[u].w; }
-        const float *rows = GU + ((size_t)ell_rows + (size_t)(r_cnt > ell ? r_off : 0)) * 32 + g_c4;
-        for (int j0 = ell; j0 < r_cnt; j0 += 4) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PG_RB; ++u) {
                 const int j = j0 + u < r_cnt ? j0 + u : r_cnt - 1;
                 v[u] = *reinterpret_cast<const float4 *>(rows + (size_t)j * 32);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < PG_RB; ++u)
                 if (j0 + u < r_cnt) { a_g.x += v[u].x; a_g.y += v[u].y; a_g.z += v[u].z; a_g.w += v[u].w; }
         }
     }
@@ -1007,13 +999,11 @@ extern "C" int apn_sa_bwd_point_grads(int b, int n, int m, const float *GU, cons
         return APN_EINVAL;
     if (precision != 1 && precision != 2) return APN_EINVAL;
     if (m > n) return APN_EINVAL;                    // query tiles are walked with the point tiles
-    const int ell = apn_sa_rowmap_ell();
-    if (ell > apn::PG_ELL) return APN_EINVAL;
     const __bf16 *hi = (const __bf16 *)ft;
     const __bf16 *lo = precision == 2 ? hi + (size_t)b * n * 32 : nullptr;
     hipLaunchKernelGGL(apn::bwd_point_grads_kernel, dim3((n + apn::WG_PTS - 1) / apn::WG_PTS, b),
                        dim3(apn::PG_NT), 0, APN_ST, n, b * m, precision == 2 ? 1 : 0, GU, pcnt_poff,
-                       pcnt_poff + (size_t)b * n, ell, (long long)b * n * ell, (const long long *)geo, HA, HB,
+                       pcnt_poff + (size_t)b * n, (const long long *)geo, HA, HB,
                        (const unsigned long long *)accT, sumsT, count, train1,
                        pack1, hi, lo, xyz, new_xyz, w1, gip, 1.0f / radius, partW, g_f, g_p, g_newp);
     APN_LAUNCH_CHECK();

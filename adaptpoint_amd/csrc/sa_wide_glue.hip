@@ -740,13 +740,6 @@ __global__ __launch_bounds__(256) void csr_sort_long_kernel(int nq, long long np
 // of dependent LDS operations: at 64 entries per list it took ~100 us on collapsed clouds.  plist / pcnt / poff are the
 // pure function of idx the kernels above compute; geo is summed in ascending row order (lists up to CSR_INS) or
 // lane-strided + butterfly (longer): fixed orders.  For m <= 1024 (query bits), rows <= 65536 and what fits in LDS.
-#ifndef APN_ROWMAP_ELL
-// rows of a point stored at a MAP-FREE address (point * ELL + j) ahead of the sorted places.  0 = off (the default): with
-// ELL = 8 the per-point kernel requests a point's rows together with its count (one round trip instead of two dependent
-// ones) but reads 64 KB per tile instead of ~31 KB and the backward pass's stores lose what contiguity the sorted order
-// has -- measured: per-point kernel 15.3 -> 17.1 us, step 0.110 -> 0.113 ms.  Kept behind this switch with its test.
-#define APN_ROWMAP_ELL 0
-#endif
 constexpr int CSR_INS = 16;      // lists up to here: insertion by the point's thread; up to 64: a wave's bitonic network in registers
 // Round 5: optional `rowdst` = the INVERSE of plist (rowdst[row] = the row's place in the point-sorted order): the
 // register-resident backward pass stores a row's g_u at that place, so that a point's rows are CONTIGUOUS and its consumer
@@ -757,7 +750,7 @@ __global__ __launch_bounds__(1024) void csr_cloud_kernel(int nq, int b, int n, i
                                                          int *__restrict__ poff, int *__restrict__ plist,
                                                          float *__restrict__ geo, const int *__restrict__ fidx,
                                                          int *__restrict__ fq, int rows_cap, int bitonic_words,
-                                                         int *__restrict__ rowdst, long long tmap_stride, int ell) {
+                                                         int *__restrict__ rowdst, long long tmap_stride) {
     extern __shared__ int csm[];
     {
         const long long z = blockIdx.y, npts = (long long)b * n;
@@ -997,31 +990,17 @@ __global__ __launch_bounds__(1024) void csr_cloud_kernel(int nq, int b, int n, i
     for (int i = t; i < total; i += 1024) {
         const int row = row0 + (int)((unsigned)slist[i] >> 16);
         if (plist) plist[row0 + i] = row;
-        if (rowdst && ell <= 0) rowdst[row] = row0 + i;
-    }
-    if (rowdst && ell > 0) {
-        // ELL + overflow places: the first `ell` rows of a point (ascending) at point * ell + j -- an address its consumer knows
-        // WITHOUT reading the map --, the others at (b n ell) + their place in the point-sorted order
-        const int ellrows = b * n * ell;
-        for (int k = t; k < n; k += 1024) {
-            const int start = soff[k], c = scnt[k] - start;      // (scnt: the list's end after the fill)
-            const int gp = (int)cbase + k;
-            for (int j = 0; j < c; ++j) {
-                const int row = row0 + (int)((unsigned)slist[start + j] >> 16);
-                rowdst[row] = j < ell ? gp * ell + j : ellrows + row0 + start + j;
-            }
-        }
+        if (rowdst) rowdst[row] = row0 + i;
     }
 }
 
 // rowdst from plist (the multi-launch builder's path): one thread per point walks its sorted list
 __global__ __launch_bounds__(256) void rowdst_kernel(long long npts, const int *__restrict__ pcnt, const int *__restrict__ poff,
-                                                     const int *__restrict__ plist, int *__restrict__ rowdst, int ell,
-                                                     int ellrows) {
+                                                     const int *__restrict__ plist, int *__restrict__ rowdst) {
     const long long gn = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gn >= npts) return;
     const int c = pcnt[gn], s0 = poff[gn];
-    for (int i = 0; i < c; ++i) rowdst[plist[s0 + i]] = (ell > 0 && i < ell) ? (int)gn * ell + i : ellrows + s0 + i;
+    for (int i = 0; i < c; ++i) rowdst[plist[s0 + i]] = s0 + i;
 }
 
 }  // namespace apn
@@ -1107,7 +1086,7 @@ extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float 
             static apn::DynLdsOnce configured;       // (per device: apn_common.h)
             if (hipError_t e = apn::set_dyn_lds(configured, (const void *)apn::csr_cloud_kernel, 150 * 1024)) return (int)e;
             hipLaunchKernelGGL(apn::csr_cloud_kernel, dim3(b), dim3(1024), (size_t)lds, st, nq, b, n, m, tmap, new_xyz, pcnt,
-                               poff, plist, geo, fidx, fq, (int)rows_cap, bitonic_words, (int *)nullptr, 0ll, 0);
+                               poff, plist, geo, fidx, fq, (int)rows_cap, bitonic_words, (int *)nullptr, 0ll);
             APN_LAUNCH_CHECK();
             return APN_OK;
         }
@@ -1131,24 +1110,23 @@ extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float 
 //   pcnt_poff + z * 2 b n   int32[2 b n]: per support point the number of tile-map rows that gather it, and the first place
 //                           of its rows in the point-sorted order (places share the row ids' index space: a cloud's places
 //                           lie inside the cloud's own range of row ids);
-//   rowdst + z * 32 b m     int32[32 b m]: where the g_u of every live row of map z (tmap + z * apn_sa_wide_tilemap_ints(b, m))
-//                           is stored, in rows of GU: the j-th row of point p (ascending row order) at p * ELL + j for
-//                           j < ELL = apn_sa_rowmap_ell() -- an address the per-point kernel knows without reading the map: it
-//                           requests a point's first ELL rows together with the count, one memory round trip instead of two
-//                           dependent ones --, the rarer later rows at b n ELL + (their place in the point-sorted order).
-//                           GU holds apn_sa_rowmap_places(b, n, m) rows.
+//   rowdst + z * 32 b m     int32[32 b m]: the place of every live row of map z (tmap + z * apn_sa_wide_tilemap_ints(b, m)): the
+//                           row of GU (apn_sa_rowmap_places(b, n, m) rows) its g_u is stored in.  A point's rows occupy
+//                           consecutive places in ascending row order.  (Measured and removed in round 5: the first ELL = 8
+//                           rows of a point at a MAP-FREE address point * ELL + j, requested together with the count -- one
+//                           round trip instead of two dependent ones, but 64 KB instead of 31 KB per 64-point tile and fully
+//                           scattered stores: the per-point kernel 15.3 -> 17.1 us.)
 // The map is a pure function of the neighbour indices (index-stage data, like the tile map).  scratch: int32[32 b m], used by the multi-launch path only (clouds whose map does not
 // fit one workgroup's LDS).
-extern "C" int apn_sa_rowmap_ell(void) { return APN_ROWMAP_ELL; }
-extern "C" int apn_sa_rowmap_places(int b, int n, int m) {     // rows of GU (0: beyond the 32-bit byte offsets of its users)
-    const long long rows = (long long)b * n * APN_ROWMAP_ELL + 32ll * b * m;
+// rows of GU a backward needs: one per tile-map row
+extern "C" int apn_sa_rowmap_places(int b, int n, int m) {
+    const long long rows = 32ll * b * m;
     return (b <= 0 || n <= 0 || m <= 0 || rows > 0x7fffffffLL / 128) ? 0 : (int)rows;
 }
 
 extern "C" int apn_sa_rowmap_many(int count, int b, int n, int m, const int *tmap, int *pcnt_poff, int *rowdst, int *scratch,
                                   void *stream) {
-    const int ell = APN_ROWMAP_ELL;
-    if ((long long)b * n * ell + 32ll * b * m > 0x7fffffffLL / 128) return APN_EINVAL;     // places as 32-bit byte offsets / 128
+    if (32ll * b * m > 0x7fffffffLL / 128) return APN_EINVAL;     // places as 32-bit byte offsets / 128
     if (count <= 0 || count > 65535 || b <= 0 || n <= 0 || m <= 0 || b > 65535 || (long long)b * m > 0x7fffffffLL / 64 ||
         (long long)b * n > 0x7fffffffLL / 8 || !tmap || !pcnt_poff || !rowdst || !scratch)
         return APN_EINVAL;
@@ -1166,7 +1144,7 @@ extern "C" int apn_sa_rowmap_many(int count, int b, int n, int m, const int *tma
         if (hipError_t e = apn::set_dyn_lds(configured, (const void *)apn::csr_cloud_kernel, 150 * 1024)) return (int)e;
         hipLaunchKernelGGL(apn::csr_cloud_kernel, dim3(b, count), dim3(1024), (size_t)lds, st, nq, b, n, m, tmap,
                            (const float *)nullptr, pcnt_poff, pcnt_poff + npts, (int *)nullptr, (float *)nullptr,
-                           (const int *)nullptr, (int *)nullptr, (int)rows_cap, bitonic_words, rowdst, tstride, ell);
+                           (const int *)nullptr, (int *)nullptr, (int)rows_cap, bitonic_words, rowdst, tstride);
         APN_LAUNCH_CHECK();
         return APN_OK;
     }
@@ -1184,8 +1162,7 @@ extern "C" int apn_sa_rowmap_many(int count, int b, int n, int m, const int *tma
                            poff, scratch, (const float *)nullptr, (float *)nullptr);
         hipLaunchKernelGGL(apn::csr_sort_long_kernel, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, st, nq, npts, tm, pcnt,
                            poff, scratch, (const float *)nullptr, (float *)nullptr);
-        hipLaunchKernelGGL(apn::rowdst_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, npts, pcnt, poff, scratch, rd,
-                           ell, (int)(npts * ell));
+        hipLaunchKernelGGL(apn::rowdst_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, npts, pcnt, poff, scratch, rd);
     }
     APN_LAUNCH_CHECK();
     return APN_OK;

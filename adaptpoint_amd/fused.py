@@ -308,8 +308,8 @@ def _backward(fw, g_out, need_p, need_newp):
     if sv["rowmap"] is None:
         raise RuntimeError("fused set abstraction: backward without a row map (the forward was run with want_backward=False)")
     pcnt_poff, rowdst = sv["rowmap"]
-    # GU: one 128-byte row per tile-map row, at the place its row map names (ELL rows per support point + the overflow's
-    # sorted places; only the map's live rows are written, the per-point kernel reads ELL rows per point and masks)
+    # GU: one 128-byte row per tile-map row, at the row's place in the point-sorted order (capacity 32 B M rows; only the
+    # map's live rows are written and read)
     sizes = zsizes + [("goa", B * M * C_OUT), ("partWs", prow * C_OUT * C_IN if has_skip else 0),
                       ("partW2", rows * C_OUT * C_MID), ("partW", wrows * 32 * 38),
                       ("HA", B * M * C_MID), ("HB", B * M * C_MID), ("GU", lib.apn_sa_rowmap_places(B, N, M) * C_MID)]

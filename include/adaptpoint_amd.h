@@ -436,14 +436,11 @@ APN_API int apn_sa_wide_tilemap_many(int count, int b, int m, int mode, const in
 /* The ROW MAP of `count` stacked tile maps (round 5; index-stage data, a pure function of the neighbour indices): per batch z
  *   pcnt_poff + z * 2 b n  int32[2 b n]: per support point, the number of tile-map rows that gather it and the place of the
  *                          first of them in the point-sorted order (a cloud's places lie in its own range of row ids);
- *   rowdst + z * 32 b m    int32[32 b m]: the GU row of every live row of map z = tmap + z * apn_sa_wide_tilemap_ints(b, m):
- *                          the j-th row of point p (ascending) at p * ELL + j for j < ELL = apn_sa_rowmap_ell() -- an address
- *                          the per-point kernel knows without the map --, later rows at b n ELL + their sorted place.
- * GU needs apn_sa_rowmap_places(b, n, m) rows of 32 floats.
+ *   rowdst + z * 32 b m    int32[32 b m]: the place of every live row of map z = tmap + z * apn_sa_wide_tilemap_ints(b, m).
+ * A point's rows occupy consecutive places in ascending row order; GU needs apn_sa_rowmap_places(b, n, m) rows of 32 floats.
  * Replaces the scatter-add of the reference's grouping backward (group_points_grad_kernel_fast,
  * openpoints/cpp/pointnet2_batch/src/group_points_gpu.cu:14-46, atomicAdd per element) inside the fused chain by a store +
  * an ordered sum.  scratch: int32[32 b m] (multi-launch path only). */
-APN_API int apn_sa_rowmap_ell(void);
 APN_API int apn_sa_rowmap_places(int b, int n, int m);
 APN_API int apn_sa_rowmap_many(int count, int b, int n, int m, const int *tmap, int *pcnt_poff, int *rowdst, int *scratch,
                                void *stream);

@@ -695,17 +695,8 @@ def test_row_map_is_the_point_sorted_order_of_the_tile_map_rows(dev, structure):
         c = int(q[k] // M)
         want_place[k] = first_row_of_cloud[c] + pos_in_cloud[c]
         pos_in_cloud[c] += 1
-    # where a row's g_u is stored: the j-th row of a point (ascending) at point * ELL + j below ELL, else behind the ELL region
-    # at its place in the point-sorted order
-    ell = _lib.load().apn_sa_rowmap_ell()
-    assert _lib.load().apn_sa_rowmap_places(B, N, M) == B * N * ell + 32 * B * M
-    rank = np.empty(len(rows), dtype=np.int64)
-    seen = {}
-    for k in order:
-        rank[k] = seen.get(int(pt[k]), 0)
-        seen[int(pt[k])] = rank[k] + 1
-    want_dst = np.where(rank < ell, pt * ell + rank, B * N * ell + want_place)
-    assert np.array_equal(rd[rows], want_dst)
+    assert _lib.load().apn_sa_rowmap_places(B, N, M) == 32 * B * M
+    assert np.array_equal(rd[rows], want_place)
     has = pc > 0
     first = np.full(B * N, np.iinfo(np.int64).max, dtype=np.int64)
     np.minimum.at(first, pt, want_place)
