@@ -397,6 +397,8 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
     __shared__ __attribute__((aligned(16))) float sfi[QT][36];
     __shared__ float sws[64][33];
     __shared__ int ssrc[QT];
+    constexpr int DW = QT == 32 ? 4 : 2; // waves per 32-query block of dL/dfi (64-query tiles: 64 KB of static LDS allow two)
+    __shared__ float sdfi[DW][QT][33];   // dL/dfi, the waves' partial blocks
     const int cloud = blockIdx.y, m0 = blockIdx.x * QT;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // ty = 0..NW-1
     const int ql = tx % QT, hh = tx / QT;
@@ -457,27 +459,30 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
         // multiply-add loops over LDS that stood here took 1.5 + 4 us of the kernel's 12):
         //   dL/dfi[q][i] = sum_c g[q][c] ws[c][i]   (QT x 32, K = 64)   -> point-major gip rows, atomics
         //   dL/dWs[c][i] = sum_q g[q][c] fi[q][i]   (64 x 32, K = QT)   -> this block's partial row
+        // dL/dfi's K = 64 is dealt to FOUR waves (32-query tiles), one 16-deep step each, their partial blocks summed through LDS and added
+        // to gip by all threads, two elements each: as one wave's four steps and sixteen atomics per lane this was the
+        // longest stretch of the kernel (3.8 of 12 us, five of eight waves idle beside it).
         constexpr int QB = QT / 32;
         const int r = tx & 31, h = tx >> 5;
-        if (ty < QB) {                                   // wave-uniform: query block ty
+        if (ty < DW * QB) {                              // wave-uniform: query block ty / DW, steps 4/DW (ty % DW) ...
+            const int qb = ty / DW, part = ty % DW;
             f32x16 acc = {0};
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
+            for (int s4 = 0; s4 < 4 / DW; ++s4) {
+                const int st = (4 / DW) * part + s4;
                 float av[8], bv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    av[j] = tile[32 * ty + r][16 * st + 8 * h + j];
+                    av[j] = tile[32 * qb + r][16 * st + 8 * h + j];
                     bv[j] = sws[16 * st + 8 * h + j][r];
                 }
                 acc = mfma<2>(make_frag<2>(av), make_frag<2>(bv), acc);
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {                // lane = input i (column), register e <-> query (row)
-                const int q = 32 * ty + acc_row(e, h);
-                if (m0 + q < m) atomicAdd(gip + ((size_t)cloud * n + ssrc[q]) * 32 + r, acc[e]);
-            }
-        } else if (ty < QB + 2) {                        // channel block ty - QB
-            const int cb = ty - QB;
+            for (int e = 0; e < 16; ++e)                  // lane = input i (column), register e <-> query (row)
+                sdfi[part][32 * qb + acc_row(e, h)][r] = acc[e];
+        } else if (ty < DW * QB + 2) {                   // channel block ty - DW QB
+            const int cb = ty - DW * QB;
             f32x16 acc = {0};
 #pragma unroll
             for (int st = 0; st < QT / 16; ++st) {
@@ -492,6 +497,14 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
 #pragma unroll
             for (int e = 0; e < 16; ++e)                  // lane = input i, register e <-> channel
                 partWs[blk * 2048 + (32 * cb + acc_row(e, h)) * 32 + r] = acc[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < QT * 32 / NT; ++k) {          // (query q, input i): a 128-byte atomic segment per 32 lanes
+            const int o = threadIdx.x + NT * k, q = o >> 5, i = o & 31;
+            float v = sdfi[0][q][i] + sdfi[1][q][i];
+            if (DW == 4) v += sdfi[DW - 2][q][i] + sdfi[DW - 1][q][i];
+            if (m0 + q < m) atomicAdd(gip + ((size_t)cloud * n + ssrc[q]) * 32 + i, v);
         }
         wg_stamp(6);
     }
