@@ -30,8 +30,13 @@ namespace apn {
 constexpr int PW_T = 128;     // workgroup tile: 128 x 128 outputs, eight waves of 64 x 32
 constexpr int PW_KC = 32;     // contraction indices per chunk (two MFMA k-steps)
 constexpr int PW_ROW = 40;    // bf16 per LDS row: 32 + 8 pad (80-byte rows: 16 lanes' 16-byte reads cover all banks)
-constexpr int PW_TROW = 144;  // bf16 per LDS row of a row-contiguous operand's tile, kept [k][i] as it lies: 128 + 16 pad
-                              // (288-byte rows: the four 32-byte row pieces of a transposed read fall into distinct banks)
+constexpr int PW_TROW = 160;  // bf16 per LDS row of a row-contiguous operand's tile, kept [k][i] as it lies: 128 + 32 pad.
+                              // 320-byte rows: a transposed read is banked per 32-LANE half over 64 banks -- four k-rows x two
+                              // 16-row column groups of 32 bytes each -- and a k-row must shift by 64 bytes for the eight
+                              // pieces to cover the 256-byte bank row once (with 288-byte rows, until round 5, the second
+                              // column group of k-row q fell on the first of k-row q + 1: every transposed read took 2x)
+static_assert(32 * PW_TROW <= PW_T * PW_ROW, "a row-contiguous tile plane fits the plane stride");
+
 
 struct PwOperand {
     const float *p;
@@ -730,6 +735,76 @@ __global__ __launch_bounds__(256) void pw_bwd_apply_kernel(int B, int C, int N, 
     });
 }
 
+// Both passes as ONE launch for a channel whose B * N values fit the registers of one workgroup (1024 threads x PW_BV
+// float4 of g and of y: B * N <= 32768, N a multiple of 4): workgroup c reads channel c's (g, y) once, forms the two sums
+// (per-thread float partial sums over <= 32 values, the workgroup's total in float64, a fixed order), then applies them to
+// the values it still holds.  As two launches every layer paid two dependent launches of 7-11 us, each a round trip over
+// the same (g, y) (18-21 us per layer, 0.61 ms of a joint training step).
+constexpr int PW_BV = 8;
+__global__ __launch_bounds__(1024) void pw_bwd_fused_kernel(int B, int C, int N, const float *__restrict__ g,
+                                                            const float *__restrict__ y, const float *__restrict__ stat,
+                                                            int relu, int training, float *__restrict__ gy,
+                                                            float *__restrict__ g_gamma, float *__restrict__ g_beta) {
+    __shared__ double scratch[2][16];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int n4 = N >> 2, total4 = B * n4;
+    float4 gv[PW_BV], yv[PW_BV];
+    size_t off[PW_BV];
+#pragma unroll
+    for (int j = 0; j < PW_BV; ++j) {                 // every load issued before the first value is used (clamped, selected below)
+        int i = t + 1024 * j;
+        i = i < total4 ? i : total4 - 1;
+        const int b = i / n4, o = i - b * n4;
+        off[j] = ((size_t)b * C + c) * n4 + o;
+        gv[j] = reinterpret_cast<const float4 *>(g)[off[j]];
+        yv[j] = reinterpret_cast<const float4 *>(y)[off[j]];
+    }
+    const float mean = stat[c], inv = stat[C + c], sc = stat[2 * C + c], sh = stat[3 * C + c];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PW_BV; ++j) {
+        const bool in = t + 1024 * j < total4;
+        float *gp = reinterpret_cast<float *>(&gv[j]);
+        const float *yp = reinterpret_cast<const float *>(&yv[j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gm = (in && (!relu || __builtin_fmaf(yp[e], sc, sh) > 0.0f)) ? gp[e] : 0.0f;
+            gp[e] = gm;                               // the masked gradient replaces g
+            s1 += gm;
+            s2 = __builtin_fmaf(gm, (yp[e] - mean) * inv, s2);
+        }
+    }
+    double d1 = (double)s1, d2 = (double)s2;
+    for (int o = 32; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+    if ((t & 63) == 0) { scratch[0][t >> 6] = d1; scratch[1][t >> 6] = d2; }
+    __syncthreads();
+    d1 = 0.0; d2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { d1 += scratch[0][w]; d2 += scratch[1][w]; }     // every thread the same fixed order
+    if (t == 0) {
+        if (g_gamma) g_gamma[c] = (float)d2;
+        if (g_beta) g_beta[c] = (float)d1;
+    }
+    float k0 = 0.0f, k1 = 0.0f;                       // gy = sc gm + k0 + k1 y  (pw_bwd_apply_kernel)
+    if (training) {
+        const double cnt = (double)B * N;
+        const double m1 = d1 / cnt, m2 = d2 / cnt;
+        k1 = (float)(-(double)sc * (double)inv * m2);
+        k0 = (float)(-(double)sc * m1 + (double)sc * (double)inv * m2 * (double)mean);
+    }
+#pragma unroll
+    for (int j = 0; j < PW_BV; ++j) {
+        if (t + 1024 * j < total4) {
+            float4 o;
+            o.x = __builtin_fmaf(gv[j].x, sc, __builtin_fmaf(k1, yv[j].x, k0));
+            o.y = __builtin_fmaf(gv[j].y, sc, __builtin_fmaf(k1, yv[j].y, k0));
+            o.z = __builtin_fmaf(gv[j].z, sc, __builtin_fmaf(k1, yv[j].z, k0));
+            o.w = __builtin_fmaf(gv[j].w, sc, __builtin_fmaf(k1, yv[j].w, k0));
+            reinterpret_cast<float4 *>(gy)[off[j]] = o;
+        }
+    }
+}
+
 // out[e] = sum_s part[s][e] in a fixed order: 64 elements x 4 interleaved split lanes per workgroup
 __global__ __launch_bounds__(256) void pw_fold_kernel(const float *__restrict__ part, int splits, size_t n,
                                                       float *__restrict__ out) {
@@ -871,8 +946,10 @@ static int pw_channel_splits(int b, int c) {
 static int pw_weight_splits(int b, int c_in, int c_out, int n) {
     const long long tiles = (long long)((c_out + PW_T - 1) / PW_T) * ((c_in + PW_T - 1) / PW_T);
     const long long total = (long long)b * ((n + PW_KC - 1) / PW_KC);
-    // tiles * s workgroups, two of which a CU holds at a time: never just over a multiple of 512
-    long long s = 512 / tiles;
+    // tiles * s workgroups, ONE of which a CU holds at a time (87 / 127 KB of LDS with two / three planes): at most one
+    // round of the 256 CUs -- with two rounds (512 / tiles, from when two tiles shared a CU) the contraction took as long
+    // and the fold read twice the shares
+    long long s = 256 / tiles;
     // (a lone workgroup walks its chunks at ~2 us each: the short contractions are spread down to two chunks per
     // share, the long ones keep at least eight and a light fold)
     const long long cap = total >= 64 ? total / 8 : total / 2;
@@ -962,6 +1039,13 @@ extern "C" int apn_pw_bn_act_grad(int b, int c, int n, const float *g, const flo
     if (b < 0 || c <= 0 || n < 0) return APN_EINVAL;
     if (b == 0 || n == 0) return APN_OK;
     if (!g || !y || !stat || !part_b || !gy) return APN_EINVAL;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0;
+    if ((n & 3) == 0 && (long long)b * n <= 1024ll * 4 * PW_BV && aligned) {       // a channel's values fit one workgroup's registers
+        hipLaunchKernelGGL(pw_bwd_fused_kernel, dim3(c), dim3(1024), 0, (hipStream_t)stream, b, c, n, g, y, stat, relu, training,
+                           gy, g_gamma, g_beta);
+        APN_LAUNCH_CHECK();
+        return APN_OK;
+    }
     const int s = pw_channel_splits(b, c);
     hipLaunchKernelGGL(pw_bwd_sums_kernel, dim3(c, s), dim3(256), 0, (hipStream_t)stream, b, c, n, g, y, stat, relu,
                        part_b);

@@ -576,7 +576,8 @@ APN_API int apn_sa_wide_colsum_f32(const float *part, int rows, int ncol, float 
  *   (tiles rows), running_mean / running_var updated with `momentum` (unbiased variance) and batches[0] += 1
  *   (each may be NULL); otherwise the running statistics are used.  stat [4][c] = {mean, invstd, scale, shift}.
  * bn_act_grad: gy = dL/dy from g = dL/dout (BatchNorm's batch-statistics gradient when training), g_gamma,
- *   g_beta [c] (may be NULL); part_b = scratch [apn_pw_bn_act_grad_splits(b, c)][2][c].  Two launches.
+ *   g_beta [c] (may be NULL); part_b = scratch [apn_pw_bn_act_grad_splits(b, c)][2][c].  One launch when a channel's b * n
+ *   values fit one workgroup's registers (b * n <= 32768, n % 4 == 0), else two.
  * conv_grad_input: gx (B,c_in,N) = w^T gy.   conv_grad_weight: gw (c_out,c_in) = sum_b gy_b x_b^T, split over
  *   apn_pw_conv_grad_weight_splits(...) ranges of (cloud, position) whose shares (scratch [splits][c_out][c_in])
  *   are added in a fixed order: bit-reproducible. */

@@ -129,8 +129,8 @@ def test_argument_validation_of_the_adaptpoint_entries_needs_no_gpu():
     assert lib.apn_pw_conv_grad_weight(2, 8, 8, 16, 3, None, None, None, None, None) == EINVAL
     assert lib.apn_pw_conv_max_backward(2, 129, 8, 16, None, None, None, None, None, 1, None, None, None, None, None) == EINVAL
     assert lib.apn_pw_contract(1, 4, 4, 4, None, 0, 4, 1, None, 0, 4, 1, None, 0, 4, 0, None, 3, None) == EINVAL
-    # split-K shares: short contractions down to two chunks per share, long ones at least eight, <= 512 workgroups
-    assert lib.apn_pw_contract_splits(1, 256, 256, 512) == 8 and lib.apn_pw_contract_splits(32, 512, 1536, 256) == 10
+    # split-K shares: short contractions down to two chunks per share, long ones at least eight, <= 256 workgroups (one per CU)
+    assert lib.apn_pw_contract_splits(1, 256, 256, 512) == 8 and lib.apn_pw_contract_splits(32, 512, 1536, 256) == 5
     assert lib.apn_spectral_norm(0, 4, None, 1, 1e-12, None, None, None, None, None, None, None, None) == EINVAL
     assert lib.apn_spectral_norm_blocks(1024, 512) == 512 and lib.apn_spectral_norm_blocks(15, 1) == 1
     assert lib.apn_anchor_transforms(0, None, None, None, 10.0, 3.0, 0.25, None, None, None) == 0

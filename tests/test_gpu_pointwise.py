@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 # (B, C_in, C_out, N): the imitator's layers at B = 2 (embedding, extract_feat 1 and 4, decoders 1 and 4), then
 # sizes that are multiples of nothing (tile edges in all three contractions, the scalar loaders)
 SHAPES = [(2, 3, 64, 1024), (2, 64, 128, 1024), (2, 512, 1024, 128), (2, 1536, 512, 256), (2, 192, 64, 1024),
-          (3, 130, 70, 77), (1, 5, 33, 257), (5, 36, 200, 130)]
+          (3, 130, 70, 77), (1, 5, 33, 257), (5, 36, 200, 130),
+          (40, 16, 24, 1024)]      # B * N above 32768: BatchNorm's gradient as two launches (below: one, csrc/pointwise.hip)
 
 # planes per operand -> (bar on out, bar on gradients), relative L2 against float64: two bf16 planes keep 16 bits
 # of each operand (~4e-6 measured), three keep all 24 (5e-8 .. 6e-7 measured, growing with the contraction length up to
