@@ -881,7 +881,10 @@ __global__ __launch_bounds__(256, OCC) void wide_bwd_main_kernel(WideArgs a, con
 // values, same products in the same order: R is bit-identical to the fragment-order kernel's.
 template <int H>
 struct WgTile {
-    static constexpr int TR = H + 16;                 // bf16 per position row: + 32 bytes, four consecutive rows on distinct banks
+    // bf16 per position row: + 64 bytes.  A transposed read is banked per 32-LANE half (four position rows x two 16-channel
+    // groups of 32 bytes): a row must shift by 64 bytes modulo the 256-byte bank row for the eight pieces to cover it once
+    // (with + 32 bytes, until round 5, the second group of row q fell on the first of row q + 1: every such read took 2x)
+    static constexpr int TR = H + 32;
     static constexpr int PLANE = 32 * TR;
     static constexpr int BYTES = 2 * 2 * PLANE * 2;   // {a1, mult a1} x {hi, lo}
 };
