@@ -61,7 +61,7 @@ SIGNATURES = {
                       + [_c_int] + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 2 + [_c_longlong, _c_void_p],
     "apn_sa_bwd_prep_rows": [_c_int] * 2,
     "apn_sa_bwd_prep": [_c_int] * 3 + [_c_void_p] + [_c_longlong] * 3 + [_c_void_p] + [_c_int]
-                       + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 7,
+                       + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 8,
     "apn_sa_bwd_main": [_c_int] * 4 + [_c_float] + [_c_void_p] * 11 + [_c_double, _c_int] + [_c_void_p] * 9,
     "apn_sa_bwd_weight_rows": [_c_int] * 2,
     "apn_sa_bwd_point_grads": [_c_int] * 3 + [_c_void_p] * 7 + [_c_double, _c_int] + [_c_void_p] * 2 + [_c_int]
@@ -91,7 +91,8 @@ SIGNATURES = {
     "apn_sa_wide_tilemap_ints": [_c_int] * 2,
     "apn_sa_wide_tilemap": [_c_int] * 3 + [_c_void_p] * 3,
     "apn_sa_wide_tilemap_many": [_c_int] * 4 + [_c_void_p] * 3,
-    "apn_sa_rowmap_many": [_c_int] * 4 + [_c_void_p] * 5,
+    "apn_sa_rowmap_many": [_c_int] * 4 + [_c_void_p] * 6,
+    "apn_sa_rowmap_ints": [_c_int] * 2,
     "apn_sa_rowmap_places": [_c_int] * 3,
     "apn_sa_wide_stats1": [_c_int] * 4 + [_c_void_p] * 6,
     "apn_sa_wide_fwd_main": [_c_int] * 5 + [_c_void_p] * 11,

@@ -389,7 +389,8 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
                                                            float *__restrict__ goa,
                                                            unsigned long long *__restrict__ accS,
                                                            float *__restrict__ partWs,
-                                                           float *__restrict__ gip) {
+                                                           float *__restrict__ gip,
+                                                           const int *__restrict__ dup) {
     // 16 QT threads per tile of QT queries, as in fwd_out_kernel
     constexpr int NT = QT * 16, NW = NT / 64, HALVES = 64 / QT;
     __shared__ float tile[QT][65];       // g[q][c]
@@ -404,6 +405,10 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
     const int ql = tx % QT, hh = tx / QT;
     critical_stream_priority();
     wg_stamp(0);
+    // the cloud's picks are m different points (the row map's verdict, index-stage data): every gip row receives ONE share,
+    // so the shares are plain stores into the zeroed rows instead of float atomics (2 MB of them per launch: ~1 us of
+    // the kernel's tail at the chip's atomic rate); a collapsed cloud (a point picked twice) keeps the atomics
+    const bool distinct = dup && dup[cloud] == 0;
     // every load of the phase is issued before the first one is used (clamped indices, selected afterwards)
     const int qc = m0 + ql < m ? m0 + ql : m - 1;
     const float *outp = relu ? out : g_out;               // (no activation: any readable address, value unused)
@@ -504,7 +509,11 @@ __global__ __launch_bounds__(QT * 16) void bwd_prep_kernel(int n, int m, const f
             const int o = threadIdx.x + NT * k, q = o >> 5, i = o & 31;
             float v = sdfi[0][q][i] + sdfi[1][q][i];
             if (DW == 4) v += sdfi[DW - 2][q][i] + sdfi[DW - 1][q][i];
-            if (m0 + q < m) atomicAdd(gip + ((size_t)cloud * n + ssrc[q]) * 32 + i, v);
+            float *dst = gip + ((size_t)cloud * n + ssrc[q]) * 32 + i;
+            if (m0 + q < m) {
+                if (distinct) *dst = v;
+                else atomicAdd(dst, v);
+            }
         }
         wg_stamp(6);
     }
@@ -972,7 +981,7 @@ extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long lon
                                long long gs_c, long long gs_m, const float *out, int relu,
                                const float *ysel, const float *pack2, const void *ft, int precision,
                                const int *fidx, const float *ws, float *goa, void *accS,
-                               float *partWs, float *gip, void *stream) {
+                               float *partWs, float *gip, const int *dup, void *stream) {
     if (b <= 0 || m <= 0 || b > 65535 || !g_out || !ysel || !pack2 || !goa || !accS) return APN_EINVAL;
     if (relu && !out) return APN_EINVAL;
     if (ws && (!ft || !fidx || !partWs || !gip || n <= 0 || (precision != 1 && precision != 2)))
@@ -982,11 +991,11 @@ extern "C" int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long lon
     if (apn_sa_glue_tile(b, m) == 32)
         hipLaunchKernelGGL(apn::bwd_prep_kernel<32>, dim3((m + 31) / 32, b), dim3(512), 0, APN_ST, n, m, g_out,
                            gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, (unsigned long long *)accS,
-                           partWs, gip);
+                           partWs, gip, dup);
     else
         hipLaunchKernelGGL(apn::bwd_prep_kernel<64>, dim3((m + 63) / 64, b), dim3(1024), 0, APN_ST, n, m, g_out,
                            gs_b, gs_c, gs_m, out, relu, ysel, pack2, hi, lo, fidx, ws, goa, (unsigned long long *)accS,
-                           partWs, gip);
+                           partWs, gip, dup);
     APN_LAUNCH_CHECK();
     return APN_OK;
 }

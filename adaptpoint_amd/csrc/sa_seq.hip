@@ -92,7 +92,8 @@ extern "C" int apn_sa_backward_seq(
     if (phases & 1) {
         if (zero_bytes) APN_TRY(apn_zero_fill(zero_base, zero_bytes, stream));
         APN_TRY(apn_sa_bwd_prep(b, n, m, g_out, gs_b, gs_c, gs_m, out, relu, ysel, pack2, ws ? ft : nullptr, precision,
-                                ws ? fidx : nullptr, ws, goa, accS, partWs, gip, stream));
+                                ws ? fidx : nullptr, ws, goa, accS, partWs, gip,
+                                pcnt_poff ? pcnt_poff + 2ll * b * n : nullptr, stream));      // (the row map's per-cloud verdict on the picks)
     }
     if (phases & 2)
         APN_TRY(apn_sa_bwd_main(b, n, m, precision, radius, xyz, new_xyz, ft, idx, tmap, w1, w2, pack1, pack2, accS,

@@ -750,22 +750,24 @@ __global__ __launch_bounds__(1024) void csr_cloud_kernel(int nq, int b, int n, i
                                                          int *__restrict__ poff, int *__restrict__ plist,
                                                          float *__restrict__ geo, const int *__restrict__ fidx,
                                                          int *__restrict__ fq, int rows_cap, int bitonic_words,
-                                                         int *__restrict__ rowdst, long long tmap_stride) {
+                                                         int *__restrict__ rowdst, long long tmap_stride,
+                                                         int *__restrict__ dup) {
     extern __shared__ int csm[];
     {
         const long long z = blockIdx.y, npts = (long long)b * n;
         tmap += z * tmap_stride;
-        pcnt += z * 2 * npts;
-        poff += z * 2 * npts;
+        pcnt += z * (2 * npts + (dup ? b : 0));
+        poff += z * (2 * npts + (dup ? b : 0));
         if (plist) plist += z * 32 * nq;
         if (rowdst) rowdst += z * 32 * nq;
         if (new_xyz) new_xyz += z * 3 * nq;
         if (geo) geo += z * 4 * npts;
         if (fidx) fidx += z * nq;
         if (fq) fq += z * npts;
+        if (dup) dup += z * (2 * npts + b);            // (the row map's blob of a batch: pcnt | poff | dup, apn_sa_rowmap_ints)
     }
     __shared__ int part[1024];
-    __shared__ int nlong;
+    __shared__ int nlong, sdup;
     int *scnt = csm, *soff = csm + n, *slist = csm + 2 * n;
     float *sq = reinterpret_cast<float *>(slist + rows_cap);            // [m][3]
     int *slong = reinterpret_cast<int *>(sq + 3 * m);                    // points with long lists (at most rows_cap / CSR_INS)
@@ -781,8 +783,22 @@ __global__ __launch_bounds__(1024) void csr_cloud_kernel(int nq, int b, int n, i
     for (int k = t; k < n; k += 1024) { scnt[k] = 0; if (fq) fq[cbase + k] = -1; }
     if (new_xyz)
         for (int e = t; e < 3 * m; e += 1024) sq[e] = new_xyz[(size_t)qbase * 3 + e];
-    if (t == 0) nlong = 0;
+    if (t == 0) { nlong = 0; sdup = 0; }
+    // dup[cloud] = 0 iff the cloud's m picks (fidx) are m DIFFERENT points -- what lets the skip branch's gradient rows be
+    // plain stores instead of float atomics (csrc/sa_glue.hip, bwd_prep_kernel); 1: a point was picked twice (a collapsed
+    // cloud), or the picks are not known here.  A bit per point in `part` (free until the scan below).
+    const bool marks = dup && fidx && n <= 32 * 1024;
+    if (marks) part[t] = 0;
     __syncthreads();
+    if (marks) {
+        bool twice = false;
+        for (int q = t; q < m; q += 1024) {
+            const int f = fidx[qbase + q];
+            const unsigned bit = 1u << (f & 31);
+            twice |= (atomicOr(reinterpret_cast<unsigned *>(&part[f >> 5]), bit) & bit) != 0u;
+        }
+        if (twice) sdup = 1;
+    }
     // count (and which query each sampled point is: one row per query has slot 0).  Round 5: a thread's rows are requested
     // in batches of eight -- record, neighbour and first query of the tile, clamped, unconditional -- and, when the cloud has
     // at most 8192 rows (always at stage 1), KEPT for the fill pass: a loop of one dependent round trip per row (4-5 per thread
@@ -816,6 +832,7 @@ __global__ __launch_bounds__(1024) void csr_cloud_kernel(int nq, int b, int n, i
         }
     }
     __syncthreads();
+    if (dup && t == 0) dup[2 * (long long)b * n + cloud] = marks ? sdup : 1;
     // exclusive scan of the counts: soff = where a point's list starts (within the cloud)
     const int per = (n + 1023) / 1024;
     int sum = 0;
@@ -1086,7 +1103,7 @@ extern "C" int apn_sa_wide_csr(int b, int n, int m, const int *idx, const float 
             static apn::DynLdsOnce configured;       // (per device: apn_common.h)
             if (hipError_t e = apn::set_dyn_lds(configured, (const void *)apn::csr_cloud_kernel, 150 * 1024)) return (int)e;
             hipLaunchKernelGGL(apn::csr_cloud_kernel, dim3(b), dim3(1024), (size_t)lds, st, nq, b, n, m, tmap, new_xyz, pcnt,
-                               poff, plist, geo, fidx, fq, (int)rows_cap, bitonic_words, (int *)nullptr, 0ll);
+                               poff, plist, geo, fidx, fq, (int)rows_cap, bitonic_words, (int *)nullptr, 0ll, (int *)nullptr);
             APN_LAUNCH_CHECK();
             return APN_OK;
         }
@@ -1124,8 +1141,19 @@ extern "C" int apn_sa_rowmap_places(int b, int n, int m) {
     return (b <= 0 || n <= 0 || m <= 0 || rows > 0x7fffffffLL / 128) ? 0 : (int)rows;
 }
 
-extern "C" int apn_sa_rowmap_many(int count, int b, int n, int m, const int *tmap, int *pcnt_poff, int *rowdst, int *scratch,
-                                  void *stream) {
+extern "C" int apn_sa_rowmap_ints(int b, int n) {
+    const long long v = 2ll * b * n + b;
+    return (b <= 0 || n <= 0 || v > 0x7fffffffLL) ? 0 : (int)v;
+}
+
+namespace apn {
+__global__ __launch_bounds__(256) void rowmap_dup_unknown_kernel(int b, int *__restrict__ dup) {
+    for (int k = threadIdx.x; k < b; k += 256) dup[k] = 1;
+}
+}  // namespace apn
+
+extern "C" int apn_sa_rowmap_many(int count, int b, int n, int m, const int *tmap, const int *fidx, int *pcnt_poff, int *rowdst,
+                                  int *scratch, void *stream) {
     if (32ll * b * m > 0x7fffffffLL / 128) return APN_EINVAL;     // places as 32-bit byte offsets / 128
     if (count <= 0 || count > 65535 || b <= 0 || n <= 0 || m <= 0 || b > 65535 || (long long)b * m > 0x7fffffffLL / 64 ||
         (long long)b * n > 0x7fffffffLL / 8 || !tmap || !pcnt_poff || !rowdst || !scratch)
@@ -1144,14 +1172,15 @@ extern "C" int apn_sa_rowmap_many(int count, int b, int n, int m, const int *tma
         if (hipError_t e = apn::set_dyn_lds(configured, (const void *)apn::csr_cloud_kernel, 150 * 1024)) return (int)e;
         hipLaunchKernelGGL(apn::csr_cloud_kernel, dim3(b, count), dim3(1024), (size_t)lds, st, nq, b, n, m, tmap,
                            (const float *)nullptr, pcnt_poff, pcnt_poff + npts, (int *)nullptr, (float *)nullptr,
-                           (const int *)nullptr, (int *)nullptr, (int)rows_cap, bitonic_words, rowdst, tstride);
+                           fidx, (int *)nullptr, (int)rows_cap, bitonic_words, rowdst, tstride, pcnt_poff);
         APN_LAUNCH_CHECK();
         return APN_OK;
     }
     const unsigned rb = (unsigned)(((long long)nq * 32 + 255) / 256);
     for (int z = 0; z < count; ++z) {
         const int *tm = tmap + z * tstride;
-        int *pcnt = pcnt_poff + z * 2 * npts, *poff = pcnt + npts, *rd = rowdst + (long long)z * 32 * nq;
+        int *pcnt = pcnt_poff + z * (2 * npts + b), *poff = pcnt + npts, *rd = rowdst + (long long)z * 32 * nq;
+        hipLaunchKernelGGL(apn::rowmap_dup_unknown_kernel, dim3(1), dim3(256), 0, st, b, pcnt + 2 * npts);   // (picks not examined on this path)
         hipLaunchKernelGGL(apn::csr_init_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, npts, pcnt, (int *)nullptr);
         hipLaunchKernelGGL(apn::csr_count_fill_kernel, dim3(rb), dim3(256), 0, st, nq, n, m, 0, (const int *)nullptr, tm, pcnt, poff,
                            scratch, (const int *)nullptr, (int *)nullptr);

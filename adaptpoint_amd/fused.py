@@ -234,7 +234,7 @@ class _Forward:
                 tmap = fused_wide.tile_map(idx)
                 rowmap = None
             if rowmap is None:
-                rowmap = fused_wide.row_map(tmap, B, N, M)
+                rowmap = fused_wide.row_map(tmap, B, N, M, fidx=fidx)
         rows1 = lib.apn_sa_prep_rows(B, N)
         v, _buf = _carve(dev, [("ft", prec * B * N * C // 2), ("pack1", 4 * C_MID), ("pack2", 4 * C_OUT),
                                ("ysel", B * M * C_OUT), ("ksel", B * M * C_OUT // 4),
@@ -393,7 +393,8 @@ def _backward_per_kernel(call, phases, fw, sv, g_out, buf, zero_floats, v, g, su
         call("apn_sa_bwd_prep", B, N, M, g_out.data_ptr(), *g_out.stride(), fw.out.data_ptr(), fw.relu,
              sv["ysel"].data_ptr(), sv["pack2"].data_ptr(), sv["ft"].data_ptr() if has_skip else None,
              fw.prec, _ptr(sv["fidx"]) if has_skip else None, _ptr(ws), v["goa"].data_ptr(),
-             v["accS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None, gip)
+             v["accS"].data_ptr(), v["partWs"].data_ptr() if has_skip else None, gip,
+             pcnt_poff.data_ptr() + 8 * B * N)            # (the row map's per-cloud verdict on the picks, behind pcnt | poff)
     if phases & 2:
         call("apn_sa_bwd_main", B, N, M, fw.prec, fw.radius, sv["p"].data_ptr(), sv["new_p"].data_ptr(),
              sv["ft"].data_ptr(), sv["idx"].data_ptr(), _ptr(sv["tmap"]), w1.data_ptr(), w2.data_ptr(),
@@ -602,7 +603,7 @@ class _SetAbstraction(torch.autograd.Function):
             # 29 -> 20 us, backward 66 -> 34 us at B = 32, N = 1024
             from . import fused_wide
             smp.tmap = fused_wide.tile_map(smp.idx)
-            smp.rowmap = fused_wide.row_map(smp.tmap, p.shape[0], p.shape[1], npoint)
+            smp.rowmap = fused_wide.row_map(smp.tmap, p.shape[0], p.shape[1], npoint, fidx=smp.fidx)
         fidx, new_p, idx = smp.fidx, smp.new_p, smp.idx
         if p.requires_grad:
             new_p = new_p.clone()          # returned as a differentiable output

@@ -140,29 +140,32 @@ def tile_maps(idx_all, count, fold=True, out=None):
     return maps
 
 
-def row_maps(maps, count, B, N, M, out=None):
+def row_maps(maps, count, B, N, M, out=None, fidx=None):
     """The ROW MAPS of `count` stacked tile maps (`tile_maps`; count = 1: `maps` may be one map) in one launch:
-    (pcnt_poff (count, 2 B N) int32, rowdst (count, 32 B M) int32) -- per support point how many tile-map rows gather it and
-    the place of the first of them in the point-sorted order; per row its place.  Index-stage data (a pure function of the
+    (pcnt_poff (count, 2 B N + B) int32, rowdst (count, 32 B M) int32) -- per support point how many tile-map rows gather it and
+    the place of the first of them in the point-sorted order, then per cloud whether its picks `fidx` ((count B, M) int32, the
+    FPS indices; None: not examined) hit a point twice; per row its place.  Index-stage data (a pure function of the
     neighbour indices), consumed by the register-resident backward pass (csrc/sa_fused.hip: the rows of g_u are stored at
     their places, so a point's rows are contiguous: no float atomics) and its per-point kernel."""
     dev = maps.device
     if out is None:
-        out = (torch.empty(count, 2 * B * N, dtype=torch.int32, device=dev),
+        out = (torch.empty(count, 2 * B * N + B, dtype=torch.int32, device=dev),
                torch.empty(count, 32 * B * M, dtype=torch.int32, device=dev))
     pcnt_poff, rowdst = out
-    assert pcnt_poff.numel() == count * 2 * B * N and rowdst.numel() == count * 32 * B * M and maps.is_contiguous()
+    assert pcnt_poff.numel() == count * _lib.load().apn_sa_rowmap_ints(B, N) and rowdst.numel() == count * 32 * B * M
+    assert maps.is_contiguous() and (fidx is None or (fidx.is_contiguous() and fidx.dtype == torch.int32
+                                                      and fidx.numel() == count * B * M))
     scratch = torch.empty(32 * B * M, dtype=torch.int32, device=dev)        # (the multi-launch path's lists)
-    _call("apn_sa_rowmap_many", dev, count, B, N, M, maps.data_ptr(), pcnt_poff.data_ptr(), rowdst.data_ptr(),
-          scratch.data_ptr())
+    _call("apn_sa_rowmap_many", dev, count, B, N, M, maps.data_ptr(), fidx.data_ptr() if fidx is not None else None,
+          pcnt_poff.data_ptr(), rowdst.data_ptr(), scratch.data_ptr())
     return out
 
 
-def row_map(tmap, B, N, M, out=None):
-    """`row_maps` for one tile map: (pcnt_poff (2 B N), rowdst (32 B M))."""
+def row_map(tmap, B, N, M, out=None, fidx=None):
+    """`row_maps` for one tile map: (pcnt_poff (2 B N + B), rowdst (32 B M))."""
     if out is not None:
         out = (out[0].view(1, -1), out[1].view(1, -1))
-    pcnt_poff, rowdst = row_maps(tmap, 1, B, N, M, out=out)
+    pcnt_poff, rowdst = row_maps(tmap, 1, B, N, M, out=out, fidx=fidx)
     return pcnt_poff.view(-1), rowdst.view(-1)
 
 

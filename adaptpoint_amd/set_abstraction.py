@@ -183,7 +183,7 @@ class SetAbstraction(nn.Module):
                 smp.tmap = fused_wide.tile_map(smp.idx, out=smp.tmap)
                 # ... and the map's row map, for their backward pass (the rows of g_u stored in point-sorted order)
                 B, M = smp.idx.shape[0], smp.idx.shape[1]
-                smp.rowmap = fused_wide.row_map(smp.tmap, B, n_points, M, out=getattr(smp, "rowmap", None))
+                smp.rowmap = fused_wide.row_map(smp.tmap, B, n_points, M, out=getattr(smp, "rowmap", None), fidx=smp.fidx)
             return None
         smp.index = fused_wide.neighbour_index(smp.idx, smp.new_p, n_points, fidx=smp.fidx if skip else None, out=out)
         return smp.index

@@ -327,7 +327,7 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
             big_maps = [fused_wide.tile_maps(b.idx, spg) for b in big]
             # ... and their row maps (the backward pass stores g_u's rows in point-sorted order: no float atomics), the twenty
             # of a replay in ONE launch
-            big_rows = [fused_wide.row_maps(maps, spg, B_PER_GPU, N_PTS, NPOINT) for maps in big_maps]
+            big_rows = [fused_wide.row_maps(maps, spg, B_PER_GPU, N_PTS, NPOINT, fidx=b.fidx) for maps, b in zip(big_maps, big)]
             for st, maps, rows_ in zip(sets, big_maps, big_rows):
                 for i in range(spg):
                     st[i].tmap = maps[i]
@@ -367,7 +367,7 @@ def measure(args, dev, world, rank, local_rank, distributed, mlp, sync_bn, steps
             blk.sample(p_all[g:hi], out=big[dst].clouds(g, hi))
         if big_maps is not None and count == spg:
             fused_wide.tile_maps(big[dst].idx, spg, out=big_maps[dst])
-            fused_wide.row_maps(big_maps[dst], spg, B_PER_GPU, N_PTS, NPOINT, out=big_rows[dst])
+            fused_wide.row_maps(big_maps[dst], spg, B_PER_GPU, N_PTS, NPOINT, out=big_rows[dst], fidx=big[dst].fidx)
             return
         for i in range(count):
             if sets[dst][i].index is not None or sets[dst][i].tmap is not None:

@@ -252,13 +252,14 @@ APN_API int apn_sa_fwd_out(int b, int n, int m, const float *ysel, const void *a
  * gradient (stride 0, e.g. from loss = out.sum()) needs no materialised copy;
  * accS (accumulator set, 128 columns, zeroed) += {S1 = sum g, S2 = sum g*yhat_sel}[64]; with the skip branch
  * partWs[apn_sa_bwd_prep_rows(b, m)][64*32] = dL/dWs per block of 64 queries and gip (B,N,32) += Ws^T g at the
- * sampled points (zeroed). */
+ * sampled points (zeroed): float atomic adds, or -- dup (int32[b], may be NULL; the tail of the row map's blob,
+ * apn_sa_rowmap_many) says 0 for a cloud, i.e. its picks are m different points -- plain stores. */
 APN_API int apn_sa_bwd_prep_rows(int b, int m);
 APN_API int apn_sa_bwd_prep(int b, int n, int m, const float *g_out, long long gs_b,
                             long long gs_c, long long gs_m, const float *out, int relu,
                             const float *ysel, const float *pack2, const void *ft, int precision,
                             const int *fidx, const float *ws, float *goa, void *accS,
-                            float *partWs, float *gip, void *stream);
+                            float *partWs, float *gip, const int *dup, void *stream);
 
 /* Backward launch 2 of 4: the pass over the positions.  Prologue (every workgroup): the constants of
  * dL/dy2 = goa*[pos==ksel] + y2*D2 + E2 from accS (or sumsS) and pack2, Qm = W2^T diag(D2) W2, evec = E2 W2.
@@ -434,15 +435,19 @@ APN_API int apn_sa_wide_tilemap(int b, int m, int mode, const int *idx, int *tma
  * and fills tmap + z * apn_sa_wide_tilemap_ints(b, m). */
 APN_API int apn_sa_wide_tilemap_many(int count, int b, int m, int mode, const int *idx, int *tmap, void *stream);
 /* The ROW MAP of `count` stacked tile maps (round 5; index-stage data, a pure function of the neighbour indices): per batch z
- *   pcnt_poff + z * 2 b n  int32[2 b n]: per support point, the number of tile-map rows that gather it and the place of the
- *                          first of them in the point-sorted order (a cloud's places lie in its own range of row ids);
+ *   pcnt_poff + z * apn_sa_rowmap_ints(b, n)  int32[2 b n + b]: per support point, the number of tile-map rows that gather it
+ *                          and the place of the first of them in the point-sorted order (a cloud's places lie in its own
+ *                          range of row ids); then per cloud dup = 0 iff its m picks fidx (z-th block of b m ints; may be
+ *                          NULL: dup = 1) are m different points -- apn_sa_bwd_prep then STORES the skip branch's gradient
+ *                          rows instead of adding them with float atomics;
  *   rowdst + z * 32 b m    int32[32 b m]: the place of every live row of map z = tmap + z * apn_sa_wide_tilemap_ints(b, m).
  * A point's rows occupy consecutive places in ascending row order; GU needs apn_sa_rowmap_places(b, n, m) rows of 32 floats.
  * Replaces the scatter-add of the reference's grouping backward (group_points_grad_kernel_fast,
  * openpoints/cpp/pointnet2_batch/src/group_points_gpu.cu:14-46, atomicAdd per element) inside the fused chain by a store +
  * an ordered sum.  scratch: int32[32 b m] (multi-launch path only). */
 APN_API int apn_sa_rowmap_places(int b, int n, int m);
-APN_API int apn_sa_rowmap_many(int count, int b, int n, int m, const int *tmap, int *pcnt_poff, int *rowdst, int *scratch,
+APN_API int apn_sa_rowmap_ints(int b, int n);
+APN_API int apn_sa_rowmap_many(int count, int b, int n, int m, const int *tmap, const int *fidx, int *pcnt_poff, int *rowdst, int *scratch,
                                void *stream);
 /* out[ncol] (float64) = column sums of part[rows][ncol] (float32) in a fixed order; two passes
  * through scratch[apn_sa_wide_colsum_chunks(rows, ncol)][ncol] (float64) when there is more than one chunk */

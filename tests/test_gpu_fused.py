@@ -680,7 +680,9 @@ def test_row_map_is_the_point_sorted_order_of_the_tile_map_rows(dev, structure):
     rows = np.nonzero(live)[0]
     q = tq0[rows >> 5] + (info[rows] & 0xff).astype(np.int64)
     pt = (q // M) * N + rownn[rows]
-    pc, po = pcnt_poff[:B * N].cpu().numpy(), pcnt_poff[B * N:].cpu().numpy()
+    pc, po = pcnt_poff[:B * N].cpu().numpy(), pcnt_poff[B * N:2 * B * N].cpu().numpy()
+    assert pcnt_poff.numel() == _lib.load().apn_sa_rowmap_ints(B, N) == 2 * B * N + B
+    assert (pcnt_poff[2 * B * N:] == 1).all()                       # picks not handed in: not known to be distinct
     rd = rowdst.cpu().numpy()
     assert np.array_equal(pc, np.bincount(pt, minlength=B * N))
     order = np.lexsort((rows, pt))                                  # by point, then by row
@@ -713,6 +715,53 @@ def test_row_map_is_the_point_sorted_order_of_the_tile_map_rows(dev, structure):
         tz = maps[z].cpu().numpy()
         lz = ((tz[off:off + 32 * BM].view(np.uint32)[:32 * t_z] >> 16) & 0xff) != 0
         assert np.array_equal(rr[z].cpu().numpy()[:32 * t_z][lz], b_.cpu().numpy()[:32 * t_z][lz])
+
+
+def test_skip_branch_gradient_rows_are_stored_where_the_picks_are_distinct(dev):
+    """The row map's per-cloud verdict on the FPS picks (csrc/sa_wide_glue.hip: 0 = m different points) lets the backward
+    entry kernel STORE the residual branch's gradient rows instead of adding them with float atomics (csrc/sa_glue.hip):
+    the verdict is right -- also for a cloud with fewer distinct points than picks, whose sampler returns a point twice --,
+    stored rows are the added rows bit for bit where every row has one share, and a collapsed cloud keeps the atomics and
+    its shares (against the same step with every cloud on the atomic path, to float rounding: the order of two adds)."""
+    import copy
+    from adaptpoint_amd import fused_wide
+    from adaptpoint_amd.set_abstraction import SetAbstraction
+    torch.manual_seed(0)
+    blk = SetAbstraction(32, 64, layers=2, stride=2, fused=True, use_res=True,
+                         group_args={'NAME': 'ballquery', 'radius': 0.15, 'nsample': 32, 'normalize_dp': True},
+                         norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, conv_args={'order': 'conv-norm-act'}).to(dev)
+    B, N, M = 6, 1024, 512
+    pn = GI.unit_sphere_cloud(B, N, seed=31)
+    pn[2, 300:] = pn[2, :N - 300][:N - 300][np.arange(N - 300) % 300]      # cloud 2: 300 distinct points, 512 picks
+    p = torch.from_numpy(pn).to(dev)
+    f = torch.from_numpy(GI.seeded_normal((B, 32, N), seed=32)).to(dev)
+    w = torch.from_numpy(GI.seeded_normal((B, 64, M), seed=33)).to(dev)
+
+    def run(clouds, verdict_from_picks):
+        b2 = copy.deepcopy(blk)
+        fa = f[clouds].clone().requires_grad_(True)
+        pc = p[clouds].contiguous()
+        smp = b2.sample(pc)
+        smp.tmap = fused_wide.tile_map(smp.idx)
+        smp.rowmap = fused_wide.row_map(smp.tmap, len(clouds), N, M, fidx=smp.fidx if verdict_from_picks else None)
+        _, o = b2([pc, fa], sampling=smp)
+        (o * w[clouds]).sum().backward()
+        return smp, [o.detach(), fa.grad] + [q.grad for q in b2.parameters()]
+
+    every = list(range(B))
+    smp, stored = run(every, True)
+    picks = smp.fidx.cpu().numpy()
+    twice = np.array([len(np.unique(picks[c])) < M for c in range(B)])
+    assert twice.tolist() == [False, False, True, False, False, False]
+    assert smp.rowmap[0][2 * B * N:].cpu().numpy().tolist() == twice.astype(np.int32).tolist()
+    _, added = run(every, False)
+    for k, (a, b) in enumerate(zip(stored, added)):
+        assert float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300)) <= 1e-6, k
+    sound = [0, 1, 3, 4, 5]                                           # without the collapsed cloud: the same bits
+    _, stored = run(sound, True)
+    _, added = run(sound, False)
+    for k, (a, b) in enumerate(zip(stored, added)):
+        assert torch.equal(a, b), k
 
 
 @pytest.mark.parametrize("kind", ["ball", "random", "partial_fill"])
