@@ -906,39 +906,56 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_bwd_kernel(SaArgs a, SaBw
                 bn1v[0][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = sci;
                 bn1v[1][(i >> 2) & 1][(i & 3) + 4 * (i >> 3)] = shi;
             }
-            {
-                uint4 *z = reinterpret_cast<uint4 *>(sp_img);
-                for (int e = lane; e < SP_WAVE / 16; e += 64) z[e] = make_uint4(0u, 0u, 0u, 0u);
-            }
         }
         __syncthreads();
-        if (wave == 2) {
+        {
             // term 3's B fragments of W2 with k = output channel in natural order 16 s + 8 h + j -- and, from the same
             // values, Qm = W2^T diag(D2) W2 and evec = E2 W2 as two small MFMA products (A = the D2-weighted /
             // the E2-in-row-0 image of W2): Qm lands as [lane = mid, register = mid' in accumulator-row order], which IS
             // the fragment order of term 1's B operand (the accumulator-as-next-operand rule): no LDS round trip.
             // (A 64-iteration multiply-add loop over LDS by all four waves took ~1.2 us of every workgroup's start.)
-            f32x16 qacc = {0}, eacc = {0};
+            // Round 5: k-step s of the two products by WAVE s -- its shares through the wave's own image region (free until
+            // the first tile), summed by wave 2 in a fixed order: as ONE wave's four steps (8 LDS reads, three operand
+            // splits and six MFMAs each, one behind the other) they were 2.2 of the prologue's 5 us with three waves idle.
+            const int s = wave;
+            float tmp[8], tmpd[8], tmpe[8];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float tmp[8], tmpd[8], tmpe[8];
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * s + 8 * h + j;
+                tmp[j] = sw2[c][r];
+                tmpd[j] = tmp[j] * sD[c];
+                tmpe[j] = r == 0 ? sE[c] : 0.0f;
+            }
+            const Frag<NS> wt = make_frag<NS>(tmp);
+            put_frag<NS>(cfrag, F_W2T + s, lane, wt);
+            const f32x16 zero16 = {0};
+            const f32x16 qp = mfma<NS>(make_frag<NS>(tmpd), wt, zero16);
+            const f32x16 ep = mfma<NS>(make_frag<NS>(tmpe), wt, zero16);
+            float *scr = reinterpret_cast<float *>(sp_img);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = 16 * s + 8 * h + j;
-                    tmp[j] = sw2[c][r];
-                    tmpd[j] = tmp[j] * sD[c];
-                    tmpe[j] = r == 0 ? sE[c] : 0.0f;
-                }
-                const Frag<NS> wt = make_frag<NS>(tmp);
-                put_frag<NS>(cfrag, F_W2T + s, lane, wt);
-                qacc = mfma<NS>(make_frag<NS>(tmpd), wt, qacc);
-                eacc = mfma<NS>(make_frag<NS>(tmpe), wt, eacc);
+            for (int e = 0; e < 16; ++e) scr[e * 64 + lane] = qp[e];
+            if (h == 0) scr[16 * 64 + r] = ep[0];                 // row 0 of the product = this step's share of evec
+        }
+        __syncthreads();
+        if (wave == 2) {
+            f32x16 qacc = {0};
+            float ev = 0.0f;
+#pragma unroll
+            for (int w = 0; w < SA_WAVES; ++w) {
+                const float *pw = reinterpret_cast<const float *>(sp_raw + w * SP_WAVE);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) qacc[e] += pw[e * 64 + lane];
+                if (h == 0) ev += pw[16 * 64 + r];
             }
             put_frag<NS>(cfrag, F_QM, lane, pack8<NS>(qacc, 0));
             put_frag<NS>(cfrag, F_QM + 1, lane, pack8<NS>(qacc, 8));
-            if (h == 0) chan[4][r] = eacc[0];                     // row 0 of the product = evec
+            if (h == 0) chan[4][r] = ev;
         }
         __syncthreads();
+        {   // the wave's image region starts cleared (behind the barrier: wave 2 has read the shares)
+            uint4 *z = reinterpret_cast<uint4 *>(sp_img);
+            for (int e = lane; e < SP_WAVE / 16; e += 64) z[e] = make_uint4(0u, 0u, 0u, 0u);
+        }
     };
 
     auto scatter_pending = [] {};
